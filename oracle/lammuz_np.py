@@ -1,0 +1,240 @@
+"""
+ORACLE (test infrastructure only - never imported by the product path).
+
+Plain-numpy restatement of ONE LamMuZ sub-problem of the reference
+(/root/reference/RDA_planner/rda_solver.py:389-421 `LamMuZ_cost_cons`,
+:874-909 `Hm_LamMu` / `Im_LamMu`, :1034-1050 cone helpers), i.e. for one
+obstacle n and one stage t (dual column t+1):
+
+    minimise   1/2 * neg(Im)^2 + 1/2*ro2*||Hm||^2                 (accelerated)
+    Im = lam'(A p - b) - mu'h - d - z + zeta        (rda_solver.py:902-907)
+    Hm = G'mu + (A R)'lam + xi                      (rda_solver.py:886)
+    s.t. ||A'lam|| <= 1 (:409-416),  lam in K_obs (:1042-1050),
+         mu in K_robot (:1034-1039),  z >= 0 (:100)
+
+The reference hands this to CVXPY/ECOS.  The minimiser is NOT unique (the cost
+only sees 3 linear functionals of the 9+ unknowns), so ECOS
+returns an interior point of the optimal face.  PARITY UNPINNED: cvxpy/ecos are
+not installable here, so this restatement fixes the tie-break explicitly:
+
+  (T1) among the minimisers, (lam, mu) maximise the linearised clearance
+       m = lam'(A p - b) - mu'h   -> implemented as the extra cost -delta*m with
+       delta = 1e-6 (perturbs the reference optimum by O(delta));
+  (T2) z = 1/2 * max(Im|z=0, 0) in accelerated mode (mid-point of its optimal
+       interval [0, Im+]);  z = max(Im|z=0, 0) when accelerated=False, where
+       that value is the unique minimiser;
+  (T3) exact ties between basic solutions: lowest candidate index wins
+       (lam-candidate major, mu-candidate, hinge state minor).
+
+Method: because -psi'(m) > 0 everywhere, for the optimal a = A'lam and g = G'mu
+the pair (lam, mu) solves two LPs  ->  basic optimal solutions have at most two
+non-zero lam_i and two non-zero mu_j.  We enumerate those supports ("closest
+features"), solve each small piecewise-quadratic problem in closed form (a 2-D
+trust-region sub-problem when the separating direction is free), evaluate the
+TRUE cost at every sign-feasible candidate and keep the best.  Only polygon
+robots (Rpositive) are covered; circle obstacles (norm2) must be in the
+canonical form produced by mpc.py:440-458 (A=[[1,0],[0,1],[0,0]], b=[cx,cy,-r]).
+"""
+import itertools
+import numpy as np
+
+DELTA = 1e-6
+SIGN_TOL = 1e-12
+
+
+def trs2(Q, c, disc):
+    """min 1/2 x'Qx + c'x  over ||x||<=1 (disc=True) or ||x||==1 (disc=False).
+    Q symmetric PSD 2x2.  Returns list of candidate minimisers (1 or 2)."""
+    q11, q12, q22 = Q[0, 0], Q[0, 1], Q[1, 1]
+    mean = 0.5 * (q11 + q22)
+    dif = 0.5 * (q11 - q22)
+    rad = np.hypot(dif, q12)
+    l1, l2 = mean - rad, mean + rad
+    # eigenvector of l2
+    if dif >= 0:
+        v2 = np.array([dif + rad, q12])
+    else:
+        v2 = np.array([q12, rad - dif])
+    nv = np.hypot(v2[0], v2[1])
+    v2 = v2 / nv if nv > 0 else np.array([1.0, 0.0])
+    v1 = np.array([-v2[1], v2[0]])
+    c1, c2 = v1 @ c, v2 @ c
+    cn = np.hypot(c1, c2)
+    out = []
+    scale = max(abs(l2), 1e-300)
+    if disc and l1 > 1e-13 * scale:
+        x = -(c1 / l1) * v1 - (c2 / l2) * v2
+        if x @ x <= 1.0:
+            return [x]
+    if cn == 0.0:
+        # flat model: only the hard case remains (direction of smallest curvature)
+        return [v1] if not disc else []
+    lo = max(cn - l2, abs(c1) - l1)
+    if disc:
+        lo = max(lo, 0.0)
+    tau = lo
+    for _ in range(40):
+        s1, s2 = l1 + tau, l2 + tau
+        if s1 <= 0 or s2 <= 0:
+            tau = max(-l1, -l2) + 1e-300
+            s1, s2 = l1 + tau, l2 + tau
+        a1 = c1 / s1 if c1 != 0 else 0.0
+        a2 = c2 / s2 if c2 != 0 else 0.0
+        phi = a1 * a1 + a2 * a2
+        if phi <= 0:
+            break
+        dphi = -2.0 * (a1 * a1 / s1 + a2 * a2 / s2)
+        sq = np.sqrt(phi)
+        g = 1.0 / sq - 1.0
+        dg = -0.5 * dphi / (phi * sq)
+        step = g / dg
+        tau_new = tau - step
+        if abs(step) <= 1e-16 * max(1.0, abs(tau)):
+            tau = tau_new
+            break
+        tau = tau_new
+    s1, s2 = l1 + tau, l2 + tau
+    x = -(c1 / s1 if c1 != 0 else 0.0) * v1 - (c2 / s2 if c2 != 0 else 0.0) * v2
+    nx = np.hypot(x[0], x[1])
+    if nx > 0:
+        x = x / nx
+    out.append(x)
+    return out
+
+
+def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
+                 accelerated=True, delta=DELTA, return_all=False):
+    """One (obstacle, stage) sub-problem.  A:(E,2) b:(E,) p:(2,) nominal position
+    (column t+1), phi nominal heading (column t, quirk Q1), G:(R,2) h:(R,),
+    xi:(2,), zeta, dbar scalars.  Returns lam(E), mu(R), z, info dict."""
+    A = np.asarray(A, float); b = np.asarray(b, float).ravel()
+    G = np.asarray(G, float); h = np.asarray(h, float).ravel()
+    E, Rn = A.shape[0], G.shape[0]
+    c, s = np.cos(phi), np.sin(phi)
+    Rm = np.array([[c, -s], [s, c]])
+    q = A @ p - b                      # obsA_trans - b  (rda_solver.py:562,902)
+    M = A @ Rm                         # obsA_rot        (rda_solver.py:561)
+    kappa0 = zeta - dbar
+    xi = np.asarray(xi, float).ravel()
+
+    def true_cost(lam, mu):
+        m = lam @ q - mu @ h + kappa0
+        H = M.T @ lam + G.T @ mu + xi
+        return 0.5 * min(m, 0.0) ** 2 - delta * m + 0.5 * ro2 * (H @ H), m, H
+
+    # ---- mu candidates -------------------------------------------------------
+    mu_cands = [()]
+    mu_cands += [(j,) for j in range(Rn) if G[j] @ G[j] > 0]
+    for j1, j2 in itertools.combinations(range(Rn), 2):
+        det = G[j1, 0] * G[j2, 1] - G[j1, 1] * G[j2, 0]
+        if abs(det) > 1e-12 * np.linalg.norm(G[j1]) * np.linalg.norm(G[j2]) and det != 0:
+            mu_cands.append((j1, j2))
+    # ---- lam candidates ------------------------------------------------------
+    if cone_norm2:
+        lam_cands = [("L0",), ("LC",)]
+    else:
+        lam_cands = [("L0",)]
+        lam_cands += [("L1", i) for i in range(E) if A[i] @ A[i] > 0]
+        for i1, i2 in itertools.combinations(range(E), 2):
+            det = A[i1, 0] * A[i2, 1] - A[i1, 1] * A[i2, 0]
+            if abs(det) > 1e-12 * np.linalg.norm(A[i1]) * np.linalg.norm(A[i2]) and det != 0:
+                lam_cands.append(("L2", i1, i2))
+
+    def gamma_star(t, e, mc, chi):
+        """minimise over the mu-support coefficients; returns gamma, m, H"""
+        if len(mc) == 0:
+            return np.zeros(0), t, e
+        if len(mc) == 1:
+            g = G[mc[0]]; eta = h[mc[0]]
+            den = chi * eta * eta + ro2 * (g @ g)
+            gam = (chi * eta * t - delta * eta - ro2 * (g @ e)) / den
+            return np.array([gam]), t - eta * gam, e + gam * g
+        j1, j2 = mc
+        P = np.array([[G[j1, 0], G[j2, 0]], [G[j1, 1], G[j2, 1]]])   # columns = G rows
+        r = np.linalg.solve(P.T, np.array([h[j1], h[j2]]))           # robot vertex
+        rr = r @ r
+        beta = (delta - chi * (t + r @ e)) / (chi * rr + ro2)
+        H = -beta * r
+        gam = np.linalg.solve(P, H - e)
+        return gam, t + r @ e + beta * rr, H
+
+    best = None
+    allc = []
+    idx = 0
+    for lc in lam_cands:
+        for mc in mu_cands:
+            for chi in (0.0, 1.0):
+                idx += 1
+                sols = []       # list of (lam_support_values as full vector)
+                if lc[0] == "L0":
+                    gam, m, H = gamma_star(kappa0, xi, mc, chi)
+                    sols.append((np.zeros(E), gam))
+                elif lc[0] == "L1":
+                    i = lc[1]
+                    amax = 1.0 / np.sqrt(A[i] @ A[i])
+                    def dphi(al):
+                        gam, m, H = gamma_star(al * q[i] + kappa0, al * M[i] + xi, mc, chi)
+                        return (chi * m - delta) * q[i] + ro2 * (M[i] @ H), gam
+                    d0, _ = dphi(0.0)
+                    d1, _ = dphi(amax)
+                    if d1 <= 0:
+                        al = amax
+                    elif d0 >= 0:
+                        al = 0.0
+                    else:
+                        al = amax * d0 / (d0 - d1)
+                    _, gam = dphi(al)
+                    lam = np.zeros(E); lam[i] = al
+                    sols.append((lam, gam))
+                else:
+                    if lc[0] == "L2":
+                        i1, i2 = lc[1], lc[2]
+                        AS = A[[i1, i2]]
+                        v = np.linalg.solve(AS, b[[i1, i2]])
+                        ut = Rm.T @ (p - v)
+                        l0 = 0.0
+                    else:   # LC circle
+                        ut = Rm.T @ (p - b[0:2])
+                        l0 = b[2]          # = -radius
+                    def grad(at):
+                        gam, m, H = gamma_star(at @ ut + l0 + kappa0, at + xi, mc, chi)
+                        return (chi * m - delta) * ut + ro2 * H
+                    g0 = grad(np.zeros(2))
+                    g1 = grad(np.array([1.0, 0.0])) - g0
+                    g2 = grad(np.array([0.0, 1.0])) - g0
+                    Q = np.array([[g1[0], 0.5 * (g1[1] + g2[0])], [0.5 * (g1[1] + g2[0]), g2[1]]])
+                    for at in trs2(Q, g0, disc=(lc[0] == "L2")):
+                        gam, m, H = gamma_star(at @ ut + l0 + kappa0, at + xi, mc, chi)
+                        a = Rm @ at
+                        lam = np.zeros(E)
+                        if lc[0] == "L2":
+                            ls = np.linalg.solve(AS.T, a)
+                            lam[i1], lam[i2] = ls
+                        else:
+                            lam[0:2] = a
+                            lam[2] = -np.hypot(a[0], a[1])
+                        sols.append((lam, gam))
+                for lam, gam in sols:
+                    mu = np.zeros(Rn)
+                    for k, j in enumerate(mc):
+                        mu[j] = gam[k]
+                    # sign feasibility
+                    if cone_norm2:
+                        ok_l = True
+                    else:
+                        ok_l = np.all(lam >= -SIGN_TOL)
+                    if not ok_l or not np.all(mu >= -SIGN_TOL):
+                        continue
+                    if not cone_norm2:
+                        lam = np.maximum(lam, 0.0)
+                    mu = np.maximum(mu, 0.0)
+                    cost, m, H = true_cost(lam, mu)
+                    allc.append((cost, idx, lc, mc, chi))
+                    if best is None or cost < best[0]:
+                        best = (cost, idx, lam, mu, m, H, lc, mc, chi)
+    cost, idx, lam, mu, m, H, lc, mc, chi = best
+    z = (0.5 if accelerated else 1.0) * max(m, 0.0)
+    info = dict(cost=cost, m=m, H=H, cand=(lc, mc, chi), index=idx)
+    if return_all:
+        info["all"] = allc
+    return lam, mu, z, info

@@ -1,0 +1,689 @@
+/*
+ * ORACLE - test infrastructure only (see rda_oracle.h).  Plain C99, fp64.
+ *
+ * Restates, function by function, /root/reference/RDA_planner/rda_solver.py:
+ *   orc_step            <- iterative_solve :573-610 + rda_solver :612-637
+ *   stage_obstacles     <- assign_obstacle_parameter :483-526   (quirk Q3: pad = duplicate last)
+ *   linearise           <- assign_state_parameter :436-460, models :949-994 (quirk Q1)
+ *   orc_lammuz_one      <- LamMuZ_cost_cons :389-421, Hm_LamMu/Im_LamMu :874-909, cones :1034-1050
+ *   dual/residual part  <- solve_parallel :781-793, assign_combine_parameter_lamobs :529-542,
+ *                          update_xi :668-690, update_zeta :639-666
+ *   orc_su_solve        <- construct_su_prob :216-231, nav_cost_cons :313-328,
+ *                          update_su_cost_cons :330-387, Im_su/Hm_su :831-872,
+ *                          dynamics/bounds :911-947, C0/C1 cost :1011-1032
+ * The two convex programs the reference gives to CVXPY/ECOS are solved here by
+ *   (i)  exhaustive enumeration of basic supports (LamMuZ; see oracle/lammuz_np.py for the
+ *        derivation and the explicit tie-break T1-T3), and
+ *  (ii)  a dense primal-dual interior point method on the control-condensed problem (su).
+ */
+#include "rda_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define EMAX 16
+#define RMAX 16
+#define SIGN_TOL 1e-12
+
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
+struct orc_handle {
+    orc_cfg c;
+    double *G, *h;                 /* R*2, R */
+    double *lam, *mu, *z, *xi, *zeta, *dis;   /* dual state, persists across steps (Q5,Q6) */
+    double *a_lam, *b_lam;         /* obsA_lam / obsb_lam (rda_solver.py:172-173), stale at step start (Q4) */
+    double *A, *b; int *cone;      /* staged obstacles [N][T+1][E][2], [N][T+1][E] */
+    double *s, *u;                 /* current nominal (para_s, para_u) */
+    int obstacle_num;
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* 2-D trust-region sub-problem: min 1/2 x'Qx + c'x,  ||x||<=1 (disc) or ||x||==1.            */
+/* returns number of solutions written (0 or 1)                                                */
+static int trs2(double q11, double q12, double q22, double c0, double c1, int disc, double *x)
+{
+    double mean = 0.5 * (q11 + q22), dif = 0.5 * (q11 - q22);
+    double rad = hypot(dif, q12);
+    double l1 = mean - rad, l2 = mean + rad;
+    double v2x, v2y;
+    if (dif >= 0) { v2x = dif + rad; v2y = q12; } else { v2x = q12; v2y = rad - dif; }
+    double nv = hypot(v2x, v2y);
+    if (nv > 0) { v2x /= nv; v2y /= nv; } else { v2x = 1; v2y = 0; }
+    double v1x = -v2y, v1y = v2x;
+    double h1 = v1x * c0 + v1y * c1, h2 = v2x * c0 + v2y * c1;
+    double cn = hypot(h1, h2);
+    double scale = fabs(l2) > 1e-300 ? fabs(l2) : 1e-300;
+    if (disc && l1 > 1e-13 * scale) {
+        double y1 = -h1 / l1, y2 = -h2 / l2;
+        if (y1 * y1 + y2 * y2 <= 1.0) { x[0] = y1 * v1x + y2 * v2x; x[1] = y1 * v1y + y2 * v2y; return 1; }
+    }
+    if (cn == 0.0) {
+        if (disc) return 0;
+        x[0] = v1x; x[1] = v1y; return 1;
+    }
+    double lo = cn - l2, lo2 = fabs(h1) - l1;
+    if (lo2 > lo) lo = lo2;
+    if (disc && lo < 0) lo = 0;
+    double tau = lo;
+    for (int it = 0; it < 40; ++it) {
+        double s1 = l1 + tau, s2 = l2 + tau;
+        if (s1 <= 0 || s2 <= 0) { tau = (-l1 > -l2 ? -l1 : -l2) + 1e-300; s1 = l1 + tau; s2 = l2 + tau; }
+        double a1 = h1 != 0 ? h1 / s1 : 0.0, a2 = h2 != 0 ? h2 / s2 : 0.0;
+        double phi = a1 * a1 + a2 * a2;
+        if (!(phi > 0)) break;
+        double dphi = -2.0 * (a1 * a1 / s1 + a2 * a2 / s2);
+        double sq = sqrt(phi);
+        double g = 1.0 / sq - 1.0, dg = -0.5 * dphi / (phi * sq);
+        double step = g / dg;
+        tau -= step;
+        if (fabs(step) <= 1e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
+    }
+    double s1 = l1 + tau, s2 = l2 + tau;
+    double y1 = h1 != 0 ? -h1 / s1 : 0.0, y2 = h2 != 0 ? -h2 / s2 : 0.0;
+    double xx = y1 * v1x + y2 * v2x, xy = y1 * v1y + y2 * v2y;
+    double nx = hypot(xx, xy);
+    if (nx > 0) { xx /= nx; xy /= nx; }
+    x[0] = xx; x[1] = xy;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int E, R;
+    const double *A, *b, *G, *h;
+    double q[EMAX], M[EMAX][2];       /* q = A p - b ; M = A R (rows) */
+    double xi[2], kappa0, ro2, delta;
+} lmz_ctx;
+
+typedef struct { int k; int j[2]; double P[2][2]; double r[2]; double rr; } mu_cand;
+
+/* minimise over the mu-support coefficients for given (t, e):  returns m, H, gamma */
+static void gamma_star(const lmz_ctx *c, const mu_cand *mc, double chi, double t, const double *e,
+                       double *gam, double *m, double *H)
+{
+    if (mc->k == 0) { *m = t; H[0] = e[0]; H[1] = e[1]; return; }
+    if (mc->k == 1) {
+        const double *g = &c->G[2 * mc->j[0]]; double eta = c->h[mc->j[0]];
+        double den = chi * eta * eta + c->ro2 * (g[0] * g[0] + g[1] * g[1]);
+        double ga = (chi * eta * t - c->delta * eta - c->ro2 * (g[0] * e[0] + g[1] * e[1])) / den;
+        gam[0] = ga; *m = t - eta * ga; H[0] = e[0] + ga * g[0]; H[1] = e[1] + ga * g[1];
+        return;
+    }
+    double re = mc->r[0] * e[0] + mc->r[1] * e[1];
+    double beta = (c->delta - chi * (t + re)) / (chi * mc->rr + c->ro2);
+    H[0] = -beta * mc->r[0]; H[1] = -beta * mc->r[1];
+    /* gamma = P^{-1}(H - e), P columns = G rows */
+    double d0 = H[0] - e[0], d1 = H[1] - e[1];
+    double det = mc->P[0][0] * mc->P[1][1] - mc->P[0][1] * mc->P[1][0];
+    gam[0] = (mc->P[1][1] * d0 - mc->P[0][1] * d1) / det;
+    gam[1] = (-mc->P[1][0] * d0 + mc->P[0][0] * d1) / det;
+    *m = t + re + beta * mc->rr;
+}
+
+int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm2,
+                   const double *p, double phi, const double *G, const double *h,
+                   const double *xi, double zeta, double dbar, double ro2, double delta,
+                   int accelerated, double *lam_out, double *mu_out, double *z_out, double *cmh)
+{
+    if (E > EMAX || R > RMAX) return -1;
+    lmz_ctx c; c.E = E; c.R = R; c.A = A; c.b = b; c.G = G; c.h = h;
+    double cs = cos(phi), sn = sin(phi);
+    for (int i = 0; i < E; ++i) {
+        c.q[i] = A[2 * i] * p[0] + A[2 * i + 1] * p[1] - b[i];
+        c.M[i][0] = A[2 * i] * cs + A[2 * i + 1] * sn;       /* (A R)[i][0] */
+        c.M[i][1] = -A[2 * i] * sn + A[2 * i + 1] * cs;
+    }
+    c.xi[0] = xi[0]; c.xi[1] = xi[1]; c.kappa0 = zeta - dbar; c.ro2 = ro2; c.delta = delta;
+
+    /* mu candidates */
+    mu_cand mcs[1 + RMAX + RMAX * (RMAX - 1) / 2]; int nm = 0;
+    mcs[nm].k = 0; nm++;
+    for (int j = 0; j < R; ++j)
+        if (G[2 * j] * G[2 * j] + G[2 * j + 1] * G[2 * j + 1] > 0) { mcs[nm].k = 1; mcs[nm].j[0] = j; nm++; }
+    for (int j1 = 0; j1 < R; ++j1) for (int j2 = j1 + 1; j2 < R; ++j2) {
+        double det = G[2 * j1] * G[2 * j2 + 1] - G[2 * j1 + 1] * G[2 * j2];
+        double n1 = hypot(G[2 * j1], G[2 * j1 + 1]), n2 = hypot(G[2 * j2], G[2 * j2 + 1]);
+        if (det != 0 && fabs(det) > 1e-12 * n1 * n2) {
+            mu_cand *m = &mcs[nm++]; m->k = 2; m->j[0] = j1; m->j[1] = j2;
+            m->P[0][0] = G[2 * j1]; m->P[0][1] = G[2 * j2]; m->P[1][0] = G[2 * j1 + 1]; m->P[1][1] = G[2 * j2 + 1];
+            /* robot vertex: G_S r = h_S */
+            m->r[0] = (h[j1] * G[2 * j2 + 1] - G[2 * j1 + 1] * h[j2]) / det;
+            m->r[1] = (G[2 * j1] * h[j2] - h[j1] * G[2 * j2]) / det;
+            m->rr = m->r[0] * m->r[0] + m->r[1] * m->r[1];
+        }
+    }
+    /* lam candidates: type 0 L0, 1 L1(i), 2 L2(i1,i2), 3 LC */
+    int lt[1 + EMAX + EMAX * (EMAX - 1) / 2], li1[1 + EMAX + EMAX * (EMAX - 1) / 2], li2[1 + EMAX + EMAX * (EMAX - 1) / 2];
+    int nl = 0;
+    lt[nl] = 0; li1[nl] = li2[nl] = -1; nl++;
+    if (cone_norm2) { lt[nl] = 3; li1[nl] = li2[nl] = -1; nl++; }
+    else {
+        for (int i = 0; i < E; ++i)
+            if (A[2 * i] * A[2 * i] + A[2 * i + 1] * A[2 * i + 1] > 0) { lt[nl] = 1; li1[nl] = i; li2[nl] = -1; nl++; }
+        for (int i1 = 0; i1 < E; ++i1) for (int i2 = i1 + 1; i2 < E; ++i2) {
+            double det = A[2 * i1] * A[2 * i2 + 1] - A[2 * i1 + 1] * A[2 * i2];
+            double n1 = hypot(A[2 * i1], A[2 * i1 + 1]), n2 = hypot(A[2 * i2], A[2 * i2 + 1]);
+            if (det != 0 && fabs(det) > 1e-12 * n1 * n2) { lt[nl] = 2; li1[nl] = i1; li2[nl] = i2; nl++; }
+        }
+    }
+
+    double best_cost = INFINITY; int best_idx = 0;
+    double best_m = 0, best_H[2] = {0, 0};
+    for (int i = 0; i < E; ++i) lam_out[i] = 0;
+    for (int j = 0; j < R; ++j) mu_out[j] = 0;
+    int idx = 0;
+    for (int il = 0; il < nl; ++il) for (int im = 0; im < nm; ++im) for (int ic = 0; ic < 2; ++ic) {
+        idx++;
+        const mu_cand *mc = &mcs[im]; double chi = (double)ic;
+        double lam[EMAX]; for (int i = 0; i < E; ++i) lam[i] = 0;
+        double gam[2] = {0, 0}, m, H[2];
+        int have = 0;
+        if (lt[il] == 0) {
+            gamma_star(&c, mc, chi, c.kappa0, c.xi, gam, &m, H); have = 1;
+        } else if (lt[il] == 1) {
+            int i = li1[il];
+            double amax = 1.0 / hypot(A[2 * i], A[2 * i + 1]);
+            double e[2], d0, d1, al;
+            gamma_star(&c, mc, chi, c.kappa0, c.xi, gam, &m, H);
+            d0 = (chi * m - delta) * c.q[i] + ro2 * (c.M[i][0] * H[0] + c.M[i][1] * H[1]);
+            e[0] = amax * c.M[i][0] + c.xi[0]; e[1] = amax * c.M[i][1] + c.xi[1];
+            gamma_star(&c, mc, chi, amax * c.q[i] + c.kappa0, e, gam, &m, H);
+            d1 = (chi * m - delta) * c.q[i] + ro2 * (c.M[i][0] * H[0] + c.M[i][1] * H[1]);
+            if (d1 <= 0) al = amax; else if (d0 >= 0) al = 0; else al = amax * d0 / (d0 - d1);
+            e[0] = al * c.M[i][0] + c.xi[0]; e[1] = al * c.M[i][1] + c.xi[1];
+            gamma_star(&c, mc, chi, al * c.q[i] + c.kappa0, e, gam, &m, H);
+            lam[i] = al; have = 1;
+        } else {
+            double ut[2], l0 = 0, AS[2][2] = {{0, 0}, {0, 0}}, detS = 1;
+            int i1 = li1[il], i2 = li2[il];
+            double dv[2];
+            if (lt[il] == 2) {
+                AS[0][0] = A[2 * i1]; AS[0][1] = A[2 * i1 + 1]; AS[1][0] = A[2 * i2]; AS[1][1] = A[2 * i2 + 1];
+                detS = AS[0][0] * AS[1][1] - AS[0][1] * AS[1][0];
+                double vx = (b[i1] * AS[1][1] - AS[0][1] * b[i2]) / detS;
+                double vy = (AS[0][0] * b[i2] - b[i1] * AS[1][0]) / detS;
+                dv[0] = p[0] - vx; dv[1] = p[1] - vy;
+            } else { dv[0] = p[0] - b[0]; dv[1] = p[1] - b[1]; l0 = b[2]; }
+            ut[0] = cs * dv[0] + sn * dv[1]; ut[1] = -sn * dv[0] + cs * dv[1];      /* R' (p - v) */
+            double g0[2], g1[2], g2[2], e[2], at[2];
+            /* gradient of the reduced model at 0, e1, e2 */
+            gamma_star(&c, mc, chi, l0 + c.kappa0, c.xi, gam, &m, H);
+            g0[0] = (chi * m - delta) * ut[0] + ro2 * H[0]; g0[1] = (chi * m - delta) * ut[1] + ro2 * H[1];
+            e[0] = 1 + c.xi[0]; e[1] = c.xi[1];
+            gamma_star(&c, mc, chi, ut[0] + l0 + c.kappa0, e, gam, &m, H);
+            g1[0] = (chi * m - delta) * ut[0] + ro2 * H[0] - g0[0]; g1[1] = (chi * m - delta) * ut[1] + ro2 * H[1] - g0[1];
+            e[0] = c.xi[0]; e[1] = 1 + c.xi[1];
+            gamma_star(&c, mc, chi, ut[1] + l0 + c.kappa0, e, gam, &m, H);
+            g2[0] = (chi * m - delta) * ut[0] + ro2 * H[0] - g0[0]; g2[1] = (chi * m - delta) * ut[1] + ro2 * H[1] - g0[1];
+            double q12 = 0.5 * (g1[1] + g2[0]);
+            if (trs2(g1[0], q12, g2[1], g0[0], g0[1], lt[il] == 2, at)) {
+                e[0] = at[0] + c.xi[0]; e[1] = at[1] + c.xi[1];
+                gamma_star(&c, mc, chi, at[0] * ut[0] + at[1] * ut[1] + l0 + c.kappa0, e, gam, &m, H);
+                double ax = cs * at[0] - sn * at[1], ay = sn * at[0] + cs * at[1];   /* a = R at */
+                if (lt[il] == 2) {
+                    /* A_S' lamS = a */
+                    lam[i1] = (ax * AS[1][1] - AS[1][0] * ay) / detS;
+                    lam[i2] = (AS[0][0] * ay - ax * AS[0][1]) / detS;
+                } else { lam[0] = ax; lam[1] = ay; lam[2] = -hypot(ax, ay); }
+                have = 1;
+            }
+        }
+        if (!have) continue;
+        double mu[RMAX]; for (int j = 0; j < R; ++j) mu[j] = 0;
+        for (int k = 0; k < mc->k; ++k) mu[mc->j[k]] = gam[k];
+        int ok = 1;
+        if (!cone_norm2) for (int i = 0; i < E; ++i) { if (lam[i] < -SIGN_TOL) ok = 0; else if (lam[i] < 0) lam[i] = 0; }
+        for (int j = 0; j < R; ++j) { if (mu[j] < -SIGN_TOL) ok = 0; else if (mu[j] < 0) mu[j] = 0; }
+        if (!ok) continue;
+        /* true cost */
+        double mm = c.kappa0, HH[2] = {c.xi[0], c.xi[1]};
+        for (int i = 0; i < E; ++i) { mm += lam[i] * c.q[i]; HH[0] += lam[i] * c.M[i][0]; HH[1] += lam[i] * c.M[i][1]; }
+        for (int j = 0; j < R; ++j) { mm -= mu[j] * h[j]; HH[0] += mu[j] * G[2 * j]; HH[1] += mu[j] * G[2 * j + 1]; }
+        double ng = mm < 0 ? mm : 0;
+        double cost = 0.5 * ng * ng - delta * mm + 0.5 * ro2 * (HH[0] * HH[0] + HH[1] * HH[1]);
+        if (cost < best_cost) {
+            best_cost = cost; best_idx = idx; best_m = mm; best_H[0] = HH[0]; best_H[1] = HH[1];
+            for (int i = 0; i < E; ++i) lam_out[i] = lam[i];
+            for (int j = 0; j < R; ++j) mu_out[j] = mu[j];
+        }
+    }
+    *z_out = (accelerated ? 0.5 : 1.0) * (best_m > 0 ? best_m : 0);          /* tie-break T2 */
+    if (cmh) { cmh[0] = best_cost; cmh[1] = best_m; cmh[2] = best_H[0]; cmh[3] = best_H[1]; }
+    return best_idx;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* linearised motion models, rda_solver.py:949-994 (A 3x3, B 3x2, C 3) about (s_t, u_t)       */
+static void lin_model(const orc_cfg *c, const double *st, const double *ut, double *A, double *B, double *C)
+{
+    double dt = c->dt;
+    memset(A, 0, 9 * sizeof(double)); memset(B, 0, 6 * sizeof(double)); memset(C, 0, 3 * sizeof(double));
+    A[0] = A[4] = A[8] = 1;
+    if (c->dynamics == 2) {         /* omni: phi := velocity heading u[1] */
+        double phi = ut[1], v = ut[0];
+        B[0] = cos(phi) * dt; B[1] = -v * sin(phi) * dt; B[2] = sin(phi) * dt; B[3] = v * cos(phi) * dt;
+        C[0] = phi * v * sin(phi) * dt; C[1] = -phi * v * cos(phi) * dt;
+        return;
+    }
+    double phi = st[2], v = ut[0];
+    A[2] = -v * dt * sin(phi); A[5] = v * dt * cos(phi);
+    B[0] = cos(phi) * dt; B[2] = sin(phi) * dt;
+    C[0] = phi * v * sin(phi) * dt; C[1] = -phi * v * cos(phi) * dt;
+    if (c->dynamics == 0) {
+        double psi = ut[1], cp = cos(psi);
+        B[4] = tan(psi) * dt / c->L; B[5] = v * dt / (c->L * cp * cp);
+        C[2] = -psi * v * dt / (c->L * cp * cp);
+    } else {
+        B[5] = dt;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* su-problem: dense primal-dual IPM on x = (u_0..u_{T-1}, d_0..d_{T-1})                       */
+typedef struct { int i1, i2; double c1, c2, e; } lincon;
+
+typedef struct {
+    const orc_cfg *c; int T, N;
+    const double *a, *cc, *g, *ref, *nom_s;
+    double ref_speed;
+    double *Ak, *Bk, *Ck;       /* T x (9,6,3) */
+    double *Gam;                /* [t][k] 3x2, k<=t : d s_{t+1} / d u_k */
+    double *Q0, *Q1, *Q2;       /* per t */
+    double s0[3];
+} su_ctx;
+
+static void su_rollout(const su_ctx *S, const double *x, double *s /*3x(T+1) row-major*/)
+{
+    int T = S->T;
+    for (int r = 0; r < 3; ++r) s[r * (T + 1)] = S->s0[r];
+    for (int t = 0; t < T; ++t) {
+        const double *A = &S->Ak[9 * t], *B = &S->Bk[6 * t], *C = &S->Ck[3 * t];
+        for (int r = 0; r < 3; ++r) {
+            double v = C[r];
+            for (int k = 0; k < 3; ++k) v += A[3 * r + k] * s[k * (T + 1) + t];
+            v += B[2 * r] * x[2 * t] + B[2 * r + 1] * x[2 * t + 1];
+            s[r * (T + 1) + t + 1] = v;
+        }
+    }
+}
+
+/* objective, gradient (n) and generalised Hessian (n x n) at x */
+static double su_eval(const su_ctx *S, const double *x, double *s, double *grad, double *Hm)
+{
+    const orc_cfg *c = S->c; int T = S->T, N = S->N, n = 3 * T;
+    su_rollout(S, x, s);
+    double f = 0;
+    if (grad) memset(grad, 0, n * sizeof(double));
+    if (Hm) memset(Hm, 0, (size_t)n * n * sizeof(double));
+    double wz = c->dynamics == 2 ? 0.0 : 1.0;
+    for (int t = 0; t < T; ++t) {
+        double st[3] = { s[t + 1], s[(T + 1) + t + 1], s[2 * (T + 1) + t + 1] };
+        double gs[3], Hs[3][3] = {{0}}, gd = 0, Hsd[2] = {0, 0}, Hdd = 0;
+        double w[3] = { 1, 1, wz };
+        for (int r = 0; r < 3; ++r) {
+            double df = st[r] - S->ref[r * (T + 1) + t + 1];
+            f += c->ws * w[r] * df * df; gs[r] = 2 * c->ws * w[r] * df; Hs[r][r] = 2 * c->ws * w[r];
+        }
+        double dl = st[2] - S->nom_s[2 * (T + 1) + t];
+        f += 0.5 * c->ro2 * (S->Q0[t] + S->Q1[t] * dl + S->Q2[t] * dl * dl);
+        gs[2] += 0.5 * c->ro2 * (S->Q1[t] + 2 * S->Q2[t] * dl); Hs[2][2] += c->ro2 * S->Q2[t];
+        double dt_ = x[2 * T + t];
+        for (int nn = 0; nn < N; ++nn) {
+            const double *a = &S->a[(nn * T + t) * 2];
+            double Im = a[0] * st[0] + a[1] * st[1] - S->cc[nn * T + t] - dt_;
+            if (!c->accelerated || Im < 0) {
+                f += 0.5 * c->ro1 * Im * Im;
+                gs[0] += c->ro1 * Im * a[0]; gs[1] += c->ro1 * Im * a[1]; gd -= c->ro1 * Im;
+                Hs[0][0] += c->ro1 * a[0] * a[0]; Hs[0][1] += c->ro1 * a[0] * a[1]; Hs[1][1] += c->ro1 * a[1] * a[1];
+                Hsd[0] -= c->ro1 * a[0]; Hsd[1] -= c->ro1 * a[1]; Hdd += c->ro1;
+            }
+        }
+        Hs[1][0] = Hs[0][1];
+        f -= c->slack_gain * dt_;
+        if (grad) {
+            grad[2 * T + t] += gd - c->slack_gain;
+            for (int k = 0; k <= t; ++k) {
+                const double *Gm = &S->Gam[(t * T + k) * 6];
+                for (int j = 0; j < 2; ++j)
+                    grad[2 * k + j] += Gm[j] * gs[0] + Gm[2 + j] * gs[1] + Gm[4 + j] * gs[2];
+            }
+        }
+        if (Hm) {
+            Hm[(2 * T + t) * n + 2 * T + t] += Hdd;
+            for (int k = 0; k <= t; ++k) {
+                const double *Gk = &S->Gam[(t * T + k) * 6];
+                double HG[3][2];
+                for (int r = 0; r < 3; ++r) for (int j = 0; j < 2; ++j)
+                    HG[r][j] = Hs[r][0] * Gk[j] + Hs[r][1] * Gk[2 + j] + Hs[r][2] * Gk[4 + j];
+                for (int j = 0; j < 2; ++j) {
+                    double v = Gk[j] * Hsd[0] + Gk[2 + j] * Hsd[1];
+                    Hm[(2 * k + j) * n + 2 * T + t] += v; Hm[(2 * T + t) * n + 2 * k + j] += v;
+                }
+                for (int l = 0; l <= t; ++l) {
+                    const double *Gl = &S->Gam[(t * T + l) * 6];
+                    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j)
+                        Hm[(2 * l + i) * n + 2 * k + j] += Gl[i] * HG[0][j] + Gl[2 + i] * HG[1][j] + Gl[4 + i] * HG[2][j];
+                }
+            }
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        double dv = x[2 * t] - S->ref_speed;
+        f += c->wu * dv * dv + 0.5 * c->eps_u * (x[2 * t] * x[2 * t] + x[2 * t + 1] * x[2 * t + 1]);
+        if (grad) { grad[2 * t] += 2 * c->wu * dv + c->eps_u * x[2 * t]; grad[2 * t + 1] += c->eps_u * x[2 * t + 1]; }
+        if (Hm) { Hm[(2 * t) * n + 2 * t] += 2 * c->wu + c->eps_u; Hm[(2 * t + 1) * n + 2 * t + 1] += c->eps_u; }
+    }
+    return f;
+}
+
+static int chol_factor(double *K, int n)
+{
+    for (int j = 0; j < n; ++j) {
+        double d = K[j * n + j];
+        for (int k = 0; k < j; ++k) d -= K[j * n + k] * K[j * n + k];
+        if (!(d > 0)) return 1;
+        d = sqrt(d); K[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double v = K[i * n + j];
+            for (int k = 0; k < j; ++k) v -= K[i * n + k] * K[j * n + k];
+            K[i * n + j] = v / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const double *K, int n, double *rhs)
+{
+    for (int i = 0; i < n; ++i) { double v = rhs[i]; for (int k = 0; k < i; ++k) v -= K[i * n + k] * rhs[k]; rhs[i] = v / K[i * n + i]; }
+    for (int i = n - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < n; ++k) v -= K[k * n + i] * rhs[k]; rhs[i] = v / K[i * n + i]; }
+}
+
+int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
+                 double ref_speed, const double *a, const double *cc, const double *g,
+                 const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters)
+{
+    int T = c->T, N = c->N, n = 3 * T;
+    su_ctx S; S.c = c; S.T = T; S.N = N; S.a = a; S.cc = cc; S.g = g; S.ref = ref_s; S.nom_s = nom_s; S.ref_speed = ref_speed;
+    S.Ak = malloc(sizeof(double) * 9 * T); S.Bk = malloc(sizeof(double) * 6 * T); S.Ck = malloc(sizeof(double) * 3 * T);
+    S.Gam = calloc((size_t)T * T * 6, sizeof(double));
+    S.Q0 = calloc(T, sizeof(double)); S.Q1 = calloc(T, sizeof(double)); S.Q2 = calloc(T, sizeof(double));
+    for (int r = 0; r < 3; ++r) S.s0[r] = nom_s[r * (T + 1)];
+    for (int t = 0; t < T; ++t) {
+        double st[3] = { nom_s[t], nom_s[(T + 1) + t], nom_s[2 * (T + 1) + t] }, ut[2] = { nom_u[t], nom_u[T + t] };
+        lin_model(c, st, ut, &S.Ak[9 * t], &S.Bk[6 * t], &S.Ck[3 * t]);
+        /* Gam[t][t] = B_t ; Gam[t][k] = A_t Gam[t-1][k] */
+        memcpy(&S.Gam[(t * T + t) * 6], &S.Bk[6 * t], 6 * sizeof(double));
+        for (int k = 0; k < t; ++k) {
+            const double *P = &S.Gam[((t - 1) * T + k) * 6]; double *Q = &S.Gam[(t * T + k) * 6];
+            for (int r = 0; r < 3; ++r) for (int j = 0; j < 2; ++j)
+                Q[2 * r + j] = S.Ak[9 * t + 3 * r] * P[j] + S.Ak[9 * t + 3 * r + 1] * P[2 + j] + S.Ak[9 * t + 3 * r + 2] * P[4 + j];
+        }
+        /* rotation-consistency penalty reduced to a scalar quadratic in delta_t */
+        double phi = st[2], cs = cos(phi), sn = sin(phi);
+        for (int nn = 0; nn < N; ++nn) {
+            const double *an = &a[(nn * T + t) * 2], *gn = &g[(nn * T + t) * 2];
+            double k0x = gn[0] + cs * an[0] + sn * an[1], k0y = gn[1] - sn * an[0] + cs * an[1];
+            double k1x = -sn * an[0] + cs * an[1], k1y = -cs * an[0] - sn * an[1];
+            S.Q0[t] += k0x * k0x + k0y * k0y; S.Q1[t] += 2 * (k0x * k1x + k0y * k1y); S.Q2[t] += k1x * k1x + k1y * k1y;
+        }
+    }
+    /* constraints C x <= e */
+    int mc = 4 * T + 4 * (T - 1) + 2 * T;
+    lincon *con = malloc(sizeof(lincon) * mc); int m = 0;
+    for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
+        con[m++] = (lincon){ 2 * t + i, -1, 1.0, 0, c->max_speed[i] };
+        con[m++] = (lincon){ 2 * t + i, -1, -1.0, 0, c->max_speed[i] };
+    }
+    for (int t = 0; t + 1 < T; ++t) for (int i = 0; i < 2; ++i) {
+        con[m++] = (lincon){ 2 * (t + 1) + i, 2 * t + i, 1.0, -1.0, c->acce_bound[i] };
+        con[m++] = (lincon){ 2 * (t + 1) + i, 2 * t + i, -1.0, 1.0, c->acce_bound[i] };
+    }
+    for (int t = 0; t < T; ++t) {
+        con[m++] = (lincon){ 2 * T + t, -1, 1.0, 0, c->max_sd };
+        con[m++] = (lincon){ 2 * T + t, -1, -1.0, 0, -c->min_sd };
+    }
+    mc = m;
+    double *x = malloc(sizeof(double) * n), *grad = malloc(sizeof(double) * n), *Hm = malloc(sizeof(double) * n * n);
+    double *K = malloc(sizeof(double) * n * n), *rhs = malloc(sizeof(double) * n), *dx = malloc(sizeof(double) * n);
+    double *w = malloc(sizeof(double) * mc), *lm = malloc(sizeof(double) * mc), *rp = malloc(sizeof(double) * mc);
+    double *dw = malloc(sizeof(double) * mc), *dl = malloc(sizeof(double) * mc), *rc = malloc(sizeof(double) * mc);
+    double *s = malloc(sizeof(double) * 3 * (T + 1));
+    for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
+        double v = nom_u[i * T + t], lim = 0.99 * c->max_speed[i];
+        x[2 * t + i] = v > lim ? lim : (v < -lim ? -lim : v);
+    }
+    for (int t = 0; t < T; ++t) {
+        double v = d0 ? d0[t] : c->max_sd, lo = c->min_sd + 0.01 * (c->max_sd - c->min_sd), hi = c->max_sd - 0.01 * (c->max_sd - c->min_sd);
+        x[2 * T + t] = v > hi ? hi : (v < lo ? lo : v);
+    }
+    for (int i = 0; i < mc; ++i) {
+        double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
+        double sl = con[i].e - cx;
+        w[i] = sl > 1e-2 ? sl : 1e-2; lm[i] = 1.0;
+    }
+    int status = 1, it;
+    for (it = 0; it < 100; ++it) {
+        su_eval(&S, x, s, grad, Hm);
+        double gn = 0, rdn = 0, rpn = 0, mu = 0;
+        for (int i = 0; i < n; ++i) { if (fabs(grad[i]) > gn) gn = fabs(grad[i]); rhs[i] = grad[i]; }
+        for (int i = 0; i < mc; ++i) {
+            rhs[con[i].i1] += con[i].c1 * lm[i]; if (con[i].i2 >= 0) rhs[con[i].i2] += con[i].c2 * lm[i];
+            double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
+            rp[i] = cx + w[i] - con[i].e; if (fabs(rp[i]) > rpn) rpn = fabs(rp[i]);
+            mu += lm[i] * w[i];
+        }
+        mu /= mc;
+        for (int i = 0; i < n; ++i) if (fabs(rhs[i]) > rdn) rdn = fabs(rhs[i]);
+        double sc = 1 + gn;
+        if (rdn <= 1e-11 * sc && rpn <= 1e-12 && mu <= 1e-13 * sc) { status = 0; break; }
+        /* K = H + C' diag(lm/w) C */
+        memcpy(K, Hm, sizeof(double) * n * n);
+        for (int i = 0; i < mc; ++i) {
+            double dgn = lm[i] / w[i]; int i1 = con[i].i1, i2 = con[i].i2;
+            K[i1 * n + i1] += dgn * con[i].c1 * con[i].c1;
+            if (i2 >= 0) { K[i2 * n + i2] += dgn * con[i].c2 * con[i].c2; K[i1 * n + i2] += dgn * con[i].c1 * con[i].c2; K[i2 * n + i1] += dgn * con[i].c1 * con[i].c2; }
+        }
+        if (chol_factor(K, n)) { status = 2; break; }
+        double sigma = 0, mu_aff = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            /* rc = lm*w (+ corrector) - sigma*mu */
+            for (int i = 0; i < mc; ++i) rc[i] = lm[i] * w[i] + (pass ? dl[i] * dw[i] - sigma * mu : 0.0);
+            for (int i = 0; i < n; ++i) dx[i] = -rhs[i];
+            for (int i = 0; i < mc; ++i) {
+                double v = (lm[i] * rp[i] - rc[i]) / w[i];
+                dx[con[i].i1] -= con[i].c1 * v; if (con[i].i2 >= 0) dx[con[i].i2] -= con[i].c2 * v;
+            }
+            chol_solve(K, n, dx);
+            for (int i = 0; i < mc; ++i) {
+                double cdx = con[i].c1 * dx[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * dx[con[i].i2] : 0);
+                dw[i] = -rp[i] - cdx; dl[i] = -(rc[i] + lm[i] * dw[i]) / w[i];
+            }
+            if (pass == 0) {
+                double al = 1.0;
+                for (int i = 0; i < mc; ++i) {
+                    if (dw[i] < 0 && -w[i] / dw[i] < al) al = -w[i] / dw[i];
+                    if (dl[i] < 0 && -lm[i] / dl[i] < al) al = -lm[i] / dl[i];
+                }
+                mu_aff = 0; for (int i = 0; i < mc; ++i) mu_aff += (lm[i] + al * dl[i]) * (w[i] + al * dw[i]);
+                mu_aff /= mc; double r = mu_aff / mu; sigma = r * r * r;
+            }
+        }
+        double al = 1.0;
+        for (int i = 0; i < mc; ++i) {
+            if (dw[i] < 0 && -0.995 * w[i] / dw[i] < al) al = -0.995 * w[i] / dw[i];
+            if (dl[i] < 0 && -0.995 * lm[i] / dl[i] < al) al = -0.995 * lm[i] / dl[i];
+        }
+        for (int i = 0; i < n; ++i) x[i] += al * dx[i];
+        for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += al * dl[i]; }
+    }
+    if (ipm_iters) *ipm_iters = it;
+    su_rollout(&S, x, s);
+    memcpy(s_out, s, sizeof(double) * 3 * (T + 1));
+    for (int t = 0; t < T; ++t) { u_out[t] = x[2 * t]; u_out[T + t] = x[2 * t + 1]; d_out[t] = x[2 * T + t]; }
+    free(S.Ak); free(S.Bk); free(S.Ck); free(S.Gam); free(S.Q0); free(S.Q1); free(S.Q2);
+    free(con); free(x); free(grad); free(Hm); free(K); free(rhs); free(dx); free(w); free(lm); free(rp); free(dw); free(dl); free(rc); free(s);
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int orc_create(const orc_cfg *cfg, const double *G, const double *h, orc_handle **out)
+{
+    if (cfg->E > EMAX || cfg->R > RMAX || cfg->N < 1 || cfg->T < 1 || cfg->robot_norm2) return -1;
+    orc_handle *H = calloc(1, sizeof(*H));
+    H->c = *cfg;
+    int T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
+    H->G = malloc(sizeof(double) * 2 * R); memcpy(H->G, G, sizeof(double) * 2 * R);
+    H->h = malloc(sizeof(double) * R); memcpy(H->h, h, sizeof(double) * R);
+    H->lam = calloc((size_t)N * (T + 1) * E, sizeof(double));
+    H->mu = calloc((size_t)N * (T + 1) * R, sizeof(double));
+    H->z = calloc((size_t)N * T, sizeof(double));
+    H->xi = calloc((size_t)N * (T + 1) * 2, sizeof(double));
+    H->zeta = calloc((size_t)N * T, sizeof(double));
+    H->dis = malloc(sizeof(double) * T); for (int t = 0; t < T; ++t) H->dis[t] = 1.0;   /* rda_solver.py:119 */
+    H->a_lam = calloc((size_t)N * (T + 1) * 2, sizeof(double));
+    H->b_lam = calloc((size_t)N * (T + 1), sizeof(double));
+    H->A = calloc((size_t)N * (T + 1) * E * 2, sizeof(double));
+    H->b = calloc((size_t)N * (T + 1) * E, sizeof(double));
+    H->cone = malloc(sizeof(int) * N); for (int n = 0; n < N; ++n) H->cone[n] = 1;        /* rda_solver.py:158 */
+    H->s = calloc(3 * (T + 1), sizeof(double)); H->u = calloc(2 * T, sizeof(double));
+    *out = H; return 0;
+}
+void orc_destroy(orc_handle *H)
+{
+    if (!H) return;
+    free(H->G); free(H->h); free(H->lam); free(H->mu); free(H->z); free(H->xi); free(H->zeta); free(H->dis);
+    free(H->a_lam); free(H->b_lam); free(H->A); free(H->b); free(H->cone); free(H->s); free(H->u); free(H);
+}
+int orc_set_adjust(orc_handle *H, double slack_gain, double max_sd, double min_sd, double ro1, double ro2)
+{ H->c.slack_gain = slack_gain; H->c.max_sd = max_sd; H->c.min_sd = min_sd; H->c.ro1 = ro1; H->c.ro2 = ro2; return 0; }
+int orc_reset(orc_handle *H)
+{
+    int T = H->c.T, N = H->c.N;
+    for (int n = 0; n < N; ++n) for (int t = 0; t < T; ++t) {
+        H->a_lam[(n * (T + 1) + t + 1) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1] = 0; H->b_lam[n * (T + 1) + t + 1] = 0;
+    }
+    return 0;
+}
+int orc_get_state(orc_handle *H, double *lam, double *mu, double *z, double *xi, double *zeta, double *dis, double *a_lam, double *b_lam)
+{
+    int T = H->c.T, N = H->c.N, E = H->c.E, R = H->c.R;
+    if (lam) memcpy(lam, H->lam, sizeof(double) * N * (T + 1) * E);
+    if (mu) memcpy(mu, H->mu, sizeof(double) * N * (T + 1) * R);
+    if (z) memcpy(z, H->z, sizeof(double) * N * T);
+    if (xi) memcpy(xi, H->xi, sizeof(double) * N * (T + 1) * 2);
+    if (zeta) memcpy(zeta, H->zeta, sizeof(double) * N * T);
+    if (dis) memcpy(dis, H->dis, sizeof(double) * T);
+    if (a_lam) memcpy(a_lam, H->a_lam, sizeof(double) * N * (T + 1) * 2);
+    if (b_lam) memcpy(b_lam, H->b_lam, sizeof(double) * N * (T + 1));
+    return 0;
+}
+int orc_set_state(orc_handle *H, const double *lam, const double *mu, const double *z, const double *xi, const double *zeta, const double *dis, const double *a_lam, const double *b_lam)
+{
+    int T = H->c.T, N = H->c.N, E = H->c.E, R = H->c.R;
+    if (lam) memcpy(H->lam, lam, sizeof(double) * N * (T + 1) * E);
+    if (mu) memcpy(H->mu, mu, sizeof(double) * N * (T + 1) * R);
+    if (z) memcpy(H->z, z, sizeof(double) * N * T);
+    if (xi) memcpy(H->xi, xi, sizeof(double) * N * (T + 1) * 2);
+    if (zeta) memcpy(H->zeta, zeta, sizeof(double) * N * T);
+    if (dis) memcpy(H->dis, dis, sizeof(double) * T);
+    if (a_lam) memcpy(H->a_lam, a_lam, sizeof(double) * N * (T + 1) * 2);
+    if (b_lam) memcpy(H->b_lam, b_lam, sizeof(double) * N * (T + 1));
+    return 0;
+}
+
+/* assign_obstacle_parameter, rda_solver.py:483-526 */
+static void stage_obstacles(orc_handle *H, int n_obs, const double *A, const double *b, const int *cone, int per_t)
+{
+    int T = H->c.T, N = H->c.N, E = H->c.E;
+    H->obstacle_num = n_obs;
+    if (n_obs <= 0) return;                      /* nothing written: stale A,b stay */
+    int nt = per_t ? T + 1 : 1;
+    for (int n = 0; n < N; ++n) {
+        int src = n < n_obs ? n : n_obs - 1;     /* pad by duplicating the last obstacle (Q3) */
+        for (int t = 0; t <= T; ++t) {
+            int ts = per_t ? t : 0;
+            memcpy(&H->A[((size_t)(n * (T + 1) + t) * E) * 2], &A[((size_t)(src * nt + ts) * E) * 2], sizeof(double) * E * 2);
+            memcpy(&H->b[(size_t)(n * (T + 1) + t) * E], &b[(size_t)(src * nt + ts) * E], sizeof(double) * E);
+        }
+        H->cone[n] = cone[src];
+    }
+    H->obstacle_num = N;                          /* rda_solver.py:492 after padding; >N truncates */
+}
+
+int orc_step(orc_handle *H, const double *nom_s, const double *nom_u, const double *ref_s,
+             double ref_speed, int n_obs, const double *A, const double *b, const int *cone,
+             int per_t, double *out_u, double *out_s, orc_info *info)
+{
+    const orc_cfg *c = &H->c; int T = c->T, N = c->N, E = c->E, R = c->R;
+    memcpy(H->s, nom_s, sizeof(double) * 3 * (T + 1)); memcpy(H->u, nom_u, sizeof(double) * 2 * T);
+    stage_obstacles(H, n_obs, A, b, cone, per_t);
+    double *ca = malloc(sizeof(double) * N * T * 2), *cc = malloc(sizeof(double) * N * T), *cg = malloc(sizeof(double) * N * T * 2);
+    double *s_new = malloc(sizeof(double) * 3 * (T + 1)), *u_new = malloc(sizeof(double) * 2 * T), *d_new = malloc(sizeof(double) * T);
+    double *resn = malloc(sizeof(double) * N), *hm2 = malloc(sizeof(double) * N);
+    double resi_dual = 0, resi_pri = 0; int it, su_status = 0, ipm_total = 0;
+    for (it = 0; it < c->iter_num; ++it) {
+        /* ---- su-problem (rda_solver.py:617,692-700) ------------------------------------- */
+        for (int n = 0; n < N; ++n) for (int t = 0; t < T; ++t) {
+            const double *mu = &H->mu[(size_t)(n * (T + 1) + t + 1) * R];
+            double muh = 0, gx = H->xi[(n * (T + 1) + t + 1) * 2], gy = H->xi[(n * (T + 1) + t + 1) * 2 + 1];
+            for (int j = 0; j < R; ++j) { muh += mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1]; }
+            ca[(n * T + t) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2]; ca[(n * T + t) * 2 + 1] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1];
+            cc[n * T + t] = H->b_lam[n * (T + 1) + t + 1] + muh + H->z[n * T + t] - H->zeta[n * T + t];
+            cg[(n * T + t) * 2] = gx; cg[(n * T + t) * 2 + 1] = gy;
+        }
+        int ipm = 0;
+        int st = orc_su_solve(c, H->s, H->u, ref_s, ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm);
+        ipm_total += ipm;
+        if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
+        else su_status |= 1 << it;                /* 'No update of state and control vector' :699 */
+        resi_dual = 0; resi_pri = 0;
+        if (H->obstacle_num == 0) {               /* Q9: only the last slot is cleared, :564-568 */
+            int n = N - 1;
+            for (int t = 0; t < T; ++t) { H->a_lam[(n * (T + 1) + t + 1) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1] = 0; H->b_lam[n * (T + 1) + t + 1] = 0; }
+        } else {
+            /* ---- LamMuZ problems + dual updates (rda_solver.py:628-635) ----------------- */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+#endif
+            for (int n = 0; n < N; ++n) {
+                double res = 0, h2 = 0;
+                for (int t = 0; t < T; ++t) {
+                    size_t o = (size_t)(n * (T + 1) + t + 1);
+                    const double *At = &H->A[o * E * 2], *bt = &H->b[o * E];
+                    double p[2] = { H->s[t + 1], H->s[(T + 1) + t + 1] }, phi = H->s[2 * (T + 1) + t];
+                    double lam[EMAX], mu[RMAX], z;
+                    orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
+                                   H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, NULL);
+                    double cs = cos(phi), sn = sin(phi);
+                    double ax = 0, ay = 0, bl = 0, im = 0, gx = 0, gy = 0;
+                    for (int i = 0; i < E; ++i) {
+                        double dl_ = lam[i] - H->lam[o * E + i]; res += dl_ * dl_; H->lam[o * E + i] = lam[i];
+                        ax += lam[i] * At[2 * i]; ay += lam[i] * At[2 * i + 1]; bl += lam[i] * bt[i];
+                    }
+                    for (int j = 0; j < R; ++j) {
+                        double dm = mu[j] - H->mu[o * R + j]; res += dm * dm; H->mu[o * R + j] = mu[j];
+                        im -= mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1];
+                    }
+                    double dz = z - H->z[n * T + t]; res += dz * dz; H->z[n * T + t] = z;
+                    H->a_lam[o * 2] = ax; H->a_lam[o * 2 + 1] = ay; H->b_lam[o] = bl;          /* :541-542 */
+                    double hx = gx + cs * ax + sn * ay, hy = gy - sn * ax + cs * ay;          /* :682 */
+                    H->xi[o * 2] += hx; H->xi[o * 2 + 1] += hy; h2 += hx * hx + hy * hy;     /* :683 */
+                    im += ax * p[0] + ay * p[1] - bl;                                         /* :659 */
+                    H->zeta[n * T + t] += im - H->dis[t] - z;                                 /* :666 */
+                }
+                resn[n] = res; hm2[n] = h2;
+            }
+            for (int n = 0; n < N; ++n) { resi_dual += resn[n]; resi_pri += hm2[n]; }
+            resi_dual /= N; resi_pri = sqrt(resi_pri);                                        /* :737,:688 */
+        }
+        if (resi_dual < c->iter_threshold && resi_pri < c->iter_threshold) { it++; break; }   /* :594 */
+    }
+    memcpy(out_u, H->u, sizeof(double) * 2 * T); memcpy(out_s, H->s, sizeof(double) * 3 * (T + 1));
+    if (info) { info->resi_dual = resi_dual; info->resi_pri = resi_pri; info->iters = it; info->su_status = su_status; info->su_ipm_iters = ipm_total; }
+    free(ca); free(cc); free(cg); free(s_new); free(u_new); free(d_new); free(resn); free(hm2);
+    return 0;
+}

@@ -1,0 +1,87 @@
+/*
+ * ORACLE - test infrastructure only.  CPU (plain C, fp64) restatement of the RDA ADMM
+ * inner solver of hanruihua/RDA-planner (RDA_planner/rda_solver.py).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product path (rda_planner_amd/) never does.
+ *
+ * PARITY UNPINNED: the reference solves its two convex sub-problems with CVXPY 1.5.2 ->
+ * ECOS (rda_solver.py:693,768,800); neither is installable in the build image and the
+ * reference ships no tests / golden vectors.  The restatement is pinned
+ * instead by KKT certificates and scipy cross-checks (tests/test_oracle_*.py).
+ */
+#ifndef RDA_ORACLE_H
+#define RDA_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int T;            /* receding                      rda_solver.py:34  */
+    int N;            /* max_obs_num                   rda_solver.py:38  */
+    int E;            /* max_edge_num                  rda_solver.py:39  */
+    int R;            /* G.shape[0]                    rda_solver.py:99  */
+    int dynamics;     /* 0 acker, 1 diff, 2 omni       rda_solver.py:446-451 */
+    int accelerated;  /*                               rda_solver.py:47  */
+    int iter_num;     /*                               rda_solver.py:42  */
+    int robot_norm2;  /* car_tuple.cone_type=='norm2'  (unsupported -> error) */
+    double dt, L;
+    double max_speed[2];   /* rda_solver.py:37 */
+    double acce_bound[2];  /* max_acce*dt, rda_solver.py:44 */
+    double iter_threshold;
+    double ws, wu;                                  /* rda_solver.py:218-219 */
+    double slack_gain, max_sd, min_sd, ro1, ro2;    /* rda_solver.py:196-201 */
+    double delta;     /* tie-break (T1): clearance reward, default 1e-6 */
+    double eps_u;     /* tie-break for an undetermined steering column, default 1e-8 */
+} orc_cfg;
+
+typedef struct {
+    double resi_dual, resi_pri;
+    int iters;          /* ADMM iterations executed */
+    int su_status;      /* bit i set: su solve of iteration i did not converge (kept nominal) */
+    int su_ipm_iters;   /* total IPM iterations */
+} orc_info;
+
+typedef struct orc_handle orc_handle;
+
+int  orc_create(const orc_cfg *cfg, const double *G /*R*2*/, const double *h /*R*/, orc_handle **out);
+void orc_destroy(orc_handle *h);
+int  orc_set_adjust(orc_handle *h, double slack_gain, double max_sd, double min_sd, double ro1, double ro2);
+int  orc_reset(orc_handle *h);      /* rda_solver.py:1060-1068 */
+void orc_set_threads(int n);
+
+/* One MPC step == RDA_solver.iterative_solve (rda_solver.py:573-610).
+ * nom_s 3x(T+1) row-major, nom_u 2xT, ref_s 3x(T+1); obstacles: n_obs entries,
+ * A [n_obs][per_t? T+1 : 1][E][2], b [n_obs][per_t? T+1 : 1][E], cone [n_obs] (0 Rpositive, 1 norm2).
+ * out_u 2xT, out_s 3x(T+1). */
+int  orc_step(orc_handle *h, const double *nom_s, const double *nom_u, const double *ref_s,
+              double ref_speed, int n_obs, const double *A, const double *b, const int *cone,
+              int per_t, double *out_u, double *out_s, orc_info *info);
+
+/* State access in the reference's shapes: lam [N][T+1][E], mu [N][T+1][R], z [N][T],
+ * xi [N][T+1][2], zeta [N][T], dis [T], a_lam [N][T+1][2], b_lam [N][T+1]. */
+int  orc_get_state(orc_handle *h, double *lam, double *mu, double *z, double *xi, double *zeta,
+                   double *dis, double *a_lam, double *b_lam);
+int  orc_set_state(orc_handle *h, const double *lam, const double *mu, const double *z,
+                   const double *xi, const double *zeta, const double *dis,
+                   const double *a_lam, const double *b_lam);
+
+/* Pure-function hooks (mirror solve_parallel, rda_solver.py:743-793) ---------------------*/
+/* One (obstacle, stage) sub-problem.  A[E][2] b[E], p[2] nominal position (column t+1),
+ * phi nominal heading (column t), xi[2].  Outputs lam[E], mu[R], z; returns candidate index. */
+int  orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm2,
+                    const double *p, double phi, const double *G, const double *h,
+                    const double *xi, double zeta, double dbar, double ro2, double delta,
+                    int accelerated, double *lam, double *mu, double *z, double *cost_m_H /*4*/);
+
+/* su-problem (rda_solver.py:216-231,313-387).  Condensed obstacle terms per (n,t):
+ * a[N][T][2], cc[N][T] (= lam'b + mu'h + z - zeta), g[N][T][2] (= G'mu + xi).
+ * nom_s 3x(T+1), nom_u 2xT linearisation point; d0 [T] initial guess.
+ * Outputs s 3x(T+1), u 2xT, d [T]. returns 0 ok, 1 not converged. */
+int  orc_su_solve(const orc_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
+                  double ref_speed, const double *a, const double *cc, const double *g,
+                  const double *d0, double *s, double *u, double *d, int *ipm_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

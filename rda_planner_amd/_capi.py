@@ -1,0 +1,77 @@
+"""ctypes view of the C-ABI declared in include/rda_hip.h.
+
+The HIP library (`librda_hip.so`, symbols `rda_*`) and the CPU oracle used by the tests
+(`oracle/librda_oracle.so`, symbols `orc_*`) deliberately share struct layouts and argument
+order, so one binding class serves both; the product package only ever instantiates it on
+the HIP library.
+"""
+import ctypes as C
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class Cfg(C.Structure):
+    _fields_ = [("T", C.c_int), ("N", C.c_int), ("E", C.c_int), ("R", C.c_int),
+                ("dynamics", C.c_int), ("accelerated", C.c_int), ("iter_num", C.c_int),
+                ("robot_norm2", C.c_int),
+                ("dt", C.c_double), ("L", C.c_double),
+                ("max_speed", C.c_double * 2), ("acce_bound", C.c_double * 2),
+                ("iter_threshold", C.c_double), ("ws", C.c_double), ("wu", C.c_double),
+                ("slack_gain", C.c_double), ("max_sd", C.c_double), ("min_sd", C.c_double),
+                ("ro1", C.c_double), ("ro2", C.c_double),
+                ("delta", C.c_double), ("eps_u", C.c_double)]
+
+
+class Info(C.Structure):
+    _fields_ = [("resi_dual", C.c_double), ("resi_pri", C.c_double), ("iters", C.c_int),
+                ("su_status", C.c_int), ("su_ipm_iters", C.c_int)]
+
+
+DYNAMICS = {"acker": 0, "diff": 1, "omni": 2}
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(c_int_p) if a is not None else None
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class CApi:
+    """Thin typed wrapper over `<prefix>_*` entry points of a loaded shared library."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+        f = self._f
+        f("create").argtypes = [C.POINTER(Cfg), c_double_p, c_double_p, C.POINTER(C.c_void_p)]
+        f("create").restype = C.c_int
+        f("destroy").argtypes = [C.c_void_p]
+        f("destroy").restype = None
+        f("set_adjust").argtypes = [C.c_void_p] + [C.c_double] * 5
+        f("set_adjust").restype = C.c_int
+        f("reset").argtypes = [C.c_void_p]
+        f("reset").restype = C.c_int
+        f("step").argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_double, C.c_int,
+                              c_double_p, c_double_p, c_int_p, C.c_int, c_double_p, c_double_p,
+                              C.POINTER(Info)]
+        f("step").restype = C.c_int
+        f("get_state").argtypes = [C.c_void_p] + [c_double_p] * 8
+        f("get_state").restype = C.c_int
+        f("set_state").argtypes = [C.c_void_p] + [c_double_p] * 8
+        f("set_state").restype = C.c_int
+
+    def _f(self, name):
+        return getattr(self.lib, f"{self.prefix}_{name}")
+
+    def __getattr__(self, name):
+        return self._f(name)

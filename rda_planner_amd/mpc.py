@@ -1,0 +1,282 @@
+"""
+`MPC` - drop-in for RDA_planner.mpc.MPC (reference mpc.py:15-569).
+
+This is the boundary CALLER of the accelerated path: reference-path
+tracking, the open-loop rollout that produces the nominal trajectory, obstacle -> (A, b, cone)
+conversion and distance ordering.  It is plain host Python by design (O(T) scalar work per tick,
+out of scope for acceleration); what matters is that it feeds `RDA_solver.iterative_solve`
+exactly what the reference's `MPC.control` feeds it, quirks included (Q5, Q12).
+Constructor / method names and argument meaning follow the reference one-to-one.
+"""
+from collections import namedtuple
+from math import cos, inf, pi, sin, sqrt, tan
+
+import numpy as np
+
+from .rda_solver import RDA_solver
+
+rdaobs = namedtuple("rdaobs", "A b cone_type center vertex")          # reference mpc.py:12
+
+
+class MPC:
+    def __init__(self, car_tuple, ref_path, receding: int = 10, sample_time: float = 0.1, iter_num: int = 4,
+                 enable_reverse: bool = False, rda_obstacle: bool = False, obstacle_order: bool = True,
+                 max_edge_num: int = 5, max_obs_num: int = 5, process_num: int = 4, accelerated: bool = True,
+                 time_print: bool = False, goal_index_threshold: int = 1, **kwargs) -> None:
+        # reference mpc.py:67-125
+        self.car_tuple = car_tuple
+        self.L = car_tuple.wheelbase
+        self.dynamics = car_tuple.dynamics
+        self.receding = receding
+        self.dt = sample_time
+        self.cur_vel_array = kwargs.get("init_vel", np.zeros((2, receding)))
+        self.state = np.zeros((3, 1))
+        self.cur_index = 0
+        self.ref_path = ref_path
+        solver_kwargs = {k: v for k, v in kwargs.items() if k != "init_vel"}
+        self.rda = RDA_solver(receding, car_tuple, max_edge_num, max_obs_num, iter_num=iter_num,
+                              step_time=sample_time, process_num=process_num, accelerated=accelerated,
+                              time_print=time_print, **solver_kwargs)
+        self.enable_reverse = enable_reverse
+        self.rda_obstacle = rda_obstacle
+        self.obstacle_order = obstacle_order
+        self.goal_index_threshold = goal_index_threshold
+        if enable_reverse:
+            self.curve_list = self.split_path(self.ref_path)
+            self.curve_index = 0
+
+    # ------------------------------------------------------------------ control (mpc.py:127-187)
+    def control(self, state, ref_speed=5, obstacle_list=[], **kwargs):
+        if np.shape(state)[0] > 3:
+            state = state[0:3]
+        self.state = state
+        if self.enable_reverse:
+            cur_ref_path = self.curve_list[self.curve_index]
+            gear_flag = cur_ref_path[0][-1, 0]
+        else:
+            cur_ref_path = self.ref_path
+            gear_flag = 1
+
+        state_pre_array, ref_traj_list, self.cur_index = self.pre_process(
+            state, cur_ref_path, self.cur_index, ref_speed, **kwargs)
+
+        if not self.rda_obstacle:
+            rda_obs_list = self.convert_rda_obstacle(obstacle_list, state, self.obstacle_order)
+        else:
+            rda_obs_list = obstacle_list
+
+        u_opt_array, info = self.rda.iterative_solve(
+            state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, rda_obs_list, **kwargs)
+
+        if self.cur_index >= len(cur_ref_path) - self.goal_index_threshold:
+            if self.enable_reverse:
+                self.curve_index += 1
+                self.cur_index = 0
+                if self.curve_index < len(self.curve_list):
+                    info["arrive"] = False
+                else:
+                    u_opt_array = np.zeros((2, self.receding))
+                    info["arrive"] = True
+            else:
+                u_opt_array = np.zeros((2, self.receding))
+                info["arrive"] = True
+        else:
+            info["arrive"] = False
+
+        self.cur_vel_array = u_opt_array
+        return u_opt_array[:, 0:1], info
+
+    # ------------------------------------------------------------------ obstacles (mpc.py:189-218)
+    def convert_rda_obstacle(self, obstacle_list, state=None, obstacle_order=False):
+        out = []
+        for obs in obstacle_list:
+            if obs.cone_type == "norm2":
+                A, b = self.convert_inequal_circle(obs.center, obs.radius, obs.velocity)
+                out.append(rdaobs(A, b, obs.cone_type, obs.center, None))
+            elif obs.cone_type == "Rpositive":
+                A, b = self.convert_inequal_polygon(obs.vertex, obs.velocity)
+                out.append(rdaobs(A, b, obs.cone_type, None, obs.vertex))
+        if obstacle_order:
+            out.sort(key=self.rda_obs_distance)
+        return out
+
+    def rda_obs_distance(self, rda_obs):
+        if rda_obs.cone_type == "norm2":
+            return MPC.distance(self.state[0:2], rda_obs.center[0:2])
+        return float(np.min(np.linalg.norm(self.state[0:2] - rda_obs.vertex, axis=0)))
+
+    def update_ref_path(self, ref_path):
+        self.ref_path = ref_path
+        self.cur_index = 0
+        if self.enable_reverse:
+            self.curve_list = self.split_path(self.ref_path)
+            self.curve_index = 0
+
+    def update_parameter(self, **kwargs):
+        self.rda.assign_adjust_parameter(**kwargs)
+
+    def split_path(self, ref_path):
+        """split the path where the gear flag (last row) flips - mpc.py:232-249"""
+        pieces, start, flag = [], 0, ref_path[0][-1, 0]
+        for i, pt in enumerate(ref_path):
+            if pt[-1, 0] != flag:
+                pieces.append(ref_path[start:i])
+                start, flag = i, pt[-1, 0]
+        pieces.append(ref_path[start:])
+        return pieces
+
+    # ------------------------------------------------------------------ nominal rollout (mpc.py:251-291)
+    def pre_process(self, state, ref_path, cur_index, ref_speed, **kwargs):
+        _, min_index = self.closest_point(state, ref_path, cur_index, **kwargs)
+        cur_state = state
+        traj_point = ref_path[min_index]
+        ref_traj_list = [traj_point]
+        state_pre_list = [cur_state]
+        step = {"acker": lambda s, v: self.motion_predict_model_acker(s, v, self.L, self.dt),
+                "diff": lambda s, v: self.motion_predict_model_diff(s, v, self.dt),
+                "omni": lambda s, v: self.motion_predict_model_omni(s, v, self.dt)}[self.dynamics]
+        move_len = ref_speed * self.dt
+        for i in range(self.receding):
+            cur_state = step(cur_state, self.cur_vel_array[:, i:i + 1])
+            state_pre_list.append(cur_state)
+            traj_point, cur_index = self.inter_point(traj_point, ref_path, cur_index, move_len)
+            # heading of the reference is unwrapped against the predicted heading (in place, Q12)
+            traj_point[2, 0] = cur_state[2, 0] + MPC.wraptopi(traj_point[2, 0] - cur_state[2, 0])
+            ref_traj_list.append(traj_point)
+        return np.hstack(state_pre_list), ref_traj_list, min_index
+
+    def motion_predict_model_acker(self, car_state, vel, wheel_base, sample_time):
+        assert car_state.shape == (3, 1) and vel.shape == (2, 1)
+        phi, v, psi = car_state[2, 0], vel[0, 0], vel[1, 0]
+        return car_state + sample_time * np.array([[v * cos(phi)], [v * sin(phi)], [v * tan(psi) / wheel_base]])
+
+    def motion_predict_model_diff(self, robot_state, vel, sample_time):
+        assert robot_state.shape == (3, 1) and vel.shape == (2, 1)
+        phi, v, w = robot_state[2, 0], vel[0, 0], vel[1, 0]
+        return robot_state + sample_time * np.array([[v * cos(phi)], [v * sin(phi)], [w]])
+
+    def motion_predict_model_omni(self, robot_state, vel, sample_time):
+        assert robot_state.shape[0] >= 2 and vel.shape == (2, 1)
+        return robot_state + sample_time * np.array([[vel[0, 0] * cos(vel[1, 0])], [vel[0, 0] * sin(vel[1, 0])], [0]])
+
+    def closest_point(self, state, ref_path, start_ind, threshold=0.1, ind_range=10, **kwargs):
+        min_dis, min_ind = inf, start_ind
+        for i, wp in enumerate(ref_path[start_ind:start_ind + ind_range]):
+            dis = MPC.distance(state[0:2], wp[0:2])
+            if dis < min_dis:
+                min_dis, min_ind = dis, start_ind + i
+                if dis < threshold:
+                    break
+        return min_dis, min_ind
+
+    def inter_point(self, traj_point, ref_path, cur_ind, length):
+        """point at arc distance `length` ahead of traj_point along the polyline - mpc.py:355-383.
+        At the path end the LAST WAYPOINT OBJECT itself is returned (quirk Q12)."""
+        centre = np.squeeze(traj_point[0:2])
+        new_point = np.copy(traj_point)
+        while True:
+            if cur_ind + 1 > len(ref_path) - 1:
+                end_point = ref_path[-1]
+                end_point[2] = MPC.wraptopi(end_point[2])
+                return end_point, cur_ind
+            a, b = ref_path[cur_ind], ref_path[cur_ind + 1]
+            hit = self.range_cir_seg(centre, length, [np.squeeze(a[0:2]), np.squeeze(b[0:2])])
+            if hit is None:
+                cur_ind += 1
+                continue
+            half = MPC.wraptopi(b[2, 0] - a[2, 0]) / 2
+            new_point[0:2, 0] = hit
+            new_point[2, 0] = MPC.wraptopi(a[2, 0] + half)
+            return new_point, cur_ind
+
+    def range_cir_seg(self, circle, r, segment):
+        assert circle.shape == (2,) and segment[0].shape == (2,) and segment[1].shape == (2,)
+        sp, ep = segment
+        d = ep - sp
+        if np.linalg.norm(d) == 0:
+            return None
+        f = sp - circle
+        qa, qb, qc = d @ d, 2 * f @ d, f @ f - r ** 2
+        disc = qb ** 2 - 4 * qa * qc
+        if disc < 0:
+            return None
+        t2 = (-qb + sqrt(disc)) / (2 * qa)
+        if 0 <= t2 <= 1:
+            return sp + t2 * d
+        return None
+
+    @staticmethod
+    def distance(point1, point2):
+        return sqrt((point1[0, 0] - point2[0, 0]) ** 2 + (point1[1, 0] - point2[1, 0]) ** 2)
+
+    @staticmethod
+    def wraptopi(radian):
+        while radian > pi:
+            radian = radian - 2 * pi
+        while radian < -pi:
+            radian = radian + 2 * pi
+        return radian
+
+    # ------------------------------------------------------------------ geometry (mpc.py:440-549)
+    def convert_inequal_circle(self, center, radius, velocity=np.zeros((2, 1))):
+        eye = np.array([[1, 0], [0, 1], [0, 0]])
+        if np.linalg.norm(velocity) <= 0.01:
+            return eye, np.vstack((center, -radius * np.ones((1, 1))))
+        A, b = [], []
+        for t in range(self.receding + 1):
+            A.append(eye.copy())
+            b.append(np.vstack((center + velocity * (t * self.dt), -radius * np.ones((1, 1)))))
+        return A, b
+
+    def convert_inequal_polygon(self, vertex, velocity=np.zeros((2, 1))):
+        if np.linalg.norm(velocity) <= 0.01:
+            return self.gen_inequal_global(vertex)
+        A, b = [], []
+        for t in range(self.receding + 1):
+            At, bt = self.gen_inequal_global(vertex + velocity * (t * self.dt))
+            A.append(At)
+            b.append(bt)
+        return A, b
+
+    def gen_inequal_global(self, vertex):
+        """half-space form of a convex polygon, un-normalised edge normals (quirk Q11)"""
+        convex_flag, order = self.is_convex_and_ordered(vertex)
+        if not convex_flag:
+            print(f"Warning: The polygon constructed by vertex is not convex. Please check the vertex: {vertex}")
+        if order == "CW":
+            vertex = vertex[:, ::-1]
+        cur = vertex[0:2, :]
+        nxt = np.roll(cur, -1, axis=1)
+        edge = nxt - cur
+        A = np.stack((edge[1], -edge[0]), axis=1)
+        b = np.sum(A * cur.T, axis=1, keepdims=True)
+        return A, b
+
+    def cross_product(self, o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    def is_convex_and_ordered(self, points):
+        n = points.shape[1]
+        if n < 3:
+            return False, None
+        direction = 0
+        for i in range(n):
+            cross = self.cross_product(points[:, i], points[:, (i + 1) % n], points[:, (i + 2) % n])
+            if cross != 0:
+                if direction == 0:
+                    direction = 1 if cross > 0 else -1
+                elif (cross > 0) != (direction > 0):
+                    return False, None
+        return True, "CCW" if direction > 0 else "CW"
+
+    def get_adjust_parameters(self):
+        return self.rda.get_adjust_parameter()
+
+    def no_ref_path(self):
+        return len(self.ref_path) == 0
+
+    def reset(self):
+        self.cur_vel_array = np.zeros((2, self.receding))
+        self.cur_index = 0
+        self.curve_index = 0
+        self.rda.reset()

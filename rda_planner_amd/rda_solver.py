@@ -1,0 +1,200 @@
+"""
+`RDA_solver` - drop-in for RDA_planner.rda_solver.RDA_solver (reference rda_solver.py:17-61).
+
+Same constructor / method signatures and `info` keys as the reference class, but every
+per-iteration computation (su-problem, the N x T LamMuZ problems, xi/zeta/residual updates)
+runs inside `librda_hip.so` on an MI355X through the C-ABI of include/rda_hip.h.  This module
+is host glue only: argument checking, obstacle staging into dense arrays
+(assign_obstacle_parameter, reference :483-526) and packing of the `info` dict (:603-608).
+
+There is NO CPU fallback: constructing the class without the HIP library or without a GPU
+raises.  (Tests inject the CPU oracle through the private `_backend` hook to exercise the
+host logic on machines without a GPU; the product never does.)
+"""
+import time
+from math import inf  # noqa: F401  (kept for API parity with the reference module namespace)
+
+import numpy as np
+
+from ._capi import Cfg, Info, DYNAMICS, dptr, iptr, f64
+import ctypes as C
+
+CONE_CODE = {"Rpositive": 0, "norm2": 1}
+
+
+class _Backend:
+    """A loaded C-ABI library plus one solver handle."""
+
+    def __init__(self, api, cfg, G, h):
+        self.api = api
+        self.handle = C.c_void_p()
+        G = f64(G)
+        h = f64(h).ravel()
+        rc = api.create(C.byref(cfg), dptr(G), dptr(h), C.byref(self.handle))
+        if rc != 0:
+            raise RuntimeError(f"{api.prefix}_create failed with code {rc}")
+
+    def close(self):
+        if self.handle:
+            self.api.destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _hip_backend(cfg, G, h):
+    from ._lib import hip_api          # raises loudly when librda_hip.so / the GPU is missing
+    return _Backend(hip_api(), cfg, G, h)
+
+
+class RDA_solver:
+    def __init__(self, receding, car_tuple, max_edge_num=5, max_obs_num=5, iter_num=2, step_time=0.1,
+                 iter_threshold=0.2, process_num=4, accelerated=True, time_print=True, **kwargs) -> None:
+        """kwargs: slack_gain (8), max_sd (1.0), min_sd (0.1), ro1 (200), ro2 (1), ws (1), wu (1)
+        - identical meaning to the reference (rda_solver.py:24-31,196-201,218-219).
+        `process_num` is accepted for compatibility and ignored: the obstacle fan-out is the
+        GPU grid, not a process pool (reference :55-59,211-214)."""
+        self.T = receding
+        self.car_tuple = car_tuple
+        self.L = car_tuple.wheelbase
+        self.max_speed = np.c_[car_tuple.max_speed]
+        self.max_obs_num = max_obs_num
+        self.max_edge_num = max_edge_num
+        self.dynamics = car_tuple.dynamics
+        self.iter_num = iter_num
+        self.dt = step_time
+        self.acce_bound = np.c_[car_tuple.max_acce] * self.dt
+        self.iter_threshold = iter_threshold
+        self.accelerated = accelerated
+        self.process_num = process_num
+        self.time_print = time_print
+        self.ws = kwargs.get("ws", 1)
+        self.wu = kwargs.get("wu", 1)
+        self._adjust = {"slack_gain": kwargs.get("slack_gain", 8), "max_sd": kwargs.get("max_sd", 1.0),
+                        "min_sd": kwargs.get("min_sd", 0.1), "ro1": kwargs.get("ro1", 200),
+                        "ro2": kwargs.get("ro2", 1)}
+        if self.dynamics not in DYNAMICS:
+            raise ValueError(f"unknown dynamics {self.dynamics!r}")
+        if max_obs_num < 1:
+            raise ValueError("max_obs_num must be >= 1")
+
+        G = f64(car_tuple.G)
+        h = f64(car_tuple.h).ravel()
+        cfg = Cfg()
+        cfg.T, cfg.N, cfg.E, cfg.R = receding, max_obs_num, max_edge_num, G.shape[0]
+        cfg.dynamics = DYNAMICS[self.dynamics]
+        cfg.accelerated = int(bool(accelerated))
+        cfg.iter_num = iter_num
+        cfg.robot_norm2 = int(car_tuple.cone_type == "norm2")
+        cfg.dt, cfg.L = step_time, float(self.L) if self.L else 0.0
+        cfg.max_speed[0], cfg.max_speed[1] = float(self.max_speed[0, 0]), float(self.max_speed[1, 0])
+        cfg.acce_bound[0], cfg.acce_bound[1] = float(self.acce_bound[0, 0]), float(self.acce_bound[1, 0])
+        cfg.iter_threshold = iter_threshold
+        cfg.ws, cfg.wu = self.ws, self.wu
+        for k, v in self._adjust.items():
+            setattr(cfg, k, float(v))
+        cfg.delta = kwargs.get("tie_margin", 1e-6)
+        cfg.eps_u = kwargs.get("tie_control", 1e-8)
+        self._cfg = cfg
+        make = kwargs.get("_backend", _hip_backend)
+        self._be = make(cfg, G, h)
+        self._R = G.shape[0]
+
+    # ---- runtime tunables (reference :426-434, :1055-1056) ------------------------------
+    def assign_adjust_parameter(self, **kwargs):
+        for k in self._adjust:
+            self._adjust[k] = kwargs.get(k, self._adjust[k])
+        a = self._adjust
+        self._be.api.set_adjust(self._be.handle, float(a["slack_gain"]), float(a["max_sd"]),
+                                float(a["min_sd"]), float(a["ro1"]), float(a["ro2"]))
+
+    def get_adjust_parameter(self):
+        d = dict(self._adjust)
+        d["ws"], d["wu"] = self.ws, self.wu
+        return d
+
+    def reset(self):
+        """reference :1060-1068 - clears the lam'A / lam'b products only, NOT the duals (Q6)."""
+        self._be.api.reset(self._be.handle)
+
+    # ---- obstacle staging (reference assign_obstacle_parameter :483-526) ------------------
+    def _stage(self, obstacle_list):
+        n = len(obstacle_list)
+        N, E, T = self.max_obs_num, self.max_edge_num, self.T
+        if 0 < n < N:
+            # quirk Q3: the reference pads the CALLER's list in place with copies of the last entry
+            obstacle_list += [obstacle_list[-1]] * (N - n)
+            n = N
+        use = min(n, N)
+        if use == 0:
+            return 0, None, None, None, 0
+        per_t = any(isinstance(o.A, list) for o in obstacle_list[:use])
+        nt = T + 1 if per_t else 1
+        A = np.zeros((use, nt, E, 2))
+        b = np.zeros((use, nt, E))
+        cone = np.zeros(use, dtype=np.int32)
+        for i in range(use):
+            o = obstacle_list[i]
+            if isinstance(o.A, list):
+                k = np.shape(o.A[0])[0]
+                if k > E:
+                    raise ValueError(f"obstacle {i} has {k} edges > max_edge_num={E}")
+                for t in range(nt):
+                    A[i, t, :k] = o.A[t]
+                    b[i, t, :k] = np.asarray(o.b[t]).ravel()
+            else:
+                k = np.shape(o.A)[0]
+                if k > E:
+                    raise ValueError(f"obstacle {i} has {k} edges > max_edge_num={E}")
+                A[i, :, :k] = o.A
+                b[i, :, :k] = np.asarray(o.b).ravel()
+            cone[i] = 0 if o.cone_type == "Rpositive" else 1
+        return use, A, b, cone, int(per_t)
+
+    # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
+    def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list, **kwargs):
+        T = self.T
+        start = time.time()
+        ref = f64(np.hstack(ref_states)[0:3, :], (3, T + 1))
+        nom_s = f64(nom_s, (3, T + 1))
+        nom_u = f64(nom_u, (2, T))
+        n_obs, A, b, cone, per_t = self._stage(obstacle_list)
+        out_u = np.zeros((2, T))
+        out_s = np.zeros((3, T + 1))
+        info_c = Info()
+        rc = self._be.api.step(self._be.handle, dptr(nom_s), dptr(nom_u), dptr(ref), float(ref_speed),
+                               n_obs, dptr(A), dptr(b), iptr(cone), per_t, dptr(out_u), dptr(out_s),
+                               C.byref(info_c))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_step failed with code {rc}")
+        if info_c.su_status and self.time_print:
+            print("No update of state and control vector")        # reference :699
+        if self.time_print:
+            print("-----------------------------------------------")
+            print("iteration time:", time.time() - start)
+            print("==============================================")
+        opt_state_list = [out_s[:, i:i + 1].copy() for i in range(T + 1)]
+        info = {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
+                "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
+                "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
+                "su_ipm_iters": info_c.su_ipm_iters}
+        return out_u, info
+
+    # ---- state access for tests -----------------------------------------------------------
+    def get_state(self):
+        T, N, E, R = self.T, self.max_obs_num, self.max_edge_num, self._R
+        st = {"lam": np.zeros((N, T + 1, E)), "mu": np.zeros((N, T + 1, R)), "z": np.zeros((N, T)),
+              "xi": np.zeros((N, T + 1, 2)), "zeta": np.zeros((N, T)), "dis": np.zeros(T),
+              "a_lam": np.zeros((N, T + 1, 2)), "b_lam": np.zeros((N, T + 1))}
+        self._be.api.get_state(self._be.handle, *[dptr(st[k]) for k in
+                                                   ("lam", "mu", "z", "xi", "zeta", "dis", "a_lam", "b_lam")])
+        return st
+
+    def set_state(self, st):
+        arrs = [f64(st[k]) if k in st and st[k] is not None else None
+                for k in ("lam", "mu", "z", "xi", "zeta", "dis", "a_lam", "b_lam")]
+        self._be.api.set_state(self._be.handle, *[dptr(a) for a in arrs])

@@ -1,0 +1,191 @@
+"""
+Headless scenario fixtures for the BASELINE configurations.
+
+The reference's examples obtain robot geometry and obstacles from the `ir-sim` simulator
+(example/*/*.py: `env.get_robot_info()`, `env.get_obstacle_info_list()`), which is not
+available here.  This module builds the same kind of objects from plain numbers:
+
+* `car_tuple`          - namedtuple 'G h cone_type wheelbase max_speed max_acce dynamics'
+                          (reference rda_solver.py:35, example/path_track/path_track.py:10,20)
+* `Obstacle`           - object with `.center .radius .vertex .cone_type .velocity`
+                          (what mpc.py:192-203 reads)
+* seeded generators for the corridor / lidar-box / dynamic-polygon / north-star scenes and the
+  literal `path_track` scene of example/path_track/path_track*.yaml.
+
+It is host-side fixture code, not part of the accelerated path.
+"""
+from collections import namedtuple
+from math import cos, sin, tan
+
+import numpy as np
+
+car = namedtuple("car", "G h cone_type wheelbase max_speed max_acce dynamics")
+Obstacle = namedtuple("Obstacle", "center radius vertex cone_type velocity")
+
+SEED = 20250509
+
+
+def polygon_halfspaces(vertex):
+    """CCW 2xk vertices -> (A kx2, b kx1) with the reference's edge rule (mpc.py:476-510)."""
+    cur = np.asarray(vertex, float)[0:2]
+    nxt = np.roll(cur, -1, axis=1)
+    e = nxt - cur
+    A = np.stack((e[1], -e[0]), axis=1)
+    b = np.sum(A * cur.T, axis=1, keepdims=True)
+    return A, b
+
+
+def rectangle_robot(length=4.6, width=1.6, wheelbase=3.0, dynamics="acker",
+                    max_speed=(10, 1), max_acce=(10, 0.5)):
+    """Rectangle robot of the example YAMLs (e.g. example/corridor/corridor.yaml:11-16).  The body
+    frame origin is the rear axle for a car (x in [-(length-wheelbase)/2, (length+wheelbase)/2])
+    and the centre otherwise."""
+    if wheelbase:
+        x0, x1 = -(length - wheelbase) / 2, (length + wheelbase) / 2
+    else:
+        x0, x1 = -length / 2, length / 2
+    y0, y1 = -width / 2, width / 2
+    G, h = polygon_halfspaces(np.array([[x0, x1, x1, x0], [y0, y0, y1, y1]]))
+    return car(G, h, "Rpositive", wheelbase, list(max_speed), list(max_acce), dynamics)
+
+
+def robot_vertices(car_tuple, state):
+    """world-frame vertices (2xk) of a polygon robot at state (x, y, phi)"""
+    G, h = np.asarray(car_tuple.G), np.asarray(car_tuple.h).ravel()
+    k = G.shape[0]
+    V = np.zeros((2, k))
+    for i in range(k):
+        j = (i - 1) % k
+        V[:, i] = np.linalg.solve(np.vstack((G[j], G[i])), np.array([h[j], h[i]]))
+    c, s = cos(state[2]), sin(state[2])
+    return np.array([[c, -s], [s, c]]) @ V + np.asarray(state[0:2], float).reshape(2, 1)
+
+
+def box(cx, cy, length, width, yaw, velocity=(0.0, 0.0)):
+    c, s = cos(yaw), sin(yaw)
+    local = np.array([[-length / 2, length / 2, length / 2, -length / 2],
+                      [-width / 2, -width / 2, width / 2, width / 2]])
+    V = np.array([[c, -s], [s, c]]) @ local + np.array([[cx], [cy]])
+    return Obstacle(None, None, V, "Rpositive", np.array(velocity, float).reshape(2, 1))
+
+
+def circle(cx, cy, radius, velocity=(0.0, 0.0)):
+    return Obstacle(np.array([[cx], [cy]], float), float(radius), None, "norm2",
+                    np.array(velocity, float).reshape(2, 1))
+
+
+def regular_polygon(cx, cy, k, rad, yaw, velocity=(0.0, 0.0)):
+    ang = yaw + 2 * np.pi * np.arange(k) / k
+    V = np.vstack((cx + rad * np.cos(ang), cy + rad * np.sin(ang)))
+    return Obstacle(None, None, V, "Rpositive", np.array(velocity, float).reshape(2, 1))
+
+
+def line_path(start, goal, step=0.1):
+    start, goal = np.asarray(start, float), np.asarray(goal, float)
+    n = int(np.ceil(np.linalg.norm(goal[0:2] - start[0:2]) / step))
+    th = np.arctan2(goal[1] - start[1], goal[0] - start[0])
+    return [np.array([[start[0] + (goal[0] - start[0]) * i / n], [start[1] + (goal[1] - start[1]) * i / n], [th]])
+            for i in range(n + 1)]
+
+
+def path_track_ref():
+    """The (137,3,1) reference path shipped as example/path_track/path_track_ref.npy is an input
+    fixture of the reference; a copy of its numbers lives in tests/golden/path_track_ref.npy."""
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "path_track_ref.npy")
+    return [np.array(x, float) for x in np.load(p)]
+
+
+# ---------------------------------------------------------------------------------------------
+def scene_path_track():
+    """C1: literal obstacle set of example/path_track/path_track_diff.yaml:23-36 (10 circles + 1 polygon)."""
+    centres = [[20, 34], [31, 38], [10, 20], [41, 25], [20, 13], [16, 26], [10.5, 24.5], [18, 20], [16, 26], [19, 26]]
+    radii = [1.5] + [1.0] * 9
+    obs = [circle(c[0], c[1], r) for c, r in zip(centres, radii)]
+    obs.append(Obstacle(None, None, np.array([[31, 33, 33, 31], [24, 24, 28, 28.0]]), "Rpositive", np.zeros((2, 1))))
+    return obs
+
+
+def scene_corridor(n_extra=14, seed=SEED):
+    """C2: the six rectangles of example/corridor/corridor.yaml:22-33 + seeded 5x2 m boxes (~20 total)."""
+    spec = [(30, 25, 0, 70), (30, 15, 0, 70), (10, 18.5, 1.57, 5), (23, 21.5, 1.57, 5), (36, 17, 2.1, 6), (50, 22, 4.3, 5)]
+    obs = [box(x, y, ln, 2, yaw) for x, y, yaw, ln in spec]
+    rng = np.random.default_rng(seed)
+    for _ in range(n_extra):
+        obs.append(box(rng.uniform(5, 58), rng.choice([rng.uniform(27, 32), rng.uniform(8, 13)]), 5, 2, rng.uniform(-np.pi, np.pi)))
+    return obs
+
+
+def scene_boxes(n, centre_lo, centre_hi, side=(0.5, 3.0), seed=SEED, keep_clear=None, clear_radius=4.0):
+    """C3-style: n seeded 4-vertex boxes (lidar min-area rectangles)."""
+    rng = np.random.default_rng(seed)
+    obs = []
+    while len(obs) < n:
+        c = rng.uniform(centre_lo, centre_hi)
+        if keep_clear is not None and np.min(np.linalg.norm(keep_clear - c, axis=1)) < clear_radius:
+            continue
+        obs.append(box(c[0], c[1], rng.uniform(*side), rng.uniform(*side), rng.uniform(-np.pi, np.pi)))
+    return obs
+
+
+def scene_polygons(n, lo=(10, 10), hi=(40, 40), seed=SEED, moving=False, keep_clear=None, clear_radius=3.0):
+    """north-star / C4: n regular k-gons (k in {3,4}), circum-radius U[0.5,1.0]; optionally moving U[-1,1]^2 m/s."""
+    rng = np.random.default_rng(seed)
+    obs = []
+    while len(obs) < n:
+        c = rng.uniform(lo, hi)
+        k = int(rng.choice([3, 4]))
+        rad = rng.uniform(0.5, 1.0)
+        yaw = rng.uniform(-np.pi, np.pi)
+        vel = rng.uniform(-1, 1, 2) if moving else (0.0, 0.0)
+        if keep_clear is not None and np.min(np.linalg.norm(keep_clear - c, axis=1)) < clear_radius:
+            continue
+        obs.append(regular_polygon(c[0], c[1], k, rad, yaw, vel))
+    return obs
+
+
+# ---------------------------------------------------------------------------------------------
+def kinematic_step(state, u, car_tuple, dt):
+    """what ir-sim's env.step does for the three kinematics (exact Euler as in mpc.py:293-336)"""
+    x, y, phi = float(state[0, 0]), float(state[1, 0]), float(state[2, 0])
+    v, w = float(u[0, 0]), float(u[1, 0])
+    if car_tuple.dynamics == "acker":
+        d = np.array([v * cos(phi), v * sin(phi), v * tan(w) / car_tuple.wheelbase])
+    elif car_tuple.dynamics == "diff":
+        d = np.array([v * cos(phi), v * sin(phi), w])
+    else:
+        d = np.array([v * cos(w), v * sin(w), 0.0])
+    return np.array([[x], [y], [phi]]) + dt * d.reshape(3, 1)
+
+
+def _poly_sep(P, Q):
+    """separating-axis test for two convex polygons given as 2xk CCW arrays -> signed gap (>0: apart)"""
+    best = -np.inf
+    for V, W in ((P, Q), (Q, P)):
+        e = np.roll(V, -1, axis=1) - V
+        nrm = np.stack((e[1], -e[0]))
+        nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=0), 1e-300)
+        for i in range(V.shape[1]):
+            gap = np.min(nrm[:, i] @ W) - nrm[:, i] @ V[:, i]
+            best = max(best, gap)
+    return best
+
+
+def clearance(car_tuple, state, obstacles, t=0.0):
+    """conservative robot/obstacle clearance (separating-axis for polygons, vertex/edge for circles)"""
+    RV = robot_vertices(car_tuple, np.asarray(state, float).ravel())
+    out = np.inf
+    for o in obstacles:
+        if o.cone_type == "norm2":
+            c = (o.center + o.velocity * t).ravel()
+            d = np.inf
+            k = RV.shape[1]
+            for i in range(k):
+                a, b2 = RV[:, i], RV[:, (i + 1) % k]
+                ab = b2 - a
+                s = np.clip((c - a) @ ab / (ab @ ab), 0, 1)
+                d = min(d, np.linalg.norm(a + s * ab - c))
+            out = min(out, d - o.radius)
+        else:
+            out = min(out, _poly_sep(RV, o.vertex + o.velocity * t))
+    return out
