@@ -1,0 +1,123 @@
+/*
+ * rda_hip.h - C-ABI of librda_hip.so, the MI355X-native RDA ADMM inner solver.
+ *
+ * Drop-in boundary: these entry points are what a ctypes / cffi binding inside
+ * the reference's RDA_planner/rda_solver.py would call instead of CVXPY + pathos.  Plain
+ * pointers and sizes only; every array is C-contiguous float64 (int32 for cone codes); host
+ * pointers unless the name says `dev`.  The library owns all device memory and keeps no
+ * caller pointer past a call.  Return value: 0 ok, >0 soft status, <0 hard error
+ * (rda_strerror).  One HIP stream per handle; a handle is not thread-safe, distinct handles
+ * are independent; no global state.
+ *
+ * reference interface replaced                       | entry point
+ * ---------------------------------------------------+-------------------------------------
+ * RDA_solver.__init__            rda_solver.py:18-61 | rda_create
+ * assign_adjust_parameter        rda_solver.py:426   | rda_set_adjust
+ * reset                          rda_solver.py:1060  | rda_reset
+ * iterative_solve                rda_solver.py:573   | rda_step (host buffers in/out)
+ * assign_obstacle_parameter      rda_solver.py:483   | rda_upload_obstacles
+ * rda_solver loop body           rda_solver.py:612   | rda_enqueue_step (device-resident inputs)
+ * solve_parallel (pure function) rda_solver.py:743   | rda_lammuz_batch
+ * su_prob_solve                  rda_solver.py:692   | rda_su_solve
+ * para_*.value getters/setters   rda_solver.py:129   | rda_get_state / rda_set_state
+ */
+#ifndef RDA_HIP_H
+#define RDA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDA_EMAX 8     /* max_edge_num supported by the kernels */
+#define RDA_RMAX 8     /* robot half-spaces supported           */
+#define RDA_TMAX 64    /* receding horizon supported            */
+
+typedef struct rda_cfg {
+    int32_t T;            /* receding                      rda_solver.py:34  */
+    int32_t N;            /* max_obs_num                   rda_solver.py:38  */
+    int32_t E;            /* max_edge_num                  rda_solver.py:39  */
+    int32_t R;            /* car_tuple.G.shape[0]          rda_solver.py:99  */
+    int32_t dynamics;     /* 0 acker, 1 diff, 2 omni       rda_solver.py:446 */
+    int32_t accelerated;  /*                               rda_solver.py:47  */
+    int32_t iter_num;     /*                               rda_solver.py:42  */
+    int32_t robot_norm2;  /* car_tuple.cone_type=='norm2' -> RDA_ERR_UNSUPPORTED */
+    double dt, L;
+    double max_speed[2];  /* rda_solver.py:37 */
+    double acce_bound[2]; /* max_acce*dt, rda_solver.py:44 */
+    double iter_threshold;
+    double ws, wu;                                /* rda_solver.py:218-219 */
+    double slack_gain, max_sd, min_sd, ro1, ro2;  /* rda_solver.py:196-201 */
+    double delta;         /* tie-break T1 (clearance reward), 1e-6 */
+    double eps_u;         /* tie-break for an undetermined steering column, 1e-8 */
+} rda_cfg;
+
+typedef struct rda_info {
+    double resi_dual, resi_pri;   /* rda_solver.py:607-608 */
+    int32_t iters;                /* ADMM iterations executed (early stop, :594) */
+    int32_t su_status;            /* bit i: su-solve of iteration i not converged -> nominal kept (:699) */
+    int32_t su_ipm_iters;         /* interior-point iterations, summed */
+} rda_info;
+
+typedef struct rda_handle rda_handle;
+
+enum { RDA_OK = 0, RDA_ERR_ARG = -1, RDA_ERR_UNSUPPORTED = -2, RDA_ERR_HIP = -3, RDA_ERR_NODEVICE = -4 };
+
+int  rda_create(const rda_cfg *cfg, const double *G /*R*2*/, const double *h /*R*/, rda_handle **out);
+void rda_destroy(rda_handle *h);
+int  rda_set_adjust(rda_handle *h, double slack_gain, double max_sd, double min_sd, double ro1, double ro2);
+int  rda_reset(rda_handle *h);
+const char *rda_strerror(int code);
+int  rda_device_count(void);
+int  rda_set_device(int dev);     /* device used by handles created afterwards (one process per GPU) */
+
+/* One MPC step, host buffers: nom_s 3x(T+1), nom_u 2xT, ref_s 3x(T+1) row-major;
+ * obstacles A [n_obs][per_t? T+1 : 1][E][2], b [n_obs][per_t? T+1 : 1][E], cone [n_obs] (0 Rpositive, 1 norm2);
+ * n_obs < N pads by duplicating the last obstacle, n_obs > N uses the first N, n_obs == 0 skips the
+ * dual side (rda_solver.py:483-526,625).  out_u 2xT, out_s 3x(T+1). */
+int  rda_step(rda_handle *h, const double *nom_s, const double *nom_u, const double *ref_s,
+              double ref_speed, int n_obs, const double *A, const double *b, const int32_t *cone,
+              int per_t, double *out_u, double *out_s, rda_info *info);
+
+/* Device-resident pipeline (what bench.py times): obstacles and a trace of K step inputs are
+ * uploaded once; rda_enqueue_step queues the whole ADMM loop of step k on the handle's stream
+ * without any host synchronisation; results land in device slot k and are fetched afterwards. */
+int  rda_upload_obstacles(rda_handle *h, int n_obs, const double *A, const double *b, const int32_t *cone, int per_t);
+int  rda_upload_trace(rda_handle *h, int K, const double *nom_s /*K*3*(T+1)*/, const double *nom_u /*K*2*T*/,
+                      const double *ref_s /*K*3*(T+1)*/, const double *ref_speed /*K*/);
+int  rda_enqueue_step(rda_handle *h, int k);
+int  rda_sync(rda_handle *h);
+int  rda_fetch_result(rda_handle *h, int k, double *out_u, double *out_s, rda_info *info);
+/* elapsed GPU time (ms, hipEvent) of the kernels named `which` (0 = LamMuZ, 1 = su) over the
+ * steps enqueued since the last rda_timing_reset, and the number of launches */
+int  rda_timing_reset(rda_handle *h, int enable);
+int  rda_timing_read(rda_handle *h, int which, double *total_ms, int *launches);
+
+/* State in the reference's shapes: lam [N][T+1][E], mu [N][T+1][R], z [N][T], xi [N][T+1][2],
+ * zeta [N][T], dis [T], a_lam [N][T+1][2] (para_obsA_lam), b_lam [N][T+1] (para_obsb_lam).
+ * NULL pointers are skipped. */
+int  rda_get_state(rda_handle *h, double *lam, double *mu, double *z, double *xi, double *zeta,
+                   double *dis, double *a_lam, double *b_lam);
+int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const double *z,
+                   const double *xi, const double *zeta, const double *dis,
+                   const double *a_lam, const double *b_lam);
+
+/* Pure-function hooks -----------------------------------------------------------------------*/
+/* B independent (obstacle, stage) sub-problems in one launch, one per wavefront.
+ * A [B][E][2], b [B][E], cone [B], p [B][2] (nominal position, column t+1), phi [B] (nominal heading,
+ * column t), xi [B][2], zeta [B], dbar [B]; G [R][2], h [R].  Outputs lam [B][E], mu [B][R], z [B],
+ * cmh [B][4] = (cost, m, H0, H1). */
+int  rda_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int32_t *cone,
+                      const double *p, const double *phi, const double *G, const double *h,
+                      const double *xi, const double *zeta, const double *dbar, double ro2, double delta,
+                      int accelerated, double *lam, double *mu, double *z, double *cmh);
+
+/* su-problem with condensed obstacle terms a [N][T][2], cc [N][T], g [N][T][2];
+ * d0 [T] initial guess; outputs s 3x(T+1), u 2xT, d [T].  Returns 0 ok, 1 not converged. */
+int  rda_su_solve(const rda_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
+                  double ref_speed, const double *a, const double *cc, const double *g,
+                  const double *d0, double *s, double *u, double *d, int32_t *ipm_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -69,6 +69,15 @@ def trs2(Q, c, disc):
     if cn == 0.0:
         # flat model: only the hard case remains (direction of smallest curvature)
         return [v1] if not disc else []
+    if abs(c1) <= 1e-9 * cn:
+        # hard case: c is (numerically) orthogonal to the low-curvature eigenvector -> two minimisers
+        gap = l2 - l1
+        if gap > 0:
+            y2 = -c2 / gap
+            if abs(y2) < 1.0:
+                sq = np.sqrt(1.0 - y2 * y2)
+                return [y2 * v2 + sq * v1, y2 * v2 - sq * v1]
+        c1 = 0.0
     lo = max(cn - l2, abs(c1) - l1)
     if disc:
         lo = max(lo, 0.0)

@@ -44,7 +44,7 @@ struct orc_handle {
 
 /* ------------------------------------------------------------------------------------------ */
 /* 2-D trust-region sub-problem: min 1/2 x'Qx + c'x,  ||x||<=1 (disc) or ||x||==1.            */
-/* returns number of solutions written (0 or 1)                                                */
+/* returns number of solutions written to x (2 doubles each): 0, 1, or 2 in the hard case          */
 static int trs2(double q11, double q12, double q22, double c0, double c1, int disc, double *x)
 {
     double mean = 0.5 * (q11 + q22), dif = 0.5 * (q11 - q22);
@@ -65,6 +65,20 @@ static int trs2(double q11, double q12, double q22, double c0, double c1, int di
     if (cn == 0.0) {
         if (disc) return 0;
         x[0] = v1x; x[1] = v1y; return 1;
+    }
+    if (fabs(h1) <= 1e-9 * cn) {
+        /* hard case: c orthogonal to the low-curvature eigenvector -> two minimisers */
+        double gap = l2 - l1;
+        if (gap > 0) {
+            double y2 = -h2 / gap;
+            if (fabs(y2) < 1.0) {
+                double sq = sqrt(1.0 - y2 * y2);
+                x[0] = y2 * v2x + sq * v1x; x[1] = y2 * v2y + sq * v1y;
+                x[2] = y2 * v2x - sq * v1x; x[3] = y2 * v2y - sq * v1y;
+                return 2;
+            }
+        }
+        h1 = 0.0;
     }
     double lo = cn - l2, lo2 = fabs(h1) - l1;
     if (lo2 > lo) lo = lo2;
@@ -182,9 +196,9 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
         const mu_cand *mc = &mcs[im]; double chi = (double)ic;
         double lam[EMAX]; for (int i = 0; i < E; ++i) lam[i] = 0;
         double gam[2] = {0, 0}, m, H[2];
-        int have = 0;
+        int nsol = 1; double ats[4] = {0, 0, 0, 0}, ut_[2] = {0, 0}, l0_ = 0, detS_ = 1, AS_[4] = {0, 0, 0, 0};
         if (lt[il] == 0) {
-            gamma_star(&c, mc, chi, c.kappa0, c.xi, gam, &m, H); have = 1;
+            gamma_star(&c, mc, chi, c.kappa0, c.xi, gam, &m, H);
         } else if (lt[il] == 1) {
             int i = li1[il];
             double amax = 1.0 / hypot(A[2 * i], A[2 * i + 1]);
@@ -197,7 +211,7 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             if (d1 <= 0) al = amax; else if (d0 >= 0) al = 0; else al = amax * d0 / (d0 - d1);
             e[0] = al * c.M[i][0] + c.xi[0]; e[1] = al * c.M[i][1] + c.xi[1];
             gamma_star(&c, mc, chi, al * c.q[i] + c.kappa0, e, gam, &m, H);
-            lam[i] = al; have = 1;
+            lam[i] = al;
         } else {
             double ut[2], l0 = 0, AS[2][2] = {{0, 0}, {0, 0}}, detS = 1;
             int i1 = li1[il], i2 = li2[il];
@@ -210,7 +224,7 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
                 dv[0] = p[0] - vx; dv[1] = p[1] - vy;
             } else { dv[0] = p[0] - b[0]; dv[1] = p[1] - b[1]; l0 = b[2]; }
             ut[0] = cs * dv[0] + sn * dv[1]; ut[1] = -sn * dv[0] + cs * dv[1];      /* R' (p - v) */
-            double g0[2], g1[2], g2[2], e[2], at[2];
+            double g0[2], g1[2], g2[2], e[2];
             /* gradient of the reduced model at 0, e1, e2 */
             gamma_star(&c, mc, chi, l0 + c.kappa0, c.xi, gam, &m, H);
             g0[0] = (chi * m - delta) * ut[0] + ro2 * H[0]; g0[1] = (chi * m - delta) * ut[1] + ro2 * H[1];
@@ -221,19 +235,24 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             gamma_star(&c, mc, chi, ut[1] + l0 + c.kappa0, e, gam, &m, H);
             g2[0] = (chi * m - delta) * ut[0] + ro2 * H[0] - g0[0]; g2[1] = (chi * m - delta) * ut[1] + ro2 * H[1] - g0[1];
             double q12 = 0.5 * (g1[1] + g2[0]);
-            if (trs2(g1[0], q12, g2[1], g0[0], g0[1], lt[il] == 2, at)) {
-                e[0] = at[0] + c.xi[0]; e[1] = at[1] + c.xi[1];
-                gamma_star(&c, mc, chi, at[0] * ut[0] + at[1] * ut[1] + l0 + c.kappa0, e, gam, &m, H);
-                double ax = cs * at[0] - sn * at[1], ay = sn * at[0] + cs * at[1];   /* a = R at */
-                if (lt[il] == 2) {
-                    /* A_S' lamS = a */
-                    lam[i1] = (ax * AS[1][1] - AS[1][0] * ay) / detS;
-                    lam[i2] = (AS[0][0] * ay - ax * AS[0][1]) / detS;
-                } else { lam[0] = ax; lam[1] = ay; lam[2] = -hypot(ax, ay); }
-                have = 1;
-            }
+            nsol = trs2(g1[0], q12, g2[1], g0[0], g0[1], lt[il] == 2, ats);
+            ut_[0] = ut[0]; ut_[1] = ut[1]; l0_ = l0; detS_ = detS;
+            AS_[0] = AS[0][0]; AS_[1] = AS[0][1]; AS_[2] = AS[1][0]; AS_[3] = AS[1][1];
         }
-        if (!have) continue;
+        for (int sol = 0; sol < nsol; ++sol) {
+        if (lt[il] >= 2) {
+            int i1 = li1[il], i2 = li2[il];
+            double at0 = ats[2 * sol], at1 = ats[2 * sol + 1], e[2];
+            for (int i = 0; i < E; ++i) lam[i] = 0;
+            e[0] = at0 + c.xi[0]; e[1] = at1 + c.xi[1];
+            gamma_star(&c, mc, chi, at0 * ut_[0] + at1 * ut_[1] + l0_ + c.kappa0, e, gam, &m, H);
+            double ax = cs * at0 - sn * at1, ay = sn * at0 + cs * at1;   /* a = R at */
+            if (lt[il] == 2) {
+                /* A_S' lamS = a */
+                lam[i1] = (ax * AS_[3] - AS_[2] * ay) / detS_;
+                lam[i2] = (AS_[0] * ay - ax * AS_[1]) / detS_;
+            } else { lam[0] = ax; lam[1] = ay; lam[2] = -hypot(ax, ay); }
+        }
         double mu[RMAX]; for (int j = 0; j < R; ++j) mu[j] = 0;
         for (int k = 0; k < mc->k; ++k) mu[mc->j[k]] = gam[k];
         int ok = 1;
@@ -250,6 +269,7 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             best_cost = cost; best_idx = idx; best_m = mm; best_H[0] = HH[0]; best_H[1] = HH[1];
             for (int i = 0; i < E; ++i) lam_out[i] = lam[i];
             for (int j = 0; j < R; ++j) mu_out[j] = mu[j];
+        }
         }
     }
     *z_out = (accelerated ? 0.5 : 1.0) * (best_m > 0 ? best_m : 0);          /* tie-break T2 */
@@ -479,7 +499,8 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
         mu /= mc;
         for (int i = 0; i < n; ++i) if (fabs(rhs[i]) > rdn) rdn = fabs(rhs[i]);
         double sc = 1 + gn;
-        if (rdn <= 1e-11 * sc && rpn <= 1e-12 && mu <= 1e-13 * sc) { status = 0; break; }
+        if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
+        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
         /* K = H + C' diag(lm/w) C */
         memcpy(K, Hm, sizeof(double) * n * n);
         for (int i = 0; i < mc; ++i) {

@@ -1,0 +1,58 @@
+"""Loader for librda_hip.so.  Fails loudly: there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+import subprocess
+
+from ._capi import CApi, Cfg, c_double_p, c_int_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "librda_hip.so")
+_api = None
+
+
+def build(force=False):
+    """compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)"""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + \
+           [os.path.join(os.path.dirname(_HERE), "include", "rda_hip.h")]
+    stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return SO_PATH
+
+
+def load_library():
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(needs hipcc); rda_planner_amd has no CPU fallback")
+    return C.CDLL(SO_PATH)
+
+
+def hip_api():
+    global _api
+    if _api is None:
+        lib = load_library()
+        api = CApi(lib, "rda")
+        lib.rda_device_count.restype = C.c_int
+        lib.rda_set_device.argtypes = [C.c_int]
+        lib.rda_set_device.restype = C.c_int
+        lib.rda_strerror.restype = C.c_char_p
+        lib.rda_strerror.argtypes = [C.c_int]
+        lib.rda_upload_obstacles.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int_p, C.c_int]
+        lib.rda_upload_trace.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+        lib.rda_enqueue_step.argtypes = [C.c_void_p, C.c_int]
+        lib.rda_sync.argtypes = [C.c_void_p]
+        lib.rda_fetch_result.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, C.c_void_p]
+        lib.rda_timing_reset.argtypes = [C.c_void_p, C.c_int]
+        lib.rda_timing_read.argtypes = [C.c_void_p, C.c_int, c_double_p, c_int_p]
+        lib.rda_lammuz_batch.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p,
+                                         c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double,
+                                         C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+        lib.rda_su_solve.argtypes = [C.POINTER(Cfg)] + [c_double_p] * 3 + [C.c_double] + [c_double_p] * 7 + [c_int_p]
+        for name in ("upload_obstacles", "upload_trace", "enqueue_step", "sync", "fetch_result", "timing_reset",
+                     "timing_read", "lammuz_batch", "su_solve"):
+            getattr(lib, "rda_" + name).restype = C.c_int
+        if lib.rda_device_count() < 1:
+            raise RuntimeError("librda_hip.so loaded but no HIP device is visible; rda_planner_amd has no CPU fallback")
+        _api = api
+    return _api

@@ -1,0 +1,309 @@
+// K1 device code: one LamMuZ sub-problem (obstacle n, stage t) per 64-lane wavefront.
+//
+// Problem solved (reference rda_solver.py:389-421, 874-909, 1034-1050):
+//     min  1/2 neg(m)^2 - delta*m + 1/2 ro2 ||H||^2,   m = lam'q - mu'h + (zeta - d),  H = M'lam + G'mu + xi
+//     s.t. lam in K_obs, mu >= 0, ||A'lam|| <= 1,       q = A p - b,  M = A R(phi)
+// Because the cost is strictly decreasing in m, optimal (lam, mu) are LP-optimal for their own
+// a = A'lam and g = G'mu, so a basic optimal solution has <= 2 non-zero lam_i and <= 2 non-zero
+// mu_j ("closest features").  The wavefront ENUMERATES all (lam-support, mu-support, hinge-state)
+// candidates, one per lane per pass, solves each tiny piecewise-quadratic problem in closed form
+// (a 2-D trust-region secular equation when the separating direction is free), evaluates the TRUE
+// cost of every sign-feasible candidate and takes the wave-wide arg-min (ties: lowest candidate
+// id).  No iteration over the problem, no divergence across sub-problems, no global scratch:
+// the obstacle half-spaces and the derived q, M live in the wave's LDS slab.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace lmz {
+
+constexpr int EMAX = 8;
+constexpr int RMAX = 8;
+constexpr double SIGN_TOL = 1e-12;
+
+struct WaveLDS {            // one slab per wave (stage-local obstacle data)
+    double A[EMAX][2];
+    double b[EMAX];
+    double q[EMAX];
+    double M[EMAX][2];
+};
+struct RobotLDS {           // one per block
+    double G[RMAX][2];
+    double h[RMAX];
+};
+
+struct Sol {
+    double cost; int id;
+    double m, H0, H1;
+    int i1, i2, j1, j2;     // supports (-1 = unused)
+    double l1, l2, g1, g2;  // lam / mu values on the supports
+};
+
+struct MuCand { int k; int j0, j1; double gx, gy, eta; double P00, P01, P10, P11, det, r0, r1, rr; };
+
+__device__ __forceinline__ void gamma_star(const MuCand &mc, double chi, double ro2, double delta,
+                                           double t, double e0, double e1,
+                                           double &ga0, double &ga1, double &m, double &H0, double &H1)
+{
+    if (mc.k == 0) { m = t; H0 = e0; H1 = e1; ga0 = 0; ga1 = 0; return; }
+    if (mc.k == 1) {
+        double den = chi * mc.eta * mc.eta + ro2 * (mc.gx * mc.gx + mc.gy * mc.gy);
+        double ga = (chi * mc.eta * t - delta * mc.eta - ro2 * (mc.gx * e0 + mc.gy * e1)) / den;
+        ga0 = ga; ga1 = 0; m = t - mc.eta * ga; H0 = e0 + ga * mc.gx; H1 = e1 + ga * mc.gy;
+        return;
+    }
+    double re = mc.r0 * e0 + mc.r1 * e1;
+    double beta = (delta - chi * (t + re)) / (chi * mc.rr + ro2);
+    H0 = -beta * mc.r0; H1 = -beta * mc.r1;
+    double d0 = H0 - e0, d1 = H1 - e1;
+    ga0 = (mc.P11 * d0 - mc.P01 * d1) / mc.det;
+    ga1 = (-mc.P10 * d0 + mc.P00 * d1) / mc.det;
+    m = t + re + beta * mc.rr;
+}
+
+// 2-D trust-region sub-problem  min 1/2 x'Qx + c'x,  ||x||<=1 (disc) or ||x||==1.
+// Returns the number of minimisers written (0, 1, or 2 in the hard case).
+__device__ __forceinline__ int trs2(double q11, double q12, double q22, double c0, double c1, bool disc,
+                                    double &x0, double &x1, double &x2, double &x3)
+{
+    double mean = 0.5 * (q11 + q22), dif = 0.5 * (q11 - q22);
+    double rad = hypot(dif, q12);
+    double l1 = mean - rad, l2 = mean + rad;
+    double v2x, v2y;
+    if (dif >= 0) { v2x = dif + rad; v2y = q12; } else { v2x = q12; v2y = rad - dif; }
+    double nv = hypot(v2x, v2y);
+    if (nv > 0) { v2x /= nv; v2y /= nv; } else { v2x = 1; v2y = 0; }
+    double v1x = -v2y, v1y = v2x;
+    double h1 = v1x * c0 + v1y * c1, h2 = v2x * c0 + v2y * c1;
+    double cn = hypot(h1, h2);
+    double scale = fabs(l2) > 1e-300 ? fabs(l2) : 1e-300;
+    if (disc && l1 > 1e-13 * scale) {
+        double y1 = -h1 / l1, y2 = -h2 / l2;
+        if (y1 * y1 + y2 * y2 <= 1.0) { x0 = y1 * v1x + y2 * v2x; x1 = y1 * v1y + y2 * v2y; return 1; }
+    }
+    if (cn == 0.0) {
+        if (disc) return 0;
+        x0 = v1x; x1 = v1y; return 1;
+    }
+    if (fabs(h1) <= 1e-9 * cn) {
+        // hard case: c orthogonal to the low-curvature eigenvector -> two minimisers
+        double gap = l2 - l1;
+        if (gap > 0) {
+            double y2 = -h2 / gap;
+            if (fabs(y2) < 1.0) {
+                double sq = sqrt(1.0 - y2 * y2);
+                x0 = y2 * v2x + sq * v1x; x1 = y2 * v2y + sq * v1y;
+                x2 = y2 * v2x - sq * v1x; x3 = y2 * v2y - sq * v1y;
+                return 2;
+            }
+        }
+        h1 = 0.0;
+    }
+    double lo = cn - l2, lo2 = fabs(h1) - l1;
+    if (lo2 > lo) lo = lo2;
+    if (disc && lo < 0) lo = 0;
+    double tau = lo;
+    for (int it = 0; it < 40; ++it) {
+        double s1 = l1 + tau, s2 = l2 + tau;
+        if (s1 <= 0 || s2 <= 0) { tau = (-l1 > -l2 ? -l1 : -l2) + 1e-300; s1 = l1 + tau; s2 = l2 + tau; }
+        double a1 = h1 != 0 ? h1 / s1 : 0.0, a2 = h2 != 0 ? h2 / s2 : 0.0;
+        double phi = a1 * a1 + a2 * a2;
+        if (!(phi > 0)) break;
+        double dphi = -2.0 * (a1 * a1 / s1 + a2 * a2 / s2);
+        double sq = sqrt(phi);
+        double g = 1.0 / sq - 1.0, dg = -0.5 * dphi / (phi * sq);
+        double step = g / dg;
+        tau -= step;
+        if (fabs(step) <= 1e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
+    }
+    double s1 = l1 + tau, s2 = l2 + tau;
+    double y1 = h1 != 0 ? -h1 / s1 : 0.0, y2 = h2 != 0 ? -h2 / s2 : 0.0;
+    double xx = y1 * v1x + y2 * v2x, xy = y1 * v1y + y2 * v2y;
+    double nx = hypot(xx, xy);
+    if (nx > 0) { xx /= nx; xy /= nx; }
+    x0 = xx; x1 = xy;
+    return 1;
+}
+
+// decode the k-th pair (lexicographic i1<i2) of {0..n-1}
+__device__ __forceinline__ void decode_pair(int k, int n, int &i1, int &i2)
+{
+    i1 = 0;
+    int rowlen = n - 1;
+    while (k >= rowlen) { k -= rowlen; ++i1; --rowlen; }
+    i2 = i1 + 1 + k;
+}
+
+struct Params { int E, R; int norm2; double px, py, cs, sn, xi0, xi1, kappa0, ro2, delta; };
+
+// sign feasibility, clamping and TRUE cost of one candidate point
+__device__ __forceinline__ bool finish(const WaveLDS &W, const RobotLDS &Rb, const Params &P, const MuCand &mc, int type,
+                                       int i1, int i2, double la1, double la2, double ga0, double ga1, Sol &s)
+{
+    if (!P.norm2) {
+        if (la1 < -SIGN_TOL || la2 < -SIGN_TOL) return false;
+        if (la1 < 0) la1 = 0;
+        if (la2 < 0) la2 = 0;
+    }
+    if (ga0 < -SIGN_TOL || ga1 < -SIGN_TOL) return false;
+    if (ga0 < 0) ga0 = 0;
+    if (ga1 < 0) ga1 = 0;
+    double mm = P.kappa0, HH0 = P.xi0, HH1 = P.xi1;
+    if (type == 3) {
+        double l3 = -hypot(la1, la2);
+        mm += la1 * W.q[0] + la2 * W.q[1] + l3 * W.q[2];
+        HH0 += la1 * W.M[0][0] + la2 * W.M[1][0] + l3 * W.M[2][0];
+        HH1 += la1 * W.M[0][1] + la2 * W.M[1][1] + l3 * W.M[2][1];
+    } else {
+        if (i1 >= 0) { mm += la1 * W.q[i1]; HH0 += la1 * W.M[i1][0]; HH1 += la1 * W.M[i1][1]; }
+        if (i2 >= 0) { mm += la2 * W.q[i2]; HH0 += la2 * W.M[i2][0]; HH1 += la2 * W.M[i2][1]; }
+    }
+    if (mc.k >= 1) { mm -= ga0 * Rb.h[mc.j0]; HH0 += ga0 * Rb.G[mc.j0][0]; HH1 += ga0 * Rb.G[mc.j0][1]; }
+    if (mc.k == 2) { mm -= ga1 * Rb.h[mc.j1]; HH0 += ga1 * Rb.G[mc.j1][0]; HH1 += ga1 * Rb.G[mc.j1][1]; }
+    double ng = mm < 0 ? mm : 0;
+    s.cost = 0.5 * ng * ng - P.delta * mm + 0.5 * P.ro2 * (HH0 * HH0 + HH1 * HH1);
+    s.m = mm; s.H0 = HH0; s.H1 = HH1;
+    s.i1 = i1; s.i2 = i2; s.l1 = la1; s.l2 = la2;
+    s.j1 = mc.j0; s.j2 = mc.j1; s.g1 = ga0; s.g2 = ga1;
+    s.id = 0;
+    return true;
+}
+
+// Evaluate candidate (il, im, ic); returns false when the candidate does not exist / is infeasible.
+__device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS &Rb, const Params &P,
+                                               int il, int im, int ic, Sol &s)
+{
+    const double chi = (double)ic, ro2 = P.ro2, delta = P.delta;
+    // ---- mu candidate ----------------------------------------------------------------------
+    MuCand mc; mc.k = 0; mc.j0 = mc.j1 = -1;
+    if (im >= 1 && im <= P.R) {
+        mc.k = 1; mc.j0 = im - 1; mc.gx = Rb.G[mc.j0][0]; mc.gy = Rb.G[mc.j0][1]; mc.eta = Rb.h[mc.j0];
+        if (!(mc.gx * mc.gx + mc.gy * mc.gy > 0)) return false;
+    } else if (im > P.R) {
+        mc.k = 2; decode_pair(im - 1 - P.R, P.R, mc.j0, mc.j1);
+        double a0 = Rb.G[mc.j0][0], a1 = Rb.G[mc.j0][1], b0 = Rb.G[mc.j1][0], b1 = Rb.G[mc.j1][1];
+        double det = a0 * b1 - a1 * b0;
+        if (det == 0 || !(fabs(det) > 1e-12 * hypot(a0, a1) * hypot(b0, b1))) return false;
+        mc.P00 = a0; mc.P01 = b0; mc.P10 = a1; mc.P11 = b1; mc.det = det;
+        double h0 = Rb.h[mc.j0], h1 = Rb.h[mc.j1];
+        mc.r0 = (h0 * b1 - a1 * h1) / det; mc.r1 = (a0 * h1 - h0 * b0) / det;
+        mc.rr = mc.r0 * mc.r0 + mc.r1 * mc.r1;
+    }
+    // ---- lam candidate ---------------------------------------------------------------------
+    int i1 = -1, i2 = -1; double la1 = 0, la2 = 0;
+    double ga0 = 0, ga1 = 0, m, H0, H1;
+    int type;                                   // 0 L0, 1 L1, 2 L2, 3 LC
+    if (il == 0) type = 0;
+    else if (P.norm2) type = 3;
+    else if (il <= P.E) { type = 1; i1 = il - 1; }
+    else { type = 2; decode_pair(il - 1 - P.E, P.E, i1, i2); }
+
+    if (type == 0) {
+        gamma_star(mc, chi, ro2, delta, P.kappa0, P.xi0, P.xi1, ga0, ga1, m, H0, H1);
+    } else if (type == 1) {
+        double ax = W.A[i1][0], ay = W.A[i1][1];
+        double n2 = ax * ax + ay * ay;
+        if (!(n2 > 0)) return false;
+        double amax = 1.0 / hypot(ax, ay);
+        double qi = W.q[i1], m0 = W.M[i1][0], m1 = W.M[i1][1];
+        gamma_star(mc, chi, ro2, delta, P.kappa0, P.xi0, P.xi1, ga0, ga1, m, H0, H1);
+        double d0 = (chi * m - delta) * qi + ro2 * (m0 * H0 + m1 * H1);
+        gamma_star(mc, chi, ro2, delta, amax * qi + P.kappa0, amax * m0 + P.xi0, amax * m1 + P.xi1, ga0, ga1, m, H0, H1);
+        double d1 = (chi * m - delta) * qi + ro2 * (m0 * H0 + m1 * H1);
+        double al;
+        if (d1 <= 0) al = amax; else if (d0 >= 0) al = 0; else al = amax * d0 / (d0 - d1);
+        gamma_star(mc, chi, ro2, delta, al * qi + P.kappa0, al * m0 + P.xi0, al * m1 + P.xi1, ga0, ga1, m, H0, H1);
+        la1 = al;
+    } else {
+        double dvx, dvy, l0 = 0, a00 = 0, a01 = 0, a10 = 0, a11 = 0, detS = 1;
+        if (type == 2) {
+            a00 = W.A[i1][0]; a01 = W.A[i1][1]; a10 = W.A[i2][0]; a11 = W.A[i2][1];
+            detS = a00 * a11 - a01 * a10;
+            if (detS == 0 || !(fabs(detS) > 1e-12 * hypot(a00, a01) * hypot(a10, a11))) return false;
+            double vx = (W.b[i1] * a11 - a01 * W.b[i2]) / detS;
+            double vy = (a00 * W.b[i2] - W.b[i1] * a10) / detS;
+            dvx = P.px - vx; dvy = P.py - vy;
+        } else { dvx = P.px - W.b[0]; dvy = P.py - W.b[1]; l0 = W.b[2]; i1 = 0; i2 = 1; }
+        double ut0 = P.cs * dvx + P.sn * dvy, ut1 = -P.sn * dvx + P.cs * dvy;       // R'(p - v)
+        double g00, g01, g10, g11, g20, g21;
+        gamma_star(mc, chi, ro2, delta, l0 + P.kappa0, P.xi0, P.xi1, ga0, ga1, m, H0, H1);
+        g00 = (chi * m - delta) * ut0 + ro2 * H0; g01 = (chi * m - delta) * ut1 + ro2 * H1;
+        gamma_star(mc, chi, ro2, delta, ut0 + l0 + P.kappa0, 1 + P.xi0, P.xi1, ga0, ga1, m, H0, H1);
+        g10 = (chi * m - delta) * ut0 + ro2 * H0 - g00; g11 = (chi * m - delta) * ut1 + ro2 * H1 - g01;
+        gamma_star(mc, chi, ro2, delta, ut1 + l0 + P.kappa0, P.xi0, 1 + P.xi1, ga0, ga1, m, H0, H1);
+        g20 = (chi * m - delta) * ut0 + ro2 * H0 - g00; g21 = (chi * m - delta) * ut1 + ro2 * H1 - g01;
+        double ats[4] = {0, 0, 0, 0};
+        int nsol = trs2(g10, 0.5 * (g11 + g20), g21, g00, g01, type == 2, ats[0], ats[1], ats[2], ats[3]);
+        bool any = false;
+        for (int sol = 0; sol < nsol; ++sol) {
+            double at0 = ats[2 * sol], at1 = ats[2 * sol + 1];
+            gamma_star(mc, chi, ro2, delta, at0 * ut0 + at1 * ut1 + l0 + P.kappa0, at0 + P.xi0, at1 + P.xi1, ga0, ga1, m, H0, H1);
+            double ax = P.cs * at0 - P.sn * at1, ay = P.sn * at0 + P.cs * at1;          // a = R at
+            if (type == 2) {
+                la1 = (ax * a11 - a10 * ay) / detS;
+                la2 = (a00 * ay - ax * a01) / detS;
+            } else { la1 = ax; la2 = ay; }
+            Sol c2;
+            if (finish(W, Rb, P, mc, type, i1, i2, la1, la2, ga0, ga1, c2) && (!any || c2.cost < s.cost)) { s = c2; any = true; }
+        }
+        return any;
+    }
+    return finish(W, Rb, P, mc, type, i1, i2, la1, la2, ga0, ga1, s);
+}
+
+// Whole-wave solve.  All 64 lanes must call; W.A/W.b and Rb must be filled and visible.  On return
+// every lane holds the winning solution in `best`.
+__device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, Sol &best)
+{
+    // q = A p - b ; M = A R  (lanes < E)
+    if (lane < P.E) {
+        double ax = W.A[lane][0], ay = W.A[lane][1];
+        W.q[lane] = ax * P.px + ay * P.py - W.b[lane];
+        W.M[lane][0] = ax * P.cs + ay * P.sn;
+        W.M[lane][1] = -ax * P.sn + ay * P.cs;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nl = P.norm2 ? 2 : 1 + P.E + P.E * (P.E - 1) / 2;
+    const int nm = 1 + P.R + P.R * (P.R - 1) / 2;
+    const int total = nl * nm * 2;
+    best.cost = INFINITY; best.id = 0x7fffffff;
+    best.m = 0; best.H0 = 0; best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
+    best.l1 = best.l2 = best.g1 = best.g2 = 0;
+    for (int c = lane; c < total; c += 64) {
+        int ic = c & 1, rest = c >> 1;
+        int im = rest % nm, il = rest / nm;
+        Sol s;
+        if (eval_candidate(W, Rb, P, il, im, ic, s)) {
+            s.id = c;
+            if (s.cost < best.cost) best = s;          // ids increase per lane: '<' keeps the lowest id
+        }
+    }
+    // wave arg-min on (cost, id)
+    double bc = best.cost; int bid = best.id;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double oc = __shfl_xor(bc, off, 64); int oid = __shfl_xor(bid, off, 64);
+        if (oc < bc || (oc == bc && oid < bid)) { bc = oc; bid = oid; }
+    }
+    unsigned long long win = __ballot(best.id == bid);
+    int src = __ffsll((long long)win) - 1;
+    best.cost = __shfl(best.cost, src, 64); best.id = bid;
+    best.m = __shfl(best.m, src, 64); best.H0 = __shfl(best.H0, src, 64); best.H1 = __shfl(best.H1, src, 64);
+    best.i1 = __shfl(best.i1, src, 64); best.i2 = __shfl(best.i2, src, 64);
+    best.j1 = __shfl(best.j1, src, 64); best.j2 = __shfl(best.j2, src, 64);
+    best.l1 = __shfl(best.l1, src, 64); best.l2 = __shfl(best.l2, src, 64);
+    best.g1 = __shfl(best.g1, src, 64); best.g2 = __shfl(best.g2, src, 64);
+}
+
+// value of lam[e] / mu[j] encoded by a solution
+__device__ __forceinline__ double lam_of(const Sol &s, int norm2, int e)
+{
+    if (norm2) {
+        if (s.i1 < 0) return 0.0;
+        return e == 0 ? s.l1 : (e == 1 ? s.l2 : (e == 2 ? -hypot(s.l1, s.l2) : 0.0));
+    }
+    return e == s.i1 ? s.l1 : (e == s.i2 ? s.l2 : 0.0);
+}
+__device__ __forceinline__ double mu_of(const Sol &s, int j) { return j == s.j1 ? s.g1 : (j == s.j2 ? s.g2 : 0.0); }
+
+}  // namespace lmz

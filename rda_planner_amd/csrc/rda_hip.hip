@@ -1,0 +1,639 @@
+// librda_hip.so - MI355X (gfx950) implementation of the C-ABI in include/rda_hip.h.
+//
+// Per ADMM iteration two launches on the handle's stream, no host synchronisation in between:
+//   k_su      <<<1, 256>>>      su-problem (interior point + Riccati), relinearisation point update,
+//                               residual reduction / early-stop flag of the previous iteration
+//   k_lammuz  <<<N*T/4, 256>>>  one (obstacle, stage) LamMuZ sub-problem per wavefront, fused with
+//                               the lam'A / lam'b products, the xi / zeta updates and the residual
+//                               partials (reference rda_solver.py:529-542, 639-690, 781-793)
+// All solver state (duals, products, nominal trajectory, staged obstacles) stays resident in HBM
+// between iterations and between MPC steps, exactly like the reference keeps it in CVXPY Parameter
+// values (quirks Q4-Q6 come for free).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/rda_hip.h"
+#include "lammuz_device.h"
+#include "su_device.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "librda_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return RDA_ERR_HIP; } } while (0)
+
+struct Ctrl {
+    int stop, iters, su_status, ipm_iters, st_tmp, it_tmp;
+    double resi_dual, resi_pri;
+};
+
+struct Dev {
+    rda_cfg c;
+    int nt;                  // time slots of the staged obstacles (T+1 or 1)
+    int obstacle_num;        // 0 or N
+    double *G, *h;
+    double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
+    double *lam, *mu, *z, *xi, *zeta, *dis;   // reference-shaped dual state
+    double *ax, *ay, *blam, *ee, *gx, *gy;    // [T][N] condensed terms for the su-problem
+    double *s, *u;                            // nominal (para_s, para_u)
+    double *ref, *ref_speed;                  // current step reference (device)
+    double *res;                              // [N*T][2] residual partials
+    Ctrl *ctrl;
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ void reduce_residuals(const Dev &d, double *red, int tid)
+{
+    const int T = d.c.T, N = d.c.N;
+    double rd = 0, rp = 0;
+    if (d.obstacle_num != 0)
+        for (int i = tid; i < N * T; i += su::NT) { rd += d.res[2 * i]; rp += d.res[2 * i + 1]; }
+    rd = su::block_reduce(rd, red, tid, false);
+    rp = su::block_reduce(rp, red, tid, false);
+    if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); }
+    __syncthreads();
+}
+
+extern __shared__ __attribute__((aligned(16))) double smem_su[];
+
+__global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u)
+{
+    const int tid = threadIdx.x;
+    if (d.ctrl->stop) return;
+    if (it > 0) {
+        reduce_residuals(d, smem_su, tid);
+        if (d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold) {   // rda_solver.py:594
+            __syncthreads();
+            if (tid == 0) d.ctrl->stop = 1;
+            return;
+        }
+    }
+    su::Args a;
+    a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
+    a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
+    a.c.ab0 = d.c.acce_bound[0]; a.c.ab1 = d.c.acce_bound[1]; a.c.ws = d.c.ws; a.c.wu = d.c.wu;
+    a.c.slack_gain = d.c.slack_gain; a.c.max_sd = d.c.max_sd; a.c.min_sd = d.c.min_sd; a.c.ro1 = d.c.ro1; a.c.ro2 = d.c.ro2;
+    a.c.eps_u = d.c.eps_u;
+    a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
+    a.ref = d.ref; a.ref_speed = d.ref_speed;
+    a.ax = d.ax; a.ay = d.ay; a.blam = d.blam; a.ee = d.ee; a.gx = d.gx; a.gy = d.gy;
+    a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp;
+    su::solve(a, smem_su);
+    __syncthreads();
+    if (tid == 0) {
+        d.ctrl->iters = it + 1;
+        if (d.ctrl->st_tmp != 0) d.ctrl->su_status |= 1 << it;
+        d.ctrl->ipm_iters += d.ctrl->it_tmp;
+    }
+}
+
+// final bookkeeping of a step: residuals of the last executed iteration, result slot
+__global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double *out_s, rda_info *info)
+{
+    const int tid = threadIdx.x;
+    if (!d.ctrl->stop) reduce_residuals(d, smem_su, tid);
+    __syncthreads();
+    const int T = d.c.T;
+    for (int i = tid; i < 2 * T; i += su::NT) out_u[i] = d.u[i];
+    for (int i = tid; i < 3 * (T + 1); i += su::NT) out_s[i] = d.s[i];
+    if (tid == 0) {
+        info->resi_dual = d.ctrl->resi_dual; info->resi_pri = d.ctrl->resi_pri;
+        info->iters = d.ctrl->iters; info->su_status = d.ctrl->su_status; info->su_ipm_iters = d.ctrl->ipm_iters;
+    }
+}
+
+__global__ void k_begin(Dev d)
+{
+    if (threadIdx.x == 0) {
+        d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0;
+        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one wavefront per (obstacle n, stage t); 4 wavefronts per workgroup.
+__global__ __launch_bounds__(256) void k_lammuz(Dev d)
+{
+    __shared__ lmz::WaveLDS wl[4];
+    __shared__ lmz::RobotLDS rb;
+    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    if (d.ctrl->stop) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (d.obstacle_num == 0) {
+        // quirk Q9 (rda_solver.py:564-568): only slot N-1 loses its lam'A / lam'b products
+        if (blockIdx.x == 0) for (int t = threadIdx.x; t < T; t += 256) { int i = t * N + (N - 1); d.ax[i] = 0; d.ay[i] = 0; d.blam[i] = 0; }
+        return;
+    }
+    if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = d.G[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = d.h[threadIdx.x - 64];
+    const int w = blockIdx.x * 4 + wv;
+    const bool live = w < N * T;
+    const int n = live ? w / T : 0, t = live ? w % T : 0;
+    lmz::WaveLDS &W = wl[wv];
+    const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
+    if (lane < 2 * E) W.A[lane >> 1][lane & 1] = d.A[ao * 2 + lane];
+    if (lane < E) W.b[lane] = d.b[ao + lane];
+    __syncthreads();
+    if (!live) return;
+    lmz::Params P;
+    P.E = E; P.R = R; P.norm2 = d.cone[n];
+    P.px = d.s[t + 1]; P.py = d.s[(T + 1) + t + 1];
+    const double phi = d.s[2 * (T + 1) + t];                  // heading of column t (quirk Q1)
+    P.cs = cos(phi); P.sn = sin(phi);
+    const size_t o = (size_t)n * (T + 1) + t + 1;
+    P.xi0 = d.xi[2 * o]; P.xi1 = d.xi[2 * o + 1];
+    const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
+    P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
+    lmz::Sol best;
+    lmz::solve_wave(W, rb, P, lane, best);
+    // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
+    const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
+    double res = 0;
+    if (lane < E) {
+        double v = lmz::lam_of(best, P.norm2, lane), old = d.lam[o * E + lane];
+        res = (v - old) * (v - old); d.lam[o * E + lane] = v;
+    } else if (lane < E + R) {
+        int j = lane - E;
+        double v = lmz::mu_of(best, j), old = d.mu[o * R + j];
+        res = (v - old) * (v - old); d.mu[o * R + j] = v;
+    } else if (lane == E + R) {
+        double old = d.z[n * T + t];
+        res = (znew - old) * (znew - old); d.z[n * T + t] = znew;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
+    if (lane == 0) {
+        double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
+        for (int i = 0; i < E; ++i) {
+            double v = lmz::lam_of(best, P.norm2, i);
+            ax += v * W.A[i][0]; ay += v * W.A[i][1]; bl += v * W.b[i];
+        }
+        for (int j = 0; j < R; ++j) {
+            double v = lmz::mu_of(best, j);
+            mh += v * rb.h[j]; gx += v * rb.G[j][0]; gy += v * rb.G[j][1];
+        }
+        const double hx = gx + P.cs * ax + P.sn * ay, hy = gy - P.sn * ax + P.cs * ay;      // Hm, :682
+        const double xin0 = P.xi0 + hx, xin1 = P.xi1 + hy;                                  // :683
+        d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
+        const double im = ax * P.px + ay * P.py - bl - mh;                                  // :659
+        const double zetan = zeta + im - dbar - znew;                                       // :666
+        d.zeta[n * T + t] = zetan;
+        const int k = t * N + n;
+        d.ax[k] = ax; d.ay[k] = ay; d.blam[k] = bl;                                         // :541-542
+        d.ee[k] = mh + znew - zetan; d.gx[k] = gx + xin0; d.gy[k] = gy + xin1;
+        d.res[2 * (n * T + t)] = res; d.res[2 * (n * T + t) + 1] = hx * hx + hy * hy;
+    }
+}
+
+// pure-function batch hook (rda_lammuz_batch)
+__global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int *cone,
+                                                      const double *p, const double *phi, const double *G, const double *h,
+                                                      const double *xi, const double *zeta, const double *dbar, double ro2,
+                                                      double delta, int accelerated, double *lam, double *mu, double *z, double *cmh)
+{
+    __shared__ lmz::WaveLDS wl[4];
+    __shared__ lmz::RobotLDS rb;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = G[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = h[threadIdx.x - 64];
+    const int w = blockIdx.x * 4 + wv;
+    const bool live = w < B;
+    const int k = live ? w : 0;
+    lmz::WaveLDS &W = wl[wv];
+    if (lane < 2 * E) W.A[lane >> 1][lane & 1] = A[(size_t)k * E * 2 + lane];
+    if (lane < E) W.b[lane] = b[(size_t)k * E + lane];
+    __syncthreads();
+    if (!live) return;
+    lmz::Params P;
+    P.E = E; P.R = R; P.norm2 = cone[k]; P.px = p[2 * k]; P.py = p[2 * k + 1];
+    P.cs = cos(phi[k]); P.sn = sin(phi[k]); P.xi0 = xi[2 * k]; P.xi1 = xi[2 * k + 1];
+    P.kappa0 = zeta[k] - dbar[k]; P.ro2 = ro2; P.delta = delta;
+    lmz::Sol best;
+    lmz::solve_wave(W, rb, P, lane, best);
+    if (lane < E) lam[(size_t)k * E + lane] = lmz::lam_of(best, P.norm2, lane);
+    else if (lane < E + R) mu[(size_t)k * R + lane - E] = lmz::mu_of(best, lane - E);
+    else if (lane == E + R) {
+        z[k] = (accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);
+        cmh[4 * k] = best.cost; cmh[4 * k + 1] = best.m; cmh[4 * k + 2] = best.H0; cmh[4 * k + 3] = best.H1;
+    }
+}
+
+// standalone su-solve hook
+__global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a) { su::solve(a, smem_su); }
+
+// [N][T+1][2] / [N][T+1] <-> [T][N] transposes for the state accessors
+__global__ void k_products_get(Dev d, double *a_lam, double *b_lam)
+{
+    const int T = d.c.T, N = d.c.N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * (T + 1); i += gridDim.x * blockDim.x) {
+        int n = i / (T + 1), tt = i % (T + 1);
+        double ax = 0, ay = 0, bl = 0;
+        if (tt >= 1) { int k = (tt - 1) * N + n; ax = d.ax[k]; ay = d.ay[k]; bl = d.blam[k]; }
+        a_lam[2 * i] = ax; a_lam[2 * i + 1] = ay; b_lam[i] = bl;
+    }
+}
+// rebuild every condensed term from the reference-shaped state (after rda_set_state)
+__global__ void k_products_set(Dev d, const double *a_lam, const double *b_lam)
+{
+    const int T = d.c.T, N = d.c.N, R = d.c.R;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) {
+        int n = i / T, t = i % T, k = t * N + n;
+        size_t o = (size_t)n * (T + 1) + t + 1;
+        if (a_lam) { d.ax[k] = a_lam[2 * o]; d.ay[k] = a_lam[2 * o + 1]; }
+        if (b_lam) d.blam[k] = b_lam[o];
+        double mh = 0, gx = 0, gy = 0;
+        for (int j = 0; j < R; ++j) { double v = d.mu[o * R + j]; mh += v * d.h[j]; gx += v * d.G[2 * j]; gy += v * d.G[2 * j + 1]; }
+        d.ee[k] = mh + d.z[n * T + t] - d.zeta[n * T + t];
+        d.gx[k] = gx + d.xi[2 * o]; d.gy[k] = gy + d.xi[2 * o + 1];
+    }
+}
+__global__ void k_reset(Dev d)
+{
+    const int T = d.c.T, N = d.c.N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) { d.ax[i] = 0; d.ay[i] = 0; d.blam[i] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct rda_handle {
+    Dev d;
+    hipStream_t stream;
+    size_t su_lds;
+    // staging
+    double *h_stage_A, *h_stage_b; int *h_stage_cone;    // pinned, N slots
+    double *h_step;                                       // pinned: nom_s | nom_u | ref | speed
+    double *d_step;                                       // device copy of the above (slot 0 of the step path)
+    double *d_out_u, *d_out_s; rda_info *d_info;          // result slot of the step path
+    double *h_out; rda_info *h_info;                      // pinned
+    // trace path
+    int K; double *d_tr_s, *d_tr_u, *d_tr_ref, *d_tr_speed, *d_tr_out_u, *d_tr_out_s; rda_info *d_tr_info;
+    // timing
+    int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
+};
+
+static void dev_free(void *p) { if (p) (void)hipFree(p); }
+
+extern "C" const char *rda_strerror(int code)
+{
+    switch (code) {
+        case RDA_OK: return "ok";
+        case RDA_ERR_ARG: return "invalid argument";
+        case RDA_ERR_UNSUPPORTED: return "unsupported configuration (norm2 robot, E/R/T above the compiled limits, non-canonical circle)";
+        case RDA_ERR_HIP: return "HIP runtime error";
+        case RDA_ERR_NODEVICE: return "no HIP device";
+        default: return code > 0 ? "soft status" : "unknown error";
+    }
+}
+extern "C" int rda_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int rda_set_device(int dev) { HIPCHK(hipSetDevice(dev)); return RDA_OK; }
+
+template <typename Tp> static int dalloc(Tp **p, size_t n)
+{
+    HIPCHK(hipMalloc((void **)p, n * sizeof(Tp)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(Tp)));
+    return 0;
+}
+
+extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out)
+{
+    if (!cfg || !G || !h || !out) return RDA_ERR_ARG;
+    if (cfg->robot_norm2) return RDA_ERR_UNSUPPORTED;
+    if (cfg->E < 1 || cfg->E > RDA_EMAX || cfg->R < 1 || cfg->R > RDA_RMAX || cfg->T < 1 || cfg->T > RDA_TMAX || cfg->N < 1) return RDA_ERR_UNSUPPORTED;
+    if (cfg->E + cfg->R + 1 > 64) return RDA_ERR_UNSUPPORTED;
+    if (rda_device_count() < 1) return RDA_ERR_NODEVICE;
+    rda_handle *H = new rda_handle();
+    memset(&H->d, 0, sizeof(Dev));
+    H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0; H->ev_used[0] = H->ev_used[1] = 0;
+    H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
+    const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
+    HIPCHK(hipStreamCreate(&H->stream));
+    Dev &d = H->d;
+    int rc = 0;
+    rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
+    rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
+    rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
+    rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
+    rc |= dalloc(&d.ax, N * T); rc |= dalloc(&d.ay, N * T); rc |= dalloc(&d.blam, N * T);
+    rc |= dalloc(&d.ee, N * T); rc |= dalloc(&d.gx, N * T); rc |= dalloc(&d.gy, N * T);
+    rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
+    rc |= dalloc(&d.res, 2 * N * T); rc |= dalloc(&d.ctrl, 1);
+    const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
+    rc |= dalloc(&H->d_step, step_n); rc |= dalloc(&H->d_out_u, 2 * T); rc |= dalloc(&H->d_out_s, 3 * (T + 1)); rc |= dalloc(&H->d_info, 1);
+    if (rc) { rda_destroy(H); return RDA_ERR_HIP; }
+    HIPCHK(hipMemcpy(d.G, G, 2 * R * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.h, h, R * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> ones(T, 1.0);                                       // para_dis init, rda_solver.py:119
+    HIPCHK(hipMemcpy(d.dis, ones.data(), T * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int> cn(N, 1);                                              // para_cone init, rda_solver.py:158
+    HIPCHK(hipMemcpy(d.cone, cn.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipHostMalloc((void **)&H->h_stage_A, N * (T + 1) * E * 2 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&H->h_stage_b, N * (T + 1) * E * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&H->h_stage_cone, N * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&H->h_step, step_n * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&H->h_out, (2 * T + 3 * (T + 1)) * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&H->h_info, sizeof(rda_info)));
+    H->su_lds = su::lds_bytes((int)T);
+    HIPCHK(hipFuncSetAttribute((const void *)k_su, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_su_hook, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
+    *out = H;
+    return RDA_OK;
+}
+
+extern "C" void rda_destroy(rda_handle *H)
+{
+    if (!H) return;
+    (void)hipStreamSynchronize(H->stream);
+    Dev &d = H->d;
+    void *ptrs[] = { d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.ax, d.ay, d.blam, d.ee, d.gx, d.gy,
+                     d.s, d.u, d.res, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
+                     H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info };
+    for (void *p : ptrs) dev_free(p);
+    if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
+    if (H->h_stage_b) (void)hipHostFree(H->h_stage_b);
+    if (H->h_stage_cone) (void)hipHostFree(H->h_stage_cone);
+    if (H->h_step) (void)hipHostFree(H->h_step);
+    if (H->h_out) (void)hipHostFree(H->h_out);
+    if (H->h_info) (void)hipHostFree(H->h_info);
+    for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(H->stream);
+    delete H;
+}
+
+extern "C" int rda_set_adjust(rda_handle *H, double slack_gain, double max_sd, double min_sd, double ro1, double ro2)
+{
+    if (!H) return RDA_ERR_ARG;
+    H->d.c.slack_gain = slack_gain; H->d.c.max_sd = max_sd; H->d.c.min_sd = min_sd; H->d.c.ro1 = ro1; H->d.c.ro2 = ro2;
+    return RDA_OK;
+}
+
+extern "C" int rda_reset(rda_handle *H)
+{
+    if (!H) return RDA_ERR_ARG;
+    hipLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, H->stream, H->d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(H->stream));
+    return RDA_OK;
+}
+
+// assign_obstacle_parameter (rda_solver.py:483-526): pad / truncate into N slots, then upload
+extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, const double *b, const int32_t *cone, int per_t)
+{
+    if (!H) return RDA_ERR_ARG;
+    Dev &d = H->d;
+    const size_t T = d.c.T, N = d.c.N, E = d.c.E;
+    if (n_obs <= 0) { d.obstacle_num = 0; return RDA_OK; }       // nothing written: stale A, b stay
+    if (!A || !b || !cone) return RDA_ERR_ARG;
+    const size_t nt = per_t ? T + 1 : 1;
+    for (size_t n = 0; n < N; ++n) {
+        size_t src = n < (size_t)n_obs ? n : (size_t)n_obs - 1;   // quirk Q3: duplicate the last obstacle
+        memcpy(&H->h_stage_A[n * nt * E * 2], &A[src * nt * E * 2], nt * E * 2 * sizeof(double));
+        memcpy(&H->h_stage_b[n * nt * E], &b[src * nt * E], nt * E * sizeof(double));
+        H->h_stage_cone[n] = cone[src];
+        if (cone[src] == 1) {         // canonical circle only (mpc.py:440-458)
+            for (size_t t = 0; t < nt; ++t) {
+                const double *At = &H->h_stage_A[(n * nt + t) * E * 2];
+                if (E < 3 || At[0] != 1 || At[1] != 0 || At[2] != 0 || At[3] != 1 || At[4] != 0 || At[5] != 0) return RDA_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d.A, H->h_stage_A, N * nt * E * 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(d.b, H->h_stage_b, N * nt * E * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(d.cone, H->h_stage_cone, N * sizeof(int), hipMemcpyHostToDevice, H->stream));
+    d.nt = (int)nt; d.obstacle_num = (int)N;
+    HIPCHK(hipStreamSynchronize(H->stream));      // staging buffers are reused by the next call
+    return RDA_OK;
+}
+
+static hipEvent_t next_event(rda_handle *H, int which)
+{
+    if (H->ev_used[which] == H->ev[which].size()) { hipEvent_t e; (void)hipEventCreate(&e); H->ev[which].push_back(e); }
+    return H->ev[which][H->ev_used[which]++];
+}
+
+// queue the whole ADMM loop of one MPC step (rda_solver.py:588-596) - no host synchronisation
+static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
+                        double *out_u, double *out_s, rda_info *info)
+{
+    Dev d = H->d;
+    d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
+    const int T = d.c.T, N = d.c.N;
+    const int blocks = (N * T + 3) / 4;
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, d);
+    for (int it = 0; it < d.c.iter_num; ++it) {
+        if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
+        hipLaunchKernelGGL(k_su, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u);
+        if (H->timing) { (void)hipEventRecord(next_event(H, 1), H->stream); (void)hipEventRecord(next_event(H, 0), H->stream); }
+        hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
+        if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, out_u, out_s, info);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+
+extern "C" int rda_step(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s,
+                        double ref_speed, int n_obs, const double *A, const double *b, const int32_t *cone,
+                        int per_t, double *out_u, double *out_s, rda_info *info)
+{
+    if (!H || !nom_s || !nom_u || !ref_s || !out_u || !out_s) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T;
+    int rc = rda_upload_obstacles(H, n_obs, A, b, cone, per_t);
+    if (rc != RDA_OK) return rc;
+    const size_t ns = 3 * (T + 1), nu = 2 * T;
+    memcpy(H->h_step, nom_s, ns * sizeof(double));
+    memcpy(H->h_step + ns, nom_u, nu * sizeof(double));
+    memcpy(H->h_step + ns + nu, ref_s, ns * sizeof(double));
+    H->h_step[ns + nu + ns] = ref_speed;
+    HIPCHK(hipMemcpyAsync(H->d_step, H->h_step, (2 * ns + nu + 1) * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
+    if (rc != RDA_OK) return rc;
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    memcpy(out_u, H->h_out, nu * sizeof(double));
+    memcpy(out_s, H->h_out + nu, ns * sizeof(double));
+    if (info) *info = *H->h_info;
+    return RDA_OK;
+}
+
+extern "C" int rda_upload_trace(rda_handle *H, int K, const double *nom_s, const double *nom_u, const double *ref_s, const double *ref_speed)
+{
+    if (!H || K < 1 || !nom_s || !nom_u || !ref_s || !ref_speed) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    dev_free(H->d_tr_s); dev_free(H->d_tr_u); dev_free(H->d_tr_ref); dev_free(H->d_tr_speed);
+    dev_free(H->d_tr_out_u); dev_free(H->d_tr_out_s); dev_free(H->d_tr_info);
+    int rc = 0;
+    rc |= dalloc(&H->d_tr_s, K * ns); rc |= dalloc(&H->d_tr_u, K * nu); rc |= dalloc(&H->d_tr_ref, K * ns); rc |= dalloc(&H->d_tr_speed, (size_t)K);
+    rc |= dalloc(&H->d_tr_out_u, K * nu); rc |= dalloc(&H->d_tr_out_s, K * ns); rc |= dalloc(&H->d_tr_info, (size_t)K);
+    if (rc) return RDA_ERR_HIP;
+    HIPCHK(hipMemcpy(H->d_tr_s, nom_s, K * ns * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(H->d_tr_u, nom_u, K * nu * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(H->d_tr_ref, ref_s, K * ns * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(H->d_tr_speed, ref_speed, K * sizeof(double), hipMemcpyHostToDevice));
+    H->K = K;
+    return RDA_OK;
+}
+
+extern "C" int rda_enqueue_step(rda_handle *H, int k)
+{
+    if (!H || k < 0 || k >= H->K) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    return enqueue_admm(H, H->d_tr_s + k * ns, H->d_tr_u + k * nu, H->d_tr_ref + k * ns, H->d_tr_speed + k,
+                        H->d_tr_out_u + k * nu, H->d_tr_out_s + k * ns, H->d_tr_info + k);
+}
+
+extern "C" int rda_sync(rda_handle *H) { if (!H) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(H->stream)); return RDA_OK; }
+
+extern "C" int rda_fetch_result(rda_handle *H, int k, double *out_u, double *out_s, rda_info *info)
+{
+    if (!H || k < 0 || k >= H->K) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (out_u) HIPCHK(hipMemcpy(out_u, H->d_tr_out_u + k * nu, nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_s) HIPCHK(hipMemcpy(out_s, H->d_tr_out_s + k * ns, ns * sizeof(double), hipMemcpyDeviceToHost));
+    if (info) HIPCHK(hipMemcpy(info, H->d_tr_info + k, sizeof(rda_info), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
+
+extern "C" int rda_timing_reset(rda_handle *H, int enable)
+{
+    if (!H) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    H->timing = enable; H->ev_used[0] = H->ev_used[1] = 0;
+    return RDA_OK;
+}
+extern "C" int rda_timing_read(rda_handle *H, int which, double *total_ms, int *launches)
+{
+    if (!H || which < 0 || which > 1) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    double tot = 0; int n = 0;
+    for (size_t i = 0; i + 1 < H->ev_used[which]; i += 2) {
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev[which][i], H->ev[which][i + 1]));
+        tot += ms; ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return RDA_OK;
+}
+
+extern "C" int rda_get_state(rda_handle *H, double *lam, double *mu, double *z, double *xi, double *zeta,
+                             double *dis, double *a_lam, double *b_lam)
+{
+    if (!H) return RDA_ERR_ARG;
+    Dev &d = H->d; const size_t T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (lam) HIPCHK(hipMemcpy(lam, d.lam, N * (T + 1) * E * sizeof(double), hipMemcpyDeviceToHost));
+    if (mu) HIPCHK(hipMemcpy(mu, d.mu, N * (T + 1) * R * sizeof(double), hipMemcpyDeviceToHost));
+    if (z) HIPCHK(hipMemcpy(z, d.z, N * T * sizeof(double), hipMemcpyDeviceToHost));
+    if (xi) HIPCHK(hipMemcpy(xi, d.xi, N * (T + 1) * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    if (zeta) HIPCHK(hipMemcpy(zeta, d.zeta, N * T * sizeof(double), hipMemcpyDeviceToHost));
+    if (dis) HIPCHK(hipMemcpy(dis, d.dis, T * sizeof(double), hipMemcpyDeviceToHost));
+    if (a_lam || b_lam) {
+        double *ta = nullptr, *tb = nullptr;
+        if (dalloc(&ta, N * (T + 1) * 2) || dalloc(&tb, N * (T + 1))) return RDA_ERR_HIP;
+        hipLaunchKernelGGL(k_products_get, dim3(64), dim3(256), 0, H->stream, d, ta, tb);
+        HIPCHK(hipStreamSynchronize(H->stream));
+        if (a_lam) HIPCHK(hipMemcpy(a_lam, ta, N * (T + 1) * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        if (b_lam) HIPCHK(hipMemcpy(b_lam, tb, N * (T + 1) * sizeof(double), hipMemcpyDeviceToHost));
+        dev_free(ta); dev_free(tb);
+    }
+    return RDA_OK;
+}
+
+extern "C" int rda_set_state(rda_handle *H, const double *lam, const double *mu, const double *z,
+                             const double *xi, const double *zeta, const double *dis,
+                             const double *a_lam, const double *b_lam)
+{
+    if (!H) return RDA_ERR_ARG;
+    Dev &d = H->d; const size_t T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (lam) HIPCHK(hipMemcpy(d.lam, lam, N * (T + 1) * E * sizeof(double), hipMemcpyHostToDevice));
+    if (mu) HIPCHK(hipMemcpy(d.mu, mu, N * (T + 1) * R * sizeof(double), hipMemcpyHostToDevice));
+    if (z) HIPCHK(hipMemcpy(d.z, z, N * T * sizeof(double), hipMemcpyHostToDevice));
+    if (xi) HIPCHK(hipMemcpy(d.xi, xi, N * (T + 1) * 2 * sizeof(double), hipMemcpyHostToDevice));
+    if (zeta) HIPCHK(hipMemcpy(d.zeta, zeta, N * T * sizeof(double), hipMemcpyHostToDevice));
+    if (dis) HIPCHK(hipMemcpy(d.dis, dis, T * sizeof(double), hipMemcpyHostToDevice));
+    double *ta = nullptr, *tb = nullptr;
+    if (a_lam) { if (dalloc(&ta, N * (T + 1) * 2)) return RDA_ERR_HIP; HIPCHK(hipMemcpy(ta, a_lam, N * (T + 1) * 2 * sizeof(double), hipMemcpyHostToDevice)); }
+    if (b_lam) { if (dalloc(&tb, N * (T + 1))) return RDA_ERR_HIP; HIPCHK(hipMemcpy(tb, b_lam, N * (T + 1) * sizeof(double), hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_products_set, dim3(64), dim3(256), 0, H->stream, d, ta, tb);
+    HIPCHK(hipStreamSynchronize(H->stream));
+    dev_free(ta); dev_free(tb);
+    return RDA_OK;
+}
+
+// ---- pure-function hooks ------------------------------------------------------------------------
+extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int32_t *cone,
+                                const double *p, const double *phi, const double *G, const double *h,
+                                const double *xi, const double *zeta, const double *dbar, double ro2, double delta,
+                                int accelerated, double *lam, double *mu, double *z, double *cmh)
+{
+    if (B < 1 || E < 1 || E > RDA_EMAX || R < 1 || R > RDA_RMAX || E + R + 1 > 64) return RDA_ERR_UNSUPPORTED;
+    if (rda_device_count() < 1) return RDA_ERR_NODEVICE;
+    double *dA, *db, *dp, *dphi, *dG, *dh, *dxi, *dzeta, *ddbar, *dlam, *dmu, *dz, *dcmh; int *dcone;
+    struct Cp { void **dst; const void *src; size_t bytes; };
+    const size_t sB = (size_t)B;
+    Cp ins[] = { {(void **)&dA, A, sB * E * 2 * 8}, {(void **)&db, b, sB * E * 8}, {(void **)&dcone, cone, sB * 4}, {(void **)&dp, p, sB * 2 * 8},
+                 {(void **)&dphi, phi, sB * 8}, {(void **)&dG, G, (size_t)R * 2 * 8}, {(void **)&dh, h, (size_t)R * 8}, {(void **)&dxi, xi, sB * 2 * 8},
+                 {(void **)&dzeta, zeta, sB * 8}, {(void **)&ddbar, dbar, sB * 8} };
+    for (auto &c : ins) { HIPCHK(hipMalloc(c.dst, c.bytes)); HIPCHK(hipMemcpy(*c.dst, c.src, c.bytes, hipMemcpyHostToDevice)); }
+    HIPCHK(hipMalloc((void **)&dlam, sB * E * 8)); HIPCHK(hipMalloc((void **)&dmu, sB * R * 8)); HIPCHK(hipMalloc((void **)&dz, sB * 8)); HIPCHK(hipMalloc((void **)&dcmh, sB * 4 * 8));
+    hipLaunchKernelGGL(k_lammuz_batch, dim3((B + 3) / 4), dim3(256), 0, 0, B, E, R, dA, db, dcone, dp, dphi, dG, dh, dxi, dzeta, ddbar,
+                       ro2, delta, accelerated, dlam, dmu, dz, dcmh);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(lam, dlam, sB * E * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(mu, dmu, sB * R * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(z, dz, sB * 8, hipMemcpyDeviceToHost));
+    if (cmh) HIPCHK(hipMemcpy(cmh, dcmh, sB * 4 * 8, hipMemcpyDeviceToHost));
+    for (auto &c : ins) dev_free(*c.dst);
+    dev_free(dlam); dev_free(dmu); dev_free(dz); dev_free(dcmh);
+    return RDA_OK;
+}
+
+extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
+                            double ref_speed, const double *a, const double *cc, const double *g,
+                            const double *d0, double *s, double *u, double *dd, int32_t *ipm_iters)
+{
+    if (!cfg || cfg->T < 1 || cfg->T > RDA_TMAX || cfg->N < 1) return RDA_ERR_UNSUPPORTED;
+    if (rda_device_count() < 1) return RDA_ERR_NODEVICE;
+    const size_t T = cfg->T, N = cfg->N, ns = 3 * (T + 1), nu = 2 * T;
+    std::vector<double> soa(6 * T * N, 0.0);
+    for (size_t n = 0; n < N; ++n) for (size_t t = 0; t < T; ++t) {
+        size_t k = t * N + n;
+        soa[0 * T * N + k] = a[(n * T + t) * 2]; soa[1 * T * N + k] = a[(n * T + t) * 2 + 1];
+        soa[2 * T * N + k] = cc[n * T + t];
+        soa[4 * T * N + k] = g[(n * T + t) * 2]; soa[5 * T * N + k] = g[(n * T + t) * 2 + 1];
+    }
+    double *dsoa, *dns, *dnu, *dref, *dspeed, *dd0, *dos, *dou, *dod; int *dst;
+    HIPCHK(hipMalloc((void **)&dsoa, soa.size() * 8)); HIPCHK(hipMemcpy(dsoa, soa.data(), soa.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&dns, ns * 8)); HIPCHK(hipMemcpy(dns, nom_s, ns * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&dnu, nu * 8)); HIPCHK(hipMemcpy(dnu, nom_u, nu * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&dref, ns * 8)); HIPCHK(hipMemcpy(dref, ref_s, ns * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&dspeed, 8)); HIPCHK(hipMemcpy(dspeed, &ref_speed, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&dd0, T * 8));
+    if (d0) HIPCHK(hipMemcpy(dd0, d0, T * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&dos, ns * 8)); HIPCHK(hipMalloc((void **)&dou, nu * 8)); HIPCHK(hipMalloc((void **)&dod, T * 8));
+    HIPCHK(hipMalloc((void **)&dst, 2 * sizeof(int)));
+    su::Args ar;
+    ar.c.T = cfg->T; ar.c.N = cfg->N; ar.c.dynamics = cfg->dynamics; ar.c.accelerated = cfg->accelerated;
+    ar.c.dt = cfg->dt; ar.c.L = cfg->L; ar.c.umax0 = cfg->max_speed[0]; ar.c.umax1 = cfg->max_speed[1];
+    ar.c.ab0 = cfg->acce_bound[0]; ar.c.ab1 = cfg->acce_bound[1]; ar.c.ws = cfg->ws; ar.c.wu = cfg->wu;
+    ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
+    ar.c.eps_u = cfg->eps_u;
+    ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
+    ar.ax = dsoa; ar.ay = dsoa + T * N; ar.blam = dsoa + 2 * T * N; ar.ee = dsoa + 3 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
+    ar.d_in = d0 ? dd0 : nullptr; ar.out_s = dos; ar.out_u = dou; ar.out_d = dod; ar.status = dst; ar.ipm_iters = dst + 1;
+    const size_t lds = su::lds_bytes((int)T);
+    HIPCHK(hipFuncSetAttribute((const void *)k_su_hook, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_su_hook, dim3(1), dim3(su::NT), lds, 0, ar);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    int st[2];
+    HIPCHK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s, dos, ns * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(u, dou, nu * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(dd, dod, T * 8, hipMemcpyDeviceToHost));
+    if (ipm_iters) *ipm_iters = st[1];
+    void *fr[] = { dsoa, dns, dnu, dref, dspeed, dd0, dos, dou, dod, dst };
+    for (void *p : fr) dev_free(p);
+    return st[0] == 0 ? 0 : 1;
+}

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """CPU oracle C-ABI (test infrastructure)"""
+    from oracle.oracle_backend import api
+    return api()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """HIP library C-ABI; fails (not skips) when the extension or the GPU is missing"""
+    from rda_planner_amd._lib import hip_api
+    return hip_api()

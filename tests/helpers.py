@@ -1,0 +1,132 @@
+"""shared generators / thin wrappers for the tests"""
+import ctypes as C
+
+import numpy as np
+
+from rda_planner_amd import scenarios as sc
+from rda_planner_amd._capi import Cfg, dptr, iptr
+
+ROBOT = sc.rectangle_robot()
+G = np.ascontiguousarray(ROBOT.G, float)
+H = np.ascontiguousarray(np.asarray(ROBOT.h, float).ravel())
+
+
+def make_cfg(T=10, N=5, E=4, R=4, dynamics=0, accelerated=1, iter_num=2, ro1=200.0, ro2=1.0, ws=1.0, wu=1.0,
+             slack_gain=8.0, max_sd=1.0, min_sd=0.1, iter_threshold=0.2, dt=0.1, L=3.0):
+    c = Cfg()
+    c.T, c.N, c.E, c.R = T, N, E, R
+    c.dynamics, c.accelerated, c.iter_num, c.robot_norm2 = dynamics, accelerated, iter_num, 0
+    c.dt, c.L = dt, L
+    c.max_speed[0], c.max_speed[1] = 10.0, 1.0
+    c.acce_bound[0], c.acce_bound[1] = 1.0, 0.05
+    c.iter_threshold, c.ws, c.wu = iter_threshold, ws, wu
+    c.slack_gain, c.max_sd, c.min_sd, c.ro1, c.ro2 = slack_gain, max_sd, min_sd, ro1, ro2
+    c.delta, c.eps_u = 1e-6, 1e-8
+    return c
+
+
+def random_polygon(rng, centre, k, rad, E):
+    ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+    ang = ang + np.linspace(0, 0.3, k)          # keep it non-degenerate
+    V = np.vstack((centre[0] + rad * np.cos(ang), centre[1] + rad * np.sin(ang)))
+    A, b = sc.polygon_halfspaces(V)
+    Ap = np.zeros((E, 2))
+    bp = np.zeros(E)
+    Ap[:k] = A
+    bp[:k] = b.ravel()
+    return Ap, bp
+
+
+def lammuz_batch_inputs(rng, B, E=4, circles=0.25, near=True):
+    """B random (obstacle, stage) sub-problems around random robot poses"""
+    A = np.zeros((B, E, 2))
+    b = np.zeros((B, E))
+    cone = np.zeros(B, np.int32)
+    p = rng.uniform(-5, 5, (B, 2))
+    phi = rng.uniform(-np.pi, np.pi, B)
+    xi = np.zeros((B, 2))
+    zeta = np.zeros(B)
+    dbar = rng.uniform(0.1, 1.0, B)
+    for i in range(B):
+        dist = rng.choice([0.5, 1.5, 3.0, 6.0, 15.0] if near else [6.0, 15.0, 30.0])
+        th = rng.uniform(0, 2 * np.pi)
+        cen = p[i] + dist * np.array([np.cos(th), np.sin(th)])
+        if rng.random() < circles and E >= 3:
+            A[i, 0] = [1, 0]
+            A[i, 1] = [0, 1]
+            b[i, 0:3] = [cen[0], cen[1], -rng.uniform(0.3, 1.5)]
+            cone[i] = 1
+        else:
+            k = int(rng.integers(3, E + 1))
+            A[i], b[i] = random_polygon(rng, cen, k, rng.uniform(0.5, 2.0), E)
+        xi[i] = rng.normal(0, rng.choice([0, 0.05, 0.5]), 2)
+        zeta[i] = rng.normal(0, rng.choice([0, 0.3, 2.0]))
+    return dict(A=A, b=b, cone=cone, p=p, phi=phi, xi=xi, zeta=zeta, dbar=dbar)
+
+
+def oracle_lammuz_batch(orc, inp, ro2=1.0, delta=1e-6, accelerated=1, G=G, h=H):
+    B, E = inp["b"].shape
+    R = G.shape[0]
+    lam = np.zeros((B, E))
+    mu = np.zeros((B, R))
+    z = np.zeros(B)
+    cmh = np.zeros((B, 4))
+    for i in range(B):
+        zz = C.c_double(0)
+        orc.lib.orc_lammuz_one(E, R, dptr(np.ascontiguousarray(inp["A"][i])), dptr(np.ascontiguousarray(inp["b"][i])),
+                               int(inp["cone"][i]), dptr(np.ascontiguousarray(inp["p"][i])), float(inp["phi"][i]),
+                               dptr(G), dptr(h), dptr(np.ascontiguousarray(inp["xi"][i])), float(inp["zeta"][i]),
+                               float(inp["dbar"][i]), ro2, delta, accelerated, dptr(lam[i]), dptr(mu[i]),
+                               C.cast(C.byref(zz), C.POINTER(C.c_double)), dptr(cmh[i]))
+        z[i] = zz.value
+    return lam, mu, z, cmh
+
+
+def hip_lammuz_batch(hip, inp, ro2=1.0, delta=1e-6, accelerated=1, G=G, h=H):
+    B, E = inp["b"].shape
+    R = G.shape[0]
+    lam = np.zeros((B, E))
+    mu = np.zeros((B, R))
+    z = np.zeros(B)
+    cmh = np.zeros((B, 4))
+    arr = {k: np.ascontiguousarray(v) for k, v in inp.items()}
+    rc = hip.lib.rda_lammuz_batch(B, E, R, dptr(arr["A"]), dptr(arr["b"]), iptr(arr["cone"]), dptr(arr["p"]), dptr(arr["phi"]),
+                                  dptr(G), dptr(h), dptr(arr["xi"]), dptr(arr["zeta"]), dptr(arr["dbar"]), ro2, delta,
+                                  accelerated, dptr(lam), dptr(mu), dptr(z), dptr(cmh))
+    assert rc == 0, rc
+    return lam, mu, z, cmh
+
+
+def su_inputs(rng, cfg):
+    """random su-problem around a rolled-out nominal, with some hinges active"""
+    T, N, dyn = cfg.T, cfg.N, cfg.dynamics
+    nom_u = np.vstack([rng.uniform(1, 4, T), rng.uniform(-0.3, 0.3, T)])
+    nom_s = np.zeros((3, T + 1))
+    nom_s[:, 0] = [rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-3, 3)]
+    for t in range(T):
+        phi, v, psi = nom_s[2, t], nom_u[0, t], nom_u[1, t]
+        if dyn == 0:
+            ds = np.array([v * np.cos(phi), v * np.sin(phi), v * np.tan(psi) / cfg.L])
+        elif dyn == 1:
+            ds = np.array([v * np.cos(phi), v * np.sin(phi), psi])
+        else:
+            ds = np.array([v * np.cos(psi), v * np.sin(psi), 0.0])
+        nom_s[:, t + 1] = nom_s[:, t] + cfg.dt * ds
+    ref = nom_s + rng.normal(0, 0.3, (3, T + 1))
+    a = rng.normal(0, 0.5, (N, T, 2))
+    a /= np.maximum(1, np.linalg.norm(a, axis=2, keepdims=True))
+    cc = np.einsum("ntk,kt->nt", a, nom_s[0:2, 1:]) - rng.uniform(-0.5, 1.5, (N, T))
+    g = rng.normal(0, 0.3, (N, T, 2))
+    return dict(nom_s=np.ascontiguousarray(nom_s), nom_u=np.ascontiguousarray(nom_u), ref=np.ascontiguousarray(ref),
+                vref=4.0, a=np.ascontiguousarray(a), cc=np.ascontiguousarray(cc), g=np.ascontiguousarray(g), d0=np.ones(T))
+
+
+def su_solve(fn, cfg, inp):
+    T = cfg.T
+    s = np.zeros((3, T + 1))
+    u = np.zeros((2, T))
+    d = np.zeros(T)
+    it = C.c_int(0)
+    st = fn(C.byref(cfg), dptr(inp["nom_s"]), dptr(inp["nom_u"]), dptr(inp["ref"]), inp["vref"], dptr(inp["a"]),
+            dptr(inp["cc"]), dptr(inp["g"]), dptr(inp["d0"]), dptr(s), dptr(u), dptr(d), C.byref(it))
+    return st, s, u, d, it.value
