@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""
+bench.py - MPC steps/s of the MI355X-native RDA ADMM inner solver (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one RDA_solver.iterative_solve (reference rda_solver.py:573-610): up to iter_num
+ADMM iterations with early stop.  Workload (north-star point of BASELINE.json / SURVEY.md 8d):
+Ackermann rectangle robot, T=20, N_obs=200 static polygons, E=4, synthetic seeded scene.
+
+Protocol: a closed-loop run (solver in the loop, kinematic robot model) records the inputs of
+W+K consecutive MPC steps; obstacles and that trace are then uploaded once, the solver state is
+reset, W steps are replayed untimed and EXACTLY K steps are enqueued back-to-back on the device
+(no host synchronisation inside or between steps) between two barriers + device synchronisation.
+`value` is therefore the device-resident rate; the host-synchronous closed-loop rate (H2D of the
+nominal, D2H of the control every step) is reported next to it as `closed_loop_steps_per_s`.
+
+N > 1: one process per GPU, independent ego replicas (BASELINE config "batched multi-ego":
+scenario batch sharded, no data-path collective) - weak scaling, value = sum over ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_workload(seed_offset=0, n_obs=200, T=20):
+    from rda_planner_amd import scenarios as sc
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 25, 0], [46, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(42, 40), seed=sc.SEED + seed_offset, keep_clear=clear, clear_radius=3.2)
+    kw = dict(receding=T, iter_num=4, max_edge_num=4, max_obs_num=n_obs, ro1=200, obstacle_order=True)
+    return car_t, path, obstacles, kw
+
+
+def record_trace(car_t, path, obstacles, kw, n_steps, backend=None):
+    """closed loop with the solver in the loop; returns per-step inputs and the staged obstacle arrays"""
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd import scenarios as sc
+    extra = {"_backend": backend} if backend is not None else {}
+    mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw, **extra)
+    T = kw["receding"]
+    state = path[0].copy().reshape(3, 1)
+    tr = {"nom_s": [], "nom_u": [], "ref": [], "speed": [], "u": []}
+    orig = mpc.rda.iterative_solve
+    staged = {}
+
+    def spy(nom_s, nom_u, ref_states, ref_speed, obstacle_list, **k):
+        tr["nom_s"].append(np.array(nom_s, float).reshape(3, T + 1))
+        tr["nom_u"].append(np.array(nom_u, float).reshape(2, T))
+        tr["ref"].append(np.array(np.hstack(ref_states)[0:3, :], float))
+        tr["speed"].append(float(ref_speed))
+        if not staged:
+            n, A, b, cone, per_t = mpc.rda._stage(list(obstacle_list))
+            staged.update(n=n, A=A, b=b, cone=cone, per_t=per_t)
+        return orig(nom_s, nom_u, ref_states, ref_speed, obstacle_list, **k)
+
+    mpc.rda.iterative_solve = spy
+    t0 = time.perf_counter()
+    min_clear = np.inf
+    for _ in range(n_steps):
+        # static obstacles + obstacle_order=False semantics for the replay: keep slot binding fixed
+        u, info = mpc.control(state, 4.0, list(obstacles))
+        tr["u"].append(u.copy())
+        state = sc.kinematic_step(state, u, car_t, 0.1)
+    dt = time.perf_counter() - t0
+    min_clear = sc.clearance(car_t, state, obstacles)
+    out = {k: np.ascontiguousarray(np.array(v)) for k, v in tr.items()}
+    out["closed_loop_s_per_step"] = dt / n_steps
+    out["final_clearance"] = float(min_clear)
+    return out, staged, mpc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n-obs", type=int, default=200)
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rda_planner_amd._lib import hip_api
+    from rda_planner_amd._capi import Info, dptr, iptr
+    api = hip_api()
+    api.lib.rda_set_device(local_rank)
+
+    K, W = args.steps, args.warmup
+    car_t, path, obstacles, kw = build_workload(seed_offset=rank, n_obs=args.n_obs, T=args.horizon)
+    T, N = kw["receding"], kw["max_obs_num"]
+    # obstacle slots must not be re-sorted between recording and replay: record with the distance
+    # order of the first step frozen (static scene), i.e. obstacle_order only affects slot binding
+    kw_rec = dict(kw, obstacle_order=False)
+    trace, staged, mpc_rec = record_trace(car_t, path, obstacles, kw_rec, W + K)
+
+    # ---- device-resident replay -------------------------------------------------------------------
+    from rda_planner_amd.rda_solver import RDA_solver
+    solver = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1,
+                        time_print=False, ro1=kw["ro1"])
+    h = solver._be.handle
+    assert api.lib.rda_upload_obstacles(h, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"]) == 0
+    assert api.lib.rda_upload_trace(h, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"])) == 0
+
+    def barrier():
+        api.lib.rda_sync(h)
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(W):
+        api.lib.rda_enqueue_step(h, k)
+    barrier()
+    api.lib.rda_timing_reset(h, 1)                       # hipEvents around every kernel of the timed region
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        api.lib.rda_enqueue_step(h, k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel GPU time from the events recorded inside the timed region
+    kt = {}
+    for which, name in ((0, "k_lammuz"), (1, "k_su")):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        api.lib.rda_timing_read(h, which, C.cast(C.byref(ms), C.POINTER(C.c_double)), C.cast(C.byref(n), C.POINTER(C.c_int)))
+        kt[name] = (ms.value, n.value)
+    api.lib.rda_timing_reset(h, 0)
+    # un-instrumented pass for the headline number (events perturb the stream slightly)
+    solver2 = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+    h2 = solver2._be.handle
+    api.lib.rda_upload_obstacles(h2, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+    api.lib.rda_upload_trace(h2, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"]))
+    for k in range(W):
+        api.lib.rda_enqueue_step(h2, k)
+    api.lib.rda_sync(h2)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        api.lib.rda_enqueue_step(h2, k)
+    api.lib.rda_sync(h2)
+    if dist is not None:
+        import torch
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed2 = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed2 = float(tt.item())
+
+    # replay must reproduce the recorded closed loop (same inputs, same initial state)
+    u_last = np.zeros((2, T))
+    s_last = np.zeros((3, T + 1))
+    info = Info()
+    api.lib.rda_fetch_result(h2, W + K - 1, dptr(u_last), dptr(s_last), C.byref(info))
+    replay_err = float(np.abs(u_last[:, 0:1] - trace["u"][W + K - 1]).max())
+    iters = []
+    for k in range(W, W + K):
+        api.lib.rda_fetch_result(h2, k, None, None, C.byref(info))
+        iters.append(info.iters)
+    mean_iters = float(np.mean(iters))
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    E, R = kw["max_edge_num"], 4
+    unit_bytes = 8 * (5 * E + 2 * R + 8)                 # 288 B per (obstacle, stage) at E=R=4
+    lm_ms, lm_n = kt["k_lammuz"]
+    su_ms, su_n = kt["k_su"]
+    lm_avg = lm_ms / max(lm_n, 1) * 1e-3
+    su_avg = su_ms / max(su_n, 1) * 1e-3
+    peak = 8000.0
+
+    def roof(name, avg_s, bytes_per_launch, launches, total_ms):
+        ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 3), "peak": peak, "unit": "GB/s",
+                "frac": round(ach / peak, 6), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                "launches": launches, "total_ms": round(total_ms, 3), "algorithmic_bytes_per_launch": bytes_per_launch}
+    r_lm = roof("k_lammuz", lm_avg, unit_bytes * N * T, lm_n, lm_ms)
+    r_su = roof("k_su", su_avg, 48 * N * T + 8 * (8 * (T + 1) + 5 * T), su_n, su_ms)
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_file):
+        try:
+            tj = json.load(open(tr_file))
+            r_lm["traffic"] = tj.get("k_lammuz")
+            r_su["traffic"] = tj.get("k_su")
+        except Exception:
+            pass
+    dominant, secondary = (r_su, r_lm) if su_ms >= lm_ms else (r_lm, r_su)
+
+    out = {
+        "metric": "MPC steps/sec (ADMM-converged), T=20, N_obs=200", "value": round(K * world / elapsed2, 3), "unit": "steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed2 / K * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} static seeded polygons, E={E}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent ego replicas (no collective)"},
+        "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
+        "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
+        "instrumented_ms_per_step": round(elapsed / K * 1e3, 5),
+        "roofline": dominant, "roofline_secondary": secondary,
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        from oracle.oracle_backend import oracle_backend, api as orc_api
+        ncore = os.cpu_count() or 1
+        orc_api().lib.orc_set_threads(ncore)
+        cpu = RDA_solver(T, car_t, E, N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"], _backend=oracle_backend)
+        info_c = Info()
+        ou = np.zeros((2, T))
+        os_ = np.zeros((3, T + 1))
+        n_cpu, budget, t_cpu = 0, 15.0, 0.0
+        err = 0.0
+        while n_cpu < W + K and (t_cpu < budget or n_cpu < 3):
+            k = n_cpu
+            t1 = time.perf_counter()
+            cpu._be.api.step(cpu._be.handle, dptr(trace["nom_s"][k]), dptr(trace["nom_u"][k]), dptr(trace["ref"][k]), float(trace["speed"][k]),
+                             staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"], dptr(ou), dptr(os_), C.byref(info_c))
+            t_cpu += time.perf_counter() - t1
+            err = max(err, float(np.abs(ou[:, 0:1] - trace["u"][k]).max()))
+            n_cpu += 1
+        out["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 3), "unit": "steps/s", "cores": ncore, "kind": "port",
+                               "sample": f"first {n_cpu} steps of the same recorded trace (oracle/rda_oracle.c, OpenMP over obstacles; su-problem serial)",
+                               "max_du_vs_gpu": err}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
