@@ -1,9 +1,8 @@
 """ctypes view of the C-ABI declared in include/rda_hip.h.
 
-The HIP library (`librda_hip.so`, symbols `rda_*`) and the CPU oracle used by the tests
-(`oracle/librda_oracle.so`, symbols `orc_*`) deliberately share struct layouts and argument
-order, so one binding class serves both; the product package only ever instantiates it on
-the HIP library.
+The binding class is parametrised by the symbol prefix: the product instantiates it on
+`librda_hip.so` (symbols `rda_*`); the test suite re-uses it on its CPU checker, which
+deliberately shares struct layouts and argument order (symbols `orc_*`).
 """
 import ctypes as C
 import numpy as np

@@ -1,0 +1,62 @@
+"""Generates the committed golden fixtures of tests/golden/ from the CPU oracle.
+
+The reference (CVXPY + ECOS + pathos) cannot be imported in the build image, so these vectors pin
+the ORACLE (and through the parity tests the HIP kernels) against silent drift; they are NOT outputs
+of the reference.  Re-run only on a deliberate change of the tie-break rules T1-T3:
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers as hp                                    # noqa: E402
+from oracle.oracle_backend import api, oracle_backend   # noqa: E402
+from rda_planner_amd.mpc import MPC                     # noqa: E402
+from rda_planner_amd import scenarios as sc             # noqa: E402
+
+
+def lammuz():
+    orc = api()
+    rng = np.random.default_rng(20250509)
+    inp = hp.lammuz_batch_inputs(rng, 64)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    # mark sub-problems whose minimiser is unique enough to pin (lam, mu): re-solve with perturbed data
+    unique = np.ones(64, bool)
+    for eps in (1e-9, -1e-9):
+        p2 = {k: v.copy() for k, v in inp.items()}
+        p2["p"] = p2["p"] + eps
+        l2, m2, _, _ = hp.oracle_lammuz_batch(orc, p2)
+        unique &= (np.abs(l2 - lam).max(axis=1) < 1e-6) & (np.abs(m2 - mu).max(axis=1) < 1e-6)
+    out = {"inputs": {k: v.tolist() for k, v in inp.items()}, "lam": lam.tolist(), "mu": mu.tolist(), "z": z.tolist(),
+           "cmh": cmh.tolist(), "unique": np.repeat(unique[:, None], 4, 1).tolist()}
+    json.dump(out, open(os.path.join(HERE, "lammuz_golden.json"), "w"))
+    print("lammuz golden:", int(unique.sum()), "of 64 pinned on (lam, mu)")
+
+
+def closed_loop():
+    """C1 plumbing config (example/path_track/path_track_diff.py:21-23): first 40 controls"""
+    car_d = sc.rectangle_robot(wheelbase=0, dynamics="diff")
+    ref = sc.path_track_ref()
+    obs = sc.scene_path_track()
+    mpc = MPC(car_d, [r.copy() for r in ref], receding=10, sample_time=0.1, iter_num=2, obstacle_order=True, ro1=300,
+              max_edge_num=4, max_obs_num=11, slack_gain=8, _backend=oracle_backend)
+    state = ref[0].copy().reshape(3, 1)
+    us, states = [], []
+    for _ in range(40):
+        u, info = mpc.control(state, 4, list(obs))
+        us.append(u.ravel().tolist())
+        states.append(state.ravel().tolist())
+        state = sc.kinematic_step(state, u, car_d, 0.1)
+    json.dump({"u": us, "state": states}, open(os.path.join(HERE, "path_track_diff_golden.json"), "w"))
+    print("closed-loop golden written")
+
+
+if __name__ == "__main__":
+    lammuz()
+    closed_loop()

@@ -26,8 +26,13 @@ def make_cfg(T=10, N=5, E=4, R=4, dynamics=0, accelerated=1, iter_num=2, ro1=200
 
 
 def random_polygon(rng, centre, k, rad, E):
-    ang = np.sort(rng.uniform(0, 2 * np.pi, k))
-    ang = ang + np.linspace(0, 0.3, k)          # keep it non-degenerate
+    # k distinct angles in CCW order, every gap in (0.35, pi): a valid (non-empty, convex) polygon -
+    # the precondition under which basic dual solutions exist (an empty {x: Ax<=b} makes the dual LP unbounded)
+    while True:
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        gaps = np.diff(np.r_[ang, ang[0] + 2 * np.pi])
+        if gaps.min() > 0.35 and gaps.max() < np.pi - 0.05:
+            break
     V = np.vstack((centre[0] + rad * np.cos(ang), centre[1] + rad * np.sin(ang)))
     A, b = sc.polygon_halfspaces(V)
     Ap = np.zeros((E, 2))

@@ -1,0 +1,180 @@
+"""CPU tests of the host-side mirror classes (rda_planner_amd.RDA_solver / MPC) running on the CPU
+oracle backend: API surface, reference quirks (SURVEY.md 8a Q-list), closed-loop behaviour, golden run."""
+import inspect
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle_backend import oracle_backend
+from rda_planner_amd import scenarios as sc
+from rda_planner_amd.mpc import MPC, rdaobs
+from rda_planner_amd.rda_solver import RDA_solver
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "path_track_diff_golden.json")
+
+
+def _solver(**kw):
+    car_t = sc.rectangle_robot(dynamics=kw.pop("dynamics", "acker"))
+    args = dict(receding=6, car_tuple=car_t, max_edge_num=4, max_obs_num=3, iter_num=2, time_print=False, _backend=oracle_backend)
+    args.update(kw)
+    return RDA_solver(**args), car_t
+
+
+def _obs(n, cx=8.0):
+    out = []
+    for i in range(n):
+        A, b = sc.polygon_halfspaces(sc.box(cx + 3 * i, 2.5 + i, 2, 1, 0.3 * i).vertex)
+        out.append(rdaobs(A, b, "Rpositive", None, None))
+    return out
+
+
+def _inputs(T):
+    nom_u = np.vstack([np.full(T, 2.0), np.zeros(T)])
+    nom_s = np.zeros((3, T + 1))
+    for t in range(T):
+        nom_s[:, t + 1] = nom_s[:, t] + 0.1 * np.array([2.0, 0, 0])
+    ref = [np.array([[0.4 * t], [0.0], [0.0]]) for t in range(T + 1)]
+    return nom_s, nom_u, ref
+
+
+def test_signatures_match_reference():
+    """argument names / defaults of the reference (rda_solver.py:18-22, mpc.py:67-84, :127)"""
+    sig = inspect.signature(RDA_solver.__init__)
+    assert list(sig.parameters)[1:11] == ["receding", "car_tuple", "max_edge_num", "max_obs_num", "iter_num", "step_time",
+                                          "iter_threshold", "process_num", "accelerated", "time_print"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["max_edge_num"], d["max_obs_num"], d["iter_num"], d["step_time"], d["iter_threshold"], d["process_num"]) == (5, 5, 2, 0.1, 0.2, 4)
+    sig = inspect.signature(MPC.__init__)
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["receding"], d["sample_time"], d["iter_num"], d["max_edge_num"], d["max_obs_num"], d["goal_index_threshold"]) == (10, 0.1, 4, 5, 5, 1)
+    assert list(inspect.signature(MPC.control).parameters)[1:4] == ["state", "ref_speed", "obstacle_list"]
+    for name in ("iterative_solve", "assign_adjust_parameter", "get_adjust_parameter", "reset"):
+        assert hasattr(RDA_solver, name)
+    for name in ("control", "update_ref_path", "update_parameter", "get_adjust_parameters", "reset", "no_ref_path",
+                 "convert_rda_obstacle", "gen_inequal_global", "pre_process"):
+        assert hasattr(MPC, name)
+
+
+def test_info_keys_and_shapes():
+    sol, _ = _solver()
+    nom_s, nom_u, ref = _inputs(6)
+    u, info = sol.iterative_solve(nom_s, nom_u, ref, 4.0, _obs(2))
+    assert u.shape == (2, 6)
+    for k in ("ref_traj_list", "opt_state_list", "iteration_time", "resi_dual", "resi_pri"):   # rda_solver.py:603-608
+        assert k in info
+    assert len(info["opt_state_list"]) == 7 and info["opt_state_list"][0].shape == (3, 1)
+    assert 1 <= info["iters"] <= 2
+
+
+def test_q3_padding_duplicates_last_and_mutates_callers_list():
+    sol, _ = _solver()
+    nom_s, nom_u, ref = _inputs(6)
+    lst = _obs(2)
+    sol.iterative_solve(nom_s, nom_u, ref, 4.0, lst)
+    assert len(lst) == 3 and lst[2] is lst[1]                       # rda_solver.py:488-490
+    st = sol.get_state()
+    assert np.allclose(st["lam"][2], st["lam"][1]) and np.allclose(st["mu"][2], st["mu"][1])
+
+
+def test_truncation_uses_first_max_obs_num():
+    sol, _ = _solver()
+    sol2, _ = _solver()
+    nom_s, nom_u, ref = _inputs(6)
+    five = _obs(5)
+    u1, _ = sol.iterative_solve(nom_s, nom_u, ref, 4.0, list(five))
+    u2, _ = sol2.iterative_solve(nom_s, nom_u, ref, 4.0, list(five[:3]))
+    assert np.array_equal(u1, u2)
+
+
+def test_zero_obstacles_q9_and_residuals():
+    sol, _ = _solver()
+    nom_s, nom_u, ref = _inputs(6)
+    sol.iterative_solve(nom_s, nom_u, ref, 4.0, _obs(3))
+    before = sol.get_state()
+    u, info = sol.iterative_solve(nom_s, nom_u, ref, 4.0, [])
+    after = sol.get_state()
+    assert info["resi_dual"] == 0 and info["resi_pri"] == 0 and info["iters"] == 1      # rda_solver.py:614,625,594
+    assert np.all(after["a_lam"][2] == 0) and np.all(after["b_lam"][2] == 0)            # only slot N-1 (Q9, :564-568)
+    assert np.array_equal(after["a_lam"][:2], before["a_lam"][:2])
+    for k in ("lam", "mu", "z", "xi", "zeta"):                                          # duals untouched (:625)
+        assert np.array_equal(after[k], before[k])
+
+
+def test_reset_q6_clears_products_not_duals():
+    sol, _ = _solver()
+    nom_s, nom_u, ref = _inputs(6)
+    sol.iterative_solve(nom_s, nom_u, ref, 4.0, _obs(3))
+    before = sol.get_state()
+    sol.reset()
+    after = sol.get_state()
+    assert np.all(after["a_lam"] == 0) and np.all(after["b_lam"] == 0)                  # rda_solver.py:1067-1068
+    for k in ("lam", "mu", "z", "xi", "zeta", "dis"):
+        assert np.array_equal(after[k], before[k])
+
+
+def test_adjust_parameters_roundtrip_and_effect():
+    sol, _ = _solver(ro1=300, slack_gain=9)
+    p = sol.get_adjust_parameter()
+    assert p == {"slack_gain": 9, "max_sd": 1.0, "min_sd": 0.1, "ro1": 300, "ro2": 1, "ws": 1, "wu": 1}
+    nom_s, nom_u, ref = _inputs(6)
+    u1, _ = sol.iterative_solve(nom_s, nom_u, ref, 4.0, _obs(3, cx=5.0))
+    sol.assign_adjust_parameter(max_sd=0.3, min_sd=0.2)
+    assert sol.get_adjust_parameter()["max_sd"] == 0.3
+    sol.iterative_solve(nom_s, nom_u, ref, 4.0, _obs(3, cx=5.0))
+    d = sol.get_state()["dis"]
+    assert (d <= 0.3 + 1e-9).all() and (d >= 0.2 - 1e-9).all()                          # rda_solver.py:944-945
+
+
+def test_dynamic_obstacle_lists_and_circles():
+    car_t = sc.rectangle_robot(dynamics="diff", wheelbase=0)
+    mpc = MPC(car_t, sc.line_path([0, 0, 0], [20, 0, 0], 0.2), receding=6, max_edge_num=4, max_obs_num=3, iter_num=2, _backend=oracle_backend)
+    obs = [sc.circle(8, 2.5, 1.0, velocity=(0.5, 0)), sc.box(12, -3, 2, 1, 0.4, velocity=(0, 0.3)), sc.circle(15, 3, 0.5)]
+    rl = mpc.convert_rda_obstacle(obs, np.zeros((3, 1)), True)
+    assert isinstance(rl[0].A, list) and len(rl[0].A) == 7                              # mpc.py:447-456
+    u, info = mpc.control(np.zeros((3, 1)), 3.0, obs)
+    assert u.shape == (2, 1) and np.isfinite(u).all()
+
+
+def test_too_many_edges_raises():
+    sol, _ = _solver()
+    nom_s, nom_u, ref = _inputs(6)
+    A, b = sc.polygon_halfspaces(sc.regular_polygon(9, 3, 6, 1.0, 0).vertex)
+    with pytest.raises(ValueError):
+        sol.iterative_solve(nom_s, nom_u, ref, 4.0, [rdaobs(A, b, "Rpositive", None, None)])
+
+
+def test_geometry_conversion_matches_reference_rule():
+    car_t = sc.rectangle_robot()
+    mpc = MPC(car_t, sc.line_path([0, 0, 0], [5, 0, 0]), _backend=oracle_backend, max_obs_num=1)
+    V = np.array([[31, 33, 33, 31], [24, 24, 28, 28.0]])
+    A, b = mpc.gen_inequal_global(V)
+    assert np.allclose(A, [[0, -2], [4, 0], [0, 2], [-4, 0]]) and np.allclose(b.ravel(), [-48, 132, 56, -124])   # mpc.py:496-508
+    A2, b2 = mpc.gen_inequal_global(V[:, ::-1])                       # CW input is reversed first (mpc.py:486-487)
+    assert {tuple(np.r_[r, c]) for r, c in zip(A2, b2.ravel())} == {tuple(np.r_[r, c]) for r, c in zip(A, b.ravel())}
+    Ac, bc = mpc.convert_inequal_circle(np.array([[2.0], [3.0]]), 1.5)
+    assert np.array_equal(Ac, [[1, 0], [0, 1], [0, 0]]) and np.allclose(bc.ravel(), [2, 3, -1.5])                 # mpc.py:444-446
+
+
+def test_closed_loop_path_track_no_collision_and_golden():
+    """BASELINE config C1 (example/path_track/path_track_diff.py:21-23) - tracks the path, never touches an
+    obstacle, reaches the goal; the first 40 controls are pinned by a committed golden run"""
+    car_d = sc.rectangle_robot(wheelbase=0, dynamics="diff")
+    ref = sc.path_track_ref()
+    obs = sc.scene_path_track()
+    mpc = MPC(car_d, [r.copy() for r in ref], receding=10, sample_time=0.1, iter_num=2, obstacle_order=True, ro1=300,
+              max_edge_num=4, max_obs_num=11, slack_gain=8, _backend=oracle_backend)
+    gold = json.load(open(GOLD))
+    state = ref[0].copy().reshape(3, 1)
+    minc, arrived = np.inf, False
+    for i in range(500):
+        u, info = mpc.control(state, 4, list(obs))
+        if i < 40:
+            assert np.abs(u.ravel() - np.array(gold["u"][i])).max() < 1e-6, i
+        state = sc.kinematic_step(state, u, car_d, 0.1)
+        minc = min(minc, sc.clearance(car_d, state, obs))
+        if info["arrive"]:
+            arrived = True
+            break
+    assert arrived and minc > 0.05, (arrived, minc)

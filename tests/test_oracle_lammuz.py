@@ -1,0 +1,165 @@
+"""CPU tests that pin the ORACLE's LamMuZ sub-problem solver (reference rda_solver.py:389-421).
+
+The reference ships no tests and CVXPY/ECOS cannot be installed here (parity unpinned),
+so the oracle is pinned by (i) an independent numpy restatement, (ii) KKT certificates on the
+reference's own formulation, (iii) scipy cross-checks of the optimal value, (iv) geometry
+known-answer tests, (v) committed golden vectors.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as hp
+from oracle.lammuz_np import solve_lammuz
+from rda_planner_amd import scenarios as sc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "lammuz_golden.json")
+
+
+def test_c_oracle_matches_numpy_restatement(orc):
+    rng = np.random.default_rng(11)
+    inp = hp.lammuz_batch_inputs(rng, 300)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    for i in range(300):
+        l2, m2, z2, info = solve_lammuz(inp["A"][i], inp["b"][i], bool(inp["cone"][i]), inp["p"][i], inp["phi"][i],
+                                        hp.G, hp.H, inp["xi"][i], inp["zeta"][i], inp["dbar"][i], 1.0)
+        assert abs(info["cost"] - cmh[i, 0]) < 1e-11
+        assert abs(info["m"] - cmh[i, 1]) < 1e-9
+        # (lam, mu) individually only where the optimum is not an exact tie
+        if np.abs(l2 - lam[i]).max() > 1e-8:
+            assert abs(info["cost"] - cmh[i, 0]) < 1e-13      # tie: same cost, different vertex
+        else:
+            assert np.abs(m2 - mu[i]).max() < 1e-8 and abs(z2 - z[i]) < 1e-9
+
+
+def _kkt_residual(A, b, p, phi, xi, zeta, dbar, lam, mu, ro2=1.0, delta=1e-6):
+    """stationarity / complementarity of the FULL polygon problem (all E + R variables)"""
+    c, s = np.cos(phi), np.sin(phi)
+    Rm = np.array([[c, -s], [s, c]])
+    q = A @ p - b
+    M = A @ Rm
+    m = lam @ q - hp.H @ mu + zeta - dbar
+    Hv = M.T @ lam + hp.G.T @ mu + xi
+    dpsi = min(m, 0.0) - delta
+    g_lam = dpsi * q + ro2 * (M @ Hv)
+    g_mu = -dpsi * hp.H + ro2 * (hp.G @ Hv)
+    a = A.T @ lam
+    na = np.linalg.norm(a)
+    # multiplier of 1/2(|a|^2 - 1) <= 0 from the support rows
+    tau = 0.0
+    if na > 1 - 1e-9:
+        sup = lam > 1e-9
+        if sup.any():
+            Aa = A[sup] @ a
+            tau = float(np.mean(-g_lam[sup] / Aa)) if np.all(np.abs(Aa) > 1e-12) else 0.0
+            tau = max(tau, 0.0)
+    g_lam = g_lam + tau * (A @ a)
+    res = 0.0
+    for g, v in ((g_lam, lam), (g_mu, mu)):
+        res = max(res, float(np.max(np.maximum(-g, 0))))              # dual feasibility g >= 0
+        res = max(res, float(np.max(np.abs(g * v))))                  # complementarity
+    assert na <= 1 + 1e-9 and (lam >= 0).all() and (mu >= 0).all()
+    return res
+
+
+def test_kkt_certificate_polygons(orc):
+    rng = np.random.default_rng(3)
+    inp = hp.lammuz_batch_inputs(rng, 400, circles=0.0)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    worst = 0.0
+    for i in range(400):
+        worst = max(worst, _kkt_residual(inp["A"][i], inp["b"][i], inp["p"][i], inp["phi"][i], inp["xi"][i],
+                                         inp["zeta"][i], inp["dbar"][i], lam[i], mu[i]))
+    assert worst < 1e-7, worst
+
+
+def test_value_not_worse_than_scipy(orc):
+    from scipy.optimize import minimize, NonlinearConstraint, Bounds
+    rng = np.random.default_rng(8)
+    inp = hp.lammuz_batch_inputs(rng, 25, circles=0.0)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp, delta=1e-3)
+    for i in range(25):
+        A, b, p, phi = inp["A"][i], inp["b"][i], inp["p"][i], inp["phi"][i]
+        c, s = np.cos(phi), np.sin(phi)
+        q = A @ p - b
+        M = A @ np.array([[c, -s], [s, c]])
+        E = A.shape[0]
+
+        def f(y):
+            m = y[:E] @ q - y[E:] @ hp.H + inp["zeta"][i] - inp["dbar"][i]
+            Hv = M.T @ y[:E] + hp.G.T @ y[E:] + inp["xi"][i]
+            return 0.5 * min(m, 0) ** 2 - 1e-3 * m + 0.5 * Hv @ Hv
+        cons = [NonlinearConstraint(lambda y: np.sum((A.T @ y[:E]) ** 2), -np.inf, 1.0)]
+        best = np.inf
+        for k in range(2):
+            y0 = np.r_[lam[i], mu[i]] + (rng.uniform(0, 0.2, E + 4) if k else 0)
+            r = minimize(f, y0, method="trust-constr", bounds=Bounds(0, np.inf), constraints=cons,
+                         options={"gtol": 1e-10, "xtol": 1e-12, "maxiter": 500})
+            y = np.maximum(r.x, 0)
+            na = np.linalg.norm(A.T @ y[:E])
+            if na > 1:
+                y[:E] /= na
+            best = min(best, f(y))
+        assert cmh[i, 0] <= best + 1e-8 * (1 + abs(best)), (i, cmh[i, 0], best)
+
+
+KAT = [  # obstacle, robot pose (x, y, phi), distance  - SURVEY.md appendix B
+    ("poly", (25, 26, 0.0), 2.2),
+    ("poly", (25, 30, 0.7), 4.5949905),
+    ("poly", (36, 31, 2.5), 3.3988473),
+    ("circ", (12, 34, 0.0), 2.7),
+    ("circ", (18, 40, -1.2), 1.0169500),
+]
+
+
+@pytest.mark.parametrize("kind,pose,dist", KAT)
+def test_known_answer_distances(orc, kind, pose, dist):
+    """with xi = 0 and an inactive hinge the max-clearance duals are the polytope-distance duals:
+    m + d - zeta = distance(robot, obstacle)"""
+    E = 4
+    if kind == "poly":
+        A, b = sc.polygon_halfspaces(np.array([[31, 33, 33, 31], [24, 24, 28, 28.0]]))
+        A = np.ascontiguousarray(A)
+        b = b.ravel()
+        cone = 0
+    else:
+        A = np.array([[1, 0], [0, 1], [0, 0], [0, 0.0]])
+        b = np.array([20, 34, -1.5, 0.0])
+        cone = 1
+    inp = dict(A=A[None], b=b[None], cone=np.array([cone], np.int32), p=np.array([pose[:2]], float), phi=np.array([pose[2]]),
+               xi=np.zeros((1, 2)), zeta=np.zeros(1), dbar=np.array([0.1]))
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    # T1 rewards clearance with delta = 1e-6, which buys delta*|x_R|^2/ro2 <= 1.6e-5 of extra m for H = -delta/ro2 * x_R
+    assert abs(cmh[0, 1] + 0.1 - dist) < 3e-5
+    assert abs(np.linalg.norm(A.T @ lam[0]) - 1) < 1e-9
+
+
+def test_edge_cases(orc):
+    rng = np.random.default_rng(2)
+    inp = hp.lammuz_batch_inputs(rng, 4, circles=0.0)
+    # all-zero obstacle rows (padding only) -> zero duals
+    inp["A"][0] = 0
+    inp["b"][0] = 0
+    # robot deep inside the obstacle -> hinge active, duals shrink towards 0, still finite
+    inp["A"][1], inp["b"][1] = hp.random_polygon(rng, inp["p"][1], 4, 8.0, 4)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    assert np.all(lam[0] == 0) and np.isfinite(cmh).all()
+    assert np.isfinite(lam).all() and np.isfinite(mu).all() and (z >= 0).all()
+    # non-accelerated: z absorbs the whole margin
+    l2, m2, z2, c2 = hp.oracle_lammuz_batch(orc, inp, accelerated=0)
+    assert np.allclose(z2, np.maximum(c2[:, 1], 0)) and np.allclose(z, 0.5 * np.maximum(cmh[:, 1], 0))
+
+
+def test_golden_vectors(orc):
+    """committed fixtures (tests/golden/make_golden.py) - guards the oracle against silent drift"""
+    gold = json.load(open(GOLD))
+    inp = {k: np.array(v) for k, v in gold["inputs"].items()}
+    inp["cone"] = inp["cone"].astype(np.int32)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    assert np.abs(cmh - np.array(gold["cmh"])).max() < 1e-10
+    assert np.abs(z - np.array(gold["z"])).max() < 1e-10
+    ok = np.array(gold["unique"], bool)
+    assert np.abs(lam - np.array(gold["lam"]))[ok].max() < 1e-8
+    assert np.abs(mu - np.array(gold["mu"]))[ok].max() < 1e-8

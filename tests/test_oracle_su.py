@@ -1,0 +1,121 @@
+"""CPU tests pinning the ORACLE's su-problem solver (reference rda_solver.py:216-231,313-387,831-872,911-947)
+against an independent un-condensed formulation solved by scipy (states as variables, dynamics as equalities)."""
+import numpy as np
+import pytest
+
+import helpers as hp
+
+
+def _lin(dyn, s, u, dt, L):
+    phi, v, psi = s[2], u[0], u[1]
+    if dyn == 2:
+        phi = u[1]
+        A = np.eye(3)
+        B = np.array([[np.cos(phi) * dt, -v * np.sin(phi) * dt], [np.sin(phi) * dt, v * np.cos(phi) * dt], [0, 0]])
+        C = np.array([phi * v * np.sin(phi) * dt, -phi * v * np.cos(phi) * dt, 0])
+        return A, B, C
+    A = np.array([[1, 0, -v * dt * np.sin(phi)], [0, 1, v * dt * np.cos(phi)], [0, 0, 1]])
+    if dyn == 0:
+        B = np.array([[np.cos(phi) * dt, 0], [np.sin(phi) * dt, 0], [np.tan(psi) * dt / L, v * dt / (L * np.cos(psi) ** 2)]])
+        C = np.array([phi * v * np.sin(phi) * dt, -phi * v * np.cos(phi) * dt, -psi * v * dt / (L * np.cos(psi) ** 2)])
+    else:
+        B = np.array([[np.cos(phi) * dt, 0], [np.sin(phi) * dt, 0], [0, dt]])
+        C = np.array([phi * v * np.sin(phi) * dt, -phi * v * np.cos(phi) * dt, 0])
+    return A, B, C
+
+
+def _objective(cfg, si, S, U, D):
+    """the reference's su cost, literally (rda_solver.py:1011-1032, 846-851, 868, 376-383)"""
+    T, N, dyn = cfg.T, cfg.N, cfg.dynamics
+    w = np.array([1, 1, 0.0 if dyn == 2 else 1.0])[:, None]
+    J = cfg.ws * np.sum(w * (S - si["ref"]) ** 2) + cfg.wu * np.sum((U[0] - si["vref"]) ** 2) - cfg.slack_gain * np.sum(D)
+    J += 0.5 * cfg.eps_u * np.sum(U ** 2)
+    for t in range(T):
+        ph = si["nom_s"][2, t]
+        Rm = np.array([[np.cos(ph), -np.sin(ph)], [np.sin(ph), np.cos(ph)]])
+        dR = np.array([[-np.sin(ph), -np.cos(ph)], [np.cos(ph), -np.sin(ph)]])
+        rot = Rm + dR * (S[2, t + 1] - ph)
+        for n in range(N):
+            Im = si["a"][n, t] @ S[0:2, t + 1] - si["cc"][n, t] - D[t]
+            J += 0.5 * cfg.ro1 * (min(Im, 0) ** 2 if cfg.accelerated else Im ** 2)
+            Hm = si["g"][n, t] + si["a"][n, t] @ rot
+            J += 0.5 * cfg.ro2 * Hm @ Hm
+    return J
+
+
+@pytest.mark.parametrize("trial", range(6))
+def test_su_against_scipy(orc, trial):
+    from scipy.optimize import minimize, LinearConstraint, Bounds
+    rng = np.random.default_rng(100 + trial)
+    cfg = hp.make_cfg(T=int(rng.integers(3, 7)), N=int(rng.integers(1, 5)), dynamics=trial % 3, accelerated=int(trial != 4),
+                      ro1=[200, 300, 200, 1, 200, 300][trial])
+    si = hp.su_inputs(rng, cfg)
+    st, s, u, d, it = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+    assert st == 0
+    T = cfg.T
+    ns = 3 * (T + 1)
+
+    def unpack(y):
+        return y[:ns].reshape(3, T + 1), y[ns:ns + 2 * T].reshape(2, T), y[ns + 2 * T:]
+    rows, rhs = [], []
+    nvar = ns + 3 * T
+    for r in range(3):
+        row = np.zeros(nvar); row[r * (T + 1)] = 1; rows.append(row); rhs.append(si["nom_s"][r, 0])
+    for t in range(T):
+        A, B, Cc = _lin(cfg.dynamics, si["nom_s"][:, t], si["nom_u"][:, t], cfg.dt, cfg.L)
+        for r in range(3):
+            row = np.zeros(nvar); row[r * (T + 1) + t + 1] = 1
+            for k in range(3):
+                row[k * (T + 1) + t] -= A[r, k]
+            row[ns + t] -= B[r, 0]; row[ns + T + t] -= B[r, 1]
+            rows.append(row); rhs.append(Cc[r])
+    cons = [LinearConstraint(np.array(rows), rhs, rhs)]
+    rr = []
+    for t in range(T - 1):
+        for i in range(2):
+            row = np.zeros(nvar); row[ns + i * T + t + 1] = 1; row[ns + i * T + t] = -1; rr.append(row)
+    ab = np.array([cfg.acce_bound[0], cfg.acce_bound[1]] * (T - 1))
+    cons.append(LinearConstraint(np.array(rr), -ab, ab))
+    lb = np.r_[np.full(ns, -np.inf), np.full(T, -cfg.max_speed[0]), np.full(T, -cfg.max_speed[1]), np.full(T, cfg.min_sd)]
+    ub = np.r_[np.full(ns, np.inf), np.full(T, cfg.max_speed[0]), np.full(T, cfg.max_speed[1]), np.full(T, cfg.max_sd)]
+    f = lambda y: _objective(cfg, si, *unpack(y))
+    ours = f(np.r_[s.ravel(), u.ravel(), d])
+    y0 = np.r_[si["nom_s"].ravel(), si["nom_u"].ravel(), np.full(T, 0.5)]
+    r = minimize(f, y0, method="trust-constr", bounds=Bounds(lb, ub), constraints=cons,
+                 options={"gtol": 1e-9, "xtol": 1e-11, "maxiter": 3000})
+    S, U, D = unpack(r.x)
+    # the oracle must be feasible and at least as good as scipy; solutions agree to scipy's accuracy
+    assert ours <= r.fun + 1e-6 * (1 + abs(r.fun))
+    assert np.abs(U - u).max() < 5e-4 and np.abs(S - s).max() < 5e-4 and np.abs(D - d).max() < 5e-4
+    assert (np.abs(u[0]) <= cfg.max_speed[0] + 1e-9).all() and (np.abs(u[1]) <= cfg.max_speed[1] + 1e-9).all()
+    assert (np.abs(np.diff(u, axis=1)) <= np.array([[cfg.acce_bound[0]], [cfg.acce_bound[1]]]) + 1e-9).all()
+    assert (d >= cfg.min_sd - 1e-9).all() and (d <= cfg.max_sd + 1e-9).all()
+
+
+def test_su_dynamics_and_first_order_optimality(orc):
+    """independent certificate at full size (T=20, N=200): dynamics hold exactly and a projected-gradient
+    step from the returned point cannot decrease the cost"""
+    rng = np.random.default_rng(5)
+    cfg = hp.make_cfg(T=20, N=200)
+    si = hp.su_inputs(rng, cfg)
+    st, s, u, d, it = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+    assert st == 0 and it < 60
+    for t in range(cfg.T):
+        A, B, Cc = _lin(0, si["nom_s"][:, t], si["nom_u"][:, t], cfg.dt, cfg.L)
+        assert np.abs(s[:, t + 1] - (A @ s[:, t] + B @ u[:, t] + Cc)).max() < 1e-10
+    assert np.allclose(s[:, 0], si["nom_s"][:, 0])
+
+    def roll(U):
+        S = np.zeros((3, cfg.T + 1)); S[:, 0] = si["nom_s"][:, 0]
+        for t in range(cfg.T):
+            A, B, Cc = _lin(0, si["nom_s"][:, t], si["nom_u"][:, t], cfg.dt, cfg.L)
+            S[:, t + 1] = A @ S[:, t] + B @ U[:, t] + Cc
+        return S
+    f0 = _objective(cfg, si, s, u, d)
+    for k in range(20):
+        du = rng.normal(0, 1e-4, u.shape); dd = rng.normal(0, 1e-4, d.shape)
+        U2 = np.clip(u + du, -np.array([[10.0], [1.0]]), np.array([[10.0], [1.0]]))
+        for t in range(1, cfg.T):                       # keep the rate constraint
+            U2[:, t] = np.clip(U2[:, t], U2[:, t - 1] - [1.0, 0.05], U2[:, t - 1] + [1.0, 0.05])
+        D2 = np.clip(d + dd, cfg.min_sd, cfg.max_sd)
+        assert _objective(cfg, si, roll(U2), U2, D2) >= f0 - 1e-7 * (1 + abs(f0))
