@@ -23,8 +23,10 @@ not installable here, so this restatement fixes the tie-break explicitly:
   (T2) z = 1/2 * max(Im|z=0, 0) in accelerated mode (mid-point of its optimal
        interval [0, Im+]);  z = max(Im|z=0, 0) when accelerated=False, where
        that value is the unique minimiser;
-  (T3) exact ties between basic solutions: lowest candidate index wins
-       (lam-candidate major, mu-candidate, hinge state minor).
+  (T3) the hinge-inactive candidates are examined first and the best of them is
+       returned when its m >= 0 (it is then globally optimal); otherwise all
+       candidates compete and exact ties go to the lowest candidate index
+       2*(lam_index*n_mu + mu_index) + hinge_state.
 
 Method: because -psi'(m) > 0 everywhere, for the optimal a = A'lam and g = G'mu
 the pair (lam, mu) solves two LPs  ->  basic optimal solutions have at most two
@@ -82,7 +84,7 @@ def trs2(Q, c, disc):
     if disc:
         lo = max(lo, 0.0)
     tau = lo
-    for _ in range(40):
+    for _ in range(20):
         s1, s2 = l1 + tau, l2 + tau
         if s1 <= 0 or s2 <= 0:
             tau = max(-l1, -l2) + 1e-300
@@ -98,7 +100,7 @@ def trs2(Q, c, disc):
         dg = -0.5 * dphi / (phi * sq)
         step = g / dg
         tau_new = tau - step
-        if abs(step) <= 1e-16 * max(1.0, abs(tau)):
+        if abs(step) <= 4e-16 * max(1.0, abs(tau)):
             tau = tau_new
             break
         tau = tau_new
@@ -169,11 +171,15 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
 
     best = None
     allc = []
-    idx = 0
-    for lc in lam_cands:
-        for mc in mu_cands:
-            for chi in (0.0, 1.0):
-                idx += 1
+    nm = len(mu_cands)
+    # rule T3: hinge-inactive candidates first; if the best of them has m >= 0 it is optimal
+    for chi in (0.0, 1.0):
+      if chi == 1.0 and best is not None and best[4] >= 0:
+        break
+      for il, lc in enumerate(lam_cands):
+        for im, mc in enumerate(mu_cands):
+            if True:
+                idx = 2 * (il * nm + im) + int(chi)
                 sols = []       # list of (lam_support_values as full vector)
                 if lc[0] == "L0":
                     gam, m, H = gamma_star(kappa0, xi, mc, chi)
@@ -239,7 +245,7 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                     mu = np.maximum(mu, 0.0)
                     cost, m, H = true_cost(lam, mu)
                     allc.append((cost, idx, lc, mc, chi))
-                    if best is None or cost < best[0]:
+                    if best is None or cost < best[0] or (cost == best[0] and idx < best[1]):
                         best = (cost, idx, lam, mu, m, H, lc, mc, chi)
     cost, idx, lam, mu, m, H, lc, mc, chi = best
     z = (0.5 if accelerated else 1.0) * max(m, 0.0)

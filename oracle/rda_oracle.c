@@ -84,7 +84,7 @@ static int trs2(double q11, double q12, double q22, double c0, double c1, int di
     if (lo2 > lo) lo = lo2;
     if (disc && lo < 0) lo = 0;
     double tau = lo;
-    for (int it = 0; it < 40; ++it) {
+    for (int it = 0; it < 20; ++it) {
         double s1 = l1 + tau, s2 = l2 + tau;
         if (s1 <= 0 || s2 <= 0) { tau = (-l1 > -l2 ? -l1 : -l2) + 1e-300; s1 = l1 + tau; s2 = l2 + tau; }
         double a1 = h1 != 0 ? h1 / s1 : 0.0, a2 = h2 != 0 ? h2 / s2 : 0.0;
@@ -95,7 +95,7 @@ static int trs2(double q11, double q12, double q22, double c0, double c1, int di
         double g = 1.0 / sq - 1.0, dg = -0.5 * dphi / (phi * sq);
         double step = g / dg;
         tau -= step;
-        if (fabs(step) <= 1e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
+        if (fabs(step) <= 4e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
     }
     double s1 = l1 + tau, s2 = l2 + tau;
     double y1 = h1 != 0 ? -h1 / s1 : 0.0, y2 = h2 != 0 ? -h2 / s2 : 0.0;
@@ -190,9 +190,13 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
     double best_m = 0, best_H[2] = {0, 0};
     for (int i = 0; i < E; ++i) lam_out[i] = 0;
     for (int j = 0; j < R; ++j) mu_out[j] = 0;
-    int idx = 0;
-    for (int il = 0; il < nl; ++il) for (int im = 0; im < nm; ++im) for (int ic = 0; ic < 2; ++ic) {
-        idx++;
+    /* Rule T3: hinge-inactive candidates (ic = 0) first; if the best of them has m >= 0 it is optimal and the
+     * hinge-active ones are skipped; otherwise all compete, lowest id = 2*(il*nm+im)+ic on exact ties. */
+    int best_id = 0x7fffffff;
+    for (int ic = 0; ic < 2; ++ic) {
+    if (ic == 1 && best_m >= 0) break;
+    for (int il = 0; il < nl; ++il) for (int im = 0; im < nm; ++im) {
+        int idx = 2 * (il * nm + im) + ic;
         const mu_cand *mc = &mcs[im]; double chi = (double)ic;
         double lam[EMAX]; for (int i = 0; i < E; ++i) lam[i] = 0;
         double gam[2] = {0, 0}, m, H[2];
@@ -265,12 +269,13 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
         for (int j = 0; j < R; ++j) { mm -= mu[j] * h[j]; HH[0] += mu[j] * G[2 * j]; HH[1] += mu[j] * G[2 * j + 1]; }
         double ng = mm < 0 ? mm : 0;
         double cost = 0.5 * ng * ng - delta * mm + 0.5 * ro2 * (HH[0] * HH[0] + HH[1] * HH[1]);
-        if (cost < best_cost) {
-            best_cost = cost; best_idx = idx; best_m = mm; best_H[0] = HH[0]; best_H[1] = HH[1];
+        if (cost < best_cost || (cost == best_cost && idx < best_id)) {
+            best_cost = cost; best_idx = idx; best_id = idx; best_m = mm; best_H[0] = HH[0]; best_H[1] = HH[1];
             for (int i = 0; i < E; ++i) lam_out[i] = lam[i];
             for (int j = 0; j < R; ++j) mu_out[j] = mu[j];
         }
         }
+    }
     }
     *z_out = (accelerated ? 0.5 : 1.0) * (best_m > 0 ? best_m : 0);          /* tie-break T2 */
     if (cmh) { cmh[0] = best_cost; cmh[1] = best_m; cmh[2] = best_H[0]; cmh[3] = best_H[1]; }
@@ -483,7 +488,7 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
     for (int i = 0; i < mc; ++i) {
         double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
         double sl = con[i].e - cx;
-        w[i] = sl > 1e-2 ? sl : 1e-2; lm[i] = 1.0;
+        w[i] = sl > 1e-2 ? sl : 1e-2; lm[i] = 1.0 / w[i];          /* lam = mu0 / w with mu0 = 1 */
     }
     int status = 1, it;
     for (it = 0; it < 100; ++it) {
@@ -499,7 +504,9 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
         mu /= mc;
         for (int i = 0; i < n; ++i) if (fabs(rhs[i]) > rdn) rdn = fabs(rhs[i]);
         double sc = 1 + gn;
-        if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
+#ifdef ORC_DEBUG
+        fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
+#endif
         if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
         /* K = H + C' diag(lm/w) C */
         memcpy(K, Hm, sizeof(double) * n * n);
@@ -530,7 +537,10 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                     if (dl[i] < 0 && -lm[i] / dl[i] < al) al = -lm[i] / dl[i];
                 }
                 mu_aff = 0; for (int i = 0; i < mc; ++i) mu_aff += (lm[i] + al * dl[i]) * (w[i] + al * dw[i]);
-                mu_aff /= mc; double r = mu_aff / mu; sigma = r * r * r;
+                mu_aff /= mc;
+                /* centering parameter from the predictor step length, floored: the classical (mu_aff/mu)^3
+                 * rule can cycle on the piecewise-quadratic hinge terms (observed with ro1 = 1) */
+                { double q = 1 - al; sigma = q * q * q; if (sigma < 0.03) sigma = 0.03; }
             }
         }
         double al = 1.0;

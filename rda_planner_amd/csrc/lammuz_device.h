@@ -103,7 +103,7 @@ __device__ __forceinline__ int trs2(double q11, double q12, double q22, double c
     if (lo2 > lo) lo = lo2;
     if (disc && lo < 0) lo = 0;
     double tau = lo;
-    for (int it = 0; it < 40; ++it) {
+    for (int it = 0; it < 20; ++it) {
         double s1 = l1 + tau, s2 = l2 + tau;
         if (s1 <= 0 || s2 <= 0) { tau = (-l1 > -l2 ? -l1 : -l2) + 1e-300; s1 = l1 + tau; s2 = l2 + tau; }
         double a1 = h1 != 0 ? h1 / s1 : 0.0, a2 = h2 != 0 ? h2 / s2 : 0.0;
@@ -114,7 +114,7 @@ __device__ __forceinline__ int trs2(double q11, double q12, double q22, double c
         double g = 1.0 / sq - 1.0, dg = -0.5 * dphi / (phi * sq);
         double step = g / dg;
         tau -= step;
-        if (fabs(step) <= 1e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
+        if (fabs(step) <= 4e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
     }
     double s1 = l1 + tau, s2 = l2 + tau;
     double y1 = h1 != 0 ? -h1 / s1 : 0.0, y2 = h2 != 0 ? -h2 / s2 : 0.0;
@@ -265,34 +265,39 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
     __builtin_amdgcn_wave_barrier();
     const int nl = P.norm2 ? 2 : 1 + P.E + P.E * (P.E - 1) / 2;
     const int nm = 1 + P.R + P.R * (P.R - 1) / 2;
-    const int total = nl * nm * 2;
+    const int half = nl * nm;
     best.cost = INFINITY; best.id = 0x7fffffff;
     best.m = 0; best.H0 = 0; best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
     best.l1 = best.l2 = best.g1 = best.g2 = 0;
-    for (int c = lane; c < total; c += 64) {
-        int ic = c & 1, rest = c >> 1;
-        int im = rest % nm, il = rest / nm;
-        Sol s;
-        if (eval_candidate(W, Rb, P, il, im, ic, s)) {
-            s.id = c;
-            if (s.cost < best.cost) best = s;          // ids increase per lane: '<' keeps the lowest id
+    // Rule T3: the hinge-inactive candidates (ic = 0) are examined first; if the best of them has m >= 0 it
+    // is the global optimum (the ic = 0 model under-estimates the true cost and is exact for m >= 0) and the
+    // hinge-active candidates are skipped.  Otherwise all candidates compete, lowest id on exact ties.
+    for (int ic = 0; ic < 2; ++ic) {
+        for (int c = lane; c < half; c += 64) {
+            int im = c % nm, il = c / nm;
+            Sol s;
+            if (eval_candidate(W, Rb, P, il, im, ic, s)) {
+                s.id = 2 * c + ic;
+                if (s.cost < best.cost || (s.cost == best.cost && s.id < best.id)) best = s;
+            }
         }
-    }
-    // wave arg-min on (cost, id)
-    double bc = best.cost; int bid = best.id;
+        // wave arg-min on (cost, id)
+        double bc = best.cost; int bid = best.id;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double oc = __shfl_xor(bc, off, 64); int oid = __shfl_xor(bid, off, 64);
-        if (oc < bc || (oc == bc && oid < bid)) { bc = oc; bid = oid; }
+        for (int off = 32; off >= 1; off >>= 1) {
+            double oc = __shfl_xor(bc, off, 64); int oid = __shfl_xor(bid, off, 64);
+            if (oc < bc || (oc == bc && oid < bid)) { bc = oc; bid = oid; }
+        }
+        unsigned long long win = __ballot(best.id == bid);
+        int src = __ffsll((long long)win) - 1;
+        best.cost = __shfl(best.cost, src, 64); best.id = bid;
+        best.m = __shfl(best.m, src, 64); best.H0 = __shfl(best.H0, src, 64); best.H1 = __shfl(best.H1, src, 64);
+        best.i1 = __shfl(best.i1, src, 64); best.i2 = __shfl(best.i2, src, 64);
+        best.j1 = __shfl(best.j1, src, 64); best.j2 = __shfl(best.j2, src, 64);
+        best.l1 = __shfl(best.l1, src, 64); best.l2 = __shfl(best.l2, src, 64);
+        best.g1 = __shfl(best.g1, src, 64); best.g2 = __shfl(best.g2, src, 64);
+        if (best.m >= 0) break;                 // wave-uniform after the broadcast
     }
-    unsigned long long win = __ballot(best.id == bid);
-    int src = __ffsll((long long)win) - 1;
-    best.cost = __shfl(best.cost, src, 64); best.id = bid;
-    best.m = __shfl(best.m, src, 64); best.H0 = __shfl(best.H0, src, 64); best.H1 = __shfl(best.H1, src, 64);
-    best.i1 = __shfl(best.i1, src, 64); best.i2 = __shfl(best.i2, src, 64);
-    best.j1 = __shfl(best.j1, src, 64); best.j2 = __shfl(best.j2, src, 64);
-    best.l1 = __shfl(best.l1, src, 64); best.l2 = __shfl(best.l2, src, 64);
-    best.g1 = __shfl(best.g1, src, 64); best.g2 = __shfl(best.g2, src, 64);
 }
 
 // value of lam[e] / mu[j] encoded by a solution

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s
     a.ref = d.ref; a.ref_speed = d.ref_speed;
     a.ax = d.ax; a.ay = d.ay; a.blam = d.blam; a.ee = d.ee; a.gx = d.gx; a.gy = d.gy;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
-    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
     su::solve(a, smem_su);
     __syncthreads();
     if (tid == 0) {
@@ -624,6 +624,9 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.blam = dsoa + 2 * T * N; ar.ee = dsoa + 3 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.d_in = d0 ? dd0 : nullptr; ar.out_s = dos; ar.out_u = dou; ar.out_d = dod; ar.status = dst; ar.ipm_iters = dst + 1;
+    long long *dprof = nullptr;
+    if (getenv("RDA_SU_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }
+    ar.prof = dprof;
     const size_t lds = su::lds_bytes((int)T);
     HIPCHK(hipFuncSetAttribute((const void *)k_su_hook, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_su_hook, dim3(1), dim3(su::NT), lds, 0, ar);
@@ -631,6 +634,11 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     HIPCHK(hipDeviceSynchronize());
     int st[2];
     HIPCHK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+    if (dprof) {
+        long long hp[16]; HIPCHK(hipMemcpy(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost));
+        fprintf(stderr, "su prof (cycles) iters=%d:", st[1]); for (int i = 0; i < 9; ++i) fprintf(stderr, " [%d]=%lld", i, hp[i]); fprintf(stderr, "\n");
+        dev_free(dprof);
+    }
     HIPCHK(hipMemcpy(s, dos, ns * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(u, dou, nu * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(dd, dod, T * 8, hipMemcpyDeviceToHost));
     if (ipm_iters) *ipm_iters = st[1];
     void *fr[] = { dsoa, dns, dnu, dref, dspeed, dd0, dos, dou, dod, dst };

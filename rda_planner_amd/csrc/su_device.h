@@ -1,8 +1,9 @@
 // K3 device code: the state/control ("su") problem of one ADMM iteration, solved by ONE
-// workgroup as a primal-dual interior point method whose Newton systems are block-tridiagonal
-// and solved by a Riccati recursion over the T stages (reference: construct_su_prob
-// rda_solver.py:216-231, nav_cost_cons :313-328, update_su_cost_cons :330-387, Im_su/Hm_su
-// :831-872, dynamics/bounds :911-947, C0/C1 cost :1011-1032).
+// workgroup as a primal-dual interior point method (Mehrotra predictor-corrector) whose Newton
+// systems are block-tridiagonal and solved by a Riccati recursion over the T stages
+// (reference: construct_su_prob rda_solver.py:216-231, nav_cost_cons :313-328,
+// update_su_cost_cons :330-387, Im_su/Hm_su :831-872, dynamics/bounds :911-947, C0/C1 cost
+// :1011-1032).
 //
 //   stage vector   y_t = [ s_t(3) | up_t(2) = u_{t-1} | u_t(2) | d_t ]            (8)
 //   dynamics       s_{t+1} = A_t s_t + B_t u_t + C_t ,  up_{t+1} = u_t
@@ -10,10 +11,15 @@
 //                  + wu (u_t[0]-v_ref)^2 + eps_u/2 |u_t|^2 - slack_gain d_t
 //   inequalities   |u_t| <= u_max, d_min <= d_t <= d_max, |u_t - up_t| <= a_max dt (t >= 1)
 //
-// The only N-dependent work per interior-point iteration is a per-stage reduction of nine sums
-// over the obstacles whose hinge is active - done by all waves of the workgroup from the
-// [T][N] structure-of-arrays coefficients (coalesced over n); the serial Riccati sweeps run on
-// wave 0 with the 8x8 stage matrix spread one entry per lane.
+// Work split inside an interior-point iteration
+//   all 4 waves : per-stage sums over the obstacles with an active hinge (the only N-dependent
+//                 work; [T][N] structure-of-arrays coefficients, (stage, chunk) thread mapping),
+//                 stage gradients / Hessian bases, slack and multiplier updates, reductions
+//   wave 0      : the serial Riccati sweeps.  Every lane carries the cost-to-go (P 5x5, p 5) in
+//                 registers and performs the stage update redundantly, with the next stage's
+//                 constants prefetched from LDS: no barrier and no LDS round trip on the serial
+//                 critical path
+//   wave 1      : adjoint sweep for the reduced gradient, concurrently with wave 0
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -38,6 +44,7 @@ struct Args {
     double *out_s, *out_u, *out_d;   // results (may alias in_*)
     int *status;                     // 0 ok / 1 not converged / 2 factorisation failed
     int *ipm_iters;
+    long long *prof;                 // optional per-phase cycle counters (debug), may be null
 };
 
 __device__ __forceinline__ void wsync()
@@ -77,33 +84,34 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
 // LDS carve-up (doubles)
 struct Lds {
     double *s, *u, *d, *phin, *ref, *Ak, *Bk, *Ck, *Q0, *Q1, *Q2;
-    double *hs;        // [T][9] hinge sums
-    double *Hw, *gw;   // [T][10], [T][4]
+    double *Jm;        // [T][32] d(s_next, d)/dy : 4x8 per stage (constant during the solve)
+    double *part;      // [NT][9] partial sums of the chunked reductions
+    double *hs;        // [T][9]  hinge sums
+    double *Hw, *gw;   // [T][16], [T][4]
+    double *bw;        // [T][5]  barrier weights (u0 box, u1 box, d box, rate u0, rate u1)
     double *gst;       // [T][8]  stage gradient (objective + C'lam)
     double *gh;        // [T][8]  Newton right-hand side gradient
+    double *gad;       // [T][3]  reduced gradient (adjoint sweep)
+    double *base;      // [T][64] stage Hessian without the cost-to-go term
     double *cw, *cl, *rp, *rc, *dw, *dl;   // [T][NC]
-    double *Minv, *Mxv, *gv, *dy;          // [T][9], [T][15], [T][3], [T][8]
-    double *Mm, *W6, *P, *pv, *red;        // 64, 36, 25, 8, NT
-    __device__ static size_t doubles(int T) {
-        return (size_t)3 * (T + 1) + 2 * T + T + T + 3 * (T + 1) + 9 * T + 6 * T + 3 * T + 3 * T
-             + 9 * T + 10 * T + 4 * T + 8 * T + 8 * T + 6 * NC * T + 9 * T + 15 * T + 3 * T + 8 * T
-             + 64 + 36 + 25 + 8 + NT;
-    }
-    __device__ void carve(double *base, int T) {
-        double *p = base;
+    double *Minv, *Wst, *kk, *dy;          // [T][9], [T][15], [T][3], [T][8]
+    double *pv, *red;                      // 8, NT
+    __device__ void carve(double *b, int T) {
+        double *p = b;
         s = p; p += 3 * (T + 1); u = p; p += 2 * T; d = p; p += T; phin = p; p += T; ref = p; p += 3 * (T + 1);
         Ak = p; p += 9 * T; Bk = p; p += 6 * T; Ck = p; p += 3 * T; Q0 = p; p += T; Q1 = p; p += T; Q2 = p; p += T;
-        hs = p; p += 9 * T; Hw = p; p += 10 * T; gw = p; p += 4 * T; gst = p; p += 8 * T; gh = p; p += 8 * T;
+        Jm = p; p += 32 * T; part = p; p += 9 * NT; hs = p; p += 9 * T; Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += 5 * T;
+        gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += 3 * T; base = p; p += 64 * T;
         cw = p; p += NC * T; cl = p; p += NC * T; rp = p; p += NC * T; rc = p; p += NC * T; dw = p; p += NC * T; dl = p; p += NC * T;
-        Minv = p; p += 9 * T; Mxv = p; p += 15 * T; gv = p; p += 3 * T; dy = p; p += 8 * T;
-        Mm = p; p += 64; W6 = p; p += 36; P = p; p += 25; pv = p; p += 8; red = p; p += NT;
+        Minv = p; p += 9 * T; Wst = p; p += 15 * T; kk = p; p += 3 * T; dy = p; p += 8 * T;
+        pv = p; p += 8; red = p; p += NT;
     }
 };
 inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)3 * (T + 1) + 2 * T + T + T + 3 * (T + 1) + 9 * T + 6 * T + 3 * T + 3 * T
-             + 9 * T + 10 * T + 4 * T + 8 * T + 8 * T + 6 * NC * T + 9 * T + 15 * T + 3 * T + 8 * T
-             + 64 + 36 + 25 + 8 + NT;
+             + 32 * T + 9 * NT + 9 * T + 16 * T + 4 * T + 5 * T + 8 * T + 8 * T + 3 * T + 64 * T + 6 * NC * T
+             + 9 * T + 15 * T + 3 * T + 8 * T + 8 + NT;
     return n * sizeof(double);
 }
 
@@ -124,23 +132,10 @@ __device__ __forceinline__ double con_rhs(const Cfg &c, int k)
         case 6: case 7: return c.ab0; default: return c.ab1;
     }
 }
-// index in y (5..7 direct, 3..4 up) and sign for the (at most two) non-zeros of row k
-__device__ __forceinline__ void con_pat(int k, int &ia, double &ca, int &ib, double &cb)
-{
-    ib = -1; cb = 0;
-    switch (k) {
-        case 0: ia = 5; ca = 1; break; case 1: ia = 5; ca = -1; break;
-        case 2: ia = 6; ca = 1; break; case 3: ia = 6; ca = -1; break;
-        case 4: ia = 7; ca = 1; break; case 5: ia = 7; ca = -1; break;
-        case 6: ia = 5; ca = 1; ib = 3; cb = -1; break; case 7: ia = 5; ca = -1; ib = 3; cb = 1; break;
-        case 8: ia = 6; ca = 1; ib = 4; cb = -1; break; default: ia = 6; ca = -1; ib = 4; cb = 1; break;
-    }
-}
 __device__ __forceinline__ bool con_on(int t, int k) { return k < 6 || t >= 1; }
 
 __device__ __forceinline__ double block_reduce(double v, double *red, int tid, bool is_max)
 {
-    // wave reduce then across 4 waves via LDS
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         double o = __shfl_xor(v, off, 64);
@@ -154,20 +149,11 @@ __device__ __forceinline__ double block_reduce(double v, double *red, int tid, b
     return r;
 }
 
-// F' p for stage t:  out(8) = F_t' p(5),  F = [A 0 B 0; 0 0 I 0]
-__device__ __forceinline__ double Ft_p(const double *A, const double *B, const double *p, int i)
+// C' x for one stage: x = per-row values of the 10 inequality rows -> entries 3..7 of y
+__device__ __forceinline__ void con_T(const double *x, int t, double &y3, double &y4, double &y5, double &y6, double &y7)
 {
-    if (i < 3) return A[0 * 3 + i] * p[0] + A[1 * 3 + i] * p[1] + A[2 * 3 + i] * p[2];
-    if (i < 5) return 0.0;
-    if (i < 7) { int j = i - 5; return B[0 * 2 + j] * p[0] + B[1 * 2 + j] * p[1] + B[2 * 2 + j] * p[2] + p[3 + j]; }
-    return 0.0;
-}
-// Kt[a][i] : 6x8 map y -> (s_next(3), up_next(2), d)
-__device__ __forceinline__ double Kt(const double *A, const double *B, int a, int i)
-{
-    if (a < 3) { if (i < 3) return A[a * 3 + i]; if (i >= 5 && i < 7) return B[a * 2 + (i - 5)]; return 0.0; }
-    if (a < 5) return (i == 5 + (a - 3)) ? 1.0 : 0.0;
-    return i == 7 ? 1.0 : 0.0;
+    double r0 = t >= 1 ? x[6] - x[7] : 0.0, r1 = t >= 1 ? x[8] - x[9] : 0.0;
+    y5 = x[0] - x[1] + r0; y6 = x[2] - x[3] + r1; y7 = x[4] - x[5]; y3 = -r0; y4 = -r1;
 }
 
 // The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).
@@ -177,6 +163,11 @@ __device__ inline void solve(const Args &a, double *smem)
     const int T = c.T, N = c.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
     const double vref = *a.ref_speed;
+    // (stage, chunk) mapping of the obstacle reductions
+    const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
+    const int rt = tid / nch, rc_ = tid % nch;    // this thread's stage and chunk
+    const bool ract = rt < T;
+
     // ---- load nominal, reference; linearise -------------------------------------------------
     for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; L.ref[i] = a.ref[i]; }
     for (int i = tid; i < 2 * T; i += NT) L.u[i] = a.in_u[i];
@@ -186,21 +177,35 @@ __device__ inline void solve(const Args &a, double *smem)
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
         lin_model(c, st, ut, &L.Ak[9 * t], &L.Bk[6 * t], &L.Ck[3 * t]);
         L.phin[t] = st[2];
+        // J_t = d(s_next, d)/dy : rows 0..2 = [A | 0 | B | 0], row 3 = e_7
+        double *J = &L.Jm[32 * t];
+        for (int i = 0; i < 32; ++i) J[i] = 0;
+        for (int r = 0; r < 3; ++r) {
+            for (int q = 0; q < 3; ++q) J[r * 8 + q] = L.Ak[9 * t + 3 * r + q];
+            for (int q = 0; q < 2; ++q) J[r * 8 + 5 + q] = L.Bk[6 * t + 2 * r + q];
+        }
+        J[3 * 8 + 7] = 1.0;
     }
     __syncthreads();
     // ---- rotation-consistency penalty -> scalar quadratic per stage --------------
-    for (int t = wave; t < T; t += NT / 64) {
-        double cs = cos(L.phin[t]), sn = sin(L.phin[t]);
+    {
         double q0 = 0, q1 = 0, q2 = 0;
-        for (int n = lane; n < N; n += 64) {
-            double ax = a.ax[t * N + n], ay = a.ay[t * N + n], gx = a.gx[t * N + n], gy = a.gy[t * N + n];
-            double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
-            double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
-            q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
+        if (ract) {
+            double cs = cos(L.phin[rt]), sn = sin(L.phin[rt]);
+            for (int n = rc_; n < N; n += nch) {
+                double ax = a.ax[rt * N + n], ay = a.ay[rt * N + n], gx = a.gx[rt * N + n], gy = a.gy[rt * N + n];
+                double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
+                double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
+                q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
+            }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { q0 += __shfl_xor(q0, off, 64); q1 += __shfl_xor(q1, off, 64); q2 += __shfl_xor(q2, off, 64); }
-        if (lane == 0) { L.Q0[t] = q0; L.Q1[t] = q1; L.Q2[t] = q2; }
+        L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
+        __syncthreads();
+        if (tid < T) {
+            double s0 = 0, s1 = 0, s2 = 0;
+            for (int k = 0; k < nch; ++k) { const double *pp = &L.part[(tid * nch + k) * 9]; s0 += pp[0]; s1 += pp[1]; s2 += pp[2]; }
+            L.Q0[tid] = s0; L.Q1[tid] = s1; L.Q2[tid] = s2;
+        }
     }
     // ---- initial point (same rule as the oracle) ------------------------------------------------
     if (tid < T) {
@@ -232,38 +237,133 @@ __device__ inline void solve(const Args &a, double *smem)
         double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
         bool on = con_on(t, k);
         L.cw[i] = on ? (sl > 1e-2 ? sl : 1e-2) : 1.0;
-        L.cl[i] = on ? 1.0 : 0.0;
+        L.cl[i] = on ? 1.0 / L.cw[i] : 0.0;            // lam = mu0 / w with mu0 = 1
     }
     __syncthreads();
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
+
+    // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w)   (threads < T, one stage each)
+    auto build_gh = [&]() {
+        if (tid < T) {
+            int t = tid;
+            double x[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) { int i = t * NC + k; x[k] = (L.cl[i] * L.rp[i] - L.rc[i]) / L.cw[i]; }
+            double y3, y4, y5, y6, y7; con_T(x, t, y3, y4, y5, y6, y7);
+            const double *g = &L.gst[8 * t]; double *o = &L.gh[8 * t];
+            o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3] + y3; o[4] = g[4] + y4; o[5] = g[5] + y5; o[6] = g[6] + y6; o[7] = g[7] + y7;
+        }
+    };
+    // vector-only backward sweep with the stored factors (calling wave, redundant lanes)
+    struct BC { double A[9], B[6], W[15], Mi[6], g[8]; };
+    auto load_bc = [&](int t, BC &k) {
+        const double *Ap = &L.Ak[9 * t], *Bp = &L.Bk[6 * t], *Wp = &L.Wst[15 * t], *Mp = &L.Minv[9 * t], *gp = &L.gh[8 * t];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k.A[i] = Ap[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) k.B[i] = Bp[i];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) k.W[i] = Wp[i];
+        k.Mi[0] = Mp[0]; k.Mi[1] = Mp[1]; k.Mi[2] = Mp[2]; k.Mi[3] = Mp[4]; k.Mi[4] = Mp[5]; k.Mi[5] = Mp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k.g[i] = gp[i];
+    };
+    auto bwd_all = [&](int lane_) {
+        double p[5] = {0, 0, 0, 0, 0};
+        BC cur, nxt;
+        load_bc(T - 1, cur);
+        for (int t = T - 1; t >= 0; --t) {
+            if (t > 0) load_bc(t - 1, nxt);
+            const double *A = cur.A, *B = cur.B, *g = cur.g, *W = cur.W;
+            double gv0 = g[5] + B[0] * p[0] + B[2] * p[1] + B[4] * p[2] + p[3];
+            double gv1 = g[6] + B[1] * p[0] + B[3] * p[1] + B[5] * p[2] + p[4];
+            double gv2 = g[7];
+            double gx0 = g[0] + A[0] * p[0] + A[3] * p[1] + A[6] * p[2];
+            double gx1 = g[1] + A[1] * p[0] + A[4] * p[1] + A[7] * p[2];
+            double gx2 = g[2] + A[2] * p[0] + A[5] * p[1] + A[8] * p[2];
+            p[0] = gx0 - (W[0] * gv0 + W[1] * gv1 + W[2] * gv2);
+            p[1] = gx1 - (W[3] * gv0 + W[4] * gv1 + W[5] * gv2);
+            p[2] = gx2 - (W[6] * gv0 + W[7] * gv1 + W[8] * gv2);
+            p[3] = g[3] - (W[9] * gv0 + W[10] * gv1 + W[11] * gv2);
+            p[4] = g[4] - (W[12] * gv0 + W[13] * gv1 + W[14] * gv2);
+            if (lane_ == 0) {
+                const double *Mi = cur.Mi;
+                L.kk[3 * t] = -(Mi[0] * gv0 + Mi[1] * gv1 + Mi[2] * gv2);
+                L.kk[3 * t + 1] = -(Mi[1] * gv0 + Mi[3] * gv1 + Mi[4] * gv2);
+                L.kk[3 * t + 2] = -(Mi[2] * gv0 + Mi[4] * gv1 + Mi[5] * gv2);
+            }
+            cur = nxt;
+        }
+    };
+    // forward sweep: dv = kk - W' dx ; dx+ = F [dx; dv]   (calling wave, redundant lanes)
+    struct FC { double A[9], B[6], W[15], kk[3]; };
+    auto load_fc = [&](int t, FC &k) {
+        const double *Ap = &L.Ak[9 * t], *Bp = &L.Bk[6 * t], *Wp = &L.Wst[15 * t], *kp = &L.kk[3 * t];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k.A[i] = Ap[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) k.B[i] = Bp[i];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) k.W[i] = Wp[i];
+        k.kk[0] = kp[0]; k.kk[1] = kp[1]; k.kk[2] = kp[2];
+    };
+    auto fwd_all = [&](int lane_) {
+        double dx[5] = {0, 0, 0, 0, 0};
+        FC cur, nxt;
+        load_fc(0, cur);
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) load_fc(t + 1, nxt);
+            const double *A = cur.A, *B = cur.B, *W = cur.W;
+            double v0 = cur.kk[0] - (W[0] * dx[0] + W[3] * dx[1] + W[6] * dx[2] + W[9] * dx[3] + W[12] * dx[4]);
+            double v1 = cur.kk[1] - (W[1] * dx[0] + W[4] * dx[1] + W[7] * dx[2] + W[10] * dx[3] + W[13] * dx[4]);
+            double v2 = cur.kk[2] - (W[2] * dx[0] + W[5] * dx[1] + W[8] * dx[2] + W[11] * dx[3] + W[14] * dx[4]);
+            if (lane_ == 0) {
+                double *y = &L.dy[8 * t];
+                y[0] = dx[0]; y[1] = dx[1]; y[2] = dx[2]; y[3] = dx[3]; y[4] = dx[4]; y[5] = v0; y[6] = v1; y[7] = v2;
+            }
+            double n0 = A[0] * dx[0] + A[1] * dx[1] + A[2] * dx[2] + B[0] * v0 + B[1] * v1;
+            double n1 = A[3] * dx[0] + A[4] * dx[1] + A[5] * dx[2] + B[2] * v0 + B[3] * v1;
+            double n2 = A[6] * dx[0] + A[7] * dx[1] + A[8] * dx[2] + B[4] * v0 + B[5] * v1;
+            dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = v0; dx[4] = v1;
+            cur = nxt;
+        }
+        if (lane_ == 0) { L.pv[0] = dx[0]; L.pv[1] = dx[1]; L.pv[2] = dx[2]; }
+    };
+
     int status = 1, it;
+    long long tprev = clock64();
+    auto mark = [&](int k) { if (a.prof && tid == 0) { long long now = clock64(); a.prof[k] += now - tprev; tprev = now; } };
+    mark(0);
     for (it = 0; it < 100; ++it) {
-        // ---- (1) hinge sums per stage -----------------------------------------------------------
-        for (int t = wave; t < T; t += NT / 64) {
-            double px = L.s[t + 1], py = L.s[(T + 1) + t + 1], dd = L.d[t];
+        // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
+        {
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
-            for (int n = lane; n < N; n += 64) {
-                double ax = a.ax[t * N + n], ay = a.ay[t * N + n];
-                double Im = ax * px + ay * py - (a.blam[t * N + n] + a.ee[t * N + n]) - dd;
-                if (!c.accelerated || Im < 0) {
-                    sxx += ax * ax; sxy += ax * ay; syy += ay * ay; sx += ax; sy += ay; s1 += 1.0;
-                    ix += Im * ax; iy += Im * ay; i1 += Im;
+            if (ract) {
+                const double px = L.s[rt + 1], py = L.s[(T + 1) + rt + 1], dd = L.d[rt];
+                const double *pax = a.ax + (size_t)rt * N, *pay = a.ay + (size_t)rt * N, *pb = a.blam + (size_t)rt * N, *pe = a.ee + (size_t)rt * N;
+                for (int n = rc_; n < N; n += nch) {
+                    double ax = pax[n], ay = pay[n];
+                    double Im = ax * px + ay * py - (pb[n] + pe[n]) - dd;
+                    if (!c.accelerated || Im < 0) {
+                        sxx += ax * ax; sxy += ax * ay; syy += ay * ay; sx += ax; sy += ay; s1 += 1.0;
+                        ix += Im * ax; iy += Im * ay; i1 += Im;
+                    }
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                sxx += __shfl_xor(sxx, off, 64); sxy += __shfl_xor(sxy, off, 64); syy += __shfl_xor(syy, off, 64);
-                sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); s1 += __shfl_xor(s1, off, 64);
-                ix += __shfl_xor(ix, off, 64); iy += __shfl_xor(iy, off, 64); i1 += __shfl_xor(i1, off, 64);
-            }
-            if (lane == 0) {
-                double *h = &L.hs[9 * t];
-                h[0] = sxx; h[1] = sxy; h[2] = syy; h[3] = sx; h[4] = sy; h[5] = s1; h[6] = ix; h[7] = iy; h[8] = i1;
+            double *pp = &L.part[tid * 9];
+            pp[0] = sxx; pp[1] = sxy; pp[2] = syy; pp[3] = sx; pp[4] = sy; pp[5] = s1; pp[6] = ix; pp[7] = iy; pp[8] = i1;
+            __syncthreads();
+            for (int i = tid; i < 9 * T; i += NT) {
+                int t = i / 9, k = i % 9;
+                double acc = 0;
+                for (int ch = 0; ch < nch; ++ch) acc += L.part[(t * nch + ch) * 9 + k];
+                L.hs[i] = acc;
             }
         }
         __syncthreads();
-        // ---- (2) stage cost derivatives wrt w = (s_next, d) and stage gradient -------------------
+        mark(1);
+        // ---- (2) per-stage derivatives wrt w = (s_next, d); barrier weights; C'lam; residuals --------
         if (tid < T) {
             int t = tid;
             const double *h = &L.hs[9 * t];
@@ -276,52 +376,189 @@ __device__ inline void solve(const Args &a, double *smem)
             gs[2] += 0.5 * c.ro2 * (L.Q1[t] + 2 * L.Q2[t] * dl); Hs22 += c.ro2 * L.Q2[t];
             gs[0] += c.ro1 * h[6]; gs[1] += c.ro1 * h[7];
             Hs00 += c.ro1 * h[0]; Hs01 += c.ro1 * h[1]; Hs11 += c.ro1 * h[2];
-            double *Hw = &L.Hw[10 * t], *gw = &L.gw[4 * t];
-            // packed symmetric 4x4: (00,01,02,03,11,12,13,22,23,33), index 3 = d
-            Hw[0] = Hs00; Hw[1] = Hs01; Hw[2] = 0; Hw[3] = -c.ro1 * h[3];
-            Hw[4] = Hs11; Hw[5] = 0; Hw[6] = -c.ro1 * h[4];
-            Hw[7] = Hs22; Hw[8] = 0; Hw[9] = c.ro1 * h[5];
+            double *Hw = &L.Hw[16 * t], *gw = &L.gw[4 * t];
+            double hsd0 = -c.ro1 * h[3], hsd1 = -c.ro1 * h[4];
+            Hw[0] = Hs00; Hw[1] = Hs01; Hw[2] = 0; Hw[3] = hsd0;
+            Hw[4] = Hs01; Hw[5] = Hs11; Hw[6] = 0; Hw[7] = hsd1;
+            Hw[8] = 0; Hw[9] = 0; Hw[10] = Hs22; Hw[11] = 0;
+            Hw[12] = hsd0; Hw[13] = hsd1; Hw[14] = 0; Hw[15] = c.ro1 * h[5];
             gw[0] = gs[0]; gw[1] = gs[1]; gw[2] = gs[2]; gw[3] = -c.ro1 * h[8] - c.slack_gain;
-        }
-        __syncthreads();
-        // stage gradient gst[t][i] = K_t' gw + direct terms + C' lam ; residuals rp
-        for (int i = tid; i < 8 * T; i += NT) {
-            int t = i >> 3, j = i & 7;
-            const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *gw = &L.gw[4 * t];
-            double v = Kt(A, B, 0, j) * gw[0] + Kt(A, B, 1, j) * gw[1] + Kt(A, B, 2, j) * gw[2] + Kt(A, B, 5, j) * gw[3];
-            if (j == 5) v += 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t];
-            if (j == 6) v += c.eps_u * L.u[T + t];
-            for (int k = 0; k < NC; ++k) {
-                int ia, ib; double ca, cb; con_pat(k, ia, ca, ib, cb);
-                if (ia == j) v += ca * L.cl[t * NC + k];
-                if (ib == j) v += cb * L.cl[t * NC + k];
-            }
-            L.gst[i] = v;
-        }
-        for (int i = tid; i < NC * T; i += NT) {
-            int t = i / NC, k = i % NC;
+            // inequality rows of this stage
             double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-            L.rp[i] = con_on(t, k) ? con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]) + L.cw[i] - con_rhs(c, k) : 0.0;
+            double lam[NC], dg[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                int i = t * NC + k;
+                bool on = con_on(t, k);
+                lam[k] = L.cl[i]; dg[k] = on ? L.cl[i] / L.cw[i] : 0.0;
+                L.rp[i] = on ? con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]) + L.cw[i] - con_rhs(c, k) : 0.0;
+                L.rc[i] = L.cl[i] * L.cw[i];                              // affine (predictor) target
+            }
+            double *bw = &L.bw[5 * t];
+            bw[0] = dg[0] + dg[1]; bw[1] = dg[2] + dg[3]; bw[2] = dg[4] + dg[5]; bw[3] = dg[6] + dg[7]; bw[4] = dg[8] + dg[9];
+            double y3, y4, y5, y6, y7; con_T(lam, t, y3, y4, y5, y6, y7);
+            // stage gradient gst = J' gw + direct terms + C' lam
+            const double *J = &L.Jm[32 * t];
+            double *g = &L.gst[8 * t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = J[j] * gw[0] + J[8 + j] * gw[1] + J[16 + j] * gw[2] + J[24 + j] * gw[3];
+            g[3] += y3; g[4] += y4;
+            g[5] += 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t] + y5;
+            g[6] += c.eps_u * L.u[T + t] + y6;
+            g[7] += y7;
         }
         __syncthreads();
-        // ---- (3) reduced gradient by an adjoint sweep (wave 0), norms ----------------------------
+        // ---- (3) stage Hessian bases  J' Hw J + direct + barrier  (all threads), predictor rhs ----------
+        for (int i = tid; i < 64 * T; i += NT) {
+            int t = i >> 6, r = (i >> 3) & 7, q = i & 7;
+            const double *J = &L.Jm[32 * t], *Hw = &L.Hw[16 * t], *bw = &L.bw[5 * t];
+            double m = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                double acc = Hw[4 * x] * J[q] + Hw[4 * x + 1] * J[8 + q] + Hw[4 * x + 2] * J[16 + q] + Hw[4 * x + 3] * J[24 + q];
+                m += J[8 * x + r] * acc;
+            }
+            if (r == q) {
+                if (r == 5) m += 2 * c.wu + c.eps_u + bw[0] + bw[3];
+                else if (r == 6) m += c.eps_u + bw[1] + bw[4];
+                else if (r == 7) m += bw[2];
+                else if (r == 3) m += bw[3];
+                else if (r == 4) m += bw[4];
+            } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= bw[3];
+            else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= bw[4];
+            L.base[i] = m;
+        }
+        build_gh();
+        __syncthreads();
+        mark(2);
+        // ---- (4) wave 0: Riccati matrix recursion fused with the predictor's backward vector sweep;
+        //          wave 1: adjoint sweep for the reduced gradient -----------------------------------
+        bool fail = false;
         if (wave == 0) {
-            if (lane < 8) L.pv[lane] = 0;
-            wsync();
+            double p[5] = {0, 0, 0, 0, 0};
+            double Pm[5][5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) Pm[r][q] = 0;
+            struct MC { double a13, a23, B[6], M[36], g[8]; };     // M: upper triangle of the 8x8 base, row-major
+            auto load_mc = [&](int t, MC &k) {
+                const double *Ap = &L.Ak[9 * t], *Bp = &L.Bk[6 * t], *bp = &L.base[64 * t], *gp = &L.gh[8 * t];
+                k.a13 = Ap[2]; k.a23 = Ap[5];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) k.B[i] = Bp[i];
+                int o = 0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int q = r; q < 8; ++q) k.M[o++] = bp[r * 8 + q];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) k.g[i] = gp[i];
+            };
+            MC cur, nxt;
+            load_mc(T - 1, cur);
             for (int t = T - 1; t >= 0; --t) {
-                double v = 0;
-                if (lane < 8) v = L.gst[8 * t + lane] + Ft_p(&L.Ak[9 * t], &L.Bk[6 * t], L.pv, lane);
-                wsync();
-                if (lane < 8) { L.gh[8 * t + lane] = v; if (lane < 5) L.pv[lane] = v; }
-                wsync();
+                if (t > 0) load_mc(t - 1, nxt);
+                double M[8][8];
+                {
+                    int o = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+#pragma unroll
+                        for (int q = r; q < 8; ++q) M[r][q] = cur.M[o++];
+                }
+                const double a13 = cur.a13, a23 = cur.a23;
+                const double *B = cur.B;
+                // A = [[1,0,a13],[0,1,a23],[0,0,1]] in all three motion models (rda_solver.py:955,971,987)
+                // T1 = Pss A ; T2 = Pss B + Psu ; T3 = Pus B + Puu
+                double T1[3][3], T2[3][2], T3[2][2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    T1[r][0] = Pm[r][0]; T1[r][1] = Pm[r][1]; T1[r][2] = Pm[r][0] * a13 + Pm[r][1] * a23 + Pm[r][2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) T2[r][q] = Pm[r][0] * B[q] + Pm[r][1] * B[2 + q] + Pm[r][2] * B[4 + q] + Pm[r][3 + q];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) T3[r][q] = Pm[3 + r][0] * B[q] + Pm[3 + r][1] * B[2 + q] + Pm[3 + r][2] * B[4 + q] + Pm[3 + r][3 + q];
+                // M += F' P F (upper triangle): rows 0,1 of A' are unit rows, row 2 = (a13, a23, 1)
+                M[0][0] += T1[0][0]; M[0][1] += T1[0][1]; M[0][2] += T1[0][2];
+                M[1][1] += T1[1][1]; M[1][2] += T1[1][2];
+                M[2][2] += a13 * T1[0][2] + a23 * T1[1][2] + T1[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    M[0][5 + q] += T2[0][q]; M[1][5 + q] += T2[1][q];
+                    M[2][5 + q] += a13 * T2[0][q] + a23 * T2[1][q] + T2[2][q];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = r; q < 2; ++q) M[5 + r][5 + q] += B[r] * T2[0][q] + B[2 + r] * T2[1][q] + B[4 + r] * T2[2][q] + T3[r][q];
+                // inverse of Mvv (rows/cols 5..7) by the adjugate: one division on the critical path
+                double m00 = M[5][5], m01 = M[5][6], m02 = M[5][7], m11 = M[6][6], m12 = M[6][7], m22 = M[7][7];
+                double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+                double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
+                double det = m00 * c00 + m01 * c01 + m02 * c02;
+                if (!(m00 > 0) || !(c22 > 0) || !(det > 0)) fail = true;
+                double id = 1.0 / det;
+                double n00 = c00 * id, n01 = c01 * id, n02 = c02 * id, n11 = c11 * id, n12 = c12 * id, n22 = c22 * id;
+                // W = Mxv Minv (5x3); P_new = Mxx - W Mxv'
+                double W[5][3];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    double x0 = M[r][5], x1 = M[r][6], x2 = M[r][7];
+                    W[r][0] = x0 * n00 + x1 * n01 + x2 * n02;
+                    W[r][1] = x0 * n01 + x1 * n11 + x2 * n12;
+                    W[r][2] = x0 * n02 + x1 * n12 + x2 * n22;
+                }
+#pragma unroll
+                for (int r = 0; r < 5; ++r)
+#pragma unroll
+                    for (int q = r; q < 5; ++q) {
+                        double v = M[r][q] - (W[r][0] * M[q][5] + W[r][1] * M[q][6] + W[r][2] * M[q][7]);
+                        Pm[r][q] = v; Pm[q][r] = v;
+                    }
+                // predictor's backward vector step with the same factors (still in registers)
+                const double *g = cur.g;
+                double gv0 = g[5] + B[0] * p[0] + B[2] * p[1] + B[4] * p[2] + p[3];
+                double gv1 = g[6] + B[1] * p[0] + B[3] * p[1] + B[5] * p[2] + p[4];
+                double gv2 = g[7];
+                double gx0 = g[0] + p[0], gx1 = g[1] + p[1], gx2 = g[2] + a13 * p[0] + a23 * p[1] + p[2];
+                p[0] = gx0 - (W[0][0] * gv0 + W[0][1] * gv1 + W[0][2] * gv2);
+                p[1] = gx1 - (W[1][0] * gv0 + W[1][1] * gv1 + W[1][2] * gv2);
+                p[2] = gx2 - (W[2][0] * gv0 + W[2][1] * gv1 + W[2][2] * gv2);
+                p[3] = g[3] - (W[3][0] * gv0 + W[3][1] * gv1 + W[3][2] * gv2);
+                p[4] = g[4] - (W[4][0] * gv0 + W[4][1] * gv1 + W[4][2] * gv2);
+                if (lane == 0) {
+                    double *Mi = &L.Minv[9 * t], *X = &L.Wst[15 * t];
+                    Mi[0] = n00; Mi[1] = n01; Mi[2] = n02; Mi[3] = n01; Mi[4] = n11; Mi[5] = n12; Mi[6] = n02; Mi[7] = n12; Mi[8] = n22;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) { X[3 * r] = W[r][0]; X[3 * r + 1] = W[r][1]; X[3 * r + 2] = W[r][2]; }
+                    L.kk[3 * t] = -(n00 * gv0 + n01 * gv1 + n02 * gv2);
+                    L.kk[3 * t + 1] = -(n01 * gv0 + n11 * gv1 + n12 * gv2);
+                    L.kk[3 * t + 2] = -(n02 * gv0 + n12 * gv1 + n22 * gv2);
+                }
+                cur = nxt;
+            }
+            wsync();
+        } else if (wave == 1) {
+            double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+            for (int t = T - 1; t >= 0; --t) {
+                const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *g = &L.gst[8 * t];
+                double g0 = g[0] + A[0] * p0 + A[3] * p1 + A[6] * p2;
+                double g1 = g[1] + A[1] * p0 + A[4] * p1 + A[7] * p2;
+                double g2 = g[2] + A[2] * p0 + A[5] * p1 + A[8] * p2;
+                double v0 = g[5] + B[0] * p0 + B[2] * p1 + B[4] * p2 + p3;
+                double v1 = g[6] + B[1] * p0 + B[3] * p1 + B[5] * p2 + p4;
+                if (lane == 0) { L.gad[3 * t] = v0; L.gad[3 * t + 1] = v1; L.gad[3 * t + 2] = g[7]; }
+                p0 = g0; p1 = g1; p2 = g2; p3 = g[3]; p4 = g[4];
             }
         }
         __syncthreads();
+        mark(4);
         double rdn = 0, gn = 0, rpn = 0, mu = 0;
-        for (int i = tid; i < 8 * T; i += NT) {
-            int j = i & 7;
-            if (j >= 5) { double v = fabs(L.gh[i]); if (v > rdn) rdn = v; }
-        }
+        for (int i = tid; i < 3 * T; i += NT) { double v = fabs(L.gad[i]); if (v > rdn) rdn = v; }
         for (int i = tid; i < 4 * T; i += NT) { double v = fabs(L.gw[i]); if (v > gn) gn = v; }
         for (int i = tid; i < NC * T; i += NT) { double v = fabs(L.rp[i]); if (v > rpn) rpn = v; mu += L.cl[i] * L.cw[i]; }
         rdn = block_reduce(rdn, L.red, tid, true);
@@ -330,149 +567,25 @@ __device__ inline void solve(const Args &a, double *smem)
         mu = block_reduce(mu, L.red, tid, false) / mcnt;
         double sc = 1 + gn;
         if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
+        if (__syncthreads_or(fail ? 1 : 0)) { status = 2; break; }
+        mark(5);
 
         double sigma = 0;
-        bool fail = false;
         for (int pass = 0; pass < 2; ++pass) {
-            // ---- (4) complementarity target and Newton gradient -------------------------------------
-            for (int i = tid; i < NC * T; i += NT)
-                L.rc[i] = L.cl[i] * L.cw[i] + (pass ? L.dl[i] * L.dw[i] - sigma * mu : 0.0);
-            __syncthreads();
-            for (int i = tid; i < 8 * T; i += NT) {
-                int t = i >> 3, j = i & 7;
-                double v = L.gst[i];
-                for (int k = 0; k < NC; ++k) {
-                    if (!con_on(t, k)) continue;
-                    int ia, ib; double ca, cb; con_pat(k, ia, ca, ib, cb);
-                    double q = (L.cl[t * NC + k] * L.rp[t * NC + k] - L.rc[t * NC + k]) / L.cw[t * NC + k];
-                    if (ia == j) v += ca * q;
-                    if (ib == j) v += cb * q;
-                }
-                L.gh[i] = v;
+            if (pass == 1) {
+                // corrector right-hand side, vector-only backward sweep with the stored factors
+                for (int i = tid; i < NC * T; i += NT) L.rc[i] = L.cl[i] * L.cw[i] + L.dl[i] * L.dw[i] - sigma * mu;
+                __syncthreads();
+                build_gh();
+                __syncthreads();
+                if (wave == 0) { bwd_all(lane); wsync(); }
             }
+            mark(6);
+            if (wave == 0) fwd_all(lane);
             __syncthreads();
-            // ---- (5) Riccati backward sweep (wave 0) ---------------------------------------------------
-            if (wave == 0) {
-                if (lane < 25) L.P[lane] = 0;
-                if (lane < 8) L.pv[lane] = 0;
-                wsync();
-                for (int t = T - 1; t >= 0; --t) {
-                    const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t];
-                    if (pass == 0) {
-                        // W6 = [Hss+Pss Psu Hsd; Pus Puu 0; Hds 0 Hdd]
-                        if (lane < 36) {
-                            int r = lane / 6, q = lane % 6;
-                            const double *Hw = &L.Hw[10 * t];
-                            double v = 0;
-                            if (r < 5 && q < 5) v = L.P[r * 5 + q];
-                            int rr = r < 3 ? r : (r == 5 ? 3 : -1), qq = q < 3 ? q : (q == 5 ? 3 : -1);
-                            if (rr >= 0 && qq >= 0) {
-                                int lo = rr < qq ? rr : qq, hi = rr < qq ? qq : rr;
-                                const int base[4] = { 0, 4, 7, 9 };
-                                v += Hw[base[lo] + (hi - lo)];
-                            }
-                            L.W6[lane] = v;
-                        }
-                        wsync();
-                        int i = lane >> 3, j = lane & 7;
-                        double m = 0;
-                        for (int r = 0; r < 6; ++r) {
-                            double kr = Kt(A, B, r, i);
-                            if (kr == 0.0) continue;
-                            double acc = 0;
-                            for (int q = 0; q < 6; ++q) acc += L.W6[r * 6 + q] * Kt(A, B, q, j);
-                            m += kr * acc;
-                        }
-                        // direct objective terms and barrier terms
-                        if (i == 5 && j == 5) m += 2 * c.wu + c.eps_u;
-                        if (i == 6 && j == 6) m += c.eps_u;
-                        for (int k = 0; k < NC; ++k) {
-                            if (!con_on(t, k)) continue;
-                            int ia, ib; double ca, cb; con_pat(k, ia, ca, ib, cb);
-                            double dg = L.cl[t * NC + k] / L.cw[t * NC + k];
-                            double ci = (ia == i ? ca : 0.0) + (ib == i ? cb : 0.0);
-                            double cj = (ia == j ? ca : 0.0) + (ib == j ? cb : 0.0);
-                            m += dg * ci * cj;
-                        }
-                        L.Mm[lane] = m;
-                        wsync();
-                        // Cholesky of Mvv (rows/cols 5..7), every lane redundantly
-                        double m00 = L.Mm[5 * 8 + 5], m10 = L.Mm[6 * 8 + 5], m20 = L.Mm[7 * 8 + 5];
-                        double m11 = L.Mm[6 * 8 + 6], m21 = L.Mm[7 * 8 + 6], m22 = L.Mm[7 * 8 + 7];
-                        double l00 = sqrt(m00), l10 = m10 / l00, l20 = m20 / l00;
-                        double d11 = m11 - l10 * l10; double l11 = sqrt(d11), l21 = (m21 - l20 * l10) / l11;
-                        double d22 = m22 - l20 * l20 - l21 * l21; double l22 = sqrt(d22);
-                        if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0)) fail = true;
-                        // inverse of L (lower): Li
-                        double i00 = 1 / l00, i11 = 1 / l11, i22 = 1 / l22;
-                        double i10 = -l10 * i00 * i11, i21 = -l21 * i11 * i22, i20 = -(l20 * i00 + l21 * i10) * i22;
-                        // Minv = Li' Li
-                        double n00 = i00 * i00 + i10 * i10 + i20 * i20, n01 = i10 * i11 + i20 * i21, n02 = i20 * i22;
-                        double n11 = i11 * i11 + i21 * i21, n12 = i21 * i22, n22 = i22 * i22;
-                        if (lane == 0) {
-                            double *Mi = &L.Minv[9 * t];
-                            Mi[0] = n00; Mi[1] = n01; Mi[2] = n02; Mi[3] = n01; Mi[4] = n11; Mi[5] = n12; Mi[6] = n02; Mi[7] = n12; Mi[8] = n22;
-                        }
-                        if (lane < 15) L.Mxv[15 * t + lane] = L.Mm[(lane / 3) * 8 + 5 + (lane % 3)];
-                        wsync();
-                        // P_t = Mxx - Mxv Minv Mvx
-                        if (lane < 25) {
-                            int r = lane / 5, q = lane % 5;
-                            const double *Mi = &L.Minv[9 * t], *Xr = &L.Mxv[15 * t + 3 * r], *Xq = &L.Mxv[15 * t + 3 * q];
-                            double acc = 0;
-                            for (int x = 0; x < 3; ++x) acc += Xr[x] * (Mi[3 * x] * Xq[0] + Mi[3 * x + 1] * Xq[1] + Mi[3 * x + 2] * Xq[2]);
-                            L.P[lane] = L.Mm[r * 8 + q] - acc;
-                        }
-                    }
-                    // vector part: ghat_t = gh_t + F' p_{t+1}; gv; p_t = ghat_x - Mxv Minv gv
-                    double v = 0;
-                    if (lane < 8) v = L.gh[8 * t + lane] + Ft_p(A, B, L.pv, lane);
-                    wsync();
-                    if (lane < 8) { L.gh[8 * t + lane] = v; if (lane >= 5) L.gv[3 * t + lane - 5] = v; }
-                    wsync();
-                    if (lane < 5) {
-                        const double *Mi = &L.Minv[9 * t], *X = &L.Mxv[15 * t + 3 * lane], *g = &L.gv[3 * t];
-                        double acc = 0;
-                        for (int x = 0; x < 3; ++x) acc += X[x] * (Mi[3 * x] * g[0] + Mi[3 * x + 1] * g[1] + Mi[3 * x + 2] * g[2]);
-                        L.pv[lane] = v - acc;
-                    }
-                    wsync();
-                }
-                // ---- (6) forward sweep --------------------------------------------------------------------
-                // dx (5) in pv[0..4]
-                if (lane < 8) L.pv[lane] = 0;
-                wsync();
-                for (int t = 0; t < T; ++t) {
-                    const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t];
-                    double dv = 0;
-                    if (lane < 3) {
-                        const double *Mi = &L.Minv[9 * t], *g = &L.gv[3 * t];
-                        double r3[3];
-                        for (int x = 0; x < 3; ++x) {
-                            double acc = g[x];
-                            for (int r = 0; r < 5; ++r) acc += L.Mxv[15 * t + 3 * r + x] * L.pv[r];
-                            r3[x] = acc;
-                        }
-                        dv = -(Mi[3 * lane] * r3[0] + Mi[3 * lane + 1] * r3[1] + Mi[3 * lane + 2] * r3[2]);
-                    }
-                    wsync();
-                    if (lane < 3) L.dy[8 * t + 5 + lane] = dv;
-                    if (lane < 5) L.dy[8 * t + lane] = L.pv[lane];
-                    wsync();
-                    double nx = 0;
-                    if (lane < 3) {
-                        const double *y = &L.dy[8 * t];
-                        nx = A[3 * lane] * y[0] + A[3 * lane + 1] * y[1] + A[3 * lane + 2] * y[2] + B[2 * lane] * y[5] + B[2 * lane + 1] * y[6];
-                    } else if (lane < 5) nx = L.dy[8 * t + 5 + (lane - 3)];
-                    wsync();
-                    if (lane < 5) L.pv[lane] = nx;
-                    wsync();
-                }
-                // dx_T (state step at the horizon end) kept in pv[0..2]
-            }
-            __syncthreads();
-            // ---- (7) slack / multiplier steps, step length -------------------------------------------
-            double al = 1.0, muaff = 0;
+            mark(7);
+            // ---- slack / multiplier steps, step length ------------------------------------------------
+            double al = 1.0;
             for (int i = tid; i < NC * T; i += NT) {
                 int t = i / NC, k = i % NC;
                 if (!con_on(t, k)) { L.dw[i] = 0; L.dl[i] = 0; continue; }
@@ -486,11 +599,9 @@ __device__ inline void solve(const Args &a, double *smem)
             }
             al = -block_reduce(-al, L.red, tid, true);
             if (pass == 0) {
-                for (int i = tid; i < NC * T; i += NT) muaff += (L.cl[i] + al * L.dl[i]) * (L.cw[i] + al * L.dw[i]);
-                muaff = block_reduce(muaff, L.red, tid, false) / mcnt;
-                double r = muaff / mu; sigma = r * r * r;
+                // centering parameter from the predictor step length, floored (see the oracle for why)
+                double q = 1 - al; sigma = q * q * q; if (sigma < 0.03) sigma = 0.03;
             } else {
-                // ---- (8) update the iterate ---------------------------------------------------------------
                 for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += al * L.dl[i]; }
                 if (tid < T) {
                     int t = tid; const double *y = &L.dy[8 * t];
@@ -500,9 +611,8 @@ __device__ inline void solve(const Args &a, double *smem)
                 if (tid < 3) L.s[tid * (T + 1) + T] += al * L.pv[tid];
                 __syncthreads();
             }
+            mark(8);
         }
-        int anyfail = __syncthreads_or(fail ? 1 : 0);
-        if (anyfail) { status = 2; break; }
     }
     __syncthreads();
     // consistent final rollout (removes accumulated rounding in s)
