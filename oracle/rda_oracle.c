@@ -540,7 +540,7 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                 mu_aff /= mc;
                 /* centering parameter from the predictor step length, floored: the classical (mu_aff/mu)^3
                  * rule can cycle on the piecewise-quadratic hinge terms (observed with ro1 = 1) */
-                { double q = 1 - al; sigma = q * q * q; if (sigma < 0.03) sigma = 0.03; }
+                { double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03; sigma = q * q * q; if (sigma < fl) sigma = fl; }
             }
         }
         double al = 1.0;

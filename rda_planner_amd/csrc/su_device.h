@@ -81,7 +81,11 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
     }
 }
 
-// LDS carve-up (doubles)
+// LDS carve-up (doubles).  Per-stage constants of the serial sweeps are packed into 16-byte aligned records so
+// that they are fetched with ds_read_b128 and prefetched one stage ahead.
+constexpr int RM = 52;   // matrix-sweep record: upper triangle of the 8x8 stage Hessian base (36) | B (6) | a13 a23 | pad
+constexpr int RV = 40;   // vector-sweep record: A (9) | B (6) | W (15) | Minv sym (6) | kk (3) | pad
+__device__ __host__ inline int ev(int n) { return (n + 1) & ~1; }
 struct Lds {
     double *s, *u, *d, *phin, *ref, *Ak, *Bk, *Ck, *Q0, *Q1, *Q2;
     double *Jm;        // [T][32] d(s_next, d)/dy : 4x8 per stage (constant during the solve)
@@ -89,29 +93,31 @@ struct Lds {
     double *hs;        // [T][9]  hinge sums
     double *Hw, *gw;   // [T][16], [T][4]
     double *bw;        // [T][5]  barrier weights (u0 box, u1 box, d box, rate u0, rate u1)
+    double *cy;        // [T][5]  C'lam per stage (entries 3..7 of y)
     double *gst;       // [T][8]  stage gradient (objective + C'lam)
     double *gh;        // [T][8]  Newton right-hand side gradient
     double *gad;       // [T][3]  reduced gradient (adjoint sweep)
-    double *base;      // [T][64] stage Hessian without the cost-to-go term
+    double *recM;      // [T][RM]
+    double *recV;      // [T][RV]
     double *cw, *cl, *rp, *rc, *dw, *dl;   // [T][NC]
-    double *Minv, *Wst, *kk, *dy;          // [T][9], [T][15], [T][3], [T][8]
+    double *dy;                            // [T][8]
     double *pv, *red;                      // 8, NT
     __device__ void carve(double *b, int T) {
         double *p = b;
-        s = p; p += 3 * (T + 1); u = p; p += 2 * T; d = p; p += T; phin = p; p += T; ref = p; p += 3 * (T + 1);
-        Ak = p; p += 9 * T; Bk = p; p += 6 * T; Ck = p; p += 3 * T; Q0 = p; p += T; Q1 = p; p += T; Q2 = p; p += T;
-        Jm = p; p += 32 * T; part = p; p += 9 * NT; hs = p; p += 9 * T; Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += 5 * T;
-        gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += 3 * T; base = p; p += 64 * T;
+        s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
+        Ak = p; p += ev(9 * T); Bk = p; p += 6 * T; Ck = p; p += ev(3 * T); Q0 = p; p += ev(T); Q1 = p; p += ev(T); Q2 = p; p += ev(T);
+        Jm = p; p += 32 * T; hs = p; p += ev(9 * T); Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += ev(5 * T); cy = p; p += ev(5 * T);
+        gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += ev(3 * T); recM = p; part = p; p += (RM * T > 9 * NT ? RM * T : 9 * NT); recV = p;   // part (phase 1) and recM (phases 3-4) never live together
+         p += RV * T;
         cw = p; p += NC * T; cl = p; p += NC * T; rp = p; p += NC * T; rc = p; p += NC * T; dw = p; p += NC * T; dl = p; p += NC * T;
-        Minv = p; p += 9 * T; Wst = p; p += 15 * T; kk = p; p += 3 * T; dy = p; p += 8 * T;
-        pv = p; p += 8; red = p; p += NT;
+        dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT;
     }
 };
 inline size_t lds_bytes(int T)
 {
-    size_t n = (size_t)3 * (T + 1) + 2 * T + T + T + 3 * (T + 1) + 9 * T + 6 * T + 3 * T + 3 * T
-             + 32 * T + 9 * NT + 9 * T + 16 * T + 4 * T + 5 * T + 8 * T + 8 * T + 3 * T + 64 * T + 6 * NC * T
-             + 9 * T + 15 * T + 3 * T + 8 * T + 8 + NT;
+    size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 3 * ev(T)
+             + 32 * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (RM * T > 9 * NT ? RM * T : 9 * NT) + RV * T
+             + 6 * NC * T + 8 * T + 8 + NT;
     return n * sizeof(double);
 }
 
@@ -185,6 +191,10 @@ __device__ inline void solve(const Args &a, double *smem)
             for (int q = 0; q < 2; ++q) J[r * 8 + 5 + q] = L.Bk[6 * t + 2 * r + q];
         }
         J[3 * 8 + 7] = 1.0;
+        // constant parts of the sweep records
+        double *rv = &L.recV[RV * t];
+        for (int i = 0; i < 6; ++i) rv[9 + i] = L.Bk[6 * t + i];
+        for (int i = 0; i < 9; ++i) rv[i] = L.Ak[9 * t + i];
     }
     __syncthreads();
     // ---- rotation-consistency penalty -> scalar quadratic per stage --------------
@@ -255,80 +265,169 @@ __device__ inline void solve(const Args &a, double *smem)
             o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3] + y3; o[4] = g[4] + y4; o[5] = g[5] + y5; o[6] = g[6] + y6; o[7] = g[7] + y7;
         }
     };
-    // vector-only backward sweep with the stored factors (calling wave, redundant lanes)
-    struct BC { double A[9], B[6], W[15], Mi[6], g[8]; };
-    auto load_bc = [&](int t, BC &k) {
-        const double *Ap = &L.Ak[9 * t], *Bp = &L.Bk[6 * t], *Wp = &L.Wst[15 * t], *Mp = &L.Minv[9 * t], *gp = &L.gh[8 * t];
+    // ---- serial sweeps (wave 0; every lane redundantly, all state in registers) -----------------------------
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    struct RecV { d2 v[RV / 2]; };
+    struct RecM { d2 v[RM / 2]; };
+    struct RecG { d2 v[4]; };
+    // The records are wave-uniform; an opaque VGPR offset keeps the fetches as plain vector LDS loads (otherwise
+    // the compiler scalarises every value through v_readlane_b32 with a wait per group).
+    auto opaque = [](int off) { asm volatile("" : "+v"(off)); return off; };
+    auto ldV = [&](int t, RecV &k) {
+        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(L.recV + opaque(RV * t), 16));
 #pragma unroll
-        for (int i = 0; i < 9; ++i) k.A[i] = Ap[i];
+        for (int i = 0; i < RV / 2; ++i) k.v[i] = q[i]; };
+    auto ldM = [&](int t, RecM &k) {
+        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(L.recM + opaque(RM * t), 16));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) k.B[i] = Bp[i];
+        for (int i = 0; i < RM / 2; ++i) k.v[i] = q[i]; };
+    auto ldG = [&](int t, RecG &k) {
+        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(L.gh + opaque(8 * t), 16));
 #pragma unroll
-        for (int i = 0; i < 15; ++i) k.W[i] = Wp[i];
-        k.Mi[0] = Mp[0]; k.Mi[1] = Mp[1]; k.Mi[2] = Mp[2]; k.Mi[3] = Mp[4]; k.Mi[4] = Mp[5]; k.Mi[5] = Mp[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) k.g[i] = gp[i];
+        for (int i = 0; i < 4; ++i) k.v[i] = q[i]; };
+#define RVAL(k, i) ((k).v[(i) >> 1][(i) & 1])
+    // one backward vector step: p <- ghat_x - W ghat_v ; stores kk = -Minv ghat_v
+    auto bwd_step = [&](int t, const RecV &k, const RecG &gg, double (&p)[5], int lane_) {
+        const double g0 = RVAL(gg, 0), g1 = RVAL(gg, 1), g2 = RVAL(gg, 2), g3 = RVAL(gg, 3), g4 = RVAL(gg, 4), g5 = RVAL(gg, 5), g6 = RVAL(gg, 6), g7 = RVAL(gg, 7);
+        double gv0 = g5 + RVAL(k, 9) * p[0] + RVAL(k, 11) * p[1] + RVAL(k, 13) * p[2] + p[3];
+        double gv1 = g6 + RVAL(k, 10) * p[0] + RVAL(k, 12) * p[1] + RVAL(k, 14) * p[2] + p[4];
+        double gv2 = g7;
+        double gx0 = g0 + RVAL(k, 0) * p[0] + RVAL(k, 3) * p[1] + RVAL(k, 6) * p[2];
+        double gx1 = g1 + RVAL(k, 1) * p[0] + RVAL(k, 4) * p[1] + RVAL(k, 7) * p[2];
+        double gx2 = g2 + RVAL(k, 2) * p[0] + RVAL(k, 5) * p[1] + RVAL(k, 8) * p[2];
+        p[0] = gx0 - (RVAL(k, 15) * gv0 + RVAL(k, 16) * gv1 + RVAL(k, 17) * gv2);
+        p[1] = gx1 - (RVAL(k, 18) * gv0 + RVAL(k, 19) * gv1 + RVAL(k, 20) * gv2);
+        p[2] = gx2 - (RVAL(k, 21) * gv0 + RVAL(k, 22) * gv1 + RVAL(k, 23) * gv2);
+        p[3] = g3 - (RVAL(k, 24) * gv0 + RVAL(k, 25) * gv1 + RVAL(k, 26) * gv2);
+        p[4] = g4 - (RVAL(k, 27) * gv0 + RVAL(k, 28) * gv1 + RVAL(k, 29) * gv2);
+        if (lane_ == 0) {
+            double *o = &L.recV[RV * t + 36];
+            o[0] = -(RVAL(k, 30) * gv0 + RVAL(k, 31) * gv1 + RVAL(k, 32) * gv2);
+            o[1] = -(RVAL(k, 31) * gv0 + RVAL(k, 33) * gv1 + RVAL(k, 34) * gv2);
+            o[2] = -(RVAL(k, 32) * gv0 + RVAL(k, 34) * gv1 + RVAL(k, 35) * gv2);
+        }
     };
     auto bwd_all = [&](int lane_) {
         double p[5] = {0, 0, 0, 0, 0};
-        BC cur, nxt;
-        load_bc(T - 1, cur);
-        for (int t = T - 1; t >= 0; --t) {
-            if (t > 0) load_bc(t - 1, nxt);
-            const double *A = cur.A, *B = cur.B, *g = cur.g, *W = cur.W;
-            double gv0 = g[5] + B[0] * p[0] + B[2] * p[1] + B[4] * p[2] + p[3];
-            double gv1 = g[6] + B[1] * p[0] + B[3] * p[1] + B[5] * p[2] + p[4];
-            double gv2 = g[7];
-            double gx0 = g[0] + A[0] * p[0] + A[3] * p[1] + A[6] * p[2];
-            double gx1 = g[1] + A[1] * p[0] + A[4] * p[1] + A[7] * p[2];
-            double gx2 = g[2] + A[2] * p[0] + A[5] * p[1] + A[8] * p[2];
-            p[0] = gx0 - (W[0] * gv0 + W[1] * gv1 + W[2] * gv2);
-            p[1] = gx1 - (W[3] * gv0 + W[4] * gv1 + W[5] * gv2);
-            p[2] = gx2 - (W[6] * gv0 + W[7] * gv1 + W[8] * gv2);
-            p[3] = g[3] - (W[9] * gv0 + W[10] * gv1 + W[11] * gv2);
-            p[4] = g[4] - (W[12] * gv0 + W[13] * gv1 + W[14] * gv2);
-            if (lane_ == 0) {
-                const double *Mi = cur.Mi;
-                L.kk[3 * t] = -(Mi[0] * gv0 + Mi[1] * gv1 + Mi[2] * gv2);
-                L.kk[3 * t + 1] = -(Mi[1] * gv0 + Mi[3] * gv1 + Mi[4] * gv2);
-                L.kk[3 * t + 2] = -(Mi[2] * gv0 + Mi[4] * gv1 + Mi[5] * gv2);
+        RecV ka, kb; RecG ga, gb;
+        ldV(T - 1, ka); ldG(T - 1, ga);
+        for (int t = T - 1; t >= 0; t -= 2) {
+            if (t >= 1) { ldV(t - 1, kb); ldG(t - 1, gb); }
+            bwd_step(t, ka, ga, p, lane_);
+            if (t >= 1) {
+                if (t >= 2) { ldV(t - 2, ka); ldG(t - 2, ga); }
+                bwd_step(t - 1, kb, gb, p, lane_);
             }
-            cur = nxt;
         }
     };
-    // forward sweep: dv = kk - W' dx ; dx+ = F [dx; dv]   (calling wave, redundant lanes)
-    struct FC { double A[9], B[6], W[15], kk[3]; };
-    auto load_fc = [&](int t, FC &k) {
-        const double *Ap = &L.Ak[9 * t], *Bp = &L.Bk[6 * t], *Wp = &L.Wst[15 * t], *kp = &L.kk[3 * t];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) k.A[i] = Ap[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) k.B[i] = Bp[i];
-#pragma unroll
-        for (int i = 0; i < 15; ++i) k.W[i] = Wp[i];
-        k.kk[0] = kp[0]; k.kk[1] = kp[1]; k.kk[2] = kp[2];
+    // one forward step: dv = kk - W' dx ; dx+ = F [dx; dv]
+    auto fwd_step = [&](int t, const RecV &k, double (&dx)[5], int lane_) {
+        double v0 = RVAL(k, 36) - (RVAL(k, 15) * dx[0] + RVAL(k, 18) * dx[1] + RVAL(k, 21) * dx[2] + RVAL(k, 24) * dx[3] + RVAL(k, 27) * dx[4]);
+        double v1 = RVAL(k, 37) - (RVAL(k, 16) * dx[0] + RVAL(k, 19) * dx[1] + RVAL(k, 22) * dx[2] + RVAL(k, 25) * dx[3] + RVAL(k, 28) * dx[4]);
+        double v2 = RVAL(k, 38) - (RVAL(k, 17) * dx[0] + RVAL(k, 20) * dx[1] + RVAL(k, 23) * dx[2] + RVAL(k, 26) * dx[3] + RVAL(k, 29) * dx[4]);
+        if (lane_ == 0) {
+            double *y = &L.dy[8 * t];
+            y[0] = dx[0]; y[1] = dx[1]; y[2] = dx[2]; y[3] = dx[3]; y[4] = dx[4]; y[5] = v0; y[6] = v1; y[7] = v2;
+        }
+        double n0 = RVAL(k, 0) * dx[0] + RVAL(k, 1) * dx[1] + RVAL(k, 2) * dx[2] + RVAL(k, 9) * v0 + RVAL(k, 10) * v1;
+        double n1 = RVAL(k, 3) * dx[0] + RVAL(k, 4) * dx[1] + RVAL(k, 5) * dx[2] + RVAL(k, 11) * v0 + RVAL(k, 12) * v1;
+        double n2 = RVAL(k, 6) * dx[0] + RVAL(k, 7) * dx[1] + RVAL(k, 8) * dx[2] + RVAL(k, 13) * v0 + RVAL(k, 14) * v1;
+        dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = v0; dx[4] = v1;
     };
     auto fwd_all = [&](int lane_) {
         double dx[5] = {0, 0, 0, 0, 0};
-        FC cur, nxt;
-        load_fc(0, cur);
-        for (int t = 0; t < T; ++t) {
-            if (t + 1 < T) load_fc(t + 1, nxt);
-            const double *A = cur.A, *B = cur.B, *W = cur.W;
-            double v0 = cur.kk[0] - (W[0] * dx[0] + W[3] * dx[1] + W[6] * dx[2] + W[9] * dx[3] + W[12] * dx[4]);
-            double v1 = cur.kk[1] - (W[1] * dx[0] + W[4] * dx[1] + W[7] * dx[2] + W[10] * dx[3] + W[13] * dx[4]);
-            double v2 = cur.kk[2] - (W[2] * dx[0] + W[5] * dx[1] + W[8] * dx[2] + W[11] * dx[3] + W[14] * dx[4]);
-            if (lane_ == 0) {
-                double *y = &L.dy[8 * t];
-                y[0] = dx[0]; y[1] = dx[1]; y[2] = dx[2]; y[3] = dx[3]; y[4] = dx[4]; y[5] = v0; y[6] = v1; y[7] = v2;
+        RecV ka, kb;
+        ldV(0, ka);
+        for (int t = 0; t < T; t += 2) {
+            if (t + 1 < T) ldV(t + 1, kb);
+            fwd_step(t, ka, dx, lane_);
+            if (t + 1 < T) {
+                if (t + 2 < T) ldV(t + 2, ka);
+                fwd_step(t + 1, kb, dx, lane_);
             }
-            double n0 = A[0] * dx[0] + A[1] * dx[1] + A[2] * dx[2] + B[0] * v0 + B[1] * v1;
-            double n1 = A[3] * dx[0] + A[4] * dx[1] + A[5] * dx[2] + B[2] * v0 + B[3] * v1;
-            double n2 = A[6] * dx[0] + A[7] * dx[1] + A[8] * dx[2] + B[4] * v0 + B[5] * v1;
-            dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = v0; dx[4] = v1;
-            cur = nxt;
         }
         if (lane_ == 0) { L.pv[0] = dx[0]; L.pv[1] = dx[1]; L.pv[2] = dx[2]; }
+    };
+    // one Riccati matrix step fused with the predictor's backward vector step
+    auto mat_step = [&](int t, const RecM &k, const RecG &gg, double (&Pm)[5][5], double (&p)[5], bool &fail_, int lane_) {
+        double M[8][8];
+        {
+            int o = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int q = r; q < 8; ++q) { M[r][q] = RVAL(k, o); ++o; }
+        }
+        const double B0 = RVAL(k, 36), B1 = RVAL(k, 37), B2 = RVAL(k, 38), B3 = RVAL(k, 39), B4 = RVAL(k, 40), B5 = RVAL(k, 41);
+        const double a13 = RVAL(k, 42), a23 = RVAL(k, 43);
+        const double Bm[3][2] = { { B0, B1 }, { B2, B3 }, { B4, B5 } };
+        // A = [[1,0,a13],[0,1,a23],[0,0,1]] in all three motion models (rda_solver.py:955,971,987)
+        double T1c[3], T2[3][2], T3[2][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T1c[r] = Pm[r][0] * a13 + Pm[r][1] * a23 + Pm[r][2];                 // (Pss A)[:,2]
+#pragma unroll
+            for (int q = 0; q < 2; ++q) T2[r][q] = Pm[r][0] * Bm[0][q] + Pm[r][1] * Bm[1][q] + Pm[r][2] * Bm[2][q] + Pm[r][3 + q];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) T3[r][q] = Pm[3 + r][0] * Bm[0][q] + Pm[3 + r][1] * Bm[1][q] + Pm[3 + r][2] * Bm[2][q] + Pm[3 + r][3 + q];
+        // M += F' P F (upper triangle)
+        M[0][0] += Pm[0][0]; M[0][1] += Pm[0][1]; M[0][2] += T1c[0];
+        M[1][1] += Pm[1][1]; M[1][2] += T1c[1];
+        M[2][2] += a13 * T1c[0] + a23 * T1c[1] + T1c[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            M[0][5 + q] += T2[0][q]; M[1][5 + q] += T2[1][q];
+            M[2][5 + q] += a13 * T2[0][q] + a23 * T2[1][q] + T2[2][q];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = r; q < 2; ++q) M[5 + r][5 + q] += Bm[0][r] * T2[0][q] + Bm[1][r] * T2[1][q] + Bm[2][r] * T2[2][q] + T3[r][q];
+        // inverse of Mvv (rows/cols 5..7) by the adjugate: one division on the critical path
+        double m00 = M[5][5], m01 = M[5][6], m02 = M[5][7], m11 = M[6][6], m12 = M[6][7], m22 = M[7][7];
+        double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+        double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
+        double det = m00 * c00 + m01 * c01 + m02 * c02;
+        if (!(m00 > 0) || !(c22 > 0) || !(det > 0)) fail_ = true;
+        double id = 1.0 / det;
+        double n00 = c00 * id, n01 = c01 * id, n02 = c02 * id, n11 = c11 * id, n12 = c12 * id, n22 = c22 * id;
+        double W[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            double x0 = M[r][5], x1 = M[r][6], x2 = M[r][7];
+            W[r][0] = x0 * n00 + x1 * n01 + x2 * n02;
+            W[r][1] = x0 * n01 + x1 * n11 + x2 * n12;
+            W[r][2] = x0 * n02 + x1 * n12 + x2 * n22;
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int q = r; q < 5; ++q) {
+                double v = M[r][q] - (W[r][0] * M[q][5] + W[r][1] * M[q][6] + W[r][2] * M[q][7]);
+                Pm[r][q] = v; Pm[q][r] = v;
+            }
+        const double g0 = RVAL(gg, 0), g1 = RVAL(gg, 1), g2 = RVAL(gg, 2), g3 = RVAL(gg, 3), g4 = RVAL(gg, 4), g5 = RVAL(gg, 5), g6 = RVAL(gg, 6), g7 = RVAL(gg, 7);
+        double gv0 = g5 + B0 * p[0] + B2 * p[1] + B4 * p[2] + p[3];
+        double gv1 = g6 + B1 * p[0] + B3 * p[1] + B5 * p[2] + p[4];
+        double gv2 = g7;
+        double gx0 = g0 + p[0], gx1 = g1 + p[1], gx2 = g2 + a13 * p[0] + a23 * p[1] + p[2];
+        p[0] = gx0 - (W[0][0] * gv0 + W[0][1] * gv1 + W[0][2] * gv2);
+        p[1] = gx1 - (W[1][0] * gv0 + W[1][1] * gv1 + W[1][2] * gv2);
+        p[2] = gx2 - (W[2][0] * gv0 + W[2][1] * gv1 + W[2][2] * gv2);
+        p[3] = g3 - (W[3][0] * gv0 + W[3][1] * gv1 + W[3][2] * gv2);
+        p[4] = g4 - (W[4][0] * gv0 + W[4][1] * gv1 + W[4][2] * gv2);
+        if (lane_ == 0) {
+            double *o = &L.recV[RV * t + 15];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) { o[3 * r] = W[r][0]; o[3 * r + 1] = W[r][1]; o[3 * r + 2] = W[r][2]; }
+            o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22;
+            o[21] = -(n00 * gv0 + n01 * gv1 + n02 * gv2);
+            o[22] = -(n01 * gv0 + n11 * gv1 + n12 * gv2);
+            o[23] = -(n02 * gv0 + n12 * gv1 + n22 * gv2);
+        }
     };
 
     int status = 1, it;
@@ -342,14 +441,21 @@ __device__ inline void solve(const Args &a, double *smem)
             if (ract) {
                 const double px = L.s[rt + 1], py = L.s[(T + 1) + rt + 1], dd = L.d[rt];
                 const double *pax = a.ax + (size_t)rt * N, *pay = a.ay + (size_t)rt * N, *pb = a.blam + (size_t)rt * N, *pe = a.ee + (size_t)rt * N;
-                for (int n = rc_; n < N; n += nch) {
-                    double ax = pax[n], ay = pay[n];
-                    double Im = ax * px + ay * py - (pb[n] + pe[n]) - dd;
+                auto term = [&](double ax, double ay, double cb) {
+                    double Im = ax * px + ay * py - cb - dd;
                     if (!c.accelerated || Im < 0) {
                         sxx += ax * ax; sxy += ax * ay; syy += ay * ay; sx += ax; sy += ay; s1 += 1.0;
                         ix += Im * ax; iy += Im * ay; i1 += Im;
                     }
+                };
+                int n = rc_;
+                for (; n + 3 * nch < N; n += 4 * nch) {      // four independent loads in flight per array
+                    double a0 = pax[n], a1 = pax[n + nch], a2 = pax[n + 2 * nch], a3 = pax[n + 3 * nch];
+                    double b0 = pay[n], b1 = pay[n + nch], b2 = pay[n + 2 * nch], b3 = pay[n + 3 * nch];
+                    double c0 = pb[n] + pe[n], c1 = pb[n + nch] + pe[n + nch], c2 = pb[n + 2 * nch] + pe[n + 2 * nch], c3 = pb[n + 3 * nch] + pe[n + 3 * nch];
+                    term(a0, b0, c0); term(a1, b1, c1); term(a2, b2, c2); term(a3, b3, c3);
                 }
+                for (; n < N; n += nch) term(pax[n], pay[n], pb[n] + pe[n]);
             }
             double *pp = &L.part[tid * 9];
             pp[0] = sxx; pp[1] = sxy; pp[2] = syy; pp[3] = sx; pp[4] = sy; pp[5] = s1; pp[6] = ix; pp[7] = iy; pp[8] = i1;
@@ -397,20 +503,28 @@ __device__ inline void solve(const Args &a, double *smem)
             double *bw = &L.bw[5 * t];
             bw[0] = dg[0] + dg[1]; bw[1] = dg[2] + dg[3]; bw[2] = dg[4] + dg[5]; bw[3] = dg[6] + dg[7]; bw[4] = dg[8] + dg[9];
             double y3, y4, y5, y6, y7; con_T(lam, t, y3, y4, y5, y6, y7);
-            // stage gradient gst = J' gw + direct terms + C' lam
-            const double *J = &L.Jm[32 * t];
-            double *g = &L.gst[8 * t];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = J[j] * gw[0] + J[8 + j] * gw[1] + J[16 + j] * gw[2] + J[24 + j] * gw[3];
-            g[3] += y3; g[4] += y4;
-            g[5] += 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t] + y5;
-            g[6] += c.eps_u * L.u[T + t] + y6;
-            g[7] += y7;
+            double *rm = &L.recM[RM * t];
+            for (int i = 0; i < 6; ++i) rm[36 + i] = L.Bk[6 * t + i];
+            rm[42] = L.Ak[9 * t + 2]; rm[43] = L.Ak[9 * t + 5];
+            double *cy = &L.cy[5 * t];
+            cy[0] = y3; cy[1] = y4; cy[2] = y5 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t]; cy[3] = y6 + c.eps_u * L.u[T + t]; cy[4] = y7;
         }
         __syncthreads();
         // ---- (3) stage Hessian bases  J' Hw J + direct + barrier  (all threads), predictor rhs ----------
-        for (int i = tid; i < 64 * T; i += NT) {
-            int t = i >> 6, r = (i >> 3) & 7, q = i & 7;
+        // stage gradient gst = J' gw + direct terms + C' lam   (one thread per entry)
+        for (int i = tid; i < 8 * T; i += NT) {
+            int t = i >> 3, j = i & 7;
+            const double *J = &L.Jm[32 * t], *gw = &L.gw[4 * t];
+            double v = J[j] * gw[0] + J[8 + j] * gw[1] + J[16 + j] * gw[2] + J[24 + j] * gw[3];
+            if (j >= 3) v += L.cy[5 * t + j - 3];
+            L.gst[i] = v;
+        }
+        // upper triangle of the stage Hessian base, written straight into the matrix-sweep records
+        for (int i = tid; i < 36 * T; i += NT) {
+            int t = i / 36, o = i % 36;
+            int r = 0, rem = o;
+            while (rem >= 8 - r) { rem -= 8 - r; ++r; }
+            int q = r + rem;
             const double *J = &L.Jm[32 * t], *Hw = &L.Hw[16 * t], *bw = &L.bw[5 * t];
             double m = 0;
 #pragma unroll
@@ -424,10 +538,11 @@ __device__ inline void solve(const Args &a, double *smem)
                 else if (r == 7) m += bw[2];
                 else if (r == 3) m += bw[3];
                 else if (r == 4) m += bw[4];
-            } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= bw[3];
-            else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= bw[4];
-            L.base[i] = m;
+            } else if (r == 3 && q == 5) m -= bw[3];
+            else if (r == 4 && q == 6) m -= bw[4];
+            L.recM[RM * t + o] = m;
         }
+        __syncthreads();
         build_gh();
         __syncthreads();
         mark(2);
@@ -441,105 +556,15 @@ __device__ inline void solve(const Args &a, double *smem)
             for (int r = 0; r < 5; ++r)
 #pragma unroll
                 for (int q = 0; q < 5; ++q) Pm[r][q] = 0;
-            struct MC { double a13, a23, B[6], M[36], g[8]; };     // M: upper triangle of the 8x8 base, row-major
-            auto load_mc = [&](int t, MC &k) {
-                const double *Ap = &L.Ak[9 * t], *Bp = &L.Bk[6 * t], *bp = &L.base[64 * t], *gp = &L.gh[8 * t];
-                k.a13 = Ap[2]; k.a23 = Ap[5];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) k.B[i] = Bp[i];
-                int o = 0;
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-#pragma unroll
-                    for (int q = r; q < 8; ++q) k.M[o++] = bp[r * 8 + q];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) k.g[i] = gp[i];
-            };
-            MC cur, nxt;
-            load_mc(T - 1, cur);
-            for (int t = T - 1; t >= 0; --t) {
-                if (t > 0) load_mc(t - 1, nxt);
-                double M[8][8];
-                {
-                    int o = 0;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r)
-#pragma unroll
-                        for (int q = r; q < 8; ++q) M[r][q] = cur.M[o++];
+            RecM ka, kb; RecG ga, gb;
+            ldM(T - 1, ka); ldG(T - 1, ga);
+            for (int t = T - 1; t >= 0; t -= 2) {
+                if (t >= 1) { ldM(t - 1, kb); ldG(t - 1, gb); }
+                mat_step(t, ka, ga, Pm, p, fail, lane);
+                if (t >= 1) {
+                    if (t >= 2) { ldM(t - 2, ka); ldG(t - 2, ga); }
+                    mat_step(t - 1, kb, gb, Pm, p, fail, lane);
                 }
-                const double a13 = cur.a13, a23 = cur.a23;
-                const double *B = cur.B;
-                // A = [[1,0,a13],[0,1,a23],[0,0,1]] in all three motion models (rda_solver.py:955,971,987)
-                // T1 = Pss A ; T2 = Pss B + Psu ; T3 = Pus B + Puu
-                double T1[3][3], T2[3][2], T3[2][2];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    T1[r][0] = Pm[r][0]; T1[r][1] = Pm[r][1]; T1[r][2] = Pm[r][0] * a13 + Pm[r][1] * a23 + Pm[r][2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) T2[r][q] = Pm[r][0] * B[q] + Pm[r][1] * B[2 + q] + Pm[r][2] * B[4 + q] + Pm[r][3 + q];
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) T3[r][q] = Pm[3 + r][0] * B[q] + Pm[3 + r][1] * B[2 + q] + Pm[3 + r][2] * B[4 + q] + Pm[3 + r][3 + q];
-                // M += F' P F (upper triangle): rows 0,1 of A' are unit rows, row 2 = (a13, a23, 1)
-                M[0][0] += T1[0][0]; M[0][1] += T1[0][1]; M[0][2] += T1[0][2];
-                M[1][1] += T1[1][1]; M[1][2] += T1[1][2];
-                M[2][2] += a13 * T1[0][2] + a23 * T1[1][2] + T1[2][2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    M[0][5 + q] += T2[0][q]; M[1][5 + q] += T2[1][q];
-                    M[2][5 + q] += a13 * T2[0][q] + a23 * T2[1][q] + T2[2][q];
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int q = r; q < 2; ++q) M[5 + r][5 + q] += B[r] * T2[0][q] + B[2 + r] * T2[1][q] + B[4 + r] * T2[2][q] + T3[r][q];
-                // inverse of Mvv (rows/cols 5..7) by the adjugate: one division on the critical path
-                double m00 = M[5][5], m01 = M[5][6], m02 = M[5][7], m11 = M[6][6], m12 = M[6][7], m22 = M[7][7];
-                double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
-                double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
-                double det = m00 * c00 + m01 * c01 + m02 * c02;
-                if (!(m00 > 0) || !(c22 > 0) || !(det > 0)) fail = true;
-                double id = 1.0 / det;
-                double n00 = c00 * id, n01 = c01 * id, n02 = c02 * id, n11 = c11 * id, n12 = c12 * id, n22 = c22 * id;
-                // W = Mxv Minv (5x3); P_new = Mxx - W Mxv'
-                double W[5][3];
-#pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    double x0 = M[r][5], x1 = M[r][6], x2 = M[r][7];
-                    W[r][0] = x0 * n00 + x1 * n01 + x2 * n02;
-                    W[r][1] = x0 * n01 + x1 * n11 + x2 * n12;
-                    W[r][2] = x0 * n02 + x1 * n12 + x2 * n22;
-                }
-#pragma unroll
-                for (int r = 0; r < 5; ++r)
-#pragma unroll
-                    for (int q = r; q < 5; ++q) {
-                        double v = M[r][q] - (W[r][0] * M[q][5] + W[r][1] * M[q][6] + W[r][2] * M[q][7]);
-                        Pm[r][q] = v; Pm[q][r] = v;
-                    }
-                // predictor's backward vector step with the same factors (still in registers)
-                const double *g = cur.g;
-                double gv0 = g[5] + B[0] * p[0] + B[2] * p[1] + B[4] * p[2] + p[3];
-                double gv1 = g[6] + B[1] * p[0] + B[3] * p[1] + B[5] * p[2] + p[4];
-                double gv2 = g[7];
-                double gx0 = g[0] + p[0], gx1 = g[1] + p[1], gx2 = g[2] + a13 * p[0] + a23 * p[1] + p[2];
-                p[0] = gx0 - (W[0][0] * gv0 + W[0][1] * gv1 + W[0][2] * gv2);
-                p[1] = gx1 - (W[1][0] * gv0 + W[1][1] * gv1 + W[1][2] * gv2);
-                p[2] = gx2 - (W[2][0] * gv0 + W[2][1] * gv1 + W[2][2] * gv2);
-                p[3] = g[3] - (W[3][0] * gv0 + W[3][1] * gv1 + W[3][2] * gv2);
-                p[4] = g[4] - (W[4][0] * gv0 + W[4][1] * gv1 + W[4][2] * gv2);
-                if (lane == 0) {
-                    double *Mi = &L.Minv[9 * t], *X = &L.Wst[15 * t];
-                    Mi[0] = n00; Mi[1] = n01; Mi[2] = n02; Mi[3] = n01; Mi[4] = n11; Mi[5] = n12; Mi[6] = n02; Mi[7] = n12; Mi[8] = n22;
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) { X[3 * r] = W[r][0]; X[3 * r + 1] = W[r][1]; X[3 * r + 2] = W[r][2]; }
-                    L.kk[3 * t] = -(n00 * gv0 + n01 * gv1 + n02 * gv2);
-                    L.kk[3 * t + 1] = -(n01 * gv0 + n11 * gv1 + n12 * gv2);
-                    L.kk[3 * t + 2] = -(n02 * gv0 + n12 * gv1 + n22 * gv2);
-                }
-                cur = nxt;
             }
             wsync();
         } else if (wave == 1) {
@@ -600,7 +625,7 @@ __device__ inline void solve(const Args &a, double *smem)
             al = -block_reduce(-al, L.red, tid, true);
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
-                double q = 1 - al; sigma = q * q * q; if (sigma < 0.03) sigma = 0.03;
+                double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03; sigma = q * q * q; if (sigma < fl) sigma = fl;
             } else {
                 for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += al * L.dl[i]; }
                 if (tid < T) {
