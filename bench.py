@@ -32,12 +32,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_workload(seed_offset=0, n_obs=200, T=20):
+def build_workload(seed_offset=0, n_obs=200, T=20, n_steps=110):
+    """straight reference path through a seeded field of polygons; long enough that the robot never arrives
+    (an arrived robot would make every later step trivial)"""
     from rda_planner_amd import scenarios as sc
     car_t = sc.rectangle_robot(dynamics="acker")
-    path = sc.line_path([4, 25, 0], [46, 25, 0], 0.1)
+    length = max(40.0, 0.4 * n_steps + 12.0)
+    path = sc.line_path([4, 25, 0], [4 + length, 25, 0], 0.1)
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
-    obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(42, 40), seed=sc.SEED + seed_offset, keep_clear=clear, clear_radius=3.2)
+    obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(4 + length - 4, 40), seed=sc.SEED + seed_offset, keep_clear=clear, clear_radius=3.2)
     kw = dict(receding=T, iter_num=4, max_edge_num=4, max_obs_num=n_obs, ro1=200, obstacle_order=True)
     return car_t, path, obstacles, kw
 
@@ -50,7 +53,8 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None):
     mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw, **extra)
     T = kw["receding"]
     state = path[0].copy().reshape(3, 1)
-    tr = {"nom_s": [], "nom_u": [], "ref": [], "speed": [], "u": []}
+    tr = {"nom_s": [], "nom_u": [], "ref": [], "speed": [], "u": [], "u_solver": []}
+    arrived = 0
     orig = mpc.rda.iterative_solve
     staged = {}
 
@@ -62,7 +66,9 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None):
         if not staged:
             n, A, b, cone, per_t = mpc.rda._stage(list(obstacle_list))
             staged.update(n=n, A=A, b=b, cone=cone, per_t=per_t)
-        return orig(nom_s, nom_u, ref_states, ref_speed, obstacle_list, **k)
+        u_sol, info_sol = orig(nom_s, nom_u, ref_states, ref_speed, obstacle_list, **k)
+        tr["u_solver"].append(np.array(u_sol, float))
+        return u_sol, info_sol
 
     mpc.rda.iterative_solve = spy
     t0 = time.perf_counter()
@@ -71,19 +77,21 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None):
         # static obstacles + obstacle_order=False semantics for the replay: keep slot binding fixed
         u, info = mpc.control(state, 4.0, list(obstacles))
         tr["u"].append(u.copy())
+        arrived += int(info["arrive"])
         state = sc.kinematic_step(state, u, car_t, 0.1)
     dt = time.perf_counter() - t0
     min_clear = sc.clearance(car_t, state, obstacles)
     out = {k: np.ascontiguousarray(np.array(v)) for k, v in tr.items()}
     out["closed_loop_s_per_step"] = dt / n_steps
     out["final_clearance"] = float(min_clear)
+    out["arrived_steps"] = arrived
     return out, staged, mpc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200)     # 200 timed MPC steps = 80 m of driving
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-obs", type=int, default=200)
     ap.add_argument("--horizon", type=int, default=20)
@@ -106,7 +114,7 @@ def main():
     api.lib.rda_set_device(local_rank)
 
     K, W = args.steps, args.warmup
-    car_t, path, obstacles, kw = build_workload(seed_offset=rank, n_obs=args.n_obs, T=args.horizon)
+    car_t, path, obstacles, kw = build_workload(seed_offset=rank, n_obs=args.n_obs, T=args.horizon, n_steps=K + W)
     T, N = kw["receding"], kw["max_obs_num"]
     # obstacle slots must not be re-sorted between recording and replay: record with the distance
     # order of the first step frozen (static scene), i.e. obstacle_order only affects slot binding
@@ -181,7 +189,8 @@ def main():
     s_last = np.zeros((3, T + 1))
     info = Info()
     api.lib.rda_fetch_result(h2, W + K - 1, dptr(u_last), dptr(s_last), C.byref(info))
-    replay_err = float(np.abs(u_last[:, 0:1] - trace["u"][W + K - 1]).max())
+    replay_err = float(np.abs(u_last - trace["u_solver"][W + K - 1]).max())
+    assert trace["arrived_steps"] == 0, "workload invalid: the robot reached the goal inside the timed region"
     iters = []
     for k in range(W, W + K):
         api.lib.rda_fetch_result(h2, k, None, None, C.byref(info))
@@ -246,7 +255,7 @@ def main():
             cpu._be.api.step(cpu._be.handle, dptr(trace["nom_s"][k]), dptr(trace["nom_u"][k]), dptr(trace["ref"][k]), float(trace["speed"][k]),
                              staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"], dptr(ou), dptr(os_), C.byref(info_c))
             t_cpu += time.perf_counter() - t1
-            err = max(err, float(np.abs(ou[:, 0:1] - trace["u"][k]).max()))
+            err = max(err, float(np.abs(ou - trace["u_solver"][k]).max()))
             n_cpu += 1
         out["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 3), "unit": "steps/s", "cores": ncore, "kind": "port",
                                "sample": f"first {n_cpu} steps of the same recorded trace (oracle/rda_oracle.c, OpenMP over obstacles; su-problem serial)",
