@@ -101,6 +101,28 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
                    const double *xi, const double *zeta, const double *dis,
                    const double *a_lam, const double *b_lam);
 
+/* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns obstacle slots
+ * [r*N/world, (r+1)*N/world): it solves their LamMuZ problems and keeps their duals; the condensed terms the
+ * su-problem needs (8 doubles per (obstacle, stage): a(2), lam'b, mu'h+z-zeta, G'mu+xi (2), two residual
+ * partials) form one contiguous chunk per rank, replicated to every rank by ONE all-gather per ADMM iteration
+ * (replaces the pool.map scatter/gather of rda_solver.py:706-725); every rank then solves the identical
+ * su-problem.  rda_shard_config must precede the first step; N must be divisible by world. */
+int  rda_shard_config(rda_handle *h, int rank, int world);
+int  rda_shard_chunk_doubles(rda_handle *h);                       /* 8*T*N/world */
+int  rda_shard_get_chunk(rda_handle *h, double *host_chunk);       /* this rank's chunk  */
+int  rda_shard_set_chunks(rda_handle *h, const double *host_all);  /* all `world` chunks, rank-major */
+/* RCCL exchange over xGMI: rank 0 calls rda_shard_unique_id and ships the 128 bytes to the other ranks (any
+ * side channel); every rank then calls rda_shard_comm_init.  From then on rda_step / rda_enqueue_step issue
+ * one in-place ncclAllGather per ADMM iteration on the handle's stream. */
+int  rda_shard_unique_id(rda_handle *h, void *out128);
+int  rda_shard_comm_init(rda_handle *h, const void *uid128);
+/* Host-driven ADMM iteration for callers that do the exchange themselves (tests, gloo, MPI):
+ *   rda_admm_begin; for it: rda_admm_su(it,&stopped); if stopped break; rda_admm_lammuz; <exchange chunks>; rda_admm_finish */
+int  rda_admm_begin(rda_handle *h, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed);
+int  rda_admm_su(rda_handle *h, int it, int *stopped);
+int  rda_admm_lammuz(rda_handle *h);
+int  rda_admm_finish(rda_handle *h, double *out_u, double *out_s, rda_info *info);
+
 /* Pure-function hooks -----------------------------------------------------------------------*/
 /* B independent (obstacle, stage) sub-problems in one launch, one per wavefront.
  * A [B][E][2], b [B][E], cone [B], p [B][2] (nominal position, column t+1), phi [B] (nominal heading,

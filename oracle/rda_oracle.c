@@ -40,6 +40,10 @@ struct orc_handle {
     double *A, *b; int *cone;      /* staged obstacles [N][T+1][E][2], [N][T+1][E] */
     double *s, *u;                 /* current nominal (para_s, para_u) */
     int obstacle_num;
+    double *resp;                  /* [N*T][2] residual partials of the last LamMuZ pass */
+    double *ref, ref_speed;        /* step inputs */
+    int stop, iters, su_status, ipm_total; double resi_dual, resi_pri;
+    int P, rank, Nloc, have_gath; size_t chunk; double *gath;      /* obstacle sharding */
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -581,13 +585,15 @@ int orc_create(const orc_cfg *cfg, const double *G, const double *h, orc_handle 
     H->b = calloc((size_t)N * (T + 1) * E, sizeof(double));
     H->cone = malloc(sizeof(int) * N); for (int n = 0; n < N; ++n) H->cone[n] = 1;        /* rda_solver.py:158 */
     H->s = calloc(3 * (T + 1), sizeof(double)); H->u = calloc(2 * T, sizeof(double));
+    H->resp = calloc((size_t)2 * N * T, sizeof(double)); H->ref = calloc(3 * (T + 1), sizeof(double));
+    H->P = 1; H->rank = 0; H->Nloc = N; H->chunk = (size_t)8 * T * N; H->gath = NULL; H->have_gath = 0;
     *out = H; return 0;
 }
 void orc_destroy(orc_handle *H)
 {
     if (!H) return;
     free(H->G); free(H->h); free(H->lam); free(H->mu); free(H->z); free(H->xi); free(H->zeta); free(H->dis);
-    free(H->a_lam); free(H->b_lam); free(H->A); free(H->b); free(H->cone); free(H->s); free(H->u); free(H);
+    free(H->a_lam); free(H->b_lam); free(H->A); free(H->b); free(H->cone); free(H->s); free(H->u); free(H->resp); free(H->ref); free(H->gath); free(H);
 }
 int orc_set_adjust(orc_handle *H, double slack_gain, double max_sd, double min_sd, double ro1, double ro2)
 { H->c.slack_gain = slack_gain; H->c.max_sd = max_sd; H->c.min_sd = min_sd; H->c.ro1 = ro1; H->c.ro2 = ro2; return 0; }
@@ -645,76 +651,165 @@ static void stage_obstacles(orc_handle *H, int n_obs, const double *A, const dou
     H->obstacle_num = N;                          /* rda_solver.py:492 after padding; >N truncates */
 }
 
+/* ---- the ADMM loop in its pieces (rda_solver.py:588-637) ------------------------------------------
+ * admm_begin; for it: admm_su (early-stop test of the previous iteration, then the su-problem);
+ * admm_lammuz (this rank's obstacle shard); [exchange of the shard chunks]; admm_finish.
+ * With one shard (P = 1) orc_step runs them back to back. */
+static void shard_chunk_of(orc_handle *H, int n, int t, double *o8)
+{   /* the 8 numbers per (obstacle, stage) the su-problem and the residual test need */
+    const orc_cfg *c = &H->c; int T = c->T, R = c->R;
+    const double *mu = &H->mu[(size_t)(n * (T + 1) + t + 1) * R];
+    double muh = 0, gx = H->xi[(n * (T + 1) + t + 1) * 2], gy = H->xi[(n * (T + 1) + t + 1) * 2 + 1];
+    for (int j = 0; j < R; ++j) { muh += mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1]; }
+    o8[0] = H->a_lam[(n * (T + 1) + t + 1) * 2]; o8[1] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1];
+    o8[2] = H->b_lam[n * (T + 1) + t + 1]; o8[3] = muh + H->z[n * T + t] - H->zeta[n * T + t];
+    o8[4] = gx; o8[5] = gy; o8[6] = H->resp[2 * (n * T + t)]; o8[7] = H->resp[2 * (n * T + t) + 1];
+}
+
+int orc_shard_config(orc_handle *H, int rank, int world)
+{
+    if (!H || world < 1 || rank < 0 || rank >= world || H->c.N % world) return -1;
+    H->P = world; H->rank = rank; H->Nloc = H->c.N / world; H->chunk = (size_t)8 * H->c.T * H->Nloc;
+    free(H->gath); H->gath = calloc(H->chunk * world, sizeof(double)); H->have_gath = 0;
+    return 0;
+}
+int orc_shard_chunk_doubles(orc_handle *H) { return (int)H->chunk; }
+int orc_shard_get_chunk(orc_handle *H, double *out)
+{   /* layout [k][t][nl], identical to the HIP library */
+    int T = H->c.T, Nl = H->Nloc;
+    for (int nl = 0; nl < Nl; ++nl) for (int t = 0; t < T; ++t) {
+        double o8[8]; shard_chunk_of(H, H->rank * Nl + nl, t, o8);
+        for (int k = 0; k < 8; ++k) out[(size_t)k * T * Nl + t * Nl + nl] = o8[k];
+    }
+    return 0;
+}
+int orc_shard_set_chunks(orc_handle *H, const double *all)
+{ memcpy(H->gath, all, sizeof(double) * H->chunk * H->P); H->have_gath = 1; return 0; }
+
+int orc_admm_begin(orc_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed)
+{
+    int T = H->c.T;
+    memcpy(H->s, nom_s, sizeof(double) * 3 * (T + 1)); memcpy(H->u, nom_u, sizeof(double) * 2 * T);
+    memcpy(H->ref, ref_s, sizeof(double) * 3 * (T + 1)); H->ref_speed = ref_speed;
+    H->stop = 0; H->iters = 0; H->su_status = 0; H->ipm_total = 0; H->resi_dual = 0; H->resi_pri = 0;
+    return 0;
+}
+static void admm_residuals(orc_handle *H)
+{
+    const orc_cfg *c = &H->c; int T = c->T, N = c->N;
+    double rd = 0, rp = 0;
+    if (H->obstacle_num != 0) {
+        if (H->P > 1 && H->have_gath) {
+            for (int r = 0; r < H->P; ++r) for (int nl = 0; nl < H->Nloc; ++nl) for (int t = 0; t < T; ++t) {
+                rd += H->gath[r * H->chunk + (size_t)6 * T * H->Nloc + t * H->Nloc + nl];
+                rp += H->gath[r * H->chunk + (size_t)7 * T * H->Nloc + t * H->Nloc + nl];
+            }
+        } else for (int i = 0; i < N * T; ++i) { rd += H->resp[2 * i]; rp += H->resp[2 * i + 1]; }
+    }
+    H->resi_dual = rd / N; H->resi_pri = sqrt(rp);                                            /* :737,:688 */
+}
+int orc_admm_su(orc_handle *H, int it, int *stopped)
+{
+    const orc_cfg *c = &H->c; int T = c->T, N = c->N;
+    if (H->stop) { if (stopped) *stopped = 1; return 0; }
+    if (it > 0) {
+        admm_residuals(H);
+        if (H->resi_dual < c->iter_threshold && H->resi_pri < c->iter_threshold) {            /* :594 */
+            H->stop = 1; if (stopped) *stopped = 1; return 0;
+        }
+    }
+    double *ca = malloc(sizeof(double) * N * T * 2), *cc = malloc(sizeof(double) * N * T), *cg = malloc(sizeof(double) * N * T * 2);
+    double *s_new = malloc(sizeof(double) * 3 * (T + 1)), *u_new = malloc(sizeof(double) * 2 * T), *d_new = malloc(sizeof(double) * T);
+    /* ---- su-problem (rda_solver.py:617,692-700) ------------------------------------- */
+    for (int n = 0; n < N; ++n) for (int t = 0; t < T; ++t) {
+        double o8[8];
+        if (H->P > 1 && H->have_gath) {
+            int r = n / H->Nloc, nl = n % H->Nloc;
+            for (int k = 0; k < 6; ++k) o8[k] = H->gath[r * H->chunk + (size_t)k * T * H->Nloc + t * H->Nloc + nl];
+        } else shard_chunk_of(H, n, t, o8);
+        ca[(n * T + t) * 2] = o8[0]; ca[(n * T + t) * 2 + 1] = o8[1];
+        cc[n * T + t] = o8[2] + o8[3];
+        cg[(n * T + t) * 2] = o8[4]; cg[(n * T + t) * 2 + 1] = o8[5];
+    }
+    int ipm = 0;
+    int st = orc_su_solve(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm);
+    H->ipm_total += ipm;
+    if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
+    else H->su_status |= 1 << it;                 /* 'No update of state and control vector' :699 */
+    H->iters = it + 1;
+    free(ca); free(cc); free(cg); free(s_new); free(u_new); free(d_new);
+    if (stopped) *stopped = 0;
+    return 0;
+}
+int orc_admm_lammuz(orc_handle *H)
+{
+    const orc_cfg *c = &H->c; int T = c->T, N = c->N, E = c->E, R = c->R;
+    if (H->stop) return 0;
+    if (H->obstacle_num == 0) {                   /* Q9: only the last slot is cleared, :564-568 */
+        if (H->rank == H->P - 1) {
+            int n = N - 1;
+            for (int t = 0; t < T; ++t) { H->a_lam[(n * (T + 1) + t + 1) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1] = 0; H->b_lam[n * (T + 1) + t + 1] = 0; }
+        }
+        return 0;
+    }
+    /* ---- LamMuZ problems + dual updates of this rank's shard (rda_solver.py:628-635) ----------------- */
+    const int n0 = H->rank * H->Nloc, n1 = n0 + H->Nloc;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+#endif
+    for (int n = n0; n < n1; ++n) {
+        for (int t = 0; t < T; ++t) {
+            size_t o = (size_t)(n * (T + 1) + t + 1);
+            const double *At = &H->A[o * E * 2], *bt = &H->b[o * E];
+            double p[2] = { H->s[t + 1], H->s[(T + 1) + t + 1] }, phi = H->s[2 * (T + 1) + t];
+            double lam[EMAX], mu[RMAX], z, res = 0;
+            orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
+                           H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, NULL);
+            double cs = cos(phi), sn = sin(phi);
+            double ax = 0, ay = 0, bl = 0, im = 0, gx = 0, gy = 0;
+            for (int i = 0; i < E; ++i) {
+                double dl_ = lam[i] - H->lam[o * E + i]; res += dl_ * dl_; H->lam[o * E + i] = lam[i];
+                ax += lam[i] * At[2 * i]; ay += lam[i] * At[2 * i + 1]; bl += lam[i] * bt[i];
+            }
+            for (int j = 0; j < R; ++j) {
+                double dm = mu[j] - H->mu[o * R + j]; res += dm * dm; H->mu[o * R + j] = mu[j];
+                im -= mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1];
+            }
+            double dz = z - H->z[n * T + t]; res += dz * dz; H->z[n * T + t] = z;
+            H->a_lam[o * 2] = ax; H->a_lam[o * 2 + 1] = ay; H->b_lam[o] = bl;          /* :541-542 */
+            double hx = gx + cs * ax + sn * ay, hy = gy - sn * ax + cs * ay;          /* :682 */
+            H->xi[o * 2] += hx; H->xi[o * 2 + 1] += hy;                               /* :683 */
+            im += ax * p[0] + ay * p[1] - bl;                                         /* :659 */
+            H->zeta[n * T + t] += im - H->dis[t] - z;                                 /* :666 */
+            H->resp[2 * (n * T + t)] = res; H->resp[2 * (n * T + t) + 1] = hx * hx + hy * hy;
+        }
+    }
+    H->have_gath = 0;       /* the gathered copy is stale until the next exchange */
+    return 0;
+}
+int orc_admm_finish(orc_handle *H, double *out_u, double *out_s, orc_info *info)
+{
+    int T = H->c.T;
+    if (!H->stop) admm_residuals(H);
+    memcpy(out_u, H->u, sizeof(double) * 2 * T); memcpy(out_s, H->s, sizeof(double) * 3 * (T + 1));
+    if (info) { info->resi_dual = H->resi_dual; info->resi_pri = H->resi_pri; info->iters = H->iters; info->su_status = H->su_status; info->su_ipm_iters = H->ipm_total; }
+    return 0;
+}
+
 int orc_step(orc_handle *H, const double *nom_s, const double *nom_u, const double *ref_s,
              double ref_speed, int n_obs, const double *A, const double *b, const int *cone,
              int per_t, double *out_u, double *out_s, orc_info *info)
 {
-    const orc_cfg *c = &H->c; int T = c->T, N = c->N, E = c->E, R = c->R;
-    memcpy(H->s, nom_s, sizeof(double) * 3 * (T + 1)); memcpy(H->u, nom_u, sizeof(double) * 2 * T);
+    if (H->P != 1) return -1;                     /* sharded handles are driven through orc_admm_* */
     stage_obstacles(H, n_obs, A, b, cone, per_t);
-    double *ca = malloc(sizeof(double) * N * T * 2), *cc = malloc(sizeof(double) * N * T), *cg = malloc(sizeof(double) * N * T * 2);
-    double *s_new = malloc(sizeof(double) * 3 * (T + 1)), *u_new = malloc(sizeof(double) * 2 * T), *d_new = malloc(sizeof(double) * T);
-    double *resn = malloc(sizeof(double) * N), *hm2 = malloc(sizeof(double) * N);
-    double resi_dual = 0, resi_pri = 0; int it, su_status = 0, ipm_total = 0;
-    for (it = 0; it < c->iter_num; ++it) {
-        /* ---- su-problem (rda_solver.py:617,692-700) ------------------------------------- */
-        for (int n = 0; n < N; ++n) for (int t = 0; t < T; ++t) {
-            const double *mu = &H->mu[(size_t)(n * (T + 1) + t + 1) * R];
-            double muh = 0, gx = H->xi[(n * (T + 1) + t + 1) * 2], gy = H->xi[(n * (T + 1) + t + 1) * 2 + 1];
-            for (int j = 0; j < R; ++j) { muh += mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1]; }
-            ca[(n * T + t) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2]; ca[(n * T + t) * 2 + 1] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1];
-            cc[n * T + t] = H->b_lam[n * (T + 1) + t + 1] + muh + H->z[n * T + t] - H->zeta[n * T + t];
-            cg[(n * T + t) * 2] = gx; cg[(n * T + t) * 2 + 1] = gy;
-        }
-        int ipm = 0;
-        int st = orc_su_solve(c, H->s, H->u, ref_s, ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm);
-        ipm_total += ipm;
-        if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
-        else su_status |= 1 << it;                /* 'No update of state and control vector' :699 */
-        resi_dual = 0; resi_pri = 0;
-        if (H->obstacle_num == 0) {               /* Q9: only the last slot is cleared, :564-568 */
-            int n = N - 1;
-            for (int t = 0; t < T; ++t) { H->a_lam[(n * (T + 1) + t + 1) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1] = 0; H->b_lam[n * (T + 1) + t + 1] = 0; }
-        } else {
-            /* ---- LamMuZ problems + dual updates (rda_solver.py:628-635) ----------------- */
-#ifdef _OPENMP
-#pragma omp parallel for num_threads(g_threads) schedule(static)
-#endif
-            for (int n = 0; n < N; ++n) {
-                double res = 0, h2 = 0;
-                for (int t = 0; t < T; ++t) {
-                    size_t o = (size_t)(n * (T + 1) + t + 1);
-                    const double *At = &H->A[o * E * 2], *bt = &H->b[o * E];
-                    double p[2] = { H->s[t + 1], H->s[(T + 1) + t + 1] }, phi = H->s[2 * (T + 1) + t];
-                    double lam[EMAX], mu[RMAX], z;
-                    orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
-                                   H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, NULL);
-                    double cs = cos(phi), sn = sin(phi);
-                    double ax = 0, ay = 0, bl = 0, im = 0, gx = 0, gy = 0;
-                    for (int i = 0; i < E; ++i) {
-                        double dl_ = lam[i] - H->lam[o * E + i]; res += dl_ * dl_; H->lam[o * E + i] = lam[i];
-                        ax += lam[i] * At[2 * i]; ay += lam[i] * At[2 * i + 1]; bl += lam[i] * bt[i];
-                    }
-                    for (int j = 0; j < R; ++j) {
-                        double dm = mu[j] - H->mu[o * R + j]; res += dm * dm; H->mu[o * R + j] = mu[j];
-                        im -= mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1];
-                    }
-                    double dz = z - H->z[n * T + t]; res += dz * dz; H->z[n * T + t] = z;
-                    H->a_lam[o * 2] = ax; H->a_lam[o * 2 + 1] = ay; H->b_lam[o] = bl;          /* :541-542 */
-                    double hx = gx + cs * ax + sn * ay, hy = gy - sn * ax + cs * ay;          /* :682 */
-                    H->xi[o * 2] += hx; H->xi[o * 2 + 1] += hy; h2 += hx * hx + hy * hy;     /* :683 */
-                    im += ax * p[0] + ay * p[1] - bl;                                         /* :659 */
-                    H->zeta[n * T + t] += im - H->dis[t] - z;                                 /* :666 */
-                }
-                resn[n] = res; hm2[n] = h2;
-            }
-            for (int n = 0; n < N; ++n) { resi_dual += resn[n]; resi_pri += hm2[n]; }
-            resi_dual /= N; resi_pri = sqrt(resi_pri);                                        /* :737,:688 */
-        }
-        if (resi_dual < c->iter_threshold && resi_pri < c->iter_threshold) { it++; break; }   /* :594 */
+    orc_admm_begin(H, nom_s, nom_u, ref_s, ref_speed);
+    for (int it = 0; it < H->c.iter_num; ++it) {
+        int stopped = 0;
+        orc_admm_su(H, it, &stopped);
+        if (stopped) break;
+        orc_admm_lammuz(H);
     }
-    memcpy(out_u, H->u, sizeof(double) * 2 * T); memcpy(out_s, H->s, sizeof(double) * 3 * (T + 1));
-    if (info) { info->resi_dual = resi_dual; info->resi_pri = resi_pri; info->iters = it; info->su_status = su_status; info->su_ipm_iters = ipm_total; }
-    free(ca); free(cc); free(cg); free(s_new); free(u_new); free(d_new); free(resn); free(hm2);
-    return 0;
+    return orc_admm_finish(H, out_u, out_s, info);
 }
+int orc_upload_obstacles(orc_handle *H, int n_obs, const double *A, const double *b, const int *cone, int per_t)
+{ stage_obstacles(H, n_obs, A, b, cone, per_t); return 0; }

@@ -57,6 +57,17 @@ int  orc_step(orc_handle *h, const double *nom_s, const double *nom_u, const dou
               double ref_speed, int n_obs, const double *A, const double *b, const int *cone,
               int per_t, double *out_u, double *out_s, orc_info *info);
 
+/* Obstacle sharding / host-driven ADMM pieces - same contract as rda_shard_* / rda_admm_* in include/rda_hip.h */
+int  orc_upload_obstacles(orc_handle *h, int n_obs, const double *A, const double *b, const int *cone, int per_t);
+int  orc_shard_config(orc_handle *h, int rank, int world);
+int  orc_shard_chunk_doubles(orc_handle *h);
+int  orc_shard_get_chunk(orc_handle *h, double *chunk);
+int  orc_shard_set_chunks(orc_handle *h, const double *all);
+int  orc_admm_begin(orc_handle *h, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed);
+int  orc_admm_su(orc_handle *h, int it, int *stopped);
+int  orc_admm_lammuz(orc_handle *h);
+int  orc_admm_finish(orc_handle *h, double *out_u, double *out_s, orc_info *info);
+
 /* State access in the reference's shapes: lam [N][T+1][E], mu [N][T+1][R], z [N][T],
  * xi [N][T+1][2], zeta [N][T], dis [T], a_lam [N][T+1][2], b_lam [N][T+1]. */
 int  orc_get_state(orc_handle *h, double *lam, double *mu, double *z, double *xi, double *zeta,

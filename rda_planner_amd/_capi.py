@@ -68,6 +68,19 @@ class CApi:
         f("get_state").restype = C.c_int
         f("set_state").argtypes = [C.c_void_p] + [c_double_p] * 8
         f("set_state").restype = C.c_int
+        # obstacle sharding + host-driven ADMM pieces
+        f("upload_obstacles").argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int_p, C.c_int]
+        f("shard_config").argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f("shard_chunk_doubles").argtypes = [C.c_void_p]
+        f("shard_get_chunk").argtypes = [C.c_void_p, c_double_p]
+        f("shard_set_chunks").argtypes = [C.c_void_p, c_double_p]
+        f("admm_begin").argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_double]
+        f("admm_su").argtypes = [C.c_void_p, C.c_int, c_int_p]
+        f("admm_lammuz").argtypes = [C.c_void_p]
+        f("admm_finish").argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Info)]
+        for name in ("upload_obstacles", "shard_config", "shard_chunk_doubles", "shard_get_chunk", "shard_set_chunks",
+                     "admm_begin", "admm_su", "admm_lammuz", "admm_finish"):
+            f(name).restype = C.c_int
 
     def _f(self, name):
         return getattr(self.lib, f"{self.prefix}_{name}")

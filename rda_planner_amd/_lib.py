@@ -38,7 +38,10 @@ def hip_api():
         lib.rda_set_device.restype = C.c_int
         lib.rda_strerror.restype = C.c_char_p
         lib.rda_strerror.argtypes = [C.c_int]
-        lib.rda_upload_obstacles.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int_p, C.c_int]
+        lib.rda_shard_unique_id.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rda_shard_comm_init.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rda_shard_unique_id.restype = C.c_int
+        lib.rda_shard_comm_init.restype = C.c_int
         lib.rda_upload_trace.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
         lib.rda_enqueue_step.argtypes = [C.c_void_p, C.c_int]
         lib.rda_sync.argtypes = [C.c_void_p]
@@ -49,7 +52,7 @@ def hip_api():
                                          c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double,
                                          C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
         lib.rda_su_solve.argtypes = [C.POINTER(Cfg)] + [c_double_p] * 3 + [C.c_double] + [c_double_p] * 7 + [c_int_p]
-        for name in ("upload_obstacles", "upload_trace", "enqueue_step", "sync", "fetch_result", "timing_reset",
+        for name in ("upload_trace", "enqueue_step", "sync", "fetch_result", "timing_reset",
                      "timing_read", "lammuz_batch", "su_solve"):
             getattr(lib, "rda_" + name).restype = C.c_int
         if lib.rda_device_count() < 1:

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <dlfcn.h>
 #include "../../include/rda_hip.h"
 #include "lammuz_device.h"
 #include "su_device.h"
@@ -26,6 +27,9 @@ struct Ctrl {
     double resi_dual, resi_pri;
 };
 
+struct Dev;
+__host__ __device__ inline double *coef_arr(const Dev &d, int r, int k);
+
 struct Dev {
     rda_cfg c;
     int nt;                  // time slots of the staged obstacles (T+1 or 1)
@@ -33,12 +37,16 @@ struct Dev {
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
     double *lam, *mu, *z, *xi, *zeta, *dis;   // reference-shaped dual state
-    double *ax, *ay, *blam, *ee, *gx, *gy;    // [T][N] condensed terms for the su-problem
+    // Condensed su terms + residual partials, one chunk per obstacle shard (P = 1 on a single GPU):
+    //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0..5 -> ax ay blam ee gx gy,  k = 6,7 -> residual partials
+    // chunk r is produced by rank r's k_lammuz and replicated by one all-gather per ADMM iteration.
+    double *coef; int P, rank, Nloc; size_t chunk;
     double *s, *u;                            // nominal (para_s, para_u)
     double *ref, *ref_speed;                  // current step reference (device)
-    double *res;                              // [N*T][2] residual partials
     Ctrl *ctrl;
 };
+
+__host__ __device__ inline double *coef_arr(const Dev &d, int r, int k) { return d.coef + (size_t)r * d.chunk + (size_t)k * d.c.T * d.Nloc; }
 
 // ------------------------------------------------------------------------------------------------
 __device__ void reduce_residuals(const Dev &d, double *red, int tid)
@@ -46,7 +54,10 @@ __device__ void reduce_residuals(const Dev &d, double *red, int tid)
     const int T = d.c.T, N = d.c.N;
     double rd = 0, rp = 0;
     if (d.obstacle_num != 0)
-        for (int i = tid; i < N * T; i += su::NT) { rd += d.res[2 * i]; rp += d.res[2 * i + 1]; }
+        for (int r = 0; r < d.P; ++r) {
+            const double *r0 = coef_arr(d, r, 6), *r1 = coef_arr(d, r, 7);
+            for (int i = tid; i < d.Nloc * T; i += su::NT) { rd += r0[i]; rp += r1[i]; }
+        }
     rd = su::block_reduce(rd, red, tid, false);
     rp = su::block_reduce(rp, red, tid, false);
     if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); }
@@ -75,7 +86,8 @@ __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s
     a.c.eps_u = d.c.eps_u;
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
     a.ref = d.ref; a.ref_speed = d.ref_speed;
-    a.ax = d.ax; a.ay = d.ay; a.blam = d.blam; a.ee = d.ee; a.gx = d.gx; a.gy = d.gy;
+    a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
+    a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
     su::solve(a, smem_su);
@@ -121,20 +133,26 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (d.obstacle_num == 0) {
         // quirk Q9 (rda_solver.py:564-568): only slot N-1 loses its lam'A / lam'b products
-        if (blockIdx.x == 0) for (int t = threadIdx.x; t < T; t += 256) { int i = t * N + (N - 1); d.ax[i] = 0; d.ay[i] = 0; d.blam[i] = 0; }
+        if (blockIdx.x == 0 && d.rank == d.P - 1)
+            for (int t = threadIdx.x; t < T; t += 256) {
+                int i = t * d.Nloc + (d.Nloc - 1);
+                coef_arr(d, d.rank, 0)[i] = 0; coef_arr(d, d.rank, 1)[i] = 0; coef_arr(d, d.rank, 2)[i] = 0;
+            }
         return;
     }
     if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = d.G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = d.h[threadIdx.x - 64];
     const int w = blockIdx.x * 4 + wv;
-    const bool live = w < N * T;
-    const int n = live ? w / T : 0, t = live ? w % T : 0;
+    const bool live = w < d.Nloc * T;
+    const int nl = live ? w / T : 0, t = live ? w % T : 0;
+    const int n = d.rank * d.Nloc + nl;                        // this rank's obstacle shard [rank*Nloc, (rank+1)*Nloc)
     lmz::WaveLDS &W = wl[wv];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
     if (lane < 2 * E) W.A[lane >> 1][lane & 1] = d.A[ao * 2 + lane];
     if (lane < E) W.b[lane] = d.b[ao + lane];
     __syncthreads();
     if (!live) return;
+    (void)N;
     lmz::Params P;
     P.E = E; P.R = R; P.norm2 = d.cone[n];
     P.px = d.s[t + 1]; P.py = d.s[(T + 1) + t + 1];
@@ -178,10 +196,10 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
         const double im = ax * P.px + ay * P.py - bl - mh;                                  // :659
         const double zetan = zeta + im - dbar - znew;                                       // :666
         d.zeta[n * T + t] = zetan;
-        const int k = t * N + n;
-        d.ax[k] = ax; d.ay[k] = ay; d.blam[k] = bl;                                         // :541-542
-        d.ee[k] = mh + znew - zetan; d.gx[k] = gx + xin0; d.gy[k] = gy + xin1;
-        d.res[2 * (n * T + t)] = res; d.res[2 * (n * T + t) + 1] = hx * hx + hy * hy;
+        const int k = t * d.Nloc + nl;
+        coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
+        coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
+        coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
     }
 }
 
@@ -228,7 +246,7 @@ __global__ void k_products_get(Dev d, double *a_lam, double *b_lam)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * (T + 1); i += gridDim.x * blockDim.x) {
         int n = i / (T + 1), tt = i % (T + 1);
         double ax = 0, ay = 0, bl = 0;
-        if (tt >= 1) { int k = (tt - 1) * N + n; ax = d.ax[k]; ay = d.ay[k]; bl = d.blam[k]; }
+        if (tt >= 1) { int r = n / d.Nloc, k = (tt - 1) * d.Nloc + (n - r * d.Nloc); ax = coef_arr(d, r, 0)[k]; ay = coef_arr(d, r, 1)[k]; bl = coef_arr(d, r, 2)[k]; }
         a_lam[2 * i] = ax; a_lam[2 * i + 1] = ay; b_lam[i] = bl;
     }
 }
@@ -237,20 +255,23 @@ __global__ void k_products_set(Dev d, const double *a_lam, const double *b_lam)
 {
     const int T = d.c.T, N = d.c.N, R = d.c.R;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) {
-        int n = i / T, t = i % T, k = t * N + n;
+        int n = i / T, t = i % T, r = n / d.Nloc, k = t * d.Nloc + (n - r * d.Nloc);
         size_t o = (size_t)n * (T + 1) + t + 1;
-        if (a_lam) { d.ax[k] = a_lam[2 * o]; d.ay[k] = a_lam[2 * o + 1]; }
-        if (b_lam) d.blam[k] = b_lam[o];
+        if (a_lam) { coef_arr(d, r, 0)[k] = a_lam[2 * o]; coef_arr(d, r, 1)[k] = a_lam[2 * o + 1]; }
+        if (b_lam) coef_arr(d, r, 2)[k] = b_lam[o];
         double mh = 0, gx = 0, gy = 0;
         for (int j = 0; j < R; ++j) { double v = d.mu[o * R + j]; mh += v * d.h[j]; gx += v * d.G[2 * j]; gy += v * d.G[2 * j + 1]; }
-        d.ee[k] = mh + d.z[n * T + t] - d.zeta[n * T + t];
-        d.gx[k] = gx + d.xi[2 * o]; d.gy[k] = gy + d.xi[2 * o + 1];
+        coef_arr(d, r, 3)[k] = mh + d.z[n * T + t] - d.zeta[n * T + t];
+        coef_arr(d, r, 4)[k] = gx + d.xi[2 * o]; coef_arr(d, r, 5)[k] = gy + d.xi[2 * o + 1];
     }
 }
 __global__ void k_reset(Dev d)
 {
     const int T = d.c.T, N = d.c.N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) { d.ax[i] = 0; d.ay[i] = 0; d.blam[i] = 0; }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) {
+        int r = i / (d.Nloc * T), k = i % (d.Nloc * T);
+        coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,6 +287,10 @@ struct rda_handle {
     double *h_out; rda_info *h_info;                      // pinned
     // trace path
     int K; double *d_tr_s, *d_tr_u, *d_tr_ref, *d_tr_speed, *d_tr_out_u, *d_tr_out_s; rda_info *d_tr_info;
+    // obstacle-shard exchange (RCCL, resolved lazily with dlopen so that single-GPU use has no rccl dependency)
+    void *nccl_lib, *comm;
+    int (*p_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
+    int (*p_comm_destroy)(void *);
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
 };
@@ -302,7 +327,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     if (rda_device_count() < 1) return RDA_ERR_NODEVICE;
     rda_handle *H = new rda_handle();
     memset(&H->d, 0, sizeof(Dev));
-    H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0; H->ev_used[0] = H->ev_used[1] = 0;
+    H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
+    H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
     HIPCHK(hipStreamCreate(&H->stream));
@@ -312,10 +338,10 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
-    rc |= dalloc(&d.ax, N * T); rc |= dalloc(&d.ay, N * T); rc |= dalloc(&d.blam, N * T);
-    rc |= dalloc(&d.ee, N * T); rc |= dalloc(&d.gx, N * T); rc |= dalloc(&d.gy, N * T);
+    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.chunk = 8 * T * N;
+    rc |= dalloc(&d.coef, d.chunk);
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
-    rc |= dalloc(&d.res, 2 * N * T); rc |= dalloc(&d.ctrl, 1);
+    rc |= dalloc(&d.ctrl, 1);
     const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
     rc |= dalloc(&H->d_step, step_n); rc |= dalloc(&H->d_out_u, 2 * T); rc |= dalloc(&H->d_out_s, 3 * (T + 1)); rc |= dalloc(&H->d_info, 1);
     if (rc) { rda_destroy(H); return RDA_ERR_HIP; }
@@ -343,9 +369,10 @@ extern "C" void rda_destroy(rda_handle *H)
 {
     if (!H) return;
     (void)hipStreamSynchronize(H->stream);
+    if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
-    void *ptrs[] = { d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.ax, d.ay, d.blam, d.ee, d.gx, d.gy,
-                     d.s, d.u, d.res, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
+    void *ptrs[] = { d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
+                     d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info };
     for (void *p : ptrs) dev_free(p);
     if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
@@ -416,8 +443,8 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
 {
     Dev d = H->d;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
-    const int T = d.c.T, N = d.c.N;
-    const int blocks = (N * T + 3) / 4;
+    const int T = d.c.T;
+    const int blocks = (d.Nloc * T + 3) / 4;
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, d);
     for (int it = 0; it < d.c.iter_num; ++it) {
         if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
@@ -425,6 +452,10 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
         if (H->timing) { (void)hipEventRecord(next_event(H, 1), H->stream); (void)hipEventRecord(next_event(H, 0), H->stream); }
         hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
+        if (H->comm) {      // one exchange per ADMM iteration: every rank's chunk to every rank (in place)
+            int nrc = H->p_allgather(d.coef + (size_t)d.rank * d.chunk, d.coef, d.chunk, /*ncclDouble*/ 8, H->comm, H->stream);
+            if (nrc != 0) { fprintf(stderr, "librda_hip: ncclAllGather failed (%d)\n", nrc); return RDA_ERR_HIP; }
+        }
     }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, out_u, out_s, info);
     HIPCHK(hipGetLastError());
@@ -563,6 +594,122 @@ extern "C" int rda_set_state(rda_handle *H, const double *lam, const double *mu,
     return RDA_OK;
 }
 
+
+// ---- obstacle sharding ------------------------------------------------------------------------------
+extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
+{
+    if (!H || world < 1 || rank < 0 || rank >= world || H->d.c.N % world != 0) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    Dev &d = H->d;
+    dev_free(d.coef); d.coef = nullptr;
+    d.P = world; d.rank = rank; d.Nloc = d.c.N / world; d.chunk = (size_t)8 * d.c.T * d.Nloc;
+    if (dalloc(&d.coef, d.chunk * world)) return RDA_ERR_HIP;
+    return RDA_OK;
+}
+extern "C" int rda_shard_chunk_doubles(rda_handle *H) { return H ? (int)H->d.chunk : RDA_ERR_ARG; }
+extern "C" int rda_shard_get_chunk(rda_handle *H, double *host)
+{
+    if (!H || !host) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(host, H->d.coef + (size_t)H->d.rank * H->d.chunk, H->d.chunk * sizeof(double), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
+extern "C" int rda_shard_set_chunks(rda_handle *H, const double *host_all)
+{
+    if (!H || !host_all) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(H->d.coef, host_all, H->d.chunk * H->d.P * sizeof(double), hipMemcpyHostToDevice));
+    return RDA_OK;
+}
+static void *rccl_sym(rda_handle *H, const char *name)
+{
+    if (!H->nccl_lib) {
+        H->nccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!H->nccl_lib) H->nccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!H->nccl_lib) H->nccl_lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
+    return H->nccl_lib ? dlsym(H->nccl_lib, name) : nullptr;
+}
+extern "C" int rda_shard_unique_id(rda_handle *H, void *out128)
+{
+    if (!H || !out128) return RDA_ERR_ARG;
+    typedef int (*fn)(void *);
+    fn f = (fn)rccl_sym(H, "ncclGetUniqueId");
+    if (!f) return RDA_ERR_UNSUPPORTED;
+    return f(out128) == 0 ? RDA_OK : RDA_ERR_HIP;
+}
+extern "C" int rda_shard_comm_init(rda_handle *H, const void *uid128)
+{
+    if (!H || !uid128 || H->d.P < 2) return RDA_ERR_ARG;
+    struct uid_t { char b[128]; } uid;
+    memcpy(&uid, uid128, 128);
+    typedef int (*init_fn)(void **, int, uid_t, int);
+    init_fn f = (init_fn)rccl_sym(H, "ncclCommInitRank");
+    H->p_allgather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))rccl_sym(H, "ncclAllGather");
+    H->p_comm_destroy = (int (*)(void *))rccl_sym(H, "ncclCommDestroy");
+    if (!f || !H->p_allgather) return RDA_ERR_UNSUPPORTED;
+    int rc = f(&H->comm, H->d.P, uid, H->d.rank);
+    if (rc != 0) { fprintf(stderr, "librda_hip: ncclCommInitRank failed (%d)\n", rc); H->comm = nullptr; return RDA_ERR_HIP; }
+    return RDA_OK;
+}
+
+// ---- host-driven ADMM iteration (exchange done by the caller: tests, gloo, MPI ...) -----------------------
+extern "C" int rda_admm_begin(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed)
+{
+    if (!H || !nom_s || !nom_u || !ref_s) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    memcpy(H->h_step, nom_s, ns * sizeof(double));
+    memcpy(H->h_step + ns, nom_u, nu * sizeof(double));
+    memcpy(H->h_step + ns + nu, ref_s, ns * sizeof(double));
+    H->h_step[ns + nu + ns] = ref_speed;
+    HIPCHK(hipMemcpyAsync(H->d_step, H->h_step, (2 * ns + nu + 1) * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, H->d);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+extern "C" int rda_admm_su(rda_handle *H, int it, int *stopped)
+{
+    if (!H || it < 0) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    Dev d = H->d;
+    d.ref = H->d_step + ns + nu; d.ref_speed = H->d_step + ns + nu + ns;
+    hipLaunchKernelGGL(k_su, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns);
+    HIPCHK(hipGetLastError());
+    if (stopped) {
+        Ctrl c;
+        HIPCHK(hipMemcpyAsync(&c, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, H->stream));
+        HIPCHK(hipStreamSynchronize(H->stream));
+        *stopped = c.stop;
+    }
+    return RDA_OK;
+}
+extern "C" int rda_admm_lammuz(rda_handle *H)
+{
+    if (!H) return RDA_ERR_ARG;
+    Dev d = H->d;
+    const int blocks = (d.Nloc * d.c.T + 3) / 4;
+    hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+extern "C" int rda_admm_finish(rda_handle *H, double *out_u, double *out_s, rda_info *info)
+{
+    if (!H || !out_u || !out_s) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    Dev d = H->d;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, H->d_out_u, H->d_out_s, H->d_info);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    memcpy(out_u, H->h_out, nu * sizeof(double));
+    memcpy(out_s, H->h_out + nu, ns * sizeof(double));
+    if (info) *info = *H->h_info;
+    return RDA_OK;
+}
+
 // ---- pure-function hooks ------------------------------------------------------------------------
 extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int32_t *cone,
                                 const double *p, const double *phi, const double *G, const double *h,
@@ -623,6 +770,7 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     ar.c.eps_u = cfg->eps_u;
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.blam = dsoa + 2 * T * N; ar.ee = dsoa + 3 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
+    ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;
     ar.d_in = d0 ? dd0 : nullptr; ar.out_s = dos; ar.out_u = dou; ar.out_d = dod; ar.status = dst; ar.ipm_iters = dst + 1;
     long long *dprof = nullptr;
     if (getenv("RDA_SU_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }

@@ -39,7 +39,8 @@ struct Args {
     const double *in_s, *in_u;       // linearisation point (3x(T+1), 2xT)
     const double *ref;               // 3x(T+1)
     const double *ref_speed;         // scalar on device
-    const double *ax, *ay, *blam, *ee, *gx, *gy;   // [T][N] condensed obstacle terms
+    const double *ax, *ay, *blam, *ee, *gx, *gy;   // condensed obstacle terms of obstacle shard 0, each [T][Nloc]
+    int P, Nloc; size_t chunk;       // P obstacle shards (N = P*Nloc); shard r's arrays start `chunk` doubles after shard r-1's
     const double *d_in;              // [T] initial guess for d
     double *out_s, *out_u, *out_d;   // results (may alias in_*)
     int *status;                     // 0 ok / 1 not converged / 2 factorisation failed
@@ -166,7 +167,7 @@ __device__ __forceinline__ void con_T(const double *x, int t, double &y3, double
 __device__ inline void solve(const Args &a, double *smem)
 {
     const Cfg &c = a.c;
-    const int T = c.T, N = c.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
     const double vref = *a.ref_speed;
     // (stage, chunk) mapping of the obstacle reductions
@@ -202,11 +203,14 @@ __device__ inline void solve(const Args &a, double *smem)
         double q0 = 0, q1 = 0, q2 = 0;
         if (ract) {
             double cs = cos(L.phin[rt]), sn = sin(L.phin[rt]);
-            for (int n = rc_; n < N; n += nch) {
-                double ax = a.ax[rt * N + n], ay = a.ay[rt * N + n], gx = a.gx[rt * N + n], gy = a.gy[rt * N + n];
-                double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
-                double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
-                q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
+            for (int r = 0; r < a.P; ++r) {
+                const size_t o = r * a.chunk + (size_t)rt * a.Nloc;
+                for (int n = rc_; n < a.Nloc; n += nch) {
+                    double ax = a.ax[o + n], ay = a.ay[o + n], gx = a.gx[o + n], gy = a.gy[o + n];
+                    double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
+                    double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
+                    q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
+                }
             }
         }
         L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
@@ -440,7 +444,6 @@ __device__ inline void solve(const Args &a, double *smem)
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
             if (ract) {
                 const double px = L.s[rt + 1], py = L.s[(T + 1) + rt + 1], dd = L.d[rt];
-                const double *pax = a.ax + (size_t)rt * N, *pay = a.ay + (size_t)rt * N, *pb = a.blam + (size_t)rt * N, *pe = a.ee + (size_t)rt * N;
                 auto term = [&](double ax, double ay, double cb) {
                     double Im = ax * px + ay * py - cb - dd;
                     if (!c.accelerated || Im < 0) {
@@ -448,14 +451,19 @@ __device__ inline void solve(const Args &a, double *smem)
                         ix += Im * ax; iy += Im * ay; i1 += Im;
                     }
                 };
-                int n = rc_;
-                for (; n + 3 * nch < N; n += 4 * nch) {      // four independent loads in flight per array
-                    double a0 = pax[n], a1 = pax[n + nch], a2 = pax[n + 2 * nch], a3 = pax[n + 3 * nch];
-                    double b0 = pay[n], b1 = pay[n + nch], b2 = pay[n + 2 * nch], b3 = pay[n + 3 * nch];
-                    double c0 = pb[n] + pe[n], c1 = pb[n + nch] + pe[n + nch], c2 = pb[n + 2 * nch] + pe[n + 2 * nch], c3 = pb[n + 3 * nch] + pe[n + 3 * nch];
-                    term(a0, b0, c0); term(a1, b1, c1); term(a2, b2, c2); term(a3, b3, c3);
+                const int Nl = a.Nloc;
+                for (int r = 0; r < a.P; ++r) {
+                    const size_t o = r * a.chunk + (size_t)rt * Nl;
+                    const double *pax = a.ax + o, *pay = a.ay + o, *pb = a.blam + o, *pe = a.ee + o;
+                    int n = rc_;
+                    for (; n + 3 * nch < Nl; n += 4 * nch) {      // four independent loads in flight per array
+                        double a0 = pax[n], a1 = pax[n + nch], a2 = pax[n + 2 * nch], a3 = pax[n + 3 * nch];
+                        double b0 = pay[n], b1 = pay[n + nch], b2 = pay[n + 2 * nch], b3 = pay[n + 3 * nch];
+                        double c0 = pb[n] + pe[n], c1 = pb[n + nch] + pe[n + nch], c2 = pb[n + 2 * nch] + pe[n + 2 * nch], c3 = pb[n + 3 * nch] + pe[n + 3 * nch];
+                        term(a0, b0, c0); term(a1, b1, c1); term(a2, b2, c2); term(a3, b3, c3);
+                    }
+                    for (; n < Nl; n += nch) term(pax[n], pay[n], pb[n] + pe[n]);
                 }
-                for (; n < N; n += nch) term(pax[n], pay[n], pb[n] + pe[n]);
             }
             double *pp = &L.part[tid * 9];
             pp[0] = sxx; pp[1] = sxy; pp[2] = syy; pp[3] = sx; pp[4] = sy; pp[5] = s1; pp[6] = ix; pp[7] = iy; pp[8] = i1;

@@ -229,3 +229,72 @@ def test_error_codes(hip):
     assert hip.create(C.byref(cfg), dptr(hp.G), dptr(hp.H), C.byref(hnd)) == -2
     assert hip.lib.rda_enqueue_step(None, 0) == -1                                    # RDA_ERR_ARG
     assert b"unsupported" in hip.lib.rda_strerror(-2)
+
+
+def test_obstacle_shards_two_handles_one_gpu(hip):
+    """N>1 path of the HIP library on one device: two handles act as rank 0 / rank 1 of a 2-way obstacle
+    shard, the per-iteration all-gather is emulated on the host (rda_shard_get_chunk / set_chunks).  Both
+    ranks must agree bit for bit with each other, and with the un-sharded solve up to the summation order of
+    the su-problem's obstacle reductions."""
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.sharded import ShardedRDA
+    from test_sharded_gloo import _problem
+    car_t, T, N, rl, steps = _problem()
+    single = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+    ranks = [RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False) for _ in range(2)]
+    pending = {}
+
+    class Emu:        # lock-step emulation: rank 0 deposits its chunk and waits for rank 1
+        def __init__(self, r): self.r = r
+        def __call__(self, chunk):
+            pending[self.r] = chunk.copy()
+            return None
+    sh = [ShardedRDA(ranks[r], r, 2, Emu(r)) for r in range(2)]
+    api = hip
+    for nom_s, nom_u, ref in steps:
+        us, infos = [], []
+        # drive both ranks iteration by iteration (what two processes would do concurrently)
+        import ctypes
+        for r in range(2):
+            s = ranks[r]
+            n_obs, A, b, cone, per_t = s._stage(list(rl))
+            assert api.upload_obstacles(sh[r].h, n_obs, dptr(A), dptr(b), iptr(cone), per_t) == 0
+            refa = np.ascontiguousarray(np.hstack(ref)[0:3, :])
+            assert api.admm_begin(sh[r].h, dptr(np.ascontiguousarray(nom_s)), dptr(np.ascontiguousarray(nom_u)), dptr(refa), 4.0) == 0
+        for it in range(3):
+            stop = [ctypes.c_int(0), ctypes.c_int(0)]
+            for r in range(2):
+                assert api.admm_su(sh[r].h, it, ctypes.byref(stop[r])) == 0
+            assert stop[0].value == stop[1].value
+            if stop[0].value:
+                break
+            chunks = []
+            for r in range(2):
+                assert api.admm_lammuz(sh[r].h) == 0
+                c = np.zeros(sh[r].chunk)
+                assert api.shard_get_chunk(sh[r].h, dptr(c)) == 0
+                chunks.append(c)
+            both = np.concatenate(chunks)
+            for r in range(2):
+                assert api.shard_set_chunks(sh[r].h, dptr(both)) == 0
+        for r in range(2):
+            u = np.zeros((2, T)); so = np.zeros((3, T + 1)); info = Info()
+            assert api.admm_finish(sh[r].h, dptr(u), dptr(so), C.byref(info)) == 0
+            us.append(u); infos.append((info.iters, info.resi_dual, info.resi_pri))
+        assert np.array_equal(us[0], us[1]) and infos[0] == infos[1]
+        u1, i1 = single.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+        assert i1["iters"] == infos[0][0]
+        assert np.abs(u1 - us[0]).max() < 1e-8 and abs(i1["resi_dual"] - infos[0][1]) < 1e-9
+
+
+def test_obstacle_shards_rccl_two_gpus():
+    """the in-library ncclAllGather path; needs two visible GPUs (skipped on the single-GPU test box)"""
+    import subprocess
+    import sys
+    from rda_planner_amd._lib import hip_api
+    if hip_api().lib.rda_device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29611", os.path.join(root, "tools", "rccl_shard_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -1,0 +1,92 @@
+"""N>1 path on CPU: two processes, gloo backend, the obstacle shards of one MPC problem split over the
+ranks, one all-gather of the shard chunks per ADMM iteration (the exchange RCCL performs over xGMI on the
+GPU node).  The compute behind the C-ABI pieces is the CPU oracle here; the sharded result must equal the
+single-process solve bit for bit (same inputs to the same su-problem on every rank)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem():
+    from rda_planner_amd import scenarios as sc
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics="acker")
+    T, N = 8, 6
+    obstacles = sc.scene_polygons(N, lo=(4, -6), hi=(16, 6), seed=11)
+    conv = MPC.__new__(MPC)
+    conv.receding, conv.dt, conv.state = T, 0.1, np.zeros((3, 1))
+    rl = MPC.convert_rda_obstacle(conv, obstacles, np.zeros((3, 1)), False)
+    steps = []
+    rng = np.random.default_rng(5)
+    for k in range(4):
+        nom_u = np.vstack([np.full(T, 3.0), rng.uniform(-0.1, 0.1, T)])
+        nom_s = np.zeros((3, T + 1))
+        for t in range(T):
+            nom_s[:, t + 1] = nom_s[:, t] + 0.1 * np.array([3.0 * np.cos(nom_s[2, t]), 3.0 * np.sin(nom_s[2, t]), 3.0 * np.tan(nom_u[1, t]) / 3.0])
+        ref = [np.array([[0.4 * t], [0.1 * k], [0.0]]) for t in range(T + 1)]
+        steps.append((nom_s, nom_u, ref))
+    return car_t, T, N, rl, steps
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.sharded import ShardedRDA
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    car_t, T, N, rl, steps = _problem()
+    solver = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False, _backend=oracle_backend)
+
+    def all_gather(chunk):
+        mine = torch.from_numpy(np.ascontiguousarray(chunk))
+        everyone = torch.zeros(world * mine.numel(), dtype=torch.float64)
+        dist.all_gather_into_tensor(everyone, mine)
+        return everyone.numpy()
+    sh = ShardedRDA(solver, rank, world, all_gather)
+    res = []
+    for nom_s, nom_u, ref in steps:
+        u, info = sh.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+        res.append((u, info["iters"], info["resi_dual"], info["resi_pri"]))
+    # every rank must hold the identical answer
+    flat = torch.from_numpy(np.concatenate([r[0].ravel() for r in res]))
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    if rank == 0:
+        np.save(out, np.concatenate([np.r_[r[0].ravel(), r[1], r[2], r[3]] for r in res]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_equal_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.rda_solver import RDA_solver
+    out = str(tmp_path / "sharded.npy")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    car_t, T, N, rl, steps = _problem()
+    single = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False, _backend=oracle_backend)
+    want = []
+    for nom_s, nom_u, ref in steps:
+        u, info = single.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+        want.append(np.r_[u.ravel(), info["iters"], info["resi_dual"], info["resi_pri"]])
+    want = np.concatenate(want)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+def test_shard_config_rejects_indivisible():
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.sharded import ShardedRDA
+    car_t, T, N, rl, steps = _problem()
+    solver = RDA_solver(T, car_t, 4, 5, iter_num=2, time_print=False, _backend=oracle_backend)
+    with pytest.raises(RuntimeError):
+        ShardedRDA(solver, 0, 2, lambda c: c)
