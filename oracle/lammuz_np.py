@@ -23,10 +23,11 @@ not installable here, so this restatement fixes the tie-break explicitly:
   (T2) z = 1/2 * max(Im|z=0, 0) in accelerated mode (mid-point of its optimal
        interval [0, Im+]);  z = max(Im|z=0, 0) when accelerated=False, where
        that value is the unique minimiser;
-  (T3) the hinge-inactive candidates are examined first and the best of them is
-       returned when its m >= 0 (it is then globally optimal); otherwise all
-       candidates compete and exact ties go to the lowest candidate index
-       2*(lam_index*n_mu + mu_index) + hinge_state.
+  (T3) pass 1 ranks the hinge-inactive candidates by the hinge-inactive model cost
+       (a lower bound of the true cost, exact for m >= 0) and returns its minimiser
+       when that has m >= 0 (it is then globally optimal); otherwise pass 2 lets the
+       hinge-active candidates and that minimiser compete on the true cost.  Exact
+       ties go to the lowest candidate index 2*(lam_index*n_mu + mu_index) + hinge.
 
 Method: because -psi'(m) > 0 everywhere, for the optimal a = A'lam and g = G'mu
 the pair (lam, mu) solves two LPs  ->  basic optimal solutions have at most two
@@ -113,6 +114,87 @@ def trs2(Q, c, disc):
     return out
 
 
+def circle_interior(gstar, chi, ut, l0, kappa0, xi, ro2, delta):
+    """Circle obstacle, candidate with 0 < ||a|| < 1 (lam_3 = -||a|| tight): minimise the smooth convex
+    Phi(at) = model(t = at'ut + l0*||at|| + kappa0, e = at + xi) by damped Newton; l0 = -radius.
+    Returns at or None (no interior stationary point: the ||a|| in {0, 1} candidates cover it)."""
+    def G(t, e):
+        gam, m, H = gstar(t, e)
+        return np.array([chi * m - delta, ro2 * H[0], ro2 * H[1]]), 0.5 * chi * m * m - delta * m + 0.5 * ro2 * (H @ H)
+    G0, _ = G(0.0, np.zeros(2))
+    Hm = np.column_stack([G(1.0, np.zeros(2))[0] - G0, G(0.0, np.array([1.0, 0.0]))[0] - G0, G(0.0, np.array([0.0, 1.0]))[0] - G0])
+    Hm = 0.5 * (Hm + Hm.T)
+    nu = np.hypot(ut[0], ut[1])
+    # start: steepest-descent ray out of the kink at at = 0, exact minimiser along it (Phi is quadratic on a ray)
+    g0 = G0_ = G(kappa0, xi)[0]
+    gk = g0[0] * ut + g0[1:]
+    ck = g0[0] * l0
+    ng = np.hypot(gk[0], gk[1])
+    if not ng > ck * (1.0 + 1e-12):
+        return None                    # at = 0 is the minimiser of this (convex) model: candidate L0 covers it
+    v = -gk / ng
+    w = np.array([v @ ut + l0, v[0], v[1]])
+    curv = w @ Hm @ w
+    s0 = (ng - ck) / curv if curv > (ng - ck) / 0.9 else 0.9
+    x = s0 * v
+    def fval(x):
+        s_ = np.hypot(x[0], x[1])
+        return G(x @ ut + l0 * s_ + kappa0, x + xi)[1]
+    f = fval(x)
+    nclip = 0
+    gscale = lambda g3: 1.0 + abs(g3[0]) * nu + np.hypot(g3[1], g3[2])
+    for _ in range(30):
+        s_ = np.hypot(x[0], x[1])
+        ah = x / s_
+        g3, _ = G(x @ ut + l0 * s_ + kappa0, x + xi)
+        Jt = ut + l0 * ah
+        grad = g3[0] * Jt + g3[1:]
+        Jm = np.vstack([Jt, np.eye(2)])
+        Hs = Jm.T @ Hm @ Jm + g3[0] * l0 / s_ * (np.eye(2) - np.outer(ah, ah))
+        # the hinge-active model is not convex in at where m > 0: shift an indefinite Hessian (modified Newton)
+        tr_, df_ = 0.5 * (Hs[0, 0] + Hs[1, 1]), 0.5 * (Hs[0, 0] - Hs[1, 1])
+        rad_ = np.hypot(df_, Hs[0, 1])
+        lmin, lmax = tr_ - rad_, tr_ + rad_
+        shift = 0.0
+        if lmin < 1e-8 * max(abs(lmax), 1e-300):
+            shift = 1e-8 * max(abs(lmax), 1e-300) - lmin
+        Hs = Hs + shift * np.eye(2)
+        det = Hs[0, 0] * Hs[1, 1] - Hs[0, 1] * Hs[1, 0]
+        if not det > 0:
+            return None
+        d = -np.array([Hs[1, 1] * grad[0] - Hs[0, 1] * grad[1], -Hs[1, 0] * grad[0] + Hs[0, 0] * grad[1]]) / det
+        if np.hypot(grad[0], grad[1]) <= 1e-13 * gscale(g3) or np.hypot(d[0], d[1]) <= 1e-15 * max(1.0, s_):
+            break
+        al = 1.0
+        ok = False
+        clipped = False
+        for _bt in range(30):
+            xn = x + al * d
+            sn = np.hypot(xn[0], xn[1])
+            if 1e-12 < sn < 1.0:
+                fn = fval(xn)
+                if fn <= f + 1e-4 * al * (grad @ d) + 1e-13 * abs(f):
+                    ok = True
+                    break
+            elif sn >= 1.0:
+                clipped = True
+            al *= 0.5
+        if clipped:
+            nclip += 1
+            if nclip >= 3:
+                return None            # heading for ||a|| = 1: the boundary candidate LC covers it
+        if not ok:
+            break                      # no further decrease possible: judged by the final gradient test
+        x, f = xn, fn
+    s_ = np.hypot(x[0], x[1])
+    ah = x / s_
+    g3, _ = G(x @ ut + l0 * s_ + kappa0, x + xi)
+    grad = g3[0] * (ut + l0 * ah) + g3[1:]
+    if np.hypot(grad[0], grad[1]) > 1e-9 * gscale(g3):
+        return None
+    return x
+
+
 def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                  accelerated=True, delta=DELTA, return_all=False):
     """One (obstacle, stage) sub-problem.  A:(E,2) b:(E,) p:(2,) nominal position
@@ -172,10 +254,17 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
     best = None
     allc = []
     nm = len(mu_cands)
-    # rule T3: hinge-inactive candidates first; if the best of them has m >= 0 it is optimal
+    # rule T3.  Pass 1: the hinge-inactive candidates are ranked by the cost of the hinge-inactive MODEL
+    # (-delta*m + ro2/2|H|^2, a lower bound of the true cost that is exact for m >= 0); if its minimiser c0 has
+    # m >= 0 it is the global optimum.  Otherwise pass 2: the hinge-active candidates (and c0) compete on the
+    # TRUE cost.  Exact ties go to the lowest candidate id.
     for chi in (0.0, 1.0):
-      if chi == 1.0 and best is not None and best[4] >= 0:
-        break
+      if chi == 1.0:
+        if best[4] >= 0:
+            break
+        c0 = best
+        tc = true_cost(c0[2], c0[3])[0]
+        best = (tc,) + c0[1:]
       for il, lc in enumerate(lam_cands):
         for im, mc in enumerate(mu_cands):
             if True:
@@ -229,6 +318,16 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                             lam[0:2] = a
                             lam[2] = -np.hypot(a[0], a[1])
                         sols.append((lam, gam))
+                    if lc[0] == "LC" and len(mc) < 2:
+                        at = circle_interior(lambda t_, e_: gamma_star(t_, e_, mc, chi), chi, ut, l0, kappa0, xi, ro2, delta)
+                        if at is not None:
+                            s_ = np.hypot(at[0], at[1])
+                            gam, m, H = gamma_star(at @ ut + l0 * s_ + kappa0, at + xi, mc, chi)
+                            a = Rm @ at
+                            lam = np.zeros(E)
+                            lam[0:2] = a
+                            lam[2] = -s_
+                            sols.append((lam, gam))
                 for lam, gam in sols:
                     mu = np.zeros(Rn)
                     for k, j in enumerate(mc):
@@ -244,6 +343,8 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                         lam = np.maximum(lam, 0.0)
                     mu = np.maximum(mu, 0.0)
                     cost, m, H = true_cost(lam, mu)
+                    if chi == 0.0:
+                        cost = cost - 0.5 * min(m, 0.0) ** 2          # model cost in pass 1
                     allc.append((cost, idx, lc, mc, chi))
                     if best is None or cost < best[0] or (cost == best[0] and idx < best[1]):
                         best = (cost, idx, lam, mu, m, H, lc, mc, chi)

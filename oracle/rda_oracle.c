@@ -143,6 +143,87 @@ static void gamma_star(const lmz_ctx *c, const mu_cand *mc, double chi, double t
     *m = t + re + beta * mc->rr;
 }
 
+/* value / gradient of the candidate model in (t, e) after eliminating the mu-support coefficients */
+static void model_g3(const lmz_ctx *c, const mu_cand *mc, double chi, double t, const double *e, double *g3, double *f)
+{
+    double gam[2] = {0, 0}, m, H[2];
+    gamma_star(c, mc, chi, t, e, gam, &m, H);
+    g3[0] = chi * m - c->delta; g3[1] = c->ro2 * H[0]; g3[2] = c->ro2 * H[1];
+    if (f) *f = 0.5 * chi * m * m - c->delta * m + 0.5 * c->ro2 * (H[0] * H[0] + H[1] * H[1]);
+}
+
+/* Circle obstacle, candidate with 0 < ||a|| < 1 (lam_3 = -||a|| tight): damped Newton on
+ * Phi(at) = model(t = at'ut + l0*||at|| + kappa0, e = at + xi), l0 = -radius, started on the steepest-descent
+ * ray out of the kink at at = 0 (Phi is quadratic along a ray).  Returns 1 and at[2], or 0 when the
+ * ||a|| in {0, 1} candidates cover the optimum.  Same steps as oracle/lammuz_np.py:circle_interior. */
+static int circle_interior(const lmz_ctx *c, const mu_cand *mc, double chi, const double *ut, double l0, double *at)
+{
+    double z2[2] = {0, 0}, e[2], G0[3], g3[3], Hm[3][3], col[3];
+    model_g3(c, mc, chi, 0.0, z2, G0, NULL);
+    model_g3(c, mc, chi, 1.0, z2, col, NULL); for (int i = 0; i < 3; ++i) Hm[i][0] = col[i] - G0[i];
+    e[0] = 1; e[1] = 0; model_g3(c, mc, chi, 0.0, e, col, NULL); for (int i = 0; i < 3; ++i) Hm[i][1] = col[i] - G0[i];
+    e[0] = 0; e[1] = 1; model_g3(c, mc, chi, 0.0, e, col, NULL); for (int i = 0; i < 3; ++i) Hm[i][2] = col[i] - G0[i];
+    for (int i = 0; i < 3; ++i) for (int j = i + 1; j < 3; ++j) { double a = 0.5 * (Hm[i][j] + Hm[j][i]); Hm[i][j] = Hm[j][i] = a; }
+    double nu = hypot(ut[0], ut[1]);
+    model_g3(c, mc, chi, c->kappa0, c->xi, g3, NULL);
+    double gk0 = g3[0] * ut[0] + g3[1], gk1 = g3[0] * ut[1] + g3[2], ck = g3[0] * l0, ng = hypot(gk0, gk1);
+    if (!(ng > ck * (1.0 + 1e-12))) return 0;
+    double v0 = -gk0 / ng, v1 = -gk1 / ng;
+    double w[3] = { v0 * ut[0] + v1 * ut[1] + l0, v0, v1 }, curv = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) curv += w[i] * Hm[i][j] * w[j];
+    double s0 = curv > (ng - ck) / 0.9 ? (ng - ck) / curv : 0.9;
+    double x0 = s0 * v0, x1 = s0 * v1, f, s_;
+    s_ = hypot(x0, x1); e[0] = x0 + c->xi[0]; e[1] = x1 + c->xi[1];
+    model_g3(c, mc, chi, x0 * ut[0] + x1 * ut[1] + l0 * s_ + c->kappa0, e, g3, &f);
+    int nclip = 0;
+    for (int it = 0; it < 30; ++it) {
+        s_ = hypot(x0, x1);
+        double a0 = x0 / s_, a1 = x1 / s_;
+        e[0] = x0 + c->xi[0]; e[1] = x1 + c->xi[1];
+        model_g3(c, mc, chi, x0 * ut[0] + x1 * ut[1] + l0 * s_ + c->kappa0, e, g3, NULL);
+        double J[3][2] = { { ut[0] + l0 * a0, ut[1] + l0 * a1 }, { 1, 0 }, { 0, 1 } };
+        double gr0 = g3[0] * J[0][0] + g3[1], gr1 = g3[0] * J[0][1] + g3[2];
+        double Hs[2][2];
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+            double acc = 0;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) acc += J[i][a] * Hm[i][j] * J[j][b];
+            Hs[a][b] = acc;
+        }
+        double kq = g3[0] * l0 / s_;
+        Hs[0][0] += kq * (1 - a0 * a0); Hs[0][1] += kq * (-a0 * a1); Hs[1][0] += kq * (-a0 * a1); Hs[1][1] += kq * (1 - a1 * a1);
+        double tr = 0.5 * (Hs[0][0] + Hs[1][1]), df = 0.5 * (Hs[0][0] - Hs[1][1]), rad = hypot(df, Hs[0][1]);
+        double lmin = tr - rad, lmax = fabs(tr + rad) > 1e-300 ? fabs(tr + rad) : 1e-300;
+        if (lmin < 1e-8 * lmax) { double sh = 1e-8 * lmax - lmin; Hs[0][0] += sh; Hs[1][1] += sh; }
+        double det = Hs[0][0] * Hs[1][1] - Hs[0][1] * Hs[1][0];
+        if (!(det > 0)) return 0;
+        double d0 = -(Hs[1][1] * gr0 - Hs[0][1] * gr1) / det, d1 = -(-Hs[1][0] * gr0 + Hs[0][0] * gr1) / det;
+        double gsc = 1.0 + fabs(g3[0]) * nu + hypot(g3[1], g3[2]);
+        if (hypot(gr0, gr1) <= 1e-13 * gsc || hypot(d0, d1) <= 1e-15 * (s_ > 1 ? s_ : 1.0)) break;
+        double al = 1.0, xn0 = x0, xn1 = x1, fn = f; int ok = 0, clipped = 0;
+        for (int bt = 0; bt < 30; ++bt) {
+            xn0 = x0 + al * d0; xn1 = x1 + al * d1;
+            double sn = hypot(xn0, xn1);
+            if (sn > 1e-12 && sn < 1.0) {
+                double g3n[3];
+                e[0] = xn0 + c->xi[0]; e[1] = xn1 + c->xi[1];
+                model_g3(c, mc, chi, xn0 * ut[0] + xn1 * ut[1] + l0 * sn + c->kappa0, e, g3n, &fn);
+                if (fn <= f + 1e-4 * al * (gr0 * d0 + gr1 * d1) + 1e-13 * fabs(f)) { ok = 1; break; }
+            } else if (sn >= 1.0) clipped = 1;
+            al *= 0.5;
+        }
+        if (clipped && ++nclip >= 3) return 0;
+        if (!ok) break;
+        x0 = xn0; x1 = xn1; f = fn;
+    }
+    s_ = hypot(x0, x1);
+    e[0] = x0 + c->xi[0]; e[1] = x1 + c->xi[1];
+    model_g3(c, mc, chi, x0 * ut[0] + x1 * ut[1] + l0 * s_ + c->kappa0, e, g3, NULL);
+    double gr0 = g3[0] * (ut[0] + l0 * x0 / s_) + g3[1], gr1 = g3[0] * (ut[1] + l0 * x1 / s_) + g3[2];
+    if (hypot(gr0, gr1) > 1e-9 * (1.0 + fabs(g3[0]) * nu + hypot(g3[1], g3[2]))) return 0;
+    at[0] = x0; at[1] = x1;
+    return 1;
+}
+
 int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm2,
                    const double *p, double phi, const double *G, const double *h,
                    const double *xi, double zeta, double dbar, double ro2, double delta,
@@ -194,17 +275,22 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
     double best_m = 0, best_H[2] = {0, 0};
     for (int i = 0; i < E; ++i) lam_out[i] = 0;
     for (int j = 0; j < R; ++j) mu_out[j] = 0;
-    /* Rule T3: hinge-inactive candidates (ic = 0) first; if the best of them has m >= 0 it is optimal and the
-     * hinge-active ones are skipped; otherwise all compete, lowest id = 2*(il*nm+im)+ic on exact ties. */
+    /* Rule T3.  Pass 1 (ic = 0): the hinge-inactive candidates are ranked by the cost of the hinge-inactive MODEL
+     * (-delta*m + ro2/2|H|^2: a lower bound of the true cost, exact for m >= 0); if its minimiser c0 has m >= 0 it
+     * is the global optimum.  Otherwise pass 2 (ic = 1): the hinge-active candidates and c0 compete on the TRUE
+     * cost.  Exact ties go to the lowest id = 2*(il*nm+im)+ic. */
     int best_id = 0x7fffffff;
     for (int ic = 0; ic < 2; ++ic) {
-    if (ic == 1 && best_m >= 0) break;
+    if (ic == 1) {
+        if (best_m >= 0) break;
+        best_cost += 0.5 * best_m * best_m;            /* c0: model cost -> true cost (m < 0 here) */
+    }
     for (int il = 0; il < nl; ++il) for (int im = 0; im < nm; ++im) {
         int idx = 2 * (il * nm + im) + ic;
         const mu_cand *mc = &mcs[im]; double chi = (double)ic;
         double lam[EMAX]; for (int i = 0; i < E; ++i) lam[i] = 0;
         double gam[2] = {0, 0}, m, H[2];
-        int nsol = 1; double ats[4] = {0, 0, 0, 0}, ut_[2] = {0, 0}, l0_ = 0, detS_ = 1, AS_[4] = {0, 0, 0, 0};
+        int nsol = 1, interior = -1; double ats[6] = {0, 0, 0, 0, 0, 0}, ut_[2] = {0, 0}, l0_ = 0, detS_ = 1, AS_[4] = {0, 0, 0, 0};
         if (lt[il] == 0) {
             gamma_star(&c, mc, chi, c.kappa0, c.xi, gam, &m, H);
         } else if (lt[il] == 1) {
@@ -244,6 +330,7 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             g2[0] = (chi * m - delta) * ut[0] + ro2 * H[0] - g0[0]; g2[1] = (chi * m - delta) * ut[1] + ro2 * H[1] - g0[1];
             double q12 = 0.5 * (g1[1] + g2[0]);
             nsol = trs2(g1[0], q12, g2[1], g0[0], g0[1], lt[il] == 2, ats);
+            if (lt[il] == 3 && mc->k < 2 && circle_interior(&c, mc, chi, ut, l0, &ats[2 * nsol])) { interior = nsol; nsol++; }
             ut_[0] = ut[0]; ut_[1] = ut[1]; l0_ = l0; detS_ = detS;
             AS_[0] = AS[0][0]; AS_[1] = AS[0][1]; AS_[2] = AS[1][0]; AS_[3] = AS[1][1];
         }
@@ -253,7 +340,8 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             double at0 = ats[2 * sol], at1 = ats[2 * sol + 1], e[2];
             for (int i = 0; i < E; ++i) lam[i] = 0;
             e[0] = at0 + c.xi[0]; e[1] = at1 + c.xi[1];
-            gamma_star(&c, mc, chi, at0 * ut_[0] + at1 * ut_[1] + l0_ + c.kappa0, e, gam, &m, H);
+            double sc_ = sol == interior ? hypot(at0, at1) : 1.0;   /* circle: lam_3 = -||a|| (1 on the boundary) */
+            gamma_star(&c, mc, chi, at0 * ut_[0] + at1 * ut_[1] + l0_ * sc_ + c.kappa0, e, gam, &m, H);
             double ax = cs * at0 - sn * at1, ay = sn * at0 + cs * at1;   /* a = R at */
             if (lt[il] == 2) {
                 /* A_S' lamS = a */
@@ -272,7 +360,7 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
         for (int i = 0; i < E; ++i) { mm += lam[i] * c.q[i]; HH[0] += lam[i] * c.M[i][0]; HH[1] += lam[i] * c.M[i][1]; }
         for (int j = 0; j < R; ++j) { mm -= mu[j] * h[j]; HH[0] += mu[j] * G[2 * j]; HH[1] += mu[j] * G[2 * j + 1]; }
         double ng = mm < 0 ? mm : 0;
-        double cost = 0.5 * ng * ng - delta * mm + 0.5 * ro2 * (HH[0] * HH[0] + HH[1] * HH[1]);
+        double cost = (ic ? 0.5 * ng * ng : 0.0) - delta * mm + 0.5 * ro2 * (HH[0] * HH[0] + HH[1] * HH[1]);
         if (cost < best_cost || (cost == best_cost && idx < best_id)) {
             best_cost = cost; best_idx = idx; best_id = idx; best_m = mm; best_H[0] = HH[0]; best_H[1] = HH[1];
             for (int i = 0; i < E; ++i) lam_out[i] = lam[i];

@@ -46,7 +46,7 @@ def closed_loop():
     obs = sc.scene_path_track()
     mpc = MPC(car_d, [r.copy() for r in ref], receding=10, sample_time=0.1, iter_num=2, obstacle_order=True, ro1=300,
               max_edge_num=4, max_obs_num=11, slack_gain=8, _backend=oracle_backend)
-    state = ref[0].copy().reshape(3, 1)
+    state = np.array([[10.0], [42.0], [1.57]])      # robot state of path_track_diff.yaml:13
     us, states = [], []
     for _ in range(40):
         u, info = mpc.control(state, 4, list(obs))

@@ -169,7 +169,7 @@ def test_closed_loop_path_track_golden_and_no_collision():
     mpc = MPC(car_d, [r.copy() for r in ref], receding=10, sample_time=0.1, iter_num=2, obstacle_order=True, ro1=300,
               max_edge_num=4, max_obs_num=11, slack_gain=8)
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "path_track_diff_golden.json")))
-    state = ref[0].copy().reshape(3, 1)
+    state = np.array([[10.0], [42.0], [1.57]])      # robot state of path_track_diff.yaml:13
     minc, arrived = np.inf, False
     for i in range(500):
         u, info = mpc.control(state, 4, list(obs))

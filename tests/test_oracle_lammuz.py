@@ -105,6 +105,60 @@ def test_value_not_worse_than_scipy(orc):
         assert cmh[i, 0] <= best + 1e-8 * (1 + abs(best)), (i, cmh[i, 0], best)
 
 
+def test_circle_value_not_worse_than_scipy(orc):
+    """norm2 obstacles (cone rda_solver.py:1041-1050): lam = (a, lam_3 <= -||a||), ||a|| <= 1.  Near a predicted
+    overlap or with a large xi the optimum has 0 < ||a|| < 1 - the circle-interior candidate must find it."""
+    from scipy.optimize import minimize, NonlinearConstraint, Bounds
+    rng = np.random.default_rng(21)
+    n_interior = 0
+    for trial in range(16):
+        delta = 10 ** rng.uniform(-6, -2)
+        ro2 = float(rng.choice([1.0, 0.3, 5.0]))
+        p = rng.uniform(-5, 5, 2)
+        phi = rng.uniform(-np.pi, np.pi)
+        th = rng.uniform(0, 2 * np.pi)
+        cen = p + rng.choice([0.3, 0.8, 2.0, 4.0]) * np.array([np.cos(th), np.sin(th)])
+        A = np.array([[1, 0], [0, 1], [0, 0], [0, 0.0]])
+        b = np.array([cen[0], cen[1], -rng.uniform(0.3, 1.5), 0])
+        xi = rng.normal(0, rng.choice([0, 0.05, 0.5]), 2)
+        zeta = rng.normal(0, rng.choice([0, 0.3, 2.0]))
+        dbar = rng.uniform(0.1, 1.0)
+        inp = dict(A=A[None], b=b[None], cone=np.ones(1, np.int32), p=p[None], phi=np.array([phi]), xi=xi[None],
+                   zeta=np.array([zeta]), dbar=np.array([dbar]))
+        lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp, ro2=ro2, delta=delta)
+        na = np.hypot(lam[0, 0], lam[0, 1])
+        assert na <= 1 + 1e-12 and lam[0, 2] <= -na + 1e-12 and (mu >= 0).all()
+        n_interior += 1e-9 < na < 1 - 1e-9
+        c, s = np.cos(phi), np.sin(phi)
+        q = A @ p - b
+        M = A @ np.array([[c, -s], [s, c]])
+
+        def f(y):
+            l = np.r_[y[:3], 0]
+            m = l @ q - y[3:] @ hp.H + zeta - dbar
+            Hv = M.T @ l + hp.G.T @ y[3:] + xi
+            return 0.5 * min(m, 0) ** 2 - delta * m + 0.5 * ro2 * Hv @ Hv
+        cons = [NonlinearConstraint(lambda y: y[0] ** 2 + y[1] ** 2, -np.inf, 1.0),
+                NonlinearConstraint(lambda y: -y[2] - np.hypot(y[0], y[1]), 0, np.inf)]
+        bnd = Bounds(np.r_[-np.inf, -np.inf, -np.inf, 0, 0, 0, 0], np.full(7, np.inf))
+        best = np.inf
+        for k in range(2):
+            y0 = np.r_[lam[0, :3], mu[0]] + (rng.normal(0, 0.1, 7) if k else 0)
+            y0[3:] = np.abs(y0[3:])
+            r = minimize(f, y0, method="trust-constr", bounds=bnd, constraints=cons,
+                         options={"gtol": 1e-11, "xtol": 1e-13, "maxiter": 1500})
+            y = r.x.copy()
+            y[3:] = np.maximum(y[3:], 0)
+            n2 = np.hypot(y[0], y[1])
+            if n2 > 1:
+                y[:2] /= n2
+                n2 = 1
+            y[2] = min(y[2], -n2)
+            best = min(best, f(y))
+        assert cmh[0, 0] <= best + 1e-8 * (1 + abs(best)), (trial, cmh[0, 0], best)
+    assert n_interior >= 3, n_interior
+
+
 KAT = [  # obstacle, robot pose (x, y, phi), distance  - SURVEY.md appendix B
     ("poly", (25, 26, 0.0), 2.2),
     ("poly", (25, 30, 0.7), 4.5949905),
