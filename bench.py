@@ -244,8 +244,9 @@ def main():
     if os.path.exists(tr_file):
         try:
             tj = json.load(open(tr_file))
-            r_lm["traffic"] = tj.get("k_lammuz")
-            r_su["traffic"] = tj.get("k_su")
+            if tj.get("workload") == {"n_obs": N, "horizon": T}:       # PMC bytes are per launch of THIS workload only
+                r_lm["traffic"] = tj.get("k_lammuz")
+                r_su["traffic"] = tj.get("k_su")
         except Exception:
             pass
     dominant, secondary = (r_su, r_lm) if su_ms >= lm_ms else (r_lm, r_su)

@@ -224,7 +224,7 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
             mu_cands.append((j1, j2))
     # ---- lam candidates ------------------------------------------------------
     if cone_norm2:
-        lam_cands = [("L0",), ("LC",)]
+        lam_cands = [("L0",), ("LC",), ("LI",)]
     else:
         lam_cands = [("L0",)]
         lam_cands += [("L1", i) for i in range(E) if A[i] @ A[i] > 0]
@@ -307,7 +307,7 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                     g1 = grad(np.array([1.0, 0.0])) - g0
                     g2 = grad(np.array([0.0, 1.0])) - g0
                     Q = np.array([[g1[0], 0.5 * (g1[1] + g2[0])], [0.5 * (g1[1] + g2[0]), g2[1]]])
-                    for at in trs2(Q, g0, disc=(lc[0] == "L2")):
+                    for at in (trs2(Q, g0, disc=(lc[0] == "L2")) if lc[0] != "LI" else []):
                         gam, m, H = gamma_star(at @ ut + l0 + kappa0, at + xi, mc, chi)
                         a = Rm @ at
                         lam = np.zeros(E)
@@ -318,7 +318,7 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                             lam[0:2] = a
                             lam[2] = -np.hypot(a[0], a[1])
                         sols.append((lam, gam))
-                    if lc[0] == "LC" and len(mc) < 2:
+                    if lc[0] == "LI" and len(mc) < 2:
                         at = circle_interior(lambda t_, e_: gamma_star(t_, e_, mc, chi), chi, ut, l0, kappa0, xi, ro2, delta)
                         if at is not None:
                             s_ = np.hypot(at[0], at[1])

@@ -256,11 +256,11 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             m->rr = m->r[0] * m->r[0] + m->r[1] * m->r[1];
         }
     }
-    /* lam candidates: type 0 L0, 1 L1(i), 2 L2(i1,i2), 3 LC */
+    /* lam candidates: type 0 L0, 1 L1(i), 2 L2(i1,i2), 3 LC (||a|| = 1), 4 LI (0 < ||a|| < 1) */
     int lt[1 + EMAX + EMAX * (EMAX - 1) / 2], li1[1 + EMAX + EMAX * (EMAX - 1) / 2], li2[1 + EMAX + EMAX * (EMAX - 1) / 2];
     int nl = 0;
     lt[nl] = 0; li1[nl] = li2[nl] = -1; nl++;
-    if (cone_norm2) { lt[nl] = 3; li1[nl] = li2[nl] = -1; nl++; }
+    if (cone_norm2) { lt[nl] = 3; li1[nl] = li2[nl] = -1; nl++; lt[nl] = 4; li1[nl] = li2[nl] = -1; nl++; }
     else {
         for (int i = 0; i < E; ++i)
             if (A[2 * i] * A[2 * i] + A[2 * i + 1] * A[2 * i + 1] > 0) { lt[nl] = 1; li1[nl] = i; li2[nl] = -1; nl++; }
@@ -290,7 +290,7 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
         const mu_cand *mc = &mcs[im]; double chi = (double)ic;
         double lam[EMAX]; for (int i = 0; i < E; ++i) lam[i] = 0;
         double gam[2] = {0, 0}, m, H[2];
-        int nsol = 1, interior = -1; double ats[6] = {0, 0, 0, 0, 0, 0}, ut_[2] = {0, 0}, l0_ = 0, detS_ = 1, AS_[4] = {0, 0, 0, 0};
+        int nsol = 1, interior = -1; double ats[4] = {0, 0, 0, 0}, ut_[2] = {0, 0}, l0_ = 0, detS_ = 1, AS_[4] = {0, 0, 0, 0};
         if (lt[il] == 0) {
             gamma_star(&c, mc, chi, c.kappa0, c.xi, gam, &m, H);
         } else if (lt[il] == 1) {
@@ -329,8 +329,8 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
             gamma_star(&c, mc, chi, ut[1] + l0 + c.kappa0, e, gam, &m, H);
             g2[0] = (chi * m - delta) * ut[0] + ro2 * H[0] - g0[0]; g2[1] = (chi * m - delta) * ut[1] + ro2 * H[1] - g0[1];
             double q12 = 0.5 * (g1[1] + g2[0]);
-            nsol = trs2(g1[0], q12, g2[1], g0[0], g0[1], lt[il] == 2, ats);
-            if (lt[il] == 3 && mc->k < 2 && circle_interior(&c, mc, chi, ut, l0, &ats[2 * nsol])) { interior = nsol; nsol++; }
+            if (lt[il] == 4) { nsol = mc->k < 2 ? circle_interior(&c, mc, chi, ut, l0, ats) : 0; interior = 0; }
+            else nsol = trs2(g1[0], q12, g2[1], g0[0], g0[1], lt[il] == 2, ats);
             ut_[0] = ut[0]; ut_[1] = ut[1]; l0_ = l0; detS_ = detS;
             AS_[0] = AS[0][0]; AS_[1] = AS[0][1]; AS_[2] = AS[1][0]; AS_[3] = AS[1][1];
         }

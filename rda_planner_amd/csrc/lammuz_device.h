@@ -125,6 +125,86 @@ __device__ __forceinline__ int trs2(double q11, double q12, double q22, double c
     return 1;
 }
 
+// gradient (d/dt, d/de) and value of the candidate model after eliminating the mu-support coefficients
+__device__ __forceinline__ void model_g3(const MuCand &mc, double chi, double ro2, double delta, double t, double e0, double e1,
+                                         double &gt, double &ge0, double &ge1, double &f)
+{
+    double ga0, ga1, m, H0, H1;
+    gamma_star(mc, chi, ro2, delta, t, e0, e1, ga0, ga1, m, H0, H1);
+    gt = chi * m - delta; ge0 = ro2 * H0; ge1 = ro2 * H1;
+    f = 0.5 * chi * m * m - delta * m + 0.5 * ro2 * (H0 * H0 + H1 * H1);
+}
+
+// Circle obstacle, candidate with 0 < ||a|| < 1 (lam_3 = -||a|| tight): damped Newton on
+// Phi(at) = model(t = at'ut + l0*||at|| + kappa0, e = at + xi), l0 = -radius, started on the steepest-descent ray out
+// of the kink at at = 0 (Phi is quadratic along a ray).  Returns false when the ||a|| in {0, 1} candidates cover
+// the optimum.  mc.k < 2 only.  Lane-local: runs on the lanes that own an LI candidate.
+__device__ __forceinline__ bool circle_interior(const MuCand &mc, double chi, double ro2, double delta, double ut0, double ut1,
+                                                double l0, double kappa0, double xi0, double xi1, double &at0, double &at1)
+{
+    double G0t, G00, G01, c0, c1, c2, f;
+    model_g3(mc, chi, ro2, delta, 0.0, 0.0, 0.0, G0t, G00, G01, f);
+    double h00, h01, h02, h11, h12, h22;                      // symmetric 3x3 model Hessian in (t, e0, e1)
+    model_g3(mc, chi, ro2, delta, 1.0, 0.0, 0.0, c0, c1, c2, f); h00 = c0 - G0t; double h10 = c1 - G00, h20 = c2 - G01;
+    model_g3(mc, chi, ro2, delta, 0.0, 1.0, 0.0, c0, c1, c2, f); h01 = c0 - G0t; h11 = c1 - G00; double h21 = c2 - G01;
+    model_g3(mc, chi, ro2, delta, 0.0, 0.0, 1.0, c0, c1, c2, f); h02 = c0 - G0t; h12 = c1 - G00; h22 = c2 - G01;
+    h01 = 0.5 * (h01 + h10); h02 = 0.5 * (h02 + h20); h12 = 0.5 * (h12 + h21);
+    const double nu = hypot(ut0, ut1);
+    double gt, ge0, ge1;
+    model_g3(mc, chi, ro2, delta, kappa0, xi0, xi1, gt, ge0, ge1, f);
+    double gk0 = gt * ut0 + ge0, gk1 = gt * ut1 + ge1, ck = gt * l0, ng = hypot(gk0, gk1);
+    if (!(ng > ck * (1.0 + 1e-12))) return false;
+    double v0 = -gk0 / ng, v1 = -gk1 / ng;
+    double w0 = v0 * ut0 + v1 * ut1 + l0;
+    double curv = w0 * (h00 * w0 + h01 * v0 + h02 * v1) + v0 * (h01 * w0 + h11 * v0 + h12 * v1) + v1 * (h02 * w0 + h12 * v0 + h22 * v1);
+    double s0 = curv > (ng - ck) / 0.9 ? (ng - ck) / curv : 0.9;
+    double x0 = s0 * v0, x1 = s0 * v1, s_ = hypot(x0, x1);
+    model_g3(mc, chi, ro2, delta, x0 * ut0 + x1 * ut1 + l0 * s_ + kappa0, x0 + xi0, x1 + xi1, gt, ge0, ge1, f);
+    int nclip = 0;
+    for (int it = 0; it < 30; ++it) {
+        s_ = hypot(x0, x1);
+        double a0 = x0 / s_, a1 = x1 / s_, fdummy;
+        model_g3(mc, chi, ro2, delta, x0 * ut0 + x1 * ut1 + l0 * s_ + kappa0, x0 + xi0, x1 + xi1, gt, ge0, ge1, fdummy);
+        double j0 = ut0 + l0 * a0, j1 = ut1 + l0 * a1;          // dt/dat
+        double gr0 = gt * j0 + ge0, gr1 = gt * j1 + ge1;
+        // Hs = J' Hm J with J = [j; I]
+        double H00 = j0 * (h00 * j0 + h01) + (h01 * j0 + h11);
+        double H01 = j0 * (h00 * j1 + h02) + (h01 * j1 + h12);
+        double H10 = j1 * (h00 * j0 + h01) + (h02 * j0 + h12);
+        double H11 = j1 * (h00 * j1 + h02) + (h02 * j1 + h22);
+        double kq = gt * l0 / s_;
+        H00 += kq * (1 - a0 * a0); H01 += kq * (-a0 * a1); H10 += kq * (-a0 * a1); H11 += kq * (1 - a1 * a1);
+        double tr = 0.5 * (H00 + H11), df = 0.5 * (H00 - H11), rad = hypot(df, H01);
+        double lmin = tr - rad, lmax = fabs(tr + rad) > 1e-300 ? fabs(tr + rad) : 1e-300;
+        if (lmin < 1e-8 * lmax) { double sh = 1e-8 * lmax - lmin; H00 += sh; H11 += sh; }
+        double det = H00 * H11 - H01 * H10;
+        if (!(det > 0)) return false;
+        double d0 = -(H11 * gr0 - H01 * gr1) / det, d1 = -(-H10 * gr0 + H00 * gr1) / det;
+        double gsc = 1.0 + fabs(gt) * nu + hypot(ge0, ge1);
+        if (hypot(gr0, gr1) <= 1e-13 * gsc || hypot(d0, d1) <= 1e-15 * (s_ > 1 ? s_ : 1.0)) break;
+        double al = 1.0, xn0 = x0, xn1 = x1, fn = f; bool ok = false, clipped = false;
+        for (int bt = 0; bt < 30; ++bt) {
+            xn0 = x0 + al * d0; xn1 = x1 + al * d1;
+            double sn = hypot(xn0, xn1);
+            if (sn > 1e-12 && sn < 1.0) {
+                double t0, t1, t2;
+                model_g3(mc, chi, ro2, delta, xn0 * ut0 + xn1 * ut1 + l0 * sn + kappa0, xn0 + xi0, xn1 + xi1, t0, t1, t2, fn);
+                if (fn <= f + 1e-4 * al * (gr0 * d0 + gr1 * d1) + 1e-13 * fabs(f)) { ok = true; break; }
+            } else if (sn >= 1.0) clipped = true;
+            al *= 0.5;
+        }
+        if (clipped && ++nclip >= 3) return false;
+        if (!ok) break;
+        x0 = xn0; x1 = xn1; f = fn;
+    }
+    s_ = hypot(x0, x1);
+    model_g3(mc, chi, ro2, delta, x0 * ut0 + x1 * ut1 + l0 * s_ + kappa0, x0 + xi0, x1 + xi1, gt, ge0, ge1, f);
+    double gr0 = gt * (ut0 + l0 * x0 / s_) + ge0, gr1 = gt * (ut1 + l0 * x1 / s_) + ge1;
+    if (hypot(gr0, gr1) > 1e-9 * (1.0 + fabs(gt) * nu + hypot(ge0, ge1))) return false;
+    at0 = x0; at1 = x1;
+    return true;
+}
+
 // decode the k-th pair (lexicographic i1<i2) of {0..n-1}
 __device__ __forceinline__ void decode_pair(int k, int n, int &i1, int &i2)
 {
@@ -136,8 +216,9 @@ __device__ __forceinline__ void decode_pair(int k, int n, int &i1, int &i2)
 
 struct Params { int E, R; int norm2; double px, py, cs, sn, xi0, xi1, kappa0, ro2, delta; };
 
-// sign feasibility, clamping and TRUE cost of one candidate point
-__device__ __forceinline__ bool finish(const WaveLDS &W, const RobotLDS &Rb, const Params &P, const MuCand &mc, int type,
+// sign feasibility, clamping and cost of one candidate point: the hinge-inactive MODEL cost in pass ic = 0
+// (a lower bound of the true cost, exact for m >= 0), the TRUE cost in pass ic = 1
+__device__ __forceinline__ bool finish(const WaveLDS &W, const RobotLDS &Rb, const Params &P, const MuCand &mc, int type, int ic,
                                        int i1, int i2, double la1, double la2, double ga0, double ga1, Sol &s)
 {
     if (!P.norm2) {
@@ -149,7 +230,7 @@ __device__ __forceinline__ bool finish(const WaveLDS &W, const RobotLDS &Rb, con
     if (ga0 < 0) ga0 = 0;
     if (ga1 < 0) ga1 = 0;
     double mm = P.kappa0, HH0 = P.xi0, HH1 = P.xi1;
-    if (type == 3) {
+    if (type >= 3) {
         double l3 = -hypot(la1, la2);
         mm += la1 * W.q[0] + la2 * W.q[1] + l3 * W.q[2];
         HH0 += la1 * W.M[0][0] + la2 * W.M[1][0] + l3 * W.M[2][0];
@@ -161,7 +242,7 @@ __device__ __forceinline__ bool finish(const WaveLDS &W, const RobotLDS &Rb, con
     if (mc.k >= 1) { mm -= ga0 * Rb.h[mc.j0]; HH0 += ga0 * Rb.G[mc.j0][0]; HH1 += ga0 * Rb.G[mc.j0][1]; }
     if (mc.k == 2) { mm -= ga1 * Rb.h[mc.j1]; HH0 += ga1 * Rb.G[mc.j1][0]; HH1 += ga1 * Rb.G[mc.j1][1]; }
     double ng = mm < 0 ? mm : 0;
-    s.cost = 0.5 * ng * ng - P.delta * mm + 0.5 * P.ro2 * (HH0 * HH0 + HH1 * HH1);
+    s.cost = (ic ? 0.5 * ng * ng : 0.0) - P.delta * mm + 0.5 * P.ro2 * (HH0 * HH0 + HH1 * HH1);
     s.m = mm; s.H0 = HH0; s.H1 = HH1;
     s.i1 = i1; s.i2 = i2; s.l1 = la1; s.l2 = la2;
     s.j1 = mc.j0; s.j2 = mc.j1; s.g1 = ga0; s.g2 = ga1;
@@ -192,9 +273,9 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
     // ---- lam candidate ---------------------------------------------------------------------
     int i1 = -1, i2 = -1; double la1 = 0, la2 = 0;
     double ga0 = 0, ga1 = 0, m, H0, H1;
-    int type;                                   // 0 L0, 1 L1, 2 L2, 3 LC
+    int type;                                   // 0 L0, 1 L1, 2 L2, 3 LC (||a|| = 1), 4 LI (0 < ||a|| < 1)
     if (il == 0) type = 0;
-    else if (P.norm2) type = 3;
+    else if (P.norm2) type = il == 1 ? 3 : 4;
     else if (il <= P.E) { type = 1; i1 = il - 1; }
     else { type = 2; decode_pair(il - 1 - P.E, P.E, i1, i2); }
 
@@ -225,6 +306,14 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
             dvx = P.px - vx; dvy = P.py - vy;
         } else { dvx = P.px - W.b[0]; dvy = P.py - W.b[1]; l0 = W.b[2]; i1 = 0; i2 = 1; }
         double ut0 = P.cs * dvx + P.sn * dvy, ut1 = -P.sn * dvx + P.cs * dvy;       // R'(p - v)
+        if (type == 4) {
+            double at0, at1;
+            if (mc.k == 2 || !circle_interior(mc, chi, ro2, delta, ut0, ut1, l0, P.kappa0, P.xi0, P.xi1, at0, at1)) return false;
+            gamma_star(mc, chi, ro2, delta, at0 * ut0 + at1 * ut1 + l0 * hypot(at0, at1) + P.kappa0, at0 + P.xi0, at1 + P.xi1,
+                       ga0, ga1, m, H0, H1);
+            la1 = P.cs * at0 - P.sn * at1; la2 = P.sn * at0 + P.cs * at1;              // a = R at
+            return finish(W, Rb, P, mc, type, ic, i1, i2, la1, la2, ga0, ga1, s);
+        }
         double g00, g01, g10, g11, g20, g21;
         gamma_star(mc, chi, ro2, delta, l0 + P.kappa0, P.xi0, P.xi1, ga0, ga1, m, H0, H1);
         g00 = (chi * m - delta) * ut0 + ro2 * H0; g01 = (chi * m - delta) * ut1 + ro2 * H1;
@@ -244,11 +333,11 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
                 la2 = (a00 * ay - ax * a01) / detS;
             } else { la1 = ax; la2 = ay; }
             Sol c2;
-            if (finish(W, Rb, P, mc, type, i1, i2, la1, la2, ga0, ga1, c2) && (!any || c2.cost < s.cost)) { s = c2; any = true; }
+            if (finish(W, Rb, P, mc, type, ic, i1, i2, la1, la2, ga0, ga1, c2) && (!any || c2.cost < s.cost)) { s = c2; any = true; }
         }
         return any;
     }
-    return finish(W, Rb, P, mc, type, i1, i2, la1, la2, ga0, ga1, s);
+    return finish(W, Rb, P, mc, type, ic, i1, i2, la1, la2, ga0, ga1, s);
 }
 
 // Whole-wave solve.  All 64 lanes must call; W.A/W.b and Rb must be filled and visible.  On return
@@ -263,15 +352,16 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
         W.M[lane][1] = -ax * P.sn + ay * P.cs;
     }
     __builtin_amdgcn_wave_barrier();
-    const int nl = P.norm2 ? 2 : 1 + P.E + P.E * (P.E - 1) / 2;
+    const int nl = P.norm2 ? 3 : 1 + P.E + P.E * (P.E - 1) / 2;
     const int nm = 1 + P.R + P.R * (P.R - 1) / 2;
     const int half = nl * nm;
     best.cost = INFINITY; best.id = 0x7fffffff;
     best.m = 0; best.H0 = 0; best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
     best.l1 = best.l2 = best.g1 = best.g2 = 0;
-    // Rule T3: the hinge-inactive candidates (ic = 0) are examined first; if the best of them has m >= 0 it
-    // is the global optimum (the ic = 0 model under-estimates the true cost and is exact for m >= 0) and the
-    // hinge-active candidates are skipped.  Otherwise all candidates compete, lowest id on exact ties.
+    // Rule T3.  Pass 1 (ic = 0): the hinge-inactive candidates are ranked by the cost of the hinge-inactive MODEL
+    // (-delta*m + ro2/2|H|^2: a lower bound of the true cost, exact for m >= 0); if its minimiser c0 has m >= 0 it is
+    // the global optimum.  Otherwise pass 2 (ic = 1): the hinge-active candidates and c0 compete on the TRUE cost.
+    // Exact ties go to the lowest id = 2*(il*nm+im)+ic.
     for (int ic = 0; ic < 2; ++ic) {
         for (int c = lane; c < half; c += 64) {
             int im = c % nm, il = c / nm;
@@ -297,6 +387,7 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
         best.l1 = __shfl(best.l1, src, 64); best.l2 = __shfl(best.l2, src, 64);
         best.g1 = __shfl(best.g1, src, 64); best.g2 = __shfl(best.g2, src, 64);
         if (best.m >= 0) break;                 // wave-uniform after the broadcast
+        if (ic == 0) best.cost += 0.5 * best.m * best.m;      // c0: model cost -> true cost (m < 0 here)
     }
 }
 
