@@ -14,12 +14,16 @@
 // Work split inside an interior-point iteration
 //   all 4 waves : per-stage sums over the obstacles with an active hinge (the only N-dependent
 //                 work; [T][N] structure-of-arrays coefficients, (stage, chunk) thread mapping),
-//                 stage gradients / Hessian bases, slack and multiplier updates, reductions
-//   wave 0      : the serial Riccati sweeps.  Every lane carries the cost-to-go (P 5x5, p 5) in
-//                 registers and performs the stage update redundantly, with the next stage's
-//                 constants prefetched from LDS: no barrier and no LDS round trip on the serial
-//                 critical path
+//                 stage gradients / Hessian bases, closed-loop sweep matrices, slack and multiplier
+//                 updates, reductions
+//   wave 0      : the serial Riccati sweeps, LANE-PARALLEL.  Matrix recursion: lane 8r+q owns entry
+//                 (r,q) of the 8x8 stage matrix M = Hb + F'PF; the two small products exchange
+//                 operands with ds_bpermute, the 3x3 pivot block is broadcast with v_readlane and
+//                 inverted by the adjugate on every lane.  Vector sweeps: one affine map per stage,
+//                 x+ = Mrow . x + c, lane r owns row r, x is broadcast with v_readlane (16 VALU
+//                 instructions per stage).  All per-stage constants are prefetched one stage ahead.
 //   wave 1      : adjoint sweep for the reduced gradient, concurrently with wave 0
+//   wave 2      : Newton right-hand side of the predictor, concurrently with wave 0
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -82,15 +86,16 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
     }
 }
 
-// LDS carve-up (doubles).  Per-stage constants of the serial sweeps are packed into 16-byte aligned records so
-// that they are fetched with ds_read_b128 and prefetched one stage ahead.
-constexpr int RM = 52;   // matrix-sweep record: upper triangle of the 8x8 stage Hessian base (36) | B (6) | a13 a23 | pad
-constexpr int RV = 40;   // vector-sweep record: A (9) | B (6) | W (15) | Minv sym (6) | kk (3) | pad
+// LDS carve-up (doubles).  Per-lane rows of the sweep matrices are 16-byte aligned (row stride 6).
+constexpr int FT = 48;   // F' of the stage, [8 columns q][6]: F[0..4][q] | pad   (x+ = F y, x = [s(3) up(2)])
+constexpr int HB = 64;   // full 8x8 stage Hessian base; re-used after the matrix sweep for Mb [8][6]
+constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
+constexpr int MF = 36;   // forward sweep rows [6][6]
 __device__ __host__ inline int ev(int n) { return (n + 1) & ~1; }
 struct Lds {
     double *s, *u, *d, *phin, *ref, *Ak, *Bk, *Ck, *Q0, *Q1, *Q2;
-    double *Jm;        // [T][32] d(s_next, d)/dy : 4x8 per stage (constant during the solve)
-    double *part;      // [NT][9] partial sums of the chunked reductions
+    double *Ft;        // [T][FT]  (constant during the solve)
+    double *part;      // [NT][9] partial sums of the chunked reductions (aliases Hb)
     double *hs;        // [T][9]  hinge sums
     double *Hw, *gw;   // [T][16], [T][4]
     double *bw;        // [T][5]  barrier weights (u0 box, u1 box, d box, rate u0, rate u1)
@@ -98,8 +103,10 @@ struct Lds {
     double *gst;       // [T][8]  stage gradient (objective + C'lam)
     double *gh;        // [T][8]  Newton right-hand side gradient
     double *gad;       // [T][3]  reduced gradient (adjoint sweep)
-    double *recM;      // [T][RM]
-    double *recV;      // [T][RV]
+    double *Hb;        // [T][HB]  stage Hessian base -> (after the matrix sweep) backward rows Mb [8][6]
+    double *Wn;        // [T][WN]
+    double *Mf;        // [T][MF]  (overlays hs..cy, which are dead once the stage Hessians are assembled)
+    double *kk;        // [T][4]   feed-forward of the current right-hand side
     double *cw, *cl, *rp, *rc, *dw, *dl;   // [T][NC]
     double *dy;                            // [T][8]
     double *pv, *red;                      // 8, NT
@@ -107,9 +114,11 @@ struct Lds {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
         Ak = p; p += ev(9 * T); Bk = p; p += 6 * T; Ck = p; p += ev(3 * T); Q0 = p; p += ev(T); Q1 = p; p += ev(T); Q2 = p; p += ev(T);
-        Jm = p; p += 32 * T; hs = p; p += ev(9 * T); Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += ev(5 * T); cy = p; p += ev(5 * T);
-        gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += ev(3 * T); recM = p; part = p; p += (RM * T > 9 * NT ? RM * T : 9 * NT); recV = p;   // part (phase 1) and recM (phases 3-4) never live together
-         p += RV * T;
+        Ft = p; p += FT * T; hs = p; Mf = p; p += ev(9 * T);      // Mf (after the matrix sweep) overlays hs|Hw|gw|bw|cy: 39T >= MF*T
+        Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += ev(5 * T); cy = p; p += ev(5 * T);
+        gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += ev(3 * T);
+        Hb = p; part = p; p += (HB * T > 9 * NT ? HB * T : 9 * NT);    // part (phase 1) is dead before Hb is written (phase 3)
+        Wn = p; p += WN * T; kk = p; p += 4 * T;
         cw = p; p += NC * T; cl = p; p += NC * T; rp = p; p += NC * T; rc = p; p += NC * T; dw = p; p += NC * T; dl = p; p += NC * T;
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT;
     }
@@ -117,8 +126,8 @@ struct Lds {
 inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 3 * ev(T)
-             + 32 * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (RM * T > 9 * NT ? RM * T : 9 * NT) + RV * T
-             + 6 * NC * T + 8 * T + 8 + NT;
+             + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
+             + WN * T + 4 * T + 6 * NC * T + 8 * T + 8 + NT;
     return n * sizeof(double);
 }
 
@@ -163,12 +172,24 @@ __device__ __forceinline__ void con_T(const double *x, int t, double &y3, double
     y5 = x[0] - x[1] + r0; y6 = x[2] - x[3] + r1; y7 = x[4] - x[5]; y3 = -r0; y4 = -r1;
 }
 
+// wave-uniform broadcast of lane `src`'s value (src is a compile-time constant after unrolling): two v_readlane_b32,
+// the result lives in an SGPR pair and feeds the FMAs as a scalar operand
+__device__ __forceinline__ double bcast(double v, int src)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// entry F[i][q] of the stage transition x+ = F y from the packed transpose
+__device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return Ft_t[6 * q + i]; }
+
 // The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).
 __device__ inline void solve(const Args &a, double *smem)
 {
     const Cfg &c = a.c;
     const int T = c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
+    long long tprev = clock64();
     const double vref = *a.ref_speed;
     // (stage, chunk) mapping of the obstacle reductions
     const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
@@ -184,18 +205,14 @@ __device__ inline void solve(const Args &a, double *smem)
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
         lin_model(c, st, ut, &L.Ak[9 * t], &L.Bk[6 * t], &L.Ck[3 * t]);
         L.phin[t] = st[2];
-        // J_t = d(s_next, d)/dy : rows 0..2 = [A | 0 | B | 0], row 3 = e_7
-        double *J = &L.Jm[32 * t];
-        for (int i = 0; i < 32; ++i) J[i] = 0;
+        // F = [[A 0 B 0],[0 0 I2 0]]  (5x8), stored transposed and padded: Ft[q][i]
+        double *F = &L.Ft[FT * t];
+        for (int i = 0; i < FT; ++i) F[i] = 0;
         for (int r = 0; r < 3; ++r) {
-            for (int q = 0; q < 3; ++q) J[r * 8 + q] = L.Ak[9 * t + 3 * r + q];
-            for (int q = 0; q < 2; ++q) J[r * 8 + 5 + q] = L.Bk[6 * t + 2 * r + q];
+            for (int q = 0; q < 3; ++q) F[6 * q + r] = L.Ak[9 * t + 3 * r + q];
+            for (int q = 0; q < 2; ++q) F[6 * (5 + q) + r] = L.Bk[6 * t + 2 * r + q];
         }
-        J[3 * 8 + 7] = 1.0;
-        // constant parts of the sweep records
-        double *rv = &L.recV[RV * t];
-        for (int i = 0; i < 6; ++i) rv[9 + i] = L.Bk[6 * t + i];
-        for (int i = 0; i < 9; ++i) rv[i] = L.Ak[9 * t + i];
+        F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
     __syncthreads();
     // ---- rotation-consistency penalty -> scalar quadratic per stage --------------
@@ -233,18 +250,22 @@ __device__ inline void solve(const Args &a, double *smem)
         L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
     }
     __syncthreads();
-    if (tid == 0) {          // roll the state out with the clipped controls
-        for (int t = 0; t < T; ++t) {
-            const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
-            for (int r = 0; r < 3; ++r) {
-                double v = C[r];
-                for (int k = 0; k < 3; ++k) v += A[3 * r + k] * L.s[k * (T + 1) + t];
-                v += B[2 * r] * L.u[t] + B[2 * r + 1] * L.u[T + t];
-                L.s[r * (T + 1) + t + 1] = v;
+    // state rollout with the current controls: wave 0, every lane redundantly, the state chain stays in registers
+    auto rollout = [&]() {
+        if (wave == 0) {
+            double s0 = L.s[0], s1 = L.s[T + 1], s2 = L.s[2 * (T + 1)];
+            for (int t = 0; t < T; ++t) {
+                const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
+                const double u0 = L.u[t], u1 = L.u[T + t];
+                double n0 = C[0] + A[0] * s0 + A[1] * s1 + A[2] * s2 + B[0] * u0 + B[1] * u1;
+                double n1 = C[1] + A[3] * s0 + A[4] * s1 + A[5] * s2 + B[2] * u0 + B[3] * u1;
+                double n2 = C[2] + A[6] * s0 + A[7] * s1 + A[8] * s2 + B[4] * u0 + B[5] * u1;
+                s0 = n0; s1 = n1; s2 = n2;
+                if (lane == 0) { L.s[t + 1] = s0; L.s[(T + 1) + t + 1] = s1; L.s[2 * (T + 1) + t + 1] = s2; }
             }
         }
-    }
-    __syncthreads();
+    };
+    rollout();
     for (int i = tid; i < NC * T; i += NT) {
         int t = i / NC, k = i % NC;
         double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
@@ -257,187 +278,131 @@ __device__ inline void solve(const Args &a, double *smem)
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
-    // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w)   (threads < T, one stage each)
-    auto build_gh = [&]() {
-        if (tid < T) {
-            int t = tid;
-            double x[NC];
+    // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w)   (one stage per thread of `base`..)
+    auto build_gh = [&](int t) {
+        double x[NC];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) { int i = t * NC + k; x[k] = (L.cl[i] * L.rp[i] - L.rc[i]) / L.cw[i]; }
-            double y3, y4, y5, y6, y7; con_T(x, t, y3, y4, y5, y6, y7);
-            const double *g = &L.gst[8 * t]; double *o = &L.gh[8 * t];
-            o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3] + y3; o[4] = g[4] + y4; o[5] = g[5] + y5; o[6] = g[6] + y6; o[7] = g[7] + y7;
+        for (int k = 0; k < NC; ++k) { int i = t * NC + k; x[k] = (L.cl[i] * L.rp[i] - L.rc[i]) / L.cw[i]; }
+        double y3, y4, y5, y6, y7; con_T(x, t, y3, y4, y5, y6, y7);
+        const double *g = &L.gst[8 * t]; double *o = &L.gh[8 * t];
+        o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3] + y3; o[4] = g[4] + y4; o[5] = g[5] + y5; o[6] = g[6] + y6; o[7] = g[7] + y7;
+    };
+    // constants of the backward affine map for the current right-hand side: cb = [g_x - W g_v ; -Minv g_v]
+    auto build_cb = [&]() {
+        for (int i = tid; i < 8 * T; i += NT) {
+            int t = i >> 3, r = i & 7;
+            const double *g = &L.gh[8 * t], *wn = &L.Wn[WN * t];
+            double v;
+            if (r < 5) v = g[r] - (wn[3 * r] * g[5] + wn[3 * r + 1] * g[6] + wn[3 * r + 2] * g[7]);
+            else {
+                int k = r - 5;
+                double n0 = k == 0 ? wn[15] : (k == 1 ? wn[16] : wn[17]);
+                double n1 = k == 0 ? wn[16] : (k == 1 ? wn[18] : wn[19]);
+                double n2 = k == 0 ? wn[17] : (k == 1 ? wn[19] : wn[20]);
+                v = -(n0 * g[5] + n1 * g[6] + n2 * g[7]);
+            }
+            L.Hb[HB * t + 6 * r + 5] = v;
         }
     };
-    // ---- serial sweeps (wave 0; every lane redundantly, all state in registers) -----------------------------
+    // ---- vector sweeps (wave 0, lane-parallel): one affine map per stage -----------------------------------
     typedef double d2 __attribute__((ext_vector_type(2)));
-    struct RecV { d2 v[RV / 2]; };
-    struct RecM { d2 v[RM / 2]; };
-    struct RecG { d2 v[4]; };
-    // The records are wave-uniform; an opaque VGPR offset keeps the fetches as plain vector LDS loads (otherwise
-    // the compiler scalarises every value through v_readlane_b32 with a wait per group).
-    auto opaque = [](int off) { asm volatile("" : "+v"(off)); return off; };
-    auto ldV = [&](int t, RecV &k) {
-        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(L.recV + opaque(RV * t), 16));
-#pragma unroll
-        for (int i = 0; i < RV / 2; ++i) k.v[i] = q[i]; };
-    auto ldM = [&](int t, RecM &k) {
-        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(L.recM + opaque(RM * t), 16));
-#pragma unroll
-        for (int i = 0; i < RM / 2; ++i) k.v[i] = q[i]; };
-    auto ldG = [&](int t, RecG &k) {
-        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(L.gh + opaque(8 * t), 16));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) k.v[i] = q[i]; };
-#define RVAL(k, i) ((k).v[(i) >> 1][(i) & 1])
-    // one backward vector step: p <- ghat_x - W ghat_v ; stores kk = -Minv ghat_v
-    auto bwd_step = [&](int t, const RecV &k, const RecG &gg, double (&p)[5], int lane_) {
-        const double g0 = RVAL(gg, 0), g1 = RVAL(gg, 1), g2 = RVAL(gg, 2), g3 = RVAL(gg, 3), g4 = RVAL(gg, 4), g5 = RVAL(gg, 5), g6 = RVAL(gg, 6), g7 = RVAL(gg, 7);
-        double gv0 = g5 + RVAL(k, 9) * p[0] + RVAL(k, 11) * p[1] + RVAL(k, 13) * p[2] + p[3];
-        double gv1 = g6 + RVAL(k, 10) * p[0] + RVAL(k, 12) * p[1] + RVAL(k, 14) * p[2] + p[4];
-        double gv2 = g7;
-        double gx0 = g0 + RVAL(k, 0) * p[0] + RVAL(k, 3) * p[1] + RVAL(k, 6) * p[2];
-        double gx1 = g1 + RVAL(k, 1) * p[0] + RVAL(k, 4) * p[1] + RVAL(k, 7) * p[2];
-        double gx2 = g2 + RVAL(k, 2) * p[0] + RVAL(k, 5) * p[1] + RVAL(k, 8) * p[2];
-        p[0] = gx0 - (RVAL(k, 15) * gv0 + RVAL(k, 16) * gv1 + RVAL(k, 17) * gv2);
-        p[1] = gx1 - (RVAL(k, 18) * gv0 + RVAL(k, 19) * gv1 + RVAL(k, 20) * gv2);
-        p[2] = gx2 - (RVAL(k, 21) * gv0 + RVAL(k, 22) * gv1 + RVAL(k, 23) * gv2);
-        p[3] = g3 - (RVAL(k, 24) * gv0 + RVAL(k, 25) * gv1 + RVAL(k, 26) * gv2);
-        p[4] = g4 - (RVAL(k, 27) * gv0 + RVAL(k, 28) * gv1 + RVAL(k, 29) * gv2);
-        if (lane_ == 0) {
-            double *o = &L.recV[RV * t + 36];
-            o[0] = -(RVAL(k, 30) * gv0 + RVAL(k, 31) * gv1 + RVAL(k, 32) * gv2);
-            o[1] = -(RVAL(k, 31) * gv0 + RVAL(k, 33) * gv1 + RVAL(k, 34) * gv2);
-            o[2] = -(RVAL(k, 32) * gv0 + RVAL(k, 34) * gv1 + RVAL(k, 35) * gv2);
-        }
+    struct Row { d2 v[3]; };
+#define RW(k, i) ((k).v[(i) >> 1][(i) & 1])
+    auto ldrow = [&](const double *base, Row &k) {
+        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(base, 16));
+        k.v[0] = q[0]; k.v[1] = q[1]; k.v[2] = q[2];
     };
-    auto bwd_all = [&](int lane_) {
-        double p[5] = {0, 0, 0, 0, 0};
-        RecV ka, kb; RecG ga, gb;
-        ldV(T - 1, ka); ldG(T - 1, ga);
+    auto affine = [&](const Row &k, double x) {
+        double e0 = RW(k, 5) + RW(k, 0) * bcast(x, 0), e1 = RW(k, 1) * bcast(x, 1);
+        e0 += RW(k, 2) * bcast(x, 2); e1 += RW(k, 3) * bcast(x, 3); e0 += RW(k, 4) * bcast(x, 4);
+        return e0 + e1;
+    };
+    // backward: [p ; kk] <- Mb [p] + cb   (lanes 0..4 carry p, lanes 5..7 deliver kk)
+    auto bwd_all = [&]() {
+        const int row = lane & 7;
+        double pl = 0;
+        Row ka, kb;
+        ldrow(L.Hb + HB * (T - 1) + 6 * row, ka);
         for (int t = T - 1; t >= 0; t -= 2) {
-            if (t >= 1) { ldV(t - 1, kb); ldG(t - 1, gb); }
-            bwd_step(t, ka, ga, p, lane_);
+            if (t >= 1) ldrow(L.Hb + HB * (t - 1) + 6 * row, kb);
+            pl = affine(ka, pl);
+            if (lane >= 5 && lane < 8) L.kk[4 * t + lane - 5] = pl;
             if (t >= 1) {
-                if (t >= 2) { ldV(t - 2, ka); ldG(t - 2, ga); }
-                bwd_step(t - 1, kb, gb, p, lane_);
+                if (t >= 2) ldrow(L.Hb + HB * (t - 2) + 6 * row, ka);
+                pl = affine(kb, pl);
+                if (lane >= 5 && lane < 8) L.kk[4 * (t - 1) + lane - 5] = pl;
             }
         }
-    };
-    // one forward step: dv = kk - W' dx ; dx+ = F [dx; dv]
-    auto fwd_step = [&](int t, const RecV &k, double (&dx)[5], int lane_) {
-        double v0 = RVAL(k, 36) - (RVAL(k, 15) * dx[0] + RVAL(k, 18) * dx[1] + RVAL(k, 21) * dx[2] + RVAL(k, 24) * dx[3] + RVAL(k, 27) * dx[4]);
-        double v1 = RVAL(k, 37) - (RVAL(k, 16) * dx[0] + RVAL(k, 19) * dx[1] + RVAL(k, 22) * dx[2] + RVAL(k, 25) * dx[3] + RVAL(k, 28) * dx[4]);
-        double v2 = RVAL(k, 38) - (RVAL(k, 17) * dx[0] + RVAL(k, 20) * dx[1] + RVAL(k, 23) * dx[2] + RVAL(k, 26) * dx[3] + RVAL(k, 29) * dx[4]);
-        if (lane_ == 0) {
-            double *y = &L.dy[8 * t];
-            y[0] = dx[0]; y[1] = dx[1]; y[2] = dx[2]; y[3] = dx[3]; y[4] = dx[4]; y[5] = v0; y[6] = v1; y[7] = v2;
+        wsync();
+        // constants of the forward map: cf = [Fv kk ; kk_2]
+        for (int i = lane; i < 6 * T; i += 64) {
+            int t = i / 6, r = i % 6;
+            const double *kq = &L.kk[4 * t], *F = &L.Ft[FT * t];
+            L.Mf[MF * t + 6 * r + 5] = r < 5 ? Fel(F, r, 5) * kq[0] + Fel(F, r, 6) * kq[1] : kq[2];
         }
-        double n0 = RVAL(k, 0) * dx[0] + RVAL(k, 1) * dx[1] + RVAL(k, 2) * dx[2] + RVAL(k, 9) * v0 + RVAL(k, 10) * v1;
-        double n1 = RVAL(k, 3) * dx[0] + RVAL(k, 4) * dx[1] + RVAL(k, 5) * dx[2] + RVAL(k, 11) * v0 + RVAL(k, 12) * v1;
-        double n2 = RVAL(k, 6) * dx[0] + RVAL(k, 7) * dx[1] + RVAL(k, 8) * dx[2] + RVAL(k, 13) * v0 + RVAL(k, 14) * v1;
-        dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = v0; dx[4] = v1;
+        wsync();
     };
-    auto fwd_all = [&](int lane_) {
-        double dx[5] = {0, 0, 0, 0, 0};
-        RecV ka, kb;
-        ldV(0, ka);
+    // forward: [dx+ ; v_2] <- Mf [dx] + cf   (lanes 0..4 carry dx, lanes 3..5 deliver v)
+    auto fwd_all = [&]() {
+        const int row = lane < 6 ? lane : 5;
+        double xl = 0;
+        Row ka, kb;
+        ldrow(L.Mf + 6 * row, ka);
         for (int t = 0; t < T; t += 2) {
-            if (t + 1 < T) ldV(t + 1, kb);
-            fwd_step(t, ka, dx, lane_);
+            if (t + 1 < T) ldrow(L.Mf + MF * (t + 1) + 6 * row, kb);
+            if (lane < 5) L.dy[8 * t + lane] = xl;
+            xl = affine(ka, xl);
+            if (lane >= 3 && lane < 6) L.dy[8 * t + 2 + lane] = xl;
             if (t + 1 < T) {
-                if (t + 2 < T) ldV(t + 2, ka);
-                fwd_step(t + 1, kb, dx, lane_);
+                if (t + 2 < T) ldrow(L.Mf + MF * (t + 2) + 6 * row, ka);
+                if (lane < 5) L.dy[8 * (t + 1) + lane] = xl;
+                xl = affine(kb, xl);
+                if (lane >= 3 && lane < 6) L.dy[8 * (t + 1) + 2 + lane] = xl;
             }
         }
-        if (lane_ == 0) { L.pv[0] = dx[0]; L.pv[1] = dx[1]; L.pv[2] = dx[2]; }
+        if (lane < 3) L.pv[lane] = xl;
     };
-    // one Riccati matrix step fused with the predictor's backward vector step
-    auto mat_step = [&](int t, const RecM &k, const RecG &gg, double (&Pm)[5][5], double (&p)[5], bool &fail_, int lane_) {
-        double M[8][8];
-        {
-            int o = 0;
+    // ---- Riccati matrix recursion (wave 0): lane 8r+q owns entry (r,q) ------------------------------------------
+    struct MatK { double hb; Row fc, fr; };
+    const int mr_ = lane >> 3, mq_ = lane & 7;
+    auto ldmat = [&](int t, MatK &k) {
+        k.hb = L.Hb[HB * t + lane];
+        ldrow(L.Ft + FT * t + 6 * mq_, k.fc);
+        ldrow(L.Ft + FT * t + 6 * mr_, k.fr);
+    };
+    auto mat_step = [&](int t, const MatK &k, double &pv, bool &fail_) {
+        // X = P F : lane (i,q) needs row i of P
+        double x = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+        for (int j = 0; j < 5; ++j) x += __shfl(pv, 8 * mr_ + j, 64) * RW(k.fc, j);
+        // M = Hb + F' X : lane (r,q) needs column q of X
+        double m = k.hb;
 #pragma unroll
-                for (int q = r; q < 8; ++q) { M[r][q] = RVAL(k, o); ++o; }
-        }
-        const double B0 = RVAL(k, 36), B1 = RVAL(k, 37), B2 = RVAL(k, 38), B3 = RVAL(k, 39), B4 = RVAL(k, 40), B5 = RVAL(k, 41);
-        const double a13 = RVAL(k, 42), a23 = RVAL(k, 43);
-        const double Bm[3][2] = { { B0, B1 }, { B2, B3 }, { B4, B5 } };
-        // A = [[1,0,a13],[0,1,a23],[0,0,1]] in all three motion models (rda_solver.py:955,971,987)
-        double T1c[3], T2[3][2], T3[2][2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            T1c[r] = Pm[r][0] * a13 + Pm[r][1] * a23 + Pm[r][2];                 // (Pss A)[:,2]
-#pragma unroll
-            for (int q = 0; q < 2; ++q) T2[r][q] = Pm[r][0] * Bm[0][q] + Pm[r][1] * Bm[1][q] + Pm[r][2] * Bm[2][q] + Pm[r][3 + q];
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) T3[r][q] = Pm[3 + r][0] * Bm[0][q] + Pm[3 + r][1] * Bm[1][q] + Pm[3 + r][2] * Bm[2][q] + Pm[3 + r][3 + q];
-        // M += F' P F (upper triangle)
-        M[0][0] += Pm[0][0]; M[0][1] += Pm[0][1]; M[0][2] += T1c[0];
-        M[1][1] += Pm[1][1]; M[1][2] += T1c[1];
-        M[2][2] += a13 * T1c[0] + a23 * T1c[1] + T1c[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            M[0][5 + q] += T2[0][q]; M[1][5 + q] += T2[1][q];
-            M[2][5 + q] += a13 * T2[0][q] + a23 * T2[1][q] + T2[2][q];
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int q = r; q < 2; ++q) M[5 + r][5 + q] += Bm[0][r] * T2[0][q] + Bm[1][r] * T2[1][q] + Bm[2][r] * T2[2][q] + T3[r][q];
-        // inverse of Mvv (rows/cols 5..7) by the adjugate: one division on the critical path
-        double m00 = M[5][5], m01 = M[5][6], m02 = M[5][7], m11 = M[6][6], m12 = M[6][7], m22 = M[7][7];
+        for (int i = 0; i < 5; ++i) m += RW(k.fr, i) * __shfl(x, 8 * i + mq_, 64);
+        // inverse of the pivot block Mvv (rows/cols 5..7) by the adjugate, on every lane
+        const double m00 = bcast(m, 45), m01 = bcast(m, 46), m02 = bcast(m, 47), m11 = bcast(m, 54), m12 = bcast(m, 55), m22 = bcast(m, 63);
         double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
         double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
         double det = m00 * c00 + m01 * c01 + m02 * c02;
         if (!(m00 > 0) || !(c22 > 0) || !(det > 0)) fail_ = true;
         double id = 1.0 / det;
         double n00 = c00 * id, n01 = c01 * id, n02 = c02 * id, n11 = c11 * id, n12 = c12 * id, n22 = c22 * id;
-        double W[5][3];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            double x0 = M[r][5], x1 = M[r][6], x2 = M[r][7];
-            W[r][0] = x0 * n00 + x1 * n01 + x2 * n02;
-            W[r][1] = x0 * n01 + x1 * n11 + x2 * n12;
-            W[r][2] = x0 * n02 + x1 * n12 + x2 * n22;
-        }
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-            for (int q = r; q < 5; ++q) {
-                double v = M[r][q] - (W[r][0] * M[q][5] + W[r][1] * M[q][6] + W[r][2] * M[q][7]);
-                Pm[r][q] = v; Pm[q][r] = v;
-            }
-        const double g0 = RVAL(gg, 0), g1 = RVAL(gg, 1), g2 = RVAL(gg, 2), g3 = RVAL(gg, 3), g4 = RVAL(gg, 4), g5 = RVAL(gg, 5), g6 = RVAL(gg, 6), g7 = RVAL(gg, 7);
-        double gv0 = g5 + B0 * p[0] + B2 * p[1] + B4 * p[2] + p[3];
-        double gv1 = g6 + B1 * p[0] + B3 * p[1] + B5 * p[2] + p[4];
-        double gv2 = g7;
-        double gx0 = g0 + p[0], gx1 = g1 + p[1], gx2 = g2 + a13 * p[0] + a23 * p[1] + p[2];
-        p[0] = gx0 - (W[0][0] * gv0 + W[0][1] * gv1 + W[0][2] * gv2);
-        p[1] = gx1 - (W[1][0] * gv0 + W[1][1] * gv1 + W[1][2] * gv2);
-        p[2] = gx2 - (W[2][0] * gv0 + W[2][1] * gv1 + W[2][2] * gv2);
-        p[3] = g3 - (W[3][0] * gv0 + W[3][1] * gv1 + W[3][2] * gv2);
-        p[4] = g4 - (W[4][0] * gv0 + W[4][1] * gv1 + W[4][2] * gv2);
-        if (lane_ == 0) {
-            double *o = &L.recV[RV * t + 15];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) { o[3 * r] = W[r][0]; o[3 * r + 1] = W[r][1]; o[3 * r + 2] = W[r][2]; }
-            o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22;
-            o[21] = -(n00 * gv0 + n01 * gv1 + n02 * gv2);
-            o[22] = -(n01 * gv0 + n11 * gv1 + n12 * gv2);
-            o[23] = -(n02 * gv0 + n12 * gv1 + n22 * gv2);
-        }
+        // W row r = M[r][5..7] Minv ;  P = Mxx - W Mvx
+        const double a0 = __shfl(m, 8 * mr_ + 5, 64), a1 = __shfl(m, 8 * mr_ + 6, 64), a2 = __shfl(m, 8 * mr_ + 7, 64);
+        const double b0 = __shfl(m, 40 + mq_, 64), b1 = __shfl(m, 48 + mq_, 64), b2 = __shfl(m, 56 + mq_, 64);
+        double w0 = a0 * n00 + a1 * n01 + a2 * n02;
+        double w1 = a0 * n01 + a1 * n11 + a2 * n12;
+        double w2 = a0 * n02 + a1 * n12 + a2 * n22;
+        double pn = m - (w0 * b0 + w1 * b1 + w2 * b2);
+        pv = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
+        double *o = &L.Wn[WN * t];
+        if (mr_ < 5 && mq_ < 3) o[3 * mr_ + mq_] = mq_ == 0 ? w0 : (mq_ == 1 ? w1 : w2);
+        if (lane == 63) { o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22; }
     };
 
     int status = 1, it;
-    long long tprev = clock64();
     auto mark = [&](int k) { if (a.prof && tid == 0) { long long now = clock64(); a.prof[k] += now - tprev; tprev = now; } };
-    mark(0);
+    mark(9);
     for (it = 0; it < 100; ++it) {
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
         {
@@ -511,70 +476,56 @@ __device__ inline void solve(const Args &a, double *smem)
             double *bw = &L.bw[5 * t];
             bw[0] = dg[0] + dg[1]; bw[1] = dg[2] + dg[3]; bw[2] = dg[4] + dg[5]; bw[3] = dg[6] + dg[7]; bw[4] = dg[8] + dg[9];
             double y3, y4, y5, y6, y7; con_T(lam, t, y3, y4, y5, y6, y7);
-            double *rm = &L.recM[RM * t];
-            for (int i = 0; i < 6; ++i) rm[36 + i] = L.Bk[6 * t + i];
-            rm[42] = L.Ak[9 * t + 2]; rm[43] = L.Ak[9 * t + 5];
             double *cy = &L.cy[5 * t];
             cy[0] = y3; cy[1] = y4; cy[2] = y5 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t]; cy[3] = y6 + c.eps_u * L.u[T + t]; cy[4] = y7;
         }
         __syncthreads();
-        // ---- (3) stage Hessian bases  J' Hw J + direct + barrier  (all threads), predictor rhs ----------
-        // stage gradient gst = J' gw + direct terms + C' lam   (one thread per entry)
+        // ---- (3) stage gradients and stage Hessian bases  J' Hw J + direct + barrier  (all threads) -------
+        // J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
         for (int i = tid; i < 8 * T; i += NT) {
             int t = i >> 3, j = i & 7;
-            const double *J = &L.Jm[32 * t], *gw = &L.gw[4 * t];
-            double v = J[j] * gw[0] + J[8 + j] * gw[1] + J[16 + j] * gw[2] + J[24 + j] * gw[3];
+            const double *F = &L.Ft[FT * t], *gw = &L.gw[4 * t];
+            double v = Fel(F, 0, j) * gw[0] + Fel(F, 1, j) * gw[1] + Fel(F, 2, j) * gw[2] + (j == 7 ? gw[3] : 0.0);
             if (j >= 3) v += L.cy[5 * t + j - 3];
             L.gst[i] = v;
         }
-        // upper triangle of the stage Hessian base, written straight into the matrix-sweep records
-        for (int i = tid; i < 36 * T; i += NT) {
-            int t = i / 36, o = i % 36;
-            int r = 0, rem = o;
-            while (rem >= 8 - r) { rem -= 8 - r; ++r; }
-            int q = r + rem;
-            const double *J = &L.Jm[32 * t], *Hw = &L.Hw[16 * t], *bw = &L.bw[5 * t];
+        double gn = 0;
+        for (int i = tid; i < 4 * T; i += NT) { double v = fabs(L.gw[i]); if (v > gn) gn = v; }
+        for (int i = tid; i < HB * T; i += NT) {
+            int t = i >> 6, r = (i >> 3) & 7, q = i & 7;
+            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *bw = &L.bw[5 * t];
+            const double jq[4] = { Fel(F, 0, q), Fel(F, 1, q), Fel(F, 2, q), q == 7 ? 1.0 : 0.0 };
+            const double jr[4] = { Fel(F, 0, r), Fel(F, 1, r), Fel(F, 2, r), r == 7 ? 1.0 : 0.0 };
             double m = 0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                double acc = Hw[4 * x] * J[q] + Hw[4 * x + 1] * J[8 + q] + Hw[4 * x + 2] * J[16 + q] + Hw[4 * x + 3] * J[24 + q];
-                m += J[8 * x + r] * acc;
-            }
+            for (int x = 0; x < 4; ++x) m += jr[x] * (Hw[4 * x] * jq[0] + Hw[4 * x + 1] * jq[1] + Hw[4 * x + 2] * jq[2] + Hw[4 * x + 3] * jq[3]);
             if (r == q) {
                 if (r == 5) m += 2 * c.wu + c.eps_u + bw[0] + bw[3];
                 else if (r == 6) m += c.eps_u + bw[1] + bw[4];
                 else if (r == 7) m += bw[2];
                 else if (r == 3) m += bw[3];
                 else if (r == 4) m += bw[4];
-            } else if (r == 3 && q == 5) m -= bw[3];
-            else if (r == 4 && q == 6) m -= bw[4];
-            L.recM[RM * t + o] = m;
+            } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= bw[3];
+            else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= bw[4];
+            L.Hb[i] = m;
         }
         __syncthreads();
-        build_gh();
-        __syncthreads();
         mark(2);
-        // ---- (4) wave 0: Riccati matrix recursion fused with the predictor's backward vector sweep;
-        //          wave 1: adjoint sweep for the reduced gradient -----------------------------------
+        // ---- (4) wave 0: Riccati matrix recursion; wave 1: adjoint sweep for the reduced gradient;
+        //          wave 2: Newton right-hand side of the predictor --------------------------------------------
         bool fail = false;
         if (wave == 0) {
-            double p[5] = {0, 0, 0, 0, 0};
-            double Pm[5][5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r)
-#pragma unroll
-                for (int q = 0; q < 5; ++q) Pm[r][q] = 0;
-            RecM ka, kb; RecG ga, gb;
-            ldM(T - 1, ka); ldG(T - 1, ga);
+            double pv = 0;
+            MatK ka, kb;
+            ldmat(T - 1, ka);
             for (int t = T - 1; t >= 0; t -= 2) {
-                if (t >= 1) { ldM(t - 1, kb); ldG(t - 1, gb); }
-                mat_step(t, ka, ga, Pm, p, fail, lane);
+                if (t >= 1) ldmat(t - 1, kb);
+                mat_step(t, ka, pv, fail);
                 if (t >= 1) {
-                    if (t >= 2) { ldM(t - 2, ka); ldG(t - 2, ga); }
-                    mat_step(t - 1, kb, gb, Pm, p, fail, lane);
+                    if (t >= 2) ldmat(t - 2, ka);
+                    mat_step(t - 1, kb, pv, fail);
                 }
             }
-            wsync();
         } else if (wave == 1) {
             double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
             for (int t = T - 1; t >= 0; --t) {
@@ -587,12 +538,40 @@ __device__ inline void solve(const Args &a, double *smem)
                 if (lane == 0) { L.gad[3 * t] = v0; L.gad[3 * t + 1] = v1; L.gad[3 * t + 2] = g[7]; }
                 p0 = g0; p1 = g1; p2 = g2; p3 = g[3]; p4 = g[4];
             }
+        } else if (wave == 2) {
+            for (int t = lane; t < T; t += 64) build_gh(t);
         }
         __syncthreads();
         mark(4);
-        double rdn = 0, gn = 0, rpn = 0, mu = 0;
+        // ---- (4b) closed-loop sweep matrices from W, Minv (all threads; Mb overwrites the consumed Hb,
+        //           Mf overwrites the consumed hs..cy) --------------------------------------------------------------
+        for (int i = tid; i < 8 * T; i += NT) {
+            int t = i >> 3, r = i & 7;
+            const double *F = &L.Ft[FT * t], *wn = &L.Wn[WN * t];
+            double *mb = &L.Hb[HB * t + 6 * r];
+            if (r < 5) {
+                double *mf = &L.Mf[MF * t + 6 * r];
+                const double w0 = wn[3 * r], w1 = wn[3 * r + 1], fr5 = Fel(F, r, 5), fr6 = Fel(F, r, 6);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    mb[j] = Fel(F, j, r) - (Fel(F, j, 5) * w0 + Fel(F, j, 6) * w1);            // Acl[j][r]
+                    mf[j] = Fel(F, r, j) - (fr5 * wn[3 * j] + fr6 * wn[3 * j + 1]);              // Acl[r][j]
+                }
+            } else {
+                int k = r - 5;
+                double n0 = k == 0 ? wn[15] : (k == 1 ? wn[16] : wn[17]);
+                double n1 = k == 0 ? wn[16] : (k == 1 ? wn[18] : wn[19]);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) mb[j] = -(n0 * Fel(F, j, 5) + n1 * Fel(F, j, 6));
+                if (k == 2) {
+                    double *mf = &L.Mf[MF * t + 6 * 5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) mf[j] = -wn[3 * j + 2];
+                }
+            }
+        }
+        double rdn = 0, rpn = 0, mu = 0;
         for (int i = tid; i < 3 * T; i += NT) { double v = fabs(L.gad[i]); if (v > rdn) rdn = v; }
-        for (int i = tid; i < 4 * T; i += NT) { double v = fabs(L.gw[i]); if (v > gn) gn = v; }
         for (int i = tid; i < NC * T; i += NT) { double v = fabs(L.rp[i]); if (v > rpn) rpn = v; mu += L.cl[i] * L.cw[i]; }
         rdn = block_reduce(rdn, L.red, tid, true);
         gn = block_reduce(gn, L.red, tid, true);
@@ -606,15 +585,16 @@ __device__ inline void solve(const Args &a, double *smem)
         double sigma = 0;
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {
-                // corrector right-hand side, vector-only backward sweep with the stored factors
+                // corrector right-hand side
                 for (int i = tid; i < NC * T; i += NT) L.rc[i] = L.cl[i] * L.cw[i] + L.dl[i] * L.dw[i] - sigma * mu;
                 __syncthreads();
-                build_gh();
+                if (tid < T) build_gh(tid);
                 __syncthreads();
-                if (wave == 0) { bwd_all(lane); wsync(); }
             }
+            build_cb();
+            __syncthreads();
             mark(6);
-            if (wave == 0) fwd_all(lane);
+            if (wave == 0) { bwd_all(); fwd_all(); }
             __syncthreads();
             mark(7);
             // ---- slack / multiplier steps, step length ------------------------------------------------
@@ -649,17 +629,7 @@ __device__ inline void solve(const Args &a, double *smem)
     }
     __syncthreads();
     // consistent final rollout (removes accumulated rounding in s)
-    if (tid == 0) {
-        for (int t = 0; t < T; ++t) {
-            const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
-            for (int r = 0; r < 3; ++r) {
-                double v = C[r];
-                for (int k = 0; k < 3; ++k) v += A[3 * r + k] * L.s[k * (T + 1) + t];
-                v += B[2 * r] * L.u[t] + B[2 * r + 1] * L.u[T + t];
-                L.s[r * (T + 1) + t + 1] = v;
-            }
-        }
-    }
+    rollout();
     __syncthreads();
     if (status == 0) {       // otherwise keep the nominal (reference :696-700)
         for (int i = tid; i < 3 * (T + 1); i += NT) a.out_s[i] = L.s[i];
@@ -671,6 +641,8 @@ __device__ inline void solve(const Args &a, double *smem)
         if (a.d_in) for (int i = tid; i < T; i += NT) a.out_d[i] = a.d_in[i];
     }
     if (tid == 0) { *a.status = status; *a.ipm_iters = it; }
+    mark(10);
 }
+#undef RW
 
 }  // namespace su
