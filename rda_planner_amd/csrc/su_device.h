@@ -106,7 +106,8 @@ struct Lds {
     double *Hb;        // [T][HB]  stage Hessian base -> (after the matrix sweep) backward rows Mb [8][6]
     double *Wn;        // [T][WN]
     double *Mf;        // [T][MF]  (overlays hs..cy, which are dead once the stage Hessians are assembled)
-    double *kk;        // [T][4]   feed-forward of the current right-hand side
+    double *kk;        // [T][8]   backward sweep outputs per stage: p (5) | feed-forward kk (3)
+    double *vv;        // [T][8]   forward sweep outputs per stage: dx+ (5) | v_2 ; v = entries 3..5
     double *cw, *cl, *rp, *rc, *dw, *dl;   // [T][NC]
     double *dy;                            // [T][8]
     double *pv, *red;                      // 8, NT
@@ -118,7 +119,7 @@ struct Lds {
         Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += ev(5 * T); cy = p; p += ev(5 * T);
         gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += ev(3 * T);
         Hb = p; part = p; p += (HB * T > 9 * NT ? HB * T : 9 * NT);    // part (phase 1) is dead before Hb is written (phase 3)
-        Wn = p; p += WN * T; kk = p; p += 4 * T;
+        Wn = p; p += WN * T; kk = p; p += 8 * T; vv = p; p += 8 * T;
         cw = p; p += NC * T; cl = p; p += NC * T; rp = p; p += NC * T; rc = p; p += NC * T; dw = p; p += NC * T; dl = p; p += NC * T;
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT;
     }
@@ -127,7 +128,7 @@ inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 3 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
-             + WN * T + 4 * T + 6 * NC * T + 8 * T + 8 + NT;
+             + WN * T + 16 * T + 6 * NC * T + 8 * T + 8 + NT;
     return n * sizeof(double);
 }
 
@@ -150,13 +151,33 @@ __device__ __forceinline__ double con_rhs(const Cfg &c, int k)
 }
 __device__ __forceinline__ bool con_on(int t, int k) { return k < 6 || t >= 1; }
 
+// wave-uniform broadcast of lane `src`'s value (src is a compile-time constant after unrolling): two v_readlane_b32,
+// the result lives in an SGPR pair and feeds the FMAs as a scalar operand
+__device__ __forceinline__ double bcast(double v, int src)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 64 lanes: DPP inside the 16-lane rows (xor 1, xor 2, half mirror, mirror), v_readlane across rows
+__device__ __forceinline__ double wave_allreduce(double v, bool is_max)
+{
+    auto op = [&](double x, double y) { return is_max ? (y > x ? y : x) : x + y; };
+    v = op(v, dpp_f64<0xB1>(v));
+    v = op(v, dpp_f64<0x4E>(v));
+    v = op(v, dpp_f64<0x141>(v));
+    v = op(v, dpp_f64<0x140>(v));
+    return op(op(bcast(v, 0), bcast(v, 16)), op(bcast(v, 32), bcast(v, 48)));
+}
 __device__ __forceinline__ double block_reduce(double v, double *red, int tid, bool is_max)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = is_max ? (o > v ? o : v) : v + o;
-    }
+    v = wave_allreduce(v, is_max);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -172,14 +193,6 @@ __device__ __forceinline__ void con_T(const double *x, int t, double &y3, double
     y5 = x[0] - x[1] + r0; y6 = x[2] - x[3] + r1; y7 = x[4] - x[5]; y3 = -r0; y4 = -r1;
 }
 
-// wave-uniform broadcast of lane `src`'s value (src is a compile-time constant after unrolling): two v_readlane_b32,
-// the result lives in an SGPR pair and feeds the FMAs as a scalar operand
-__device__ __forceinline__ double bcast(double v, int src)
-{
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 // entry F[i][q] of the stage transition x+ = F y from the packed transpose
 __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return Ft_t[6 * q + i]; }
 
@@ -317,50 +330,54 @@ __device__ inline void solve(const Args &a, double *smem)
         e0 += RW(k, 2) * bcast(x, 2); e1 += RW(k, 3) * bcast(x, 3); e0 += RW(k, 4) * bcast(x, 4);
         return e0 + e1;
     };
-    // backward: [p ; kk] <- Mb [p] + cb   (lanes 0..4 carry p, lanes 5..7 deliver kk)
+    // backward: [p ; kk] <- Mb [p] + cb   (lanes 0..4 carry p, lanes 5..7 deliver kk).  Only lanes 0..7 are active
+    // (v_readlane ignores EXEC), so the per-stage stores need no predicate.
     auto bwd_all = [&]() {
-        const int row = lane & 7;
-        double pl = 0;
-        Row ka, kb;
-        ldrow(L.Hb + HB * (T - 1) + 6 * row, ka);
-        for (int t = T - 1; t >= 0; t -= 2) {
-            if (t >= 1) ldrow(L.Hb + HB * (t - 1) + 6 * row, kb);
-            pl = affine(ka, pl);
-            if (lane >= 5 && lane < 8) L.kk[4 * t + lane - 5] = pl;
-            if (t >= 1) {
-                if (t >= 2) ldrow(L.Hb + HB * (t - 2) + 6 * row, ka);
-                pl = affine(kb, pl);
-                if (lane >= 5 && lane < 8) L.kk[4 * (t - 1) + lane - 5] = pl;
+        if (lane < 8) {
+            double pl = 0;
+            Row ka, kb;
+            ldrow(L.Hb + HB * (T - 1) + 6 * lane, ka);
+            for (int t = T - 1; t >= 0; t -= 2) {
+                if (t >= 1) ldrow(L.Hb + HB * (t - 1) + 6 * lane, kb);
+                pl = affine(ka, pl);
+                L.kk[8 * t + lane] = pl;
+                if (t >= 1) {
+                    if (t >= 2) ldrow(L.Hb + HB * (t - 2) + 6 * lane, ka);
+                    pl = affine(kb, pl);
+                    L.kk[8 * (t - 1) + lane] = pl;
+                }
             }
         }
         wsync();
         // constants of the forward map: cf = [Fv kk ; kk_2]
         for (int i = lane; i < 6 * T; i += 64) {
             int t = i / 6, r = i % 6;
-            const double *kq = &L.kk[4 * t], *F = &L.Ft[FT * t];
+            const double *kq = &L.kk[8 * t + 5], *F = &L.Ft[FT * t];
             L.Mf[MF * t + 6 * r + 5] = r < 5 ? Fel(F, r, 5) * kq[0] + Fel(F, r, 6) * kq[1] : kq[2];
         }
         wsync();
     };
-    // forward: [dx+ ; v_2] <- Mf [dx] + cf   (lanes 0..4 carry dx, lanes 3..5 deliver v)
+    // forward: [dx+ ; v_2] <- Mf [dx] + cf   (lanes 0..4 carry dx; v = outputs 3..5)
     auto fwd_all = [&]() {
-        const int row = lane < 6 ? lane : 5;
-        double xl = 0;
-        Row ka, kb;
-        ldrow(L.Mf + 6 * row, ka);
-        for (int t = 0; t < T; t += 2) {
-            if (t + 1 < T) ldrow(L.Mf + MF * (t + 1) + 6 * row, kb);
-            if (lane < 5) L.dy[8 * t + lane] = xl;
-            xl = affine(ka, xl);
-            if (lane >= 3 && lane < 6) L.dy[8 * t + 2 + lane] = xl;
-            if (t + 1 < T) {
-                if (t + 2 < T) ldrow(L.Mf + MF * (t + 2) + 6 * row, ka);
-                if (lane < 5) L.dy[8 * (t + 1) + lane] = xl;
-                xl = affine(kb, xl);
-                if (lane >= 3 && lane < 6) L.dy[8 * (t + 1) + 2 + lane] = xl;
+        if (lane < 8) {
+            const int row = lane < 6 ? lane : 5;
+            double xl = 0;
+            Row ka, kb;
+            ldrow(L.Mf + 6 * row, ka);
+            for (int t = 0; t < T; t += 2) {
+                if (t + 1 < T) ldrow(L.Mf + MF * (t + 1) + 6 * row, kb);
+                L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
+                xl = affine(ka, xl);
+                L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
+                if (t + 1 < T) {
+                    if (t + 2 < T) ldrow(L.Mf + MF * (t + 2) + 6 * row, ka);
+                    L.dy[8 * (t + 1) + lane] = xl;
+                    xl = affine(kb, xl);
+                    L.vv[8 * (t + 1) + lane] = xl;
+                }
             }
+            if (lane < 3) L.pv[lane] = xl;
         }
-        if (lane < 3) L.pv[lane] = xl;
     };
     // ---- Riccati matrix recursion (wave 0): lane 8r+q owns entry (r,q) ------------------------------------------
     struct MatK { double hb; Row fc, fr; };
@@ -442,7 +459,8 @@ __device__ inline void solve(const Args &a, double *smem)
         }
         __syncthreads();
         mark(1);
-        // ---- (2) per-stage derivatives wrt w = (s_next, d); barrier weights; C'lam; residuals --------
+        // ---- (2) per-stage derivatives wrt w = (s_next, d)  (threads < T)  ||  inequality rows: barrier weight
+        //          lam/w (kept in dw, which is dead here), primal residual, predictor target  (all threads) ------
         if (tid < T) {
             int t = tid;
             const double *h = &L.hs[9 * t];
@@ -462,51 +480,49 @@ __device__ inline void solve(const Args &a, double *smem)
             Hw[8] = 0; Hw[9] = 0; Hw[10] = Hs22; Hw[11] = 0;
             Hw[12] = hsd0; Hw[13] = hsd1; Hw[14] = 0; Hw[15] = c.ro1 * h[5];
             gw[0] = gs[0]; gw[1] = gs[1]; gw[2] = gs[2]; gw[3] = -c.ro1 * h[8] - c.slack_gain;
-            // inequality rows of this stage
+        }
+        for (int i = tid; i < NC * T; i += NT) {
+            int t = i / NC, k = i % NC;
+            bool on = con_on(t, k);
             double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-            double lam[NC], dg[NC];
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                int i = t * NC + k;
-                bool on = con_on(t, k);
-                lam[k] = L.cl[i]; dg[k] = on ? L.cl[i] / L.cw[i] : 0.0;
-                L.rp[i] = on ? con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]) + L.cw[i] - con_rhs(c, k) : 0.0;
-                L.rc[i] = L.cl[i] * L.cw[i];                              // affine (predictor) target
-            }
-            double *bw = &L.bw[5 * t];
-            bw[0] = dg[0] + dg[1]; bw[1] = dg[2] + dg[3]; bw[2] = dg[4] + dg[5]; bw[3] = dg[6] + dg[7]; bw[4] = dg[8] + dg[9];
-            double y3, y4, y5, y6, y7; con_T(lam, t, y3, y4, y5, y6, y7);
-            double *cy = &L.cy[5 * t];
-            cy[0] = y3; cy[1] = y4; cy[2] = y5 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t]; cy[3] = y6 + c.eps_u * L.u[T + t]; cy[4] = y7;
+            double w = L.cw[i], l = L.cl[i];
+            L.dw[i] = on ? l / w : 0.0;
+            L.rp[i] = on ? con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]) + w - con_rhs(c, k) : 0.0;
+            L.rc[i] = l * w;                                          // affine (predictor) target
         }
         __syncthreads();
         // ---- (3) stage gradients and stage Hessian bases  J' Hw J + direct + barrier  (all threads) -------
         // J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
         for (int i = tid; i < 8 * T; i += NT) {
             int t = i >> 3, j = i & 7;
-            const double *F = &L.Ft[FT * t], *gw = &L.gw[4 * t];
+            const double *F = &L.Ft[FT * t], *gw = &L.gw[4 * t], *lam = &L.cl[NC * t];
             double v = Fel(F, 0, j) * gw[0] + Fel(F, 1, j) * gw[1] + Fel(F, 2, j) * gw[2] + (j == 7 ? gw[3] : 0.0);
-            if (j >= 3) v += L.cy[5 * t + j - 3];
+            // + direct control cost + C' lam   (rate rows 6..9 exist for t >= 1; their multipliers are 0 at t = 0)
+            const double r0 = lam[6] - lam[7], r1 = lam[8] - lam[9];
+            if (j == 3) v -= r0;
+            else if (j == 4) v -= r1;
+            else if (j == 5) v += lam[0] - lam[1] + r0 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t];
+            else if (j == 6) v += lam[2] - lam[3] + r1 + c.eps_u * L.u[T + t];
+            else if (j == 7) v += lam[4] - lam[5];
             L.gst[i] = v;
         }
-        double gn = 0;
-        for (int i = tid; i < 4 * T; i += NT) { double v = fabs(L.gw[i]); if (v > gn) gn = v; }
         for (int i = tid; i < HB * T; i += NT) {
             int t = i >> 6, r = (i >> 3) & 7, q = i & 7;
-            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *bw = &L.bw[5 * t];
+            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *dg = &L.dw[NC * t];
             const double jq[4] = { Fel(F, 0, q), Fel(F, 1, q), Fel(F, 2, q), q == 7 ? 1.0 : 0.0 };
             const double jr[4] = { Fel(F, 0, r), Fel(F, 1, r), Fel(F, 2, r), r == 7 ? 1.0 : 0.0 };
             double m = 0;
 #pragma unroll
             for (int x = 0; x < 4; ++x) m += jr[x] * (Hw[4 * x] * jq[0] + Hw[4 * x + 1] * jq[1] + Hw[4 * x + 2] * jq[2] + Hw[4 * x + 3] * jq[3]);
+            // barrier weights: u0 box (rows 0,1), u1 box (2,3), d box (4,5), rate u0 (6,7), rate u1 (8,9)
             if (r == q) {
-                if (r == 5) m += 2 * c.wu + c.eps_u + bw[0] + bw[3];
-                else if (r == 6) m += c.eps_u + bw[1] + bw[4];
-                else if (r == 7) m += bw[2];
-                else if (r == 3) m += bw[3];
-                else if (r == 4) m += bw[4];
-            } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= bw[3];
-            else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= bw[4];
+                if (r == 5) m += 2 * c.wu + c.eps_u + dg[0] + dg[1] + dg[6] + dg[7];
+                else if (r == 6) m += c.eps_u + dg[2] + dg[3] + dg[8] + dg[9];
+                else if (r == 7) m += dg[4] + dg[5];
+                else if (r == 3) m += dg[6] + dg[7];
+                else if (r == 4) m += dg[8] + dg[9];
+            } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= dg[6] + dg[7];
+            else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= dg[8] + dg[9];
             L.Hb[i] = m;
         }
         __syncthreads();
@@ -538,8 +554,20 @@ __device__ inline void solve(const Args &a, double *smem)
                 if (lane == 0) { L.gad[3 * t] = v0; L.gad[3 * t + 1] = v1; L.gad[3 * t + 2] = g[7]; }
                 p0 = g0; p1 = g1; p2 = g2; p3 = g[3]; p4 = g[4];
             }
+            wsync();
+            double rd = 0;
+            for (int i = lane; i < 3 * T; i += 64) { double v = fabs(L.gad[i]); if (v > rd) rd = v; }
+            rd = wave_allreduce(rd, true);
+            if (lane == 0) L.red[8] = rd;
         } else if (wave == 2) {
             for (int t = lane; t < T; t += 64) build_gh(t);
+        } else {
+            // termination measures that do not depend on the sweeps
+            double g = 0, rp_ = 0, m_ = 0;
+            for (int i = lane; i < 4 * T; i += 64) { double v = fabs(L.gw[i]); if (v > g) g = v; }
+            for (int i = lane; i < NC * T; i += 64) { double v = fabs(L.rp[i]); if (v > rp_) rp_ = v; m_ += L.cl[i] * L.cw[i]; }
+            g = wave_allreduce(g, true); rp_ = wave_allreduce(rp_, true); m_ = wave_allreduce(m_, false);
+            if (lane == 0) { L.red[9] = g; L.red[10] = rp_; L.red[11] = m_; }
         }
         __syncthreads();
         mark(4);
@@ -570,13 +598,7 @@ __device__ inline void solve(const Args &a, double *smem)
                 }
             }
         }
-        double rdn = 0, rpn = 0, mu = 0;
-        for (int i = tid; i < 3 * T; i += NT) { double v = fabs(L.gad[i]); if (v > rdn) rdn = v; }
-        for (int i = tid; i < NC * T; i += NT) { double v = fabs(L.rp[i]); if (v > rpn) rpn = v; mu += L.cl[i] * L.cw[i]; }
-        rdn = block_reduce(rdn, L.red, tid, true);
-        gn = block_reduce(gn, L.red, tid, true);
-        rpn = block_reduce(rpn, L.red, tid, true);
-        mu = block_reduce(mu, L.red, tid, false) / mcnt;
+        const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
         if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
         if (__syncthreads_or(fail ? 1 : 0)) { status = 2; break; }
@@ -602,8 +624,8 @@ __device__ inline void solve(const Args &a, double *smem)
             for (int i = tid; i < NC * T; i += NT) {
                 int t = i / NC, k = i % NC;
                 if (!con_on(t, k)) { L.dw[i] = 0; L.dl[i] = 0; continue; }
-                const double *y = &L.dy[8 * t];
-                double cdx = con_val(k, y[5], y[6], y[3], y[4], y[7]);
+                const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
+                double cdx = con_val(k, v[0], v[1], y[3], y[4], v[2]);
                 double dwv = -L.rp[i] - cdx, dlv = -(L.rc[i] + L.cl[i] * dwv) / L.cw[i];
                 L.dw[i] = dwv; L.dl[i] = dlv;
                 double fr = pass ? 0.995 : 1.0;
@@ -617,8 +639,8 @@ __device__ inline void solve(const Args &a, double *smem)
             } else {
                 for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += al * L.dl[i]; }
                 if (tid < T) {
-                    int t = tid; const double *y = &L.dy[8 * t];
-                    L.u[t] += al * y[5]; L.u[T + t] += al * y[6]; L.d[t] += al * y[7];
+                    int t = tid; const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
+                    L.u[t] += al * v[0]; L.u[T + t] += al * v[1]; L.d[t] += al * v[2];
                     if (t >= 1) for (int r = 0; r < 3; ++r) L.s[r * (T + 1) + t] += al * y[r];
                 }
                 if (tid < 3) L.s[tid * (T + 1) + T] += al * L.pv[tid];
