@@ -321,6 +321,9 @@ __device__ inline void solve(const Args &a, double *smem)
     typedef double d2 __attribute__((ext_vector_type(2)));
     struct Row { d2 v[3]; };
 #define RW(k, i) ((k).v[(i) >> 1][(i) & 1])
+// s_waitcnt lgkmcnt(0) at the END of a sweep stage: the next stage's rows (issued one stage ahead) have landed, so the
+// compiler does not have to drain the freshly issued prefetch before the first use at the top of the next stage
+#define LDS_DRAIN() __builtin_amdgcn_s_waitcnt(0xc07f)
     auto ldrow = [&](const double *base, Row &k) {
         const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(base, 16));
         k.v[0] = q[0]; k.v[1] = q[1]; k.v[2] = q[2];
@@ -337,14 +340,17 @@ __device__ inline void solve(const Args &a, double *smem)
             double pl = 0;
             Row ka, kb;
             ldrow(L.Hb + HB * (T - 1) + 6 * lane, ka);
+            LDS_DRAIN();
             for (int t = T - 1; t >= 0; t -= 2) {
                 if (t >= 1) ldrow(L.Hb + HB * (t - 1) + 6 * lane, kb);
                 pl = affine(ka, pl);
                 L.kk[8 * t + lane] = pl;
+                LDS_DRAIN();
                 if (t >= 1) {
                     if (t >= 2) ldrow(L.Hb + HB * (t - 2) + 6 * lane, ka);
                     pl = affine(kb, pl);
                     L.kk[8 * (t - 1) + lane] = pl;
+                    LDS_DRAIN();
                 }
             }
         }
@@ -364,16 +370,19 @@ __device__ inline void solve(const Args &a, double *smem)
             double xl = 0;
             Row ka, kb;
             ldrow(L.Mf + 6 * row, ka);
+            LDS_DRAIN();
             for (int t = 0; t < T; t += 2) {
                 if (t + 1 < T) ldrow(L.Mf + MF * (t + 1) + 6 * row, kb);
                 L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
                 xl = affine(ka, xl);
                 L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
+                LDS_DRAIN();
                 if (t + 1 < T) {
                     if (t + 2 < T) ldrow(L.Mf + MF * (t + 2) + 6 * row, ka);
                     L.dy[8 * (t + 1) + lane] = xl;
                     xl = affine(kb, xl);
                     L.vv[8 * (t + 1) + lane] = xl;
+                    LDS_DRAIN();
                 }
             }
             if (lane < 3) L.pv[lane] = xl;
@@ -534,12 +543,15 @@ __device__ inline void solve(const Args &a, double *smem)
             double pv = 0;
             MatK ka, kb;
             ldmat(T - 1, ka);
+            LDS_DRAIN();
             for (int t = T - 1; t >= 0; t -= 2) {
                 if (t >= 1) ldmat(t - 1, kb);
                 mat_step(t, ka, pv, fail);
+                LDS_DRAIN();
                 if (t >= 1) {
                     if (t >= 2) ldmat(t - 2, ka);
                     mat_step(t - 1, kb, pv, fail);
+                    LDS_DRAIN();
                 }
             }
         } else if (wave == 1) {
@@ -666,5 +678,6 @@ __device__ inline void solve(const Args &a, double *smem)
     mark(10);
 }
 #undef RW
+#undef LDS_DRAIN
 
 }  // namespace su
