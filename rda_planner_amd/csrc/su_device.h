@@ -340,17 +340,14 @@ __device__ inline void solve(const Args &a, double *smem)
             double pl = 0;
             Row ka, kb;
             ldrow(L.Hb + HB * (T - 1) + 6 * lane, ka);
-            LDS_DRAIN();
             for (int t = T - 1; t >= 0; t -= 2) {
                 if (t >= 1) ldrow(L.Hb + HB * (t - 1) + 6 * lane, kb);
                 pl = affine(ka, pl);
                 L.kk[8 * t + lane] = pl;
-                LDS_DRAIN();
                 if (t >= 1) {
                     if (t >= 2) ldrow(L.Hb + HB * (t - 2) + 6 * lane, ka);
                     pl = affine(kb, pl);
                     L.kk[8 * (t - 1) + lane] = pl;
-                    LDS_DRAIN();
                 }
             }
         }
@@ -370,19 +367,16 @@ __device__ inline void solve(const Args &a, double *smem)
             double xl = 0;
             Row ka, kb;
             ldrow(L.Mf + 6 * row, ka);
-            LDS_DRAIN();
             for (int t = 0; t < T; t += 2) {
                 if (t + 1 < T) ldrow(L.Mf + MF * (t + 1) + 6 * row, kb);
                 L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
                 xl = affine(ka, xl);
                 L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
-                LDS_DRAIN();
                 if (t + 1 < T) {
                     if (t + 2 < T) ldrow(L.Mf + MF * (t + 2) + 6 * row, ka);
                     L.dy[8 * (t + 1) + lane] = xl;
                     xl = affine(kb, xl);
                     L.vv[8 * (t + 1) + lane] = xl;
-                    LDS_DRAIN();
                 }
             }
             if (lane < 3) L.pv[lane] = xl;
@@ -427,7 +421,9 @@ __device__ inline void solve(const Args &a, double *smem)
     };
 
     int status = 1, it;
-    auto mark = [&](int k) { if (a.prof && tid == 0) { long long now = clock64(); a.prof[k] += now - tprev; tprev = now; } };
+    long long pacc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
+    const bool prof_on = a.prof != nullptr;
+    auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
     mark(9);
     for (it = 0; it < 100; ++it) {
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
@@ -676,6 +672,7 @@ __device__ inline void solve(const Args &a, double *smem)
     }
     if (tid == 0) { *a.status = status; *a.ipm_iters = it; }
     mark(10);
+    if (prof_on && tid == 0) for (int k = 0; k < 11; ++k) a.prof[k] += pacc[k];
 }
 #undef RW
 #undef LDS_DRAIN
