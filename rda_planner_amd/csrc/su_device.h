@@ -328,9 +328,18 @@ __device__ inline void solve(const Args &a, double *smem)
         const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(base, 16));
         k.v[0] = q[0]; k.v[1] = q[1]; k.v[2] = q[2];
     };
+    // x+ = row . x[0..4] + c with x held by lanes 0..4 of the row: v_fmac_f64 with a DPP row_newbcast source operand
+    // (gfx90a+ allows DPP on 64-bit VALU ops for row_newbcast) - one instruction per term instead of two v_readlane
+    // and an FMA.  s_nop 1: a VGPR written by the previous VALU op needs two wait states before a DPP read.
     auto affine = [&](const Row &k, double x) {
-        double e0 = RW(k, 5) + RW(k, 0) * bcast(x, 0), e1 = RW(k, 1) * bcast(x, 1);
-        e0 += RW(k, 2) * bcast(x, 2); e1 += RW(k, 3) * bcast(x, 3); e0 += RW(k, 4) * bcast(x, 4);
+        double e0 = RW(k, 5), e1 = 0.0;
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(e0), "+v"(e1) : "v"(x), "v"(RW(k, 0)), "v"(RW(k, 1)), "v"(RW(k, 2)), "v"(RW(k, 3)), "v"(RW(k, 4)));
         return e0 + e1;
     };
     // backward: [p ; kk] <- Mb [p] + cb   (lanes 0..4 carry p, lanes 5..7 deliver kk).  Only lanes 0..7 are active
