@@ -235,12 +235,21 @@ __device__ inline void solve(const Args &a, double *smem)
             double cs = cos(L.phin[rt]), sn = sin(L.phin[rt]);
             for (int r = 0; r < a.P; ++r) {
                 const size_t o = r * a.chunk + (size_t)rt * a.Nloc;
-                for (int n = rc_; n < a.Nloc; n += nch) {
-                    double ax = a.ax[o + n], ay = a.ay[o + n], gx = a.gx[o + n], gy = a.gy[o + n];
+                auto term = [&](double ax, double ay, double gx, double gy) {
                     double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
                     double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
                     q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
+                };
+                const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o;
+                int n = rc_;
+                for (; n + 7 * nch < a.Nloc; n += 8 * nch) {      // eight independent loads in flight per array
+                    double x[8], y[8], g[8], h[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { x[k] = pax[n + k * nch]; y[k] = pay[n + k * nch]; g[k] = pgx[n + k * nch]; h[k] = pgy[n + k * nch]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) term(x[k], y[k], g[k], h[k]);
                 }
+                for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n]);
             }
         }
         L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
@@ -452,11 +461,12 @@ __device__ inline void solve(const Args &a, double *smem)
                     const size_t o = r * a.chunk + (size_t)rt * Nl;
                     const double *pax = a.ax + o, *pay = a.ay + o, *pb = a.blam + o, *pe = a.ee + o;
                     int n = rc_;
-                    for (; n + 3 * nch < Nl; n += 4 * nch) {      // four independent loads in flight per array
-                        double a0 = pax[n], a1 = pax[n + nch], a2 = pax[n + 2 * nch], a3 = pax[n + 3 * nch];
-                        double b0 = pay[n], b1 = pay[n + nch], b2 = pay[n + 2 * nch], b3 = pay[n + 3 * nch];
-                        double c0 = pb[n] + pe[n], c1 = pb[n + nch] + pe[n + nch], c2 = pb[n + 2 * nch] + pe[n + 2 * nch], c3 = pb[n + 3 * nch] + pe[n + 3 * nch];
-                        term(a0, b0, c0); term(a1, b1, c1); term(a2, b2, c2); term(a3, b3, c3);
+                    for (; n + 7 * nch < Nl; n += 8 * nch) {      // eight independent loads in flight per array
+                        double x[8], y[8], cb[8], ce[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { x[k] = pax[n + k * nch]; y[k] = pay[n + k * nch]; cb[k] = pb[n + k * nch]; ce[k] = pe[n + k * nch]; }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) term(x[k], y[k], cb[k] + ce[k]);
                     }
                     for (; n < Nl; n += nch) term(pax[n], pay[n], pb[n] + pe[n]);
                 }
@@ -520,24 +530,29 @@ __device__ inline void solve(const Args &a, double *smem)
             else if (j == 7) v += lam[4] - lam[5];
             L.gst[i] = v;
         }
-        for (int i = tid; i < HB * T; i += NT) {
-            int t = i >> 6, r = (i >> 3) & 7, q = i & 7;
+        for (int i = tid; i < 8 * T; i += NT) {               // one thread per (stage, row): Hw and the row's J column stay in registers
+            int t = i >> 3, r = i & 7;
             const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *dg = &L.dw[NC * t];
-            const double jq[4] = { Fel(F, 0, q), Fel(F, 1, q), Fel(F, 2, q), q == 7 ? 1.0 : 0.0 };
-            const double jr[4] = { Fel(F, 0, r), Fel(F, 1, r), Fel(F, 2, r), r == 7 ? 1.0 : 0.0 };
-            double m = 0;
+            const double h00 = Hw[0], h01 = Hw[1], hd0 = Hw[3], h11 = Hw[5], hd1 = Hw[7], h22 = Hw[10], hdd = Hw[15];
+            const double a0 = Fel(F, 0, r), a1 = Fel(F, 1, r), a2 = Fel(F, 2, r), a3 = r == 7 ? 1.0 : 0.0;
+            // v = Hw J[:, r]
+            const double v0 = h00 * a0 + h01 * a1 + hd0 * a3, v1 = h01 * a0 + h11 * a1 + hd1 * a3, v2 = h22 * a2, v3 = hd0 * a0 + hd1 * a1 + hdd * a3;
+            const double bu0 = dg[0] + dg[1], bu1 = dg[2] + dg[3], bd = dg[4] + dg[5], br0 = dg[6] + dg[7], br1 = dg[8] + dg[9];
+            double *row = &L.Hb[HB * t + 8 * r];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) m += jr[x] * (Hw[4 * x] * jq[0] + Hw[4 * x + 1] * jq[1] + Hw[4 * x + 2] * jq[2] + Hw[4 * x + 3] * jq[3]);
-            // barrier weights: u0 box (rows 0,1), u1 box (2,3), d box (4,5), rate u0 (6,7), rate u1 (8,9)
-            if (r == q) {
-                if (r == 5) m += 2 * c.wu + c.eps_u + dg[0] + dg[1] + dg[6] + dg[7];
-                else if (r == 6) m += c.eps_u + dg[2] + dg[3] + dg[8] + dg[9];
-                else if (r == 7) m += dg[4] + dg[5];
-                else if (r == 3) m += dg[6] + dg[7];
-                else if (r == 4) m += dg[8] + dg[9];
-            } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= dg[6] + dg[7];
-            else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= dg[8] + dg[9];
-            L.Hb[i] = m;
+            for (int q = 0; q < 8; ++q) {
+                double m = Fel(F, 0, q) * v0 + Fel(F, 1, q) * v1 + Fel(F, 2, q) * v2 + (q == 7 ? v3 : 0.0);
+                // barrier weights: u0 box, u1 box, d box, rate u0 (rows u0 - up0), rate u1
+                if (r == q) {
+                    if (r == 5) m += 2 * c.wu + c.eps_u + bu0 + br0;
+                    else if (r == 6) m += c.eps_u + bu1 + br1;
+                    else if (r == 7) m += bd;
+                    else if (r == 3) m += br0;
+                    else if (r == 4) m += br1;
+                } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= br0;
+                else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= br1;
+                row[q] = m;
+            }
         }
         __syncthreads();
         mark(2);
