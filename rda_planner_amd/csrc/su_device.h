@@ -408,34 +408,43 @@ __device__ inline void solve(const Args &a, double *smem)
         ldrow(L.Ft + FT * t + 6 * mq_, k.fc);
         ldrow(L.Ft + FT * t + 6 * mr_, k.fr);
     };
-    auto mat_step = [&](int t, const MatK &k, double &pv, bool &fail_) {
+    // Cross-lane operands travel through a 3 x 64-double LDS scratch of this wave (LDS executes one wave's
+    // instructions in order, so a write followed by reads needs no barrier): 19 LDS instructions per stage instead of
+    // 44 ds_bpermute_b32 + 12 v_readlane_b32.
+    double *const Px = L.red + 16, *const Xs = L.red + 80, *const Ms = L.red + 144;
+    auto mat_step = [&](int t, const MatK &k) {
         // X = P F : lane (i,q) needs row i of P
-        double x = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) x += __shfl(pv, 8 * mr_ + j, 64) * RW(k.fc, j);
+        Row pr; ldrow(Px + 8 * mr_, pr);
+        double x = RW(pr, 0) * RW(k.fc, 0) + RW(pr, 1) * RW(k.fc, 1);
+        x += RW(pr, 2) * RW(k.fc, 2); x += RW(pr, 3) * RW(k.fc, 3); x += RW(pr, 4) * RW(k.fc, 4);
+        Xs[lane] = x;
         // M = Hb + F' X : lane (r,q) needs column q of X
-        double m = k.hb;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) m += RW(k.fr, i) * __shfl(x, 8 * i + mq_, 64);
-        // inverse of the pivot block Mvv (rows/cols 5..7) by the adjugate, on every lane
-        const double m00 = bcast(m, 45), m01 = bcast(m, 46), m02 = bcast(m, 47), m11 = bcast(m, 54), m12 = bcast(m, 55), m22 = bcast(m, 63);
+        const double *xc = Xs + mq_;
+        double m = k.hb + RW(k.fr, 0) * xc[0] + RW(k.fr, 1) * xc[8];
+        m += RW(k.fr, 2) * xc[16]; m += RW(k.fr, 3) * xc[24]; m += RW(k.fr, 4) * xc[32];
+        Ms[lane] = m;
+        // pivot block Mvv (rows/cols 5..7), M[r][5..7], M[5..7][q]
+        const double m00 = Ms[45], m01 = Ms[46], m02 = Ms[47], m11 = Ms[54], m12 = Ms[55], m22 = Ms[63];
+        const double a0 = Ms[8 * mr_ + 5], a1 = Ms[8 * mr_ + 6], a2 = Ms[8 * mr_ + 7];
+        const double b0 = Ms[40 + mq_], b1 = Ms[48 + mq_], b2 = Ms[56 + mq_];
+        // inverse of Mvv by the adjugate, on every lane; reciprocal of the determinant by v_rcp_f64 + two Newton steps
         double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
         double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
         double det = m00 * c00 + m01 * c01 + m02 * c02;
-        if (!(m00 > 0) || !(c22 > 0) || !(det > 0)) fail_ = true;
-        double id = 1.0 / det;
+        double id = __builtin_amdgcn_rcp(det);
+        id = __builtin_fma(id, __builtin_fma(-det, id, 1.0), id);
+        id = __builtin_fma(id, __builtin_fma(-det, id, 1.0), id);
         double n00 = c00 * id, n01 = c01 * id, n02 = c02 * id, n11 = c11 * id, n12 = c12 * id, n22 = c22 * id;
         // W row r = M[r][5..7] Minv ;  P = Mxx - W Mvx
-        const double a0 = __shfl(m, 8 * mr_ + 5, 64), a1 = __shfl(m, 8 * mr_ + 6, 64), a2 = __shfl(m, 8 * mr_ + 7, 64);
-        const double b0 = __shfl(m, 40 + mq_, 64), b1 = __shfl(m, 48 + mq_, 64), b2 = __shfl(m, 56 + mq_, 64);
         double w0 = a0 * n00 + a1 * n01 + a2 * n02;
         double w1 = a0 * n01 + a1 * n11 + a2 * n12;
         double w2 = a0 * n02 + a1 * n12 + a2 * n22;
         double pn = m - (w0 * b0 + w1 * b1 + w2 * b2);
-        pv = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
+        Px[lane] = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
         double *o = &L.Wn[WN * t];
         if (mr_ < 5 && mq_ < 3) o[3 * mr_ + mq_] = mq_ == 0 ? w0 : (mq_ == 1 ? w1 : w2);
         if (lane == 63) { o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22; }
+        return (m00 > 0) && (c22 > 0) && (det > 0);
     };
 
     int status = 1, it;
@@ -560,20 +569,19 @@ __device__ inline void solve(const Args &a, double *smem)
         //          wave 2: Newton right-hand side of the predictor --------------------------------------------
         bool fail = false;
         if (wave == 0) {
-            double pv = 0;
+            Px[lane] = 0.0;                               // P_T = 0
             MatK ka, kb;
+            bool ok = true;
             ldmat(T - 1, ka);
-            LDS_DRAIN();
             for (int t = T - 1; t >= 0; t -= 2) {
                 if (t >= 1) ldmat(t - 1, kb);
-                mat_step(t, ka, pv, fail);
-                LDS_DRAIN();
+                ok = mat_step(t, ka) && ok;
                 if (t >= 1) {
                     if (t >= 2) ldmat(t - 2, ka);
-                    mat_step(t - 1, kb, pv, fail);
-                    LDS_DRAIN();
+                    ok = mat_step(t - 1, kb) && ok;
                 }
             }
+            fail = !ok;
         } else if (wave == 1) {
             double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
             for (int t = T - 1; t >= 0; --t) {
