@@ -401,12 +401,18 @@ __device__ inline void solve(const Args &a, double *smem)
         }
     };
     // ---- Riccati matrix recursion (wave 0): lane 8r+q owns entry (r,q) ------------------------------------------
-    struct MatK { double hb; Row fc, fr; };
+    struct Row5 { d2 a, b; double c; };
+    auto ldrow5 = [&](const double *base, Row5 &k) {
+        const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(base, 16));
+        k.a = q[0]; k.b = q[1]; k.c = base[4];
+    };
+#define R5(k, i) ((i) < 2 ? (k).a[(i) & 1] : ((i) < 4 ? (k).b[(i) & 1] : (k).c))
+    struct MatK { double hb; Row5 fc, fr; };
     const int mr_ = lane >> 3, mq_ = lane & 7;
     auto ldmat = [&](int t, MatK &k) {
         k.hb = L.Hb[HB * t + lane];
-        ldrow(L.Ft + FT * t + 6 * mq_, k.fc);
-        ldrow(L.Ft + FT * t + 6 * mr_, k.fr);
+        ldrow5(L.Ft + FT * t + 6 * mq_, k.fc);
+        ldrow5(L.Ft + FT * t + 6 * mr_, k.fr);
     };
     // Cross-lane operands travel through a 3 x 64-double LDS scratch of this wave (LDS executes one wave's
     // instructions in order, so a write followed by reads needs no barrier): 19 LDS instructions per stage instead of
@@ -414,19 +420,21 @@ __device__ inline void solve(const Args &a, double *smem)
     double *const Px = L.red + 16, *const Xs = L.red + 80, *const Ms = L.red + 144;
     auto mat_step = [&](int t, const MatK &k) {
         // X = P F : lane (i,q) needs row i of P
-        Row pr; ldrow(Px + 8 * mr_, pr);
-        double x = RW(pr, 0) * RW(k.fc, 0) + RW(pr, 1) * RW(k.fc, 1);
-        x += RW(pr, 2) * RW(k.fc, 2); x += RW(pr, 3) * RW(k.fc, 3); x += RW(pr, 4) * RW(k.fc, 4);
+        Row5 pr; ldrow5(Px + 8 * mr_, pr);
+        double x = R5(pr, 0) * R5(k.fc, 0) + R5(pr, 1) * R5(k.fc, 1);
+        x += R5(pr, 2) * R5(k.fc, 2); x += R5(pr, 3) * R5(k.fc, 3); x += R5(pr, 4) * R5(k.fc, 4);
         Xs[lane] = x;
         // M = Hb + F' X : lane (r,q) needs column q of X
         const double *xc = Xs + mq_;
-        double m = k.hb + RW(k.fr, 0) * xc[0] + RW(k.fr, 1) * xc[8];
-        m += RW(k.fr, 2) * xc[16]; m += RW(k.fr, 3) * xc[24]; m += RW(k.fr, 4) * xc[32];
+        const double x0 = xc[0], x1 = xc[8], x2 = xc[16], x3 = xc[24], x4 = xc[32];
+        double m = k.hb + R5(k.fr, 0) * x0 + R5(k.fr, 1) * x1;
+        m += R5(k.fr, 2) * x2; m += R5(k.fr, 3) * x3; m += R5(k.fr, 4) * x4;
         Ms[lane] = m;
         // pivot block Mvv (rows/cols 5..7), M[r][5..7], M[5..7][q]
         const double m00 = Ms[45], m01 = Ms[46], m02 = Ms[47], m11 = Ms[54], m12 = Ms[55], m22 = Ms[63];
         const double a0 = Ms[8 * mr_ + 5], a1 = Ms[8 * mr_ + 6], a2 = Ms[8 * mr_ + 7];
-        const double b0 = Ms[40 + mq_], b1 = Ms[48 + mq_], b2 = Ms[56 + mq_];
+        double b0 = Ms[40 + mq_], b1 = Ms[48 + mq_], b2 = Ms[56 + mq_];
+        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));      // keep these loads in the same LDS round as the pivot block
         // inverse of Mvv by the adjugate, on every lane; reciprocal of the determinant by v_rcp_f64 + two Newton steps
         double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
         double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
@@ -707,6 +715,7 @@ __device__ inline void solve(const Args &a, double *smem)
     if (prof_on && tid == 0) for (int k = 0; k < 11; ++k) a.prof[k] += pacc[k];
 }
 #undef RW
+#undef R5
 #undef LDS_DRAIN
 
 }  // namespace su
