@@ -599,7 +599,7 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
 #ifdef ORC_DEBUG
         fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
 #endif
-        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-9 * sc) { status = 0; break; }
+        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
         /* K = H + C' diag(lm/w) C */
         memcpy(K, Hm, sizeof(double) * n * n);
         for (int i = 0; i < mc; ++i) {

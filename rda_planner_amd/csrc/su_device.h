@@ -648,7 +648,7 @@ __device__ inline void solve(const Args &a, double *smem)
         }
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
-        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-9 * sc) { status = 0; break; }
+        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
         if (__syncthreads_or(fail ? 1 : 0)) { status = 2; break; }
         mark(5);
 
