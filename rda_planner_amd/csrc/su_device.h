@@ -408,28 +408,37 @@ __device__ inline void solve(const Args &a, double *smem)
     };
 #define R5(k, i) ((i) < 2 ? (k).a[(i) & 1] : ((i) < 4 ? (k).b[(i) & 1] : (k).c))
     struct MatK { double hb; Row5 fc, fr; };
-    const int mr_ = lane >> 3, mq_ = lane & 7;
+    const int mq_ = lane >> 3, mr_ = lane & 7;          // lane 8q+r owns entry (r,q): a column of M per 8-lane group
     auto ldmat = [&](int t, MatK &k) {
         k.hb = L.Hb[HB * t + lane];
         ldrow5(L.Ft + FT * t + 6 * mq_, k.fc);
         ldrow5(L.Ft + FT * t + 6 * mr_, k.fr);
     };
-    // Cross-lane operands travel through a 3 x 64-double LDS scratch of this wave (LDS executes one wave's
-    // instructions in order, so a write followed by reads needs no barrier): 19 LDS instructions per stage instead of
-    // 44 ds_bpermute_b32 + 12 v_readlane_b32.
-    double *const Px = L.red + 16, *const Xs = L.red + 80, *const Ms = L.red + 144;
+    // Cross-lane operands: rows of P and the blocks of M travel through a 2 x 64-double LDS scratch of this wave (LDS
+    // executes one wave's instructions in order, so a write followed by reads needs no barrier); the column of X a
+    // lane needs sits in its own 8-lane group and is consumed straight from the neighbours' registers by
+    // v_fmac_f64 with a DPP row_newbcast operand (bank_mask selects the lower / upper group of the 16-lane row).
+    double *const Px = L.red + 16, *const Ms = L.red + 80;
     auto mat_step = [&](int t, const MatK &k) {
-        // X = P F : lane (i,q) needs row i of P
+        // X = P F : lane (q,i) needs row i of P
         Row5 pr; ldrow5(Px + 8 * mr_, pr);
         double x = R5(pr, 0) * R5(k.fc, 0) + R5(pr, 1) * R5(k.fc, 1);
         x += R5(pr, 2) * R5(k.fc, 2); x += R5(pr, 3) * R5(k.fc, 3); x += R5(pr, 4) * R5(k.fc, 4);
-        Xs[lane] = x;
-        // M = Hb + F' X : lane (r,q) needs column q of X
-        const double *xc = Xs + mq_;
-        const double x0 = xc[0], x1 = xc[8], x2 = xc[16], x3 = xc[24], x4 = xc[32];
-        double m = k.hb + R5(k.fr, 0) * x0 + R5(k.fr, 1) * x1;
-        m += R5(k.fr, 2) * x2; m += R5(k.fr, 3) * x3; m += R5(k.fr, 4) * x4;
-        Ms[lane] = m;
+        // M = Hb + F' X : lane (q,r) needs X[0..4][q] = positions 0..4 of its own group
+        double m = k.hb;
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:9 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:10 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:12 row_mask:0xf bank_mask:0xc"
+                     : "+v"(m) : "v"(x), "v"(R5(k.fr, 0)), "v"(R5(k.fr, 1)), "v"(R5(k.fr, 2)), "v"(R5(k.fr, 3)), "v"(R5(k.fr, 4)));
+        Ms[8 * mr_ + mq_] = m;
         // pivot block Mvv (rows/cols 5..7), M[r][5..7], M[5..7][q]
         const double m00 = Ms[45], m01 = Ms[46], m02 = Ms[47], m11 = Ms[54], m12 = Ms[55], m22 = Ms[63];
         const double a0 = Ms[8 * mr_ + 5], a1 = Ms[8 * mr_ + 6], a2 = Ms[8 * mr_ + 7];
@@ -448,7 +457,7 @@ __device__ inline void solve(const Args &a, double *smem)
         double w1 = a0 * n01 + a1 * n11 + a2 * n12;
         double w2 = a0 * n02 + a1 * n12 + a2 * n22;
         double pn = m - (w0 * b0 + w1 * b1 + w2 * b2);
-        Px[lane] = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
+        Px[8 * mr_ + mq_] = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
         double *o = &L.Wn[WN * t];
         if (mr_ < 5 && mq_ < 3) o[3 * mr_ + mq_] = mq_ == 0 ? w0 : (mq_ == 1 ? w1 : w2);
         if (lane == 63) { o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22; }
