@@ -425,19 +425,21 @@ __device__ inline void solve(const Args &a, double *smem)
         double x = R5(pr, 0) * R5(k.fc, 0) + R5(pr, 1) * R5(k.fc, 1);
         x += R5(pr, 2) * R5(k.fc, 2); x += R5(pr, 3) * R5(k.fc, 3); x += R5(pr, 4) * R5(k.fc, 4);
         // M = Hb + F' X : lane (q,r) needs X[0..4][q] = positions 0..4 of its own group
-        double m = k.hb;
+        // (64-bit DPP takes full row/bank masks only: both halves of the row are formed and the own group's is kept)
+        double me = 0.0, mo = 0.0;
         asm volatile("s_nop 1\n\t"
-                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:9 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:10 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
-                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:12 row_mask:0xf bank_mask:0xc"
-                     : "+v"(m) : "v"(x), "v"(R5(k.fr, 0)), "v"(R5(k.fr, 1)), "v"(R5(k.fr, 2)), "v"(R5(k.fr, 3)), "v"(R5(k.fr, 4)));
+                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %3 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %4 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %6 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %2, %7 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+                     : "+v"(me), "+v"(mo) : "v"(x), "v"(R5(k.fr, 0)), "v"(R5(k.fr, 1)), "v"(R5(k.fr, 2)), "v"(R5(k.fr, 3)), "v"(R5(k.fr, 4)));
+        const double m = k.hb + ((mq_ & 1) ? mo : me);
         Ms[8 * mr_ + mq_] = m;
         // pivot block Mvv (rows/cols 5..7), M[r][5..7], M[5..7][q]
         const double m00 = Ms[45], m01 = Ms[46], m02 = Ms[47], m11 = Ms[54], m12 = Ms[55], m22 = Ms[63];
