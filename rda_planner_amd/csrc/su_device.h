@@ -369,6 +369,14 @@ __device__ inline void solve(const Args &a, double *smem)
                 }
             }
         }
+        wsync();
+        // constants of the forward map: cf = [Fv kk ; kk_2]
+        for (int i = lane; i < 6 * T; i += 64) {
+            int t = i / 6, r = i % 6;
+            const double *kq = &L.kk[8 * t + 5], *F = &L.Ft[FT * t];
+            L.Mf[MF * t + 6 * r + 5] = r < 5 ? Fel(F, r, 5) * kq[0] + Fel(F, r, 6) * kq[1] : kq[2];
+        }
+        wsync();
     };
     // forward: [dx+ ; v_2] <- Mf [dx] + cf   (lanes 0..4 carry dx; v = outputs 3..5)
     auto fwd_all = [&]() {
@@ -391,93 +399,6 @@ __device__ inline void solve(const Args &a, double *smem)
             }
             if (lane < 3) L.pv[lane] = xl;
         }
-    };
-    // Register-resident variant for T <= 32: stage t is owned by the 8-lane group t & 7, whose lanes keep their rows
-    // of all their stages (t, t+8, ..) in registers - no LDS traffic inside the serial loop.  The state hops from
-    // group to group: inside a 16-lane row through the DPP operand, across rows through v_readlane.  Every lane
-    // executes every stage; only the owning group commits the result.
-    auto affine_hi = [&](const Row &k, double x) {          // x held by lanes 8..12 of the row
-        double e0 = RW(k, 5), e1 = 0.0;
-        asm volatile("s_nop 1\n\t"
-                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %1, %2, %4 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %0, %2, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %1, %2, %6 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %0, %2, %7 row_newbcast:12 row_mask:0xf bank_mask:0xf"
-                     : "+v"(e0), "+v"(e1) : "v"(x), "v"(RW(k, 0)), "v"(RW(k, 1)), "v"(RW(k, 2)), "v"(RW(k, 3)), "v"(RW(k, 4)));
-        return e0 + e1;
-    };
-    auto affine_rl = [&](const Row &k, double x, int base) { // x held by lanes base..base+4 of the wave
-        double e0 = RW(k, 5) + RW(k, 0) * bcast(x, base), e1 = RW(k, 1) * bcast(x, base + 1);
-        e0 += RW(k, 2) * bcast(x, base + 2); e1 += RW(k, 3) * bcast(x, base + 3); e0 += RW(k, 4) * bcast(x, base + 4);
-        return e0 + e1;
-    };
-    constexpr int NBK = 4;                                   // blocks of 8 stages kept in registers
-    auto zero_row = [&](Row &k) { k.v[0] = d2{0.0, 0.0}; k.v[1] = d2{0.0, 0.0}; k.v[2] = d2{0.0, 0.0}; };
-    auto bwd_reg = [&]() {
-        const int grp = lane >> 3, pos = lane & 7;
-        Row rows[NBK]; double out[NBK];
-#pragma unroll
-        for (int b = 0; b < NBK; ++b) {
-            const int t = 8 * b + grp;
-            if (t < T) ldrow(L.Hb + HB * t + 6 * pos, rows[b]); else zero_row(rows[b]);
-            out[b] = 0.0;
-        }
-#pragma unroll
-        for (int b = NBK - 1; b >= 0; --b) {
-#pragma unroll
-            for (int g = 7; g >= 0; --g) {
-                const int t = 8 * b + g;
-                if (t < T) {                                  // wave-uniform
-                    double cand;
-                    if (t == T - 1) cand = RW(rows[b], 5);                                   // p_T = 0
-                    else if (!(g & 1)) cand = affine_hi(rows[b], out[b]);                    // stage t+1: upper group of this row
-                    else cand = affine_rl(rows[b], g == 7 ? out[b + 1 < NBK ? b + 1 : b] : out[b], 8 * ((g + 1) & 7));
-                    out[b] = grp == g ? cand : out[b];
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < NBK; ++b) { const int t = 8 * b + grp; if (t < T) L.kk[8 * t + pos] = out[b]; }
-    };
-    auto fwd_reg = [&]() {
-        const int grp = lane >> 3, pos = lane & 7, rowi = pos < 6 ? pos : 5;
-        Row rows[NBK]; double out[NBK];
-#pragma unroll
-        for (int b = 0; b < NBK; ++b) {
-            const int t = 8 * b + grp;
-            if (t < T) ldrow(L.Mf + MF * t + 6 * rowi, rows[b]); else zero_row(rows[b]);
-            out[b] = 0.0;
-        }
-#pragma unroll
-        for (int b = 0; b < NBK; ++b) {
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int t = 8 * b + g;
-                if (t < T) {
-                    double cand;
-                    if (t == 0) cand = RW(rows[0], 5);                                       // dx_0 = 0
-                    else if (g & 1) cand = affine(rows[b], out[b]);                          // stage t-1: lower group of this row
-                    else cand = affine_rl(rows[b], g == 0 ? out[b > 0 ? b - 1 : 0] : out[b], 8 * ((g + 7) & 7));
-                    out[b] = grp == g ? cand : out[b];
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < NBK; ++b) { const int t = 8 * b + grp; if (t < T) L.vv[8 * t + pos] = out[b]; }
-        wsync();
-        for (int i = lane; i < 8 * T; i += 64) L.dy[i] = i >= 8 ? L.vv[i - 8] : 0.0;       // dx_t = output of stage t-1
-        if (lane < 3) L.pv[lane] = L.vv[8 * (T - 1) + lane];
-    };
-    // constants of the forward map: cf = [Fv kk ; kk_2]   (wave 0, between the two sweeps)
-    auto build_cf = [&]() {
-        wsync();
-        for (int i = lane; i < 6 * T; i += 64) {
-            int t = i / 6, r = i % 6;
-            const double *kq = &L.kk[8 * t + 5], *F = &L.Ft[FT * t];
-            L.Mf[MF * t + 6 * r + 5] = r < 5 ? Fel(F, r, 5) * kq[0] + Fel(F, r, 6) * kq[1] : kq[2];
-        }
-        wsync();
     };
     // ---- Riccati matrix recursion (wave 0): lane 8r+q owns entry (r,q) ------------------------------------------
     struct Row5 { d2 a, b; double c; };
@@ -754,10 +675,7 @@ __device__ inline void solve(const Args &a, double *smem)
             build_cb();
             __syncthreads();
             mark(6);
-            if (wave == 0) {
-                if (T <= 8 * NBK) { bwd_reg(); build_cf(); fwd_reg(); }
-                else { bwd_all(); build_cf(); fwd_all(); }
-            }
+            if (wave == 0) { bwd_all(); fwd_all(); }
             __syncthreads();
             mark(7);
             // ---- slack / multiplier steps, step length ------------------------------------------------
