@@ -66,7 +66,7 @@ __device__ void reduce_residuals(const Dev &d, double *red, int tid)
 
 extern __shared__ __attribute__((aligned(16))) double smem_su[];
 
-__global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u)
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u)
 {
     const int tid = threadIdx.x;
     if (d.ctrl->stop) return;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
-    su::solve(a, smem_su);
+    su::solve<TT>(a, smem_su);
     __syncthreads();
     if (tid == 0) {
         d.ctrl->iters = it + 1;
@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
 }
 
 // standalone su-solve hook
-__global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a) { su::solve(a, smem_su); }
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a) { su::solve<TT>(a, smem_su); }
+
+// horizons with a compile-time specialisation of the su kernel (the BASELINE configurations); any other T runs the generic one
+#define RDA_SU_DISPATCH(T, CALL) do { switch (T) { case 10: { constexpr int TT = 10; CALL; } break; case 20: { constexpr int TT = 20; CALL; } break; \
+                                                    default: { constexpr int TT = 0; CALL; } break; } } while (0)
 
 // [N][T+1][2] / [N][T+1] <-> [T][N] transposes for the state accessors
 __global__ void k_products_get(Dev d, double *a_lam, double *b_lam)
@@ -358,8 +362,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     HIPCHK(hipHostMalloc((void **)&H->h_out, (2 * T + 3 * (T + 1)) * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&H->h_info, sizeof(rda_info)));
     H->su_lds = su::lds_bytes((int)T);
-    HIPCHK(hipFuncSetAttribute((const void *)k_su, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_su_hook, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
+    RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds)));
     HIPCHK(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
     *out = H;
     return RDA_OK;
@@ -448,7 +451,7 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, d);
     for (int it = 0; it < d.c.iter_num; ++it) {
         if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
-        hipLaunchKernelGGL(k_su, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u);
+        RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
         if (H->timing) { (void)hipEventRecord(next_event(H, 1), H->stream); (void)hipEventRecord(next_event(H, 0), H->stream); }
         hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
@@ -674,7 +677,7 @@ extern "C" int rda_admm_su(rda_handle *H, int it, int *stopped)
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     Dev d = H->d;
     d.ref = H->d_step + ns + nu; d.ref_speed = H->d_step + ns + nu + ns;
-    hipLaunchKernelGGL(k_su, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns);
+    RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns));
     HIPCHK(hipGetLastError());
     if (stopped) {
         Ctrl c;
@@ -776,8 +779,8 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     if (getenv("RDA_SU_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }
     ar.prof = dprof;
     const size_t lds = su::lds_bytes((int)T);
-    HIPCHK(hipFuncSetAttribute((const void *)k_su_hook, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_su_hook, dim3(1), dim3(su::NT), lds, 0, ar);
+    RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_hook<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+    RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su_hook<TT>, dim3(1), dim3(su::NT), lds, 0, ar));
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     int st[2];

@@ -196,11 +196,12 @@ __device__ __forceinline__ void con_T(const double *x, int t, double &y3, double
 // entry F[i][q] of the stage transition x+ = F y from the packed transpose
 __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return Ft_t[6 * q + i]; }
 
-// The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).
-__device__ inline void solve(const Args &a, double *smem)
+// The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).  TT > 0 fixes the horizon
+// at compile time (every LDS offset becomes an immediate, the stage loops get constant bounds); TT == 0 reads it from c.T.
+template <int TT> __device__ inline void solve(const Args &a, double *smem)
 {
     const Cfg &c = a.c;
-    const int T = c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
     long long tprev = clock64();
     const double vref = *a.ref_speed;
