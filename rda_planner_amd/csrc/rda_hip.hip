@@ -239,8 +239,9 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
 // standalone su-solve hook
 template <int TT> __global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a) { su::solve<TT>(a, smem_su); }
 
-// horizons with a compile-time specialisation of the su kernel (the BASELINE configurations); any other T runs the generic one
+// horizons with a compile-time specialisation of the su kernel (BASELINE configs C1, north star, C5, C4); any other T runs the generic one
 #define RDA_SU_DISPATCH(T, CALL) do { switch (T) { case 10: { constexpr int TT = 10; CALL; } break; case 20: { constexpr int TT = 20; CALL; } break; \
+                                                    case 25: { constexpr int TT = 25; CALL; } break; case 30: { constexpr int TT = 30; CALL; } break; \
                                                     default: { constexpr int TT = 0; CALL; } break; } } while (0)
 
 // [N][T+1][2] / [N][T+1] <-> [T][N] transposes for the state accessors

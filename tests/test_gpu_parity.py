@@ -89,7 +89,8 @@ def test_lammuz_full_size_properties(hip):
 
 
 @pytest.mark.parametrize("T,N,dyn,acc,ro1", [(5, 3, 0, 1, 200), (10, 5, 1, 0, 300), (20, 20, 2, 1, 200), (30, 50, 0, 1, 1.0),
-                                             (10, 200, 1, 1, 200), (20, 200, 0, 1, 300), (20, 2000, 0, 1, 200), (64, 7, 1, 1, 200)])
+                                             (10, 200, 1, 1, 200), (20, 200, 0, 1, 300), (20, 2000, 0, 1, 200), (64, 7, 1, 1, 200),
+                                             (25, 40, 0, 1, 200)])
 def test_su_solve(orc, hip, T, N, dyn, acc, ro1):
     rng = np.random.default_rng(T * 1000 + N)
     cfg = hp.make_cfg(T=T, N=N, dynamics=dyn, accelerated=acc, ro1=ro1)
