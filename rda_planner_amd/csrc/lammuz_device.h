@@ -39,7 +39,9 @@ struct Sol {
     double l1, l2, g1, g2;  // lam / mu values on the supports
 };
 
-struct MuCand { int k; int j0, j1; double gx, gy, eta; double P00, P01, P10, P11, det, r0, r1, rr; };
+struct MuCand { int k; int j0, j1; double gx, gy, eta; double P00, P01, P10, P11, det, r0, r1, rr;
+                double iden;   // reciprocal of the mu-elimination pivot for the current hinge state (k = 1, 2)
+                double idet; };
 
 __device__ __forceinline__ void gamma_star(const MuCand &mc, double chi, double ro2, double delta,
                                            double t, double e0, double e1,
@@ -47,17 +49,16 @@ __device__ __forceinline__ void gamma_star(const MuCand &mc, double chi, double 
 {
     if (mc.k == 0) { m = t; H0 = e0; H1 = e1; ga0 = 0; ga1 = 0; return; }
     if (mc.k == 1) {
-        double den = chi * mc.eta * mc.eta + ro2 * (mc.gx * mc.gx + mc.gy * mc.gy);
-        double ga = (chi * mc.eta * t - delta * mc.eta - ro2 * (mc.gx * e0 + mc.gy * e1)) / den;
+        double ga = (chi * mc.eta * t - delta * mc.eta - ro2 * (mc.gx * e0 + mc.gy * e1)) * mc.iden;
         ga0 = ga; ga1 = 0; m = t - mc.eta * ga; H0 = e0 + ga * mc.gx; H1 = e1 + ga * mc.gy;
         return;
     }
     double re = mc.r0 * e0 + mc.r1 * e1;
-    double beta = (delta - chi * (t + re)) / (chi * mc.rr + ro2);
+    double beta = (delta - chi * (t + re)) * mc.iden;
     H0 = -beta * mc.r0; H1 = -beta * mc.r1;
     double d0 = H0 - e0, d1 = H1 - e1;
-    ga0 = (mc.P11 * d0 - mc.P01 * d1) / mc.det;
-    ga1 = (-mc.P10 * d0 + mc.P00 * d1) / mc.det;
+    ga0 = (mc.P11 * d0 - mc.P01 * d1) * mc.idet;
+    ga1 = (-mc.P10 * d0 + mc.P00 * d1) * mc.idet;
     m = t + re + beta * mc.rr;
 }
 
@@ -67,15 +68,15 @@ __device__ __forceinline__ int trs2(double q11, double q12, double q22, double c
                                     double &x0, double &x1, double &x2, double &x3)
 {
     double mean = 0.5 * (q11 + q22), dif = 0.5 * (q11 - q22);
-    double rad = hypot(dif, q12);
+    double rad = sqrt(dif * dif + q12 * q12);
     double l1 = mean - rad, l2 = mean + rad;
     double v2x, v2y;
     if (dif >= 0) { v2x = dif + rad; v2y = q12; } else { v2x = q12; v2y = rad - dif; }
-    double nv = hypot(v2x, v2y);
-    if (nv > 0) { v2x /= nv; v2y /= nv; } else { v2x = 1; v2y = 0; }
+    double nv2 = v2x * v2x + v2y * v2y;
+    if (nv2 > 0) { double inv = rsqrt(nv2); v2x *= inv; v2y *= inv; } else { v2x = 1; v2y = 0; }
     double v1x = -v2y, v1y = v2x;
     double h1 = v1x * c0 + v1y * c1, h2 = v2x * c0 + v2y * c1;
-    double cn = hypot(h1, h2);
+    double cn = sqrt(h1 * h1 + h2 * h2);
     double scale = fabs(l2) > 1e-300 ? fabs(l2) : 1e-300;
     if (disc && l1 > 1e-13 * scale) {
         double y1 = -h1 / l1, y2 = -h2 / l2;
@@ -106,12 +107,13 @@ __device__ __forceinline__ int trs2(double q11, double q12, double q22, double c
     for (int it = 0; it < 20; ++it) {
         double s1 = l1 + tau, s2 = l2 + tau;
         if (s1 <= 0 || s2 <= 0) { tau = (-l1 > -l2 ? -l1 : -l2) + 1e-300; s1 = l1 + tau; s2 = l2 + tau; }
-        double a1 = h1 != 0 ? h1 / s1 : 0.0, a2 = h2 != 0 ? h2 / s2 : 0.0;
+        const double s1i = 1.0 / s1, s2i = 1.0 / s2;
+        double a1 = h1 != 0 ? h1 * s1i : 0.0, a2 = h2 != 0 ? h2 * s2i : 0.0;
         double phi = a1 * a1 + a2 * a2;
         if (!(phi > 0)) break;
-        double dphi = -2.0 * (a1 * a1 / s1 + a2 * a2 / s2);
-        double sq = sqrt(phi);
-        double g = 1.0 / sq - 1.0, dg = -0.5 * dphi / (phi * sq);
+        double dphi = -2.0 * (a1 * a1 * s1i + a2 * a2 * s2i);
+        double rs = rsqrt(phi);                               // g = 1/||y|| - 1,  dg = -1/2 dphi / ||y||^3
+        double g = rs - 1.0, dg = -0.5 * dphi * rs * rs * rs;
         double step = g / dg;
         tau -= step;
         if (fabs(step) <= 4e-16 * (fabs(tau) > 1 ? fabs(tau) : 1)) break;
@@ -119,8 +121,8 @@ __device__ __forceinline__ int trs2(double q11, double q12, double q22, double c
     double s1 = l1 + tau, s2 = l2 + tau;
     double y1 = h1 != 0 ? -h1 / s1 : 0.0, y2 = h2 != 0 ? -h2 / s2 : 0.0;
     double xx = y1 * v1x + y2 * v2x, xy = y1 * v1y + y2 * v2y;
-    double nx = hypot(xx, xy);
-    if (nx > 0) { xx /= nx; xy /= nx; }
+    double nx2 = xx * xx + xy * xy;
+    if (nx2 > 0) { double inv = rsqrt(nx2); xx *= inv; xy *= inv; }
     x0 = xx; x1 = xy;
     return 1;
 }
@@ -259,16 +261,19 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
     MuCand mc; mc.k = 0; mc.j0 = mc.j1 = -1;
     if (im >= 1 && im <= P.R) {
         mc.k = 1; mc.j0 = im - 1; mc.gx = Rb.G[mc.j0][0]; mc.gy = Rb.G[mc.j0][1]; mc.eta = Rb.h[mc.j0];
-        if (!(mc.gx * mc.gx + mc.gy * mc.gy > 0)) return false;
+        const double g2 = mc.gx * mc.gx + mc.gy * mc.gy;
+        if (!(g2 > 0)) return false;
+        mc.iden = 1.0 / (chi * mc.eta * mc.eta + ro2 * g2);
     } else if (im > P.R) {
         mc.k = 2; decode_pair(im - 1 - P.R, P.R, mc.j0, mc.j1);
         double a0 = Rb.G[mc.j0][0], a1 = Rb.G[mc.j0][1], b0 = Rb.G[mc.j1][0], b1 = Rb.G[mc.j1][1];
         double det = a0 * b1 - a1 * b0;
-        if (det == 0 || !(fabs(det) > 1e-12 * hypot(a0, a1) * hypot(b0, b1))) return false;
-        mc.P00 = a0; mc.P01 = b0; mc.P10 = a1; mc.P11 = b1; mc.det = det;
+        if (det == 0 || !(det * det > 1e-24 * (a0 * a0 + a1 * a1) * (b0 * b0 + b1 * b1))) return false;
+        mc.P00 = a0; mc.P01 = b0; mc.P10 = a1; mc.P11 = b1; mc.det = det; mc.idet = 1.0 / det;
         double h0 = Rb.h[mc.j0], h1 = Rb.h[mc.j1];
-        mc.r0 = (h0 * b1 - a1 * h1) / det; mc.r1 = (a0 * h1 - h0 * b0) / det;
+        mc.r0 = (h0 * b1 - a1 * h1) * mc.idet; mc.r1 = (a0 * h1 - h0 * b0) * mc.idet;
         mc.rr = mc.r0 * mc.r0 + mc.r1 * mc.r1;
+        mc.iden = 1.0 / (chi * mc.rr + ro2);
     }
     // ---- lam candidate ---------------------------------------------------------------------
     int i1 = -1, i2 = -1; double la1 = 0, la2 = 0;
@@ -285,7 +290,7 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
         double ax = W.A[i1][0], ay = W.A[i1][1];
         double n2 = ax * ax + ay * ay;
         if (!(n2 > 0)) return false;
-        double amax = 1.0 / hypot(ax, ay);
+        double amax = rsqrt(n2);
         double qi = W.q[i1], m0 = W.M[i1][0], m1 = W.M[i1][1];
         gamma_star(mc, chi, ro2, delta, P.kappa0, P.xi0, P.xi1, ga0, ga1, m, H0, H1);
         double d0 = (chi * m - delta) * qi + ro2 * (m0 * H0 + m1 * H1);
@@ -296,13 +301,14 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
         gamma_star(mc, chi, ro2, delta, al * qi + P.kappa0, al * m0 + P.xi0, al * m1 + P.xi1, ga0, ga1, m, H0, H1);
         la1 = al;
     } else {
-        double dvx, dvy, l0 = 0, a00 = 0, a01 = 0, a10 = 0, a11 = 0, detS = 1;
+        double dvx, dvy, l0 = 0, a00 = 0, a01 = 0, a10 = 0, a11 = 0, detS = 1, idetS = 1;
         if (type == 2) {
             a00 = W.A[i1][0]; a01 = W.A[i1][1]; a10 = W.A[i2][0]; a11 = W.A[i2][1];
             detS = a00 * a11 - a01 * a10;
-            if (detS == 0 || !(fabs(detS) > 1e-12 * hypot(a00, a01) * hypot(a10, a11))) return false;
-            double vx = (W.b[i1] * a11 - a01 * W.b[i2]) / detS;
-            double vy = (a00 * W.b[i2] - W.b[i1] * a10) / detS;
+            if (detS == 0 || !(detS * detS > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11))) return false;
+            idetS = 1.0 / detS;
+            double vx = (W.b[i1] * a11 - a01 * W.b[i2]) * idetS;
+            double vy = (a00 * W.b[i2] - W.b[i1] * a10) * idetS;
             dvx = P.px - vx; dvy = P.py - vy;
         } else { dvx = P.px - W.b[0]; dvy = P.py - W.b[1]; l0 = W.b[2]; i1 = 0; i2 = 1; }
         double ut0 = P.cs * dvx + P.sn * dvy, ut1 = -P.sn * dvx + P.cs * dvy;       // R'(p - v)
@@ -329,8 +335,8 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
             gamma_star(mc, chi, ro2, delta, at0 * ut0 + at1 * ut1 + l0 + P.kappa0, at0 + P.xi0, at1 + P.xi1, ga0, ga1, m, H0, H1);
             double ax = P.cs * at0 - P.sn * at1, ay = P.sn * at0 + P.cs * at1;          // a = R at
             if (type == 2) {
-                la1 = (ax * a11 - a10 * ay) / detS;
-                la2 = (a00 * ay - ax * a01) / detS;
+                la1 = (ax * a11 - a10 * ay) * idetS;
+                la2 = (a00 * ay - ax * a01) * idetS;
             } else { la1 = ax; la2 = ay; }
             Sol c2;
             if (finish(W, Rb, P, mc, type, ic, i1, i2, la1, la2, ga0, ga1, c2) && (!any || c2.cost < s.cost)) { s = c2; any = true; }
