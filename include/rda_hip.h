@@ -16,6 +16,7 @@
  * reset                          rda_solver.py:1060  | rda_reset
  * iterative_solve                rda_solver.py:573   | rda_step (host buffers in/out)
  * assign_obstacle_parameter      rda_solver.py:483   | rda_upload_obstacles
+ * MPC.convert_rda_obstacle + sort mpc.py:189-218,440 | rda_upload_scene / rda_step_scene (caller-side obstacle pipeline on device)
  * rda_solver loop body           rda_solver.py:612   | rda_enqueue_step (device-resident inputs)
  * solve_parallel (pure function) rda_solver.py:743   | rda_lammuz_batch
  * su_prob_solve                  rda_solver.py:692   | rda_su_solve
@@ -77,6 +78,29 @@ int  rda_set_device(int dev);     /* device used by handles created afterwards (
 int  rda_step(rda_handle *h, const double *nom_s, const double *nom_u, const double *ref_s,
               double ref_speed, int n_obs, const double *A, const double *b, const int32_t *cone,
               int per_t, double *out_u, double *out_s, rda_info *info);
+
+/* Caller-side obstacle pipeline on the device.  Replaces, per MPC tick: MPC.convert_rda_obstacle,
+ * rda_obs_distance and the distance sort (mpc.py:189-218), convert_inequal_circle / convert_inequal_polygon with
+ * the constant-velocity prediction `+ velocity * (t * dt)` (mpc.py:440-472), gen_inequal_global / is_convex_and_ordered
+ * (mpc.py:476-549), and RDA_solver.assign_obstacle_parameter (rda_solver.py:483-526: first max_obs_num by distance,
+ * padding with the last one, zeroed spare rows, per-t replication).  The solver's obstacle slots come out bit-identical
+ * to what the Python caller stages.
+ *   kind [n]      0 = polygon (cone 'Rpositive'), 1 = circle (cone 'norm2')
+ *   nvert [n]     polygon vertex count, <= E (ignored for circles)
+ *   geom [n][E][2] polygon: vertices in the caller's order (CW input is reversed like the reference does);
+ *                  circle: geom[i][0] = centre, geom[i][1][0] = radius
+ *   vel [n][2]    obstacle velocity; |vel| > 0.01 makes the obstacle time-varying over the horizon
+ *   robot_xy [2]  robot position for the ordering (order != 0: nearest first, stable; order == 0: caller's order)
+ *   n_nonconvex   (optional) number of staged polygons that fail the reference's convexity test (it prints a warning)
+ * n == 0 leaves the slots untouched and skips the dual side, like rda_step. */
+int  rda_upload_scene(rda_handle *h, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                      const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex);
+/* rda_step with the obstacle conversion done on the device */
+int  rda_step_scene(rda_handle *h, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed,
+                    int n, const int32_t *kind, const int32_t *nvert, const double *geom, const double *vel,
+                    const double *robot_xy, int order, double *out_u, double *out_s, rda_info *info);
+/* test hook: staged slots A [N][nt][E][2], b [N][nt][E], cone [N]; *nt = 1 or T+1 (buffers sized for T+1) */
+int  rda_get_obstacles(rda_handle *h, double *A, double *b, int32_t *cone, int32_t *nt);
 
 /* Device-resident pipeline (what bench.py times): obstacles and a trace of K step inputs are
  * uploaded once; rda_enqueue_step queues the whole ADMM loop of step k on the handle's stream

@@ -82,6 +82,17 @@ class CApi:
                      "admm_begin", "admm_su", "admm_lammuz", "admm_finish"):
             f(name).restype = C.c_int
 
+        # caller-side obstacle pipeline on the device (HIP library only)
+        self.has_scene = hasattr(lib, f"{prefix}_step_scene")
+        if self.has_scene:
+            f("upload_scene").argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, C.c_int, c_int_p]
+            f("upload_scene").restype = C.c_int
+            f("step_scene").argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_double, C.c_int, c_int_p, c_int_p,
+                                        c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, C.POINTER(Info)]
+            f("step_scene").restype = C.c_int
+            f("get_obstacles").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, c_int_p]
+            f("get_obstacles").restype = C.c_int
+
     def _f(self, name):
         return getattr(self.lib, f"{self.prefix}_{name}")
 

@@ -18,6 +18,7 @@
 #include "../../include/rda_hip.h"
 #include "lammuz_device.h"
 #include "su_device.h"
+#include "scene_device.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "librda_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return RDA_ERR_HIP; } } while (0)
@@ -298,6 +299,9 @@ struct rda_handle {
     int (*p_comm_destroy)(void *);
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
+    // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
+    int sc_cap; int *d_sc_kind, *d_sc_nvert, *d_sc_sel, *d_sc_bad; double *d_sc_geom, *d_sc_vel, *d_sc_robot, *d_sc_key;
+    void *h_sc; size_t h_sc_bytes;
 };
 
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -377,7 +381,8 @@ extern "C" void rda_destroy(rda_handle *H)
     Dev &d = H->d;
     void *ptrs[] = { d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
                      d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
-                     H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info };
+                     H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
+                     H->d_sc_kind, H->d_sc_nvert, H->d_sc_sel, H->d_sc_bad, H->d_sc_geom, H->d_sc_vel, H->d_sc_robot, H->d_sc_key };
     for (void *p : ptrs) dev_free(p);
     if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
     if (H->h_stage_b) (void)hipHostFree(H->h_stage_b);
@@ -385,6 +390,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->h_step) (void)hipHostFree(H->h_step);
     if (H->h_out) (void)hipHostFree(H->h_out);
     if (H->h_info) (void)hipHostFree(H->h_info);
+    if (H->h_sc) (void)hipHostFree(H->h_sc);
     for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(H->stream);
     delete H;
@@ -435,6 +441,92 @@ extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, c
     return RDA_OK;
 }
 
+// ---- device-side obstacle pipeline -----------------------------------------------------------------------------
+static int scene_reserve(rda_handle *H, int n)
+{
+    const size_t E = H->d.c.E;
+    if (n > H->sc_cap) {
+        dev_free(H->d_sc_kind); dev_free(H->d_sc_nvert); dev_free(H->d_sc_sel); dev_free(H->d_sc_geom); dev_free(H->d_sc_vel); dev_free(H->d_sc_key);
+        int cap = n + n / 2 + 16, rc = 0;
+        rc |= dalloc(&H->d_sc_kind, (size_t)cap); rc |= dalloc(&H->d_sc_nvert, (size_t)cap); rc |= dalloc(&H->d_sc_sel, (size_t)cap);
+        rc |= dalloc(&H->d_sc_geom, (size_t)cap * E * 2); rc |= dalloc(&H->d_sc_vel, (size_t)cap * 2); rc |= dalloc(&H->d_sc_key, (size_t)cap);
+        if (rc) return RDA_ERR_HIP;
+        H->sc_cap = cap;
+    }
+    if (!H->d_sc_robot) { if (dalloc(&H->d_sc_robot, (size_t)2) || dalloc(&H->d_sc_bad, (size_t)1)) return RDA_ERR_HIP; }
+    const size_t need = (size_t)n * (2 * sizeof(int) + (E * 2 + 2) * sizeof(double)) + 2 * sizeof(double);
+    if (need > H->h_sc_bytes) {
+        if (H->h_sc) (void)hipHostFree(H->h_sc);
+        H->h_sc = nullptr; H->h_sc_bytes = 0;
+        HIPCHK(hipHostMalloc(&H->h_sc, need * 2));
+        H->h_sc_bytes = need * 2;
+    }
+    return RDA_OK;
+}
+
+extern "C" int rda_upload_scene(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                                const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex)
+{
+    if (!H) return RDA_ERR_ARG;
+    Dev &d = H->d;
+    if (n_nonconvex) *n_nonconvex = 0;
+    if (n <= 0) { d.obstacle_num = 0; return RDA_OK; }           // nothing written: stale A, b stay (rda_solver.py:485)
+    if (!kind || !nvert || !geom || !vel || (order && !robot_xy)) return RDA_ERR_ARG;
+    const int E = d.c.E, T = d.c.T, N = d.c.N;
+    bool any_moving = false;
+    for (int i = 0; i < n; ++i) {
+        if (kind[i] == 1) { if (E < 3) return RDA_ERR_UNSUPPORTED; }
+        else if (kind[i] != 0 || nvert[i] < 0 || nvert[i] > E) return RDA_ERR_ARG;
+        any_moving = any_moving || sqrt(vel[2 * i] * vel[2 * i] + vel[2 * i + 1] * vel[2 * i + 1]) > 0.01;
+    }
+    int rc = scene_reserve(H, n);
+    if (rc != RDA_OK) return rc;
+    // one pinned staging block -> four device arrays
+    char *hp = (char *)H->h_sc;
+    double *hg = (double *)hp; memcpy(hg, geom, (size_t)n * E * 2 * sizeof(double)); hp += (size_t)n * E * 2 * sizeof(double);
+    double *hv = (double *)hp; memcpy(hv, vel, (size_t)n * 2 * sizeof(double)); hp += (size_t)n * 2 * sizeof(double);
+    double *hr = (double *)hp; hr[0] = robot_xy ? robot_xy[0] : 0; hr[1] = robot_xy ? robot_xy[1] : 0; hp += 2 * sizeof(double);
+    int *hk = (int *)hp; memcpy(hk, kind, (size_t)n * sizeof(int)); hp += (size_t)n * sizeof(int);
+    int *hn = (int *)hp; memcpy(hn, nvert, (size_t)n * sizeof(int));
+    HIPCHK(hipMemcpyAsync(H->d_sc_geom, hg, (size_t)n * E * 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(H->d_sc_vel, hv, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(H->d_sc_robot, hr, 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(H->d_sc_kind, hk, (size_t)n * sizeof(int), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(H->d_sc_nvert, hn, (size_t)n * sizeof(int), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemsetAsync(H->d_sc_bad, 0, sizeof(int), H->stream));
+    scene::Args a;
+    a.n = n; a.N = N; a.E = E; a.T = T; a.nt = any_moving ? T + 1 : 1; a.order = order; a.dt = d.c.dt;
+    a.kind = H->d_sc_kind; a.nvert = H->d_sc_nvert; a.geom = H->d_sc_geom; a.vel = H->d_sc_vel; a.robot = H->d_sc_robot;
+    a.key = H->d_sc_key; a.sel = H->d_sc_sel; a.A = d.A; a.b = d.b; a.cone = d.cone; a.nonconvex = H->d_sc_bad;
+    hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
+    hipLaunchKernelGGL(scene::k_rank, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
+    hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, H->stream, a);
+    HIPCHK(hipGetLastError());
+    d.nt = a.nt; d.obstacle_num = N;
+    if (n_nonconvex) {
+        HIPCHK(hipMemcpyAsync(H->h_sc, H->d_sc_bad, sizeof(int), hipMemcpyDeviceToHost, H->stream));
+        HIPCHK(hipStreamSynchronize(H->stream));
+        *n_nonconvex = *(int *)H->h_sc;
+    } else {
+        HIPCHK(hipStreamSynchronize(H->stream));                  // the staging block is reused by the next call
+    }
+    return RDA_OK;
+}
+
+// test hook: the staged obstacle slots as the solver sees them
+extern "C" int rda_get_obstacles(rda_handle *H, double *A, double *b, int32_t *cone, int32_t *nt)
+{
+    if (!H || !A || !b || !cone || !nt) return RDA_ERR_ARG;
+    const Dev &d = H->d;
+    const size_t N = d.c.N, E = d.c.E;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(A, d.A, N * d.nt * E * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b, d.b, N * d.nt * E * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cone, d.cone, N * sizeof(int), hipMemcpyDeviceToHost));
+    *nt = d.nt;
+    return RDA_OK;
+}
+
 static hipEvent_t next_event(rda_handle *H, int which)
 {
     if (H->ev_used[which] == H->ev[which].size()) { hipEvent_t e; (void)hipEventCreate(&e); H->ev[which].push_back(e); }
@@ -466,21 +558,18 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
     return RDA_OK;
 }
 
-extern "C" int rda_step(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s,
-                        double ref_speed, int n_obs, const double *A, const double *b, const int32_t *cone,
-                        int per_t, double *out_u, double *out_s, rda_info *info)
+// nominal / reference in, ADMM loop, control / state / info out (host buffers, synchronous)
+static int step_common(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed,
+                       double *out_u, double *out_s, rda_info *info)
 {
-    if (!H || !nom_s || !nom_u || !ref_s || !out_u || !out_s) return RDA_ERR_ARG;
     const size_t T = H->d.c.T;
-    int rc = rda_upload_obstacles(H, n_obs, A, b, cone, per_t);
-    if (rc != RDA_OK) return rc;
     const size_t ns = 3 * (T + 1), nu = 2 * T;
     memcpy(H->h_step, nom_s, ns * sizeof(double));
     memcpy(H->h_step + ns, nom_u, nu * sizeof(double));
     memcpy(H->h_step + ns + nu, ref_s, ns * sizeof(double));
     H->h_step[ns + nu + ns] = ref_speed;
     HIPCHK(hipMemcpyAsync(H->d_step, H->h_step, (2 * ns + nu + 1) * sizeof(double), hipMemcpyHostToDevice, H->stream));
-    rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
+    int rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) return rc;
     HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
@@ -490,6 +579,26 @@ extern "C" int rda_step(rda_handle *H, const double *nom_s, const double *nom_u,
     memcpy(out_s, H->h_out + nu, ns * sizeof(double));
     if (info) *info = *H->h_info;
     return RDA_OK;
+}
+
+extern "C" int rda_step(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s,
+                        double ref_speed, int n_obs, const double *A, const double *b, const int32_t *cone,
+                        int per_t, double *out_u, double *out_s, rda_info *info)
+{
+    if (!H || !nom_s || !nom_u || !ref_s || !out_u || !out_s) return RDA_ERR_ARG;
+    int rc = rda_upload_obstacles(H, n_obs, A, b, cone, per_t);
+    if (rc != RDA_OK) return rc;
+    return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info);
+}
+
+extern "C" int rda_step_scene(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed,
+                              int n, const int32_t *kind, const int32_t *nvert, const double *geom, const double *vel,
+                              const double *robot_xy, int order, double *out_u, double *out_s, rda_info *info)
+{
+    if (!H || !nom_s || !nom_u || !ref_s || !out_u || !out_s) return RDA_ERR_ARG;
+    int rc = rda_upload_scene(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr);
+    if (rc != RDA_OK) return rc;
+    return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info);
 }
 
 extern "C" int rda_upload_trace(rda_handle *H, int K, const double *nom_s, const double *nom_u, const double *ref_s, const double *ref_speed)

@@ -33,7 +33,10 @@ class MPC:
         self.state = np.zeros((3, 1))
         self.cur_index = 0
         self.ref_path = ref_path
-        solver_kwargs = {k: v for k, v in kwargs.items() if k != "init_vel"}
+        # extension (not in the reference): device_obstacles=True lets the accelerated backend convert, predict, sort
+        # and stage the raw obstacles on the GPU (rda_step_scene) instead of the host code below; same staged values
+        self.device_obstacles = bool(kwargs.get("device_obstacles", True))
+        solver_kwargs = {k: v for k, v in kwargs.items() if k not in ("init_vel", "device_obstacles")}
         self.rda = RDA_solver(receding, car_tuple, max_edge_num, max_obs_num, iter_num=iter_num,
                               step_time=sample_time, process_num=process_num, accelerated=accelerated,
                               time_print=time_print, **solver_kwargs)
@@ -60,13 +63,20 @@ class MPC:
         state_pre_array, ref_traj_list, self.cur_index = self.pre_process(
             state, cur_ref_path, self.cur_index, ref_speed, **kwargs)
 
-        if not self.rda_obstacle:
-            rda_obs_list = self.convert_rda_obstacle(obstacle_list, state, self.obstacle_order)
+        scene = None
+        if not self.rda_obstacle and self.device_obstacles and self.rda.has_scene:
+            scene = self.rda.flatten_scene(obstacle_list)
+        if scene is not None:
+            u_opt_array, info = self.rda.iterative_solve_scene(
+                state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, scene,
+                np.asarray(state, float)[0:2], self.obstacle_order, **kwargs)
         else:
-            rda_obs_list = obstacle_list
-
-        u_opt_array, info = self.rda.iterative_solve(
-            state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, rda_obs_list, **kwargs)
+            if not self.rda_obstacle:
+                rda_obs_list = self.convert_rda_obstacle(obstacle_list, state, self.obstacle_order)
+            else:
+                rda_obs_list = obstacle_list
+            u_opt_array, info = self.rda.iterative_solve(
+                state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, rda_obs_list, **kwargs)
 
         if self.cur_index >= len(cur_ref_path) - self.goal_index_threshold:
             if self.enable_reverse:

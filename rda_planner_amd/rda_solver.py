@@ -155,6 +155,73 @@ class RDA_solver:
             cone[i] = 0 if o.cone_type == "Rpositive" else 1
         return use, A, b, cone, int(per_t)
 
+    # ---- caller-side obstacle pipeline on the device ------------------------------------------
+    @property
+    def has_scene(self):
+        """True when the backend converts raw obstacles (vertices / centre+radius / velocity) on the device"""
+        return bool(getattr(self._be.api, "has_scene", False))
+
+    def flatten_scene(self, obstacle_list):
+        """raw obstacle objects (`.cone_type`, `.vertex` 2xk | `.center`, `.radius`, `.velocity`; the attributes the
+        reference's MPC.convert_rda_obstacle reads, mpc.py:192-203) -> flat arrays for rda_upload_scene, or None if
+        an object cannot be expressed (then the caller falls back to the host conversion)."""
+        n, E = len(obstacle_list), self.max_edge_num
+        kind = np.zeros(n, np.int32)
+        nvert = np.zeros(n, np.int32)
+        geom = np.zeros((n, E, 2))
+        vel = np.zeros((n, 2))
+        keep = 0
+        for o in obstacle_list:
+            ct = o.cone_type
+            if ct == "norm2":
+                if E < 3:
+                    return None
+                kind[keep] = 1
+                c = np.asarray(o.center, float).ravel()
+                geom[keep, 0, 0], geom[keep, 0, 1], geom[keep, 1, 0] = c[0], c[1], float(o.radius)
+            elif ct == "Rpositive":
+                v = np.asarray(o.vertex, float)
+                k = v.shape[1]
+                if k > E:
+                    return None
+                nvert[keep] = k
+                geom[keep, :k, 0], geom[keep, :k, 1] = v[0], v[1]
+            else:
+                continue                                   # the reference silently skips other cone types (mpc.py:196-203)
+            w = np.asarray(o.velocity, float).ravel()
+            vel[keep, 0], vel[keep, 1] = w[0], w[1]
+            keep += 1
+        return keep, kind[:keep], nvert[:keep], geom[:keep], vel[:keep]
+
+    def iterative_solve_scene(self, nom_s, nom_u, ref_states, ref_speed, scene, robot_xy, order, **kwargs):
+        """`iterative_solve` fed with a flattened raw scene (see `flatten_scene`): conversion to half-spaces, the
+        constant-velocity prediction, distance ordering, truncation and padding all run on the device."""
+        T = self.T
+        start = time.time()
+        n, kind, nvert, geom, vel = scene
+        ref = f64(np.hstack(ref_states)[0:3, :], (3, T + 1))
+        nom_s = f64(nom_s, (3, T + 1))
+        nom_u = f64(nom_u, (2, T))
+        rob = f64(np.asarray(robot_xy, float).ravel()[0:2])
+        out_u = np.zeros((2, T))
+        out_s = np.zeros((3, T + 1))
+        info_c = Info()
+        kind = np.ascontiguousarray(kind, np.int32); nvert = np.ascontiguousarray(nvert, np.int32)
+        geom = f64(geom); vel = f64(vel)
+        rc = self._be.api.step_scene(self._be.handle, dptr(nom_s), dptr(nom_u), dptr(ref), float(ref_speed), int(n),
+                                     iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(rob), int(bool(order)),
+                                     dptr(out_u), dptr(out_s), C.byref(info_c))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_step_scene failed with code {rc}")
+        if info_c.su_status and self.time_print:
+            print("No update of state and control vector")        # reference :699
+        opt_state_list = [out_s[:, i:i + 1].copy() for i in range(T + 1)]
+        info = {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
+                "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
+                "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
+                "su_ipm_iters": info_c.su_ipm_iters}
+        return out_u, info
+
     # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
     def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list, **kwargs):
         T = self.T
