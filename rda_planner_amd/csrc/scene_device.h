@@ -5,8 +5,8 @@
 //   gen_inequal_global, is_convex_and_ordered, cross_product    mpc.py:492-549
 //   RDA_solver.assign_obstacle_parameter (truncate / pad / zero rows, per-t replication)   rda_solver.py:483-526
 // - as three small kernels that write the solver's obstacle slots A [N][nt][E][2], b [N][nt][E], cone [N] directly.
-// The arithmetic reproduces the numpy expressions operation by operation (explicit round-to-nearest mul/add, no FMA
-// contraction), so the slots are BIT-IDENTICAL to what the Python caller stages (tests/test_gpu_scene.py).
+// The arithmetic reproduces the numpy expressions operation by operation (FMA contraction is switched off in these
+// kernels), so the slots are BIT-IDENTICAL to what the Python caller stages (tests/test_gpu_scene.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -29,6 +29,7 @@ struct Args {
 // distance key of one obstacle: rda_obs_distance, mpc.py:214-218 (circle: centre distance; polygon: nearest vertex)
 __global__ void k_keys(Args a)
 {
+#pragma clang fp contract(off)        // numpy does not fuse: keep every product and sum separately rounded
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (!a.order) { a.key[i] = (double)i; return; }
@@ -62,6 +63,7 @@ __global__ void k_rank(Args a)
 // one thread per (slot, time slot): half-space form of the selected obstacle at time t
 __global__ void k_build(Args a)
 {
+#pragma clang fp contract(off)
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.N * a.nt) return;
     const int s = w / a.nt, t = w % a.nt;
