@@ -36,13 +36,13 @@ __global__ void k_keys(Args a)
     const double x = a.robot[0], y = a.robot[1];
     const double *g = a.geom + (size_t)i * a.E * 2;
     if (a.kind[i] == 1) {
-        double dx = __dsub_rn(x, g[0]), dy = __dsub_rn(y, g[1]);
-        a.key[i] = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+        double dx = x - g[0], dy = y - g[1];
+        a.key[i] = sqrt(dx * dx + dy * dy);
     } else {
         double best = INFINITY;
         for (int j = 0; j < a.nvert[i]; ++j) {
-            double dx = __dsub_rn(x, g[2 * j]), dy = __dsub_rn(y, g[2 * j + 1]);
-            double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+            double dx = x - g[2 * j], dy = y - g[2 * j + 1];
+            double d = sqrt(dx * dx + dy * dy);
             if (d < best) best = d;
         }
         a.key[i] = best;
@@ -74,27 +74,26 @@ __global__ void k_build(Args a)
     double *A = a.A + ((size_t)s * a.nt + t) * E * 2, *b = a.b + ((size_t)s * a.nt + t) * E;
     for (int e = 0; e < E; ++e) { A[2 * e] = 0; A[2 * e + 1] = 0; b[e] = 0; }
     const double vx = a.vel[2 * i], vy = a.vel[2 * i + 1];
-    const bool moving = sqrt(__dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy))) > 0.01;     // mpc.py:443,462
-    const double tt = __dmul_rn((double)t, a.dt);
-    const double sx = moving ? __dmul_rn(vx, tt) : 0.0, sy = moving ? __dmul_rn(vy, tt) : 0.0;
+    const bool moving = sqrt(vx * vx + vy * vy) > 0.01;     // mpc.py:443,462
+    const double tt = (double)t * a.dt;
+    const double sx = moving ? vx * tt : 0.0, sy = moving ? vy * tt : 0.0;
     if (a.kind[i] == 1) {
         if (t == 0) a.cone[s] = 1;
         A[0] = 1; A[3] = 1;                                        // [[1,0],[0,1],[0,0]]   mpc.py:441
-        b[0] = moving ? __dadd_rn(g[0], sx) : g[0];
-        b[1] = moving ? __dadd_rn(g[1], sy) : g[1];
+        b[0] = moving ? g[0] + sx : g[0];
+        b[1] = moving ? g[1] + sy : g[1];
         b[2] = -g[2];
         return;
     }
     if (t == 0) a.cone[s] = 0;
     const int k = a.nvert[i];
     double px[16], py[16];
-    for (int j = 0; j < k; ++j) { px[j] = moving ? __dadd_rn(g[2 * j], sx) : g[2 * j]; py[j] = moving ? __dadd_rn(g[2 * j + 1], sy) : g[2 * j + 1]; }
+    for (int j = 0; j < k; ++j) { px[j] = moving ? g[2 * j] + sx : g[2 * j]; py[j] = moving ? g[2 * j + 1] + sy : g[2 * j + 1]; }
     // is_convex_and_ordered, mpc.py:527-549
     int direction = 0; bool convex = k >= 3;
     for (int j = 0; j < k && convex; ++j) {
         int j1 = (j + 1) % k, j2 = (j + 2) % k;
-        double cr = __dsub_rn(__dmul_rn(__dsub_rn(px[j1], px[j]), __dsub_rn(py[j2], py[j])),
-                              __dmul_rn(__dsub_rn(py[j1], py[j]), __dsub_rn(px[j2], px[j])));
+        double cr = (px[j1] - px[j]) * (py[j2] - py[j]) - (py[j1] - py[j]) * (px[j2] - px[j]);
         if (cr != 0) {
             if (direction == 0) direction = cr > 0 ? 1 : -1;
             else if ((cr > 0) != (direction > 0)) convex = false;
@@ -104,10 +103,10 @@ __global__ void k_build(Args a)
     const bool cw = convex && direction <= 0;                      // order == 'CW' (direction 0 also reports CW), :500-501
     for (int j = 0; j < k; ++j) {
         int c0 = cw ? k - 1 - j : j, c1 = cw ? (k - 1 - ((j + 1) % k)) : (j + 1) % k;
-        double ex = __dsub_rn(px[c1], px[c0]), ey = __dsub_rn(py[c1], py[c0]);
+        double ex = px[c1] - px[c0], ey = py[c1] - py[c0];
         double a0 = ey, a1 = -ex;                                  // A = [edge_y, -edge_x]   :505-506
         A[2 * j] = a0; A[2 * j + 1] = a1;
-        b[j] = __dadd_rn(__dmul_rn(a0, px[c0]), __dmul_rn(a1, py[c0]));   // sum(A * cur, axis=1)   :507
+        b[j] = a0 * px[c0] + a1 * py[c0];   // sum(A * cur, axis=1)   :507
     }
 }
 
