@@ -50,7 +50,8 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=No
     from rda_planner_amd.mpc import MPC
     from rda_planner_amd import scenarios as sc
     extra = {"_backend": backend} if backend is not None else {}
-    mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw, **extra)
+    # host-side obstacle staging here: the spy below needs the staged arrays for the device-resident replay
+    mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, device_obstacles=False, **kw, **extra)
     if post_init is not None:
         post_init(mpc.rda)
     T = kw["receding"]
@@ -141,6 +142,23 @@ def main():
     # order of the first step frozen (static scene), i.e. obstacle_order only affects slot binding
     kw_rec = dict(kw, obstacle_order=False)
     trace, staged, mpc_rec = record_trace(car_t, path, obstacles, kw_rec, W + K, post_init=make_sharded)
+    # the same closed loop with the caller-side obstacle pipeline on the device (rda_step_scene)
+    cl_dev = None
+    if rank == 0 and not shard:
+        from rda_planner_amd.mpc import MPC
+        from rda_planner_amd import scenarios as sc
+        mpc_d = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw_rec)
+        if mpc_d.rda.has_scene:
+            st = path[0].copy().reshape(3, 1)
+            nd = min(W + K, 100)
+            du = 0.0
+            t0 = time.perf_counter()
+            for k in range(nd):
+                u, _ = mpc_d.control(st, 4.0, list(obstacles))
+                du = max(du, float(np.abs(u - trace["u"][k]).max()))
+                st = sc.kinematic_step(st, u, car_t, 0.1)
+            cl_dev = {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": du}
+        del mpc_d
 
     # ---- device-resident replay -------------------------------------------------------------------
     from rda_planner_amd.rda_solver import RDA_solver
@@ -259,6 +277,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else (f"one ego, obstacles sharded {world}-way, RCCL all-gather per ADMM iteration" if shard else f"{world} independent ego replicas (no collective)")},
         "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
         "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
+        "closed_loop_device_obstacles": cl_dev,
         "instrumented_ms_per_step": round(elapsed / K * 1e3, 5),
         "roofline": dominant, "roofline_secondary": secondary,
     }
