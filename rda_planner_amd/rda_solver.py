@@ -165,33 +165,32 @@ class RDA_solver:
         """raw obstacle objects (`.cone_type`, `.vertex` 2xk | `.center`, `.radius`, `.velocity`; the attributes the
         reference's MPC.convert_rda_obstacle reads, mpc.py:192-203) -> flat arrays for rda_upload_scene, or None if
         an object cannot be expressed (then the caller falls back to the host conversion)."""
-        n, E = len(obstacle_list), self.max_edge_num
-        kind = np.zeros(n, np.int32)
+        E = self.max_edge_num
+        objs = [o for o in obstacle_list if o.cone_type in ("norm2", "Rpositive")]   # other cone types are skipped (mpc.py:196-203)
+        n = len(objs)
+        kind = np.fromiter((o.cone_type == "norm2" for o in objs), np.int32, n)
         nvert = np.zeros(n, np.int32)
         geom = np.zeros((n, E, 2))
-        vel = np.zeros((n, 2))
-        keep = 0
-        for o in obstacle_list:
-            ct = o.cone_type
-            if ct == "norm2":
-                if E < 3:
-                    return None
-                kind[keep] = 1
-                c = np.asarray(o.center, float).ravel()
-                geom[keep, 0, 0], geom[keep, 0, 1], geom[keep, 1, 0] = c[0], c[1], float(o.radius)
-            elif ct == "Rpositive":
-                v = np.asarray(o.vertex, float)
-                k = v.shape[1]
-                if k > E:
-                    return None
-                nvert[keep] = k
-                geom[keep, :k, 0], geom[keep, :k, 1] = v[0], v[1]
-            else:
-                continue                                   # the reference silently skips other cone types (mpc.py:196-203)
-            w = np.asarray(o.velocity, float).ravel()
-            vel[keep, 0], vel[keep, 1] = w[0], w[1]
-            keep += 1
-        return keep, kind[:keep], nvert[:keep], geom[:keep], vel[:keep]
+        if n == 0:
+            return 0, kind, nvert, geom, np.zeros((0, 2))
+        vel = np.asarray([o.velocity for o in objs], float).reshape(n, -1)[:, 0:2]
+        circ = np.flatnonzero(kind == 1)
+        if circ.size:
+            if E < 3:
+                return None
+            geom[circ, 0, :] = np.asarray([objs[i].center for i in circ], float).reshape(circ.size, -1)[:, 0:2]
+            geom[circ, 1, 0] = [float(objs[i].radius) for i in circ]
+        poly = np.flatnonzero(kind == 0)
+        if poly.size:
+            ks = np.fromiter((np.shape(objs[i].vertex)[1] for i in poly), np.int64, poly.size)
+            if ks.max() > E:
+                return None
+            nvert[poly] = ks
+            for k in np.unique(ks):                                   # one vectorised fill per vertex count
+                idx = poly[ks == k]
+                V = np.asarray([objs[i].vertex for i in idx], float)[:, 0:2, :]           # (m, 2, k)
+                geom[idx, :k, :] = V.transpose(0, 2, 1)
+        return n, kind, nvert, geom, np.ascontiguousarray(vel)
 
     def iterative_solve_scene(self, nom_s, nom_u, ref_states, ref_speed, scene, robot_xy, order, **kwargs):
         """`iterative_solve` fed with a flattened raw scene (see `flatten_scene`): conversion to half-spaces, the
