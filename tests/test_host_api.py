@@ -178,3 +178,28 @@ def test_closed_loop_path_track_no_collision_and_golden():
             arrived = True
             break
     assert arrived and minc > 0.05, (arrived, minc)
+
+
+def test_flatten_scene_layout():
+    """raw obstacle objects -> the flat arrays rda_upload_scene takes (include/rda_hip.h); unknown cone types are
+    skipped like the reference's convert_rda_obstacle does (mpc.py:196-203); too many vertices -> host fallback"""
+    car_t = sc.rectangle_robot()
+    path = sc.line_path([0, 0, 0], [10, 0, 0])
+    mpc = MPC(car_t, path, receding=5, max_edge_num=4, max_obs_num=3, _backend=oracle_backend)
+    assert not mpc.rda.has_scene                                   # the CPU oracle has no device pipeline
+    tri = sc.regular_polygon(3.0, 1.0, 3, 0.5, 0.2, velocity=(0.5, -0.25))
+    quad = sc.box(6.0, -1.0, 2.0, 1.0, 0.3)
+    cir = sc.circle(8.0, 2.0, 0.7, velocity=(0.0, 0.1))
+    odd = sc.Obstacle(None, None, None, "something_else", np.zeros((2, 1)))
+    n, kind, nvert, geom, vel = mpc.rda.flatten_scene([tri, odd, cir, quad])
+    assert n == 3 and kind.tolist() == [0, 1, 0] and nvert.tolist() == [3, 0, 4]
+    assert np.array_equal(geom[0, :3], tri.vertex.T) and np.array_equal(geom[0, 3], [0, 0])
+    assert np.array_equal(geom[1, 0], cir.center.ravel()) and geom[1, 1, 0] == 0.7
+    assert np.array_equal(geom[2], quad.vertex.T)
+    assert np.array_equal(vel, [[0.5, -0.25], [0.0, 0.1], [0.0, 0.0]])
+    penta = sc.regular_polygon(0, 0, 5, 1.0, 0.0)
+    assert mpc.rda.flatten_scene([penta]) is None                  # 5 vertices > max_edge_num = 4
+    assert mpc.rda.flatten_scene([])[0] == 0
+    # and the MPC runs through the host conversion with this backend
+    u, info = mpc.control(np.zeros((3, 1)), 2.0, [tri, cir, quad])
+    assert np.isfinite(u).all()
