@@ -111,13 +111,20 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        oversub = ndev < world                     # fewer GPUs than ranks (plumbing test on a 1-GPU box): gloo + shared device
+        dev_index = local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
+        if oversub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        tdev = "cpu" if oversub else "cuda"
 
     from rda_planner_amd._lib import hip_api
     from rda_planner_amd._capi import Info, dptr, iptr
     api = hip_api()
-    api.lib.rda_set_device(local_rank)
+    api.lib.rda_set_device(dev_index if world > 1 else local_rank)
 
     K, W = args.steps, args.warmup
     shard = args.mode == "shard" and world > 1
@@ -187,7 +194,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -221,7 +228,7 @@ def main():
     elapsed2 = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed2], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed2], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed2 = float(tt.item())
 
