@@ -299,3 +299,47 @@ def test_obstacle_shards_rccl_two_gpus():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29611", os.path.join(root, "tools", "rccl_shard_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_full_size_step_properties():
+    """BASELINE scaling point T=20, N=2000 (40 000 sub-problems per ADMM iteration), where the oracle is too slow to
+    be the checker for many steps: size-independent properties of one solver step instead.
+      * slot permutation: the su-problem sums over obstacles, the LamMuZ problems are per obstacle -> permuting the
+        obstacle slots leaves the control unchanged (up to the summation order of the hinge sums)
+      * padding (quirk Q3, rda_solver.py:488-490): n < N obstacles == the same list padded with copies of the last one
+      * zero obstacles: pure tracking step, dual side skipped (:625)
+      * one step against the oracle (5 ADMM iterations' worth of work, ~seconds on the CPU)"""
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot()
+    path = sc.line_path([5, 25, 0], [45, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    obstacles = sc.scene_polygons(2000, lo=(5, 5), hi=(60, 45), keep_clear=clear, clear_radius=2.5)
+    kw = dict(receding=20, iter_num=3, max_edge_num=4, max_obs_num=2000, obstacle_order=False, time_print=False)
+    state = path[0].copy().reshape(3, 1)
+
+    def first_controls(obs, steps=3, backend=None, **over):
+        extra = {"_backend": backend} if backend is not None else {}
+        mpc = MPC(car_t, [p.copy() for p in path], **dict(kw, **over), **extra)
+        st, us = state.copy(), []
+        for _ in range(steps):
+            u, info = mpc.control(st, 4.0, list(obs))
+            assert info["status"] == 0 and 1 <= info["iters"] <= 3
+            us.append(u.ravel().copy())
+            st = sc.kinematic_step(st, u, car_t, 0.1)
+        return np.array(us), mpc
+
+    base, mpc0 = first_controls(obstacles)
+    perm = np.random.default_rng(3).permutation(2000)
+    shuf, _ = first_controls([obstacles[i] for i in perm])
+    assert np.abs(base - shuf).max() < 1e-7, np.abs(base - shuf).max()
+    short = obstacles[:1500]
+    padded, _ = first_controls(short + [short[-1]] * 500)
+    auto, _ = first_controls(short)
+    assert np.array_equal(padded, auto)
+    free, _ = first_controls([])
+    assert np.isfinite(free).all() and np.abs(free - base).max() > 0          # the obstacles do act on the control
+    lam = mpc0.rda.get_state()["lam"]
+    assert (lam >= 0).all() and np.isfinite(lam).all()
+    ref, _ = first_controls(obstacles, steps=1, backend=oracle_backend)
+    assert np.abs(ref[0] - base[0]).max() < 1e-6, np.abs(ref[0] - base[0]).max()
