@@ -216,7 +216,7 @@ __device__ __forceinline__ void decode_pair(int k, int n, int &i1, int &i2)
     i2 = i1 + 1 + k;
 }
 
-struct Params { int E, R; int norm2; double px, py, cs, sn, xi0, xi1, kappa0, ro2, delta; };
+struct Params { int E, R; int norm2; double px, py, cs, sn, xi0, xi1, kappa0, ro2, delta; long long *prof = nullptr; };
 
 // sign feasibility, clamping and cost of one candidate point: the hinge-inactive MODEL cost in pass ic = 0
 // (a lower bound of the true cost, exact for m >= 0), the TRUE cost in pass ic = 1
@@ -364,11 +364,14 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
     best.cost = INFINITY; best.id = 0x7fffffff;
     best.m = 0; best.H0 = 0; best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
     best.l1 = best.l2 = best.g1 = best.g2 = 0;
+    long long tprev = P.prof ? clock64() : 0;
+    auto mark = [&](int k) { if (P.prof && lane == 0) { long long now = clock64(); P.prof[k] += now - tprev; tprev = now; } };
     // Rule T3.  Pass 1 (ic = 0): the hinge-inactive candidates are ranked by the cost of the hinge-inactive MODEL
     // (-delta*m + ro2/2|H|^2: a lower bound of the true cost, exact for m >= 0); if its minimiser c0 has m >= 0 it is
     // the global optimum.  Otherwise pass 2 (ic = 1): the hinge-active candidates and c0 compete on the TRUE cost.
     // Exact ties go to the lowest id = 2*(il*nm+im)+ic.
     for (int ic = 0; ic < 2; ++ic) {
+        int itn = 0;
         for (int c = lane; c < half; c += 64) {
             int im = c % nm, il = c / nm;
             Sol s;
@@ -376,6 +379,7 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
                 s.id = 2 * c + ic;
                 if (s.cost < best.cost || (s.cost == best.cost && s.id < best.id)) best = s;
             }
+            mark(1 + 2 * ic + (itn < 1 ? itn : 1)); ++itn;
         }
         // wave arg-min on (cost, id)
         double bc = best.cost; int bid = best.id;
@@ -392,6 +396,7 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
         best.j1 = __shfl(best.j1, src, 64); best.j2 = __shfl(best.j2, src, 64);
         best.l1 = __shfl(best.l1, src, 64); best.l2 = __shfl(best.l2, src, 64);
         best.g1 = __shfl(best.g1, src, 64); best.g2 = __shfl(best.g2, src, 64);
+        mark(5 + ic);
         if (best.m >= 0) break;                 // wave-uniform after the broadcast
         if (ic == 0) best.cost += 0.5 * best.m * best.m;      // c0: model cost -> true cost (m < 0 here)
     }

@@ -208,11 +208,12 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
 __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int *cone,
                                                       const double *p, const double *phi, const double *G, const double *h,
                                                       const double *xi, const double *zeta, const double *dbar, double ro2,
-                                                      double delta, int accelerated, double *lam, double *mu, double *z, double *cmh)
+                                                      double delta, int accelerated, double *lam, double *mu, double *z, double *cmh, long long *prof)
 {
     __shared__ lmz::WaveLDS wl[4];
     __shared__ lmz::RobotLDS rb;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long t_begin = prof ? clock64() : 0;
     if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = h[threadIdx.x - 64];
     const int w = blockIdx.x * 4 + wv;
@@ -227,8 +228,11 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
     P.E = E; P.R = R; P.norm2 = cone[k]; P.px = p[2 * k]; P.py = p[2 * k + 1];
     P.cs = cos(phi[k]); P.sn = sin(phi[k]); P.xi0 = xi[2 * k]; P.xi1 = xi[2 * k + 1];
     P.kappa0 = zeta[k] - dbar[k]; P.ro2 = ro2; P.delta = delta;
+    P.prof = (prof && w == 0) ? prof : nullptr;               // wave 0 of the batch reports its phase cycles
+    if (P.prof && lane == 0) prof[0] += clock64() - t_begin;
     lmz::Sol best;
     lmz::solve_wave(W, rb, P, lane, best);
+    if (P.prof && lane == 0) prof[7] += clock64() - t_begin;
     if (lane < E) lam[(size_t)k * E + lane] = lmz::lam_of(best, P.norm2, lane);
     else if (lane < E + R) mu[(size_t)k * R + lane - E] = lmz::mu_of(best, lane - E);
     else if (lane == E + R) {
@@ -839,10 +843,18 @@ extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const doub
                  {(void **)&dzeta, zeta, sB * 8}, {(void **)&ddbar, dbar, sB * 8} };
     for (auto &c : ins) { HIPCHK(hipMalloc(c.dst, c.bytes)); HIPCHK(hipMemcpy(*c.dst, c.src, c.bytes, hipMemcpyHostToDevice)); }
     HIPCHK(hipMalloc((void **)&dlam, sB * E * 8)); HIPCHK(hipMalloc((void **)&dmu, sB * R * 8)); HIPCHK(hipMalloc((void **)&dz, sB * 8)); HIPCHK(hipMalloc((void **)&dcmh, sB * 4 * 8));
+    long long *dprof = nullptr;
+    if (getenv("RDA_LMZ_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 8 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 8 * sizeof(long long))); }
     hipLaunchKernelGGL(k_lammuz_batch, dim3((B + 3) / 4), dim3(256), 0, 0, B, E, R, dA, db, dcone, dp, dphi, dG, dh, dxi, dzeta, ddbar,
-                       ro2, delta, accelerated, dlam, dmu, dz, dcmh);
+                       ro2, delta, accelerated, dlam, dmu, dz, dcmh, dprof);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    if (dprof) {
+        long long hp[8]; HIPCHK(hipMemcpy(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost));
+        fprintf(stderr, "lammuz prof (ticks, sub-problem 0): setup=%lld p1.it0=%lld p1.it1=%lld p2.it0=%lld p2.it1=%lld argmin1=%lld argmin2=%lld total=%lld\n",
+                hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
+        dev_free(dprof);
+    }
     HIPCHK(hipMemcpy(lam, dlam, sB * E * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(mu, dmu, sB * R * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(z, dz, sB * 8, hipMemcpyDeviceToHost));
     if (cmh) HIPCHK(hipMemcpy(cmh, dcmh, sB * 4 * 8, hipMemcpyDeviceToHost));
