@@ -111,6 +111,7 @@ struct Lds {
     double *cw, *cl, *rp, *rc, *dw, *dl;   // [T][NC]
     double *dy;                            // [T][8]
     double *pv, *red;                      // 8, NT
+    double *p0;                            // [2][T] reference positions of the hinge screening
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
@@ -121,14 +122,14 @@ struct Lds {
         Hb = p; part = p; p += (HB * T > 9 * NT ? HB * T : 9 * NT);    // part (phase 1) is dead before Hb is written (phase 3)
         Wn = p; p += WN * T; kk = p; p += 8 * T; vv = p; p += 8 * T;
         cw = p; p += NC * T; cl = p; p += NC * T; rp = p; p += NC * T; rc = p; p += NC * T; dw = p; p += NC * T; dl = p; p += NC * T;
-        dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT;
+        dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT; p0 = p; p += 2 * T;
     }
 };
 inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 3 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
-             + WN * T + 16 * T + 6 * NC * T + 8 * T + 8 + NT;
+             + WN * T + 16 * T + 6 * NC * T + 8 * T + 8 + NT + 2 * T;
     return n * sizeof(double);
 }
 
@@ -213,6 +214,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     // ---- load nominal, reference; linearise -------------------------------------------------
     for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; L.ref[i] = a.ref[i]; }
     for (int i = tid; i < 2 * T; i += NT) L.u[i] = a.in_u[i];
+    for (int i = tid; i < 2 * T; i += NT) L.p0[i] = a.in_s[(i / T) * (T + 1) + (i % T) + 1];      // nominal positions of stages 1..T
     __syncthreads();
     if (tid < T) {
         int t = tid;
@@ -229,28 +231,45 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
     __syncthreads();
-    // ---- rotation-consistency penalty -> scalar quadratic per stage --------------
+    // ---- rotation-consistency penalty -> scalar quadratic per stage, fused with the HINGE SCREENING:
+    // Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so an obstacle term whose margin at the nominal
+    // position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Each thread
+    // keeps a bit mask of the terms of ITS (stage, chunk) slice that may become active and only those are visited by
+    // the per-iteration hinge sums (same visiting order -> the sums are unchanged).  The assumption is verified on
+    // the converged iterate; if violated the iteration continues with all terms.  Excluded terms are inactive at the
+    // verified solution, so it satisfies the optimality conditions of the full problem.
+    constexpr int MW = 4;
+    constexpr double DELTA = 1.0;
+    unsigned long long amask[MW] = {0, 0, 0, 0};
+    const int KS = (a.Nloc + nch - 1) / nch;                    // terms per shard in one thread's slice
+    bool screened = c.accelerated && a.P * KS <= 64 * MW;
     {
         double q0 = 0, q1 = 0, q2 = 0;
         if (ract) {
             double cs = cos(L.phin[rt]), sn = sin(L.phin[rt]);
+            const double p0x = L.p0[rt], p0y = L.p0[T + rt];
             for (int r = 0; r < a.P; ++r) {
                 const size_t o = r * a.chunk + (size_t)rt * a.Nloc;
-                auto term = [&](double ax, double ay, double gx, double gy) {
+                int bit = r * KS;
+                auto term = [&](double ax, double ay, double gx, double gy, double cb) {
                     double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
                     double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
                     q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
+                    double margin = ax * p0x + ay * p0y - cb - c.max_sd;
+                    if (screened && !(margin > DELTA * sqrt(ax * ax + ay * ay))) amask[bit >> 6] |= 1ull << (bit & 63);
+                    ++bit;
                 };
-                const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o;
+                const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o, *pb = a.blam + o, *pe = a.ee + o;
                 int n = rc_;
                 for (; n + 7 * nch < a.Nloc; n += 8 * nch) {      // eight independent loads in flight per array
-                    double x[8], y[8], g[8], h[8];
+                    double x[8], y[8], g[8], h[8], cb[8], ce[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { x[k] = pax[n + k * nch]; y[k] = pay[n + k * nch]; g[k] = pgx[n + k * nch]; h[k] = pgy[n + k * nch]; }
+                    for (int k = 0; k < 8; ++k) { x[k] = pax[n + k * nch]; y[k] = pay[n + k * nch]; g[k] = pgx[n + k * nch]; h[k] = pgy[n + k * nch];
+                                                  cb[k] = pb[n + k * nch]; ce[k] = pe[n + k * nch]; }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) term(x[k], y[k], g[k], h[k]);
+                    for (int k = 0; k < 8; ++k) term(x[k], y[k], g[k], h[k], cb[k] + ce[k]);
                 }
-                for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n]);
+                for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n], pb[n] + pe[n]);
             }
         }
         L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
@@ -486,6 +505,25 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                     }
                 };
                 const int Nl = a.Nloc;
+                if (screened) {
+                    // visit only the terms that may be active, four loads in flight
+                    for (int w = 0; w < MW; ++w) {
+                        unsigned long long m = amask[w];
+                        while (m) {
+                            size_t off[4]; int cnt = 0;
+                            while (m && cnt < 4) {
+                                int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
+                                int r = a.P == 1 ? 0 : bit / KS, k = bit - r * KS;
+                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + rc_ + (size_t)k * nch;
+                            }
+                            double x[4], y[4], cb[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (q < cnt) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.blam[off[q]] + a.ee[off[q]]; }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (q < cnt) term(x[q], y[q], cb[q]);
+                        }
+                    }
+                } else
                 for (int r = 0; r < a.P; ++r) {
                     const size_t o = r * a.chunk + (size_t)rt * Nl;
                     const double *pax = a.ax + o, *pay = a.ay + o, *pb = a.blam + o, *pe = a.ee + o;
@@ -660,7 +698,15 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         }
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
-        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
+        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) {
+            if (screened) {        // the positions must have stayed within DELTA of the screening reference
+                double dv = 0;
+                if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
+                dv = block_reduce(dv, L.red, tid, true);
+                if (dv > DELTA) { screened = false; continue; }       // rare: go on with every term
+            }
+            status = 0; break;
+        }
         if (__syncthreads_or(fail ? 1 : 0)) { status = 2; break; }
         mark(5);
 
