@@ -272,6 +272,12 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n], pb[n] + pe[n]);
             }
         }
+        if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %
+            double cnt = 0;
+            for (int w = 0; w < MW; ++w) cnt += (double)__popcll(amask[w]);
+            cnt = block_reduce(cnt, L.red, tid, false);
+            if (cnt > 0.3 * (double)a.P * a.Nloc * T) screened = false;
+        }
         L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
         __syncthreads();
         if (tid < T) {
