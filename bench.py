@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--n-obs", type=int, default=200)
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--egos", type=int, default=8, help="extra leg: this many independent egos concurrently on one GPU (0/1 = skip)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="N>1: independent ego replicas (default, no collective) or ONE ego whose obstacles are sharded over the ranks "
                          "with an RCCL all-gather per ADMM iteration (strong scaling, --n-obs = total obstacles)")
@@ -245,6 +246,36 @@ def main():
         iters.append(info.iters)
     mean_iters = float(np.mean(iters))
 
+    # ---- batched multi-ego on ONE GPU (BASELINE "batched multi-ego", replicas only): M independent handles, one HIP
+    #      stream each, the same recorded step inputs; k_su occupies one CU per ego, so the egos overlap on the device
+    multi = None
+    if rank == 0 and world == 1 and args.egos > 1:
+        M, Km = args.egos, min(K, 100)
+        hs = []
+        for _ in range(M):
+            sm = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+            hm = sm._be.handle
+            api.lib.rda_upload_obstacles(hm, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+            api.lib.rda_upload_trace(hm, W + Km, dptr(trace["nom_s"][:W + Km]), dptr(trace["nom_u"][:W + Km]), dptr(trace["ref"][:W + Km]), dptr(trace["speed"][:W + Km]))
+            hs.append((sm, hm))
+        for k in range(W):
+            for _, hm in hs:
+                api.lib.rda_enqueue_step(hm, k)
+        for _, hm in hs:
+            api.lib.rda_sync(hm)
+        t0 = time.perf_counter()
+        for k in range(W, W + Km):
+            for _, hm in hs:
+                api.lib.rda_enqueue_step(hm, k)
+        for _, hm in hs:
+            api.lib.rda_sync(hm)
+        el = time.perf_counter() - t0
+        um = np.zeros((2, T)); sm_ = np.zeros((3, T + 1))
+        api.lib.rda_fetch_result(hs[-1][1], W + Km - 1, dptr(um), dptr(sm_), C.byref(info))
+        multi = {"egos": M, "steps_per_ego": Km, "aggregate_steps_per_s": round(M * Km / el, 1),
+                 "max_du_vs_single": float(np.abs(um - trace["u_solver"][W + Km - 1]).max())}
+        del hs
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -285,6 +316,7 @@ def main():
         "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
         "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
         "closed_loop_device_obstacles": cl_dev,
+        "multi_ego_one_gpu": multi,
         "instrumented_ms_per_step": round(elapsed / K * 1e3, 5),
         "roofline": dominant, "roofline_secondary": secondary,
     }
