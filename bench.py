@@ -264,9 +264,9 @@ def main():
         for _, hm in hs:
             api.lib.rda_sync(hm)
         t0 = time.perf_counter()
-        for k in range(W, W + Km):
+        for k in range(W, W + Km, 10):                    # ten steps per ego per host call, egos interleaved
             for _, hm in hs:
-                api.lib.rda_enqueue_step(hm, k)
+                api.lib.rda_enqueue_range(hm, k, min(k + 10, W + Km))
         for _, hm in hs:
             api.lib.rda_sync(hm)
         el = time.perf_counter() - t0

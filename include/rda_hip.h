@@ -109,6 +109,7 @@ int  rda_upload_obstacles(rda_handle *h, int n_obs, const double *A, const doubl
 int  rda_upload_trace(rda_handle *h, int K, const double *nom_s /*K*3*(T+1)*/, const double *nom_u /*K*2*T*/,
                       const double *ref_s /*K*3*(T+1)*/, const double *ref_speed /*K*/);
 int  rda_enqueue_step(rda_handle *h, int k);
+int  rda_enqueue_range(rda_handle *h, int k0, int k1);      /* steps k0 .. k1-1, one host call */
 int  rda_sync(rda_handle *h);
 int  rda_fetch_result(rda_handle *h, int k, double *out_u, double *out_s, rda_info *info);
 /* elapsed GPU time (ms, hipEvent) of the kernels named `which` (0 = LamMuZ, 1 = su) over the

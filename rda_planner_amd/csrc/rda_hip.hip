@@ -631,6 +631,14 @@ extern "C" int rda_enqueue_step(rda_handle *H, int k)
                         H->d_tr_out_u + k * nu, H->d_tr_out_s + k * ns, H->d_tr_info + k);
 }
 
+// steps k0 .. k1-1 of the uploaded trace, queued back to back (one host call instead of k1-k0)
+extern "C" int rda_enqueue_range(rda_handle *H, int k0, int k1)
+{
+    if (!H || k0 < 0 || k1 > H->K || k0 > k1) return RDA_ERR_ARG;
+    for (int k = k0; k < k1; ++k) { int rc = rda_enqueue_step(H, k); if (rc != RDA_OK) return rc; }
+    return RDA_OK;
+}
+
 extern "C" int rda_sync(rda_handle *H) { if (!H) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(H->stream)); return RDA_OK; }
 
 extern "C" int rda_fetch_result(rda_handle *H, int k, double *out_u, double *out_s, rda_info *info)
