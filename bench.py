@@ -19,6 +19,8 @@ nominal, D2H of the control every step) is reported next to it as `closed_loop_s
 N > 1: one process per GPU, independent ego replicas (BASELINE config "batched multi-ego":
 scenario batch sharded, no data-path collective) - weak scaling, value = sum over ranks.
 """
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # the multi-ego leg runs one HIP stream per ego; the default 4 hardware queues serialise them
 import argparse
 import ctypes as C
 import json
@@ -99,7 +101,7 @@ def main():
     ap.add_argument("--n-obs", type=int, default=200)
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--egos", type=int, default=8, help="extra leg: this many independent egos concurrently on one GPU (0/1 = skip)")
+    ap.add_argument("--egos", type=int, default=16, help="extra leg: this many independent egos concurrently on one GPU (0/1 = skip)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="N>1: independent ego replicas (default, no collective) or ONE ego whose obstacles are sharded over the ranks "
                          "with an RCCL all-gather per ADMM iteration (strong scaling, --n-obs = total obstacles)")
