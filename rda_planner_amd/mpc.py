@@ -24,15 +24,11 @@ class MPC:
                  max_edge_num: int = 5, max_obs_num: int = 5, process_num: int = 4, accelerated: bool = True,
                  time_print: bool = False, goal_index_threshold: int = 1, **kwargs) -> None:
         # reference mpc.py:67-125
-        self.car_tuple = car_tuple
-        self.L = car_tuple.wheelbase
-        self.dynamics = car_tuple.dynamics
-        self.receding = receding
-        self.dt = sample_time
+        self.car_tuple, self.ref_path = car_tuple, ref_path
+        self.L, self.dynamics = car_tuple.wheelbase, car_tuple.dynamics
+        self.receding, self.dt = receding, sample_time
+        self.state, self.cur_index = np.zeros((3, 1)), 0
         self.cur_vel_array = kwargs.get("init_vel", np.zeros((2, receding)))
-        self.state = np.zeros((3, 1))
-        self.cur_index = 0
-        self.ref_path = ref_path
         # extension (not in the reference): device_obstacles=True lets the accelerated backend convert, predict, sort
         # and stage the raw obstacles on the GPU (rda_step_scene) instead of the host code below; same staged values
         self.device_obstacles = bool(kwargs.get("device_obstacles", True))
@@ -40,10 +36,8 @@ class MPC:
         self.rda = RDA_solver(receding, car_tuple, max_edge_num, max_obs_num, iter_num=iter_num,
                               step_time=sample_time, process_num=process_num, accelerated=accelerated,
                               time_print=time_print, **solver_kwargs)
-        self.enable_reverse = enable_reverse
-        self.rda_obstacle = rda_obstacle
-        self.obstacle_order = obstacle_order
-        self.goal_index_threshold = goal_index_threshold
+        self.enable_reverse, self.rda_obstacle = enable_reverse, rda_obstacle
+        self.obstacle_order, self.goal_index_threshold = obstacle_order, goal_index_threshold
         if enable_reverse:
             self.curve_list = self.split_path(self.ref_path)
             self.curve_index = 0
@@ -78,20 +72,16 @@ class MPC:
             u_opt_array, info = self.rda.iterative_solve(
                 state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, rda_obs_list, **kwargs)
 
-        if self.cur_index >= len(cur_ref_path) - self.goal_index_threshold:
-            if self.enable_reverse:
-                self.curve_index += 1
-                self.cur_index = 0
-                if self.curve_index < len(self.curve_list):
-                    info["arrive"] = False
-                else:
-                    u_opt_array = np.zeros((2, self.receding))
-                    info["arrive"] = True
-            else:
-                u_opt_array = np.zeros((2, self.receding))
-                info["arrive"] = True
-        else:
-            info["arrive"] = False
+        # end of the (current piece of the) path, mpc.py:166-183: with reverse enabled the next gear piece starts,
+        # the last one (or a plain path) stops the robot
+        at_end = self.cur_index >= len(cur_ref_path) - self.goal_index_threshold
+        last_piece = True
+        if at_end and self.enable_reverse:
+            self.curve_index, self.cur_index = self.curve_index + 1, 0
+            last_piece = self.curve_index >= len(self.curve_list)
+        info["arrive"] = bool(at_end and last_piece)
+        if info["arrive"]:
+            u_opt_array = np.zeros((2, self.receding))
 
         self.cur_vel_array = u_opt_array
         return u_opt_array[:, 0:1], info
@@ -217,36 +207,30 @@ class MPC:
 
     @staticmethod
     def distance(point1, point2):
-        return sqrt((point1[0, 0] - point2[0, 0]) ** 2 + (point1[1, 0] - point2[1, 0]) ** 2)
+        dx, dy = point1[0, 0] - point2[0, 0], point1[1, 0] - point2[1, 0]
+        return sqrt(dx ** 2 + dy ** 2)
 
     @staticmethod
     def wraptopi(radian):
-        while radian > pi:
-            radian = radian - 2 * pi
-        while radian < -pi:
-            radian = radian + 2 * pi
+        # shift by whole turns until inside [-pi, pi]; same subtraction / addition sequence as mpc.py:425-433
+        while abs(radian) > pi:
+            radian = radian - 2 * pi if radian > 0 else radian + 2 * pi
         return radian
 
     # ------------------------------------------------------------------ geometry (mpc.py:440-549)
     def convert_inequal_circle(self, center, radius, velocity=np.zeros((2, 1))):
         eye = np.array([[1, 0], [0, 1], [0, 0]])
+        tail = -radius * np.ones((1, 1))
         if np.linalg.norm(velocity) <= 0.01:
-            return eye, np.vstack((center, -radius * np.ones((1, 1))))
-        A, b = [], []
-        for t in range(self.receding + 1):
-            A.append(eye.copy())
-            b.append(np.vstack((center + velocity * (t * self.dt), -radius * np.ones((1, 1)))))
-        return A, b
+            return eye, np.vstack((center, tail))
+        steps = range(self.receding + 1)                   # constant-velocity prediction over the horizon
+        return [eye.copy() for _ in steps], [np.vstack((center + velocity * (t * self.dt), tail)) for t in steps]
 
     def convert_inequal_polygon(self, vertex, velocity=np.zeros((2, 1))):
         if np.linalg.norm(velocity) <= 0.01:
             return self.gen_inequal_global(vertex)
-        A, b = [], []
-        for t in range(self.receding + 1):
-            At, bt = self.gen_inequal_global(vertex + velocity * (t * self.dt))
-            A.append(At)
-            b.append(bt)
-        return A, b
+        pairs = [self.gen_inequal_global(vertex + velocity * (t * self.dt)) for t in range(self.receding + 1)]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
 
     def gen_inequal_global(self, vertex):
         """half-space form of a convex polygon, un-normalised edge normals (quirk Q11)"""
@@ -266,18 +250,17 @@ class MPC:
         return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
 
     def is_convex_and_ordered(self, points):
+        """(convex?, 'CCW' | 'CW' | None): all non-zero turns of consecutive vertex triples share one sign; the sign of
+        the first one names the order (all-collinear input reports 'CW', like mpc.py:527-549)"""
         n = points.shape[1]
         if n < 3:
             return False, None
-        direction = 0
-        for i in range(n):
-            cross = self.cross_product(points[:, i], points[:, (i + 1) % n], points[:, (i + 2) % n])
-            if cross != 0:
-                if direction == 0:
-                    direction = 1 if cross > 0 else -1
-                elif (cross > 0) != (direction > 0):
-                    return False, None
-        return True, "CCW" if direction > 0 else "CW"
+        o, a, b = points[0:2], np.roll(points[0:2], -1, axis=1), np.roll(points[0:2], -2, axis=1)
+        turns = (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+        turns = turns[turns != 0]
+        if turns.size and not (np.all(turns > 0) or np.all(turns < 0)):
+            return False, None
+        return True, "CCW" if turns.size and turns[0] > 0 else "CW"
 
     def get_adjust_parameters(self):
         return self.rda.get_adjust_parameter()
