@@ -402,6 +402,86 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
     }
 }
 
+// Warm start for polygon obstacles: the support (non-zero pattern) of the previous (lam, mu) of this (obstacle, stage)
+// usually survives from one ADMM iteration / MPC step to the next.  Lanes 0 and 1 solve that one support for the
+// two hinge states, every lane then checks the optimality conditions of the FULL problem for the result
+// (lam_i >= 0 : g_i + nu A_i'a^ >= 0 off the support, mu_j >= 0 : g_j >= 0 off the support, nu >= 0 for |A'lam| <= 1).
+// The problem is convex, so a point that passes is a global minimiser and the enumeration is skipped; any doubt
+// (sign, tolerance, circle obstacle, more than two non-zeros) falls back to solve_wave.  `prev` is this lane's
+// previous value: lam[lane] for lane < E, mu[lane - E] for E <= lane < E + R.
+__device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, double prev, Sol &best)
+{
+    if (P.norm2) return false;
+    const int E = P.E, R = P.R;
+    const unsigned long long nzl = __ballot(lane < E && prev > 0.0), nzm = __ballot(lane >= E && lane < E + R && prev > 0.0) >> E;
+    if (__popcll(nzl) > 2 || __popcll(nzm) > 2) return false;
+    auto cand_of = [](unsigned long long bits, int n) {
+        if (!bits) return 0;
+        int i1 = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        if (!bits) return 1 + i1;
+        int i2 = __ffsll((long long)bits) - 1;
+        return 1 + n + (i1 * (2 * n - i1 - 1)) / 2 + (i2 - i1 - 1);
+    };
+    const int il = cand_of(nzl, E), im = cand_of(nzm, R);
+    // q = A p - b ; M = A R  (lanes < E) - solve_wave recomputes the same values if we fall back
+    if (lane < E) {
+        double ax = W.A[lane][0], ay = W.A[lane][1];
+        W.q[lane] = ax * P.px + ay * P.py - W.b[lane];
+        W.M[lane][0] = ax * P.cs + ay * P.sn;
+        W.M[lane][1] = -ax * P.sn + ay * P.cs;
+    }
+    __builtin_amdgcn_wave_barrier();
+    Sol s; s.m = 0; s.H0 = s.H1 = 0; s.i1 = s.i2 = s.j1 = s.j2 = -1; s.l1 = s.l2 = s.g1 = s.g2 = 0; s.cost = 0; s.id = 0;
+    bool ok = false;
+    if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);
+    // hinge-inactive solution with m >= 0, else hinge-active solution with m < 0
+    const double m0 = __shfl(s.m, 0, 64), m1 = __shfl(s.m, 1, 64);
+    const unsigned long long okb = __ballot(ok);
+    int src;
+    if ((okb & 1) && m0 >= 0) src = 0; else if ((okb & 2) && m1 < 0) src = 1; else return false;
+    best.m = src ? m1 : m0;
+    best.cost = __shfl(s.cost, src, 64); best.id = 2 * (il * (1 + R + R * (R - 1) / 2) + im) + src;
+    best.H0 = __shfl(s.H0, src, 64); best.H1 = __shfl(s.H1, src, 64);
+    best.i1 = __shfl(s.i1, src, 64); best.i2 = __shfl(s.i2, src, 64);
+    best.j1 = __shfl(s.j1, src, 64); best.j2 = __shfl(s.j2, src, 64);
+    best.l1 = __shfl(s.l1, src, 64); best.l2 = __shfl(s.l2, src, 64);
+    best.g1 = __shfl(s.g1, src, 64); best.g2 = __shfl(s.g2, src, 64);
+    // ---- optimality conditions of the full problem ---------------------------------------------------------------
+    double ax = 0, ay = 0;
+    if (best.i1 >= 0) { ax += best.l1 * W.A[best.i1][0]; ay += best.l1 * W.A[best.i1][1]; }
+    if (best.i2 >= 0) { ax += best.l2 * W.A[best.i2][0]; ay += best.l2 * W.A[best.i2][1]; }
+    const double na = sqrt(ax * ax + ay * ay);
+    if (na > 1.0 + 1e-12) return false;
+    const double phim = (best.m < 0 ? best.m : 0.0) - P.delta;          // d cost / d m
+    const bool tight = na >= 1.0 - 1e-9;
+    const double ux = tight ? ax / na : 0.0, uy = tight ? ay / na : 0.0;
+    auto glam = [&](int i) { return phim * W.q[i] + P.ro2 * (W.M[i][0] * best.H0 + W.M[i][1] * best.H1); };
+    double nu = 0.0;
+    if (tight) {           // multiplier of |A'lam| <= 1 from the support row with the larger A_i'a^
+        int ib = best.i1;
+        double d1 = best.i1 >= 0 ? W.A[best.i1][0] * ux + W.A[best.i1][1] * uy : 0.0;
+        double d2 = best.i2 >= 0 ? W.A[best.i2][0] * ux + W.A[best.i2][1] * uy : 0.0;
+        double db = d1;
+        if (fabs(d2) > fabs(d1)) { ib = best.i2; db = d2; }
+        if (ib < 0 || !(fabs(db) > 1e-12)) return false;
+        nu = -glam(ib) / db;
+        if (!(nu >= -1e-10)) return false;
+    }
+    bool pass = true;
+    if (lane < E) {
+        const double gi = glam(lane) + nu * (W.A[lane][0] * ux + W.A[lane][1] * uy);
+        const double tol = 1e-10 * (1.0 + fabs(phim * W.q[lane]) + P.ro2 * (fabs(W.M[lane][0] * best.H0) + fabs(W.M[lane][1] * best.H1)));
+        pass = (lane == best.i1 || lane == best.i2) ? fabs(gi) <= 1e3 * tol : gi >= -tol;
+    } else if (lane < E + R) {
+        const int j = lane - E;
+        const double gj = -phim * Rb.h[j] + P.ro2 * (Rb.G[j][0] * best.H0 + Rb.G[j][1] * best.H1);
+        const double tol = 1e-10 * (1.0 + fabs(phim * Rb.h[j]) + P.ro2 * (fabs(Rb.G[j][0] * best.H0) + fabs(Rb.G[j][1] * best.H1)));
+        pass = (j == best.j1 || j == best.j2) ? fabs(gj) <= 1e3 * tol : gj >= -tol;
+    }
+    return __ballot(!pass) == 0;
+}
+
 // value of lam[e] / mu[j] encoded by a solution
 __device__ __forceinline__ double lam_of(const Sol &s, int norm2, int e)
 {

@@ -34,6 +34,7 @@ __host__ __device__ inline double *coef_arr(const Dev &d, int r, int k);
 struct Dev {
     rda_cfg c;
     int nt;                  // time slots of the staged obstacles (T+1 or 1)
+    int warm;                // k_lammuz tries the previous support first (RDA_LMZ_WARM=0 disables)
     int obstacle_num;        // 0 or N
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
@@ -164,17 +165,21 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
     P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
     lmz::Sol best;
-    lmz::solve_wave(W, rb, P, lane, best);
+    // previous value of this lane's dual entry: warm start of the support + the dual residual below
+    double prev = 0.0;
+    if (lane < E) prev = d.lam[o * E + lane];
+    else if (lane < E + R) prev = d.mu[o * R + lane - E];
+    if (!d.warm || !lmz::solve_wave_warm(W, rb, P, lane, prev, best)) lmz::solve_wave(W, rb, P, lane, best);
     // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
     double res = 0;
     if (lane < E) {
-        double v = lmz::lam_of(best, P.norm2, lane), old = d.lam[o * E + lane];
-        res = (v - old) * (v - old); d.lam[o * E + lane] = v;
+        double v = lmz::lam_of(best, P.norm2, lane);
+        res = (v - prev) * (v - prev); d.lam[o * E + lane] = v;
     } else if (lane < E + R) {
         int j = lane - E;
-        double v = lmz::mu_of(best, j), old = d.mu[o * R + j];
-        res = (v - old) * (v - old); d.mu[o * R + j] = v;
+        double v = lmz::mu_of(best, j);
+        res = (v - prev) * (v - prev); d.mu[o * R + j] = v;
     } else if (lane == E + R) {
         double old = d.z[n * T + t];
         res = (znew - old) * (znew - old); d.z[n * T + t] = znew;
@@ -341,6 +346,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     rda_handle *H = new rda_handle();
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
+    { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
