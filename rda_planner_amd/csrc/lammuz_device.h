@@ -26,6 +26,7 @@ struct WaveLDS {            // one slab per wave (stage-local obstacle data)
     double b[EMAX];
     double q[EMAX];
     double M[EMAX][2];
+    unsigned char lamc[40], muc[40];   // surviving lam / mu support candidates (original indices), heavy types first
 };
 struct RobotLDS {           // one per block
     double G[RMAX][2];
@@ -358,9 +359,75 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
         W.M[lane][1] = -ax * P.sn + ay * P.cs;
     }
     __builtin_amdgcn_wave_barrier();
-    const int nl = P.norm2 ? 3 : 1 + P.E + P.E * (P.E - 1) / 2;
-    const int nm = 1 + P.R + P.R * (P.R - 1) / 2;
-    const int half = nl * nm;
+    const int nm = 1 + P.R + P.R * (P.R - 1) / 2;            // original candidate numbering (ids, tie-break T3)
+    // ---- candidate lists.  A two-element support {i1,i2} can only be optimal if the intersection of its two lines is a
+    // vertex of the polygon (the optimal lam is LP-optimal for its a = A'lam, and an optimal basis is primal
+    // feasible); same for the robot.  Infeasible pairs and null rows are dropped up front, so the lane loop runs over
+    // the survivors only: a quadrilateral x rectangle problem shrinks from 121 to 81 candidates per hinge state, a
+    // triangle from 121 to 63 (one lane pass).  Pairs first: the last pass then carries only the cheap types.
+    int nlv, nmv;
+    {
+        const int E = P.E, R = P.R;
+        if (P.norm2) {
+            if (lane == 0) { W.lamc[0] = 1; W.lamc[1] = 2; W.lamc[2] = 0; }
+            nlv = 3;
+        } else {
+            bool vp = false;
+            if (lane < E * (E - 1) / 2) {
+                int i1, i2; decode_pair(lane, E, i1, i2);
+                const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1];
+                const double det = a00 * a11 - a01 * a10;
+                if (det != 0 && det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11)) {
+                    const double id = 1.0 / det;
+                    const double vx = (W.b[i1] * a11 - a01 * W.b[i2]) * id, vy = (a00 * W.b[i2] - W.b[i1] * a10) * id;
+                    vp = true;
+                    for (int k = 0; k < E; ++k) {
+                        const double ak0 = W.A[k][0], ak1 = W.A[k][1];
+                        const double viol = ak0 * vx + ak1 * vy - W.b[k];
+                        if (viol > 1e-9 * (1.0 + fabs(W.b[k]) + fabs(ak0 * vx) + fabs(ak1 * vy))) vp = false;
+                    }
+                }
+            }
+            const bool vs = lane < E && (W.A[lane < E ? lane : 0][0] != 0 || W.A[lane < E ? lane : 0][1] != 0);
+            const unsigned long long bp = __ballot(vp), bs = __ballot(vs), below = (1ull << lane) - 1;
+            const int npv = __popcll(bp), nsv = __popcll(bs);
+            if (vp) W.lamc[__popcll(bp & below)] = (unsigned char)(1 + E + lane);
+            if (vs) W.lamc[npv + __popcll(bs & below)] = (unsigned char)(1 + lane);
+            if (lane == 0) W.lamc[npv + nsv] = 0;
+            nlv = npv + nsv + 1;
+        }
+        {
+            const int l2 = lane - 32;
+            bool vp = false;
+            if (l2 >= 0 && l2 < R * (R - 1) / 2) {
+                int j1, j2; decode_pair(l2, R, j1, j2);
+                const double a00 = Rb.G[j1][0], a01 = Rb.G[j1][1], a10 = Rb.G[j2][0], a11 = Rb.G[j2][1];
+                const double det = a00 * a11 - a01 * a10;
+                if (det != 0 && det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11)) {
+                    const double id = 1.0 / det;
+                    const double vx = (Rb.h[j1] * a11 - a01 * Rb.h[j2]) * id, vy = (a00 * Rb.h[j2] - Rb.h[j1] * a10) * id;
+                    vp = true;
+                    for (int k = 0; k < R; ++k) {
+                        const double ak0 = Rb.G[k][0], ak1 = Rb.G[k][1];
+                        const double viol = ak0 * vx + ak1 * vy - Rb.h[k];
+                        if (viol > 1e-9 * (1.0 + fabs(Rb.h[k]) + fabs(ak0 * vx) + fabs(ak1 * vy))) vp = false;
+                    }
+                }
+            }
+            const int jr = l2 >= 0 && l2 < R ? l2 : 0;
+            const bool vs = l2 >= 0 && l2 < R && (Rb.G[jr][0] != 0 || Rb.G[jr][1] != 0);
+            const unsigned long long bp = __ballot(vp) >> 32, bs = __ballot(vs) >> 32, below = l2 >= 0 ? (1ull << l2) - 1 : 0;
+            const int npv = __popcll(bp), nsv = __popcll(bs);
+            if (vp) W.muc[__popcll(bp & below)] = (unsigned char)(1 + R + l2);
+            if (vs) W.muc[npv + __popcll(bs & below)] = (unsigned char)(1 + l2);
+            if (lane == 0) W.muc[npv + nsv] = 0;
+            nmv = npv + nsv + 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    const int half = nlv * nmv;
     best.cost = INFINITY; best.id = 0x7fffffff;
     best.m = 0; best.H0 = 0; best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
     best.l1 = best.l2 = best.g1 = best.g2 = 0;
@@ -373,10 +440,10 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
     for (int ic = 0; ic < 2; ++ic) {
         int itn = 0;
         for (int c = lane; c < half; c += 64) {
-            int im = c % nm, il = c / nm;
+            const int ilx = c / nmv, il = W.lamc[ilx], im = W.muc[c - ilx * nmv];
             Sol s;
             if (eval_candidate(W, Rb, P, il, im, ic, s)) {
-                s.id = 2 * c + ic;
+                s.id = 2 * (il * nm + im) + ic;
                 if (s.cost < best.cost || (s.cost == best.cost && s.id < best.id)) best = s;
             }
             mark(1 + 2 * ic + (itn < 1 ? itn : 1)); ++itn;
