@@ -26,11 +26,12 @@ struct WaveLDS {            // one slab per wave (stage-local obstacle data)
     double b[EMAX];
     double q[EMAX];
     double M[EMAX][2];
-    unsigned char lamc[40], muc[40];   // surviving lam / mu support candidates (original indices), heavy types first
+    unsigned char lamc[40];            // surviving lam support candidates (original indices), heavy types first
 };
 struct RobotLDS {           // one per block
     double G[RMAX][2];
     double h[RMAX];
+    unsigned char muc[40]; int nmv;    // surviving mu support candidates (robot geometry only: built once on the host)
 };
 
 struct Sol {
@@ -378,13 +379,13 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
                 const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1];
                 const double det = a00 * a11 - a01 * a10;
                 if (det != 0 && det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11)) {
-                    const double id = 1.0 / det;
-                    const double vx = (W.b[i1] * a11 - a01 * W.b[i2]) * id, vy = (a00 * W.b[i2] - W.b[i1] * a10) * id;
+                    // v det = (b1 a11 - a01 b2, a00 b2 - b1 a10);  A_k v - b_k <= tol  <=>  sign(det) (A_k (v det) - b_k det) <= tol |det|
+                    const double wx = W.b[i1] * a11 - a01 * W.b[i2], wy = a00 * W.b[i2] - W.b[i1] * a10, sg = det > 0 ? 1.0 : -1.0, ad = fabs(det);
                     vp = true;
                     for (int k = 0; k < E; ++k) {
-                        const double ak0 = W.A[k][0], ak1 = W.A[k][1];
-                        const double viol = ak0 * vx + ak1 * vy - W.b[k];
-                        if (viol > 1e-9 * (1.0 + fabs(W.b[k]) + fabs(ak0 * vx) + fabs(ak1 * vy))) vp = false;
+                        const double ak0 = W.A[k][0], ak1 = W.A[k][1], bk = W.b[k];
+                        const double viol = sg * (ak0 * wx + ak1 * wy - bk * det);
+                        if (viol > 1e-9 * (ad + fabs(bk) * ad + fabs(ak0 * wx) + fabs(ak1 * wy))) vp = false;
                     }
                 }
             }
@@ -396,33 +397,7 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
             if (lane == 0) W.lamc[npv + nsv] = 0;
             nlv = npv + nsv + 1;
         }
-        {
-            const int l2 = lane - 32;
-            bool vp = false;
-            if (l2 >= 0 && l2 < R * (R - 1) / 2) {
-                int j1, j2; decode_pair(l2, R, j1, j2);
-                const double a00 = Rb.G[j1][0], a01 = Rb.G[j1][1], a10 = Rb.G[j2][0], a11 = Rb.G[j2][1];
-                const double det = a00 * a11 - a01 * a10;
-                if (det != 0 && det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11)) {
-                    const double id = 1.0 / det;
-                    const double vx = (Rb.h[j1] * a11 - a01 * Rb.h[j2]) * id, vy = (a00 * Rb.h[j2] - Rb.h[j1] * a10) * id;
-                    vp = true;
-                    for (int k = 0; k < R; ++k) {
-                        const double ak0 = Rb.G[k][0], ak1 = Rb.G[k][1];
-                        const double viol = ak0 * vx + ak1 * vy - Rb.h[k];
-                        if (viol > 1e-9 * (1.0 + fabs(Rb.h[k]) + fabs(ak0 * vx) + fabs(ak1 * vy))) vp = false;
-                    }
-                }
-            }
-            const int jr = l2 >= 0 && l2 < R ? l2 : 0;
-            const bool vs = l2 >= 0 && l2 < R && (Rb.G[jr][0] != 0 || Rb.G[jr][1] != 0);
-            const unsigned long long bp = __ballot(vp) >> 32, bs = __ballot(vs) >> 32, below = l2 >= 0 ? (1ull << l2) - 1 : 0;
-            const int npv = __popcll(bp), nsv = __popcll(bs);
-            if (vp) W.muc[__popcll(bp & below)] = (unsigned char)(1 + R + l2);
-            if (vs) W.muc[npv + __popcll(bs & below)] = (unsigned char)(1 + l2);
-            if (lane == 0) W.muc[npv + nsv] = 0;
-            nmv = npv + nsv + 1;
-        }
+        nmv = Rb.nmv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -440,7 +415,7 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
     for (int ic = 0; ic < 2; ++ic) {
         int itn = 0;
         for (int c = lane; c < half; c += 64) {
-            const int ilx = c / nmv, il = W.lamc[ilx], im = W.muc[c - ilx * nmv];
+            const int ilx = c / nmv, il = W.lamc[ilx], im = Rb.muc[c - ilx * nmv];
             Sol s;
             if (eval_candidate(W, Rb, P, il, im, ic, s)) {
                 s.id = 2 * (il * nm + im) + ic;

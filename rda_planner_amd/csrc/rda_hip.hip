@@ -35,6 +35,7 @@ struct Dev {
     rda_cfg c;
     int nt;                  // time slots of the staged obstacles (T+1 or 1)
     int warm;                // k_lammuz tries the previous support first (RDA_LMZ_WARM=0 disables)
+    unsigned char muc[40]; int nmv;   // robot support candidates that survive the vertex test (host, rda_create)
     int obstacle_num;        // 0 or N
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     }
     if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = d.G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = d.h[threadIdx.x - 64];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = d.muc[threadIdx.x - 128];
+    if (threadIdx.x == 192) rb.nmv = d.nmv;
     const int w = blockIdx.x * 4 + wv;
     const bool live = w < d.Nloc * T;
     const int nl = live ? w / T : 0, t = live ? w % T : 0;
@@ -209,11 +212,13 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     }
 }
 
+struct RobotCands { unsigned char muc[40]; int nmv; };
+
 // pure-function batch hook (rda_lammuz_batch)
 __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int *cone,
                                                       const double *p, const double *phi, const double *G, const double *h,
                                                       const double *xi, const double *zeta, const double *dbar, double ro2,
-                                                      double delta, int accelerated, double *lam, double *mu, double *z, double *cmh, long long *prof)
+                                                      double delta, int accelerated, double *lam, double *mu, double *z, double *cmh, long long *prof, RobotCands rc)
 {
     __shared__ lmz::WaveLDS wl[4];
     __shared__ lmz::RobotLDS rb;
@@ -221,6 +226,8 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
     const long long t_begin = prof ? clock64() : 0;
     if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = h[threadIdx.x - 64];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = rc.muc[threadIdx.x - 128];
+    if (threadIdx.x == 192) rb.nmv = rc.nmv;
     const int w = blockIdx.x * 4 + wv;
     const bool live = w < B;
     const int k = live ? w : 0;
@@ -336,6 +343,28 @@ template <typename Tp> static int dalloc(Tp **p, size_t n)
     return 0;
 }
 
+// mu support candidates of a polygon robot: pairs whose intersection is a vertex of the robot, then the non-null rows, then
+// the empty support (same rule and order as the lam lists built per wave in lmz::solve_wave)
+static int robot_candidates(int R, const double *G, const double *h, unsigned char *out)
+{
+    int n = 0, p = 0;
+    for (int j1 = 0; j1 < R; ++j1) for (int j2 = j1 + 1; j2 < R; ++j2, ++p) {
+        const double a00 = G[2 * j1], a01 = G[2 * j1 + 1], a10 = G[2 * j2], a11 = G[2 * j2 + 1];
+        const double det = a00 * a11 - a01 * a10;
+        if (det == 0 || !(det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11))) continue;
+        const double wx = h[j1] * a11 - a01 * h[j2], wy = a00 * h[j2] - h[j1] * a10, sg = det > 0 ? 1.0 : -1.0, ad = fabs(det);
+        bool ok = true;
+        for (int k = 0; k < R; ++k) {
+            const double viol = sg * (G[2 * k] * wx + G[2 * k + 1] * wy - h[k] * det);
+            if (viol > 1e-9 * (ad + fabs(h[k]) * ad + fabs(G[2 * k] * wx) + fabs(G[2 * k + 1] * wy))) ok = false;
+        }
+        if (ok) out[n++] = (unsigned char)(1 + R + p);
+    }
+    for (int j = 0; j < R; ++j) if (G[2 * j] != 0 || G[2 * j + 1] != 0) out[n++] = (unsigned char)(1 + j);
+    out[n++] = 0;
+    return n;
+}
+
 extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out)
 {
     if (!cfg || !G || !h || !out) return RDA_ERR_ARG;
@@ -347,6 +376,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
     { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
+    H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc);
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
@@ -857,10 +887,11 @@ extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const doub
                  {(void **)&dzeta, zeta, sB * 8}, {(void **)&ddbar, dbar, sB * 8} };
     for (auto &c : ins) { HIPCHK(hipMalloc(c.dst, c.bytes)); HIPCHK(hipMemcpy(*c.dst, c.src, c.bytes, hipMemcpyHostToDevice)); }
     HIPCHK(hipMalloc((void **)&dlam, sB * E * 8)); HIPCHK(hipMalloc((void **)&dmu, sB * R * 8)); HIPCHK(hipMalloc((void **)&dz, sB * 8)); HIPCHK(hipMalloc((void **)&dcmh, sB * 4 * 8));
+    RobotCands rcands; rcands.nmv = robot_candidates(R, G, h, rcands.muc);
     long long *dprof = nullptr;
     if (getenv("RDA_LMZ_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 8 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 8 * sizeof(long long))); }
     hipLaunchKernelGGL(k_lammuz_batch, dim3((B + 3) / 4), dim3(256), 0, 0, B, E, R, dA, db, dcone, dp, dphi, dG, dh, dxi, dzeta, ddbar,
-                       ro2, delta, accelerated, dlam, dmu, dz, dcmh, dprof);
+                       ro2, delta, accelerated, dlam, dmu, dz, dcmh, dprof, rcands);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     if (dprof) {
