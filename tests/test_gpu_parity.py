@@ -343,3 +343,30 @@ def test_full_size_step_properties():
     assert (lam >= 0).all() and np.isfinite(lam).all()
     ref, _ = first_controls(obstacles, steps=1, backend=oracle_backend)
     assert np.abs(ref[0] - base[0]).max() < 1e-6, np.abs(ref[0] - base[0]).max()
+
+
+def test_warm_started_lammuz_equals_enumeration(monkeypatch):
+    """k_lammuz accepts the previous support only with an optimality certificate of the full convex problem, so the
+    closed loop with the warm start (default) and with plain enumeration (RDA_LMZ_WARM=0) must coincide"""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot()
+    path = sc.line_path([5, 25, 0], [45, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    obstacles = sc.scene_polygons(150, lo=(5, 12), hi=(50, 38), keep_clear=clear, clear_radius=2.2) + \
+        [sc.circle(20.0, 28.5, 0.8), sc.circle(30.0, 21.5, 0.6, velocity=(0.2, 0.3))]
+    runs = []
+    for warm in ("1", "0"):
+        monkeypatch.setenv("RDA_LMZ_WARM", warm)
+        mpc = MPC(car_t, [p.copy() for p in path], receding=15, iter_num=4, max_edge_num=4, max_obs_num=152, time_print=False)
+        state = path[0].copy().reshape(3, 1)
+        us, its = [], []
+        for k in range(60):
+            u, info = mpc.control(state, 4.0, list(obstacles))
+            us.append(u.ravel().copy()); its.append(info["iters"])
+            state = sc.kinematic_step(state, u, car_t, 0.1)
+        runs.append((np.array(us), its, mpc.rda.get_state()))
+    (ua, ia, sa), (ub, ib, sb) = runs
+    assert ia == ib
+    assert np.abs(ua - ub).max() < 1e-8, np.abs(ua - ub).max()
+    for k in ("lam", "mu", "z"):
+        assert np.abs(sa[k] - sb[k]).max() < 1e-7, (k, np.abs(sa[k] - sb[k]).max())
