@@ -127,7 +127,7 @@ __global__ void k_begin(Dev d)
 
 // ------------------------------------------------------------------------------------------------
 // K1: one wavefront per (obstacle n, stage t); 4 wavefronts per workgroup.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lammuz(Dev d)
+__global__ __launch_bounds__(256) void k_lammuz(Dev d)
 {
     __shared__ lmz::WaveLDS wl[4];
     __shared__ lmz::RobotLDS rb;
