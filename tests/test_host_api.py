@@ -203,3 +203,32 @@ def test_flatten_scene_layout():
     # and the MPC runs through the host conversion with this backend
     u, info = mpc.control(np.zeros((3, 1)), 2.0, [tri, cir, quad])
     assert np.isfinite(u).all()
+
+
+def test_headless_world_runs_the_example_loop():
+    """the loop of example/path_track/path_track_diff.py:15-40 against the headless world (YAML subset of ir-sim)"""
+    from collections import namedtuple
+    import rda_planner_amd.world as irsim
+    env = irsim.make(os.path.join(os.path.dirname(__file__), "golden", "world_path_track_diff.yaml"))
+    assert env.step_time == 0.1 and len(env.get_obstacle_info_list()) == 13
+    kinds = [o.cone_type for o in env.get_obstacle_info_list()]
+    assert kinds.count("norm2") == 12 and kinds.count("Rpositive") == 1
+    assert float(env.get_obstacle_info_list()[0].radius) == 1.5 and float(env.get_obstacle_info_list()[5].radius) == 1.0
+    car = namedtuple("car", "G h cone_type wheelbase max_speed max_acce dynamics")
+    info_r = env.get_robot_info()
+    car_tuple = car(info_r.G, info_r.h, info_r.cone_type, info_r.shape[2], [10, 1], [10, 0.5], "diff")
+    ref_path_list = sc.path_track_ref()
+    mpc_opt = MPC(car_tuple, ref_path_list, receding=10, sample_time=env.step_time, process_num=4, iter_num=2, obstacle_order=True,
+                  ro1=300, max_edge_num=4, max_obs_num=13, slack_gain=8, _backend=oracle_backend)
+    moved = env.get_obstacle_info_list()[-1].center.copy()
+    min_clear = np.inf
+    for i in range(120):
+        opt_vel, info = mpc_opt.control(env.robot.state[0:3], 4, env.get_obstacle_info_list())
+        env.step(opt_vel)
+        env.render(show_traj=True)
+        min_clear = min(min_clear, env.clearance())
+        if env.done() or info["arrive"]:
+            break
+    assert not env.collided and min_clear > 0.05
+    assert np.linalg.norm(env.get_obstacle_info_list()[-1].center - moved) > 0.1      # the dynamic obstacles do move
+    assert np.linalg.norm(env.robot.state[0:2] - np.array([[10.0], [42.0]])) > 15.0   # and the robot made progress
