@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_workload(seed_offset=0, n_obs=200, T=20, n_steps=110):
+def build_workload(seed_offset=0, n_obs=200, T=20, n_steps=110, moving=False):
     """straight reference path through a seeded field of polygons; long enough that the robot never arrives
     (an arrived robot would make every later step trivial)"""
     from rda_planner_amd import scenarios as sc
@@ -42,7 +42,8 @@ def build_workload(seed_offset=0, n_obs=200, T=20, n_steps=110):
     length = max(40.0, 0.4 * n_steps + 12.0)
     path = sc.line_path([4, 25, 0], [4 + length, 25, 0], 0.1)
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
-    obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(4 + length - 4, 40), seed=sc.SEED + seed_offset, keep_clear=clear, clear_radius=3.2)
+    obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(4 + length - 4, 40), seed=sc.SEED + seed_offset, keep_clear=clear, clear_radius=3.2,
+                                  moving=moving)     # moving: velocities U[-1,1]^2 m/s, (A, b) per horizon stage (BASELINE dynamic_obs)
     kw = dict(receding=T, iter_num=4, max_edge_num=4, max_obs_num=n_obs, ro1=200, obstacle_order=True)
     return car_t, path, obstacles, kw
 
@@ -101,6 +102,7 @@ def main():
     ap.add_argument("--n-obs", type=int, default=200)
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--moving", action="store_true", help="moving obstacles: per-stage (A, b) over the horizon (dynamic_obs config)")
     ap.add_argument("--egos", type=int, default=16, help="extra leg: this many independent egos concurrently on one GPU (0/1 = skip)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="N>1: independent ego replicas (default, no collective) or ONE ego whose obstacles are sharded over the ranks "
@@ -131,7 +133,7 @@ def main():
 
     K, W = args.steps, args.warmup
     shard = args.mode == "shard" and world > 1
-    car_t, path, obstacles, kw = build_workload(seed_offset=0 if shard else rank, n_obs=args.n_obs, T=args.horizon, n_steps=K + W)
+    car_t, path, obstacles, kw = build_workload(seed_offset=0 if shard else rank, n_obs=args.n_obs, T=args.horizon, n_steps=K + W, moving=args.moving)
 
     def make_sharded(solver):
         """obstacle shards + in-library ncclAllGather; the 128-byte unique id travels over torch.distributed"""
@@ -164,10 +166,13 @@ def main():
             du = 0.0
             t0 = time.perf_counter()
             for k in range(nd):
-                u, _ = mpc_d.control(st, 4.0, list(obstacles))
-                du = max(du, float(np.abs(u - trace["u"][k]).max()))
+                cur = obstacles if not args.moving else [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) for o in obstacles]
+                u, _ = mpc_d.control(st, 4.0, list(cur))
+                if not args.moving:
+                    du = max(du, float(np.abs(u - trace["u"][k]).max()))
                 st = sc.kinematic_step(st, u, car_t, 0.1)
-            cl_dev = {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": du}
+            cl_dev = {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": None if args.moving else du,
+                      "obstacles_advance_every_tick": bool(args.moving)}
         del mpc_d
 
     # ---- device-resident replay -------------------------------------------------------------------
@@ -313,7 +318,7 @@ def main():
         "metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(K * (1 if shard else world) / elapsed2, 3), "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed2 / K * 1e3, 5),
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} static seeded polygons, E={E}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
+        "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} {"moving" if args.moving else "static"} seeded polygons, E={E}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
                    "parallelism": "single GPU" if world == 1 else (f"one ego, obstacles sharded {world}-way, RCCL all-gather per ADMM iteration" if shard else f"{world} independent ego replicas (no collective)")},
         "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
         "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
