@@ -314,11 +314,12 @@ def main():
             pass
     dominant, secondary = (r_su, r_lm) if su_ms >= lm_ms else (r_lm, r_su)
 
+    kind_word = "moving" if args.moving else "static"
     out = {
         "metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(K * (1 if shard else world) / elapsed2, 3), "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed2 / K * 1e3, 5),
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} {"moving" if args.moving else "static"} seeded polygons, E={E}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
+        "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} {kind_word} seeded polygons, E={E}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
                    "parallelism": "single GPU" if world == 1 else (f"one ego, obstacles sharded {world}-way, RCCL all-gather per ADMM iteration" if shard else f"{world} independent ego replicas (no collective)")},
         "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
         "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
