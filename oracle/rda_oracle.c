@@ -632,7 +632,9 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                 mu_aff /= mc;
                 /* centering parameter from the predictor step length, floored: the classical (mu_aff/mu)^3
                  * rule can cycle on the piecewise-quadratic hinge terms (observed with ro1 = 1) */
-                { double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03; sigma = q * q * q; if (sigma < fl) sigma = fl; }
+                { double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03;
+                if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
+                sigma = q * q * q; if (sigma < fl) sigma = fl; }
             }
         }
         double al = 1.0;

@@ -747,7 +747,9 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             al = -block_reduce(-al, L.red, tid, true);
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
-                double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03; sigma = q * q * q; if (sigma < fl) sigma = fl;
+                double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03;
+                if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
+                sigma = q * q * q; if (sigma < fl) sigma = fl;
             } else {
                 for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += al * L.dl[i]; }
                 if (tid < T) {
