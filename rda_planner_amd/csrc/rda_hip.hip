@@ -945,6 +945,9 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     long long *dprof = nullptr;
     if (getenv("RDA_SU_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }
     ar.prof = dprof;
+    double *ddbg = nullptr;
+    if (getenv("RDA_SU_TRACE")) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }
+    ar.dbg = ddbg;
     const size_t lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_hook<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
     RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su_hook<TT>, dim3(1), dim3(su::NT), lds, 0, ar));
@@ -952,6 +955,12 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     HIPCHK(hipDeviceSynchronize());
     int st[2];
     HIPCHK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+    if (ddbg) {
+        double hd[400]; HIPCHK(hipMemcpy(hd, ddbg, sizeof(hd), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 100 && (i == 0 || hd[4 * i + 3] != 0); ++i)
+            fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", i, hd[4 * i], hd[4 * i + 1], hd[4 * i + 2], hd[4 * i + 3]);
+        dev_free(ddbg);
+    }
     if (dprof) {
         long long hp[16]; HIPCHK(hipMemcpy(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost));
         fprintf(stderr, "su prof (cycles) iters=%d:", st[1]); for (int i = 0; i < 11; ++i) fprintf(stderr, " [%d]=%lld", i, hp[i]); fprintf(stderr, "\n");

@@ -50,6 +50,7 @@ struct Args {
     int *status;                     // 0 ok / 1 not converged / 2 factorisation failed
     int *ipm_iters;
     long long *prof;                 // optional per-phase cycle counters (debug), may be null
+    double *dbg = nullptr;           // optional per-iteration trace (rdn, rpn, mu, sc) x 100 (debug), may be null
 };
 
 __device__ __forceinline__ void wsync()
@@ -704,6 +705,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         }
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
+        if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
         if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) {
             if (screened) {        // the positions must have stayed within DELTA of the screening reference
                 double dv = 0;
