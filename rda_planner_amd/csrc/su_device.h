@@ -711,7 +711,19 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 double dv = 0;
                 if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
                 dv = block_reduce(dv, L.red, tid, true);
-                if (dv > DELTA) { screened = false; continue; }       // rare: go on with every term
+                if (dv > DELTA) {           // safety net (the per-iteration check below normally acts first): all terms, and a
+                    screened = false;       // fresh, well-centred set of slacks / multipliers at the current primal point
+                    for (int i = tid; i < NC * T; i += NT) {
+                        int t = i / NC, k = i % NC;
+                        double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
+                        double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
+                        bool on = con_on(t, k);
+                        L.cw[i] = on ? (sl > 1e-2 ? sl : 1e-2) : 1.0;
+                        L.cl[i] = on ? 1.0 / L.cw[i] : 0.0;
+                    }
+                    __syncthreads();
+                    continue;
+                }
             }
             status = 0; break;
         }
@@ -761,6 +773,12 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 }
                 if (tid < 3) L.s[tid * (T + 1) + T] += al * L.pv[tid];
                 __syncthreads();
+                if (screened) {        // the screening holds only while every stage stays within DELTA of its reference position
+                    double dv = 0;
+                    if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
+                    dv = block_reduce(dv, L.red, tid, true);
+                    if (dv > DELTA) screened = false;      // from the next iteration on: every term (the streaming loop)
+                }
             }
             mark(8);
         }
