@@ -963,7 +963,7 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     }
     if (dprof) {
         long long hp[16]; HIPCHK(hipMemcpy(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost));
-        fprintf(stderr, "su prof (cycles) iters=%d:", st[1]); for (int i = 0; i < 11; ++i) fprintf(stderr, " [%d]=%lld", i, hp[i]); fprintf(stderr, "\n");
+        fprintf(stderr, "su prof (cycles) iters=%d:", st[1]); for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%lld", i, hp[i]); fprintf(stderr, "\n");
         dev_free(dprof);
     }
     HIPCHK(hipMemcpy(s, dos, ns * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(u, dou, nu * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(dd, dod, T * 8, hipMemcpyDeviceToHost));

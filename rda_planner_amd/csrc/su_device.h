@@ -206,6 +206,9 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
     long long tprev = clock64();
+    long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
+    const bool prof_on = a.prof != nullptr;
+    auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
     const double vref = *a.ref_speed;
     // (stage, chunk) mapping of the obstacle reductions
     const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
@@ -232,6 +235,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
     __syncthreads();
+    mark(11);
     // ---- rotation-consistency penalty -> scalar quadratic per stage, fused with the HINGE SCREENING:
     // Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so an obstacle term whose margin at the nominal
     // position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Each thread
@@ -287,6 +291,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             L.Q0[tid] = s0; L.Q1[tid] = s1; L.Q2[tid] = s2;
         }
     }
+    mark(12);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
     if (tid < T) {
         int t = tid;
@@ -315,6 +320,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         }
     };
     rollout();
+    mark(13);
     for (int i = tid; i < NC * T; i += NT) {
         int t = i / NC, k = i % NC;
         double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
@@ -494,9 +500,6 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     };
 
     int status = 1, it;
-    long long pacc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
-    const bool prof_on = a.prof != nullptr;
-    auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
     mark(9);
     for (it = 0; it < 100; ++it) {
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
@@ -798,7 +801,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     }
     if (tid == 0) { *a.status = status; *a.ipm_iters = it; }
     mark(10);
-    if (prof_on && tid == 0) for (int k = 0; k < 11; ++k) a.prof[k] += pacc[k];
+    if (prof_on && tid == 0) for (int k = 0; k < 16; ++k) a.prof[k] += pacc[k];
 }
 #undef RW
 #undef R5
