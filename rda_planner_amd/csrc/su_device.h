@@ -261,7 +261,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                     double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
                     q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
                     double margin = ax * p0x + ay * p0y - cb - c.max_sd;
-                    if (screened && !(margin > DELTA * sqrt(ax * ax + ay * ay))) amask[bit >> 6] |= 1ull << (bit & 63);
+                    if (screened && !(margin > 0 && margin * margin > DELTA * DELTA * (ax * ax + ay * ay))) amask[bit >> 6] |= 1ull << (bit & 63);
                     ++bit;
                 };
                 const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o, *pb = a.blam + o, *pe = a.ee + o;
@@ -304,18 +304,34 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
     }
     __syncthreads();
-    // state rollout with the current controls: wave 0, every lane redundantly, the state chain stays in registers
+    // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
+    // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
+    // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
+    // on values that were fetched in one go (wave 0 only).
     auto rollout = [&]() {
         if (wave == 0) {
-            double s0 = L.s[0], s1 = L.s[T + 1], s2 = L.s[2 * (T + 1)];
-            for (int t = 0; t < T; ++t) {
-                const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
+            double *inc = L.dy;                         // scratch: dy is dead outside the sweeps
+            for (int t = lane; t < T; t += 64) {
+                const double *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
                 const double u0 = L.u[t], u1 = L.u[T + t];
-                double n0 = C[0] + A[0] * s0 + A[1] * s1 + A[2] * s2 + B[0] * u0 + B[1] * u1;
-                double n1 = C[1] + A[3] * s0 + A[4] * s1 + A[5] * s2 + B[2] * u0 + B[3] * u1;
-                double n2 = C[2] + A[6] * s0 + A[7] * s1 + A[8] * s2 + B[4] * u0 + B[5] * u1;
-                s0 = n0; s1 = n1; s2 = n2;
-                if (lane == 0) { L.s[t + 1] = s0; L.s[(T + 1) + t + 1] = s1; L.s[2 * (T + 1) + t + 1] = s2; }
+                inc[3 * t + 2] = (B[4] * u0 + B[5] * u1) + C[2];
+                inc[3 * t] = (B[0] * u0 + B[1] * u1) + C[0];
+                inc[3 * t + 1] = (B[2] * u0 + B[3] * u1) + C[1];
+            }
+            wsync();
+            if (lane == 0) {
+                double ph = L.s[2 * (T + 1)];
+                for (int t = 0; t < T; ++t) { ph += inc[3 * t + 2]; L.s[2 * (T + 1) + t + 1] = ph; }
+            }
+            wsync();
+            for (int t = lane; t < T; t += 64) {        // x, y increments need the heading of their own stage
+                const double ph = L.s[2 * (T + 1) + t];
+                inc[3 * t] += L.Ak[9 * t + 2] * ph; inc[3 * t + 1] += L.Ak[9 * t + 5] * ph;
+            }
+            wsync();
+            if (lane == 0) {
+                double x = L.s[0], y = L.s[T + 1];
+                for (int t = 0; t < T; ++t) { x += inc[3 * t]; y += inc[3 * t + 1]; L.s[t + 1] = x; L.s[(T + 1) + t + 1] = y; }
             }
         }
     };
