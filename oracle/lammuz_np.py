@@ -195,8 +195,107 @@ def circle_interior(gstar, chi, ut, l0, kappa0, xi, ro2, delta):
     return x
 
 
+
+CENTRE_H2 = 1e-8      # slack regime: the max-clearance optimum has m > 0 and |H|^2 below this (H = O(delta))
+
+
+def polygon_vertices(A, b):
+    """vertices of {x : A x <= b} with the two rows meeting there: pairs (i1 < i2) whose lines intersect in a point
+    of the polygon (same test as the candidate pruning of the kernel)"""
+    out = []
+    E = A.shape[0]
+    for i1 in range(E):
+        for i2 in range(i1 + 1, E):
+            det = A[i1, 0] * A[i2, 1] - A[i1, 1] * A[i2, 0]
+            if det == 0 or not det * det > 1e-24 * (A[i1] @ A[i1]) * (A[i2] @ A[i2]):
+                continue
+            wx = b[i1] * A[i2, 1] - A[i1, 1] * b[i2]
+            wy = A[i1, 0] * b[i2] - b[i1] * A[i2, 0]
+            sg, ad = (1.0 if det > 0 else -1.0), abs(det)
+            ok = True
+            for k in range(E):
+                viol = sg * (A[k, 0] * wx + A[k, 1] * wy - b[k] * det)
+                if viol > 1e-9 * (ad + abs(b[k]) * ad + abs(A[k, 0] * wx) + abs(A[k, 1] * wy)):
+                    ok = False
+            if ok:
+                out.append((wx / det, wy / det, i1, i2))
+    return out
+
+
+def central_normal(A, b, cone_norm2, p, phi, G, h, xi, kappa0, a_star):
+    """Tie-break T1 in the slack regime (every (lam, mu) with H = 0, m >= 0 is optimal): instead of the max-clearance
+    normal a*, the UNIT normal in the middle of the arc {theta : m(a(theta)) >= 0} of all separating directions around
+    a*, with the duals that support it (H = 0 exactly).  For unit a the clearance is
+        m(a) = min_{k,j} [ a'(p - v_k + R r_j) + xi'r_j ] + kappa0   (v_k obstacle vertices, r_j robot vertices; a circle
+    obstacle contributes its centre and -radius), so every vertex pair admits an arc centred at the direction of its
+    w_kj = p - v_k + R r_j with half-width acos(-c_j / |w_kj|); the feasible arc is their intersection.
+    Returns (lam, mu, m) or None (arc undefined / degenerate -> keep the max-clearance solution)."""
+    c, s = np.cos(phi), np.sin(phi)
+    Rm = np.array([[c, -s], [s, c]])
+    E, Rn = A.shape[0], G.shape[0]
+    rv = polygon_vertices(G, h)
+    if len(rv) < 3:
+        return None
+    if cone_norm2:
+        ov = [(b[0], b[1], -1, -1)]
+        off = b[2]                       # = -radius
+    else:
+        ov = polygon_vertices(A, b)
+        off = 0.0
+        if len(ov) < 3:
+            return None
+    th0 = np.arctan2(a_star[1], a_star[0])
+    lo = hi = np.pi
+    for (vx, vy, _, _) in ov:
+        for (rx, ry, _, _) in rv:
+            w = p - np.array([vx, vy]) + Rm @ np.array([rx, ry])
+            cj = xi[0] * rx + xi[1] * ry + kappa0 + off
+            nw = np.hypot(w[0], w[1])
+            if not nw > 0:
+                if cj < 0:
+                    return None
+                continue
+            q = -cj / nw
+            if q >= 1.0:
+                return None              # this pair admits no direction: not the slack regime
+            if q <= -1.0:
+                continue                 # every direction is fine for this pair
+            beta = np.arccos(q)
+            d = th0 - np.arctan2(w[1], w[0])
+            d = (d + np.pi) % (2 * np.pi) - np.pi
+            if abs(d) > beta:
+                return None              # a* itself does not separate for unit length: keep it
+            hi = min(hi, beta - d)
+            lo = min(lo, beta + d)
+    if hi >= np.pi and lo >= np.pi:
+        return None
+    thc = th0 + 0.5 * (hi - lo)
+    a = np.array([np.cos(thc), np.sin(thc)])
+    lam = np.zeros(E)
+    if cone_norm2:
+        lam[0], lam[1], lam[2] = a[0], a[1], -1.0
+    else:
+        k = int(np.argmax([a[0] * v[0] + a[1] * v[1] for v in ov]))
+        i1, i2 = ov[k][2], ov[k][3]
+        lam[[i1, i2]] = np.linalg.solve(A[[i1, i2]].T, a)
+    g = -(Rm.T @ a) - xi
+    j = int(np.argmax([g[0] * r[0] + g[1] * r[1] for r in rv]))
+    j1, j2 = rv[j][2], rv[j][3]
+    mu = np.zeros(Rn)
+    mu[[j1, j2]] = np.linalg.solve(G[[j1, j2]].T, g)
+    if (not cone_norm2 and lam.min() < -1e-9) or mu.min() < -1e-9:
+        return None
+    if not cone_norm2:
+        lam = np.maximum(lam, 0.0)
+    mu = np.maximum(mu, 0.0)
+    m = lam @ (A @ p - b) - mu @ h + kappa0
+    if m < 0:
+        return None
+    return lam, mu, m
+
+
 def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
-                 accelerated=True, delta=DELTA, return_all=False):
+                 accelerated=True, delta=DELTA, return_all=False, centre=True):
     """One (obstacle, stage) sub-problem.  A:(E,2) b:(E,) p:(2,) nominal position
     (column t+1), phi nominal heading (column t, quirk Q1), G:(R,2) h:(R,),
     xi:(2,), zeta, dbar scalars.  Returns lam(E), mu(R), z, info dict."""
@@ -349,8 +448,16 @@ def solve_lammuz(A, b, cone_norm2, p, phi, G, h, xi, zeta, dbar, ro2,
                     if best is None or cost < best[0] or (cost == best[0] and idx < best[1]):
                         best = (cost, idx, lam, mu, m, H, lc, mc, chi)
     cost, idx, lam, mu, m, H, lc, mc, chi = best
+    central = False
+    a_st = A.T @ lam
+    if centre and m > 0 and H @ H < CENTRE_H2 and a_st @ a_st >= 1.0 - 1e-9:      # a* on the unit circle: it has a direction
+        cn = central_normal(A, b, cone_norm2, np.asarray(p, float), phi, G, h, xi, kappa0, A.T @ lam)
+        if cn is not None:
+            lam, mu, m = cn
+            H = M.T @ lam + G.T @ mu + xi
+            central = True
     z = (0.5 if accelerated else 1.0) * max(m, 0.0)
-    info = dict(cost=cost, m=m, H=H, cand=(lc, mc, chi), index=idx)
+    info = dict(cost=cost, m=m, H=H, cand=(lc, mc, chi), index=idx, central=central)
     if return_all:
         info["all"] = allc
     return lam, mu, z, info

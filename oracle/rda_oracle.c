@@ -30,6 +30,8 @@
 #define SIGN_TOL 1e-12
 
 static int g_threads = 1;
+static int g_centre = 1;     /* tie-break T1: central separating normal in the slack regime (orc_set_centre(0): max clearance) */
+void orc_set_centre(int on) { g_centre = on; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 
 struct orc_handle {
@@ -224,6 +226,89 @@ static int circle_interior(const lmz_ctx *c, const mu_cand *mc, double chi, cons
     return 1;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* Tie-break T1 in the slack regime: the unit normal in the middle of the arc of all separating   */
+/* directions around the max-clearance normal a*, with the duals that support it (H = 0).        */
+/* Same steps as oracle/lammuz_np.py:central_normal.                                              */
+typedef struct { double x, y; int i1, i2; } pvert;
+static int polygon_vertices(int E, const double *A, const double *b, pvert *out)
+{
+    int n = 0;
+    for (int i1 = 0; i1 < E; ++i1) for (int i2 = i1 + 1; i2 < E; ++i2) {
+        const double a00 = A[2 * i1], a01 = A[2 * i1 + 1], a10 = A[2 * i2], a11 = A[2 * i2 + 1];
+        const double det = a00 * a11 - a01 * a10;
+        if (det == 0 || !(det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11))) continue;
+        const double wx = b[i1] * a11 - a01 * b[i2], wy = a00 * b[i2] - b[i1] * a10, sg = det > 0 ? 1.0 : -1.0, ad = fabs(det);
+        int ok = 1;
+        for (int k = 0; k < E; ++k) {
+            const double viol = sg * (A[2 * k] * wx + A[2 * k + 1] * wy - b[k] * det);
+            if (viol > 1e-9 * (ad + fabs(b[k]) * ad + fabs(A[2 * k] * wx) + fabs(A[2 * k + 1] * wy))) ok = 0;
+        }
+        if (ok) { out[n].x = wx / det; out[n].y = wy / det; out[n].i1 = i1; out[n].i2 = i2; n++; }
+    }
+    return n;
+}
+
+static int central_normal(int E, int R, const double *A, const double *b, int cone_norm2, const double *p, double cs, double sn,
+                          const double *G, const double *h, const double *xi, double kappa0, const double *a_star,
+                          double *lam, double *mu, double *m_out)
+{
+    const double PI = 3.14159265358979323846;
+    pvert rv[EMAX * (EMAX - 1) / 2 > RMAX * (RMAX - 1) / 2 ? EMAX * (EMAX - 1) / 2 : RMAX * (RMAX - 1) / 2], ov[EMAX * (EMAX - 1) / 2 + 1];
+    int nr = polygon_vertices(R, G, h, rv), nv; double off = 0;
+    if (nr < 3) return 0;
+    if (cone_norm2) { ov[0].x = b[0]; ov[0].y = b[1]; ov[0].i1 = ov[0].i2 = -1; nv = 1; off = b[2]; }
+    else { nv = polygon_vertices(E, A, b, ov); if (nv < 3) return 0; }
+    const double th0 = atan2(a_star[1], a_star[0]);
+    double lo = PI, hi = PI;
+    for (int k = 0; k < nv; ++k) for (int j = 0; j < nr; ++j) {
+        const double wx = p[0] - ov[k].x + (cs * rv[j].x - sn * rv[j].y), wy = p[1] - ov[k].y + (sn * rv[j].x + cs * rv[j].y);
+        const double cj = xi[0] * rv[j].x + xi[1] * rv[j].y + kappa0 + off;
+        const double nw = hypot(wx, wy);
+        if (!(nw > 0)) { if (cj < 0) return 0; continue; }
+        const double q = -cj / nw;
+        if (q >= 1.0) return 0;
+        if (q <= -1.0) continue;
+        const double beta = acos(q);
+        double d = th0 - atan2(wy, wx);
+        d = fmod(d + PI, 2 * PI); if (d < 0) d += 2 * PI; d -= PI;
+        if (fabs(d) > beta) return 0;
+        if (beta - d < hi) hi = beta - d;
+        if (beta + d < lo) lo = beta + d;
+    }
+    if (hi >= PI && lo >= PI) return 0;
+    const double thc = th0 + 0.5 * (hi - lo), a0 = cos(thc), a1 = sin(thc);
+    for (int i = 0; i < E; ++i) lam[i] = 0;
+    for (int j = 0; j < R; ++j) mu[j] = 0;
+    if (cone_norm2) { lam[0] = a0; lam[1] = a1; lam[2] = -1.0; }
+    else {
+        int kb = 0; double best = -INFINITY;
+        for (int k = 0; k < nv; ++k) { double v = a0 * ov[k].x + a1 * ov[k].y; if (v > best) { best = v; kb = k; } }
+        const int i1 = ov[kb].i1, i2 = ov[kb].i2;
+        const double det = A[2 * i1] * A[2 * i2 + 1] - A[2 * i1 + 1] * A[2 * i2];
+        lam[i1] = (a0 * A[2 * i2 + 1] - A[2 * i2] * a1) / det;          /* A_S' lam_S = a */
+        lam[i2] = (A[2 * i1] * a1 - a0 * A[2 * i1 + 1]) / det;
+    }
+    const double gx = -(cs * a0 + sn * a1) - xi[0], gy = -(-sn * a0 + cs * a1) - xi[1];    /* g = -R'a - xi */
+    {
+        int jb = 0; double best = -INFINITY;
+        for (int j = 0; j < nr; ++j) { double v = gx * rv[j].x + gy * rv[j].y; if (v > best) { best = v; jb = j; } }
+        const int j1 = rv[jb].i1, j2 = rv[jb].i2;
+        const double det = G[2 * j1] * G[2 * j2 + 1] - G[2 * j1 + 1] * G[2 * j2];
+        mu[j1] = (gx * G[2 * j2 + 1] - G[2 * j2] * gy) / det;
+        mu[j2] = (G[2 * j1] * gy - gx * G[2 * j1 + 1]) / det;
+    }
+    if (!cone_norm2) for (int i = 0; i < E; ++i) { if (lam[i] < -1e-9) return 0; if (lam[i] < 0) lam[i] = 0; }
+    for (int j = 0; j < R; ++j) { if (mu[j] < -1e-9) return 0; if (mu[j] < 0) mu[j] = 0; }
+    double m = kappa0;
+    for (int i = 0; i < E; ++i) m += lam[i] * (A[2 * i] * p[0] + A[2 * i + 1] * p[1] - b[i]);
+    for (int j = 0; j < R; ++j) m -= mu[j] * h[j];
+    if (m < 0) return 0;
+    *m_out = m;
+    return 1;
+}
+
 int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm2,
                    const double *p, double phi, const double *G, const double *h,
                    const double *xi, double zeta, double dbar, double ro2, double delta,
@@ -368,6 +453,19 @@ int orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_norm
         }
         }
     }
+    }
+    /* tie-break T1 (slack regime): central separating normal instead of the max-clearance one */
+    if (g_centre && best_m > 0 && best_H[0] * best_H[0] + best_H[1] * best_H[1] < 1e-8) {
+        double as[2] = {0, 0}, lc[EMAX], mc_[RMAX], mm;
+        for (int i = 0; i < E; ++i) { as[0] += lam_out[i] * A[2 * i]; as[1] += lam_out[i] * A[2 * i + 1]; }
+        if (as[0] * as[0] + as[1] * as[1] >= 1.0 - 1e-9 &&      /* a* on the unit circle: it has a direction */
+            central_normal(E, R, A, b, cone_norm2, p, cs, sn, G, h, xi, c.kappa0, as, lc, mc_, &mm)) {
+            for (int i = 0; i < E; ++i) lam_out[i] = lc[i];
+            for (int j = 0; j < R; ++j) mu_out[j] = mc_[j];
+            best_m = mm; best_H[0] = c.xi[0]; best_H[1] = c.xi[1];
+            for (int i = 0; i < E; ++i) { best_H[0] += lc[i] * c.M[i][0]; best_H[1] += lc[i] * c.M[i][1]; }
+            for (int j = 0; j < R; ++j) { best_H[0] += mc_[j] * G[2 * j]; best_H[1] += mc_[j] * G[2 * j + 1]; }
+        }
     }
     *z_out = (accelerated ? 0.5 : 1.0) * (best_m > 0 ? best_m : 0);          /* tie-break T2 */
     if (cmh) { cmh[0] = best_cost; cmh[1] = best_m; cmh[2] = best_H[0]; cmh[3] = best_H[1]; }

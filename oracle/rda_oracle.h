@@ -48,6 +48,7 @@ void orc_destroy(orc_handle *h);
 int  orc_set_adjust(orc_handle *h, double slack_gain, double max_sd, double min_sd, double ro1, double ro2);
 int  orc_reset(orc_handle *h);      /* rda_solver.py:1060-1068 */
 void orc_set_threads(int n);
+void orc_set_centre(int on);   /* tie-break T1: 1 (default) central separating normal in the slack regime, 0 max clearance */
 
 /* One MPC step == RDA_solver.iterative_solve (rda_solver.py:573-610).
  * nom_s 3x(T+1) row-major, nom_u 2xT, ref_s 3x(T+1); obstacles: n_obs entries,

@@ -65,9 +65,14 @@ def _kkt_residual(A, b, p, phi, xi, zeta, dbar, lam, mu, ro2=1.0, delta=1e-6):
 
 
 def test_kkt_certificate_polygons(orc):
+    """the enumeration (tie-break T1 = max clearance, i.e. the delta-perturbed problem) returns a KKT point"""
     rng = np.random.default_rng(3)
     inp = hp.lammuz_batch_inputs(rng, 400, circles=0.0)
-    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    orc.lib.orc_set_centre(0)
+    try:
+        lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    finally:
+        orc.lib.orc_set_centre(1)
     worst = 0.0
     for i in range(400):
         worst = max(worst, _kkt_residual(inp["A"][i], inp["b"][i], inp["p"][i], inp["phi"][i], inp["xi"][i],
@@ -159,6 +164,68 @@ def test_circle_value_not_worse_than_scipy(orc):
     assert n_interior >= 3, n_interior
 
 
+def test_central_normal_rule(orc):
+    """tie-break T1 in the slack regime (the default): whenever the max-clearance optimum has m > 0 and H ~ 0, the duals
+    returned are an optimal point of the REFERENCE problem (cost 0: H = 0, m >= 0, cone and norm constraints hold) whose
+    unit normal sits in the middle of the arc of separating directions - checked against a brute-force scan of that arc"""
+    rng = np.random.default_rng(12)
+    inp = hp.lammuz_batch_inputs(rng, 300, circles=0.3)
+    orc.lib.orc_set_centre(0)
+    lam0, mu0, z0, cmh0 = hp.oracle_lammuz_batch(orc, inp)
+    orc.lib.orc_set_centre(1)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    n_central = 0
+    for i in range(300):
+        A, b, p, phi, xi = inp["A"][i], inp["b"][i], inp["p"][i], inp["phi"][i], inp["xi"][i]
+        a0 = A.T @ lam0[i]
+        slack = cmh0[i, 1] > 0 and cmh0[i, 2] ** 2 + cmh0[i, 3] ** 2 < 1e-8 and a0 @ a0 >= 1 - 1e-9
+        changed = np.abs(lam[i] - lam0[i]).max() > 1e-12
+        if not slack:
+            assert not changed
+            continue
+        if not changed:
+            continue                                         # full-circle arc or a symmetric configuration
+        n_central += 1
+        c, s = np.cos(phi), np.sin(phi)
+        Rm = np.array([[c, -s], [s, c]])
+        kappa0 = inp["zeta"][i] - inp["dbar"][i]
+        a = A.T @ lam[i]
+        assert abs(np.hypot(*a) - 1) < 1e-9 and (mu[i] >= 0).all()
+        if inp["cone"][i]:
+            assert lam[i, 2] <= -np.hypot(lam[i, 0], lam[i, 1]) + 1e-12
+        else:
+            assert (lam[i] >= 0).all()
+        Hc = (A @ Rm).T @ lam[i] + hp.G.T @ mu[i] + xi
+        m = lam[i] @ (A @ p - b) - mu[i] @ hp.H + kappa0
+        assert np.abs(Hc).max() < 1e-9 and -1e-12 <= m <= cmh0[i, 1] + 1e-5 and abs(m - cmh[i, 1]) < 1e-9
+        assert abs(z[i] - 0.5 * m) < 1e-12                   # T2 on the new m
+
+        def clear(th):                                       # clearance of the unit normal a(th) with H = 0 duals
+            aa = np.array([np.cos(th), np.sin(th)])
+            if inp["cone"][i]:
+                so = aa @ b[0:2] - b[2]                      # support of the disc: c'a + r
+            else:
+                so = max(aa @ np.array(v[:2]) for v in _verts(A, b))
+            g = -(Rm.T @ aa) - xi
+            sr = max(g @ np.array(v[:2]) for v in _verts(hp.G, hp.H))
+            return aa @ p - so - sr + kappa0
+        th0 = np.arctan2(*(A.T @ lam0[i])[::-1])
+        thc = np.arctan2(a[1], a[0])
+        step = 2 * np.pi / 20000
+        up = next(k for k in range(1, 20001) if clear(th0 + k * step) < 0) * step
+        dn = next(k for k in range(1, 20001) if clear(th0 - k * step) < 0) * step
+        mid = th0 + 0.5 * (up - dn)
+        assert abs((thc - mid + np.pi) % (2 * np.pi) - np.pi) < 2 * step, (i, thc, mid)
+        if n_central >= 40:
+            break
+    assert n_central >= 20
+
+
+def _verts(A, b):
+    from oracle.lammuz_np import polygon_vertices
+    return polygon_vertices(np.asarray(A, float), np.asarray(b, float).ravel())
+
+
 KAT = [  # obstacle, robot pose (x, y, phi), distance  - SURVEY.md appendix B
     ("poly", (25, 26, 0.0), 2.2),
     ("poly", (25, 30, 0.7), 4.5949905),
@@ -184,8 +251,12 @@ def test_known_answer_distances(orc, kind, pose, dist):
         cone = 1
     inp = dict(A=A[None], b=b[None], cone=np.array([cone], np.int32), p=np.array([pose[:2]], float), phi=np.array([pose[2]]),
                xi=np.zeros((1, 2)), zeta=np.zeros(1), dbar=np.array([0.1]))
-    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
-    # T1 rewards clearance with delta = 1e-6, which buys delta*|x_R|^2/ro2 <= 1.6e-5 of extra m for H = -delta/ro2 * x_R
+    orc.lib.orc_set_centre(0)
+    try:
+        lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp)
+    finally:
+        orc.lib.orc_set_centre(1)
+    # max clearance is rewarded with delta = 1e-6, which buys delta*|x_R|^2/ro2 <= 1.6e-5 of extra m for H = -delta/ro2 * x_R
     assert abs(cmh[0, 1] + 0.1 - dist) < 3e-5
     assert abs(np.linalg.norm(A.T @ lam[0]) - 1) < 1e-9
 
