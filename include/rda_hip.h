@@ -69,7 +69,11 @@ int  rda_set_adjust(rda_handle *h, double slack_gain, double max_sd, double min_
 int  rda_reset(rda_handle *h);
 const char *rda_strerror(int code);
 int  rda_device_count(void);
-int  rda_set_device(int dev);     /* device used by handles created afterwards (one process per GPU) */
+int  rda_set_device(int dev);
+/* Tie-break T1 for the (degenerate) slack regime of the LamMuZ problem, where every (lam, mu) with H = 0 and m >= 0 is
+ * optimal: 1 (default) = duals of the unit normal in the middle of the arc of separating directions, 0 = max-clearance
+ * duals.  Process-wide; read by rda_create and rda_lammuz_batch. */
+void rda_set_tie_centre(int on);     /* device used by handles created afterwards (one process per GPU) */
 
 /* One MPC step, host buffers: nom_s 3x(T+1), nom_u 2xT, ref_s 3x(T+1) row-major;
  * obstacles A [n_obs][per_t? T+1 : 1][E][2], b [n_obs][per_t? T+1 : 1][E], cone [n_obs] (0 Rpositive, 1 norm2);

@@ -27,11 +27,14 @@ struct WaveLDS {            // one slab per wave (stage-local obstacle data)
     double q[EMAX];
     double M[EMAX][2];
     unsigned char lamc[40];            // surviving lam support candidates (original indices), heavy types first
+    double vtx[28][2];                 // polygon vertices of the surviving pairs, in list order (= lamc[0..npv))
+    int npv, nlv;                      // number of vertex pairs / of all lam candidates
 };
 struct RobotLDS {           // one per block
     double G[RMAX][2];
     double h[RMAX];
     unsigned char muc[40]; int nmv;    // surviving mu support candidates (robot geometry only: built once on the host)
+    double rv[28][2]; int nrv;         // robot vertices of the surviving pairs, in list order (= muc[0..nrv))
 };
 
 struct Sol {
@@ -348,60 +351,60 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
     return finish(W, Rb, P, mc, type, ic, i1, i2, la1, la2, ga0, ga1, s);
 }
 
-// Whole-wave solve.  All 64 lanes must call; W.A/W.b and Rb must be filled and visible.  On return
-// every lane holds the winning solution in `best`.
-__device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, Sol &best)
+// Per-wave preparation, all 64 lanes: q = A p - b, M = A R, and the lam candidate list.  A two-element support {i1,i2}
+// can only be optimal if the intersection of its two lines is a vertex of the polygon (the optimal lam is LP-optimal
+// for its a = A'lam, and an optimal basis is primal feasible); same for the robot (list built once on the host).
+// Infeasible pairs and null rows are dropped up front, so the lane loop of solve_wave runs over the survivors only: a
+// quadrilateral x rectangle problem shrinks from 121 to 81 candidates per hinge state, a triangle from 121 to 63 (one
+// lane pass).  Pairs first: the last pass then carries only the cheap types.  The vertices are kept for the
+// central-normal rule.
+__device__ __forceinline__ void prepare_wave(WaveLDS &W, const Params &P, int lane)
 {
-    // q = A p - b ; M = A R  (lanes < E)
-    if (lane < P.E) {
+    const int E = P.E;
+    if (lane < E) {
         double ax = W.A[lane][0], ay = W.A[lane][1];
         W.q[lane] = ax * P.px + ay * P.py - W.b[lane];
         W.M[lane][0] = ax * P.cs + ay * P.sn;
         W.M[lane][1] = -ax * P.sn + ay * P.cs;
     }
-    __builtin_amdgcn_wave_barrier();
-    const int nm = 1 + P.R + P.R * (P.R - 1) / 2;            // original candidate numbering (ids, tie-break T3)
-    // ---- candidate lists.  A two-element support {i1,i2} can only be optimal if the intersection of its two lines is a
-    // vertex of the polygon (the optimal lam is LP-optimal for its a = A'lam, and an optimal basis is primal
-    // feasible); same for the robot.  Infeasible pairs and null rows are dropped up front, so the lane loop runs over
-    // the survivors only: a quadrilateral x rectangle problem shrinks from 121 to 81 candidates per hinge state, a
-    // triangle from 121 to 63 (one lane pass).  Pairs first: the last pass then carries only the cheap types.
-    int nlv, nmv;
-    {
-        const int E = P.E, R = P.R;
-        if (P.norm2) {
-            if (lane == 0) { W.lamc[0] = 1; W.lamc[1] = 2; W.lamc[2] = 0; }
-            nlv = 3;
-        } else {
-            bool vp = false;
-            if (lane < E * (E - 1) / 2) {
-                int i1, i2; decode_pair(lane, E, i1, i2);
-                const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1];
-                const double det = a00 * a11 - a01 * a10;
-                if (det != 0 && det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11)) {
-                    // v det = (b1 a11 - a01 b2, a00 b2 - b1 a10);  A_k v - b_k <= tol  <=>  sign(det) (A_k (v det) - b_k det) <= tol |det|
-                    const double wx = W.b[i1] * a11 - a01 * W.b[i2], wy = a00 * W.b[i2] - W.b[i1] * a10, sg = det > 0 ? 1.0 : -1.0, ad = fabs(det);
-                    vp = true;
-                    for (int k = 0; k < E; ++k) {
-                        const double ak0 = W.A[k][0], ak1 = W.A[k][1], bk = W.b[k];
-                        const double viol = sg * (ak0 * wx + ak1 * wy - bk * det);
-                        if (viol > 1e-9 * (ad + fabs(bk) * ad + fabs(ak0 * wx) + fabs(ak1 * wy))) vp = false;
-                    }
+    if (P.norm2) {
+        if (lane == 0) { W.lamc[0] = 1; W.lamc[1] = 2; W.lamc[2] = 0; W.npv = 0; W.nlv = 3; }
+    } else {
+        bool vp = false; double vx = 0, vy = 0;
+        if (lane < E * (E - 1) / 2) {
+            int i1, i2; decode_pair(lane, E, i1, i2);
+            const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1];
+            const double det = a00 * a11 - a01 * a10;
+            if (det != 0 && det * det > 1e-24 * (a00 * a00 + a01 * a01) * (a10 * a10 + a11 * a11)) {
+                // v det = (b1 a11 - a01 b2, a00 b2 - b1 a10);  A_k v - b_k <= tol  <=>  sign(det) (A_k (v det) - b_k det) <= tol |det|
+                const double wx = W.b[i1] * a11 - a01 * W.b[i2], wy = a00 * W.b[i2] - W.b[i1] * a10, sg = det > 0 ? 1.0 : -1.0, ad = fabs(det);
+                vp = true;
+                for (int k = 0; k < E; ++k) {
+                    const double ak0 = W.A[k][0], ak1 = W.A[k][1], bk = W.b[k];
+                    const double viol = sg * (ak0 * wx + ak1 * wy - bk * det);
+                    if (viol > 1e-9 * (ad + fabs(bk) * ad + fabs(ak0 * wx) + fabs(ak1 * wy))) vp = false;
                 }
+                vx = wx / det; vy = wy / det;
             }
-            const bool vs = lane < E && (W.A[lane < E ? lane : 0][0] != 0 || W.A[lane < E ? lane : 0][1] != 0);
-            const unsigned long long bp = __ballot(vp), bs = __ballot(vs), below = (1ull << lane) - 1;
-            const int npv = __popcll(bp), nsv = __popcll(bs);
-            if (vp) W.lamc[__popcll(bp & below)] = (unsigned char)(1 + E + lane);
-            if (vs) W.lamc[npv + __popcll(bs & below)] = (unsigned char)(1 + lane);
-            if (lane == 0) W.lamc[npv + nsv] = 0;
-            nlv = npv + nsv + 1;
         }
-        nmv = Rb.nmv;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool vs = lane < E && (W.A[lane < E ? lane : 0][0] != 0 || W.A[lane < E ? lane : 0][1] != 0);
+        const unsigned long long bp = __ballot(vp), bs = __ballot(vs), below = (1ull << lane) - 1;
+        const int npv = __popcll(bp), nsv = __popcll(bs);
+        if (vp) { const int k = __popcll(bp & below); W.lamc[k] = (unsigned char)(1 + E + lane); W.vtx[k][0] = vx; W.vtx[k][1] = vy; }
+        if (vs) W.lamc[npv + __popcll(bs & below)] = (unsigned char)(1 + lane);
+        if (lane == 0) { W.lamc[npv + nsv] = 0; W.npv = npv; W.nlv = npv + nsv + 1; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Whole-wave enumeration.  All 64 lanes must call after prepare_wave.  On return every lane holds the winning
+// solution in `best`.
+__device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, Sol &best)
+{
+    const int nm = 1 + P.R + P.R * (P.R - 1) / 2;            // original candidate numbering (ids, tie-break T3)
+    const int nlv = W.nlv, nmv = Rb.nmv;
     const int half = nlv * nmv;
     best.cost = INFINITY; best.id = 0x7fffffff;
     best.m = 0; best.H0 = 0; best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
@@ -449,7 +452,7 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
 // two hinge states, every lane then checks the optimality conditions of the FULL problem for the result
 // (lam_i >= 0 : g_i + nu A_i'a^ >= 0 off the support, mu_j >= 0 : g_j >= 0 off the support, nu >= 0 for |A'lam| <= 1).
 // The problem is convex, so a point that passes is a global minimiser and the enumeration is skipped; any doubt
-// (sign, tolerance, circle obstacle, more than two non-zeros) falls back to solve_wave.  `prev` is this lane's
+// (sign, tolerance, circle obstacle, more than two non-zeros) falls back to solve_wave.  Call after prepare_wave.  `prev` is this lane's
 // previous value: lam[lane] for lane < E, mu[lane - E] for E <= lane < E + R.
 __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, double prev, Sol &best)
 {
@@ -466,14 +469,6 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
         return 1 + n + (i1 * (2 * n - i1 - 1)) / 2 + (i2 - i1 - 1);
     };
     const int il = cand_of(nzl, E), im = cand_of(nzm, R);
-    // q = A p - b ; M = A R  (lanes < E) - solve_wave recomputes the same values if we fall back
-    if (lane < E) {
-        double ax = W.A[lane][0], ay = W.A[lane][1];
-        W.q[lane] = ax * P.px + ay * P.py - W.b[lane];
-        W.M[lane][0] = ax * P.cs + ay * P.sn;
-        W.M[lane][1] = -ax * P.sn + ay * P.cs;
-    }
-    __builtin_amdgcn_wave_barrier();
     Sol s; s.m = 0; s.H0 = s.H1 = 0; s.i1 = s.i2 = s.j1 = s.j2 = -1; s.l1 = s.l2 = s.g1 = s.g2 = 0; s.cost = 0; s.id = 0;
     bool ok = false;
     if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);
@@ -522,6 +517,99 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
         pass = (j == best.j1 || j == best.j2) ? fabs(gj) <= 1e3 * tol : gj >= -tol;
     }
     return __ballot(!pass) == 0;
+}
+
+// Tie-break T1 in the slack regime (every (lam, mu) with H = 0, m >= 0 is optimal for the reference's problem): replace
+// the max-clearance solution in `best` by the duals of the UNIT normal in the middle of the arc {theta : m(a(theta)) >= 0}
+// of all separating directions around it.  For unit a:  m(a) = min_{k,j} [a'(p - v_k + R r_j) + xi'r_j] + kappa0 (a circle
+// obstacle contributes its centre and -radius): one (obstacle vertex, robot vertex) pair per lane, its admissible arc is
+// centred at the direction of w_kj with half-width acos(-c_j/|w_kj|); the feasible arc is the intersection (two wave
+// minima).  Same steps as oracle/lammuz_np.py:central_normal.  All lanes call, after prepare_wave; `best` is wave-uniform.
+__device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, Sol &best)
+{
+    const double PI = 3.14159265358979323846;
+    if (!(best.m > 0) || !(best.H0 * best.H0 + best.H1 * best.H1 < 1e-8)) return false;
+    double as0 = 0, as1 = 0;
+    if (P.norm2) { if (best.i1 >= 0) { as0 = best.l1; as1 = best.l2; } }
+    else {
+        if (best.i1 >= 0) { as0 += best.l1 * W.A[best.i1][0]; as1 += best.l1 * W.A[best.i1][1]; }
+        if (best.i2 >= 0) { as0 += best.l2 * W.A[best.i2][0]; as1 += best.l2 * W.A[best.i2][1]; }
+    }
+    if (!(as0 * as0 + as1 * as1 >= 1.0 - 1e-9)) return false;          // a* on the unit circle: it has a direction
+    const int nv = P.norm2 ? 1 : W.npv, nr = Rb.nrv;
+    if (nr < 3 || (!P.norm2 && nv < 3) || nv * nr > 64) return false;
+    const double off = P.norm2 ? W.b[2] : 0.0, th0 = atan2(as1, as0);
+    bool fail = false; double hi = PI, lo = PI;
+    if (lane < nv * nr) {
+        const int k = lane / nr, j = lane - k * nr;
+        const double vx = P.norm2 ? W.b[0] : W.vtx[k][0], vy = P.norm2 ? W.b[1] : W.vtx[k][1];
+        const double rx = Rb.rv[j][0], ry = Rb.rv[j][1];
+        const double wx = P.px - vx + (P.cs * rx - P.sn * ry), wy = P.py - vy + (P.sn * rx + P.cs * ry);
+        const double cj = P.xi0 * rx + P.xi1 * ry + P.kappa0 + off;
+        const double nw = hypot(wx, wy);
+        if (!(nw > 0)) fail = cj < 0;
+        else {
+            const double q = -cj / nw;
+            if (q >= 1.0) fail = true;
+            else if (q > -1.0) {
+                const double beta = acos(q);
+                double d = fmod(th0 - atan2(wy, wx) + PI, 2 * PI);
+                if (d < 0) d += 2 * PI;
+                d -= PI;
+                if (fabs(d) > beta) fail = true;
+                else { hi = beta - d; lo = beta + d; }
+            }
+        }
+    }
+    if (__ballot(fail)) return false;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { double h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64); hi = h2 < hi ? h2 : hi; lo = l2 < lo ? l2 : lo; }
+    if (hi >= PI && lo >= PI) return false;
+    const double thc = th0 + 0.5 * (hi - lo), a0 = cos(thc), a1 = sin(thc);
+    // supporting duals: lam for a, mu for g = -R'a - xi  (argmax over the vertices, lowest index on ties)
+    int i1 = -1, i2 = -1; double l1 = 0, l2 = 0;
+    if (P.norm2) { i1 = 0; i2 = 1; l1 = a0; l2 = a1; }
+    else {
+        double val = lane < nv ? a0 * W.vtx[lane < nv ? lane : 0][0] + a1 * W.vtx[lane < nv ? lane : 0][1] : -INFINITY, mx = val;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { double v2 = __shfl_xor(mx, o, 64); mx = v2 > mx ? v2 : mx; }
+        const int kb = __ffsll((long long)__ballot(val == mx)) - 1;
+        decode_pair((int)W.lamc[kb] - 1 - P.E, P.E, i1, i2);
+        const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1], det = a00 * a11 - a01 * a10;
+        l1 = (a0 * a11 - a10 * a1) / det;            // A_S' lam_S = a
+        l2 = (a00 * a1 - a0 * a01) / det;
+        if (l1 < -1e-9 || l2 < -1e-9) return false;
+        if (l1 < 0) l1 = 0;
+        if (l2 < 0) l2 = 0;
+    }
+    const double gx = -(P.cs * a0 + P.sn * a1) - P.xi0, gy = -(-P.sn * a0 + P.cs * a1) - P.xi1;
+    int j1, j2; double g1, g2;
+    {
+        double val = lane < nr ? gx * Rb.rv[lane < nr ? lane : 0][0] + gy * Rb.rv[lane < nr ? lane : 0][1] : -INFINITY, mx = val;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { double v2 = __shfl_xor(mx, o, 64); mx = v2 > mx ? v2 : mx; }
+        const int jb = __ffsll((long long)__ballot(val == mx)) - 1;
+        decode_pair((int)Rb.muc[jb] - 1 - P.R, P.R, j1, j2);
+        const double a00 = Rb.G[j1][0], a01 = Rb.G[j1][1], a10 = Rb.G[j2][0], a11 = Rb.G[j2][1], det = a00 * a11 - a01 * a10;
+        g1 = (gx * a11 - a10 * gy) / det;
+        g2 = (a00 * gy - gx * a01) / det;
+        if (g1 < -1e-9 || g2 < -1e-9) return false;
+        if (g1 < 0) g1 = 0;
+        if (g2 < 0) g2 = 0;
+    }
+    double m = P.kappa0 - g1 * Rb.h[j1] - g2 * Rb.h[j2];
+    double H0 = P.xi0 + g1 * Rb.G[j1][0] + g2 * Rb.G[j2][0], H1 = P.xi1 + g1 * Rb.G[j1][1] + g2 * Rb.G[j2][1];
+    if (P.norm2) {
+        m += l1 * W.q[0] + l2 * W.q[1] - W.q[2];
+        H0 += l1 * W.M[0][0] + l2 * W.M[1][0] - W.M[2][0]; H1 += l1 * W.M[0][1] + l2 * W.M[1][1] - W.M[2][1];
+    } else {
+        m += l1 * W.q[i1] + l2 * W.q[i2];
+        H0 += l1 * W.M[i1][0] + l2 * W.M[i2][0]; H1 += l1 * W.M[i1][1] + l2 * W.M[i2][1];
+    }
+    if (m < 0) return false;
+    best.i1 = i1; best.i2 = i2; best.l1 = l1; best.l2 = l2; best.j1 = j1; best.j2 = j2; best.g1 = g1; best.g2 = g2;
+    best.m = m; best.H0 = H0; best.H1 = H1;
+    return true;
 }
 
 // value of lam[e] / mu[j] encoded by a solution

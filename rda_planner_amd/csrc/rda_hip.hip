@@ -36,6 +36,8 @@ struct Dev {
     int nt;                  // time slots of the staged obstacles (T+1 or 1)
     int warm;                // k_lammuz tries the previous support first (RDA_LMZ_WARM=0 disables)
     unsigned char muc[40]; int nmv;   // robot support candidates that survive the vertex test (host, rda_create)
+    double rv[28][2]; int nrv;        // robot vertices of the surviving pairs (list order)
+    int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
     int obstacle_num;        // 0 or N
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = d.G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = d.h[threadIdx.x - 64];
     if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = d.muc[threadIdx.x - 128];
-    if (threadIdx.x == 192) rb.nmv = d.nmv;
+    if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
+    if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int w = blockIdx.x * 4 + wv;
     const bool live = w < d.Nloc * T;
     const int nl = live ? w / T : 0, t = live ? w % T : 0;
@@ -172,7 +175,9 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     double prev = 0.0;
     if (lane < E) prev = d.lam[o * E + lane];
     else if (lane < E + R) prev = d.mu[o * R + lane - E];
+    lmz::prepare_wave(W, P, lane);
     if (!d.warm || !lmz::solve_wave_warm(W, rb, P, lane, prev, best)) lmz::solve_wave(W, rb, P, lane, best);
+    if (d.centre) lmz::central_normal_wave(W, rb, P, lane, best);
     // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
     double res = 0;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     }
 }
 
-struct RobotCands { unsigned char muc[40]; int nmv; };
+struct RobotCands { unsigned char muc[40]; int nmv; double rv[28][2]; int nrv; int centre; };
 
 // pure-function batch hook (rda_lammuz_batch)
 __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int *cone,
@@ -227,7 +232,8 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
     if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = G[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = h[threadIdx.x - 64];
     if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = rc.muc[threadIdx.x - 128];
-    if (threadIdx.x == 192) rb.nmv = rc.nmv;
+    if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&rc.rv[0][0])[threadIdx.x - 192];
+    if (threadIdx.x == 255) { rb.nmv = rc.nmv; rb.nrv = rc.nrv; }
     const int w = blockIdx.x * 4 + wv;
     const bool live = w < B;
     const int k = live ? w : 0;
@@ -243,7 +249,9 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
     P.prof = (prof && w == 0) ? prof : nullptr;               // wave 0 of the batch reports its phase cycles
     if (P.prof && lane == 0) prof[0] += clock64() - t_begin;
     lmz::Sol best;
+    lmz::prepare_wave(W, P, lane);
     lmz::solve_wave(W, rb, P, lane, best);
+    if (rc.centre) lmz::central_normal_wave(W, rb, P, lane, best);
     if (P.prof && lane == 0) prof[7] += clock64() - t_begin;
     if (lane < E) lam[(size_t)k * E + lane] = lmz::lam_of(best, P.norm2, lane);
     else if (lane < E + R) mu[(size_t)k * R + lane - E] = lmz::mu_of(best, lane - E);
@@ -345,7 +353,10 @@ template <typename Tp> static int dalloc(Tp **p, size_t n)
 
 // mu support candidates of a polygon robot: pairs whose intersection is a vertex of the robot, then the non-null rows, then
 // the empty support (same rule and order as the lam lists built per wave in lmz::solve_wave)
-static int robot_candidates(int R, const double *G, const double *h, unsigned char *out)
+static int g_tie_centre = 1;
+extern "C" void rda_set_tie_centre(int on) { g_tie_centre = on ? 1 : 0; }
+
+static int robot_candidates(int R, const double *G, const double *h, unsigned char *out, double (*rv)[2], int *nrv)
 {
     int n = 0, p = 0;
     for (int j1 = 0; j1 < R; ++j1) for (int j2 = j1 + 1; j2 < R; ++j2, ++p) {
@@ -358,8 +369,9 @@ static int robot_candidates(int R, const double *G, const double *h, unsigned ch
             const double viol = sg * (G[2 * k] * wx + G[2 * k + 1] * wy - h[k] * det);
             if (viol > 1e-9 * (ad + fabs(h[k]) * ad + fabs(G[2 * k] * wx) + fabs(G[2 * k + 1] * wy))) ok = false;
         }
-        if (ok) out[n++] = (unsigned char)(1 + R + p);
+        if (ok) { rv[n][0] = wx / det; rv[n][1] = wy / det; out[n++] = (unsigned char)(1 + R + p); }
     }
+    *nrv = n;
     for (int j = 0; j < R; ++j) if (G[2 * j] != 0 || G[2 * j + 1] != 0) out[n++] = (unsigned char)(1 + j);
     out[n++] = 0;
     return n;
@@ -376,7 +388,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
     { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
-    H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc);
+    H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
+    H->d.centre = g_tie_centre;
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
@@ -887,7 +900,7 @@ extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const doub
                  {(void **)&dzeta, zeta, sB * 8}, {(void **)&ddbar, dbar, sB * 8} };
     for (auto &c : ins) { HIPCHK(hipMalloc(c.dst, c.bytes)); HIPCHK(hipMemcpy(*c.dst, c.src, c.bytes, hipMemcpyHostToDevice)); }
     HIPCHK(hipMalloc((void **)&dlam, sB * E * 8)); HIPCHK(hipMalloc((void **)&dmu, sB * R * 8)); HIPCHK(hipMalloc((void **)&dz, sB * 8)); HIPCHK(hipMalloc((void **)&dcmh, sB * 4 * 8));
-    RobotCands rcands; rcands.nmv = robot_candidates(R, G, h, rcands.muc);
+    RobotCands rcands; rcands.nmv = robot_candidates(R, G, h, rcands.muc, rcands.rv, &rcands.nrv); rcands.centre = g_tie_centre;
     long long *dprof = nullptr;
     if (getenv("RDA_LMZ_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 8 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 8 * sizeof(long long))); }
     hipLaunchKernelGGL(k_lammuz_batch, dim3((B + 3) / 4), dim3(256), 0, 0, B, E, R, dA, db, dcone, dp, dphi, dG, dh, dxi, dzeta, ddbar,
