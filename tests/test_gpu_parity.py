@@ -389,3 +389,34 @@ def test_su_hard_instances_from_the_soak_run(orc, hip, name):
     assert abs(so[4] - sh[4]) <= 1, (so[4], sh[4])
     for k in (1, 2, 3):
         assert np.abs(so[k] - sh[k]).max() < 1e-6
+
+
+def test_closed_loop_corridor_example():
+    """BASELINE config C2, the reference's corridor example with its default MPC parameters: the GPU path follows the
+    oracle step by step (state re-synchronised every step) AND, run on its own, slaloms through to the goal"""
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.mpc import MPC
+    car_a = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([0, 20, 0], [60, 20, 0], 0.1)
+    obs = sc.scene_corridor(n_extra=0)
+    kw = dict(max_edge_num=4, max_obs_num=6)
+    cpu, gpu = _pair(kw, car_a, path, oracle_backend)
+    state = np.array([[0.0], [20.0], [0.0]])
+    for i in range(120):
+        uc, ic = cpu.control(state.copy(), 4.0, list(obs))
+        ug, ig = gpu.control(state.copy(), 4.0, list(obs))
+        assert ic["iters"] == ig["iters"], i
+        assert np.abs(uc - ug).max() < 1e-6, (i, np.abs(uc - ug).max())
+        gpu.rda.set_state(cpu.rda.get_state())
+        gpu.cur_vel_array = cpu.cur_vel_array.copy()
+        state = sc.kinematic_step(state, uc, car_a, 0.1)
+    solo = MPC(car_a, [p.copy() for p in path], sample_time=0.1, **kw)
+    state = np.array([[0.0], [20.0], [0.0]])
+    minc = np.inf
+    for i in range(260):
+        u, info = solo.control(state, 4.0, list(obs))
+        state = sc.kinematic_step(state, u, car_a, 0.1)
+        minc = min(minc, sc.clearance(car_a, state, obs))
+        if info["arrive"]:
+            break
+    assert info["arrive"] and minc > 0.2, (info["arrive"], minc)

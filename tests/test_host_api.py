@@ -232,3 +232,25 @@ def test_headless_world_runs_the_example_loop():
     assert not env.collided and min_clear > 0.05
     assert np.linalg.norm(env.get_obstacle_info_list()[-1].center - moved) > 0.1      # the dynamic obstacles do move
     assert np.linalg.norm(env.robot.state[0:2] - np.array([[10.0], [42.0]])) > 15.0   # and the robot made progress
+
+
+def test_corridor_example_is_traversed():
+    """BASELINE config C2 (example/corridor/corridor.py:8-30, corridor.yaml:22-33): the straight reference path is blocked by
+    four boxes inside a 8 m wide corridor; with the reference's default MPC parameters the robot slaloms to the goal.
+    This is what tie-break T1 (central separating normal in the slack regime) is for: with max-clearance duals the
+    approach is head-on and the robot pushes into the first box at step 17."""
+    car_a = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([0, 20, 0], [60, 20, 0], 0.1)
+    obs = sc.scene_corridor(n_extra=0)
+    mpc = MPC(car_a, [p.copy() for p in path], sample_time=0.1, max_edge_num=4, max_obs_num=6, _backend=oracle_backend)
+    state = np.array([[0.0], [20.0], [0.0]])
+    minc, ys = np.inf, []
+    for i in range(260):
+        u, info = mpc.control(state, 4, list(obs))
+        state = sc.kinematic_step(state, u, car_a, 0.1)
+        minc = min(minc, sc.clearance(car_a, state, obs))
+        ys.append(state[1, 0])
+        if info["arrive"]:
+            break
+    assert info["arrive"] and minc > 0.2, (info["arrive"], minc)
+    assert max(ys) > 21.3 and min(ys) < 19.3                       # it went above the first box and below the second
