@@ -527,7 +527,6 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
 // minima).  Same steps as oracle/lammuz_np.py:central_normal.  All lanes call, after prepare_wave; `best` is wave-uniform.
 __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, Sol &best)
 {
-    const double PI = 3.14159265358979323846;
     if (!(best.m > 0) || !(best.H0 * best.H0 + best.H1 * best.H1 < 1e-8)) return false;
     double as0 = 0, as1 = 0;
     if (P.norm2) { if (best.i1 >= 0) { as0 = best.l1; as1 = best.l2; } }
@@ -538,34 +537,50 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     if (!(as0 * as0 + as1 * as1 >= 1.0 - 1e-9)) return false;          // a* on the unit circle: it has a direction
     const int nv = P.norm2 ? 1 : W.npv, nr = Rb.nrv;
     if (nr < 3 || (!P.norm2 && nv < 3) || nv * nr > 64) return false;
-    const double off = P.norm2 ? W.b[2] : 0.0, th0 = atan2(as1, as0);
-    bool fail = false; double hi = PI, lo = PI;
+    // The oracle does this with atan2 / acos; here the same arc arithmetic is carried out on unit vectors (no
+    // trigonometric calls): the end points of a pair's arc are w^ rotated by -+beta (cos beta = q), the room from a* to an
+    // end point is an angle in [0, pi] iff the cross product is >= 0, and tan(angle/2) = sin/(1 + cos) orders such angles
+    // accurately even when they are tiny.
+    const double off = P.norm2 ? W.b[2] : 0.0;
+    const double ins = rsqrt(as0 * as0 + as1 * as1), u0 = as0 * ins, u1 = as1 * ins;
+    bool fail = false; double thi = INFINITY, tlo = INFINITY;           // tan(hi/2), tan(lo/2); INFINITY = the cap hi = lo = pi
     if (lane < nv * nr) {
         const int k = lane / nr, j = lane - k * nr;
         const double vx = P.norm2 ? W.b[0] : W.vtx[k][0], vy = P.norm2 ? W.b[1] : W.vtx[k][1];
         const double rx = Rb.rv[j][0], ry = Rb.rv[j][1];
         const double wx = P.px - vx + (P.cs * rx - P.sn * ry), wy = P.py - vy + (P.sn * rx + P.cs * ry);
         const double cj = P.xi0 * rx + P.xi1 * ry + P.kappa0 + off;
-        const double nw = hypot(wx, wy);
-        if (!(nw > 0)) fail = cj < 0;
+        const double n2 = wx * wx + wy * wy;
+        if (!(n2 > 0)) fail = cj < 0;
         else {
-            const double q = -cj / nw;
+            const double inw = rsqrt(n2), q = -cj * inw, hx = wx * inw, hy = wy * inw;
             if (q >= 1.0) fail = true;
             else if (q > -1.0) {
-                const double beta = acos(q);
-                double d = fmod(th0 - atan2(wy, wx) + PI, 2 * PI);
-                if (d < 0) d += 2 * PI;
-                d -= PI;
-                if (fabs(d) > beta) fail = true;
-                else { hi = beta - d; lo = beta + d; }
+                if (u0 * hx + u1 * hy < q - 1e-15) fail = true;                  // a* itself must separate at unit length
+                else {
+                    const double sb = sqrt((1.0 - q) * (1.0 + q));
+                    const double epx = q * hx - sb * hy, epy = sb * hx + q * hy;  // w^ rotated by +beta: upper end of the arc
+                    const double emx = q * hx + sb * hy, emy = -sb * hx + q * hy; // w^ rotated by -beta: lower end
+                    const double cp = u0 * epx + u1 * epy, sp = u0 * epy - u1 * epx;     // angle a* -> upper end
+                    const double cm = u0 * emx + u1 * emy, sm = emx * u1 - emy * u0;     // angle lower end -> a*
+                    if (sp >= 0 && cp > -1.0) thi = sp / (1.0 + cp);
+                    else if (sp < 0 && sp > -1e-15) thi = 0.0;                    // a* on the upper end up to rounding
+                    if (sm >= 0 && cm > -1.0) tlo = sm / (1.0 + cm);
+                    else if (sm < 0 && sm > -1e-15) tlo = 0.0;
+                }
             }
         }
     }
     if (__ballot(fail)) return false;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { double h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64); hi = h2 < hi ? h2 : hi; lo = l2 < lo ? l2 : lo; }
-    if (hi >= PI && lo >= PI) return false;
-    const double thc = th0 + 0.5 * (hi - lo), a0 = cos(thc), a1 = sin(thc);
+    for (int o = 32; o >= 1; o >>= 1) { double h2 = __shfl_xor(thi, o, 64), l2 = __shfl_xor(tlo, o, 64); thi = h2 < thi ? h2 : thi; tlo = l2 < tlo ? l2 : tlo; }
+    if (isinf(thi) && isinf(tlo)) return false;
+    // a_c = a* rotated by (hi - lo)/2, from the half-angle tangents
+    double chh, shh, chl, shl;
+    if (isinf(thi)) { chh = 0; shh = 1; } else { const double r = rsqrt(1.0 + thi * thi); chh = r; shh = thi * r; }
+    if (isinf(tlo)) { chl = 0; shl = 1; } else { const double r = rsqrt(1.0 + tlo * tlo); chl = r; shl = tlo * r; }
+    const double Cr = chh * chl + shh * shl, Sr = shh * chl - chh * shl;
+    const double a0 = u0 * Cr - u1 * Sr, a1 = u1 * Cr + u0 * Sr;
     // supporting duals: lam for a, mu for g = -R'a - xi  (argmax over the vertices, lowest index on ties)
     int i1 = -1, i2 = -1; double l1 = 0, l2 = 0;
     if (P.norm2) { i1 = 0; i2 = 1; l1 = a0; l2 = a1; }
