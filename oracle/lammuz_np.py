@@ -17,9 +17,11 @@ only sees 3 linear functionals of the 9+ unknowns), so ECOS
 returns an interior point of the optimal face.  PARITY UNPINNED: cvxpy/ecos are
 not installable here, so this restatement fixes the tie-break explicitly:
 
-  (T1) among the minimisers, (lam, mu) maximise the linearised clearance
-       m = lam'(A p - b) - mu'h   -> implemented as the extra cost -delta*m with
-       delta = 1e-6 (perturbs the reference optimum by O(delta));
+  (T1) slack regime (some (lam, mu) reaches H = 0 with m >= 0: every such point is optimal): the duals that support
+       the UNIT normal in the middle of the arc of all separating directions (`central_normal`); the arc is taken
+       around the max-clearance normal a*, which the enumeration below delivers by solving the problem with the extra
+       cost -delta*m, delta = 1e-6 (perturbs the reference optimum by O(delta)).  Outside the slack regime the
+       optimum is unique and the enumeration result is final;
   (T2) z = 1/2 * max(Im|z=0, 0) in accelerated mode (mid-point of its optimal
        interval [0, Im+]);  z = max(Im|z=0, 0) when accelerated=False, where
        that value is the unique minimiser;

@@ -11,6 +11,8 @@
 // cost of every sign-feasible candidate and takes the wave-wide arg-min (ties: lowest candidate
 // id).  No iteration over the problem, no divergence across sub-problems, no global scratch:
 // the obstacle half-spaces and the derived q, M live in the wave's LDS slab.
+// Around the enumeration: prepare_wave (candidate pruning), solve_wave_warm (previous support + optimality certificate)
+// and central_normal_wave (tie-break T1 of the degenerate slack regime).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
