@@ -360,16 +360,21 @@ __device__ __forceinline__ bool eval_candidate(const WaveLDS &W, const RobotLDS 
 // quadrilateral x rectangle problem shrinks from 121 to 81 candidates per hinge state, a triangle from 121 to 63 (one
 // lane pass).  Pairs first: the last pass then carries only the cheap types.  The vertices are kept for the
 // central-normal rule.
-__device__ __forceinline__ void prepare_wave(WaveLDS &W, const Params &P, int lane)
+// q = A p - b ; M = A R  (lanes < E; the caller synchronises the wave afterwards)
+__device__ __forceinline__ void pose_products(WaveLDS &W, const Params &P, int lane)
 {
-    const int E = P.E;
-    if (lane < E) {
+    if (lane < P.E) {
         double ax = W.A[lane][0], ay = W.A[lane][1];
         W.q[lane] = ax * P.px + ay * P.py - W.b[lane];
         W.M[lane][0] = ax * P.cs + ay * P.sn;
         W.M[lane][1] = -ax * P.sn + ay * P.cs;
     }
-    if (P.norm2) {
+}
+
+// candidate list + vertices of the obstacle in W.A / W.b (pose independent: k_prepare caches it per obstacle slot)
+__device__ __forceinline__ void build_lists(WaveLDS &W, int E, int norm2, int lane)
+{
+    if (norm2) {
         if (lane == 0) { W.lamc[0] = 1; W.lamc[1] = 2; W.lamc[2] = 0; W.npv = 0; W.nlv = 3; }
     } else {
         bool vp = false; double vx = 0, vy = 0;
@@ -396,9 +401,20 @@ __device__ __forceinline__ void prepare_wave(WaveLDS &W, const Params &P, int la
         if (vs) W.lamc[npv + __popcll(bs & below)] = (unsigned char)(1 + lane);
         if (lane == 0) { W.lamc[npv + nsv] = 0; W.npv = npv; W.nlv = npv + nsv + 1; }
     }
+}
+
+__device__ __forceinline__ void wave_sync()
+{
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void prepare_wave(WaveLDS &W, const Params &P, int lane)
+{
+    pose_products(W, P, lane);
+    build_lists(W, P.E, P.norm2, lane);
+    wave_sync();
 }
 
 // Whole-wave enumeration.  All 64 lanes must call after prepare_wave.  On return every lane holds the winning

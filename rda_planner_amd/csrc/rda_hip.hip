@@ -41,6 +41,8 @@ struct Dev {
     int obstacle_num;        // 0 or N
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
+    // per (slot, time slot) candidate list and vertices of the staged obstacle (pose independent): k_prepare, at upload
+    unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][40], [N*nt][28][2], [N*nt][2] = (npv, nlv)
     double *lam, *mu, *z, *xi, *zeta, *dis;   // reference-shaped dual state
     // Condensed su terms + residual partials, one chunk per obstacle shard (P = 1 on a single GPU):
     //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0..5 -> ax ay blam ee gx gy,  k = 6,7 -> residual partials
@@ -129,6 +131,25 @@ __global__ void k_begin(Dev d)
 
 // ------------------------------------------------------------------------------------------------
 // K1: one wavefront per (obstacle n, stage t); 4 wavefronts per workgroup.
+// candidate list + vertices of every staged obstacle slot (one wave per (slot, time slot)); runs once per upload
+__global__ __launch_bounds__(256) void k_prepare(Dev d)
+{
+    __shared__ lmz::WaveLDS wl[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, E = d.c.E;
+    const int w = blockIdx.x * 4 + wv;
+    if (w >= d.c.N * d.nt) return;
+    const int n = w / d.nt;
+    lmz::WaveLDS &W = wl[wv];
+    if (lane < 2 * E) W.A[lane >> 1][lane & 1] = d.A[(size_t)w * E * 2 + lane];
+    if (lane < E) W.b[lane] = d.b[(size_t)w * E + lane];
+    lmz::wave_sync();
+    lmz::build_lists(W, E, d.cone[n], lane);
+    lmz::wave_sync();
+    if (lane < 40) d.oc_lamc[(size_t)w * 40 + lane] = W.lamc[lane];
+    if (lane < 56) d.oc_vtx[(size_t)w * 56 + lane] = (&W.vtx[0][0])[lane];
+    if (lane == 0) { d.oc_cnt[2 * w] = W.npv; d.oc_cnt[2 * w + 1] = W.nlv; }
+}
+
 __global__ __launch_bounds__(256) void k_lammuz(Dev d)
 {
     __shared__ lmz::WaveLDS wl[4];
@@ -175,7 +196,14 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     double prev = 0.0;
     if (lane < E) prev = d.lam[o * E + lane];
     else if (lane < E + R) prev = d.mu[o * R + lane - E];
-    lmz::prepare_wave(W, P, lane);
+    lmz::pose_products(W, P, lane);
+    {   // candidate list and vertices of this slot from the upload-time cache
+        const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
+        if (lane < 40) W.lamc[lane] = d.oc_lamc[oc * 40 + lane];
+        if (lane < 56) (&W.vtx[0][0])[lane] = d.oc_vtx[oc * 56 + lane];
+        if (lane == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
+    }
+    lmz::wave_sync();
     if (!d.warm || !lmz::solve_wave_warm(W, rb, P, lane, prev, best)) lmz::solve_wave(W, rb, P, lane, best);
     if (d.centre) lmz::central_normal_wave(W, rb, P, lane, best);
     // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
@@ -398,6 +426,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
+    rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
     d.P = 1; d.rank = 0; d.Nloc = (int)N; d.chunk = 8 * T * N;
@@ -432,7 +461,7 @@ extern "C" void rda_destroy(rda_handle *H)
     (void)hipStreamSynchronize(H->stream);
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
-    void *ptrs[] = { d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
+    void *ptrs[] = { d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
                      d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_kind, H->d_sc_nvert, H->d_sc_sel, H->d_sc_bad, H->d_sc_geom, H->d_sc_vel, H->d_sc_robot, H->d_sc_key };
@@ -490,6 +519,7 @@ extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, c
     HIPCHK(hipMemcpyAsync(d.b, H->h_stage_b, N * nt * E * sizeof(double), hipMemcpyHostToDevice, H->stream));
     HIPCHK(hipMemcpyAsync(d.cone, H->h_stage_cone, N * sizeof(int), hipMemcpyHostToDevice, H->stream));
     d.nt = (int)nt; d.obstacle_num = (int)N;
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * nt + 3) / 4)), dim3(256), 0, H->stream, d);
     HIPCHK(hipStreamSynchronize(H->stream));      // staging buffers are reused by the next call
     return RDA_OK;
 }
@@ -554,8 +584,9 @@ extern "C" int rda_upload_scene(rda_handle *H, int n, const int32_t *kind, const
     hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
     hipLaunchKernelGGL(scene::k_rank, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
     hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, H->stream, a);
-    HIPCHK(hipGetLastError());
     d.nt = a.nt; d.obstacle_num = N;
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, H->stream, d);
+    HIPCHK(hipGetLastError());
     if (n_nonconvex) {
         HIPCHK(hipMemcpyAsync(H->h_sc, H->d_sc_bad, sizeof(int), hipMemcpyDeviceToHost, H->stream));
         HIPCHK(hipStreamSynchronize(H->stream));
