@@ -527,12 +527,15 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
     if (lane < E) {
         const double gi = glam(lane) + nu * (W.A[lane][0] * ux + W.A[lane][1] * uy);
         const double tol = 1e-10 * (1.0 + fabs(phim * W.q[lane]) + P.ro2 * (fabs(W.M[lane][0] * best.H0) + fabs(W.M[lane][1] * best.H1)));
-        pass = (lane == best.i1 || lane == best.i2) ? fabs(gi) <= 1e3 * tol : gi >= -tol;
+        // complementarity: a support entry that came out at its bound (0) is just an inactive-side constraint
+        const bool pos = (lane == best.i1 && best.l1 > 0) || (lane == best.i2 && best.l2 > 0);
+        pass = pos ? fabs(gi) <= 1e3 * tol : gi >= -tol;
     } else if (lane < E + R) {
         const int j = lane - E;
         const double gj = -phim * Rb.h[j] + P.ro2 * (Rb.G[j][0] * best.H0 + Rb.G[j][1] * best.H1);
         const double tol = 1e-10 * (1.0 + fabs(phim * Rb.h[j]) + P.ro2 * (fabs(Rb.G[j][0] * best.H0) + fabs(Rb.G[j][1] * best.H1)));
-        pass = (j == best.j1 || j == best.j2) ? fabs(gj) <= 1e3 * tol : gj >= -tol;
+        const bool pos = (j == best.j1 && best.g1 > 0) || (j == best.j2 && best.g2 > 0);
+        pass = pos ? fabs(gj) <= 1e3 * tol : gj >= -tol;
     }
     return __ballot(!pass) == 0;
 }
