@@ -470,23 +470,15 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
 // two hinge states, every lane then checks the optimality conditions of the FULL problem for the result
 // (lam_i >= 0 : g_i + nu A_i'a^ >= 0 off the support, mu_j >= 0 : g_j >= 0 off the support, nu >= 0 for |A'lam| <= 1).
 // The problem is convex, so a point that passes is a global minimiser and the enumeration is skipped; any doubt
-// (sign, tolerance, circle obstacle, more than two non-zeros) falls back to solve_wave.  Call after prepare_wave.  `prev` is this lane's
-// previous value: lam[lane] for lane < E, mu[lane - E] for E <= lane < E + R.
-__device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, double prev, Sol &best)
+// (sign, tolerance, circle obstacle, no hint yet) falls back to solve_wave.  Call after prepare_wave.  `hint` is the
+// candidate index il*n_mu + im remembered from the last solve of this (n, t) (-1: none); it is only a hint - whatever it
+// is, a result is accepted on the certificate alone.
+__device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, int hint, Sol &best)
 {
-    if (P.norm2) return false;
-    const int E = P.E, R = P.R;
-    const unsigned long long nzl = __ballot(lane < E && prev > 0.0), nzm = __ballot(lane >= E && lane < E + R && prev > 0.0) >> E;
-    if (__popcll(nzl) > 2 || __popcll(nzm) > 2) return false;
-    auto cand_of = [](unsigned long long bits, int n) {
-        if (!bits) return 0;
-        int i1 = __ffsll((long long)bits) - 1;
-        bits &= bits - 1;
-        if (!bits) return 1 + i1;
-        int i2 = __ffsll((long long)bits) - 1;
-        return 1 + n + (i1 * (2 * n - i1 - 1)) / 2 + (i2 - i1 - 1);
-    };
-    const int il = cand_of(nzl, E), im = cand_of(nzm, R);
+    if (P.norm2 || hint < 0) return false;
+    const int R = P.R, E = P.E, nm0 = 1 + R + R * (R - 1) / 2;
+    const int il = hint / nm0, im = hint - il * nm0;            // support of the last max-clearance optimum of this (n, t)
+    if (il >= 1 + E + E * (E - 1) / 2) return false;
     Sol s; s.m = 0; s.H0 = s.H1 = 0; s.i1 = s.i2 = s.j1 = s.j2 = -1; s.l1 = s.l2 = s.g1 = s.g2 = 0; s.cost = 0; s.id = 0;
     bool ok = false;
     if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);

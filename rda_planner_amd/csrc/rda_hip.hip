@@ -43,6 +43,7 @@ struct Dev {
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
     // per (slot, time slot) candidate list and vertices of the staged obstacle (pose independent): k_prepare, at upload
     unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][40], [N*nt][28][2], [N*nt][2] = (npv, nlv)
+    int *hint;                                // [N][T] support (candidate index) of the last max-clearance optimum, -1 = none
     double *lam, *mu, *z, *xi, *zeta, *dis;   // reference-shaped dual state
     // Condensed su terms + residual partials, one chunk per obstacle shard (P = 1 on a single GPU):
     //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0..5 -> ax ay blam ee gx gy,  k = 6,7 -> residual partials
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
         if (lane == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
-    if (!d.warm || !lmz::solve_wave_warm(W, rb, P, lane, prev, best)) lmz::solve_wave(W, rb, P, lane, best);
+    if (!d.warm || !lmz::solve_wave_warm(W, rb, P, lane, d.hint[n * T + t], best)) lmz::solve_wave(W, rb, P, lane, best);
+    if (lane == 0) d.hint[n * T + t] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave(W, rb, P, lane, best);
     // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
@@ -427,7 +429,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
-    rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
+    rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
     d.P = 1; d.rank = 0; d.Nloc = (int)N; d.chunk = 8 * T * N;
@@ -462,7 +464,7 @@ extern "C" void rda_destroy(rda_handle *H)
     (void)hipStreamSynchronize(H->stream);
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
-    void *ptrs[] = { d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
+    void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
                      d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_kind, H->d_sc_nvert, H->d_sc_sel, H->d_sc_bad, H->d_sc_geom, H->d_sc_vel, H->d_sc_robot, H->d_sc_key };
