@@ -735,15 +735,13 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                 sigma = q * q * q; if (sigma < fl) sigma = fl; }
             }
         }
-        /* separate primal / dual step lengths: a multiplier that has run away next to an almost tight bound can then
-         * recover without dragging the primal step to zero (a common step length was seen to cycle there) */
-        double al = 1.0, ald = 1.0;
+        double al = 1.0;
         for (int i = 0; i < mc; ++i) {
             if (dw[i] < 0 && -0.995 * w[i] / dw[i] < al) al = -0.995 * w[i] / dw[i];
-            if (dl[i] < 0 && -0.995 * lm[i] / dl[i] < ald) ald = -0.995 * lm[i] / dl[i];
+            if (dl[i] < 0 && -0.995 * lm[i] / dl[i] < al) al = -0.995 * lm[i] / dl[i];
         }
         for (int i = 0; i < n; ++i) x[i] += al * dx[i];
-        for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += ald * dl[i]; }
+        for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += al * dl[i]; }
     }
     if (ipm_iters) *ipm_iters = it;
     su_rollout(&S, x, s);

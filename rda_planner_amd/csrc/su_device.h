@@ -765,7 +765,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             __syncthreads();
             mark(7);
             // ---- slack / multiplier steps, step length ------------------------------------------------
-            double al = 1.0, ald = 1.0;          // primal / dual step lengths (separate in the corrector, like the oracle)
+            double al = 1.0;
             for (int i = tid; i < NC * T; i += NT) {
                 int t = i / NC, k = i % NC;
                 if (!con_on(t, k)) { L.dw[i] = 0; L.dl[i] = 0; continue; }
@@ -775,18 +775,16 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 L.dw[i] = dwv; L.dl[i] = dlv;
                 double fr = pass ? 0.995 : 1.0;
                 if (dwv < 0) { double x = -fr * L.cw[i] / dwv; if (x < al) al = x; }
-                if (dlv < 0) { double x = -fr * L.cl[i] / dlv; if (x < ald) ald = x; }
+                if (dlv < 0) { double x = -fr * L.cl[i] / dlv; if (x < al) al = x; }
             }
             al = -block_reduce(-al, L.red, tid, true);
-            ald = -block_reduce(-ald, L.red, tid, true);
             if (pass == 0) {
-                if (ald < al) al = ald;          // predictor: one common step length for the centering rule
                 // centering parameter from the predictor step length, floored (see the oracle for why)
                 double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl;
             } else {
-                for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += ald * L.dl[i]; }
+                for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += al * L.dl[i]; }
                 if (tid < T) {
                     int t = tid; const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
                     L.u[t] += al * v[0]; L.u[T + t] += al * v[1]; L.d[t] += al * v[2];
