@@ -532,6 +532,26 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
     return __ballot(!pass) == 0;
 }
 
+// wave-wide max of a double on every lane: DPP inside the 16-lane rows (xor 1, xor 2, half mirror, mirror), two
+// ds_bpermute rounds across the rows
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    double o;
+    o = dpp_mov_f64<0xB1>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x4E>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x141>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x140>(v); v = o > v ? o : v;
+    o = __shfl_xor(v, 16, 64); v = o > v ? o : v;
+    o = __shfl_xor(v, 32, 64); v = o > v ? o : v;
+    return v;
+}
+
 // Tie-break T1 in the slack regime (every (lam, mu) with H = 0, m >= 0 is optimal for the reference's problem): replace
 // the max-clearance solution in `best` by the duals of the UNIT normal in the middle of the arc {theta : m(a(theta)) >= 0}
 // of all separating directions around it.  For unit a:  m(a) = min_{k,j} [a'(p - v_k + R r_j) + xi'r_j] + kappa0 (a circle
@@ -585,8 +605,7 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
         }
     }
     if (__ballot(fail)) return false;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { double h2 = __shfl_xor(thi, o, 64), l2 = __shfl_xor(tlo, o, 64); thi = h2 < thi ? h2 : thi; tlo = l2 < tlo ? l2 : tlo; }
+    thi = -wave_max(-thi); tlo = -wave_max(-tlo);
     if (isinf(thi) && isinf(tlo)) return false;
     // a_c = a* rotated by (hi - lo)/2, from the half-angle tangents
     double chh, shh, chl, shl;
@@ -598,9 +617,7 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     int i1 = -1, i2 = -1; double l1 = 0, l2 = 0;
     if (P.norm2) { i1 = 0; i2 = 1; l1 = a0; l2 = a1; }
     else {
-        double val = lane < nv ? a0 * W.vtx[lane < nv ? lane : 0][0] + a1 * W.vtx[lane < nv ? lane : 0][1] : -INFINITY, mx = val;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { double v2 = __shfl_xor(mx, o, 64); mx = v2 > mx ? v2 : mx; }
+        const double val = lane < nv ? a0 * W.vtx[lane < nv ? lane : 0][0] + a1 * W.vtx[lane < nv ? lane : 0][1] : -INFINITY, mx = wave_max(val);
         const int kb = __ffsll((long long)__ballot(val == mx)) - 1;
         decode_pair((int)W.lamc[kb] - 1 - P.E, P.E, i1, i2);
         const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1], det = a00 * a11 - a01 * a10;
@@ -613,9 +630,7 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     const double gx = -(P.cs * a0 + P.sn * a1) - P.xi0, gy = -(-P.sn * a0 + P.cs * a1) - P.xi1;
     int j1, j2; double g1, g2;
     {
-        double val = lane < nr ? gx * Rb.rv[lane < nr ? lane : 0][0] + gy * Rb.rv[lane < nr ? lane : 0][1] : -INFINITY, mx = val;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { double v2 = __shfl_xor(mx, o, 64); mx = v2 > mx ? v2 : mx; }
+        const double val = lane < nr ? gx * Rb.rv[lane < nr ? lane : 0][0] + gy * Rb.rv[lane < nr ? lane : 0][1] : -INFINITY, mx = wave_max(val);
         const int jb = __ffsll((long long)__ballot(val == mx)) - 1;
         decode_pair((int)Rb.muc[jb] - 1 - P.R, P.R, j1, j2);
         const double a00 = Rb.G[j1][0], a01 = Rb.G[j1][1], a10 = Rb.G[j2][0], a11 = Rb.G[j2][1], det = a00 * a11 - a01 * a10;
