@@ -667,6 +667,12 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
     double *w = malloc(sizeof(double) * mc), *lm = malloc(sizeof(double) * mc), *rp = malloc(sizeof(double) * mc);
     double *dw = malloc(sizeof(double) * mc), *dl = malloc(sizeof(double) * mc), *rc = malloc(sizeof(double) * mc);
     double *s = malloc(sizeof(double) * 3 * (T + 1));
+    /* Two attempts.  The second one only runs when the first ends without convergence (the iteration
+     * cap, ~0.1% of closed-loop solves, where the iterates cycle): it restarts from the same nominal
+     * with a more central point (slack floor 0.1, mu0 = 10), which is enough to break the cycle. */
+    int status = 1, it = 0, used = 0;
+    for (int attempt = 0; attempt < 2 && status != 0; ++attempt) {
+    const double wfl = attempt ? 1e-1 : 1e-2, mu0 = attempt ? 10.0 : 1.0;
     for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
         double v = nom_u[i * T + t], lim = 0.99 * c->max_speed[i];
         x[2 * t + i] = v > lim ? lim : (v < -lim ? -lim : v);
@@ -678,9 +684,9 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
     for (int i = 0; i < mc; ++i) {
         double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
         double sl = con[i].e - cx;
-        w[i] = sl > 1e-2 ? sl : 1e-2; lm[i] = 1.0 / w[i];          /* lam = mu0 / w with mu0 = 1 */
+        w[i] = sl > wfl ? sl : wfl; lm[i] = mu0 / w[i];
     }
-    int status = 1, it;
+    status = 1;
     for (it = 0; it < 100; ++it) {
         su_eval(&S, x, s, grad, Hm);
         double gn = 0, rdn = 0, rpn = 0, mu = 0;
@@ -743,7 +749,9 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
         for (int i = 0; i < n; ++i) x[i] += al * dx[i];
         for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += al * dl[i]; }
     }
-    if (ipm_iters) *ipm_iters = it;
+    used += it;
+    }
+    if (ipm_iters) *ipm_iters = used;
     su_rollout(&S, x, s);
     memcpy(s_out, s, sizeof(double) * 3 * (T + 1));
     for (int t = 0; t < T; ++t) { u_out[t] = x[2 * t]; u_out[T + t] = x[2 * t + 1]; d_out[t] = x[2 * T + t]; }

@@ -293,17 +293,20 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     }
     mark(12);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
-    if (tid < T) {
-        int t = tid;
-        double lim0 = 0.99 * c.umax0, lim1 = 0.99 * c.umax1;
-        double v0 = L.u[t], v1 = L.u[T + t];
-        L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
-        L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
-        double lo = c.min_sd + 0.01 * (c.max_sd - c.min_sd), hi = c.max_sd - 0.01 * (c.max_sd - c.min_sd);
-        double dv = a.d_in ? a.d_in[t] : c.max_sd;
-        L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
-    }
-    __syncthreads();
+    auto clip_controls = [&]() {
+        if (tid < T) {
+            int t = tid;
+            double lim0 = 0.99 * c.umax0, lim1 = 0.99 * c.umax1;
+            double v0 = a.in_u[t], v1 = a.in_u[T + t];
+            L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
+            L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
+            double lo = c.min_sd + 0.01 * (c.max_sd - c.min_sd), hi = c.max_sd - 0.01 * (c.max_sd - c.min_sd);
+            double dv = a.d_in ? a.d_in[t] : c.max_sd;
+            L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
+        }
+        __syncthreads();
+    };
+    clip_controls();
     // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
     // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
     // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
@@ -337,15 +340,19 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     };
     rollout();
     mark(13);
-    for (int i = tid; i < NC * T; i += NT) {
-        int t = i / NC, k = i % NC;
-        double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-        double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
-        bool on = con_on(t, k);
-        L.cw[i] = on ? (sl > 1e-2 ? sl : 1e-2) : 1.0;
-        L.cl[i] = on ? 1.0 / L.cw[i] : 0.0;            // lam = mu0 / w with mu0 = 1
-    }
-    __syncthreads();
+    // slacks floored at wfl, multipliers lam = mu0 / w  (first attempt: 1e-2 and 1)
+    auto centre_duals = [&](double wfl, double mu0) {
+        for (int i = tid; i < NC * T; i += NT) {
+            int t = i / NC, k = i % NC;
+            double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
+            double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
+            bool on = con_on(t, k);
+            L.cw[i] = on ? (sl > wfl ? sl : wfl) : 1.0;
+            L.cl[i] = on ? mu0 / L.cw[i] : 0.0;
+        }
+        __syncthreads();
+    };
+    centre_duals(1e-2, 1.0);
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
@@ -515,8 +522,21 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         return (m00 > 0) && (c22 > 0) && (det > 0);
     };
 
-    int status = 1, it;
+    // Two attempts (same rule as the oracle): when the first one ends without convergence -- the iteration cap, ~0.1 % of
+    // closed-loop solves, where the iterates cycle -- restart from the same nominal with a more central point (slack floor
+    // 0.1, mu0 = 10) and every hinge term in play.
+    int status = 1, it = 0, used = 0;
     mark(9);
+    for (int attempt = 0; attempt < 2 && status != 0; ++attempt) {
+    if (attempt) {
+        __syncthreads();
+        clip_controls();
+        rollout();
+        __syncthreads();
+        screened = false;
+        centre_duals(1e-1, 10.0);
+        status = 1;
+    }
     for (it = 0; it < 100; ++it) {
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
         {
@@ -732,15 +752,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 dv = block_reduce(dv, L.red, tid, true);
                 if (dv > DELTA) {           // safety net (the per-iteration check below normally acts first): all terms, and a
                     screened = false;       // fresh, well-centred set of slacks / multipliers at the current primal point
-                    for (int i = tid; i < NC * T; i += NT) {
-                        int t = i / NC, k = i % NC;
-                        double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-                        double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
-                        bool on = con_on(t, k);
-                        L.cw[i] = on ? (sl > 1e-2 ? sl : 1e-2) : 1.0;
-                        L.cl[i] = on ? 1.0 / L.cw[i] : 0.0;
-                    }
-                    __syncthreads();
+                    centre_duals(1e-2, 1.0);
                     continue;
                 }
             }
@@ -802,6 +814,8 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             mark(8);
         }
     }
+    used += it;
+    }
     __syncthreads();
     // consistent final rollout (removes accumulated rounding in s)
     rollout();
@@ -815,7 +829,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         for (int i = tid; i < 2 * T; i += NT) a.out_u[i] = a.in_u[i];
         if (a.d_in) for (int i = tid; i < T; i += NT) a.out_d[i] = a.d_in[i];
     }
-    if (tid == 0) { *a.status = status; *a.ipm_iters = it; }
+    if (tid == 0) { *a.status = status; *a.ipm_iters = used; }
     mark(10);
     if (prof_on && tid == 0) for (int k = 0; k < 16; ++k) a.prof[k] += pacc[k];
 }

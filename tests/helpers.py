@@ -135,3 +135,14 @@ def su_solve(fn, cfg, inp):
     st = fn(C.byref(cfg), dptr(inp["nom_s"]), dptr(inp["nom_u"]), dptr(inp["ref"]), inp["vref"], dptr(inp["a"]),
             dptr(inp["cc"]), dptr(inp["g"]), dptr(inp["d0"]), dptr(s), dptr(u), dptr(d), C.byref(it))
     return st, s, u, d, it.value
+
+
+def load_su_case(path):
+    """(cfg, inputs) of a recorded su-problem (tests/golden/su_hard/*.npz, written by the soak run)"""
+    d = np.load(path)
+    dyn = {"acker": 0, "diff": 1, "omni": 2}[str(d["dyn"])]
+    cfg = make_cfg(T=int(d["T"]), N=int(d["N"]), dynamics=dyn, ro1=float(d["ro1"]))
+    inp = dict(nom_s=np.ascontiguousarray(d["nom_s"], float).reshape(3, -1), nom_u=np.ascontiguousarray(d["nom_u"], float),
+               ref=np.ascontiguousarray(d["ref"], float), vref=float(d["speed"]), a=np.ascontiguousarray(d["a"]),
+               cc=np.ascontiguousarray(d["cc"]), g=np.ascontiguousarray(d["g"]), d0=np.ascontiguousarray(d["d0"], float).ravel())
+    return cfg, inp
