@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--moving", action="store_true", help="moving obstacles: per-stage (A, b) over the horizon (dynamic_obs config)")
     ap.add_argument("--egos", type=int, default=16, help="extra leg: this many independent egos concurrently on one GPU (0/1 = skip)")
+    ap.add_argument("--fleet-egos", type=int, default=64, help="extra leg: this many egos stepped as one fleet (batched launches; 0/1 = skip)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="N>1: independent ego replicas (default, no collective) or ONE ego whose obstacles are sharded over the ranks "
                          "with an RCCL all-gather per ADMM iteration (strong scaling, --n-obs = total obstacles)")
@@ -283,6 +284,37 @@ def main():
                  "max_du_vs_single": float(np.abs(um - trace["u_solver"][W + Km - 1]).max())}
         del hs
 
+    # ---- the same, as a FLEET: one set of launches per ADMM iteration with an ego dimension in the grid (rda_fleet_*):
+    #      k_su runs one workgroup per ego side by side, the k_lammuz grid is egos x N*T/4 workgroups
+    fleet = None
+    if rank == 0 and world == 1 and args.fleet_egos > 1 and getattr(api, "has_fleet", False):
+        M, Km = args.fleet_egos, min(K, 100)
+        members = []
+        for _ in range(M):
+            sm = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+            hm = sm._be.handle
+            api.lib.rda_upload_obstacles(hm, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+            api.lib.rda_upload_trace(hm, W + Km, dptr(trace["nom_s"][:W + Km]), dptr(trace["nom_u"][:W + Km]), dptr(trace["ref"][:W + Km]), dptr(trace["speed"][:W + Km]))
+            members.append(sm)
+        arr = (C.c_void_p * M)(*[m._be.handle for m in members])
+        F = C.c_void_p()
+        assert api.fleet_create(arr, M, C.byref(F)) == 0
+        api.fleet_enqueue_range(F, 0, W)
+        api.fleet_sync(F)
+        t0 = time.perf_counter()
+        api.fleet_enqueue_range(F, W, W + Km)
+        api.fleet_sync(F)
+        el = time.perf_counter() - t0
+        worst = 0.0
+        um = np.zeros((2, T)); sm_ = np.zeros((3, T + 1))
+        for m in (members[0], members[M // 2], members[-1]):
+            api.lib.rda_fetch_result(m._be.handle, W + Km - 1, dptr(um), dptr(sm_), C.byref(info))
+            worst = max(worst, float(np.abs(um - trace["u_solver"][W + Km - 1]).max()))
+        fleet = {"egos": M, "steps_per_ego": Km, "aggregate_steps_per_s": round(M * Km / el, 1),
+                 "ms_per_fleet_step": round(el / Km * 1e3, 4), "max_du_vs_single": worst}
+        api.fleet_destroy(F)
+        del members
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -325,6 +357,7 @@ def main():
         "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
         "closed_loop_device_obstacles": cl_dev,
         "multi_ego_one_gpu": multi,
+        "multi_ego_fleet": fleet,
         "instrumented_ms_per_step": round(elapsed / K * 1e3, 5),
         "roofline": dominant, "roofline_secondary": secondary,
     }

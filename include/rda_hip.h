@@ -121,6 +121,26 @@ int  rda_fetch_result(rda_handle *h, int k, double *out_u, double *out_s, rda_in
 int  rda_timing_reset(rda_handle *h, int enable);
 int  rda_timing_read(rda_handle *h, int which, double *total_ms, int *launches);
 
+/* ---- Fleet: B independent egos advanced together (BASELINE config C5, "batched multi-ego") -------------------
+ * The reference plans one robot per RDA_solver object (rda_solver.py:54-109) and a multi-robot user loops over
+ * objects.  Here the members stay ordinary handles (own state, obstacles, trace, accessors); the fleet launches
+ * their ADMM iterations as ONE grid with an ego dimension, which is what fills the 256 CUs.  Members must agree on
+ * T, N, E, R and iter_num (weights, bounds, kinematics, robot polygons and obstacles may differ), must live on the
+ * current device and must not be obstacle shards.  Results are identical to stepping every member with rda_step /
+ * rda_enqueue_step.  Between rda_fleet_enqueue_range and rda_fleet_sync the members must not be used. */
+typedef struct rda_fleet rda_fleet;
+int  rda_fleet_create(rda_handle *const *egos, int B, rda_fleet **out);   /* does not take ownership of the members */
+void rda_fleet_destroy(rda_fleet *f);
+int  rda_fleet_size(rda_fleet *f);
+/* one synchronous MPC step of every member with the obstacles each member has staged (rda_upload_obstacles /
+ * rda_upload_scene): per-ego arrays of rda_step, concatenated ego-major */
+int  rda_fleet_step(rda_fleet *f, const double *nom_s /*B*3*(T+1)*/, const double *nom_u /*B*2*T*/,
+                    const double *ref_s /*B*3*(T+1)*/, const double *ref_speed /*B*/,
+                    double *out_u /*B*2*T*/, double *out_s /*B*3*(T+1)*/, rda_info *info /*B, may be NULL*/);
+/* steps k0 .. k1-1 of every member's uploaded trace, asynchronous; read with rda_fetch_result after rda_fleet_sync */
+int  rda_fleet_enqueue_range(rda_fleet *f, int k0, int k1);
+int  rda_fleet_sync(rda_fleet *f);
+
 /* State in the reference's shapes: lam [N][T+1][E], mu [N][T+1][R], z [N][T], xi [N][T+1][2],
  * zeta [N][T], dis [T], a_lam [N][T+1][2] (para_obsA_lam), b_lam [N][T+1] (para_obsb_lam).
  * NULL pointers are skipped. */

@@ -93,6 +93,20 @@ class CApi:
             f("get_obstacles").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, c_int_p]
             f("get_obstacles").restype = C.c_int
 
+        # batched multi-ego stepping (HIP library only)
+        self.has_fleet = hasattr(lib, f"{prefix}_fleet_step")
+        if self.has_fleet:
+            f("fleet_create").argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+            f("fleet_destroy").argtypes = [C.c_void_p]
+            f("fleet_destroy").restype = None
+            f("fleet_size").argtypes = [C.c_void_p]
+            f("fleet_step").argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                        C.POINTER(Info)]
+            f("fleet_enqueue_range").argtypes = [C.c_void_p, C.c_int, C.c_int]
+            f("fleet_sync").argtypes = [C.c_void_p]
+            for name in ("fleet_create", "fleet_size", "fleet_step", "fleet_enqueue_range", "fleet_sync"):
+                f(name).restype = C.c_int
+
     def _f(self, name):
         return getattr(self.lib, f"{self.prefix}_{name}")
 

@@ -74,7 +74,8 @@ __device__ void reduce_residuals(const Dev &d, double *red, int tid)
 
 extern __shared__ __attribute__((aligned(16))) double smem_su[];
 
-template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u)
+template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s, const double *in_u,
+                                                           const double *ref, const double *ref_speed)
 {
     const int tid = threadIdx.x;
     if (d.ctrl->stop) return;
@@ -93,7 +94,7 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, 
     a.c.slack_gain = d.c.slack_gain; a.c.max_sd = d.c.max_sd; a.c.min_sd = d.c.min_sd; a.c.ro1 = d.c.ro1; a.c.ro2 = d.c.ro2;
     a.c.eps_u = d.c.eps_u;
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
-    a.ref = d.ref; a.ref_speed = d.ref_speed;
+    a.ref = ref; a.ref_speed = ref_speed;
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
@@ -107,8 +108,13 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, 
     }
 }
 
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u)
+{
+    su_body<TT>(d, it, in_s, in_u, d.ref, d.ref_speed);
+}
+
 // final bookkeeping of a step: residuals of the last executed iteration, result slot
-__global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double *out_s, rda_info *info)
+__device__ __forceinline__ void finish_body(const Dev &d, double *out_u, double *out_s, rda_info *info)
 {
     const int tid = threadIdx.x;
     if (!d.ctrl->stop) reduce_residuals(d, smem_su, tid);
@@ -122,13 +128,17 @@ __global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double 
     }
 }
 
-__global__ void k_begin(Dev d)
+__global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double *out_s, rda_info *info) { finish_body(d, out_u, out_s, info); }
+
+__device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
         d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0;
         d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
     }
 }
+
+__global__ void k_begin(Dev d) { begin_body(d); }
 
 // ------------------------------------------------------------------------------------------------
 // K1: one wavefront per (obstacle n, stage t); 4 wavefronts per workgroup.
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(256) void k_prepare(Dev d)
     if (lane == 0) { d.oc_cnt[2 * w] = W.npv; d.oc_cnt[2 * w + 1] = W.nlv; }
 }
 
-__global__ __launch_bounds__(256) void k_lammuz(Dev d)
+__device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
 {
     __shared__ lmz::WaveLDS wl[4];
     __shared__ lmz::RobotLDS rb;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (d.obstacle_num == 0) {
         // quirk Q9 (rda_solver.py:564-568): only slot N-1 loses its lam'A / lam'b products
-        if (blockIdx.x == 0 && d.rank == d.P - 1)
+        if (block == 0 && d.rank == d.P - 1)
             for (int t = threadIdx.x; t < T; t += 256) {
                 int i = t * d.Nloc + (d.Nloc - 1);
                 coef_arr(d, d.rank, 0)[i] = 0; coef_arr(d, d.rank, 1)[i] = 0; coef_arr(d, d.rank, 2)[i] = 0;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
     if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = d.muc[threadIdx.x - 128];
     if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
-    const int w = blockIdx.x * 4 + wv;
+    const int w = block * 4 + wv;
     const bool live = w < d.Nloc * T;
     const int nl = live ? w / T : 0, t = live ? w % T : 0;
     const int n = d.rank * d.Nloc + nl;                        // this rank's obstacle shard [rank*Nloc, (rank+1)*Nloc)
@@ -246,6 +256,8 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d)
         coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
     }
 }
+
+__global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx.x); }
 
 struct RobotCands { unsigned char muc[40]; int nmv; double rv[28][2]; int nrv; int centre; };
 
@@ -917,6 +929,183 @@ extern "C" int rda_admm_finish(rda_handle *H, double *out_u, double *out_s, rda_
     if (info) *info = *H->h_info;
     return RDA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fleet: B independent egos (BASELINE config C5) advanced by ONE set of launches per ADMM iteration.  Every member keeps
+// its own handle (state, obstacles, trace) - the fleet only holds a device array of their `Dev` records and a table of
+// per-ego input / output locations.  The grid gets an ego dimension: k_su runs B workgroups (one CU each) side by side,
+// k_lammuz B * N*T/4 workgroups, so the launch fills the 256 CUs that a single ego cannot.
+struct EgoIO {            // base pointers, indexed by the step number k inside the kernels
+    const double *s, *u, *ref, *speed; double *out_u, *out_s; rda_info *info;
+};
+
+__global__ void k_begin_fleet(const Dev *devs) { begin_body(devs[blockIdx.x]); }
+
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su_fleet(const Dev *devs, const EgoIO *io, int it, int k)
+{
+    const Dev &d = devs[blockIdx.x];
+    const EgoIO e = io[blockIdx.x];
+    const size_t ns = 3 * (d.c.T + 1), nu = 2 * d.c.T;
+    su_body<TT>(d, it, e.s + k * ns, e.u + k * nu, e.ref + k * ns, e.speed + k);
+}
+
+__global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs) { lammuz_body(devs[blockIdx.y], blockIdx.x); }
+
+__global__ __launch_bounds__(su::NT) void k_finish_fleet(const Dev *devs, const EgoIO *io, int k)
+{
+    const Dev &d = devs[blockIdx.x];
+    const EgoIO e = io[blockIdx.x];
+    const size_t ns = 3 * (d.c.T + 1), nu = 2 * d.c.T;
+    finish_body(d, e.out_u + k * nu, e.out_s + k * ns, e.info + k);
+}
+
+struct rda_fleet {
+    int B;
+    std::vector<rda_handle *> egos;
+    hipStream_t stream;
+    Dev *h_devs, *d_devs;                 // pinned mirror / device array
+    EgoIO *h_io, *d_io_step, *d_io_trace;
+    double *h_in, *d_in;                  // step path, per ego: nom_s | nom_u | ref | speed
+    double *h_out, *d_out;                // per ego: u | s
+    rda_info *h_info, *d_info;
+    hipEvent_t ev;
+    int T, iter_num, blocks;
+    size_t su_lds;
+};
+
+extern "C" void rda_fleet_destroy(rda_fleet *F)
+{
+    if (!F) return;
+    (void)hipStreamSynchronize(F->stream);
+    void *dp[] = { F->d_devs, F->d_io_step, F->d_io_trace, F->d_in, F->d_out, F->d_info };
+    for (void *q : dp) dev_free(q);
+    void *hp[] = { F->h_devs, F->h_io, F->h_in, F->h_out, F->h_info };
+    for (void *q : hp) if (q) (void)hipHostFree(q);
+    (void)hipEventDestroy(F->ev);
+    (void)hipStreamDestroy(F->stream);
+    delete F;
+}
+
+extern "C" int rda_fleet_create(rda_handle *const *egos, int B, rda_fleet **out)
+{
+    if (!egos || B < 1 || !out) return RDA_ERR_ARG;
+    for (int i = 0; i < B; ++i) {
+        if (!egos[i]) return RDA_ERR_ARG;
+        const rda_cfg &a = egos[0]->d.c, &b = egos[i]->d.c;
+        // one grid for all members: the problem SHAPE must agree (weights, bounds, kinematics and robots may differ)
+        if (a.T != b.T || a.N != b.N || a.E != b.E || a.R != b.R || a.iter_num != b.iter_num) return RDA_ERR_UNSUPPORTED;
+        if (egos[i]->comm || egos[i]->d.P != 1) return RDA_ERR_UNSUPPORTED;        // egos are replicas, obstacle shards are not
+    }
+    rda_fleet *F = new rda_fleet();
+    F->B = B; F->egos.assign(egos, egos + B);
+    F->d_devs = nullptr; F->d_io_step = F->d_io_trace = nullptr; F->d_in = F->d_out = nullptr; F->d_info = nullptr;
+    F->h_devs = nullptr; F->h_io = nullptr; F->h_in = F->h_out = nullptr; F->h_info = nullptr;
+    const rda_cfg &c = egos[0]->d.c;
+    F->T = c.T; F->iter_num = c.iter_num; F->blocks = (c.N * c.T + 3) / 4; F->su_lds = egos[0]->su_lds;
+    HIPCHK(hipStreamCreate(&F->stream));
+    HIPCHK(hipEventCreateWithFlags(&F->ev, hipEventDisableTiming));
+    const size_t T = c.T, ns = 3 * (T + 1), nu = 2 * T, nin = 2 * ns + nu + 1, nout = nu + ns;
+    int rc = 0;
+    rc |= dalloc(&F->d_devs, (size_t)B); rc |= dalloc(&F->d_io_step, (size_t)B); rc |= dalloc(&F->d_io_trace, (size_t)B);
+    rc |= dalloc(&F->d_in, B * nin); rc |= dalloc(&F->d_out, B * nout); rc |= dalloc(&F->d_info, (size_t)B);
+    if (rc) { rda_fleet_destroy(F); return RDA_ERR_HIP; }
+    HIPCHK(hipHostMalloc((void **)&F->h_devs, B * sizeof(Dev)));
+    HIPCHK(hipHostMalloc((void **)&F->h_io, B * sizeof(EgoIO)));
+    HIPCHK(hipHostMalloc((void **)&F->h_in, B * nin * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&F->h_out, B * nout * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&F->h_info, B * sizeof(rda_info)));
+    memset(F->h_devs, 0, B * sizeof(Dev));
+    for (int i = 0; i < B; ++i) {
+        EgoIO &e = F->h_io[i];
+        e.s = F->d_in + i * nin; e.u = e.s + ns; e.ref = e.u + nu; e.speed = e.ref + ns;
+        e.out_u = F->d_out + i * nout; e.out_s = e.out_u + nu; e.info = F->d_info + i;
+    }
+    HIPCHK(hipMemcpy(F->d_io_step, F->h_io, B * sizeof(EgoIO), hipMemcpyHostToDevice));
+    RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_fleet<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F->su_lds)));
+    HIPCHK(hipFuncSetAttribute((const void *)k_finish_fleet, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F->su_lds));
+    *out = F;
+    return RDA_OK;
+}
+
+// members' records (obstacle count, staged pointers, weights may have changed since the last call) -> device; the fleet
+// stream then waits for whatever the members still have in flight on their own streams (obstacle uploads)
+static int fleet_refresh(rda_fleet *F)
+{
+    bool changed = false;
+    for (int i = 0; i < F->B; ++i) {
+        if (memcmp(&F->h_devs[i], &F->egos[i]->d, sizeof(Dev)) != 0) changed = true;
+        HIPCHK(hipEventRecord(F->ev, F->egos[i]->stream));
+        HIPCHK(hipStreamWaitEvent(F->stream, F->ev, 0));
+    }
+    if (changed) {
+        HIPCHK(hipStreamSynchronize(F->stream));            // an earlier copy out of the pinned mirror may still be queued
+        for (int i = 0; i < F->B; ++i) memcpy(&F->h_devs[i], &F->egos[i]->d, sizeof(Dev));
+        HIPCHK(hipMemcpyAsync(F->d_devs, F->h_devs, F->B * sizeof(Dev), hipMemcpyHostToDevice, F->stream));
+    }
+    return RDA_OK;
+}
+
+static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
+{
+    const int B = F->B;
+    hipLaunchKernelGGL(k_begin_fleet, dim3(B), dim3(64), 0, F->stream, F->d_devs);
+    for (int it = 0; it < F->iter_num; ++it) {
+        RDA_SU_DISPATCH(F->T, hipLaunchKernelGGL(k_su_fleet<TT>, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, it, k));
+        hipLaunchKernelGGL(k_lammuz_fleet, dim3(F->blocks, B), dim3(256), 0, F->stream, F->d_devs);
+    }
+    hipLaunchKernelGGL(k_finish_fleet, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, k);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+
+// one synchronous MPC step of every member: inputs / outputs are the per-ego arrays of rda_step, concatenated
+extern "C" int rda_fleet_step(rda_fleet *F, const double *nom_s, const double *nom_u, const double *ref_s, const double *ref_speed,
+                              double *out_u, double *out_s, rda_info *info)
+{
+    if (!F || !nom_s || !nom_u || !ref_s || !ref_speed || !out_u || !out_s) return RDA_ERR_ARG;
+    const size_t T = F->T, ns = 3 * (T + 1), nu = 2 * T, nin = 2 * ns + nu + 1, nout = nu + ns, B = F->B;
+    for (size_t i = 0; i < B; ++i) {
+        double *q = F->h_in + i * nin;
+        memcpy(q, nom_s + i * ns, ns * sizeof(double)); memcpy(q + ns, nom_u + i * nu, nu * sizeof(double));
+        memcpy(q + ns + nu, ref_s + i * ns, ns * sizeof(double)); q[2 * ns + nu] = ref_speed[i];
+    }
+    int rc = fleet_refresh(F);
+    if (rc != RDA_OK) return rc;
+    HIPCHK(hipMemcpyAsync(F->d_in, F->h_in, B * nin * sizeof(double), hipMemcpyHostToDevice, F->stream));
+    rc = fleet_enqueue(F, F->d_io_step, 0);
+    if (rc != RDA_OK) return rc;
+    HIPCHK(hipMemcpyAsync(F->h_out, F->d_out, B * nout * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+    HIPCHK(hipMemcpyAsync(F->h_info, F->d_info, B * sizeof(rda_info), hipMemcpyDeviceToHost, F->stream));
+    HIPCHK(hipStreamSynchronize(F->stream));
+    for (size_t i = 0; i < B; ++i) {
+        memcpy(out_u + i * nu, F->h_out + i * nout, nu * sizeof(double));
+        memcpy(out_s + i * ns, F->h_out + i * nout + nu, ns * sizeof(double));
+        if (info) info[i] = F->h_info[i];
+    }
+    return RDA_OK;
+}
+
+// steps k0 .. k1-1 of every member's uploaded trace (rda_upload_trace), no host synchronisation; results are read with
+// rda_fetch_result on the members after rda_fleet_sync
+extern "C" int rda_fleet_enqueue_range(rda_fleet *F, int k0, int k1)
+{
+    if (!F || k0 < 0 || k0 > k1) return RDA_ERR_ARG;
+    for (int i = 0; i < F->B; ++i) {
+        rda_handle *H = F->egos[i];
+        if (k1 > H->K) return RDA_ERR_ARG;
+        EgoIO &e = F->h_io[i];
+        e.s = H->d_tr_s; e.u = H->d_tr_u; e.ref = H->d_tr_ref; e.speed = H->d_tr_speed;
+        e.out_u = H->d_tr_out_u; e.out_s = H->d_tr_out_s; e.info = H->d_tr_info;
+    }
+    int rc = fleet_refresh(F);
+    if (rc != RDA_OK) return rc;
+    HIPCHK(hipMemcpyAsync(F->d_io_trace, F->h_io, F->B * sizeof(EgoIO), hipMemcpyHostToDevice, F->stream));
+    for (int k = k0; k < k1; ++k) { rc = fleet_enqueue(F, F->d_io_trace, k); if (rc != RDA_OK) return rc; }
+    return RDA_OK;
+}
+
+extern "C" int rda_fleet_sync(rda_fleet *F) { if (!F) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(F->stream)); return RDA_OK; }
+extern "C" int rda_fleet_size(rda_fleet *F) { return F ? F->B : RDA_ERR_ARG; }
 
 // ---- pure-function hooks ------------------------------------------------------------------------
 extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const double *b, const int32_t *cone,

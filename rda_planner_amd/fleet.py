@@ -1,0 +1,90 @@
+"""
+`Fleet` - B independent `MPC` planners stepped together (BASELINE config C5, "batched multi-ego").
+
+The reference has one `MPC` / `RDA_solver` object per robot and a multi-robot user calls `control` in a loop, one
+CVXPY solve after the other (mpc.py:127-187).  Here the members are still ordinary `MPC` objects - own path, state,
+obstacles, weights - but `Fleet.control` issues their ADMM iterations as ONE set of kernel launches with an ego
+dimension in the grid (include/rda_hip.h, `rda_fleet_*`): the su-problems of all members run side by side on B compute
+units and the LamMuZ grid is B times larger, which is what a 256-CU part needs.  Every member's result is identical to
+what `member.control(...)` would have returned.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from ._capi import Info, dptr, f64
+
+
+class Fleet:
+    def __init__(self, members):
+        """members: `MPC` objects with equal receding / max_obs_num / max_edge_num / iter_num and robots with the same
+        number of edges (anything else may differ)."""
+        self.members = list(members)
+        if not self.members:
+            raise ValueError("a fleet needs at least one member")
+        self.api = self.members[0].rda._be.api
+        if not getattr(self.api, "has_fleet", False):
+            raise RuntimeError("the loaded solver library has no fleet entry points")
+        B = len(self.members)
+        arr = (C.c_void_p * B)(*[m.rda._be.handle for m in self.members])
+        self._handle = C.c_void_p()
+        rc = self.api.fleet_create(arr, B, C.byref(self._handle))
+        if rc != 0:
+            raise RuntimeError(f"rda_fleet_create failed with code {rc} (members must agree on T, N, E, R, iter_num)")
+        T = self.members[0].receding
+        self._in_s, self._in_u = np.zeros((B, 3, T + 1)), np.zeros((B, 2, T))
+        self._ref, self._speed = np.zeros((B, 3, T + 1)), np.zeros(B)
+        self._out_u, self._out_s = np.zeros((B, 2, T)), np.zeros((B, 3, T + 1))
+        self._info = (Info * B)()
+
+    def __len__(self):
+        return len(self.members)
+
+    def close(self):
+        if self._handle:
+            self.api.fleet_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def control(self, states, ref_speeds, obstacle_lists, **kwargs):
+        """one MPC step of every member: `states[i]`, `ref_speeds[i]` (a scalar is shared) and `obstacle_lists[i]` are
+        what `members[i].control` takes; returns the list of its `(u, info)` results."""
+        B, start = len(self.members), time.time()
+        if np.isscalar(ref_speeds):
+            ref_speeds = [ref_speeds] * B
+        begun = []
+        for i, m in enumerate(self.members):
+            cur_ref_path, speed, nom_s, ref_list = m._begin(states[i], ref_speeds[i], **kwargs)
+            T = m.receding
+            self._in_s[i] = f64(nom_s, (3, T + 1))
+            self._in_u[i] = f64(m.cur_vel_array, (2, T))
+            self._ref[i] = np.hstack(ref_list)[0:3, :]
+            self._speed[i] = speed
+            obstacles = obstacle_lists[i]
+            scene = None
+            if not m.rda_obstacle and m.device_obstacles and m.rda.has_scene:
+                scene = m.rda.flatten_scene(obstacles)
+            if scene is not None:
+                m.rda.upload_scene(scene, np.asarray(m.state, float)[0:2], m.obstacle_order)
+            else:
+                rda_obs = obstacles if m.rda_obstacle else m.convert_rda_obstacle(obstacles, m.state, m.obstacle_order)
+                m.rda.upload_obstacles(rda_obs)
+            begun.append((cur_ref_path, ref_list))
+        rc = self.api.fleet_step(self._handle, dptr(self._in_s), dptr(self._in_u), dptr(self._ref), dptr(self._speed),
+                                 dptr(self._out_u), dptr(self._out_s), self._info)
+        if rc < 0:
+            raise RuntimeError(f"rda_fleet_step failed with code {rc}")
+        out = []
+        for i, m in enumerate(self.members):
+            cur_ref_path, ref_list = begun[i]
+            if self._info[i].su_status and m.rda.time_print:
+                print("No update of state and control vector")        # reference rda_solver.py:699
+            info = m.rda.pack_info(ref_list, self._out_s[i], self._info[i], start)
+            out.append(m._end(cur_ref_path, self._out_u[i].copy(), info))
+        return out

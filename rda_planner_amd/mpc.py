@@ -44,6 +44,26 @@ class MPC:
 
     # ------------------------------------------------------------------ control (mpc.py:127-187)
     def control(self, state, ref_speed=5, obstacle_list=[], **kwargs):
+        cur_ref_path, speed, state_pre_array, ref_traj_list = self._begin(state, ref_speed, **kwargs)
+        scene = None
+        if not self.rda_obstacle and self.device_obstacles and self.rda.has_scene:
+            scene = self.rda.flatten_scene(obstacle_list)
+        if scene is not None:
+            u_opt_array, info = self.rda.iterative_solve_scene(
+                state_pre_array, self.cur_vel_array, ref_traj_list, speed, scene,
+                np.asarray(state, float)[0:2], self.obstacle_order, **kwargs)
+        else:
+            if not self.rda_obstacle:
+                rda_obs_list = self.convert_rda_obstacle(obstacle_list, self.state, self.obstacle_order)
+            else:
+                rda_obs_list = obstacle_list
+            u_opt_array, info = self.rda.iterative_solve(
+                state_pre_array, self.cur_vel_array, ref_traj_list, speed, rda_obs_list, **kwargs)
+        return self._end(cur_ref_path, u_opt_array, info)
+
+    def _begin(self, state, ref_speed, **kwargs):
+        """first half of `control` (mpc.py:127-147): the piece of the path in force, the signed reference speed, the
+        nominal roll-out and the reference samples.  Shared with `Fleet.control`."""
         if np.shape(state)[0] > 3:
             state = state[0:3]
         self.state = state
@@ -53,27 +73,13 @@ class MPC:
         else:
             cur_ref_path = self.ref_path
             gear_flag = 1
-
         state_pre_array, ref_traj_list, self.cur_index = self.pre_process(
             state, cur_ref_path, self.cur_index, ref_speed, **kwargs)
+        return cur_ref_path, gear_flag * ref_speed, state_pre_array, ref_traj_list
 
-        scene = None
-        if not self.rda_obstacle and self.device_obstacles and self.rda.has_scene:
-            scene = self.rda.flatten_scene(obstacle_list)
-        if scene is not None:
-            u_opt_array, info = self.rda.iterative_solve_scene(
-                state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, scene,
-                np.asarray(state, float)[0:2], self.obstacle_order, **kwargs)
-        else:
-            if not self.rda_obstacle:
-                rda_obs_list = self.convert_rda_obstacle(obstacle_list, state, self.obstacle_order)
-            else:
-                rda_obs_list = obstacle_list
-            u_opt_array, info = self.rda.iterative_solve(
-                state_pre_array, self.cur_vel_array, ref_traj_list, gear_flag * ref_speed, rda_obs_list, **kwargs)
-
-        # end of the (current piece of the) path, mpc.py:166-183: with reverse enabled the next gear piece starts,
-        # the last one (or a plain path) stops the robot
+    def _end(self, cur_ref_path, u_opt_array, info):
+        """second half of `control`, mpc.py:166-187: at the end of the (current piece of the) path the next gear piece
+        starts when reverse is enabled; the last piece (or a plain path) stops the robot"""
         at_end = self.cur_index >= len(cur_ref_path) - self.goal_index_threshold
         last_piece = True
         if at_end and self.enable_reverse:
@@ -82,7 +88,6 @@ class MPC:
         info["arrive"] = bool(at_end and last_piece)
         if info["arrive"]:
             u_opt_array = np.zeros((2, self.receding))
-
         self.cur_vel_array = u_opt_array
         return u_opt_array[:, 0:1], info
 

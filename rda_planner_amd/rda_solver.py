@@ -214,12 +214,32 @@ class RDA_solver:
             raise RuntimeError(f"{self._be.api.prefix}_step_scene failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
-        opt_state_list = [out_s[:, i:i + 1].copy() for i in range(T + 1)]
-        info = {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
+        return out_u, self.pack_info(ref_states, out_s, info_c, start)
+
+    # ---- staging only (the solve is then issued by a Fleet for all of its members at once) -----------
+    def upload_scene(self, scene, robot_xy, order):
+        n, kind, nvert, geom, vel = scene
+        kind = np.ascontiguousarray(kind, np.int32); nvert = np.ascontiguousarray(nvert, np.int32)
+        geom = f64(geom); vel = f64(vel)
+        rob = f64(np.asarray(robot_xy, float).ravel()[0:2])
+        rc = self._be.api.upload_scene(self._be.handle, int(n), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(rob),
+                                       int(bool(order)), None)
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_upload_scene failed with code {rc}")
+
+    def upload_obstacles(self, obstacle_list):
+        n_obs, A, b, cone, per_t = self._stage(obstacle_list)
+        rc = self._be.api.upload_obstacles(self._be.handle, n_obs, dptr(A), dptr(b), iptr(cone), per_t)
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_upload_obstacles failed with code {rc}")
+
+    def pack_info(self, ref_states, out_s, info_c, start):
+        """the `info` dict of the reference (:603-608) plus the solver counters"""
+        opt_state_list = [out_s[:, i:i + 1].copy() for i in range(self.T + 1)]
+        return {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
                 "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
                 "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
                 "su_ipm_iters": info_c.su_ipm_iters}
-        return out_u, info
 
     # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
     def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list, **kwargs):
@@ -243,12 +263,7 @@ class RDA_solver:
             print("-----------------------------------------------")
             print("iteration time:", time.time() - start)
             print("==============================================")
-        opt_state_list = [out_s[:, i:i + 1].copy() for i in range(T + 1)]
-        info = {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
-                "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
-                "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
-                "su_ipm_iters": info_c.su_ipm_iters}
-        return out_u, info
+        return out_u, self.pack_info(ref_states, out_s, info_c, start)
 
     # ---- state access for tests -----------------------------------------------------------
     def get_state(self):

@@ -1,0 +1,179 @@
+"""GPU tests of the fleet path (include/rda_hip.h `rda_fleet_*`, rda_planner_amd/fleet.py): B independent egos advanced by
+one set of launches per ADMM iteration must give, ego by ego, exactly what the members give when stepped on their own
+(the same device code runs on the same data; only the grid has one more dimension) - BASELINE config C5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as hp
+from rda_planner_amd import scenarios as sc
+from rda_planner_amd._capi import Info, dptr, iptr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rda_planner_amd._lib import hip_api
+    return hip_api()
+
+
+def _members(B, T, N, iter_num=3, per_ego_robot=False):
+    """B twins (solo, fleet member) of solvers with different kinematics / weights / obstacle sets"""
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.mpc import MPC
+    solo, memb, staged = [], [], []
+    for i in range(B):
+        dyn = ["acker", "diff", "omni"][i % 3]
+        car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0,
+                                   length=4.6 + (0.2 * i if per_ego_robot else 0))
+        kw = dict(iter_num=iter_num, time_print=False, ro1=[200.0, 100.0, 300.0][i % 3], slack_gain=8.0 + i)
+        solo.append(RDA_solver(T, car_t, 4, N, **kw))
+        memb.append(RDA_solver(T, car_t, 4, N, **kw))
+        n_obs = [N, N // 2, 0, N + 3][i % 4]                     # full, padded (Q3), empty (Q9), truncated
+        obstacles = sc.scene_polygons(n_obs, lo=(5, -8), hi=(25, 8), seed=11 + i, moving=(i % 2 == 1)) if n_obs else []
+        conv = MPC.__new__(MPC); conv.receding = T; conv.dt = 0.1; conv.state = np.zeros((3, 1))
+        staged.append(MPC.convert_rda_obstacle(conv, obstacles, np.zeros((3, 1)), True))
+    return solo, memb, staged
+
+
+def _inputs(rng, B, T, N, K):
+    noms, nomu, refs = np.zeros((K, B, 3, T + 1)), np.zeros((K, B, 2, T)), np.zeros((K, B, 3, T + 1))
+    for k in range(K):
+        for i in range(B):
+            si = hp.su_inputs(rng, hp.make_cfg(T=T, N=N, dynamics=i % 3))
+            noms[k, i], nomu[k, i], refs[k, i] = si["nom_s"], si["nom_u"].reshape(2, T), si["ref"]
+    return noms, nomu, refs
+
+
+def _fleet(hip, memb):
+    B = len(memb)
+    arr = (C.c_void_p * B)(*[m._be.handle for m in memb])
+    F = C.c_void_p()
+    assert hip.fleet_create(arr, B, C.byref(F)) == 0
+    assert hip.fleet_size(F) == B
+    return F
+
+
+def test_fleet_step_equals_member_steps(hip):
+    """7 egos (three kinematics, different weights, robots, obstacle counts incl. none / padded / truncated, static and
+    moving), 5 steps: controls, states, iteration counts, residuals and the whole dual state are bit-identical"""
+    rng = np.random.default_rng(5)
+    B, T, N, K = 7, 10, 12, 5
+    solo, memb, staged = _members(B, T, N, per_ego_robot=True)
+    noms, nomu, refs = _inputs(rng, B, T, N, K)
+    speed = np.linspace(2.0, 5.0, B)
+    F = _fleet(hip, memb)
+    for k in range(K):
+        want = []
+        for i in range(B):
+            u, info = solo[i].iterative_solve(noms[k, i], nomu[k, i], [refs[k, i][:, j:j + 1] for j in range(T + 1)], speed[i], list(staged[i]))
+            want.append((u, info))
+            memb[i].upload_obstacles(list(staged[i]))
+        ou, os_ = np.zeros((B, 2, T)), np.zeros((B, 3, T + 1))
+        infos = (Info * B)()
+        assert hip.fleet_step(F, dptr(noms[k]), dptr(nomu[k]), dptr(refs[k]), dptr(speed), dptr(ou), dptr(os_), infos) == 0
+        for i in range(B):
+            u, info = want[i]
+            assert np.array_equal(ou[i], u), (k, i, np.abs(ou[i] - u).max())
+            assert np.array_equal(os_[i], np.hstack(info["opt_state_list"])), (k, i)
+            assert infos[i].iters == info["iters"] and infos[i].su_status == info["status"], (k, i)
+            assert infos[i].resi_dual == info["resi_dual"] and infos[i].resi_pri == info["resi_pri"], (k, i)
+            assert infos[i].su_ipm_iters == info["su_ipm_iters"], (k, i)
+    for i in range(B):
+        a, b = solo[i].get_state(), memb[i].get_state()
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (i, key)
+    hip.fleet_destroy(F)
+    # the members are still ordinary solvers afterwards
+    u, info = memb[0].iterative_solve(noms[0, 0], nomu[0, 0], [refs[0, 0][:, j:j + 1] for j in range(T + 1)], 3.0, list(staged[0]))
+    assert np.isfinite(u).all()
+
+
+def test_fleet_trace_replay_equals_member_replay(hip):
+    """the device-resident replay that bench.py times: rda_fleet_enqueue_range == rda_enqueue_range on every member"""
+    rng = np.random.default_rng(8)
+    B, T, N, K = 5, 20, 24, 6
+    solo, memb, staged = _members(B, T, N, iter_num=4)
+    noms, nomu, refs = _inputs(rng, B, T, N, K)
+    speed = np.full(K, 4.0)
+    for i in range(B):
+        n, A, b, cone, per_t = solo[i]._stage(list(staged[i]))
+        for s in (solo[i], memb[i]):
+            h = s._be.handle
+            assert hip.lib.rda_upload_obstacles(h, n, dptr(A), dptr(b), iptr(cone), per_t) == 0
+            tr = [np.ascontiguousarray(x[:, i]) for x in (noms, nomu, refs)]
+            assert hip.lib.rda_upload_trace(h, K, dptr(tr[0]), dptr(tr[1]), dptr(tr[2]), dptr(speed)) == 0
+        assert hip.lib.rda_enqueue_range(solo[i]._be.handle, 0, K) == 0
+    F = _fleet(hip, memb)
+    assert hip.fleet_enqueue_range(F, 0, 2) == 0
+    assert hip.fleet_enqueue_range(F, 2, K) == 0
+    assert hip.fleet_enqueue_range(F, 0, K + 1) != 0              # beyond the uploaded trace
+    assert hip.fleet_sync(F) == 0
+    for i in range(B):
+        for k in range(K):
+            ua, sa, ia = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+            ub, sb, ib = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+            assert hip.lib.rda_fetch_result(solo[i]._be.handle, k, dptr(ua), dptr(sa), C.byref(ia)) == 0
+            assert hip.lib.rda_fetch_result(memb[i]._be.handle, k, dptr(ub), dptr(sb), C.byref(ib)) == 0
+            assert np.array_equal(ua, ub) and np.array_equal(sa, sb), (i, k)
+            assert (ia.iters, ia.su_status, ia.resi_dual, ia.resi_pri) == (ib.iters, ib.su_status, ib.resi_dual, ib.resi_pri)
+    hip.fleet_destroy(F)
+
+
+def test_fleet_rejects_mismatched_members(hip):
+    from rda_planner_amd.rda_solver import RDA_solver
+    car_t = sc.rectangle_robot()
+    a = RDA_solver(10, car_t, 4, 8, iter_num=2, time_print=False)
+    for other in (RDA_solver(12, car_t, 4, 8, iter_num=2, time_print=False), RDA_solver(10, car_t, 5, 8, iter_num=2, time_print=False),
+                  RDA_solver(10, car_t, 4, 9, iter_num=2, time_print=False), RDA_solver(10, car_t, 4, 8, iter_num=3, time_print=False)):
+        arr = (C.c_void_p * 2)(a._be.handle, other._be.handle)
+        F = C.c_void_p()
+        assert hip.fleet_create(arr, 2, C.byref(F)) != 0
+    F = C.c_void_p()
+    assert hip.fleet_create(None, 0, C.byref(F)) != 0
+
+
+def test_fleet_control_equals_member_control():
+    """`Fleet.control` over 6 closed loops (different paths, kinematics, static / moving scenes, device and host obstacle
+    staging) == six `MPC.control` loops, bit for bit, until every member has arrived"""
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd.fleet import Fleet
+    B = 6
+    solo, memb, cars, scenes, states = [], [], [], [], []
+    for i in range(B):
+        dyn = ["acker", "diff", "omni"][i % 3]
+        car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+        y = 20.0 + 3 * i
+        path = sc.line_path([4, y, 0], [24 + 2 * i, y, 0], 0.1)
+        clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+        scene = sc.scene_polygons([12, 6][i % 2], lo=(6, y - 10), hi=(30, y + 10), seed=40 + i, keep_clear=clear, clear_radius=3.0, moving=(i % 2 == 0))
+        scene.append(sc.circle(15.0, y + 4.0, 0.8, (0.0, -0.2)))
+        kw = dict(receding=10, iter_num=3, max_edge_num=4, max_obs_num=10, device_obstacles=(i != 4))
+        solo.append(MPC(car_t, [p.copy() for p in path], **kw))
+        memb.append(MPC(car_t, [p.copy() for p in path], **kw))
+        cars.append(car_t); scenes.append(scene)
+        st = path[0].copy().reshape(3, 1)
+        if dyn == "omni":
+            st[2, 0] = 0.0
+        states.append(st)
+    fleet = Fleet(memb)
+    assert len(fleet) == B
+    arrived = [False] * B
+    for k in range(90):
+        cur = [[o if not o.velocity.any() else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
+                                                else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in scenes[i]] for i in range(B)]
+        res = fleet.control([s.copy() for s in states], [3.0 + 0.2 * i for i in range(B)], [list(c) for c in cur])
+        for i in range(B):
+            u, info = solo[i].control(states[i].copy(), 3.0 + 0.2 * i, list(cur[i]))
+            uf, inf = res[i]
+            assert np.array_equal(u, uf), (k, i, np.abs(u - uf).max())
+            assert info["iters"] == inf["iters"] and info["arrive"] == inf["arrive"] and info["resi_dual"] == inf["resi_dual"]
+            assert np.array_equal(np.hstack(info["opt_state_list"]), np.hstack(inf["opt_state_list"]))
+            arrived[i] = arrived[i] or info["arrive"]
+            states[i] = sc.kinematic_step(states[i], u, cars[i], 0.1)
+        if all(arrived):
+            break
+    assert sum(arrived) >= 3
+    fleet.close()
