@@ -54,7 +54,7 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=No
     from rda_planner_amd import scenarios as sc
     extra = {"_backend": backend} if backend is not None else {}
     # host-side obstacle staging here: the spy below needs the staged arrays for the device-resident replay
-    mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, device_obstacles=False, **kw, **extra)
+    mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, device_obstacles=False, device_track=False, **kw, **extra)
     if post_init is not None:
         post_init(mpc.rda)
     T = kw["receding"]
@@ -156,12 +156,15 @@ def main():
     kw_rec = dict(kw, obstacle_order=False)
     trace, staged, mpc_rec = record_trace(car_t, path, obstacles, kw_rec, W + K, post_init=make_sharded)
     # the same closed loop with the caller-side obstacle pipeline on the device (rda_step_scene)
-    cl_dev = None
+    cl_dev = cl_trk = None
     if rank == 0 and not shard:
         from rda_planner_amd.mpc import MPC
         from rda_planner_amd import scenarios as sc
-        mpc_d = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw_rec)
-        if mpc_d.rda.has_scene:
+
+        def closed_loop(track):
+            mpc_d = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, device_track=track, **kw_rec)
+            if not mpc_d.rda.has_scene or (track and not mpc_d.rda.has_track):
+                return None
             st = path[0].copy().reshape(3, 1)
             nd = min(W + K, 100)
             du = 0.0
@@ -172,9 +175,11 @@ def main():
                 if not args.moving:
                     du = max(du, float(np.abs(u - trace["u"][k]).max()))
                 st = sc.kinematic_step(st, u, car_t, 0.1)
-            cl_dev = {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": None if args.moving else du,
-                      "obstacles_advance_every_tick": bool(args.moving)}
-        del mpc_d
+            return {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": None if args.moving else du,
+                    "obstacles_advance_every_tick": bool(args.moving)}
+        cl_dev = closed_loop(False)
+        # ... and with MPC.pre_process on the device as well (rda_step_tracked): state in, control out
+        cl_trk = closed_loop(True)
 
     # ---- device-resident replay -------------------------------------------------------------------
     from rda_planner_amd.rda_solver import RDA_solver
@@ -356,6 +361,7 @@ def main():
         "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
         "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
         "closed_loop_device_obstacles": cl_dev,
+        "closed_loop_device_resident": cl_trk,
         "multi_ego_one_gpu": multi,
         "multi_ego_fleet": fleet,
         "instrumented_ms_per_step": round(elapsed / K * 1e3, 5),

@@ -121,6 +121,21 @@ int  rda_fetch_result(rda_handle *h, int k, double *out_u, double *out_s, rda_in
 int  rda_timing_reset(rda_handle *h, int enable);
 int  rda_timing_read(rda_handle *h, int which, double *total_ms, int *launches);
 
+/* ---- caller-side nominal roll-out + reference sampling on the device ------------------------------
+ * What MPC.pre_process (mpc.py:251-291) with closest_point / inter_point / range_cir_seg / wraptopi and the three
+ * motion_predict_model_* (mpc.py:293-433) computes per tick, as a device kernel in front of the ADMM loop: the caller
+ * hands over the robot state, the signed reference speed and its path index instead of the 3x(T+1) nominal states
+ * and reference.  rda_upload_path stores the polyline (L waypoints x, y, heading; row-major [L][3]).  The last
+ * waypoint's heading is rewritten by a tick that reaches the end of the path exactly like the reference rewrites it
+ * in place (quirk Q12); `end_heading` returns it so a host mirror of the path can follow.
+ * nom_u: the nominal controls [2][T] (MPC.cur_vel_array), or NULL = the controls of the previous solve, which are
+ * still resident (what cur_vel_array holds unless the caller replaced it).  min_index = the new MPC.cur_index.
+ * nom_s_out / ref_out (may be NULL) return the 3x(T+1) nominal states / reference the solver was given. */
+int  rda_upload_path(rda_handle *h, int L, const double *path /*L*3*/);
+int  rda_step_tracked(rda_handle *h, const double *state /*3*/, double ref_speed, int cur_index, double threshold, int ind_range,
+                      const double *nom_u, double *out_u, double *out_s, rda_info *info,
+                      double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading);
+
 /* ---- Fleet: B independent egos advanced together (BASELINE config C5, "batched multi-ego") -------------------
  * The reference plans one robot per RDA_solver object (rda_solver.py:54-109) and a multi-robot user loops over
  * objects.  Here the members stay ordinary handles (own state, obstacles, trace, accessors); the fleet launches
@@ -137,6 +152,12 @@ int  rda_fleet_size(rda_fleet *f);
 int  rda_fleet_step(rda_fleet *f, const double *nom_s /*B*3*(T+1)*/, const double *nom_u /*B*2*T*/,
                     const double *ref_s /*B*3*(T+1)*/, const double *ref_speed /*B*/,
                     double *out_u /*B*2*T*/, double *out_s /*B*3*(T+1)*/, rda_info *info /*B, may be NULL*/);
+/* rda_step_tracked for every member (paths uploaded with rda_upload_path on the members); per-ego arrays ego-major,
+ * nom_u NULL = every member's resident controls */
+int  rda_fleet_step_tracked(rda_fleet *f, const double *states /*B*3*/, const double *ref_speed /*B*/, const int32_t *cur_index /*B*/,
+                            double threshold, int ind_range, const double *nom_u /*B*2*T or NULL*/,
+                            double *out_u, double *out_s, rda_info *info, double *ref_out /*B*3*(T+1) or NULL*/,
+                            int32_t *min_index /*B*/, double *end_heading /*B*/);
 /* steps k0 .. k1-1 of every member's uploaded trace, asynchronous; read with rda_fetch_result after rda_fleet_sync */
 int  rda_fleet_enqueue_range(rda_fleet *f, int k0, int k1);
 int  rda_fleet_sync(rda_fleet *f);

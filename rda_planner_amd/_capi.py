@@ -93,6 +93,18 @@ class CApi:
             f("get_obstacles").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, c_int_p]
             f("get_obstacles").restype = C.c_int
 
+        # caller-side pre_process on the device (HIP library only)
+        self.has_track = hasattr(lib, f"{prefix}_step_tracked")
+        if self.has_track:
+            f("upload_path").argtypes = [C.c_void_p, C.c_int, c_double_p]
+            f("upload_path").restype = C.c_int
+            f("step_tracked").argtypes = [C.c_void_p, c_double_p, C.c_double, C.c_int, C.c_double, C.c_int, c_double_p,
+                                          c_double_p, c_double_p, C.POINTER(Info), c_double_p, c_double_p, c_int_p, c_double_p]
+            f("step_tracked").restype = C.c_int
+            if hasattr(lib, f"{prefix}_fleet_step_tracked"):
+                f("fleet_step_tracked").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, C.c_double, C.c_int, c_double_p,
+                                                    c_double_p, c_double_p, C.POINTER(Info), c_double_p, c_int_p, c_double_p]
+                f("fleet_step_tracked").restype = C.c_int
         # batched multi-ego stepping (HIP library only)
         self.has_fleet = hasattr(lib, f"{prefix}_fleet_step")
         if self.has_fleet:

@@ -19,6 +19,7 @@
 #include "lammuz_device.h"
 #include "su_device.h"
 #include "scene_device.h"
+#include "track_device.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "librda_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return RDA_ERR_HIP; } } while (0)
@@ -368,6 +369,8 @@ struct rda_handle {
     // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
     int sc_cap; int *d_sc_kind, *d_sc_nvert, *d_sc_sel, *d_sc_bad; double *d_sc_geom, *d_sc_vel, *d_sc_robot, *d_sc_key;
     void *h_sc; size_t h_sc_bytes;
+    // device-side pre_process (rda_upload_path / rda_step_tracked)
+    double *d_path; int path_len; track::Out *d_trk, *h_trk;
 };
 
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -479,7 +482,7 @@ extern "C" void rda_destroy(rda_handle *H)
     void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
                      d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
-                     H->d_sc_kind, H->d_sc_nvert, H->d_sc_sel, H->d_sc_bad, H->d_sc_geom, H->d_sc_vel, H->d_sc_robot, H->d_sc_key };
+                     H->d_sc_kind, H->d_sc_nvert, H->d_sc_sel, H->d_sc_bad, H->d_sc_geom, H->d_sc_vel, H->d_sc_robot, H->d_sc_key, H->d_path, H->d_trk };
     for (void *p : ptrs) dev_free(p);
     if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
     if (H->h_stage_b) (void)hipHostFree(H->h_stage_b);
@@ -488,6 +491,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->h_out) (void)hipHostFree(H->h_out);
     if (H->h_info) (void)hipHostFree(H->h_info);
     if (H->h_sc) (void)hipHostFree(H->h_sc);
+    if (H->h_trk) (void)hipHostFree(H->h_trk);
     for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(H->stream);
     delete H;
@@ -698,6 +702,65 @@ extern "C" int rda_step_scene(rda_handle *H, const double *nom_s, const double *
     int rc = rda_upload_scene(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr);
     if (rc != RDA_OK) return rc;
     return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info);
+}
+
+// ---- device-side pre_process --------------------------------------------------------------------
+__global__ void k_track(Dev d, track::In in, double *path, int L, const double *nom_u, double *step, track::Out *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int T = d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    track::Ego e;
+    e.path = path; e.L = L; e.nom_u = nom_u; e.nom_s = step; e.ref = step + ns + nu; e.speed = step + 2 * ns + nu;
+    e.T = T; e.dynamics = d.c.dynamics; e.dt = d.c.dt; e.wheelbase = d.c.L;
+    track::run(e, in, *out);
+}
+
+extern "C" int rda_upload_path(rda_handle *H, int L, const double *path)
+{
+    if (!H || L < 1 || !path) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (L > H->path_len || !H->d_path) { dev_free(H->d_path); H->d_path = nullptr; if (dalloc(&H->d_path, (size_t)3 * L)) return RDA_ERR_HIP; }
+    H->path_len = L;
+    HIPCHK(hipMemcpy(H->d_path, path, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice));
+    if (!H->d_trk) {
+        if (dalloc(&H->d_trk, 1)) return RDA_ERR_HIP;
+        HIPCHK(hipHostMalloc((void **)&H->h_trk, sizeof(track::Out)));
+    }
+    return RDA_OK;
+}
+
+extern "C" int rda_step_tracked(rda_handle *H, const double *state, double ref_speed, int cur_index, double threshold, int ind_range,
+                                const double *nom_u, double *out_u, double *out_s, rda_info *info,
+                                double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading)
+{
+    if (!H || !state || !out_u || !out_s) return RDA_ERR_ARG;
+    if (!H->d_path || cur_index < 0 || cur_index >= H->path_len || ind_range < 1) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    const double *in_u = H->d.u;                       // the controls of the last solve are still resident
+    if (nom_u) {
+        memcpy(H->h_step + ns, nom_u, nu * sizeof(double));
+        HIPCHK(hipMemcpyAsync(H->d_step + ns, H->h_step + ns, nu * sizeof(double), hipMemcpyHostToDevice, H->stream));
+        in_u = H->d_step + ns;
+    }
+    track::In in; in.sx = state[0]; in.sy = state[1]; in.sth = state[2]; in.speed = ref_speed; in.threshold = threshold;
+    in.cur_index = cur_index; in.ind_range = ind_range;
+    hipLaunchKernelGGL(k_track, dim3(1), dim3(64), 0, H->stream, H->d, in, H->d_path, H->path_len, in_u, H->d_step, H->d_trk);
+    int rc = enqueue_admm(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu, H->d_out_u, H->d_out_s, H->d_info);
+    if (rc != RDA_OK) return rc;
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_trk, H->d_trk, sizeof(track::Out), hipMemcpyDeviceToHost, H->stream));
+    if (nom_s_out || ref_out) HIPCHK(hipMemcpyAsync(H->h_step, H->d_step, (2 * ns + nu) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    memcpy(out_u, H->h_out, nu * sizeof(double));
+    memcpy(out_s, H->h_out + nu, ns * sizeof(double));
+    if (info) *info = *H->h_info;
+    if (nom_s_out) memcpy(nom_s_out, H->h_step, ns * sizeof(double));
+    if (ref_out) memcpy(ref_out, H->h_step + ns + nu, ns * sizeof(double));
+    if (min_index) *min_index = H->h_trk->min_index;
+    if (end_heading) *end_heading = H->h_trk->end_heading;
+    return RDA_OK;
 }
 
 extern "C" int rda_upload_trace(rda_handle *H, int K, const double *nom_s, const double *nom_u, const double *ref_s, const double *ref_speed)
@@ -971,15 +1034,18 @@ struct rda_fleet {
     hipEvent_t ev;
     int T, iter_num, blocks;
     size_t su_lds;
+    // tracked stepping (device-side pre_process), allocated on first use
+    track::In *h_trk_in, *d_trk_in; track::Out *h_trk_out, *d_trk_out;
+    double **h_paths, **d_paths; int *h_lens, *d_lens; EgoIO *h_io_track, *d_io_track;
 };
 
 extern "C" void rda_fleet_destroy(rda_fleet *F)
 {
     if (!F) return;
     (void)hipStreamSynchronize(F->stream);
-    void *dp[] = { F->d_devs, F->d_io_step, F->d_io_trace, F->d_in, F->d_out, F->d_info };
+    void *dp[] = { F->d_devs, F->d_io_step, F->d_io_trace, F->d_in, F->d_out, F->d_info, F->d_trk_in, F->d_trk_out, F->d_paths, F->d_lens, F->d_io_track };
     for (void *q : dp) dev_free(q);
-    void *hp[] = { F->h_devs, F->h_io, F->h_in, F->h_out, F->h_info };
+    void *hp[] = { F->h_devs, F->h_io, F->h_in, F->h_out, F->h_info, F->h_trk_in, F->h_trk_out, F->h_paths, F->h_lens, F->h_io_track };
     for (void *q : hp) if (q) (void)hipHostFree(q);
     (void)hipEventDestroy(F->ev);
     (void)hipStreamDestroy(F->stream);
@@ -1081,6 +1147,91 @@ extern "C" int rda_fleet_step(rda_fleet *F, const double *nom_s, const double *n
         memcpy(out_u + i * nu, F->h_out + i * nout, nu * sizeof(double));
         memcpy(out_s + i * ns, F->h_out + i * nout + nu, ns * sizeof(double));
         if (info) info[i] = F->h_info[i];
+    }
+    return RDA_OK;
+}
+
+// device-side pre_process of every member (one thread per ego), then the fleet step on what it wrote
+__global__ void k_track_fleet(const Dev *devs, const EgoIO *io, const track::In *ins, double *const *paths, const int *lens,
+                              track::Out *outs, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const Dev &d = devs[b];
+    track::Ego e;
+    e.path = paths[b]; e.L = lens[b]; e.nom_u = io[b].u; e.nom_s = const_cast<double *>(io[b].s); e.ref = const_cast<double *>(io[b].ref);
+    e.speed = const_cast<double *>(io[b].speed);
+    e.T = d.c.T; e.dynamics = d.c.dynamics; e.dt = d.c.dt; e.wheelbase = d.c.L;
+    track::run(e, ins[b], outs[b]);
+}
+
+extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const double *ref_speed, const int32_t *cur_index,
+                                      double threshold, int ind_range, const double *nom_u,
+                                      double *out_u, double *out_s, rda_info *info, double *ref_out, int32_t *min_index, double *end_heading)
+{
+    if (!F || !states || !ref_speed || !cur_index || !out_u || !out_s || ind_range < 1) return RDA_ERR_ARG;
+    const size_t T = F->T, ns = 3 * (T + 1), nu = 2 * T, nin = 2 * ns + nu + 1, nout = nu + ns, B = F->B;
+    if (!F->d_trk_in) {
+        int rc = 0;
+        rc |= dalloc(&F->d_trk_in, B); rc |= dalloc(&F->d_trk_out, B); rc |= dalloc(&F->d_paths, B); rc |= dalloc(&F->d_lens, B);
+        rc |= dalloc(&F->d_io_track, B);
+        if (rc) return RDA_ERR_HIP;
+        HIPCHK(hipHostMalloc((void **)&F->h_trk_in, B * sizeof(track::In)));
+        HIPCHK(hipHostMalloc((void **)&F->h_trk_out, B * sizeof(track::Out)));
+        HIPCHK(hipHostMalloc((void **)&F->h_paths, B * sizeof(double *)));
+        HIPCHK(hipHostMalloc((void **)&F->h_lens, B * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&F->h_io_track, B * sizeof(EgoIO)));
+        memset(F->h_paths, 0, B * sizeof(double *)); memset(F->h_lens, 0, B * sizeof(int)); memset(F->h_io_track, 0, B * sizeof(EgoIO));
+    }
+    bool tables = false;
+    for (size_t i = 0; i < B; ++i) {
+        rda_handle *H = F->egos[i];
+        if (!H->d_path || cur_index[i] < 0 || cur_index[i] >= H->path_len) return RDA_ERR_ARG;
+        track::In &in = F->h_trk_in[i];
+        in.sx = states[3 * i]; in.sy = states[3 * i + 1]; in.sth = states[3 * i + 2]; in.speed = ref_speed[i]; in.threshold = threshold;
+        in.cur_index = cur_index[i]; in.ind_range = ind_range;
+        EgoIO e;
+        e.s = F->d_in + i * nin; e.u = nom_u ? e.s + ns : H->d.u; e.ref = e.s + ns + nu; e.speed = e.ref + ns;
+        e.out_u = F->d_out + i * nout; e.out_s = e.out_u + nu; e.info = F->d_info + i;
+        if (memcmp(&e, &F->h_io_track[i], sizeof(EgoIO)) != 0 || F->h_paths[i] != H->d_path || F->h_lens[i] != H->path_len) tables = true;
+    }
+    int rc = fleet_refresh(F);
+    if (rc != RDA_OK) return rc;
+    if (tables) {
+        HIPCHK(hipStreamSynchronize(F->stream));
+        for (size_t i = 0; i < B; ++i) {
+            rda_handle *H = F->egos[i];
+            EgoIO &e = F->h_io_track[i];
+            e.s = F->d_in + i * nin; e.u = nom_u ? e.s + ns : H->d.u; e.ref = e.s + ns + nu; e.speed = e.ref + ns;
+            e.out_u = F->d_out + i * nout; e.out_s = e.out_u + nu; e.info = F->d_info + i;
+            F->h_paths[i] = H->d_path; F->h_lens[i] = H->path_len;
+        }
+        HIPCHK(hipMemcpyAsync(F->d_io_track, F->h_io_track, B * sizeof(EgoIO), hipMemcpyHostToDevice, F->stream));
+        HIPCHK(hipMemcpyAsync(F->d_paths, F->h_paths, B * sizeof(double *), hipMemcpyHostToDevice, F->stream));
+        HIPCHK(hipMemcpyAsync(F->d_lens, F->h_lens, B * sizeof(int), hipMemcpyHostToDevice, F->stream));
+    }
+    if (nom_u) {
+        for (size_t i = 0; i < B; ++i) memcpy(F->h_in + i * nin + ns, nom_u + i * nu, nu * sizeof(double));
+        HIPCHK(hipMemcpy2DAsync(F->d_in + ns, nin * sizeof(double), F->h_in + ns, nin * sizeof(double), nu * sizeof(double), B,
+                                hipMemcpyHostToDevice, F->stream));
+    }
+    HIPCHK(hipMemcpyAsync(F->d_trk_in, F->h_trk_in, B * sizeof(track::In), hipMemcpyHostToDevice, F->stream));
+    hipLaunchKernelGGL(k_track_fleet, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, F->stream, F->d_devs, F->d_io_track, F->d_trk_in,
+                       F->d_paths, F->d_lens, F->d_trk_out, (int)B);
+    rc = fleet_enqueue(F, F->d_io_track, 0);
+    if (rc != RDA_OK) return rc;
+    HIPCHK(hipMemcpyAsync(F->h_out, F->d_out, B * nout * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+    HIPCHK(hipMemcpyAsync(F->h_info, F->d_info, B * sizeof(rda_info), hipMemcpyDeviceToHost, F->stream));
+    HIPCHK(hipMemcpyAsync(F->h_trk_out, F->d_trk_out, B * sizeof(track::Out), hipMemcpyDeviceToHost, F->stream));
+    if (ref_out) HIPCHK(hipMemcpyAsync(F->h_in, F->d_in, B * nin * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+    HIPCHK(hipStreamSynchronize(F->stream));
+    for (size_t i = 0; i < B; ++i) {
+        memcpy(out_u + i * nu, F->h_out + i * nout, nu * sizeof(double));
+        memcpy(out_s + i * ns, F->h_out + i * nout + nu, ns * sizeof(double));
+        if (info) info[i] = F->h_info[i];
+        if (ref_out) memcpy(ref_out + i * ns, F->h_in + i * nin + ns + nu, ns * sizeof(double));
+        if (min_index) min_index[i] = F->h_trk_out[i].min_index;
+        if (end_heading) end_heading[i] = F->h_trk_out[i].end_heading;
     }
     return RDA_OK;
 }

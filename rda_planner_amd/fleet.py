@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-from ._capi import Info, dptr, f64
+from ._capi import Info, dptr, iptr, f64
 
 
 class Fleet:
@@ -58,6 +58,8 @@ class Fleet:
         B, start = len(self.members), time.time()
         if np.isscalar(ref_speeds):
             ref_speeds = [ref_speeds] * B
+        if hasattr(self.api.lib, "rda_fleet_step_tracked") and all(m._tracks(kwargs) for m in self.members):
+            return self._control_tracked(states, ref_speeds, obstacle_lists, start, **kwargs)
         begun = []
         for i, m in enumerate(self.members):
             cur_ref_path, speed, nom_s, ref_list = m._begin(states[i], ref_speeds[i], **kwargs)
@@ -87,4 +89,39 @@ class Fleet:
                 print("No update of state and control vector")        # reference rda_solver.py:699
             info = m.rda.pack_info(ref_list, self._out_s[i], self._info[i], start)
             out.append(m._end(cur_ref_path, self._out_u[i].copy(), info))
+        return out
+
+    def _control_tracked(self, states, ref_speeds, obstacle_lists, start, threshold=0.1, ind_range=10):
+        """the same with every member's pre_process on the device (rda_fleet_step_tracked): per ego only the state, the
+        signed speed and the path index travel"""
+        B, T = len(self.members), self.members[0].receding
+        st, cur = np.zeros((B, 3)), np.zeros(B, np.int32)
+        pieces, resident = [], True
+        for i, m in enumerate(self.members):
+            cur_ref_path, gear = m._piece(states[i])
+            m._sync_path(cur_ref_path)
+            m._stage_obstacles(obstacle_lists[i])
+            st[i] = np.asarray(m.state, float).ravel()[0:3]
+            self._speed[i] = gear * ref_speeds[i]
+            cur[i] = m.cur_index
+            resident = resident and m._nominal_u() is None
+            pieces.append(cur_ref_path)
+        nom_u = None
+        if not resident:            # some member's cur_vel_array was replaced since its last solve: send them all
+            for i, m in enumerate(self.members):
+                self._in_u[i] = f64(m.cur_vel_array, (2, T))
+            nom_u = self._in_u
+        mi, eh = np.zeros(B, np.int32), np.zeros(B)
+        rc = self.api.fleet_step_tracked(self._handle, dptr(st), dptr(self._speed), iptr(cur), float(threshold), int(ind_range),
+                                         dptr(nom_u), dptr(self._out_u), dptr(self._out_s), self._info, dptr(self._ref),
+                                         iptr(mi), dptr(eh))
+        if rc < 0:
+            raise RuntimeError(f"rda_fleet_step_tracked failed with code {rc}")
+        out = []
+        for i, m in enumerate(self.members):
+            if self._info[i].su_status and m.rda.time_print:
+                print("No update of state and control vector")        # reference rda_solver.py:699
+            ref_list = [self._ref[i][:, j:j + 1].copy() for j in range(T + 1)]
+            info = m.rda.pack_info(ref_list, self._out_s[i], self._info[i], start)
+            out.append(m._tracked_done(pieces[i], self._out_u[i].copy(), info, int(mi[i]), float(eh[i])))
         return out

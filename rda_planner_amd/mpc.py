@@ -32,7 +32,11 @@ class MPC:
         # extension (not in the reference): device_obstacles=True lets the accelerated backend convert, predict, sort
         # and stage the raw obstacles on the GPU (rda_step_scene) instead of the host code below; same staged values
         self.device_obstacles = bool(kwargs.get("device_obstacles", True))
-        solver_kwargs = {k: v for k, v in kwargs.items() if k not in ("init_vel", "device_obstacles")}
+        # extension: device_track=True additionally runs pre_process (closest waypoint, nominal roll-out, reference
+        # sampling) on the GPU (rda_step_tracked) - same values to rounding, the host code below is the fallback
+        self.device_track = bool(kwargs.get("device_track", True))
+        self._dev_path_key, self._dev_u = None, None
+        solver_kwargs = {k: v for k, v in kwargs.items() if k not in ("init_vel", "device_obstacles", "device_track")}
         self.rda = RDA_solver(receding, car_tuple, max_edge_num, max_obs_num, iter_num=iter_num,
                               step_time=sample_time, process_num=process_num, accelerated=accelerated,
                               time_print=time_print, **solver_kwargs)
@@ -44,6 +48,8 @@ class MPC:
 
     # ------------------------------------------------------------------ control (mpc.py:127-187)
     def control(self, state, ref_speed=5, obstacle_list=[], **kwargs):
+        if self._tracks(kwargs):
+            return self._control_tracked(state, ref_speed, obstacle_list, **kwargs)
         cur_ref_path, speed, state_pre_array, ref_traj_list = self._begin(state, ref_speed, **kwargs)
         scene = None
         if not self.rda_obstacle and self.device_obstacles and self.rda.has_scene:
@@ -60,6 +66,55 @@ class MPC:
             u_opt_array, info = self.rda.iterative_solve(
                 state_pre_array, self.cur_vel_array, ref_traj_list, speed, rda_obs_list, **kwargs)
         return self._end(cur_ref_path, u_opt_array, info)
+
+    # ---- extension: pre_process on the device (rda_step_tracked); same control, cur_index, path side effect ----------
+    def _tracks(self, kwargs):
+        return self.device_track and self.rda.has_track and set(kwargs) <= {"threshold", "ind_range"}
+
+    def _piece(self, state):
+        if np.shape(state)[0] > 3:
+            state = state[0:3]
+        self.state = state
+        if self.enable_reverse:
+            cur_ref_path = self.curve_list[self.curve_index]
+            return cur_ref_path, cur_ref_path[0][-1, 0]
+        return self.ref_path, 1
+
+    def _stage_obstacles(self, obstacle_list):
+        """obstacles into the solver's slots without solving: raw scene through the device pipeline, else host staging"""
+        scene = None
+        if not self.rda_obstacle and self.device_obstacles and self.rda.has_scene:
+            scene = self.rda.flatten_scene(obstacle_list)
+        if scene is not None:
+            self.rda.upload_scene(scene, np.asarray(self.state, float)[0:2], self.obstacle_order)
+        else:
+            rda_obs = obstacle_list if self.rda_obstacle else self.convert_rda_obstacle(obstacle_list, self.state, self.obstacle_order)
+            self.rda.upload_obstacles(rda_obs)
+
+    def _sync_path(self, cur_ref_path):
+        key = (id(cur_ref_path), len(cur_ref_path))
+        if key != self._dev_path_key:
+            self.rda.upload_path(cur_ref_path)
+            self._dev_path_key = key
+
+    def _nominal_u(self):
+        """None when the device still holds cur_vel_array (the controls of the previous solve), else the array"""
+        return None if self.cur_vel_array is self._dev_u else self.cur_vel_array
+
+    def _tracked_done(self, cur_ref_path, u_opt_array, info, min_index, end_heading):
+        self.cur_index = min_index
+        cur_ref_path[-1][2, 0] = end_heading            # quirk Q12: the reference rewrites the last waypoint's heading in place
+        out = self._end(cur_ref_path, u_opt_array, info)
+        self._dev_u = None if info["arrive"] else self.cur_vel_array
+        return out
+
+    def _control_tracked(self, state, ref_speed, obstacle_list, **kwargs):
+        cur_ref_path, gear_flag = self._piece(state)
+        self._sync_path(cur_ref_path)
+        self._stage_obstacles(obstacle_list)
+        u_opt_array, info, min_index, end_heading = self.rda.iterative_solve_tracked(
+            self.state, gear_flag * ref_speed, self.cur_index, self._nominal_u(), **kwargs)
+        return self._tracked_done(cur_ref_path, u_opt_array, info, min_index, end_heading)
 
     def _begin(self, state, ref_speed, **kwargs):
         """first half of `control` (mpc.py:127-147): the piece of the path in force, the signed reference speed, the
@@ -113,6 +168,7 @@ class MPC:
     def update_ref_path(self, ref_path):
         self.ref_path = ref_path
         self.cur_index = 0
+        self._dev_path_key = None
         if self.enable_reverse:
             self.curve_list = self.split_path(self.ref_path)
             self.curve_index = 0

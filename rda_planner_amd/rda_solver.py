@@ -241,6 +241,37 @@ class RDA_solver:
                 "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
                 "su_ipm_iters": info_c.su_ipm_iters}
 
+    # ---- caller-side pre_process on the device ------------------------------------------------------
+    @property
+    def has_track(self):
+        return bool(getattr(self._be.api, "has_track", False))
+
+    def upload_path(self, ref_path):
+        """the polyline of MPC.ref_path (list of (>=3)x1 waypoints) for `iterative_solve_tracked`"""
+        P = np.ascontiguousarray(np.hstack(ref_path)[0:3, :].T, dtype=float)
+        rc = self._be.api.upload_path(self._be.handle, int(P.shape[0]), dptr(P))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_upload_path failed with code {rc}")
+
+    def iterative_solve_tracked(self, state, ref_speed, cur_index, nom_u=None, threshold=0.1, ind_range=10):
+        """`iterative_solve` with MPC.pre_process (nominal roll-out, closest waypoint, arc-length reference sampling)
+        done on the device from the robot state; obstacles are whatever is staged (upload_scene / upload_obstacles).
+        Returns (u, info, new cur_index, heading of the last waypoint after the tick - quirk Q12)."""
+        T = self.T
+        start = time.time()
+        st = f64(np.asarray(state, float).ravel()[0:3])
+        out_u, out_s, ref = np.zeros((2, T)), np.zeros((3, T + 1)), np.zeros((3, T + 1))
+        info_c, mi, eh = Info(), np.zeros(1, np.int32), np.zeros(1)
+        un = f64(nom_u, (2, T)) if nom_u is not None else None
+        rc = self._be.api.step_tracked(self._be.handle, dptr(st), float(ref_speed), int(cur_index), float(threshold), int(ind_range),
+                                       dptr(un), dptr(out_u), dptr(out_s), C.byref(info_c), None, dptr(ref), iptr(mi), dptr(eh))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_step_tracked failed with code {rc}")
+        if info_c.su_status and self.time_print:
+            print("No update of state and control vector")        # reference :699
+        ref_states = [ref[:, i:i + 1].copy() for i in range(T + 1)]
+        return out_u, self.pack_info(ref_states, out_s, info_c, start), int(mi[0]), float(eh[0])
+
     # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
     def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list, **kwargs):
         T = self.T

@@ -1,0 +1,117 @@
+"""GPU tests of the device-side pre_process (include/rda_hip.h `rda_upload_path`, `rda_step_tracked`):
+closest waypoint, nominal roll-out and arc-length reference sampling of MPC.pre_process (reference mpc.py:251-433) computed
+by a kernel in front of the ADMM loop.  Sums and products are rounded like the Python expressions, sin / cos / tan come
+from the device maths library: the values are compared at 1e-12, the indices exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rda_planner_amd import scenarios as sc
+from rda_planner_amd._capi import Info, dptr, iptr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def _host_pre_process(mpc, state, speed, kwargs):
+    """MPC.pre_process on a deep copy of the path (it rewrites the last waypoint, Q12); returns the copy as well"""
+    path = [p.copy() for p in mpc.ref_path]
+    nom_s, ref_list, min_index = mpc.pre_process(state, path, mpc.cur_index, speed, **kwargs)
+    return nom_s, np.hstack(ref_list)[0:3, :], min_index, path
+
+
+@pytest.mark.parametrize("dyn", ["acker", "diff", "omni"])
+def test_tracked_inputs_equal_pre_process(dyn):
+    """random states near a curved path (incl. the last waypoints, where the reference aliases the end object), random
+    nominal controls, both signs of the speed, non-default window: nominal states, reference and index"""
+    from rda_planner_amd.mpc import MPC
+    rng = np.random.default_rng({"acker": 1, "diff": 2, "omni": 3}[dyn])
+    car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+    T = 12
+    s = np.arange(0, 30, 0.13)
+    pts = [np.array([[x], [3 * np.sin(0.2 * x)], [np.arctan(0.6 * np.cos(0.2 * x)) + (7.0 if i % 50 == 3 else 0.0)]]) for i, x in enumerate(s)]
+    pts.insert(40, pts[40].copy())                               # a repeated waypoint (zero-length segment)
+    mpc = MPC(car_t, pts, receding=T, max_edge_num=4, max_obs_num=3, iter_num=1, device_track=False)
+    api, h = mpc.rda._be.api, mpc.rda._be.handle
+    L = len(pts)
+    for trial in range(60):
+        k = int(rng.integers(0, L)) if trial % 3 else int(rng.integers(L - 6, L))
+        mpc.cur_index = max(0, k - int(rng.integers(0, 4)))
+        state = pts[k][0:3].copy() + rng.normal(0, 0.3, (3, 1))
+        mpc.cur_vel_array = np.vstack((rng.uniform(0, 5, (1, T)), rng.uniform(-0.5, 0.5, (1, T))))
+        speed = float(rng.choice([4.0, 1.5, 9.0]))
+        kwargs = {} if trial % 2 else {"threshold": 0.3, "ind_range": 25}
+        want_s, want_ref, want_idx, path_after = _host_pre_process(mpc, state, speed, kwargs)
+        mpc.rda.upload_path(mpc.ref_path)
+        u, out_s, nom_s, ref = np.zeros((2, T)), np.zeros((3, T + 1)), np.zeros((3, T + 1)), np.zeros((3, T + 1))
+        info, mi, eh = Info(), np.zeros(1, np.int32), np.zeros(1)
+        st = np.ascontiguousarray(state.ravel())
+        nu = np.ascontiguousarray(mpc.cur_vel_array)
+        assert api.step_tracked(h, dptr(st), speed, mpc.cur_index, kwargs.get("threshold", 0.1), kwargs.get("ind_range", 10),
+                                dptr(nu), dptr(u), dptr(out_s), C.byref(info), dptr(nom_s), dptr(ref), iptr(mi), dptr(eh)) == 0
+        assert mi[0] == want_idx, trial
+        assert np.abs(nom_s - want_s).max() < TOL, (trial, np.abs(nom_s - want_s).max())
+        assert np.abs(ref - want_ref).max() < TOL, (trial, np.abs(ref - want_ref).max())
+        assert abs(eh[0] - path_after[-1][2, 0]) < TOL, trial     # Q12: the rewritten heading of the last waypoint
+    # error paths
+    st = np.zeros(3)
+    assert api.step_tracked(h, dptr(st), 1.0, L, 0.1, 10, None, dptr(u), dptr(out_s), None, None, None, None, None) != 0
+    assert api.step_tracked(h, dptr(st), 1.0, 0, 0.1, 0, None, dptr(u), dptr(out_s), None, None, None, None, None) != 0
+
+
+def test_tracked_control_equals_host_control():
+    """closed loops to the goal with `device_track` on and off (path end, arrival, Q12 rewrite of the last waypoint, resident
+    nominal controls): same path indices and iteration counts, controls within 1e-9"""
+    from rda_planner_amd.mpc import MPC
+    for i, dyn in enumerate(["acker", "diff", "omni"]):
+        car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+        path = sc.line_path([4, 20, 0], [22, 20, 0], 0.1)
+        clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+        scene = sc.scene_polygons(10, lo=(6, 12), hi=(24, 28), seed=70 + i, keep_clear=clear, clear_radius=3.0)
+        kw = dict(receding=10, iter_num=3, max_edge_num=4, max_obs_num=10)
+        a = MPC(car_t, [p.copy() for p in path], device_track=False, **kw)
+        b = MPC(car_t, [p.copy() for p in path], device_track=True, **kw)
+        assert b._tracks({}) and not a._tracks({})
+        st = path[0].copy().reshape(3, 1)
+        if dyn == "omni":
+            st[2, 0] = 0.0
+        arrived = False
+        for k in range(150):
+            ua, ia = a.control(st.copy(), 4.0, list(scene))
+            ub, ib = b.control(st.copy(), 4.0, list(scene))
+            assert a.cur_index == b.cur_index and ia["iters"] == ib["iters"] and ia["arrive"] == ib["arrive"], (dyn, k)
+            assert np.abs(ua - ub).max() < 1e-9, (dyn, k, np.abs(ua - ub).max())
+            assert np.abs(np.hstack(ia["ref_traj_list"])[0:3] - np.hstack(ib["ref_traj_list"])).max() < TOL
+            assert abs(a.ref_path[-1][2, 0] - b.ref_path[-1][2, 0]) < TOL
+            st = sc.kinematic_step(st, ua, car_t, 0.1)
+            if ia["arrive"]:
+                arrived = True
+                break
+        assert arrived, dyn
+
+
+def test_tracked_control_with_reverse_pieces():
+    """enable_reverse: the path is split at gear flips (mpc.py:232-249); every piece is uploaded when it comes into force
+    and the signed speed reaches the kernel"""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics="acker")
+    fwd = sc.line_path([0, 0, 0], [8, 0, 0], 0.1)
+    back = sc.line_path([8, 0, 0], [2, 0, 0], 0.1)
+    path = [np.vstack((p[0:3], [[1.0]])) for p in fwd] + [np.vstack((p[0:2], [[0.0]], [[-1.0]])) for p in back]
+    kw = dict(receding=8, iter_num=2, max_edge_num=4, max_obs_num=2, enable_reverse=True)
+    a = MPC(car_t, [p.copy() for p in path], device_track=False, **kw)
+    b = MPC(car_t, [p.copy() for p in path], device_track=True, **kw)
+    st = np.zeros((3, 1))
+    seen_reverse = False
+    for k in range(140):
+        ua, ia = a.control(st.copy(), 3.0, [])
+        ub, ib = b.control(st.copy(), 3.0, [])
+        assert (a.cur_index, a.curve_index) == (b.cur_index, b.curve_index), k
+        assert np.abs(ua - ub).max() < 1e-9, (k, np.abs(ua - ub).max())
+        seen_reverse = seen_reverse or ua[0, 0] < -0.1
+        st = sc.kinematic_step(st, ua, car_t, 0.1)
+        if ia["arrive"]:
+            break
+    assert seen_reverse and ia["arrive"]
