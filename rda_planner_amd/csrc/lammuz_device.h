@@ -465,6 +465,48 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
     }
 }
 
+// wave-wide max of a double on every lane: DPP inside the 16-lane rows (xor 1, xor 2, half mirror, mirror), two
+// ds_bpermute rounds across the rows
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    double o;
+    o = dpp_mov_f64<0xB1>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x4E>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x141>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x140>(v); v = o > v ? o : v;
+    o = __shfl_xor(v, 16, 64); v = o > v ? o : v;
+    o = __shfl_xor(v, 32, 64); v = o > v ? o : v;
+    return v;
+}
+
+// Lane groups.  GW = 64: the wave works on one sub-problem.  GW = 16: four sub-problems per wave, one per DPP row - every
+// cross-lane step below stays inside a row, so the rows may diverge from each other (different supports, early exits).
+__device__ __forceinline__ double row_max(double v)
+{
+    double o;
+    o = dpp_mov_f64<0xB1>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x4E>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x141>(v); v = o > v ? o : v;
+    o = dpp_mov_f64<0x140>(v); v = o > v ? o : v;
+    return v;
+}
+template <int GW> struct Grp {
+    static __device__ __forceinline__ unsigned long long ballot(bool p, int lane)
+    {
+        const unsigned long long b = __ballot(p);
+        if (GW == 64) return b;
+        return (b >> (lane & 48)) & 0xffffull;
+    }
+    static __device__ __forceinline__ double max(double v) { return GW == 64 ? wave_max(v) : row_max(v); }
+    template <typename Tv> static __device__ __forceinline__ Tv bcast(Tv v, int src) { return __shfl(v, src, GW); }
+};
+
 // Warm start for polygon obstacles: the support (non-zero pattern) of the previous (lam, mu) of this (obstacle, stage)
 // usually survives from one ADMM iteration / MPC step to the next.  Lanes 0 and 1 solve that one support for the
 // two hinge states, every lane then checks the optimality conditions of the FULL problem for the result
@@ -473,8 +515,9 @@ __device__ __forceinline__ void solve_wave(WaveLDS &W, const RobotLDS &Rb, const
 // (sign, tolerance, circle obstacle, no hint yet) falls back to solve_wave.  Call after prepare_wave.  `hint` is the
 // candidate index il*n_mu + im remembered from the last solve of this (n, t) (-1: none); it is only a hint - whatever it
 // is, a result is accepted on the certificate alone.
-__device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, int hint, Sol &best)
+template <int GW> __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int wlane, int hint, Sol &best)
 {
+    const int lane = wlane & (GW - 1);                          // lane inside the group
     if (P.norm2 || hint < 0) return false;
     const int R = P.R, E = P.E, nm0 = 1 + R + R * (R - 1) / 2;
     const int il = hint / nm0, im = hint - il * nm0;            // support of the last max-clearance optimum of this (n, t)
@@ -483,17 +526,17 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
     bool ok = false;
     if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);
     // hinge-inactive solution with m >= 0, else hinge-active solution with m < 0
-    const double m0 = __shfl(s.m, 0, 64), m1 = __shfl(s.m, 1, 64);
-    const unsigned long long okb = __ballot(ok);
+    const double m0 = Grp<GW>::bcast(s.m, 0), m1 = Grp<GW>::bcast(s.m, 1);
+    const unsigned long long okb = Grp<GW>::ballot(ok, wlane);
     int src;
     if ((okb & 1) && m0 >= 0) src = 0; else if ((okb & 2) && m1 < 0) src = 1; else return false;
     best.m = src ? m1 : m0;
-    best.cost = __shfl(s.cost, src, 64); best.id = 2 * (il * (1 + R + R * (R - 1) / 2) + im) + src;
-    best.H0 = __shfl(s.H0, src, 64); best.H1 = __shfl(s.H1, src, 64);
-    best.i1 = __shfl(s.i1, src, 64); best.i2 = __shfl(s.i2, src, 64);
-    best.j1 = __shfl(s.j1, src, 64); best.j2 = __shfl(s.j2, src, 64);
-    best.l1 = __shfl(s.l1, src, 64); best.l2 = __shfl(s.l2, src, 64);
-    best.g1 = __shfl(s.g1, src, 64); best.g2 = __shfl(s.g2, src, 64);
+    best.cost = Grp<GW>::bcast(s.cost, src); best.id = 2 * (il * (1 + R + R * (R - 1) / 2) + im) + src;
+    best.H0 = Grp<GW>::bcast(s.H0, src); best.H1 = Grp<GW>::bcast(s.H1, src);
+    best.i1 = Grp<GW>::bcast(s.i1, src); best.i2 = Grp<GW>::bcast(s.i2, src);
+    best.j1 = Grp<GW>::bcast(s.j1, src); best.j2 = Grp<GW>::bcast(s.j2, src);
+    best.l1 = Grp<GW>::bcast(s.l1, src); best.l2 = Grp<GW>::bcast(s.l2, src);
+    best.g1 = Grp<GW>::bcast(s.g1, src); best.g2 = Grp<GW>::bcast(s.g2, src);
     // ---- optimality conditions of the full problem ---------------------------------------------------------------
     double ax = 0, ay = 0;
     if (best.i1 >= 0) { ax += best.l1 * W.A[best.i1][0]; ay += best.l1 * W.A[best.i1][1]; }
@@ -529,27 +572,7 @@ __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, 
         const bool pos = (j == best.j1 && best.g1 > 0) || (j == best.j2 && best.g2 > 0);
         pass = pos ? fabs(gj) <= 1e3 * tol : gj >= -tol;
     }
-    return __ballot(!pass) == 0;
-}
-
-// wave-wide max of a double on every lane: DPP inside the 16-lane rows (xor 1, xor 2, half mirror, mirror), two
-// ds_bpermute rounds across the rows
-template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v)
-{
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-    double o;
-    o = dpp_mov_f64<0xB1>(v); v = o > v ? o : v;
-    o = dpp_mov_f64<0x4E>(v); v = o > v ? o : v;
-    o = dpp_mov_f64<0x141>(v); v = o > v ? o : v;
-    o = dpp_mov_f64<0x140>(v); v = o > v ? o : v;
-    o = __shfl_xor(v, 16, 64); v = o > v ? o : v;
-    o = __shfl_xor(v, 32, 64); v = o > v ? o : v;
-    return v;
+    return Grp<GW>::ballot(!pass, wlane) == 0;
 }
 
 // Tie-break T1 in the slack regime (every (lam, mu) with H = 0, m >= 0 is optimal for the reference's problem): replace
@@ -558,8 +581,9 @@ __device__ __forceinline__ double wave_max(double v)
 // obstacle contributes its centre and -radius): one (obstacle vertex, robot vertex) pair per lane, its admissible arc is
 // centred at the direction of w_kj with half-width acos(-c_j/|w_kj|); the feasible arc is the intersection (two wave
 // minima).  Same steps as oracle/lammuz_np.py:central_normal.  All lanes call, after prepare_wave; `best` is wave-uniform.
-__device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const RobotLDS &Rb, const Params &P, int lane, Sol &best)
+template <int GW> __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const RobotLDS &Rb, const Params &P, int wlane, Sol &best)
 {
+    const int lane = wlane & (GW - 1);
     if (!(best.m > 0) || !(best.H0 * best.H0 + best.H1 * best.H1 < 1e-8)) return false;
     double as0 = 0, as1 = 0;
     if (P.norm2) { if (best.i1 >= 0) { as0 = best.l1; as1 = best.l2; } }
@@ -569,7 +593,7 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     }
     if (!(as0 * as0 + as1 * as1 >= 1.0 - 1e-9)) return false;          // a* on the unit circle: it has a direction
     const int nv = P.norm2 ? 1 : W.npv, nr = Rb.nrv;
-    if (nr < 3 || (!P.norm2 && nv < 3) || nv * nr > 64) return false;
+    if (nr < 3 || (!P.norm2 && nv < 3) || nv * nr > 64 || nv > GW || nr > GW) return false;
     // The oracle does this with atan2 / acos; here the same arc arithmetic is carried out on unit vectors (no
     // trigonometric calls): the end points of a pair's arc are w^ rotated by -+beta (cos beta = q), the room from a* to an
     // end point is an angle in [0, pi] iff the cross product is >= 0, and tan(angle/2) = sin/(1 + cos) orders such angles
@@ -577,14 +601,14 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     const double off = P.norm2 ? W.b[2] : 0.0;
     const double ins = rsqrt(as0 * as0 + as1 * as1), u0 = as0 * ins, u1 = as1 * ins;
     bool fail = false; double thi = INFINITY, tlo = INFINITY;           // tan(hi/2), tan(lo/2); INFINITY = the cap hi = lo = pi
-    if (lane < nv * nr) {
-        const int k = lane / nr, j = lane - k * nr;
+    for (int pi = lane; pi < nv * nr; pi += GW) {           // one (obstacle vertex, robot vertex) pair per lane and round
+        const int k = pi / nr, j = pi - k * nr;
         const double vx = P.norm2 ? W.b[0] : W.vtx[k][0], vy = P.norm2 ? W.b[1] : W.vtx[k][1];
         const double rx = Rb.rv[j][0], ry = Rb.rv[j][1];
         const double wx = P.px - vx + (P.cs * rx - P.sn * ry), wy = P.py - vy + (P.sn * rx + P.cs * ry);
         const double cj = P.xi0 * rx + P.xi1 * ry + P.kappa0 + off;
         const double n2 = wx * wx + wy * wy;
-        if (!(n2 > 0)) fail = cj < 0;
+        if (!(n2 > 0)) fail = fail || cj < 0;
         else {
             const double inw = rsqrt(n2), q = -cj * inw, hx = wx * inw, hy = wy * inw;
             if (q >= 1.0) fail = true;
@@ -596,16 +620,19 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
                     const double emx = q * hx + sb * hy, emy = -sb * hx + q * hy; // w^ rotated by -beta: lower end
                     const double cp = u0 * epx + u1 * epy, sp = u0 * epy - u1 * epx;     // angle a* -> upper end
                     const double cm = u0 * emx + u1 * emy, sm = emx * u1 - emy * u0;     // angle lower end -> a*
-                    if (sp >= 0 && cp > -1.0) thi = sp / (1.0 + cp);
-                    else if (sp < 0 && sp > -1e-15) thi = 0.0;                    // a* on the upper end up to rounding
-                    if (sm >= 0 && cm > -1.0) tlo = sm / (1.0 + cm);
-                    else if (sm < 0 && sm > -1e-15) tlo = 0.0;
+                    double th = INFINITY, tl = INFINITY;
+                    if (sp >= 0 && cp > -1.0) th = sp / (1.0 + cp);
+                    else if (sp < 0 && sp > -1e-15) th = 0.0;                     // a* on the upper end up to rounding
+                    if (sm >= 0 && cm > -1.0) tl = sm / (1.0 + cm);
+                    else if (sm < 0 && sm > -1e-15) tl = 0.0;
+                    if (th < thi) thi = th;
+                    if (tl < tlo) tlo = tl;
                 }
             }
         }
     }
-    if (__ballot(fail)) return false;
-    thi = -wave_max(-thi); tlo = -wave_max(-tlo);
+    if (Grp<GW>::ballot(fail, wlane)) return false;
+    thi = -Grp<GW>::max(-thi); tlo = -Grp<GW>::max(-tlo);
     if (isinf(thi) && isinf(tlo)) return false;
     // a_c = a* rotated by (hi - lo)/2, from the half-angle tangents
     double chh, shh, chl, shl;
@@ -617,8 +644,8 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     int i1 = -1, i2 = -1; double l1 = 0, l2 = 0;
     if (P.norm2) { i1 = 0; i2 = 1; l1 = a0; l2 = a1; }
     else {
-        const double val = lane < nv ? a0 * W.vtx[lane < nv ? lane : 0][0] + a1 * W.vtx[lane < nv ? lane : 0][1] : -INFINITY, mx = wave_max(val);
-        const int kb = __ffsll((long long)__ballot(val == mx)) - 1;
+        const double val = lane < nv ? a0 * W.vtx[lane < nv ? lane : 0][0] + a1 * W.vtx[lane < nv ? lane : 0][1] : -INFINITY, mx = Grp<GW>::max(val);
+        const int kb = __ffsll((long long)Grp<GW>::ballot(val == mx, wlane)) - 1;
         decode_pair((int)W.lamc[kb] - 1 - P.E, P.E, i1, i2);
         const double a00 = W.A[i1][0], a01 = W.A[i1][1], a10 = W.A[i2][0], a11 = W.A[i2][1], det = a00 * a11 - a01 * a10;
         l1 = (a0 * a11 - a10 * a1) / det;            // A_S' lam_S = a
@@ -630,8 +657,8 @@ __device__ __forceinline__ bool central_normal_wave(const WaveLDS &W, const Robo
     const double gx = -(P.cs * a0 + P.sn * a1) - P.xi0, gy = -(-P.sn * a0 + P.cs * a1) - P.xi1;
     int j1, j2; double g1, g2;
     {
-        const double val = lane < nr ? gx * Rb.rv[lane < nr ? lane : 0][0] + gy * Rb.rv[lane < nr ? lane : 0][1] : -INFINITY, mx = wave_max(val);
-        const int jb = __ffsll((long long)__ballot(val == mx)) - 1;
+        const double val = lane < nr ? gx * Rb.rv[lane < nr ? lane : 0][0] + gy * Rb.rv[lane < nr ? lane : 0][1] : -INFINITY, mx = Grp<GW>::max(val);
+        const int jb = __ffsll((long long)Grp<GW>::ballot(val == mx, wlane)) - 1;
         decode_pair((int)Rb.muc[jb] - 1 - P.R, P.R, j1, j2);
         const double a00 = Rb.G[j1][0], a01 = Rb.G[j1][1], a10 = Rb.G[j2][0], a11 = Rb.G[j2][1], det = a00 * a11 - a01 * a10;
         g1 = (gx * a11 - a10 * gy) / det;

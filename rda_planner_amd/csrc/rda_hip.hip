@@ -36,6 +36,7 @@ struct Dev {
     rda_cfg c;
     int nt;                  // time slots of the staged obstacles (T+1 or 1)
     int warm;                // k_lammuz tries the previous support first (RDA_LMZ_WARM=0 disables)
+    int rows;                // four sub-problems per wave (k_lammuz_rows) when E+R+1 <= 16 (RDA_LMZ_ROWS=0 disables)
     unsigned char muc[40]; int nmv;   // robot support candidates that survive the vertex test (host, rda_create)
     double rv[28][2]; int nrv;        // robot vertices of the surviving pairs (list order)
     int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
@@ -216,9 +217,9 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
         if (lane == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
-    if (!d.warm || !lmz::solve_wave_warm(W, rb, P, lane, d.hint[n * T + t], best)) lmz::solve_wave(W, rb, P, lane, best);
+    if (!d.warm || !lmz::solve_wave_warm<64>(W, rb, P, lane, d.hint[n * T + t], best)) lmz::solve_wave(W, rb, P, lane, best);
     if (lane == 0) d.hint[n * T + t] = best.id >> 1;
-    if (d.centre) lmz::central_normal_wave(W, rb, P, lane, best);
+    if (d.centre) lmz::central_normal_wave<64>(W, rb, P, lane, best);
     // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
     double res = 0;
@@ -260,6 +261,113 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
 
 __global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx.x); }
 
+// K1, packed: FOUR sub-problems per wavefront, one per 16-lane DPP row (16 per workgroup).  The warm-started path - one
+// candidate on two lanes, the optimality certificate on E+R lanes, the central-normal step on (vertex, vertex) pairs, the
+// dual updates on E+R+1 lanes - never used more than a quarter of a wave, and the kernel is bound by instruction issue
+// (DESIGN.md section 5): the rows run it side by side.  Only a row whose certificate fails needs the 64-lane enumeration;
+// those rows are served one after the other by the whole wave.  Same device functions, same arithmetic, same results as
+// lammuz_body.  Requires E + R + 1 <= 16 (else the one-per-wave body is launched).
+__device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
+{
+    __shared__ lmz::WaveLDS wl[16];
+    __shared__ lmz::RobotLDS rb;
+    const int T = d.c.T, E = d.c.E, R = d.c.R;
+    if (d.ctrl->stop) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4, gl = lane & 15;
+    if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = d.G[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = d.h[threadIdx.x - 64];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = d.muc[threadIdx.x - 128];
+    if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
+    if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
+    const int w0 = block * 16 + wv * 4 + row;
+    const bool live = w0 < d.Nloc * T;
+    const int w = live ? w0 : block * 16;                      // a row past the end shadows a live one and writes nothing
+    const int nl = w / T, t = w % T;
+    const int n = d.rank * d.Nloc + nl;
+    lmz::WaveLDS &W = wl[wv * 4 + row];
+    const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
+    if (gl < 2 * E) W.A[gl >> 1][gl & 1] = d.A[ao * 2 + gl];
+    if (gl < E) W.b[gl] = d.b[ao + gl];
+    __syncthreads();
+    lmz::Params P;
+    P.E = E; P.R = R; P.norm2 = d.cone[n];
+    P.px = d.s[t + 1]; P.py = d.s[(T + 1) + t + 1];
+    const double phi = d.s[2 * (T + 1) + t];                  // heading of column t (quirk Q1)
+    P.cs = cos(phi); P.sn = sin(phi);
+    const size_t o = (size_t)n * (T + 1) + t + 1;
+    P.xi0 = d.xi[2 * o]; P.xi1 = d.xi[2 * o + 1];
+    const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
+    P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
+    lmz::Sol best;
+    double prev = 0.0;
+    if (gl < E) prev = d.lam[o * E + gl];
+    else if (gl < E + R) prev = d.mu[o * R + gl - E];
+    lmz::pose_products(W, P, gl);
+    {
+        const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
+        for (int i = gl; i < 40; i += 16) W.lamc[i] = d.oc_lamc[oc * 40 + i];
+        for (int i = gl; i < 56; i += 16) (&W.vtx[0][0])[i] = d.oc_vtx[oc * 56 + i];
+        if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
+    }
+    lmz::wave_sync();
+    const bool ok = d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[n * T + t], best);
+    unsigned long long need = __ballot(!ok);                   // rows that need the enumeration (wave-uniform from here)
+    while (need) {
+        const int g = (__ffsll((long long)need) - 1) >> 4;
+        need &= ~(0xffffull << (16 * g));
+        lmz::Params Pg;
+        const int src = 16 * g;
+        Pg.E = E; Pg.R = R; Pg.norm2 = __shfl(P.norm2, src, 64);
+        Pg.px = __shfl(P.px, src, 64); Pg.py = __shfl(P.py, src, 64); Pg.cs = __shfl(P.cs, src, 64); Pg.sn = __shfl(P.sn, src, 64);
+        Pg.xi0 = __shfl(P.xi0, src, 64); Pg.xi1 = __shfl(P.xi1, src, 64); Pg.kappa0 = __shfl(P.kappa0, src, 64);
+        Pg.ro2 = P.ro2; Pg.delta = P.delta;
+        lmz::Sol bg;
+        lmz::solve_wave(wl[wv * 4 + g], rb, Pg, lane, bg);
+        if (row == g) best = bg;
+    }
+    if (gl == 0 && live) d.hint[n * T + t] = best.id >> 1;
+    if (d.centre) lmz::central_normal_wave<16>(W, rb, P, lane, best);
+    // ---- fused dual / residual updates (every lane of the row holds the row's winner) ----------------
+    const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
+    double res = 0;
+    if (gl < E) {
+        double v = lmz::lam_of(best, P.norm2, gl);
+        res = (v - prev) * (v - prev); if (live) d.lam[o * E + gl] = v;
+    } else if (gl < E + R) {
+        int j = gl - E;
+        double v = lmz::mu_of(best, j);
+        res = (v - prev) * (v - prev); if (live) d.mu[o * R + j] = v;
+    } else if (gl == E + R) {
+        double old = d.z[n * T + t];
+        res = (znew - old) * (znew - old); if (live) d.z[n * T + t] = znew;
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) res += __shfl_xor(res, off, 16);
+    if (gl == 0 && live) {
+        double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
+        for (int i = 0; i < E; ++i) {
+            double v = lmz::lam_of(best, P.norm2, i);
+            ax += v * W.A[i][0]; ay += v * W.A[i][1]; bl += v * W.b[i];
+        }
+        for (int j = 0; j < R; ++j) {
+            double v = lmz::mu_of(best, j);
+            mh += v * rb.h[j]; gx += v * rb.G[j][0]; gy += v * rb.G[j][1];
+        }
+        const double hx = gx + P.cs * ax + P.sn * ay, hy = gy - P.sn * ax + P.cs * ay;      // Hm, :682
+        const double xin0 = P.xi0 + hx, xin1 = P.xi1 + hy;                                  // :683
+        d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
+        const double im = ax * P.px + ay * P.py - bl - mh;                                  // :659
+        const double zetan = zeta + im - dbar - znew;                                       // :666
+        d.zeta[n * T + t] = zetan;
+        const int k = t * d.Nloc + nl;
+        coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
+        coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
+        coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_lammuz_rows(Dev d) { lammuz_body_rows(d, blockIdx.x); }
+
 struct RobotCands { unsigned char muc[40]; int nmv; double rv[28][2]; int nrv; int centre; };
 
 // pure-function batch hook (rda_lammuz_batch)
@@ -294,7 +402,7 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
     lmz::Sol best;
     lmz::prepare_wave(W, P, lane);
     lmz::solve_wave(W, rb, P, lane, best);
-    if (rc.centre) lmz::central_normal_wave(W, rb, P, lane, best);
+    if (rc.centre) lmz::central_normal_wave<64>(W, rb, P, lane, best);
     if (P.prof && lane == 0) prof[7] += clock64() - t_begin;
     if (lane < E) lam[(size_t)k * E + lane] = lmz::lam_of(best, P.norm2, lane);
     else if (lane < E + R) mu[(size_t)k * R + lane - E] = lmz::mu_of(best, lane - E);
@@ -433,6 +541,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
     { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
+    { const char *w = getenv("RDA_LMZ_ROWS"); H->d.rows = (cfg->E + cfg->R + 1 <= 16) && (w ? atoi(w) != 0 : true); }
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
     H->d.centre = g_tie_centre;
     { const char *e = getenv("RDA_TIE_CENTRE"); if (e) H->d.centre = atoi(e) ? 1 : 0; }      // experiments only
@@ -649,7 +758,8 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
         if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
         RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
         if (H->timing) { (void)hipEventRecord(next_event(H, 1), H->stream); (void)hipEventRecord(next_event(H, 0), H->stream); }
-        hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
+        if (d.rows && d.obstacle_num) hipLaunchKernelGGL(k_lammuz_rows, dim3((d.Nloc * d.c.T + 15) / 16), dim3(256), 0, H->stream, d);
+        else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         if (H->comm) {      // one exchange per ADMM iteration: every rank's chunk to every rank (in place)
             int nrc = H->p_allgather(d.coef + (size_t)d.rank * d.chunk, d.coef, d.chunk, /*ncclDouble*/ 8, H->comm, H->stream);
@@ -972,7 +1082,8 @@ extern "C" int rda_admm_lammuz(rda_handle *H)
     if (!H) return RDA_ERR_ARG;
     Dev d = H->d;
     const int blocks = (d.Nloc * d.c.T + 3) / 4;
-    hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
+    if (d.rows && d.obstacle_num) hipLaunchKernelGGL(k_lammuz_rows, dim3((d.Nloc * d.c.T + 15) / 16), dim3(256), 0, H->stream, d);
+        else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
@@ -1012,7 +1123,10 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su_fleet(const Dev
     su_body<TT>(d, it, e.s + k * ns, e.u + k * nu, e.ref + k * ns, e.speed + k);
 }
 
+// a member without obstacles (Q9) or of a shape the packed body does not take runs the one-per-wave body on the first quarter
+// of the (packed-size) grid... kept simple: the fleet uses the packed kernel only when every member can
 __global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs) { lammuz_body(devs[blockIdx.y], blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_rows(const Dev *devs) { lammuz_body_rows(devs[blockIdx.y], blockIdx.x); }
 
 __global__ __launch_bounds__(su::NT) void k_finish_fleet(const Dev *devs, const EgoIO *io, int k)
 {
@@ -1032,7 +1146,7 @@ struct rda_fleet {
     double *h_out, *d_out;                // per ego: u | s
     rda_info *h_info, *d_info;
     hipEvent_t ev;
-    int T, iter_num, blocks;
+    int T, iter_num, blocks, rows;
     size_t su_lds;
     // tracked stepping (device-side pre_process), allocated on first use
     track::In *h_trk_in, *d_trk_in; track::Out *h_trk_out, *d_trk_out;
@@ -1103,6 +1217,8 @@ static int fleet_refresh(rda_fleet *F)
         HIPCHK(hipEventRecord(F->ev, F->egos[i]->stream));
         HIPCHK(hipStreamWaitEvent(F->stream, F->ev, 0));
     }
+    F->rows = 1;
+    for (int i = 0; i < F->B; ++i) if (!F->egos[i]->d.rows || !F->egos[i]->d.obstacle_num) F->rows = 0;
     if (changed) {
         HIPCHK(hipStreamSynchronize(F->stream));            // an earlier copy out of the pinned mirror may still be queued
         for (int i = 0; i < F->B; ++i) memcpy(&F->h_devs[i], &F->egos[i]->d, sizeof(Dev));
@@ -1117,7 +1233,8 @@ static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
     hipLaunchKernelGGL(k_begin_fleet, dim3(B), dim3(64), 0, F->stream, F->d_devs);
     for (int it = 0; it < F->iter_num; ++it) {
         RDA_SU_DISPATCH(F->T, hipLaunchKernelGGL(k_su_fleet<TT>, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, it, k));
-        hipLaunchKernelGGL(k_lammuz_fleet, dim3(F->blocks, B), dim3(256), 0, F->stream, F->d_devs);
+        if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
+        else hipLaunchKernelGGL(k_lammuz_fleet, dim3(F->blocks, B), dim3(256), 0, F->stream, F->d_devs);
     }
     hipLaunchKernelGGL(k_finish_fleet, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, k);
     HIPCHK(hipGetLastError());
