@@ -366,7 +366,10 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_lammuz_rows(Dev d) { lammuz_body_rows(d, blockIdx.x); }
+// two builds: all registers and one workgroup per CU (no spills: the shorter critical path a single ego wants), or two
+// workgroups per CU with a few spilled registers (more sub-problems in flight: what a full chip wants)
+__global__ __launch_bounds__(256) void k_lammuz_rows(Dev d) { lammuz_body_rows(d, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void k_lammuz_rows_dense(Dev d) { lammuz_body_rows(d, blockIdx.x); }
 
 struct RobotCands { unsigned char muc[40]; int nmv; double rv[28][2]; int nrv; int centre; };
 
@@ -479,6 +482,7 @@ struct rda_handle {
     void *h_sc; size_t h_sc_bytes;
     // device-side pre_process (rda_upload_path / rda_step_tracked)
     double *d_path; int path_len; track::Out *d_trk, *h_trk;
+    int dense_from;          // grids above this many workgroups use k_lammuz_rows_dense (RDA_LMZ_DENSE_FROM)
 };
 
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -541,6 +545,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
     { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
+    { const char *w = getenv("RDA_LMZ_DENSE_FROM"); H->dense_from = w ? atoi(w) : 256; }
     { const char *w = getenv("RDA_LMZ_ROWS"); H->d.rows = (cfg->E + cfg->R + 1 <= 16) && (w ? atoi(w) != 0 : true); }
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
     H->d.centre = g_tie_centre;
@@ -745,6 +750,18 @@ static hipEvent_t next_event(rda_handle *H, int which)
     return H->ev[which][H->ev_used[which]++];
 }
 
+// K1 launch: packed rows when the shape allows (small grids: the no-spill build, large grids: two workgroups per CU), else
+// one sub-problem per wave (also the no-obstacle case, quirk Q9)
+static void launch_lammuz(rda_handle *H, const Dev &d)
+{
+    const int units = d.Nloc * d.c.T;
+    if (d.rows && d.obstacle_num) {
+        const int nb = (units + 15) / 16;
+        if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d);
+        else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(256), 0, H->stream, d);
+    } else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
+}
+
 // queue the whole ADMM loop of one MPC step (rda_solver.py:588-596) - no host synchronisation
 static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
                         double *out_u, double *out_s, rda_info *info)
@@ -752,14 +769,12 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
     Dev d = H->d;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     const int T = d.c.T;
-    const int blocks = (d.Nloc * T + 3) / 4;
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, d);
     for (int it = 0; it < d.c.iter_num; ++it) {
         if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
         RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
         if (H->timing) { (void)hipEventRecord(next_event(H, 1), H->stream); (void)hipEventRecord(next_event(H, 0), H->stream); }
-        if (d.rows && d.obstacle_num) hipLaunchKernelGGL(k_lammuz_rows, dim3((d.Nloc * d.c.T + 15) / 16), dim3(256), 0, H->stream, d);
-        else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
+        launch_lammuz(H, d);
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         if (H->comm) {      // one exchange per ADMM iteration: every rank's chunk to every rank (in place)
             int nrc = H->p_allgather(d.coef + (size_t)d.rank * d.chunk, d.coef, d.chunk, /*ncclDouble*/ 8, H->comm, H->stream);
@@ -817,12 +832,12 @@ extern "C" int rda_step_scene(rda_handle *H, const double *nom_s, const double *
 // ---- device-side pre_process --------------------------------------------------------------------
 __global__ void k_track(Dev d, track::In in, double *path, int L, const double *nom_u, double *step, track::Out *out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double win[track::LDS_DOUBLES];
     const int T = d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     track::Ego e;
     e.path = path; e.L = L; e.nom_u = nom_u; e.nom_s = step; e.ref = step + ns + nu; e.speed = step + 2 * ns + nu;
     e.T = T; e.dynamics = d.c.dynamics; e.dt = d.c.dt; e.wheelbase = d.c.L;
-    track::run(e, in, *out);
+    track::run(e, in, *out, win, threadIdx.x);
 }
 
 extern "C" int rda_upload_path(rda_handle *H, int L, const double *path)
@@ -1081,9 +1096,7 @@ extern "C" int rda_admm_lammuz(rda_handle *H)
 {
     if (!H) return RDA_ERR_ARG;
     Dev d = H->d;
-    const int blocks = (d.Nloc * d.c.T + 3) / 4;
-    if (d.rows && d.obstacle_num) hipLaunchKernelGGL(k_lammuz_rows, dim3((d.Nloc * d.c.T + 15) / 16), dim3(256), 0, H->stream, d);
-        else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? blocks : 1), dim3(256), 0, H->stream, d);
+    launch_lammuz(H, d);
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
@@ -1268,18 +1281,19 @@ extern "C" int rda_fleet_step(rda_fleet *F, const double *nom_s, const double *n
     return RDA_OK;
 }
 
-// device-side pre_process of every member (one thread per ego), then the fleet step on what it wrote
+// device-side pre_process of every member (one wave per ego), then the fleet step on what it wrote
 __global__ void k_track_fleet(const Dev *devs, const EgoIO *io, const track::In *ins, double *const *paths, const int *lens,
                               track::Out *outs, int B)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double win[track::LDS_DOUBLES];
+    const int b = blockIdx.x;
     if (b >= B) return;
     const Dev &d = devs[b];
     track::Ego e;
     e.path = paths[b]; e.L = lens[b]; e.nom_u = io[b].u; e.nom_s = const_cast<double *>(io[b].s); e.ref = const_cast<double *>(io[b].ref);
     e.speed = const_cast<double *>(io[b].speed);
     e.T = d.c.T; e.dynamics = d.c.dynamics; e.dt = d.c.dt; e.wheelbase = d.c.L;
-    track::run(e, ins[b], outs[b]);
+    track::run(e, ins[b], outs[b], win, threadIdx.x);
 }
 
 extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const double *ref_speed, const int32_t *cur_index,
@@ -1333,7 +1347,7 @@ extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const 
                                 hipMemcpyHostToDevice, F->stream));
     }
     HIPCHK(hipMemcpyAsync(F->d_trk_in, F->h_trk_in, B * sizeof(track::In), hipMemcpyHostToDevice, F->stream));
-    hipLaunchKernelGGL(k_track_fleet, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, F->stream, F->d_devs, F->d_io_track, F->d_trk_in,
+    hipLaunchKernelGGL(k_track_fleet, dim3((unsigned)B), dim3(64), 0, F->stream, F->d_devs, F->d_io_track, F->d_trk_in,
                        F->d_paths, F->d_lens, F->d_trk_out, (int)B);
     rc = fleet_enqueue(F, F->d_io_track, 0);
     if (rc != RDA_OK) return rc;

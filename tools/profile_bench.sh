@@ -9,7 +9,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_${TAG}
 rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o bench -- \
-    python bench.py --steps 200 --warmup 10 --no-cpu-baseline --egos 0 > "$OUT/bench.log" 2>&1 || true
+    python bench.py --steps 200 --warmup 10 --no-cpu-baseline --egos 0 --fleet-egos 0 > "$OUT/bench.log" 2>&1 || true
 grep '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
 find "$OUT" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 cat "$OUT/kernel_stats.csv" 2>/dev/null | head -20

@@ -14,7 +14,7 @@ for GROUP in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
   OUT=gpurun_out/issue_${TAG}_$(echo $GROUP | cut -d' ' -f1)
   rm -rf "$OUT"; mkdir -p "$OUT"
   rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d "$OUT" -o pmc -- \
-      python bench.py --steps 40 --warmup 5 --no-cpu-baseline --egos 0 > "$OUT/bench.log" 2>&1 || true
+      python bench.py --steps 40 --warmup 5 --no-cpu-baseline --egos 0 --fleet-egos 0 > "$OUT/bench.log" 2>&1 || true
   find "$OUT" -name '*counter_collection.csv' -exec cp {} "$OUT/counters.csv" \;
   python - "$OUT/counters.csv" >> "$SUMMARY" <<'PY'
 import csv, sys, collections

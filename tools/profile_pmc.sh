@@ -8,7 +8,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   OUT=gpurun_out/pmc_${TAG}_${C}
   rm -rf "$OUT"; mkdir -p "$OUT"
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT" -o pmc -- \
-      python bench.py --steps 40 --warmup 5 --no-cpu-baseline --egos 0 > "$OUT/bench.log" 2>&1 || true
+      python bench.py --steps 40 --warmup 5 --no-cpu-baseline --egos 0 --fleet-egos 0 > "$OUT/bench.log" 2>&1 || true
   find "$OUT" -name '*counter_collection.csv' -exec cp {} "$OUT/counters.csv" \;
   python - "$OUT/counters.csv" $C <<'PY'
 import csv, sys, collections
