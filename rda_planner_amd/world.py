@@ -12,6 +12,7 @@ Supported YAML subset: world.step_time; one robot with kinematics acker|diff|omn
 groups with `number`, distribution manual (`state` list) or random (`range_low/high`, seeded), shapes circle / polygon
 (`vertices`, absolute) / rectangle, optional `kinematics` + `vel_max` (then the obstacle moves with a seeded constant
 velocity and is reflected at the world border - a simplification of ir-sim's `dash`/`wander` behaviours).
+A `lidar2d` sensor of the robot is simulated by exact ray casting (`get_lidar_scan`).
 Rendering calls are accepted and ignored.
 """
 from types import SimpleNamespace
@@ -101,6 +102,14 @@ class World:
                     self.obstacles.append(_Obstacle("polygon", None, None, V, vel))
         self.collided = False
         self.arrived = False
+        # first lidar2d sensor of the robot (ir-sim: beams over [-angle_range/2, angle_range/2] about the heading)
+        self.lidar = None
+        for sen in rb.get("sensors", []) or []:
+            if sen.get("type", sen.get("name")) == "lidar2d":
+                half = 0.5 * float(sen.get("angle_range", np.pi))
+                self.lidar = SimpleNamespace(range_min=float(sen.get("range_min", 0.0)), range_max=float(sen.get("range_max", 10.0)),
+                                             angle_min=-half, angle_max=half, number=int(sen.get("number", 100)))
+                break
 
     # ---- the calls the example scripts make ---------------------------------------------------------------------
     def get_robot_info(self):
@@ -110,6 +119,44 @@ class World:
 
     def get_obstacle_info_list(self):
         return list(self.obstacles)
+
+    def get_lidar_scan(self):
+        """ranges of the lidar beams against the current obstacles (noise-free), in the dict layout of ir-sim's scan"""
+        ld = self.lidar
+        if ld is None:
+            raise RuntimeError("the robot of this world has no lidar2d sensor")
+        ang = np.linspace(ld.angle_min, ld.angle_max, ld.number)
+        th = self.robot.state[2, 0] + ang
+        o = self.robot.state[0:2, 0]
+        d = np.stack((np.cos(th), np.sin(th)), axis=1)                      # (beams, 2) unit directions
+        rng = np.full(ld.number, ld.range_max)
+        for ob in self.obstacles:
+            if ob.center is not None:                                        # ray / circle
+                f = o - ob.center[:, 0]
+                b = d @ f
+                disc = b * b - (f @ f - ob.radius ** 2)
+                ok = disc >= 0
+                t = np.where(ok, -b - np.sqrt(np.where(ok, disc, 0.0)), np.inf)
+                t = np.where(t >= 0, t, np.inf)
+                rng = np.minimum(rng, t)
+            else:                                                            # ray / polygon edges
+                V = ob.vertex
+                for k in range(V.shape[1]):
+                    p, q = V[:, k], V[:, (k + 1) % V.shape[1]]
+                    e = q - p
+                    den = d[:, 0] * e[1] - d[:, 1] * e[0]
+                    w = p - o
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        t = (w[0] * e[1] - w[1] * e[0]) / den               # along the beam
+                        s_ = (w[0] * d[:, 1] - w[1] * d[:, 0]) / den         # along the edge
+                    ok = (np.abs(den) > 1e-12) & (t >= 0) & (s_ >= 0) & (s_ <= 1)
+                    rng = np.minimum(rng, np.where(ok, t, np.inf))
+        rng = np.clip(rng, ld.range_min, ld.range_max)
+        return {"ranges": rng, "angle_min": ld.angle_min, "angle_max": ld.angle_max, "range_min": ld.range_min,
+                "range_max": ld.range_max, "angle_increment": (ld.angle_max - ld.angle_min) / max(ld.number - 1, 1)}
+
+    def draw_box(self, *a, **k):
+        pass
 
     def step(self, vel):
         self.robot.state = sc.kinematic_step(self.robot.state, np.asarray(vel, float).reshape(2, 1), self._car, self.step_time)

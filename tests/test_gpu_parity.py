@@ -418,3 +418,39 @@ def test_closed_loop_corridor_example():
         if info["arrive"]:
             break
     assert info["arrive"] and minc > 0.2, (info["arrive"], minc)
+
+
+def test_closed_loop_lidar_example():
+    """BASELINE config C3 (example/lidar_nav/lidar_path_track.py): boxes clustered from each lidar scan, max_obs_num=4 - the set of
+    obstacles, their order and their number change from tick to tick.  The GPU path follows the oracle step by step (state
+    re-synchronised every step) and, run on its own, reaches the goal without touching anything"""
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd.lidar import scan_box
+    import rda_planner_amd.world as irsim
+    yaml_path = os.path.join(os.path.dirname(__file__), "golden", "world_lidar_track.yaml")
+    env = irsim.make(yaml_path)
+    ri = env.get_robot_info()
+    car_t = sc.car(ri.G, ri.h, ri.cone_type, ri.wheelbase, [10, 1], [10, 0.5], "acker")
+    kw = dict(receding=10, iter_num=2, max_edge_num=4, max_obs_num=4, obstacle_order=True, wu=1.0, slack_gain=13)
+    cpu, gpu = _pair(kw, car_t, sc.path_track_ref(), oracle_backend)
+    for i in range(150):
+        obs = scan_box(env.robot.state, env.get_lidar_scan())
+        uc, ic = cpu.control(env.robot.state.copy(), 4.0, list(obs))
+        ug, ig = gpu.control(env.robot.state.copy(), 4.0, list(obs))
+        assert ic["iters"] == ig["iters"] and cpu.cur_index == gpu.cur_index, i
+        assert np.abs(uc - ug).max() < 1e-6, (i, np.abs(uc - ug).max())
+        gpu.rda.set_state(cpu.rda.get_state())
+        gpu.cur_vel_array = cpu.cur_vel_array.copy()
+        env.step(uc)
+    env = irsim.make(yaml_path)
+    solo = MPC(car_t, sc.path_track_ref(), sample_time=0.1, **kw)
+    min_clear, arrived = np.inf, False
+    for i in range(500):
+        u, info = solo.control(env.robot.state, 4.0, scan_box(env.robot.state, env.get_lidar_scan()))
+        env.step(u)
+        min_clear = min(min_clear, env.clearance())
+        if env.done() or info["arrive"]:
+            arrived = info["arrive"]
+            break
+    assert arrived and not env.collided and min_clear > 0.3

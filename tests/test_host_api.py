@@ -254,3 +254,96 @@ def test_corridor_example_is_traversed():
             break
     assert info["arrive"] and minc > 0.2, (info["arrive"], minc)
     assert max(ys) > 21.3 and min(ys) < 19.3                       # it went above the first box and below the second
+
+
+# ---- lidar front end (reference example/lidar_nav/lidar_path_track.py:20-60) ----------------------------------
+def test_dbscan_equals_scikit_learn():
+    """the numpy DBSCAN labels every point like sklearn.cluster.DBSCAN (cluster numbering, border points, noise)"""
+    sk = pytest.importorskip("sklearn.cluster")
+    from rda_planner_amd import lidar
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        n, k = int(rng.integers(4, 150)), int(rng.integers(1, 6))
+        cent = rng.uniform(-10, 10, (k, 2))
+        X = cent[rng.integers(0, k, n)] + rng.normal(0, rng.uniform(0.2, 1.5), (n, 2))
+        eps, ms = float(rng.choice([0.5, 1.0, 2.0])), int(rng.choice([3, 6, 10]))
+        assert np.array_equal(lidar.dbscan(X, eps, ms), sk.DBSCAN(eps=eps, min_samples=ms).fit_predict(X)), trial
+    assert lidar.dbscan(np.zeros((0, 2))).shape == (0,)
+
+
+def test_min_area_rect_known_answers():
+    from rda_planner_amd import lidar
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        th = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        L, W = rng.uniform(1, 5), rng.uniform(0.3, 2)
+        corners = np.array([[0, 0], [L, 0], [L, W], [0, W]])
+        shift = rng.uniform(-5, 5, 2)
+        pts = np.vstack([corners, rng.uniform([0, 0], [L, W], (30, 2))]) @ R.T + shift
+        box = lidar.min_area_rect(pts)
+        want = corners @ R.T + shift
+        # the same four corners (any starting corner), counter-clockwise
+        d = np.linalg.norm(box[:, None, :] - want[None, :, :], axis=2)
+        assert d.min(axis=1).max() < 1e-9 and len(set(d.argmin(axis=1))) == 4
+        e = np.roll(box, -1, axis=0) - box
+        assert all(e[i][0] * e[(i + 1) % 4][1] - e[i][1] * e[(i + 1) % 4][0] > 0 for i in range(4))
+    # degenerate clusters stay bounded obstacles: collinear points, a single point
+    seg = lidar.min_area_rect(np.array([[0.0, 0.0], [1.0, 1.0], [2.0, 2.0], [0.5, 0.5]]))
+    assert abs(np.linalg.norm(seg[1] - seg[0]) * np.linalg.norm(seg[2] - seg[1]) - 2 * np.sqrt(2) * 0.01) < 1e-12
+    pt = lidar.min_area_rect(np.array([[3.0, 4.0]] * 5))
+    assert np.allclose(pt.mean(axis=0), [3, 4]) and np.allclose(np.ptp(pt, axis=0), 0.01)
+
+
+def test_lidar_scan_and_scan_box():
+    """ray casting of the headless world against known geometry, then the scan_box chain on it"""
+    import rda_planner_amd.world as irsim
+    from rda_planner_amd import lidar
+    cfg = {"world": {"step_time": 0.1},
+           "robot": [{"kinematics": {"name": "acker"}, "shape": {"name": "rectangle", "length": 4.6, "width": 1.6, "wheelbase": 3},
+                      "state": [0, 0, 0.5], "sensors": [{"type": "lidar2d", "range_max": 10, "angle_range": np.pi, "number": 181}]}],
+           "obstacle": [{"number": 1, "distribution": {"name": "manual"}, "state": [[6 * np.cos(0.5), 6 * np.sin(0.5)]], "shape": [{"name": "circle", "radius": 1.0}]},
+                        {"number": 1, "distribution": {"name": "manual"}, "state": [[0, 0, 0]],
+                         "shape": [{"name": "polygon", "vertices": [[-4, 3], [-2, 3], [-2, 30], [-4, 30]]}]}]}
+    env = irsim.World(cfg)
+    scan = env.get_lidar_scan()
+    r = np.asarray(scan["ranges"])
+    assert len(r) == 181 and scan["angle_min"] == -scan["angle_max"] and scan["range_max"] == 10
+    assert abs(r[90] - 5.0) < 1e-12                                  # straight ahead: centre distance 6 - radius 1
+    k = 90 + 5                                                       # 5 degrees off axis: law of cosines
+    a = np.deg2rad(5.0)
+    assert abs(r[k] - (6 * np.cos(a) - np.sqrt(1 - (6 * np.sin(a)) ** 2))) < 1e-9
+    assert r[0] == 10.0                                              # nothing on the right
+    boxes = lidar.scan_box(env.robot.state, scan)
+    assert len(boxes) == 2 and all(b.cone_type == "Rpositive" and b.vertex.shape == (2, 4) for b in boxes)
+    cents = sorted([b.vertex.mean(axis=1) for b in boxes], key=lambda c: c[0])
+    # the circle is seen as the box of its near arc: centre on the line of sight, between 5 m and 6 m away
+    c = cents[1]
+    assert abs(np.arctan2(c[1], c[0]) - 0.5) < 0.02 and 5.0 < np.linalg.norm(c) < 6.0
+    # the wall: only its visible faces, all corners on / inside the true polygon (1 cm minimum thickness)
+    wv = [b for b in boxes if b.vertex.mean(axis=1)[0] < 0][0].vertex
+    assert wv[0].min() > -4.02 and wv[0].max() < -1.98 and wv[1].min() > 2.98
+    assert lidar.scan_box(env.robot.state, dict(scan, ranges=np.full(181, 10.0))) == []
+
+
+def test_lidar_example_is_driven_to_the_goal():
+    """BASELINE config C3, the loop of example/lidar_nav/lidar_path_track.py:64-95 against the headless world: the planner only
+    knows the boxes `scan_box` builds from each scan"""
+    import rda_planner_amd.world as irsim
+    from rda_planner_amd.lidar import scan_box
+    env = irsim.make(os.path.join(os.path.dirname(__file__), "golden", "world_lidar_track.yaml"))
+    ri = env.get_robot_info()
+    car_tuple = sc.car(ri.G, ri.h, ri.cone_type, ri.wheelbase, [10, 1], [10, 0.5], "acker")
+    mpc_opt = MPC(car_tuple, sc.path_track_ref(), receding=10, sample_time=env.step_time, process_num=4, iter_num=2, max_edge_num=4,
+                  max_obs_num=4, obstacle_order=True, wu=1.0, slack_gain=13, _backend=oracle_backend)
+    min_clear, seen, arrived = np.inf, 0, False
+    for i in range(500):
+        obs_list = scan_box(env.robot.state, env.get_lidar_scan())
+        seen = max(seen, len(obs_list))
+        opt_vel, info = mpc_opt.control(env.robot.state, 4, obs_list)
+        env.step(opt_vel)
+        min_clear = min(min_clear, env.clearance())
+        if env.done() or info["arrive"]:
+            arrived = info["arrive"]
+            break
+    assert arrived and not env.collided and min_clear > 0.3 and seen >= 2
