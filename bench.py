@@ -338,8 +338,14 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 3), "peak": peak, "unit": "GB/s",
                 "frac": round(ach / peak, 6), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
                 "launches": launches, "total_ms": round(total_ms, 3), "algorithmic_bytes_per_launch": bytes_per_launch}
-    r_lm = roof("k_lammuz", lm_avg, unit_bytes * N * T, lm_n, lm_ms)
-    r_su = roof("k_su", su_avg, 48 * N * T + 8 * (8 * (T + 1) + 5 * T), su_n, su_ms)
+    # the LamMuZ kernel that was actually launched (rda_hip.hip launch_lammuz): packed rows when E+R+1 <= 16, the two-workgroup
+    # build above 256 workgroups; RDA_LMZ_ROWS=0 selects the one-sub-problem-per-wave kernel
+    lm_kernel = "k_lammuz"
+    if E + R + 1 <= 16 and os.environ.get("RDA_LMZ_ROWS", "1") != "0":
+        n_loc = N // world if shard else N
+        lm_kernel = "k_lammuz_rows_dense" if (n_loc * T + 15) // 16 > int(os.environ.get("RDA_LMZ_DENSE_FROM", "256")) else "k_lammuz_rows"
+    r_lm = roof(lm_kernel, lm_avg, unit_bytes * N * T, lm_n, lm_ms)
+    r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", su_avg, 48 * N * T + 8 * (8 * (T + 1) + 5 * T), su_n, su_ms)
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file):
         try:

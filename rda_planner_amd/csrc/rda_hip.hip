@@ -3,9 +3,12 @@
 // Per ADMM iteration two launches on the handle's stream, no host synchronisation in between:
 //   k_su      <<<1, 256>>>      su-problem (interior point + Riccati), relinearisation point update,
 //                               residual reduction / early-stop flag of the previous iteration
-//   k_lammuz  <<<N*T/4, 256>>>  one (obstacle, stage) LamMuZ sub-problem per wavefront, fused with
+//   k_lammuz_rows <<<N*T/16, 256>>>  one (obstacle, stage) LamMuZ sub-problem per 16-lane row of a wavefront (k_lammuz
+//                               <<<N*T/4, 256>>>: one per wavefront, for E+R+1 > 16), fused with
 //                               the lam'A / lam'b products, the xi / zeta updates and the residual
 //                               partials (reference rda_solver.py:529-542, 639-690, 781-793)
+// In front of them, optional: scene::k_* (the caller's obstacle conversion / ordering) and k_track (the caller's
+// pre_process); rda_fleet_* launches the same bodies once for B egos.
 // All solver state (duals, products, nominal trajectory, staged obstacles) stays resident in HBM
 // between iterations and between MPC steps, exactly like the reference keeps it in CVXPY Parameter
 // values (quirks Q4-Q6 come for free).
