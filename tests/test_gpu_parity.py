@@ -454,3 +454,46 @@ def test_closed_loop_lidar_example():
             arrived = info["arrive"]
             break
     assert arrived and not env.collided and min_clear > 0.3
+
+
+@pytest.mark.parametrize("E,dyn,moving", [(4, "acker", False), (3, "diff", True), (6, "omni", False), (8, "acker", True)])
+def test_packed_rows_kernel_equals_one_per_wave_kernel(monkeypatch, E, dyn, moving):
+    """k_lammuz_rows (four sub-problems per wavefront, default when E+R+1 <= 16) and k_lammuz (one per wavefront,
+    RDA_LMZ_ROWS=0) run the same device functions: closed loops over polygons with 3..E edges, circles, padded and truncated
+    obstacle lists must agree BIT FOR BIT - controls, iteration counts, residuals and the dual state.  E=8 exercises two
+    rounds of (vertex, vertex) pairs per row in the central-normal step, N*T not a multiple of 16 the shadow rows."""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+    path = sc.line_path([5, 25, 0], [35, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    rng = np.random.default_rng(E)
+    obstacles = []
+    while len(obstacles) < 37:
+        c = rng.uniform((6, 14), (40, 36))
+        if np.min(np.linalg.norm(clear - c, axis=1)) < 2.4:
+            continue
+        k = int(rng.integers(3, E + 1))
+        vel = rng.uniform(-0.5, 0.5, 2) if (moving and rng.random() < 0.5) else (0.0, 0.0)
+        obstacles.append(sc.regular_polygon(c[0], c[1], k, rng.uniform(0.4, 1.0), rng.uniform(-np.pi, np.pi), vel))
+    obstacles += [sc.circle(18.0, 28.6, 0.7), sc.circle(27.0, 21.2, 0.5, velocity=(0.1, 0.2))]
+    runs = []
+    for rows in ("1", "0"):
+        monkeypatch.setenv("RDA_LMZ_ROWS", rows)
+        mpc = MPC(car_t, [p.copy() for p in path], receding=11, iter_num=3, max_edge_num=E, max_obs_num=41, time_print=False)
+        state = path[0].copy().reshape(3, 1)
+        if dyn == "omni":
+            state[2, 0] = 0.0
+        us, meta = [], []
+        for k in range(45):
+            cur = [o if not o.velocity.any() else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
+                                                   else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in obstacles]
+            shown = cur if k % 7 else cur[:20]                      # now and then fewer obstacles than slots (padding, Q3)
+            u, info = mpc.control(state, 4.0, list(shown))
+            us.append(u.ravel().copy()); meta.append((info["iters"], info["resi_dual"], info["resi_pri"], info["su_ipm_iters"]))
+            state = sc.kinematic_step(state, u, car_t, 0.1)
+        runs.append((np.array(us), meta, mpc.rda.get_state()))
+    (ua, ma, sa), (ub, mb, sb) = runs
+    assert ma == mb
+    assert np.array_equal(ua, ub), np.abs(ua - ub).max()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
