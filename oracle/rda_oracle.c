@@ -617,6 +617,9 @@ static void chol_solve(const double *K, int n, double *rhs)
     for (int i = n - 1; i >= 0; --i) { double v = rhs[i]; for (int k = i + 1; k < n; ++k) v -= K[k * n + i] * rhs[k]; rhs[i] = v / K[i * n + i]; }
 }
 
+#ifndef SIGMA_FLOOR
+#define SIGMA_FLOOR 1e-3
+#endif
 int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
                  double ref_speed, const double *a, const double *cc, const double *g,
                  const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters)
@@ -704,6 +707,9 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
         fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
 #endif
         if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
+        /* past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
+         * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
+        if (rdn <= 1e-7 * sc && rpn <= 1e-10 && mu <= 1e-12 * sc) { status = 0; break; }
         /* K = H + C' diag(lm/w) C */
         memcpy(K, Hm, sizeof(double) * n * n);
         for (int i = 0; i < mc; ++i) {
@@ -736,15 +742,16 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                 mu_aff /= mc;
                 /* centering parameter from the predictor step length, floored: the classical (mu_aff/mu)^3
                  * rule can cycle on the piecewise-quadratic hinge terms (observed with ro1 = 1) */
-                { double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03;
+                { double q = 1 - al, fl = al >= 0.95 ? SIGMA_FLOOR : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl; }
             }
         }
-        double al = 1.0;
+        /* fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game) */
+        double al = 1.0, tau = 1.0 - mu; if (tau < 0.995) tau = 0.995;
         for (int i = 0; i < mc; ++i) {
-            if (dw[i] < 0 && -0.995 * w[i] / dw[i] < al) al = -0.995 * w[i] / dw[i];
-            if (dl[i] < 0 && -0.995 * lm[i] / dl[i] < al) al = -0.995 * lm[i] / dl[i];
+            if (dw[i] < 0 && -tau * w[i] / dw[i] < al) al = -tau * w[i] / dw[i];
+            if (dl[i] < 0 && -tau * lm[i] / dl[i] < al) al = -tau * lm[i] / dl[i];
         }
         for (int i = 0; i < n; ++i) x[i] += al * dx[i];
         for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += al * dl[i]; }

@@ -28,6 +28,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#ifndef SIGMA_FLOOR
+#define SIGMA_FLOOR 1e-3
+#endif
 namespace su {
 
 constexpr int NT = 256;          // workgroup size
@@ -745,7 +748,8 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
-        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) {
+        // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
+        if ((rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) || (rdn <= 1e-7 * sc && rpn <= 1e-10 && mu <= 1e-12 * sc)) {
             if (screened) {        // the positions must have stayed within DELTA of the screening reference
                 double dv = 0;
                 if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
@@ -785,14 +789,16 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 double cdx = con_val(k, v[0], v[1], y[3], y[4], v[2]);
                 double dwv = -L.rp[i] - cdx, dlv = -(L.rc[i] + L.cl[i] * dwv) / L.cw[i];
                 L.dw[i] = dwv; L.dl[i] = dlv;
-                double fr = pass ? 0.995 : 1.0;
+                // fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
+                double fr = 1.0;
+                if (pass) { fr = 1.0 - mu; if (fr < 0.995) fr = 0.995; }
                 if (dwv < 0) { double x = -fr * L.cw[i] / dwv; if (x < al) al = x; }
                 if (dlv < 0) { double x = -fr * L.cl[i] / dlv; if (x < al) al = x; }
             }
             al = -block_reduce(-al, L.red, tid, true);
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
-                double q = 1 - al, fl = al >= 0.95 ? 0.003 : 0.03;
+                double q = 1 - al, fl = al >= 0.95 ? SIGMA_FLOOR : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl;
             } else {
