@@ -135,6 +135,21 @@ int  rda_upload_path(rda_handle *h, int L, const double *path /*L*3*/);
 int  rda_step_tracked(rda_handle *h, const double *state /*3*/, double ref_speed, int cur_index, double threshold, int ind_range,
                       const double *nom_u, double *out_u, double *out_s, rda_info *info,
                       double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading);
+/* The same tick in two halves, so that the caller's per-tick obstacle work overlaps the first su-problem.  The first
+ * su-problem of a step reads the nominal trajectory and the lam'A / lam'b products of the PREVIOUS step (the reference never
+ * refreshes them before rda_solver.py:591 - SURVEY quirk Q4) and nothing of the obstacles staged for this tick, so
+ *   rda_tracked_begin        queues k_track, the step reset and su-problem 0 and returns at once;
+ *   rda_upload_scene_async   (optional, at most once) stages this tick's raw scene like rda_upload_scene, without waiting;
+ *                            rda_upload_obstacles / rda_upload_scene may be used instead (they synchronise);
+ *   rda_tracked_finish       queues the rest of the ADMM loop, waits, returns what rda_step_tracked returns.
+ * Results are bit-identical to rda_upload_scene + rda_step_tracked (same kernels, same order of dependent work).
+ * Between begin and finish only the upload calls may be used on the handle. */
+int  rda_tracked_begin(rda_handle *h, const double *state /*3*/, double ref_speed, int cur_index, double threshold, int ind_range,
+                       const double *nom_u);
+int  rda_upload_scene_async(rda_handle *h, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                            const double *vel, const double *robot_xy, int order);
+int  rda_tracked_finish(rda_handle *h, double *out_u, double *out_s, rda_info *info,
+                        double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading);
 
 /* ---- Fleet: B independent egos advanced together (BASELINE config C5, "batched multi-ego") -------------------
  * The reference plans one robot per RDA_solver object (rda_solver.py:54-109) and a multi-robot user loops over

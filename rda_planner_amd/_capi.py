@@ -95,12 +95,21 @@ class CApi:
 
         # caller-side pre_process on the device (HIP library only)
         self.has_track = hasattr(lib, f"{prefix}_step_tracked")
+        self.has_pipeline = False
         if self.has_track:
             f("upload_path").argtypes = [C.c_void_p, C.c_int, c_double_p]
             f("upload_path").restype = C.c_int
             f("step_tracked").argtypes = [C.c_void_p, c_double_p, C.c_double, C.c_int, C.c_double, C.c_int, c_double_p,
                                           c_double_p, c_double_p, C.POINTER(Info), c_double_p, c_double_p, c_int_p, c_double_p]
             f("step_tracked").restype = C.c_int
+            self.has_pipeline = hasattr(lib, f"{prefix}_tracked_begin")
+            if self.has_pipeline:
+                f("tracked_begin").argtypes = [C.c_void_p, c_double_p, C.c_double, C.c_int, C.c_double, C.c_int, c_double_p]
+                f("upload_scene_async").argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, C.c_int]
+                f("tracked_finish").argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Info), c_double_p, c_double_p,
+                                                c_int_p, c_double_p]
+                for name in ("tracked_begin", "upload_scene_async", "tracked_finish"):
+                    f(name).restype = C.c_int
             if hasattr(lib, f"{prefix}_fleet_step_tracked"):
                 f("fleet_step_tracked").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, C.c_double, C.c_int, c_double_p,
                                                     c_double_p, c_double_p, C.POINTER(Info), c_double_p, c_int_p, c_double_p]

@@ -30,6 +30,9 @@
 struct Ctrl {
     int stop, iters, su_status, ipm_iters, st_tmp, it_tmp;
     double resi_dual, resi_pri;
+#ifdef RDA_LMZ_STATS
+    unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
+#endif
 };
 
 struct Dev;
@@ -315,6 +318,13 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     lmz::wave_sync();
     const bool ok = d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[n * T + t], best);
     unsigned long long need = __ballot(!ok);                   // rows that need the enumeration (wave-uniform from here)
+#ifdef RDA_LMZ_STATS
+    if (lane == 0) {
+        const int nf = __popcll(need) >> 4;
+        if (block == 0 && wv == 0) atomicAdd(&d.ctrl->lmz_stat[0], 1u);
+        atomicAdd(&d.ctrl->lmz_stat[1], (unsigned)nf); atomicAdd(&d.ctrl->lmz_stat[2 + nf], 1u);
+    }
+#endif
     while (need) {
         const int g = (__ffsll((long long)need) - 1) >> 4;
         need &= ~(0xffffull << (16 * g));
@@ -478,6 +488,8 @@ struct rda_handle {
     void *nccl_lib, *comm;
     int (*p_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
     int (*p_comm_destroy)(void *);
+    // a tick opened by rda_tracked_begin and not yet closed by rda_tracked_finish
+    int pending, pending_scene; const double *pending_in_u;
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
     // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
@@ -631,7 +643,7 @@ extern "C" int rda_reset(rda_handle *H)
 }
 
 // assign_obstacle_parameter (rda_solver.py:483-526): pad / truncate into N slots, then upload
-extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, const double *b, const int32_t *cone, int per_t)
+static int obstacles_stage(rda_handle *H, int n_obs, const double *A, const double *b, const int32_t *cone, int per_t, bool sync)
 {
     if (!H) return RDA_ERR_ARG;
     Dev &d = H->d;
@@ -656,8 +668,13 @@ extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, c
     HIPCHK(hipMemcpyAsync(d.cone, H->h_stage_cone, N * sizeof(int), hipMemcpyHostToDevice, H->stream));
     d.nt = (int)nt; d.obstacle_num = (int)N;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * nt + 3) / 4)), dim3(256), 0, H->stream, d);
-    HIPCHK(hipStreamSynchronize(H->stream));      // staging buffers are reused by the next call
+    if (sync) HIPCHK(hipStreamSynchronize(H->stream));      // staging buffers are reused by the next call
     return RDA_OK;
+}
+
+extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, const double *b, const int32_t *cone, int per_t)
+{
+    return obstacles_stage(H, n_obs, A, b, cone, per_t, true);
 }
 
 // ---- device-side obstacle pipeline -----------------------------------------------------------------------------
@@ -683,8 +700,8 @@ static int scene_reserve(rda_handle *H, int n)
     return RDA_OK;
 }
 
-extern "C" int rda_upload_scene(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
-                                const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex)
+static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                       const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex, bool sync)
 {
     if (!H) return RDA_ERR_ARG;
     Dev &d = H->d;
@@ -727,10 +744,16 @@ extern "C" int rda_upload_scene(rda_handle *H, int n, const int32_t *kind, const
         HIPCHK(hipMemcpyAsync(H->h_sc, H->d_sc_bad, sizeof(int), hipMemcpyDeviceToHost, H->stream));
         HIPCHK(hipStreamSynchronize(H->stream));
         *n_nonconvex = *(int *)H->h_sc;
-    } else {
+    } else if (sync) {
         HIPCHK(hipStreamSynchronize(H->stream));                  // the staging block is reused by the next call
     }
     return RDA_OK;
+}
+
+extern "C" int rda_upload_scene(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                                const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex)
+{
+    return scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, n_nonconvex, true);
 }
 
 // test hook: the staged obstacle slots as the solver sees them
@@ -766,17 +789,33 @@ static void launch_lammuz(rda_handle *H, const Dev &d)
 }
 
 // queue the whole ADMM loop of one MPC step (rda_solver.py:588-596) - no host synchronisation
-static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
-                        double *out_u, double *out_s, rda_info *info)
+// The ADMM loop of one MPC step in two parts.  The HEAD (k_begin + the first su-problem) reads the nominal trajectory and the
+// condensed terms of the PREVIOUS step (quirk Q4) but nothing of the staged obstacles, so a caller may stage this tick's
+// obstacles on the stream between head and tail while the first su-problem is being solved (rda_tracked_begin/_finish).
+static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, const double *in_u)
+{
+    const int T = d.c.T;
+    if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
+    RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
+    if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
+}
+static int enqueue_admm_head(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed)
 {
     Dev d = H->d;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
-    const int T = d.c.T;
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, d);
+    launch_su(H, d, 0, in_s, in_u);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
+                             double *out_u, double *out_s, rda_info *info)
+{
+    Dev d = H->d;                                     // taken AFTER the obstacles of this tick were staged (nt, obstacle_num)
+    d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     for (int it = 0; it < d.c.iter_num; ++it) {
-        if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
-        RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
-        if (H->timing) { (void)hipEventRecord(next_event(H, 1), H->stream); (void)hipEventRecord(next_event(H, 0), H->stream); }
+        if (it > 0) launch_su(H, d, it, in_s, in_u);
+        if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         launch_lammuz(H, d);
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         if (H->comm) {      // one exchange per ADMM iteration: every rank's chunk to every rank (in place)
@@ -788,11 +827,24 @@ static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, c
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
-
-// nominal / reference in, ADMM loop, control / state / info out (host buffers, synchronous)
-static int step_common(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed,
-                       double *out_u, double *out_s, rda_info *info)
+static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
+                        double *out_u, double *out_s, rda_info *info)
 {
+    int rc = enqueue_admm_head(H, in_s, in_u, ref, speed);
+    if (rc != RDA_OK) return rc;
+    return enqueue_admm_tail(H, in_s, in_u, ref, speed, out_u, out_s, info);
+}
+
+// nominal / reference in, ADMM loop, control / state / info out (host buffers, synchronous).  `stage` queues this tick's
+// obstacles (pinned staging block -> H2D -> conversion kernels) WITHOUT waiting: the one synchronisation of the step is
+// the one at its end, which also makes the staging blocks reusable by the next call.
+template <typename Stage>
+static int step_common(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed,
+                       double *out_u, double *out_s, rda_info *info, Stage stage)
+{
+    if (H->pending) return RDA_ERR_ARG;
+    int rc = stage();
+    if (rc != RDA_OK) { (void)hipStreamSynchronize(H->stream); return rc; }
     const size_t T = H->d.c.T;
     const size_t ns = 3 * (T + 1), nu = 2 * T;
     memcpy(H->h_step, nom_s, ns * sizeof(double));
@@ -800,7 +852,7 @@ static int step_common(rda_handle *H, const double *nom_s, const double *nom_u, 
     memcpy(H->h_step + ns + nu, ref_s, ns * sizeof(double));
     H->h_step[ns + nu + ns] = ref_speed;
     HIPCHK(hipMemcpyAsync(H->d_step, H->h_step, (2 * ns + nu + 1) * sizeof(double), hipMemcpyHostToDevice, H->stream));
-    int rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
+    rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) return rc;
     HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
@@ -817,9 +869,8 @@ extern "C" int rda_step(rda_handle *H, const double *nom_s, const double *nom_u,
                         int per_t, double *out_u, double *out_s, rda_info *info)
 {
     if (!H || !nom_s || !nom_u || !ref_s || !out_u || !out_s) return RDA_ERR_ARG;
-    int rc = rda_upload_obstacles(H, n_obs, A, b, cone, per_t);
-    if (rc != RDA_OK) return rc;
-    return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info);
+    return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info,
+                       [&]() { return obstacles_stage(H, n_obs, A, b, cone, per_t, false); });
 }
 
 extern "C" int rda_step_scene(rda_handle *H, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed,
@@ -827,9 +878,8 @@ extern "C" int rda_step_scene(rda_handle *H, const double *nom_s, const double *
                               const double *robot_xy, int order, double *out_u, double *out_s, rda_info *info)
 {
     if (!H || !nom_s || !nom_u || !ref_s || !out_u || !out_s) return RDA_ERR_ARG;
-    int rc = rda_upload_scene(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr);
-    if (rc != RDA_OK) return rc;
-    return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info);
+    return step_common(H, nom_s, nom_u, ref_s, ref_speed, out_u, out_s, info,
+                       [&]() { return scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false); });
 }
 
 // ---- device-side pre_process --------------------------------------------------------------------
@@ -857,11 +907,10 @@ extern "C" int rda_upload_path(rda_handle *H, int L, const double *path)
     return RDA_OK;
 }
 
-extern "C" int rda_step_tracked(rda_handle *H, const double *state, double ref_speed, int cur_index, double threshold, int ind_range,
-                                const double *nom_u, double *out_u, double *out_s, rda_info *info,
-                                double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading)
+extern "C" int rda_tracked_begin(rda_handle *H, const double *state, double ref_speed, int cur_index, double threshold, int ind_range,
+                                 const double *nom_u)
 {
-    if (!H || !state || !out_u || !out_s) return RDA_ERR_ARG;
+    if (!H || !state || H->pending) return RDA_ERR_ARG;
     if (!H->d_path || cur_index < 0 || cur_index >= H->path_len || ind_range < 1) return RDA_ERR_ARG;
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     const double *in_u = H->d.u;                       // the controls of the last solve are still resident
@@ -873,22 +922,55 @@ extern "C" int rda_step_tracked(rda_handle *H, const double *state, double ref_s
     track::In in; in.sx = state[0]; in.sy = state[1]; in.sth = state[2]; in.speed = ref_speed; in.threshold = threshold;
     in.cur_index = cur_index; in.ind_range = ind_range;
     hipLaunchKernelGGL(k_track, dim3(1), dim3(64), 0, H->stream, H->d, in, H->d_path, H->path_len, in_u, H->d_step, H->d_trk);
-    int rc = enqueue_admm(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu, H->d_out_u, H->d_out_s, H->d_info);
+    int rc = enqueue_admm_head(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu);
     if (rc != RDA_OK) return rc;
+    H->pending = 1; H->pending_in_u = in_u;
+    return RDA_OK;
+}
+
+extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                                      const double *vel, const double *robot_xy, int order)
+{
+    if (!H || !H->pending) return RDA_ERR_ARG;          // only between rda_tracked_begin and rda_tracked_finish (which synchronises)
+    if (H->pending_scene) return RDA_ERR_ARG;           // one staging block: at most one scene per tick
+    int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false);
+    if (rc == RDA_OK) H->pending_scene = 1;
+    return rc;
+}
+
+extern "C" int rda_tracked_finish(rda_handle *H, double *out_u, double *out_s, rda_info *info,
+                                  double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading)
+{
+    if (!H || !H->pending) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    const double *in_u = H->pending_in_u;
+    H->pending = 0; H->pending_scene = 0;
+    int rc = enqueue_admm_tail(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu, H->d_out_u, H->d_out_s, H->d_info);
+    if (rc != RDA_OK) { (void)hipStreamSynchronize(H->stream); return rc; }
     HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipMemcpyAsync(H->h_trk, H->d_trk, sizeof(track::Out), hipMemcpyDeviceToHost, H->stream));
     if (nom_s_out || ref_out) HIPCHK(hipMemcpyAsync(H->h_step, H->d_step, (2 * ns + nu) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipStreamSynchronize(H->stream));
-    memcpy(out_u, H->h_out, nu * sizeof(double));
-    memcpy(out_s, H->h_out + nu, ns * sizeof(double));
+    if (out_u) memcpy(out_u, H->h_out, nu * sizeof(double));
+    if (out_s) memcpy(out_s, H->h_out + nu, ns * sizeof(double));
     if (info) *info = *H->h_info;
     if (nom_s_out) memcpy(nom_s_out, H->h_step, ns * sizeof(double));
     if (ref_out) memcpy(ref_out, H->h_step + ns + nu, ns * sizeof(double));
     if (min_index) *min_index = H->h_trk->min_index;
     if (end_heading) *end_heading = H->h_trk->end_heading;
     return RDA_OK;
+}
+
+extern "C" int rda_step_tracked(rda_handle *H, const double *state, double ref_speed, int cur_index, double threshold, int ind_range,
+                                const double *nom_u, double *out_u, double *out_s, rda_info *info,
+                                double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading)
+{
+    if (!H || !state || !out_u || !out_s) return RDA_ERR_ARG;
+    int rc = rda_tracked_begin(H, state, ref_speed, cur_index, threshold, ind_range, nom_u);
+    if (rc != RDA_OK) return rc;
+    return rda_tracked_finish(H, out_u, out_s, info, nom_s_out, ref_out, min_index, end_heading);
 }
 
 extern "C" int rda_upload_trace(rda_handle *H, int K, const double *nom_s, const double *nom_u, const double *ref_s, const double *ref_speed)
@@ -925,6 +1007,14 @@ extern "C" int rda_enqueue_range(rda_handle *H, int k0, int k1)
     return RDA_OK;
 }
 
+#ifdef RDA_LMZ_STATS
+extern "C" int rda_debug_lmz_stats(rda_handle *H, unsigned *out)
+{
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(out, (char *)H->d.ctrl + offsetof(Ctrl, lmz_stat), 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
+#endif
 extern "C" int rda_sync(rda_handle *H) { if (!H) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(H->stream)); return RDA_OK; }
 
 extern "C" int rda_fetch_result(rda_handle *H, int k, double *out_u, double *out_s, rda_info *info)

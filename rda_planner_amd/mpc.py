@@ -80,13 +80,15 @@ class MPC:
             return cur_ref_path, cur_ref_path[0][-1, 0]
         return self.ref_path, 1
 
-    def _stage_obstacles(self, obstacle_list):
-        """obstacles into the solver's slots without solving: raw scene through the device pipeline, else host staging"""
+    def _stage_obstacles(self, obstacle_list, in_tick=False):
+        """obstacles into the solver's slots without solving: raw scene through the device pipeline, else host staging.
+        in_tick: a tick is open (`tracked_begin`), the scene goes behind the first su-problem without waiting."""
         scene = None
         if not self.rda_obstacle and self.device_obstacles and self.rda.has_scene:
             scene = self.rda.flatten_scene(obstacle_list)
         if scene is not None:
-            self.rda.upload_scene(scene, np.asarray(self.state, float)[0:2], self.obstacle_order)
+            upload = self.rda.upload_scene_async if in_tick else self.rda.upload_scene
+            upload(scene, np.asarray(self.state, float)[0:2], self.obstacle_order)
         else:
             rda_obs = obstacle_list if self.rda_obstacle else self.convert_rda_obstacle(obstacle_list, self.state, self.obstacle_order)
             self.rda.upload_obstacles(rda_obs)
@@ -111,9 +113,21 @@ class MPC:
     def _control_tracked(self, state, ref_speed, obstacle_list, **kwargs):
         cur_ref_path, gear_flag = self._piece(state)
         self._sync_path(cur_ref_path)
-        self._stage_obstacles(obstacle_list)
-        u_opt_array, info, min_index, end_heading = self.rda.iterative_solve_tracked(
-            self.state, gear_flag * ref_speed, self.cur_index, self._nominal_u(), **kwargs)
+        if self.rda.has_pipeline:
+            # pre_process and the first su-problem do not read this tick's obstacles (the first su-problem works with the
+            # products of the previous step, reference quirk Q4): they run on the device while the obstacle objects are
+            # flattened and staged here.  Same kernels, same order of dependent work, identical results.
+            self.rda.tracked_begin(self.state, gear_flag * ref_speed, self.cur_index, self._nominal_u(), **kwargs)
+            try:
+                self._stage_obstacles(obstacle_list, in_tick=True)
+            except BaseException:
+                self.rda.tracked_finish(discard=True)           # close the tick before reporting the caller's error
+                raise
+            u_opt_array, info, min_index, end_heading = self.rda.tracked_finish()
+        else:
+            self._stage_obstacles(obstacle_list)
+            u_opt_array, info, min_index, end_heading = self.rda.iterative_solve_tracked(
+                self.state, gear_flag * ref_speed, self.cur_index, self._nominal_u(), **kwargs)
         return self._tracked_done(cur_ref_path, u_opt_array, info, min_index, end_heading)
 
     def _begin(self, state, ref_speed, **kwargs):

@@ -103,6 +103,7 @@ class RDA_solver:
         make = kwargs.get("_backend", _hip_backend)
         self._be = make(cfg, G, h)
         self._R = G.shape[0]
+        self.pipeline = True        # MPC overlaps its per-tick obstacle staging with the first su-problem (set False to serialise)
 
     # ---- runtime tunables (reference :426-434, :1055-1056) ------------------------------
     def assign_adjust_parameter(self, **kwargs):
@@ -271,6 +272,48 @@ class RDA_solver:
             print("No update of state and control vector")        # reference :699
         ref_states = [ref[:, i:i + 1].copy() for i in range(T + 1)]
         return out_u, self.pack_info(ref_states, out_s, info_c, start), int(mi[0]), float(eh[0])
+
+    # ---- the tracked tick in two halves: the first su-problem runs while the caller stages this tick's obstacles ------
+    @property
+    def has_pipeline(self):
+        return self.pipeline and bool(getattr(self._be.api, "has_pipeline", False))
+
+    def tracked_begin(self, state, ref_speed, cur_index, nom_u=None, threshold=0.1, ind_range=10):
+        """queue pre_process + the first su-problem of the step (neither reads the obstacles of this tick: the first
+        su-problem uses the products of the previous step, reference quirk Q4) and return without waiting"""
+        self._tick_start = time.time()
+        st = f64(np.asarray(state, float).ravel()[0:3])
+        un = f64(nom_u, (2, self.T)) if nom_u is not None else None
+        rc = self._be.api.tracked_begin(self._be.handle, dptr(st), float(ref_speed), int(cur_index), float(threshold),
+                                        int(ind_range), dptr(un))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_tracked_begin failed with code {rc}")
+
+    def upload_scene_async(self, scene, robot_xy, order):
+        """`upload_scene` inside an open tick: staged on the stream behind the first su-problem, no wait"""
+        n, kind, nvert, geom, vel = scene
+        kind = np.ascontiguousarray(kind, np.int32); nvert = np.ascontiguousarray(nvert, np.int32)
+        geom = f64(geom); vel = f64(vel)
+        rob = f64(np.asarray(robot_xy, float).ravel()[0:2])
+        rc = self._be.api.upload_scene_async(self._be.handle, int(n), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(rob),
+                                             int(bool(order)))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_upload_scene_async failed with code {rc}")
+
+    def tracked_finish(self, discard=False):
+        """queue the rest of the ADMM loop, wait, return what `iterative_solve_tracked` returns"""
+        T = self.T
+        out_u, out_s, ref = np.zeros((2, T)), np.zeros((3, T + 1)), np.zeros((3, T + 1))
+        info_c, mi, eh = Info(), np.zeros(1, np.int32), np.zeros(1)
+        rc = self._be.api.tracked_finish(self._be.handle, dptr(out_u), dptr(out_s), C.byref(info_c), None, dptr(ref), iptr(mi), dptr(eh))
+        if discard:
+            return None
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_tracked_finish failed with code {rc}")
+        if info_c.su_status and self.time_print:
+            print("No update of state and control vector")        # reference :699
+        ref_states = [ref[:, i:i + 1].copy() for i in range(T + 1)]
+        return out_u, self.pack_info(ref_states, out_s, info_c, self._tick_start), int(mi[0]), float(eh[0])
 
     # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
     def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list, **kwargs):

@@ -115,3 +115,62 @@ def test_tracked_control_with_reverse_pieces():
         if ia["arrive"]:
             break
     assert seen_reverse and ia["arrive"]
+
+
+def test_pipelined_tick_is_bit_identical():
+    """`rda_tracked_begin` / `rda_upload_scene_async` / `rda_tracked_finish` (the first su-problem runs while the caller
+    stages this tick's obstacles) against the serialised `rda_upload_scene` + `rda_step_tracked`: the same kernels in the
+    same order of dependent work, so controls, states, residuals, iteration counts and the whole dual state must be EQUAL.
+    Moving obstacles (per-stage slots, re-sorted every tick), an empty list in the middle and a truncated list included."""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 20, 0], [30, 20, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    scene = sc.scene_polygons(14, lo=(6, 12), hi=(30, 28), seed=91, keep_clear=clear, clear_radius=3.0)
+    vel = np.random.default_rng(5).uniform(-0.4, 0.4, (len(scene), 2))
+    kw = dict(receding=10, iter_num=3, max_edge_num=4, max_obs_num=12)
+    a = MPC(car_t, [p.copy() for p in path], device_track=True, **kw)
+    b = MPC(car_t, [p.copy() for p in path], device_track=True, **kw)
+    a.rda.pipeline = False
+    assert b.rda.has_pipeline and not a.rda.has_pipeline
+    st = path[0].copy().reshape(3, 1)
+    for k in range(40):
+        cur = [o._replace(vertex=o.vertex + (vel[i] * 0.1 * k).reshape(2, 1), velocity=vel[i].reshape(2, 1)) for i, o in enumerate(scene)]
+        if k in (7, 8):
+            cur = []
+        elif k % 5 == 0:
+            cur = cur[:6]
+        ua, ia = a.control(st.copy(), 4.0, list(cur))
+        ub, ib = b.control(st.copy(), 4.0, list(cur))
+        assert np.array_equal(ua, ub), (k, np.abs(ua - ub).max())
+        assert ia["iters"] == ib["iters"] and ia["resi_dual"] == ib["resi_dual"] and ia["resi_pri"] == ib["resi_pri"], k
+        assert np.array_equal(np.hstack(ia["opt_state_list"]), np.hstack(ib["opt_state_list"])), k
+        assert a.cur_index == b.cur_index
+        st = sc.kinematic_step(st, ua, car_t, 0.1)
+    sa, sb = a.rda.get_state(), b.rda.get_state()
+    for key in sa:
+        assert np.array_equal(sa[key], sb[key]), key
+
+
+def test_pipelined_tick_closes_on_caller_error():
+    """an obstacle object the staging rejects raises out of `control`; the open tick is closed first, so the handle stays usable"""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics="diff", wheelbase=0)
+    path = sc.line_path([0, 0, 0], [10, 0, 0], 0.1)
+    scene = sc.scene_polygons(3, lo=(2, 3), hi=(9, 8), seed=3)
+    m = MPC(car_t, [p.copy() for p in path], receding=8, iter_num=2, max_edge_num=4, max_obs_num=3)
+    st = np.zeros((3, 1))
+    m.control(st.copy(), 2.0, list(scene))
+
+    class Broken:
+        cone_type = "Rpositive"
+        velocity = np.zeros((2, 1))
+
+        @property
+        def vertex(self):
+            raise ValueError("broken obstacle")
+
+    with pytest.raises(ValueError):
+        m.control(st.copy(), 2.0, list(scene) + [Broken()])
+    u, info = m.control(st.copy(), 2.0, list(scene))
+    assert np.isfinite(u).all() and info["iters"] >= 1
