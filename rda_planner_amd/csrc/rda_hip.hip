@@ -493,7 +493,7 @@ struct rda_handle {
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
     // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
-    int sc_cap; int *d_sc_kind, *d_sc_nvert, *d_sc_sel, *d_sc_bad; double *d_sc_geom, *d_sc_vel, *d_sc_robot, *d_sc_key;
+    int sc_cap; int *d_sc_sel; double *d_sc_blk, *d_sc_key;     // d_sc_blk mirrors the pinned block h_sc (ONE H2D copy per upload)
     void *h_sc; size_t h_sc_bytes;
     // device-side pre_process (rda_upload_path / rda_step_tracked)
     double *d_path; int path_len; track::Out *d_trk, *h_trk;
@@ -611,7 +611,7 @@ extern "C" void rda_destroy(rda_handle *H)
     void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
                      d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
-                     H->d_sc_kind, H->d_sc_nvert, H->d_sc_sel, H->d_sc_bad, H->d_sc_geom, H->d_sc_vel, H->d_sc_robot, H->d_sc_key, H->d_path, H->d_trk };
+                     H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path, H->d_trk };
     for (void *p : ptrs) dev_free(p);
     if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
     if (H->h_stage_b) (void)hipHostFree(H->h_stage_b);
@@ -678,19 +678,22 @@ extern "C" int rda_upload_obstacles(rda_handle *H, int n_obs, const double *A, c
 }
 
 // ---- device-side obstacle pipeline -----------------------------------------------------------------------------
+// raw scene block, identical on the host (pinned) and on the device: geom [n][E][2] | vel [n][2] | robot [2] | nonconvex
+// counter (int, padded to 8 bytes) | kind [n] | nvert [n]
+static size_t scene_block_bytes(size_t n, size_t E) { return n * (E * 2 + 2) * sizeof(double) + 3 * sizeof(double) + 2 * n * sizeof(int); }
 static int scene_reserve(rda_handle *H, int n)
 {
     const size_t E = H->d.c.E;
     if (n > H->sc_cap) {
-        dev_free(H->d_sc_kind); dev_free(H->d_sc_nvert); dev_free(H->d_sc_sel); dev_free(H->d_sc_geom); dev_free(H->d_sc_vel); dev_free(H->d_sc_key);
+        dev_free(H->d_sc_blk); dev_free(H->d_sc_sel); dev_free(H->d_sc_key);
+        H->d_sc_blk = nullptr; H->d_sc_sel = nullptr; H->d_sc_key = nullptr; H->sc_cap = 0;
         int cap = n + n / 2 + 16, rc = 0;
-        rc |= dalloc(&H->d_sc_kind, (size_t)cap); rc |= dalloc(&H->d_sc_nvert, (size_t)cap); rc |= dalloc(&H->d_sc_sel, (size_t)cap);
-        rc |= dalloc(&H->d_sc_geom, (size_t)cap * E * 2); rc |= dalloc(&H->d_sc_vel, (size_t)cap * 2); rc |= dalloc(&H->d_sc_key, (size_t)cap);
+        rc |= dalloc(&H->d_sc_blk, scene_block_bytes((size_t)cap, E) / sizeof(double) + 1);
+        rc |= dalloc(&H->d_sc_sel, (size_t)cap); rc |= dalloc(&H->d_sc_key, (size_t)cap);
         if (rc) return RDA_ERR_HIP;
         H->sc_cap = cap;
     }
-    if (!H->d_sc_robot) { if (dalloc(&H->d_sc_robot, (size_t)2) || dalloc(&H->d_sc_bad, (size_t)1)) return RDA_ERR_HIP; }
-    const size_t need = (size_t)n * (2 * sizeof(int) + (E * 2 + 2) * sizeof(double)) + 2 * sizeof(double);
+    const size_t need = scene_block_bytes((size_t)n, E);
     if (need > H->h_sc_bytes) {
         if (H->h_sc) (void)hipHostFree(H->h_sc);
         H->h_sc = nullptr; H->h_sc_bytes = 0;
@@ -717,23 +720,21 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     }
     int rc = scene_reserve(H, n);
     if (rc != RDA_OK) return rc;
-    // one pinned staging block -> four device arrays
-    char *hp = (char *)H->h_sc;
-    double *hg = (double *)hp; memcpy(hg, geom, (size_t)n * E * 2 * sizeof(double)); hp += (size_t)n * E * 2 * sizeof(double);
-    double *hv = (double *)hp; memcpy(hv, vel, (size_t)n * 2 * sizeof(double)); hp += (size_t)n * 2 * sizeof(double);
-    double *hr = (double *)hp; hr[0] = robot_xy ? robot_xy[0] : 0; hr[1] = robot_xy ? robot_xy[1] : 0; hp += 2 * sizeof(double);
-    int *hk = (int *)hp; memcpy(hk, kind, (size_t)n * sizeof(int)); hp += (size_t)n * sizeof(int);
-    int *hn = (int *)hp; memcpy(hn, nvert, (size_t)n * sizeof(int));
-    HIPCHK(hipMemcpyAsync(H->d_sc_geom, hg, (size_t)n * E * 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
-    HIPCHK(hipMemcpyAsync(H->d_sc_vel, hv, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
-    HIPCHK(hipMemcpyAsync(H->d_sc_robot, hr, 2 * sizeof(double), hipMemcpyHostToDevice, H->stream));
-    HIPCHK(hipMemcpyAsync(H->d_sc_kind, hk, (size_t)n * sizeof(int), hipMemcpyHostToDevice, H->stream));
-    HIPCHK(hipMemcpyAsync(H->d_sc_nvert, hn, (size_t)n * sizeof(int), hipMemcpyHostToDevice, H->stream));
-    HIPCHK(hipMemsetAsync(H->d_sc_bad, 0, sizeof(int), H->stream));
+    // one pinned staging block -> its device mirror, one copy
+    const size_t o_vel = (size_t)n * E * 2, o_rob = o_vel + (size_t)n * 2, o_bad = o_rob + 2, o_int = o_bad + 1;   // in doubles
+    double *hb = (double *)H->h_sc, *db = H->d_sc_blk;
+    memcpy(hb, geom, o_vel * sizeof(double));
+    memcpy(hb + o_vel, vel, (size_t)n * 2 * sizeof(double));
+    hb[o_rob] = robot_xy ? robot_xy[0] : 0; hb[o_rob + 1] = robot_xy ? robot_xy[1] : 0;
+    hb[o_bad] = 0.0;                                                       // all-zero bits: the int counter starts at 0
+    memcpy((int *)(hb + o_int), kind, (size_t)n * sizeof(int));
+    memcpy((int *)(hb + o_int) + n, nvert, (size_t)n * sizeof(int));
+    HIPCHK(hipMemcpyAsync(db, hb, scene_block_bytes((size_t)n, (size_t)E), hipMemcpyHostToDevice, H->stream));
+    int *const d_bad = (int *)(db + o_bad);
     scene::Args a;
     a.n = n; a.N = N; a.E = E; a.T = T; a.nt = any_moving ? T + 1 : 1; a.order = order; a.dt = d.c.dt;
-    a.kind = H->d_sc_kind; a.nvert = H->d_sc_nvert; a.geom = H->d_sc_geom; a.vel = H->d_sc_vel; a.robot = H->d_sc_robot;
-    a.key = H->d_sc_key; a.sel = H->d_sc_sel; a.A = d.A; a.b = d.b; a.cone = d.cone; a.nonconvex = H->d_sc_bad;
+    a.kind = (int *)(db + o_int); a.nvert = (int *)(db + o_int) + n; a.geom = db; a.vel = db + o_vel; a.robot = db + o_rob;
+    a.key = H->d_sc_key; a.sel = H->d_sc_sel; a.A = d.A; a.b = d.b; a.cone = d.cone; a.nonconvex = d_bad;
     hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
     hipLaunchKernelGGL(scene::k_rank, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
     hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, H->stream, a);
@@ -741,7 +742,7 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, H->stream, d);
     HIPCHK(hipGetLastError());
     if (n_nonconvex) {
-        HIPCHK(hipMemcpyAsync(H->h_sc, H->d_sc_bad, sizeof(int), hipMemcpyDeviceToHost, H->stream));
+        HIPCHK(hipMemcpyAsync(H->h_sc, d_bad, sizeof(int), hipMemcpyDeviceToHost, H->stream));
         HIPCHK(hipStreamSynchronize(H->stream));
         *n_nonconvex = *(int *)H->h_sc;
     } else if (sync) {
