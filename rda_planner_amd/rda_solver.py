@@ -167,30 +167,49 @@ class RDA_solver:
         reference's MPC.convert_rda_obstacle reads, mpc.py:192-203) -> flat arrays for rda_upload_scene, or None if
         an object cannot be expressed (then the caller falls back to the host conversion)."""
         E = self.max_edge_num
-        objs = [o for o in obstacle_list if o.cone_type in ("norm2", "Rpositive")]   # other cone types are skipped (mpc.py:196-203)
+        ct = [o.cone_type for o in obstacle_list]
+        n_poly, n_circ = ct.count("Rpositive"), ct.count("norm2")
+        if n_poly + n_circ == len(ct):
+            objs = obstacle_list
+        else:                                                          # other cone types are skipped (mpc.py:196-203)
+            objs = [o for o in obstacle_list if o.cone_type in ("norm2", "Rpositive")]
+            ct = [o.cone_type for o in objs]
         n = len(objs)
-        kind = np.fromiter((o.cone_type == "norm2" for o in objs), np.int32, n)
+        kind = np.zeros(n, np.int32) if n_circ == 0 else np.array([c == "norm2" for c in ct], np.int32)
         nvert = np.zeros(n, np.int32)
         geom = np.zeros((n, E, 2))
         if n == 0:
             return 0, kind, nvert, geom, np.zeros((0, 2))
-        vel = np.asarray([o.velocity for o in objs], float).reshape(n, -1)[:, 0:2]
+        try:                                                           # 2x1 columns (what the reference's obstacles carry): one concatenate
+            vel = np.concatenate([o.velocity for o in objs], axis=1, dtype=float)[0:2].T
+            if vel.shape != (n, 2):
+                raise ValueError
+        except (ValueError, TypeError, np.exceptions.AxisError):
+            vel = np.asarray([o.velocity for o in objs], float).reshape(n, -1)[:, 0:2]
         circ = np.flatnonzero(kind == 1)
         if circ.size:
             if E < 3:
                 return None
             geom[circ, 0, :] = np.asarray([objs[i].center for i in circ], float).reshape(circ.size, -1)[:, 0:2]
             geom[circ, 1, 0] = [float(objs[i].radius) for i in circ]
-        poly = np.flatnonzero(kind == 0)
-        if poly.size:
-            ks = np.fromiter((np.shape(objs[i].vertex)[1] for i in poly), np.int64, poly.size)
+        poly = np.flatnonzero(kind == 0) if n_circ else None
+        if n_poly:
+            verts = [o.vertex for o in objs] if poly is None else [objs[i].vertex for i in poly]
+            try:
+                ks = np.array([v.shape[1] for v in verts], np.int64)
+            except AttributeError:                                     # vertices given as nested lists
+                ks = np.array([np.shape(v)[1] for v in verts], np.int64)
             if ks.max() > E:
                 return None
-            nvert[poly] = ks
-            for k in np.unique(ks):                                   # one vectorised fill per vertex count
-                idx = poly[ks == k]
-                V = np.asarray([objs[i].vertex for i in idx], float)[:, 0:2, :]           # (m, 2, k)
-                geom[idx, :k, :] = V.transpose(0, 2, 1)
+            # all vertices side by side, then one scatter: vertex j of polygon i -> geom[i, j, :]
+            V = np.concatenate(verts, axis=1, dtype=float)[0:2]
+            rows = np.repeat(np.arange(n) if poly is None else poly, ks)
+            cols = np.arange(V.shape[1]) - np.repeat(np.cumsum(ks) - ks, ks)
+            geom[rows, cols, :] = V.T
+            if poly is None:
+                nvert[:] = ks
+            else:
+                nvert[poly] = ks
         return n, kind, nvert, geom, np.ascontiguousarray(vel)
 
     def iterative_solve_scene(self, nom_s, nom_u, ref_states, ref_speed, scene, robot_xy, order, **kwargs):
