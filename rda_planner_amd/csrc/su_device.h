@@ -478,6 +478,8 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     // lane needs sits in its own 8-lane group and is consumed straight from the neighbours' registers by
     // v_fmac_f64 with a DPP row_newbcast operand (bank_mask selects the lower / upper group of the 16-lane row).
     double *const Px = L.red + 16, *const Ms = L.red + 80;
+    unsigned long long stopf = 0, seq = 0;               // seq = tag of the current interior-point iteration (early-verdict flags)
+    unsigned long long *const flag_meas = reinterpret_cast<unsigned long long *>(L.red + 12), *const flag_stop = flag_meas + 1;
     auto mat_step = [&](int t, const MatK &k) {
         // X = P F : lane (q,i) needs row i of P
         Row5 pr; ldrow5(Px + 8 * mr_, pr);
@@ -504,6 +506,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         const double m00 = Ms[45], m01 = Ms[46], m02 = Ms[47], m11 = Ms[54], m12 = Ms[55], m22 = Ms[63];
         const double a0 = Ms[8 * mr_ + 5], a1 = Ms[8 * mr_ + 6], a2 = Ms[8 * mr_ + 7];
         double b0 = Ms[40 + mq_], b1 = Ms[48 + mq_], b2 = Ms[56 + mq_];
+        stopf = __atomic_load_n(flag_stop, __ATOMIC_RELAXED);   // "this iterate has converged" (wave 1), same LDS round
         asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));      // keep these loads in the same LDS round as the pivot block
         // inverse of Mvv by the adjugate, on every lane; reciprocal of the determinant by v_rcp_f64 + two Newton steps
         double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
@@ -529,6 +532,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     // closed-loop solves, where the iterates cycle -- restart from the same nominal with a more central point (slack floor
     // 0.1, mu0 = 10) and every hinge term in play.
     int status = 1, it = 0, used = 0;
+    if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
     mark(9);
     for (int attempt = 0; attempt < 2 && status != 0; ++attempt) {
     if (attempt) {
@@ -541,6 +545,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         status = 1;
     }
     for (it = 0; it < 100; ++it) {
+        seq += 1;
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
         {
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
@@ -680,32 +685,53 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             MatK ka, kb;
             bool ok = true;
             ldmat(T - 1, ka);
+            // The termination measures do not need the factorisation: waves 1 and 3 evaluate the test while this wave
+            // factorises and raise *flag_stop = seq when the iterate has converged; the recursion of that (last, unused)
+            // factorisation is then abandoned.  The test itself is repeated by all threads after the barrier.
             for (int t = T - 1; t >= 0; t -= 2) {
                 if (t >= 1) ldmat(t - 1, kb);
                 ok = mat_step(t, ka) && ok;
+                if (stopf == seq) break;
                 if (t >= 1) {
                     if (t >= 2) ldmat(t - 2, ka);
                     ok = mat_step(t - 1, kb) && ok;
                 }
             }
-            fail = !ok;
+            fail = !ok && stopf != seq;
         } else if (wave == 1) {
-            double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
-            for (int t = T - 1; t >= 0; --t) {
-                const double *A = &L.Ak[9 * t], *B = &L.Bk[6 * t], *g = &L.gst[8 * t];
-                double g0 = g[0] + A[0] * p0 + A[3] * p1 + A[6] * p2;
-                double g1 = g[1] + A[1] * p0 + A[4] * p1 + A[7] * p2;
-                double g2 = g[2] + A[2] * p0 + A[5] * p1 + A[8] * p2;
-                double v0 = g[5] + B[0] * p0 + B[2] * p1 + B[4] * p2 + p3;
-                double v1 = g[6] + B[1] * p0 + B[3] * p1 + B[5] * p2 + p4;
-                if (lane == 0) { L.gad[3 * t] = v0; L.gad[3 * t + 1] = v1; L.gad[3 * t + 2] = g[7]; }
-                p0 = g0; p1 = g1; p2 = g2; p3 = g[3]; p4 = g[4];
-            }
-            wsync();
+            // Adjoint sweep p_t = g_x,t + A_t' p_{t+1}, one stage per lane.  A_t = [[1,0,a13],[0,1,a23],[0,0,1]] in all three
+            // motion models, so p0 and p1 are suffix sums of g0, g1 and p2 is the suffix sum of g2 + a13 p0' + a23 p1'
+            // (' = the value of stage t+1): three wave scans instead of T dependent stages.  Only the termination measure
+            // |reduced gradient|_inf is taken from it.
+            const bool on = lane < T;
+            const double *A = &L.Ak[9 * (on ? lane : 0)], *B = &L.Bk[6 * (on ? lane : 0)], *g = &L.gst[8 * (on ? lane : 0)];
+            auto suffix = [&](double v) {
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { double o = __shfl_down(v, off, 64); if (lane + off < 64) v += o; }
+                return v;
+            };
+            auto next = [&](double v) { double o = __shfl_down(v, 1, 64); return lane < 63 ? o : 0.0; };
+            const double s0 = suffix(on ? g[0] : 0.0), s1 = suffix(on ? g[1] : 0.0);
+            const double p0 = next(s0), p1 = next(s1);
+            const double s2 = suffix(on ? g[2] + A[2] * p0 + A[5] * p1 : 0.0);
+            const double p2 = next(s2), p3 = next(on ? g[3] : 0.0), p4 = next(on ? g[4] : 0.0);
             double rd = 0;
-            for (int i = lane; i < 3 * T; i += 64) { double v = fabs(L.gad[i]); if (v > rd) rd = v; }
+            if (on) {
+                const double v0 = g[5] + B[0] * p0 + B[2] * p1 + B[4] * p2 + p3;
+                const double v1 = g[6] + B[1] * p0 + B[3] * p1 + B[5] * p2 + p4;
+                L.gad[3 * lane] = v0; L.gad[3 * lane + 1] = v1; L.gad[3 * lane + 2] = g[7];
+                rd = fmax(fabs(v0), fmax(fabs(v1), fabs(g[7])));
+            }
             rd = wave_allreduce(rd, true);
             if (lane == 0) L.red[8] = rd;
+            // early verdict for wave 0 (see there): wave 3's measures are published under *flag_meas = seq
+            while (__atomic_load_n(flag_meas, __ATOMIC_ACQUIRE) != seq) __builtin_amdgcn_s_sleep(1);
+            {
+                const double gn_ = *(volatile double *)&L.red[9], rpn_ = *(volatile double *)&L.red[10];
+                const double mu_ = *(volatile double *)&L.red[11] / mcnt, sc_ = 1 + gn_;
+                if ((rd <= 1e-9 * sc_ && rpn_ <= 1e-10 && mu_ <= 1e-11 * sc_) || (rd <= 1e-7 * sc_ && rpn_ <= 1e-10 && mu_ <= 1e-12 * sc_))
+                    if (lane == 0) __atomic_store_n(flag_stop, seq, __ATOMIC_RELAXED);
+            }
         } else if (wave == 2) {
             for (int t = lane; t < T; t += 64) build_gh(t);
         } else {
@@ -714,7 +740,10 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             for (int i = lane; i < 4 * T; i += 64) { double v = fabs(L.gw[i]); if (v > g) g = v; }
             for (int i = lane; i < NC * T; i += 64) { double v = fabs(L.rp[i]); if (v > rp_) rp_ = v; m_ += L.cl[i] * L.cw[i]; }
             g = wave_allreduce(g, true); rp_ = wave_allreduce(rp_, true); m_ = wave_allreduce(m_, false);
-            if (lane == 0) { L.red[9] = g; L.red[10] = rp_; L.red[11] = m_; }
+            if (lane == 0) {
+                L.red[9] = g; L.red[10] = rp_; L.red[11] = m_;
+                __atomic_store_n(flag_meas, seq, __ATOMIC_RELEASE);
+            }
         }
         __syncthreads();
         mark(4);
