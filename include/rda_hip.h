@@ -139,7 +139,9 @@ int  rda_step_tracked(rda_handle *h, const double *state /*3*/, double ref_speed
  * su-problem of a step reads the nominal trajectory and the lam'A / lam'b products of the PREVIOUS step (the reference never
  * refreshes them before rda_solver.py:591 - SURVEY quirk Q4) and nothing of the obstacles staged for this tick, so
  *   rda_tracked_begin        queues k_track, the step reset and su-problem 0 and returns at once;
- *   rda_upload_scene_async   (optional, at most once) stages this tick's raw scene like rda_upload_scene, without waiting;
+ *   rda_upload_scene_async   (optional) stages this tick's raw scene like rda_upload_scene, without waiting; also usable on
+ *                            its own when the caller's next call on the handle synchronises (rda_sync, a step, a fleet
+ *                            step) - a second upload before that waits for the first one;
  *                            rda_upload_obstacles / rda_upload_scene may be used instead (they synchronise);
  *   rda_tracked_finish       queues the rest of the ADMM loop, waits, returns what rda_step_tracked returns.
  * Results are bit-identical to rda_upload_scene + rda_step_tracked (same kernels, same order of dependent work).
@@ -167,6 +169,10 @@ int  rda_fleet_size(rda_fleet *f);
 int  rda_fleet_step(rda_fleet *f, const double *nom_s /*B*3*(T+1)*/, const double *nom_u /*B*2*T*/,
                     const double *ref_s /*B*3*(T+1)*/, const double *ref_speed /*B*/,
                     double *out_u /*B*2*T*/, double *out_s /*B*3*(T+1)*/, rda_info *info /*B, may be NULL*/);
+/* rda_upload_scene_async for every member in one call: member i owns counts[i] consecutive entries of kind / nvert / geom /
+ * vel, robot_xy [B][2], order [B].  No waiting: the next fleet step orders itself behind the staging and synchronises. */
+int  rda_fleet_upload_scenes(rda_fleet *f, const int32_t *counts /*B*/, const int32_t *kind, const int32_t *nvert, const double *geom,
+                             const double *vel, const double *robot_xy /*B*2*/, const int32_t *order /*B*/);
 /* rda_step_tracked for every member (paths uploaded with rda_upload_path on the members); per-ego arrays ego-major,
  * nom_u NULL = every member's resident controls */
 int  rda_fleet_step_tracked(rda_fleet *f, const double *states /*B*3*/, const double *ref_speed /*B*/, const int32_t *cur_index /*B*/,

@@ -127,6 +127,10 @@ class CApi:
             f("fleet_sync").argtypes = [C.c_void_p]
             for name in ("fleet_create", "fleet_size", "fleet_step", "fleet_enqueue_range", "fleet_sync"):
                 f(name).restype = C.c_int
+            self.has_fleet_scenes = hasattr(lib, f"{prefix}_fleet_upload_scenes")
+            if self.has_fleet_scenes:
+                f("fleet_upload_scenes").argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, c_int_p]
+                f("fleet_upload_scenes").restype = C.c_int
 
     def _f(self, name):
         return getattr(self.lib, f"{self.prefix}_{name}")

@@ -932,10 +932,12 @@ extern "C" int rda_tracked_begin(rda_handle *H, const double *state, double ref_
 extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
                                       const double *vel, const double *robot_xy, int order)
 {
-    if (!H || !H->pending) return RDA_ERR_ARG;          // only between rda_tracked_begin and rda_tracked_finish (which synchronises)
-    if (H->pending_scene) return RDA_ERR_ARG;           // one staging block: at most one scene per tick
+    if (!H) return RDA_ERR_ARG;
+    // one pinned staging block per handle: a second upload before the caller's synchronising call (rda_tracked_finish,
+    // rda_sync, a fleet step) has to wait for the first one to have been copied
+    if (H->pending_scene) { HIPCHK(hipStreamSynchronize(H->stream)); H->pending_scene = 0; }
     int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false);
-    if (rc == RDA_OK) H->pending_scene = 1;
+    if (rc == RDA_OK && n > 0) H->pending_scene = 1;
     return rc;
 }
 
@@ -1016,7 +1018,7 @@ extern "C" int rda_debug_lmz_stats(rda_handle *H, unsigned *out)
     return RDA_OK;
 }
 #endif
-extern "C" int rda_sync(rda_handle *H) { if (!H) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(H->stream)); return RDA_OK; }
+extern "C" int rda_sync(rda_handle *H) { if (!H) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(H->stream)); H->pending_scene = 0; return RDA_OK; }
 
 extern "C" int rda_fetch_result(rda_handle *H, int k, double *out_u, double *out_s, rda_info *info)
 {
@@ -1367,6 +1369,7 @@ extern "C" int rda_fleet_step(rda_fleet *F, const double *nom_s, const double *n
     HIPCHK(hipMemcpyAsync(F->h_out, F->d_out, B * nout * sizeof(double), hipMemcpyDeviceToHost, F->stream));
     HIPCHK(hipMemcpyAsync(F->h_info, F->d_info, B * sizeof(rda_info), hipMemcpyDeviceToHost, F->stream));
     HIPCHK(hipStreamSynchronize(F->stream));
+    for (rda_handle *Hm : F->egos) Hm->pending_scene = 0;      // their staged scenes have been consumed
     for (size_t i = 0; i < B; ++i) {
         memcpy(out_u + i * nu, F->h_out + i * nout, nu * sizeof(double));
         memcpy(out_s + i * ns, F->h_out + i * nout + nu, ns * sizeof(double));
@@ -1388,6 +1391,26 @@ __global__ void k_track_fleet(const Dev *devs, const EgoIO *io, const track::In 
     e.speed = const_cast<double *>(io[b].speed);
     e.T = d.c.T; e.dynamics = d.c.dynamics; e.dt = d.c.dt; e.wheelbase = d.c.L;
     track::run(e, ins[b], outs[b], win, threadIdx.x);
+}
+
+// every member's raw scene in one call (member i owns counts[i] consecutive entries of the arrays): staged on the members'
+// streams without waiting - the next fleet step orders itself behind them (fleet_refresh) and ends with a synchronisation
+extern "C" int rda_fleet_upload_scenes(rda_fleet *F, const int32_t *counts, const int32_t *kind, const int32_t *nvert, const double *geom,
+                                       const double *vel, const double *robot_xy, const int32_t *order)
+{
+    if (!F || !counts || !robot_xy || !order) return RDA_ERR_ARG;
+    size_t off = 0;
+    for (int i = 0; i < F->B; ++i) {
+        rda_handle *H = F->egos[i];
+        const size_t E = H->d.c.E;
+        const int n = counts[i];
+        if (n < 0) return RDA_ERR_ARG;
+        int rc = rda_upload_scene_async(H, n, kind ? kind + off : nullptr, nvert ? nvert + off : nullptr, geom ? geom + off * E * 2 : nullptr,
+                                        vel ? vel + off * 2 : nullptr, robot_xy + 2 * i, order[i]);
+        if (rc != RDA_OK) return rc;
+        off += (size_t)n;
+    }
+    return RDA_OK;
 }
 
 extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const double *ref_speed, const int32_t *cur_index,
@@ -1450,6 +1473,7 @@ extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const 
     HIPCHK(hipMemcpyAsync(F->h_trk_out, F->d_trk_out, B * sizeof(track::Out), hipMemcpyDeviceToHost, F->stream));
     if (ref_out) HIPCHK(hipMemcpyAsync(F->h_in, F->d_in, B * nin * sizeof(double), hipMemcpyDeviceToHost, F->stream));
     HIPCHK(hipStreamSynchronize(F->stream));
+    for (rda_handle *Hm : F->egos) Hm->pending_scene = 0;      // their staged scenes have been consumed
     for (size_t i = 0; i < B; ++i) {
         memcpy(out_u + i * nu, F->h_out + i * nout, nu * sizeof(double));
         memcpy(out_s + i * ns, F->h_out + i * nout + nu, ns * sizeof(double));

@@ -37,6 +37,7 @@ class Fleet:
         self._ref, self._speed = np.zeros((B, 3, T + 1)), np.zeros(B)
         self._out_u, self._out_s = np.zeros((B, 2, T)), np.zeros((B, 3, T + 1))
         self._info = (Info * B)()
+        self.batched_ticks = 0          # ticks whose scenes went through the one-pass staging (diagnostics)
 
     def __len__(self):
         return len(self.members)
@@ -91,6 +92,31 @@ class Fleet:
             out.append(m._end(cur_ref_path, self._out_u[i].copy(), info))
         return out
 
+    def _stage_all(self, obstacle_lists, st):
+        """all members' raw scenes flattened in ONE pass over the obstacle objects and staged by one library call
+        (rda_fleet_upload_scenes, no waiting); False when some member needs the per-member route (host conversion, cone
+        types the reference skips, too many vertices)"""
+        ms = self.members
+        if not getattr(self.api, "has_fleet_scenes", False):
+            return False
+        if any(m.rda_obstacle or not m.device_obstacles or not m.rda.has_scene for m in ms):
+            return False
+        counts = np.fromiter((len(ol) for ol in obstacle_lists), np.int32, len(ms))
+        every = [o for ol in obstacle_lists for o in ol]
+        scene = ms[0].rda.flatten_scene(every)
+        if scene is None or scene[0] != len(every):
+            return False
+        _, kind, nvert, geom, vel = scene
+        kind = np.ascontiguousarray(kind, np.int32); nvert = np.ascontiguousarray(nvert, np.int32)
+        geom = f64(geom); vel = f64(vel)
+        rob = np.ascontiguousarray(st[:, 0:2])
+        order = np.fromiter((bool(m.obstacle_order) for m in ms), np.int32, len(ms))
+        rc = self.api.fleet_upload_scenes(self._handle, iptr(counts), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(rob), iptr(order))
+        if rc < 0:
+            raise RuntimeError(f"rda_fleet_upload_scenes failed with code {rc}")
+        self.batched_ticks += 1
+        return True
+
     def _control_tracked(self, states, ref_speeds, obstacle_lists, start, threshold=0.1, ind_range=10):
         """the same with every member's pre_process on the device (rda_fleet_step_tracked): per ego only the state, the
         signed speed and the path index travel"""
@@ -100,12 +126,14 @@ class Fleet:
         for i, m in enumerate(self.members):
             cur_ref_path, gear = m._piece(states[i])
             m._sync_path(cur_ref_path)
-            m._stage_obstacles(obstacle_lists[i])
             st[i] = np.asarray(m.state, float).ravel()[0:3]
             self._speed[i] = gear * ref_speeds[i]
             cur[i] = m.cur_index
             resident = resident and m._nominal_u() is None
             pieces.append(cur_ref_path)
+        if not self._stage_all(obstacle_lists, st):
+            for i, m in enumerate(self.members):
+                m._stage_obstacles(obstacle_lists[i])
         nom_u = None
         if not resident:            # some member's cur_vel_array was replaced since its last solve: send them all
             for i, m in enumerate(self.members):

@@ -135,9 +135,12 @@ def test_fleet_rejects_mismatched_members(hip):
     assert hip.fleet_create(None, 0, C.byref(F)) != 0
 
 
-def test_fleet_control_equals_member_control():
+@pytest.mark.parametrize("mixed", [True, False])
+def test_fleet_control_equals_member_control(mixed):
     """`Fleet.control` over 6 closed loops (different paths, kinematics, static / moving scenes, device and host obstacle
-    staging) == six `MPC.control` loops, bit for bit, until every member has arrived"""
+    staging) == six `MPC.control` loops, bit for bit, until every member has arrived.  mixed: one member converts its
+    obstacles on the host, which sends every member through the per-member staging; otherwise all scenes are flattened in
+    one pass and staged by one call (rda_fleet_upload_scenes)"""
     from rda_planner_amd.mpc import MPC
     from rda_planner_amd.fleet import Fleet
     B = 6
@@ -150,7 +153,7 @@ def test_fleet_control_equals_member_control():
         clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
         scene = sc.scene_polygons([12, 6][i % 2], lo=(6, y - 10), hi=(30, y + 10), seed=40 + i, keep_clear=clear, clear_radius=3.0, moving=(i % 2 == 0))
         scene.append(sc.circle(15.0, y + 4.0, 0.8, (0.0, -0.2)))
-        kw = dict(receding=10, iter_num=3, max_edge_num=4, max_obs_num=10, device_obstacles=(i != 4))
+        kw = dict(receding=10, iter_num=3, max_edge_num=4, max_obs_num=10, device_obstacles=(i != 4 or not mixed))
         solo.append(MPC(car_t, [p.copy() for p in path], **kw))
         memb.append(MPC(car_t, [p.copy() for p in path], **kw))
         cars.append(car_t); scenes.append(scene)
@@ -176,4 +179,5 @@ def test_fleet_control_equals_member_control():
         if all(arrived):
             break
     assert sum(arrived) >= 3
+    assert (fleet.batched_ticks == 0) if mixed else (fleet.batched_ticks > 0)
     fleet.close()
