@@ -88,7 +88,7 @@ class Fleet:
             cur_ref_path, ref_list = begun[i]
             if self._info[i].su_status and m.rda.time_print:
                 print("No update of state and control vector")        # reference rda_solver.py:699
-            info = m.rda.pack_info(ref_list, self._out_s[i], self._info[i], start)
+            info = m.rda.pack_info(ref_list, self._out_s[i].copy(), self._info[i], start)
             out.append(m._end(cur_ref_path, self._out_u[i].copy(), info))
         return out
 
@@ -149,7 +149,8 @@ class Fleet:
         for i, m in enumerate(self.members):
             if self._info[i].su_status and m.rda.time_print:
                 print("No update of state and control vector")        # reference rda_solver.py:699
-            ref_list = [self._ref[i][:, j:j + 1].copy() for j in range(T + 1)]
-            info = m.rda.pack_info(ref_list, self._out_s[i], self._info[i], start)
+            ref_own = self._ref[i].copy()
+            ref_list = [ref_own[:, j:j + 1] for j in range(T + 1)]
+            info = m.rda.pack_info(ref_list, self._out_s[i].copy(), self._info[i], start)
             out.append(m._tracked_done(pieces[i], self._out_u[i].copy(), info, int(mi[i]), float(eh[i])))
         return out

@@ -255,7 +255,7 @@ class RDA_solver:
 
     def pack_info(self, ref_states, out_s, info_c, start):
         """the `info` dict of the reference (:603-608) plus the solver counters"""
-        opt_state_list = [out_s[:, i:i + 1].copy() for i in range(self.T + 1)]
+        opt_state_list = [out_s[:, i:i + 1] for i in range(self.T + 1)]      # columns of an array this call owns (no copies)
         return {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
                 "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
                 "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
@@ -289,7 +289,7 @@ class RDA_solver:
             raise RuntimeError(f"{self._be.api.prefix}_step_tracked failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
-        ref_states = [ref[:, i:i + 1].copy() for i in range(T + 1)]
+        ref_states = [ref[:, i:i + 1] for i in range(T + 1)]
         return out_u, self.pack_info(ref_states, out_s, info_c, start), int(mi[0]), float(eh[0])
 
     # ---- the tracked tick in two halves: the first su-problem runs while the caller stages this tick's obstacles ------
@@ -331,7 +331,7 @@ class RDA_solver:
             raise RuntimeError(f"{self._be.api.prefix}_tracked_finish failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
-        ref_states = [ref[:, i:i + 1].copy() for i in range(T + 1)]
+        ref_states = [ref[:, i:i + 1] for i in range(T + 1)]
         return out_u, self.pack_info(ref_states, out_s, info_c, self._tick_start), int(mi[0]), float(eh[0])
 
     # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
