@@ -490,6 +490,7 @@ struct rda_handle {
     int (*p_comm_destroy)(void *);
     // a tick opened by rda_tracked_begin and not yet closed by rda_tracked_finish
     int pending, pending_scene; const double *pending_in_u;
+    hipStream_t stream2; hipEvent_t ev_tick, ev_scene; int scene_on_s2;   // in-tick scene staging runs beside the first su-problem
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
     // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
@@ -569,6 +570,9 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
     HIPCHK(hipStreamCreate(&H->stream));
+    HIPCHK(hipStreamCreate(&H->stream2));
+    HIPCHK(hipEventCreateWithFlags(&H->ev_tick, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&H->ev_scene, hipEventDisableTiming));
     Dev &d = H->d;
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
@@ -622,6 +626,9 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->h_sc) (void)hipHostFree(H->h_sc);
     if (H->h_trk) (void)hipHostFree(H->h_trk);
     for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
+    if (H->stream2) { (void)hipStreamSynchronize(H->stream2); (void)hipStreamDestroy(H->stream2); }
+    if (H->ev_tick) (void)hipEventDestroy(H->ev_tick);
+    if (H->ev_scene) (void)hipEventDestroy(H->ev_scene);
     (void)hipStreamDestroy(H->stream);
     delete H;
 }
@@ -704,9 +711,10 @@ static int scene_reserve(rda_handle *H, int n)
 }
 
 static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
-                       const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex, bool sync)
+                       const double *vel, const double *robot_xy, int order, int32_t *n_nonconvex, bool sync, hipStream_t st = nullptr)
 {
     if (!H) return RDA_ERR_ARG;
+    if (!st) st = H->stream;
     Dev &d = H->d;
     if (n_nonconvex) *n_nonconvex = 0;
     if (n <= 0) { d.obstacle_num = 0; return RDA_OK; }           // nothing written: stale A, b stay (rda_solver.py:485)
@@ -729,24 +737,24 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     hb[o_bad] = 0.0;                                                       // all-zero bits: the int counter starts at 0
     memcpy((int *)(hb + o_int), kind, (size_t)n * sizeof(int));
     memcpy((int *)(hb + o_int) + n, nvert, (size_t)n * sizeof(int));
-    HIPCHK(hipMemcpyAsync(db, hb, scene_block_bytes((size_t)n, (size_t)E), hipMemcpyHostToDevice, H->stream));
+    HIPCHK(hipMemcpyAsync(db, hb, scene_block_bytes((size_t)n, (size_t)E), hipMemcpyHostToDevice, st));
     int *const d_bad = (int *)(db + o_bad);
     scene::Args a;
     a.n = n; a.N = N; a.E = E; a.T = T; a.nt = any_moving ? T + 1 : 1; a.order = order; a.dt = d.c.dt;
     a.kind = (int *)(db + o_int); a.nvert = (int *)(db + o_int) + n; a.geom = db; a.vel = db + o_vel; a.robot = db + o_rob;
     a.key = H->d_sc_key; a.sel = H->d_sc_sel; a.A = d.A; a.b = d.b; a.cone = d.cone; a.nonconvex = d_bad;
-    hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
-    hipLaunchKernelGGL(scene::k_rank, dim3((n + 255) / 256), dim3(256), 0, H->stream, a);
-    hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, H->stream, a);
+    hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scene::k_rank, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
     d.nt = a.nt; d.obstacle_num = N;
-    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, H->stream, d);
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);
     HIPCHK(hipGetLastError());
     if (n_nonconvex) {
-        HIPCHK(hipMemcpyAsync(H->h_sc, d_bad, sizeof(int), hipMemcpyDeviceToHost, H->stream));
-        HIPCHK(hipStreamSynchronize(H->stream));
+        HIPCHK(hipMemcpyAsync(H->h_sc, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         *n_nonconvex = *(int *)H->h_sc;
     } else if (sync) {
-        HIPCHK(hipStreamSynchronize(H->stream));                  // the staging block is reused by the next call
+        HIPCHK(hipStreamSynchronize(st));                  // the staging block is reused by the next call
     }
     return RDA_OK;
 }
@@ -922,6 +930,7 @@ extern "C" int rda_tracked_begin(rda_handle *H, const double *state, double ref_
     }
     track::In in; in.sx = state[0]; in.sy = state[1]; in.sth = state[2]; in.speed = ref_speed; in.threshold = threshold;
     in.cur_index = cur_index; in.ind_range = ind_range;
+    HIPCHK(hipEventRecord(H->ev_tick, H->stream));      // everything queued before this tick: the in-tick scene staging starts behind it
     hipLaunchKernelGGL(k_track, dim3(1), dim3(64), 0, H->stream, H->d, in, H->d_path, H->path_len, in_u, H->d_step, H->d_trk);
     int rc = enqueue_admm_head(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu);
     if (rc != RDA_OK) return rc;
@@ -935,9 +944,17 @@ extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind,
     if (!H) return RDA_ERR_ARG;
     // one pinned staging block per handle: a second upload before the caller's synchronising call (rda_tracked_finish,
     // rda_sync, a fleet step) has to wait for the first one to have been copied
-    if (H->pending_scene) { HIPCHK(hipStreamSynchronize(H->stream)); H->pending_scene = 0; }
-    int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false);
-    if (rc == RDA_OK && n > 0) H->pending_scene = 1;
+    if (H->pending_scene) { HIPCHK(hipStreamSynchronize(H->stream)); HIPCHK(hipStreamSynchronize(H->stream2)); H->pending_scene = 0; H->scene_on_s2 = 0; }
+    if (!H->pending) {
+        int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false);
+        if (rc == RDA_OK && n > 0) H->pending_scene = 1;
+        return rc;
+    }
+    // inside a tick: the copy and the conversion kernels touch only the obstacle slots, which nothing of the head (k_track,
+    // the first su-problem) reads - they run on the second stream BESIDE the first su-problem; rda_tracked_finish joins
+    HIPCHK(hipStreamWaitEvent(H->stream2, H->ev_tick, 0));
+    int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false, H->stream2);
+    if (rc == RDA_OK && n > 0) { HIPCHK(hipEventRecord(H->ev_scene, H->stream2)); H->pending_scene = 1; H->scene_on_s2 = 1; }
     return rc;
 }
 
@@ -947,7 +964,8 @@ extern "C" int rda_tracked_finish(rda_handle *H, double *out_u, double *out_s, r
     if (!H || !H->pending) return RDA_ERR_ARG;
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     const double *in_u = H->pending_in_u;
-    H->pending = 0; H->pending_scene = 0;
+    if (H->scene_on_s2) HIPCHK(hipStreamWaitEvent(H->stream, H->ev_scene, 0));
+    H->pending = 0; H->pending_scene = 0; H->scene_on_s2 = 0;
     int rc = enqueue_admm_tail(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) { (void)hipStreamSynchronize(H->stream); return rc; }
     HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
