@@ -517,6 +517,8 @@ extern "C" const char *rda_strerror(int code)
 extern "C" int rda_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int rda_set_device(int dev) { HIPCHK(hipSetDevice(dev)); return RDA_OK; }
 
+static size_t res_doubles(size_t T) { return 2 * T + 3 * (T + 1) + 8; }
+
 template <typename Tp> static int dalloc(Tp **p, size_t n)
 {
     HIPCHK(hipMalloc((void **)p, n * sizeof(Tp)));
@@ -585,7 +587,11 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
     rc |= dalloc(&d.ctrl, 1);
     const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
-    rc |= dalloc(&H->d_step, step_n); rc |= dalloc(&H->d_out_u, 2 * T); rc |= dalloc(&H->d_out_s, 3 * (T + 1)); rc |= dalloc(&H->d_info, 1);
+    rc |= dalloc(&H->d_step, step_n);
+    // result block, identical on the device and in pinned memory: u [2T] | s [3(T+1)] | rda_info (4 doubles) | track::Out (4 doubles):
+    // ONE copy back per step
+    rc |= dalloc(&H->d_out_u, res_doubles(T));
+    if (!rc) { H->d_out_s = H->d_out_u + 2 * T; H->d_info = (rda_info *)(H->d_out_s + 3 * (T + 1)); H->d_trk = (track::Out *)(H->d_out_s + 3 * (T + 1) + 4); }
     if (rc) { rda_destroy(H); return RDA_ERR_HIP; }
     HIPCHK(hipMemcpy(d.G, G, 2 * R * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d.h, h, R * sizeof(double), hipMemcpyHostToDevice));
@@ -597,8 +603,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     HIPCHK(hipHostMalloc((void **)&H->h_stage_b, N * (T + 1) * E * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&H->h_stage_cone, N * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&H->h_step, step_n * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&H->h_out, (2 * T + 3 * (T + 1)) * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&H->h_info, sizeof(rda_info)));
+    HIPCHK(hipHostMalloc((void **)&H->h_out, res_doubles(T) * sizeof(double)));
+    H->h_info = (rda_info *)(H->h_out + 2 * T + 3 * (T + 1)); H->h_trk = (track::Out *)(H->h_out + 2 * T + 3 * (T + 1) + 4);
     H->su_lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds)));
     HIPCHK(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
@@ -613,18 +619,16 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
     void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
-                     d.s, d.u, d.ctrl, H->d_step, H->d_out_u, H->d_out_s, H->d_info,
+                     d.s, d.u, d.ctrl, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
-                     H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path, H->d_trk };
+                     H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
     for (void *p : ptrs) dev_free(p);
     if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
     if (H->h_stage_b) (void)hipHostFree(H->h_stage_b);
     if (H->h_stage_cone) (void)hipHostFree(H->h_stage_cone);
     if (H->h_step) (void)hipHostFree(H->h_step);
     if (H->h_out) (void)hipHostFree(H->h_out);
-    if (H->h_info) (void)hipHostFree(H->h_info);
     if (H->h_sc) (void)hipHostFree(H->h_sc);
-    if (H->h_trk) (void)hipHostFree(H->h_trk);
     for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
     if (H->stream2) { (void)hipStreamSynchronize(H->stream2); (void)hipStreamDestroy(H->stream2); }
     if (H->ev_tick) (void)hipEventDestroy(H->ev_tick);
@@ -863,9 +867,7 @@ static int step_common(rda_handle *H, const double *nom_s, const double *nom_u, 
     HIPCHK(hipMemcpyAsync(H->d_step, H->h_step, (2 * ns + nu + 1) * sizeof(double), hipMemcpyHostToDevice, H->stream));
     rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) return rc;
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipStreamSynchronize(H->stream));
     memcpy(out_u, H->h_out, nu * sizeof(double));
     memcpy(out_s, H->h_out + nu, ns * sizeof(double));
@@ -909,10 +911,6 @@ extern "C" int rda_upload_path(rda_handle *H, int L, const double *path)
     if (L > H->path_len || !H->d_path) { dev_free(H->d_path); H->d_path = nullptr; if (dalloc(&H->d_path, (size_t)3 * L)) return RDA_ERR_HIP; }
     H->path_len = L;
     HIPCHK(hipMemcpy(H->d_path, path, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice));
-    if (!H->d_trk) {
-        if (dalloc(&H->d_trk, 1)) return RDA_ERR_HIP;
-        HIPCHK(hipHostMalloc((void **)&H->h_trk, sizeof(track::Out)));
-    }
     return RDA_OK;
 }
 
@@ -968,10 +966,7 @@ extern "C" int rda_tracked_finish(rda_handle *H, double *out_u, double *out_s, r
     H->pending = 0; H->pending_scene = 0; H->scene_on_s2 = 0;
     int rc = enqueue_admm_tail(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) { (void)hipStreamSynchronize(H->stream); return rc; }
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_trk, H->d_trk, sizeof(track::Out), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     if (nom_s_out || ref_out) HIPCHK(hipMemcpyAsync(H->h_step, H->d_step, (2 * ns + nu) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipStreamSynchronize(H->stream));
     if (out_u) memcpy(out_u, H->h_out, nu * sizeof(double));
@@ -1221,9 +1216,7 @@ extern "C" int rda_admm_finish(rda_handle *H, double *out_u, double *out_s, rda_
     Dev d = H->d;
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, H->d_out_u, H->d_out_s, H->d_info);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, nu * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_out + nu, H->d_out_s, ns * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipMemcpyAsync(H->h_info, H->d_info, sizeof(rda_info), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipStreamSynchronize(H->stream));
     memcpy(out_u, H->h_out, nu * sizeof(double));
     memcpy(out_s, H->h_out + nu, ns * sizeof(double));
