@@ -86,7 +86,13 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
                                                            const double *ref, const double *ref_speed)
 {
     const int tid = threadIdx.x;
-    if (d.ctrl->stop) return;
+    if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
+        if (tid == 0) {
+            d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0;
+            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
+        }
+        __syncthreads();
+    } else if (d.ctrl->stop) return;
     if (it > 0) {
         reduce_residuals(d, smem_su, tid);
         if (d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold) {   // rda_solver.py:594
@@ -802,7 +808,7 @@ static void launch_lammuz(rda_handle *H, const Dev &d)
 }
 
 // queue the whole ADMM loop of one MPC step (rda_solver.py:588-596) - no host synchronisation
-// The ADMM loop of one MPC step in two parts.  The HEAD (k_begin + the first su-problem) reads the nominal trajectory and the
+// The ADMM loop of one MPC step in two parts.  The HEAD (the first su-problem, which also resets the step's control block) reads the nominal trajectory and the
 // condensed terms of the PREVIOUS step (quirk Q4) but nothing of the staged obstacles, so a caller may stage this tick's
 // obstacles on the stream between head and tail while the first su-problem is being solved (rda_tracked_begin/_finish).
 static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, const double *in_u)
@@ -816,8 +822,7 @@ static int enqueue_admm_head(rda_handle *H, const double *in_s, const double *in
 {
     Dev d = H->d;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
-    hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, H->stream, d);
-    launch_su(H, d, 0, in_s, in_u);
+    launch_su(H, d, 0, in_s, in_u);                    // resets the step's control block itself (su_body, it == 0)
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
@@ -1233,7 +1238,6 @@ struct EgoIO {            // base pointers, indexed by the step number k inside 
     const double *s, *u, *ref, *speed; double *out_u, *out_s; rda_info *info;
 };
 
-__global__ void k_begin_fleet(const Dev *devs) { begin_body(devs[blockIdx.x]); }
 
 template <int TT> __global__ __launch_bounds__(su::NT) void k_su_fleet(const Dev *devs, const EgoIO *io, int it, int k)
 {
@@ -1350,8 +1354,7 @@ static int fleet_refresh(rda_fleet *F)
 static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
 {
     const int B = F->B;
-    hipLaunchKernelGGL(k_begin_fleet, dim3(B), dim3(64), 0, F->stream, F->d_devs);
-    for (int it = 0; it < F->iter_num; ++it) {
+    for (int it = 0; it < F->iter_num; ++it) {          // iteration 0 resets every member's control block (su_body)
         RDA_SU_DISPATCH(F->T, hipLaunchKernelGGL(k_su_fleet<TT>, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, it, k));
         if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
         else hipLaunchKernelGGL(k_lammuz_fleet, dim3(F->blocks, B), dim3(256), 0, F->stream, F->d_devs);
