@@ -223,6 +223,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     for (int i = tid; i < 2 * T; i += NT) L.u[i] = a.in_u[i];
     for (int i = tid; i < 2 * T; i += NT) L.p0[i] = a.in_s[(i / T) * (T + 1) + (i % T) + 1];      // nominal positions of stages 1..T
     __syncthreads();
+    mark(0);
     if (tid < T) {
         int t = tid;
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
@@ -258,13 +259,22 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             const double p0x = L.p0[rt], p0y = L.p0[T + rt];
             for (int r = 0; r < a.P; ++r) {
                 const size_t o = r * a.chunk + (size_t)rt * a.Nloc;
-                int bit = r * KS;
+                // the bit position only depends on the loop counters, i.e. it is the same in every thread: the word index and
+                // the shift are scalar, the per-thread part is one select + or on a register (no indexed access to amask)
+                int bit = r * KS, curw = bit >> 6;
+                unsigned long long cur = 0;
+                auto flush = [&]() {
+                    switch (curw) { case 0: amask[0] |= cur; break; case 1: amask[1] |= cur; break; case 2: amask[2] |= cur; break; default: amask[3] |= cur; break; }
+                    cur = 0;
+                };
                 auto term = [&](double ax, double ay, double gx, double gy, double cb) {
                     double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
                     double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
                     q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
                     double margin = ax * p0x + ay * p0y - cb - c.max_sd;
-                    if (screened && !(margin > 0 && margin * margin > DELTA * DELTA * (ax * ax + ay * ay))) amask[bit >> 6] |= 1ull << (bit & 63);
+                    const bool may = screened && !(margin > 0 && margin * margin > DELTA * DELTA * (ax * ax + ay * ay));
+                    if ((bit >> 6) != curw) { flush(); curw = bit >> 6; }
+                    cur |= may ? 1ull << (bit & 63) : 0ull;
                     ++bit;
                 };
                 const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o, *pb = a.blam + o, *pe = a.ee + o;
@@ -278,14 +288,17 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                     for (int k = 0; k < 8; ++k) term(x[k], y[k], g[k], h[k], cb[k] + ce[k]);
                 }
                 for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n], pb[n] + pe[n]);
+                flush();
             }
         }
+        mark(3);
         if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %
             double cnt = 0;
             for (int w = 0; w < MW; ++w) cnt += (double)__popcll(amask[w]);
             cnt = block_reduce(cnt, L.red, tid, false);
             if (cnt > 0.3 * (double)a.P * a.Nloc * T) screened = false;
         }
+        mark(14);
         L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
         __syncthreads();
         if (tid < T) {
