@@ -71,20 +71,23 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
     for (int i = 0; i < 6; ++i) B[i] = 0;
     C[0] = C[1] = C[2] = 0;
     A[0] = A[4] = A[8] = 1;
+    // sin and cos of the heading from one sincos (shared argument reduction, same values)
     if (c.dynamics == 2) {
-        double phi = ut[1], v = ut[0];
-        B[0] = cos(phi) * dt; B[1] = -v * sin(phi) * dt; B[2] = sin(phi) * dt; B[3] = v * cos(phi) * dt;
-        C[0] = phi * v * sin(phi) * dt; C[1] = -phi * v * cos(phi) * dt;
+        double phi = ut[1], v = ut[0], sp, cp;
+        sincos(phi, &sp, &cp);
+        B[0] = cp * dt; B[1] = -v * sp * dt; B[2] = sp * dt; B[3] = v * cp * dt;
+        C[0] = phi * v * sp * dt; C[1] = -phi * v * cp * dt;
         return;
     }
-    double phi = st[2], v = ut[0];
-    A[2] = -v * dt * sin(phi); A[5] = v * dt * cos(phi);
-    B[0] = cos(phi) * dt; B[2] = sin(phi) * dt;
-    C[0] = phi * v * sin(phi) * dt; C[1] = -phi * v * cos(phi) * dt;
+    double phi = st[2], v = ut[0], sp, cp;
+    sincos(phi, &sp, &cp);
+    A[2] = -v * dt * sp; A[5] = v * dt * cp;
+    B[0] = cp * dt; B[2] = sp * dt;
+    C[0] = phi * v * sp * dt; C[1] = -phi * v * cp * dt;
     if (c.dynamics == 0) {
-        double psi = ut[1], cp = cos(psi);
-        B[4] = tan(psi) * dt / c.L; B[5] = v * dt / (c.L * cp * cp);
-        C[2] = -psi * v * dt / (c.L * cp * cp);
+        double psi = ut[1], cs = cos(psi);
+        B[4] = tan(psi) * dt / c.L; B[5] = v * dt / (c.L * cs * cs);
+        C[2] = -psi * v * dt / (c.L * cs * cs);
     } else {
         B[5] = dt;
     }
