@@ -347,3 +347,53 @@ def test_lidar_example_is_driven_to_the_goal():
             arrived = info["arrive"]
             break
     assert arrived and not env.collided and min_clear > 0.3 and seen >= 2
+
+
+def test_flatten_scene_matches_object_by_object_packing():
+    """`RDA_solver.flatten_scene` (one concatenate + one scatter over all obstacle objects) against packing the objects one by
+    one the way the reference reads them (mpc.py:192-203: `.cone_type`, `.vertex` 2xk, `.center`, `.radius`, `.velocity`):
+    polygons of mixed vertex counts, circles, skipped cone types, 1-D / nested-list attributes, the empty list, too many
+    vertices"""
+    from rda_planner_amd import scenarios as sc
+    from rda_planner_amd.rda_solver import RDA_solver
+
+    class Host:                       # flatten_scene only reads max_edge_num
+        max_edge_num = 5
+
+    def packed(objs, E):
+        objs = [o for o in objs if o.cone_type in ("norm2", "Rpositive")]
+        n = len(objs)
+        kind, nvert, geom, vel = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, E, 2)), np.zeros((n, 2))
+        for i, o in enumerate(objs):
+            vel[i] = np.asarray(o.velocity, float).ravel()[0:2]
+            if o.cone_type == "norm2":
+                kind[i] = 1
+                geom[i, 0] = np.asarray(o.center, float).ravel()[0:2]
+                geom[i, 1, 0] = float(o.radius)
+            else:
+                V = np.asarray(o.vertex, float)[0:2]
+                nvert[i] = V.shape[1]
+                geom[i, :V.shape[1]] = V.T
+        return n, kind, nvert, geom, vel
+
+    rng = np.random.default_rng(11)
+    poly = [sc.Obstacle(center=np.zeros((2, 1)), radius=1.0, vertex=rng.uniform(0, 9, (2, k)), cone_type="Rpositive",
+                        velocity=rng.uniform(-1, 1, (2, 1))) for k in (3, 4, 5, 4, 3, 3, 5, 4)]
+    circ = [sc.Obstacle(center=rng.uniform(0, 9, (2, 1)), radius=float(rng.uniform(0.3, 1)), vertex=None, cone_type="norm2",
+                        velocity=rng.uniform(-1, 1, (2, 1))) for _ in range(4)]
+
+    class Skipped:
+        cone_type, vertex, velocity, center, radius = "exponential", None, np.zeros((2, 1)), np.zeros((2, 1)), 1.0
+
+    mixed = [poly[0], circ[0], poly[1], Skipped(), poly[2], circ[1], circ[2], poly[3], poly[4], circ[3]]
+    lists = [p._replace(vertex=p.vertex.tolist(), velocity=[0.25, -0.5]) for p in poly[:3]]      # nested lists, 1-D velocity
+    three_rows = [p._replace(vertex=np.vstack((p.vertex, np.ones((1, p.vertex.shape[1]))))) for p in poly[:4]]   # homogeneous 3xk
+    for name, objs in (("polygons", poly), ("circles", circ), ("mixed", mixed), ("lists", lists), ("three rows", three_rows), ("empty", [])):
+        got, want = RDA_solver.flatten_scene(Host, objs), packed(objs, Host.max_edge_num)
+        assert got[0] == want[0], name
+        for g, w in zip(got[1:], want[1:]):
+            assert g.dtype == w.dtype and g.shape == w.shape and np.array_equal(g, w), name
+    Host.max_edge_num = 4
+    assert RDA_solver.flatten_scene(Host, poly) is None            # a pentagon does not fit: the caller converts on the host
+    Host.max_edge_num = 2
+    assert RDA_solver.flatten_scene(Host, circ) is None            # a circle needs three rows
