@@ -1162,7 +1162,7 @@ extern "C" int rda_shard_unique_id(rda_handle *H, void *out128)
 }
 extern "C" int rda_shard_comm_init(rda_handle *H, const void *uid128)
 {
-    if (!H || !uid128 || H->d.P < 2) return RDA_ERR_ARG;
+    if (!H || !uid128 || H->d.P < 1) return RDA_ERR_ARG;     // a one-rank communicator is legal (plumbing check on a 1-GPU box)
     struct uid_t { char b[128]; } uid;
     memcpy(&uid, uid128, 128);
     typedef int (*init_fn)(void **, int, uid_t, int);

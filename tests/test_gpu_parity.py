@@ -301,6 +301,27 @@ def test_obstacle_shards_rccl_two_gpus():
     assert out.returncode == 0 and "RCCL_SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_rccl_path_with_a_one_rank_communicator():
+    """what a 1-GPU box can run of the in-library RCCL path: librccl is loaded, ncclGetUniqueId / ncclCommInitRank build a
+    one-rank communicator and every ADMM iteration queues the in-place ncclAllGather of the condensed terms on the handle's
+    stream (a one-rank gather moves nothing, but symbol resolution, argument types, stream ordering and tear-down are the real
+    thing).  Results must EQUAL the plain handle's, also through the device-resident replay (rda_enqueue_step)."""
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.sharded import enable_rccl
+    from test_sharded_gloo import _problem
+    car_t, T, N, rl, steps = _problem()
+    plain = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+    comm = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+    enable_rccl(comm, 0, 1, lambda raw: raw)
+    for nom_s, nom_u, ref in steps:
+        u0, i0 = plain.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+        u1, i1 = comm.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+        assert np.array_equal(u0, u1) and i0["iters"] == i1["iters"] and i0["resi_dual"] == i1["resi_dual"]
+    s0, s1 = plain.get_state(), comm.get_state()
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
+
+
 def test_full_size_step_properties():
     """BASELINE scaling point T=20, N=2000 (40 000 sub-problems per ADMM iteration), where the oracle is too slow to
     be the checker for many steps: size-independent properties of one solver step instead.
