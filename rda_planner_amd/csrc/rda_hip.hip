@@ -45,6 +45,8 @@ struct Dev {
     int rows;                // four sub-problems per wave (k_lammuz_rows) when E+R+1 <= 16 (RDA_LMZ_ROWS=0 disables)
     unsigned char muc[40]; int nmv;   // robot support candidates that survive the vertex test (host, rda_create)
     double rv[28][2]; int nrv;        // robot vertices of the surviving pairs (list order)
+    double *su_lam_keep;               // inequality multipliers of the last converged su-solve [10*T] (interior-point warm start)
+    double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
     int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
     int obstacle_num;        // 0 or N
     double *G, *h;
@@ -113,6 +115,9 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
+    // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
+    if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; }
+    a.lam_keep = d.su_lam_keep;
     su::solve<TT>(a, smem_su);
     __syncthreads();
     if (tid == 0) {
@@ -573,6 +578,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     { const char *w = getenv("RDA_LMZ_ROWS"); H->d.rows = (cfg->E + cfg->R + 1 <= 16) && (w ? atoi(w) != 0 : true); }
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
     H->d.centre = g_tie_centre;
+    H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3;
+    { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf", &H->d.su_warm_wfl, &H->d.su_warm_mu0); }
     { const char *e = getenv("RDA_TIE_CENTRE"); if (e) H->d.centre = atoi(e) ? 1 : 0; }      // experiments only
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
@@ -592,6 +599,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     rc |= dalloc(&d.coef, d.chunk);
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
     rc |= dalloc(&d.ctrl, 1);
+    rc |= dalloc(&d.su_lam_keep, 10 * T);
     const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
     rc |= dalloc(&H->d_step, step_n);
     // result block, identical on the device and in pinned memory: u [2T] | s [3(T+1)] | rda_info (4 doubles) | track::Out (4 doubles):
@@ -625,7 +633,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
     void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
-                     d.s, d.u, d.ctrl, H->d_step, H->d_out_u,
+                     d.s, d.u, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
     for (void *p : ptrs) dev_free(p);

@@ -54,6 +54,11 @@ struct Args {
     int *ipm_iters;
     long long *prof;                 // optional per-phase cycle counters (debug), may be null
     double *dbg = nullptr;           // optional per-iteration trace (rdn, rpn, mu, sc) x 100 (debug), may be null
+    // Warm start of the su-problems of ADMM iterations >= 1 (the problem differs from the previous iteration's only through the
+    // duals, the linearisation point IS the previous solution): slack floor / barrier parameter of the start (0 = the cold
+    // rule) and the multipliers of the previous converged solve [NC*T] (read when warm, written by every converged solve)
+    double warm_wfl = 0, warm_mu0 = 0;
+    double *lam_keep = nullptr;
 };
 
 __device__ __forceinline__ void wsync()
@@ -371,7 +376,16 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         }
         __syncthreads();
     };
-    centre_duals(1e-2, 1.0);
+    // Start.  Cold: slacks floored at 1e-2, lam = 1/w (mu0 = 1).  Warm (ADMM iterations >= 1): the primal point is the previous
+    // solution, so the slacks are the previous ones; they are floored at warm_wfl, the multipliers are the larger of the centred
+    // ones (warm_mu0 / w) and those the previous solve ended with.  Starting with a small mu0 WITHOUT the old multipliers costs
+    // iterations (measured: 75 -> 92 us per launch), with them it saves about one per solve (75 -> 67 us).
+    const bool warm = a.warm_mu0 > 0 && a.lam_keep != nullptr;
+    if (warm) {
+        centre_duals(a.warm_wfl, a.warm_mu0);
+        for (int i = tid; i < NC * T; i += NT) { const double lp = a.lam_keep[i]; if (con_on(i / NC, i % NC) && lp > L.cl[i]) L.cl[i] = lp; }
+        __syncthreads();
+    } else centre_duals(1e-2, 1.0);
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
@@ -550,17 +564,20 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     int status = 1, it = 0, used = 0;
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
     mark(9);
-    for (int attempt = 0; attempt < 2 && status != 0; ++attempt) {
-    if (attempt) {
+    // Attempts: [-1: the warm start, at most 12 iterations - it either pays off at once or is abandoned], 0: the cold start,
+    // 1: the central restart described above.
+    for (int attempt = warm ? -1 : 0; attempt < 2 && status != 0; ++attempt) {
+    if (attempt == 1 || (attempt == 0 && warm)) {
         __syncthreads();
         clip_controls();
         rollout();
         __syncthreads();
-        screened = false;
-        centre_duals(1e-1, 10.0);
+        if (attempt == 1) { screened = false; centre_duals(1e-1, 10.0); }
+        else centre_duals(1e-2, 1.0);
         status = 1;
     }
-    for (it = 0; it < 100; ++it) {
+    const int it_cap = attempt < 0 ? 12 : 100;
+    for (it = 0; it < it_cap; ++it) {
         seq += 1;
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
         {
@@ -871,6 +888,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     // consistent final rollout (removes accumulated rounding in s)
     rollout();
     __syncthreads();
+    if (status == 0 && a.lam_keep) for (int i = tid; i < NC * T; i += NT) a.lam_keep[i] = L.cl[i];
     if (status == 0) {       // otherwise keep the nominal (reference :696-700)
         for (int i = tid; i < 3 * (T + 1); i += NT) a.out_s[i] = L.s[i];
         for (int i = tid; i < 2 * T; i += NT) a.out_u[i] = L.u[i];

