@@ -57,7 +57,7 @@ struct Args {
     // Warm start of the su-problems of ADMM iterations >= 1 (the problem differs from the previous iteration's only through the
     // duals, the linearisation point IS the previous solution): slack floor / barrier parameter of the start (0 = the cold
     // rule) and the multipliers of the previous converged solve [NC*T] (read when warm, written by every converged solve)
-    double warm_wfl = 0, warm_mu0 = 0;
+    double warm_wfl = 0, warm_mu0 = 0; int warm_cap = 30;
     double *lam_keep = nullptr;
 };
 
@@ -564,8 +564,10 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     int status = 1, it = 0, used = 0;
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
     mark(9);
-    // Attempts: [-1: the warm start, at most 12 iterations - it either pays off at once or is abandoned], 0: the cold start,
-    // 1: the central restart described above.
+    // Attempts: [-1: the warm start, at most warm_cap = 30 iterations.  Where consecutive su-problems are close (static scenes) it
+    // converges within 3-4; with many moving obstacles it needs as many iterations as the cold start (8-20) but does arrive:
+    // cutting it at 5 / 7 / 12 iterations and starting over cost +29 / +35 / +5 % on the dynamic_obs benchmark, 30 costs
+    // nothing], 0: the cold start, 1: the central restart described above.
     for (int attempt = warm ? -1 : 0; attempt < 2 && status != 0; ++attempt) {
     if (attempt == 1 || (attempt == 0 && warm)) {
         __syncthreads();
@@ -576,7 +578,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         else centre_duals(1e-2, 1.0);
         status = 1;
     }
-    const int it_cap = attempt < 0 ? 12 : 100;
+    const int it_cap = attempt < 0 ? a.warm_cap : 100;
     for (it = 0; it < it_cap; ++it) {
         seq += 1;
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
