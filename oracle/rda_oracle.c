@@ -30,6 +30,8 @@
 #define SIGN_TOL 1e-12
 
 static int g_threads = 1;
+static double g_su_warm_wfl = 1e-3, g_su_warm_mu0 = 1e-3; static int g_su_warm_cap = 30;   /* su warm start (orc_set_su_warm(0,0,0): cold) */
+void orc_set_su_warm(double wfl, double mu0, int cap) { g_su_warm_wfl = wfl; g_su_warm_mu0 = mu0; g_su_warm_cap = cap; }
 static int g_centre = 1;     /* tie-break T1: central separating normal in the slack regime (orc_set_centre(0): max clearance) */
 void orc_set_centre(int on) { g_centre = on; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
@@ -45,6 +47,7 @@ struct orc_handle {
     double *resp;                  /* [N*T][2] residual partials of the last LamMuZ pass */
     double *ref, ref_speed;        /* step inputs */
     int stop, iters, su_status, ipm_total; double resi_dual, resi_pri;
+    double *su_lam_keep;          /* inequality multipliers of the last converged su-solve (10T - 4 rows) */
     int P, rank, Nloc, have_gath; size_t chunk; double *gath;      /* obstacle sharding */
 };
 
@@ -620,9 +623,13 @@ static void chol_solve(const double *K, int n, double *rhs)
 #ifndef SIGMA_FLOOR
 #define SIGMA_FLOOR 1e-3
 #endif
-int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
-                 double ref_speed, const double *a, const double *cc, const double *g,
-                 const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters)
+/* Warm start of the su-problems of ADMM iterations >= 1 (same rule as csrc/su_device.h): lam_keep[mc] = the inequality multipliers
+ * the last converged solve ended with (this function's own row order); warm != 0: the slacks of the start are floored at warm_wfl
+ * and the multipliers are the larger of warm_mu0 / w and lam_keep; the warm attempt gets warm_cap iterations, then the cold rule. */
+static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
+                         double ref_speed, const double *a, const double *cc, const double *g,
+                         const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters,
+                         double *lam_keep, int warm, double warm_wfl, double warm_mu0, int warm_cap)
 {
     int T = c->T, N = c->N, n = 3 * T;
     su_ctx S; S.c = c; S.T = T; S.N = N; S.a = a; S.cc = cc; S.g = g; S.ref = ref_s; S.nom_s = nom_s; S.ref_speed = ref_speed;
@@ -674,8 +681,10 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
      * cap, ~0.1% of closed-loop solves, where the iterates cycle): it restarts from the same nominal
      * with a more central point (slack floor 0.1, mu0 = 10), which is enough to break the cycle. */
     int status = 1, it = 0, used = 0;
-    for (int attempt = 0; attempt < 2 && status != 0; ++attempt) {
-    const double wfl = attempt ? 1e-1 : 1e-2, mu0 = attempt ? 10.0 : 1.0;
+    warm = warm && lam_keep != NULL;
+    for (int attempt = warm ? -1 : 0; attempt < 2 && status != 0; ++attempt) {
+    const double wfl = attempt < 0 ? warm_wfl : (attempt ? 1e-1 : 1e-2), mu0 = attempt < 0 ? warm_mu0 : (attempt ? 10.0 : 1.0);
+    const int it_cap = attempt < 0 ? warm_cap : 100;
     for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
         double v = nom_u[i * T + t], lim = 0.99 * c->max_speed[i];
         x[2 * t + i] = v > lim ? lim : (v < -lim ? -lim : v);
@@ -688,9 +697,10 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
         double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
         double sl = con[i].e - cx;
         w[i] = sl > wfl ? sl : wfl; lm[i] = mu0 / w[i];
+        if (attempt < 0 && lam_keep[i] > lm[i]) lm[i] = lam_keep[i];
     }
     status = 1;
-    for (it = 0; it < 100; ++it) {
+    for (it = 0; it < it_cap; ++it) {
         su_eval(&S, x, s, grad, Hm);
         double gn = 0, rdn = 0, rpn = 0, mu = 0;
         for (int i = 0; i < n; ++i) { if (fabs(grad[i]) > gn) gn = fabs(grad[i]); rhs[i] = grad[i]; }
@@ -759,12 +769,20 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
     used += it;
     }
     if (ipm_iters) *ipm_iters = used;
+    if (status == 0 && lam_keep) memcpy(lam_keep, lm, sizeof(double) * mc);
     su_rollout(&S, x, s);
     memcpy(s_out, s, sizeof(double) * 3 * (T + 1));
     for (int t = 0; t < T; ++t) { u_out[t] = x[2 * t]; u_out[T + t] = x[2 * t + 1]; d_out[t] = x[2 * T + t]; }
     free(S.Ak); free(S.Bk); free(S.Ck); free(S.Gam); free(S.Q0); free(S.Q1); free(S.Q2);
     free(con); free(x); free(grad); free(Hm); free(K); free(rhs); free(dx); free(w); free(lm); free(rp); free(dw); free(dl); free(rc); free(s);
     return status;
+}
+
+int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
+                 double ref_speed, const double *a, const double *cc, const double *g,
+                 const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters)
+{
+    return su_solve_impl(c, nom_s, nom_u, ref_s, ref_speed, a, cc, g, d0, s_out, u_out, d_out, ipm_iters, NULL, 0, 0, 0, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -790,13 +808,14 @@ int orc_create(const orc_cfg *cfg, const double *G, const double *h, orc_handle 
     H->s = calloc(3 * (T + 1), sizeof(double)); H->u = calloc(2 * T, sizeof(double));
     H->resp = calloc((size_t)2 * N * T, sizeof(double)); H->ref = calloc(3 * (T + 1), sizeof(double));
     H->P = 1; H->rank = 0; H->Nloc = N; H->chunk = (size_t)8 * T * N; H->gath = NULL; H->have_gath = 0;
+    H->su_lam_keep = calloc((size_t)10 * T, sizeof(double));
     *out = H; return 0;
 }
 void orc_destroy(orc_handle *H)
 {
     if (!H) return;
     free(H->G); free(H->h); free(H->lam); free(H->mu); free(H->z); free(H->xi); free(H->zeta); free(H->dis);
-    free(H->a_lam); free(H->b_lam); free(H->A); free(H->b); free(H->cone); free(H->s); free(H->u); free(H->resp); free(H->ref); free(H->gath); free(H);
+    free(H->a_lam); free(H->b_lam); free(H->A); free(H->b); free(H->cone); free(H->s); free(H->u); free(H->resp); free(H->ref); free(H->gath); free(H->su_lam_keep); free(H);
 }
 int orc_set_adjust(orc_handle *H, double slack_gain, double max_sd, double min_sd, double ro1, double ro2)
 { H->c.slack_gain = slack_gain; H->c.max_sd = max_sd; H->c.min_sd = min_sd; H->c.ro1 = ro1; H->c.ro2 = ro2; return 0; }
@@ -935,7 +954,10 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
         cg[(n * T + t) * 2] = o8[4]; cg[(n * T + t) * 2 + 1] = o8[5];
     }
     int ipm = 0;
-    int st = orc_su_solve(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm);
+    /* ADMM iterations >= 1 start from the multipliers of the previous su-solve of this step, if that one converged */
+    const int warm = it > 0 && g_su_warm_mu0 > 0 && !((H->su_status >> (it - 1)) & 1);
+    int st = su_solve_impl(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm,
+                           H->su_lam_keep, warm, g_su_warm_wfl, g_su_warm_mu0, g_su_warm_cap);
     H->ipm_total += ipm;
     if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
     else H->su_status |= 1 << it;                 /* 'No update of state and control vector' :699 */

@@ -89,6 +89,9 @@ int  orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_nor
  * a[N][T][2], cc[N][T] (= lam'b + mu'h + z - zeta), g[N][T][2] (= G'mu + xi).
  * nom_s 3x(T+1), nom_u 2xT linearisation point; d0 [T] initial guess.
  * Outputs s 3x(T+1), u 2xT, d [T]. returns 0 ok, 1 not converged. */
+/* interior-point start of the su-problems of ADMM iterations >= 1 inside orc_step / orc_admm_su (defaults 1e-3, 1e-3, 30; 0,0,0 = cold);
+ * orc_su_solve itself always starts cold */
+void orc_set_su_warm(double wfl, double mu0, int cap);
 int  orc_su_solve(const orc_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
                   double ref_speed, const double *a, const double *cc, const double *g,
                   const double *d0, double *s, double *u, double *d, int *ipm_iters);

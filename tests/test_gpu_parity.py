@@ -464,9 +464,7 @@ def test_closed_loop_lidar_example():
         uc, ic = cpu.control(env.robot.state.copy(), 4.0, list(obs))
         ug, ig = gpu.control(env.robot.state.copy(), 4.0, list(obs))
         assert ic["iters"] == ig["iters"] and cpu.cur_index == gpu.cur_index, i
-        # 1e-5: the kernel warm-starts the su-problems of ADMM iterations >= 1, the oracle does not; both stop at the same residual
-        # tolerances, which leaves ~1e-6 in the flat (steering) direction on a few steps (1.6e-6 at step 34 here), 1e-9 elsewhere
-        assert np.abs(uc - ug).max() < 1e-5, (i, np.abs(uc - ug).max())
+        assert np.abs(uc - ug).max() < 1e-6, (i, np.abs(uc - ug).max())
         gpu.rda.set_state(cpu.rda.get_state())
         gpu.cur_vel_array = cpu.cur_vel_array.copy()
         env.step(uc)
