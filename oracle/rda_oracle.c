@@ -14,7 +14,9 @@
  * The two convex programs the reference gives to CVXPY/ECOS are solved here by
  *   (i)  exhaustive enumeration of basic supports (LamMuZ; see oracle/lammuz_np.py for the
  *        derivation and the explicit tie-break T1-T3), and
- *  (ii)  a dense primal-dual interior point method on the control-condensed problem (su).
+ *  (ii)  a dense primal-dual interior point method on the control-condensed problem (su); inside an MPC step the
+ *        su-problems of ADMM iterations >= 1 start from the multipliers of the previous one (su_solve_impl, the same
+ *        start rule as the kernel's, so both walk the same iteration path; the solution itself is unique).
  */
 #include "rda_oracle.h"
 #include <math.h>
