@@ -32,7 +32,7 @@
 #define SIGN_TOL 1e-12
 
 static int g_threads = 1;
-static double g_su_warm_wfl = 1e-3, g_su_warm_mu0 = 1e-3; static int g_su_warm_cap = 30;   /* su warm start (orc_set_su_warm(0,0,0): cold) */
+static double g_su_warm_wfl = 1e-3, g_su_warm_mu0 = 1e-3; static int g_su_warm_cap = 30, g_su_warm_first = 1;   /* su warm start (orc_set_su_warm(0,0,0): cold) */
 void orc_set_su_warm(double wfl, double mu0, int cap) { g_su_warm_wfl = wfl; g_su_warm_mu0 = mu0; g_su_warm_cap = cap; }
 static int g_centre = 1;     /* tie-break T1: central separating normal in the slack regime (orc_set_centre(0): max clearance) */
 void orc_set_centre(int on) { g_centre = on; }
@@ -631,7 +631,7 @@ static void chol_solve(const double *K, int n, double *rhs)
 static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
                          double ref_speed, const double *a, const double *cc, const double *g,
                          const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters,
-                         double *lam_keep, int warm, double warm_wfl, double warm_mu0, int warm_cap)
+                         double *lam_keep, int warm, double warm_wfl, double warm_mu0, int warm_cap, int warm_shift)
 {
     int T = c->T, N = c->N, n = 3 * T;
     su_ctx S; S.c = c; S.T = T; S.N = N; S.a = a; S.cc = cc; S.g = g; S.ref = ref_s; S.nom_s = nom_s; S.ref_speed = ref_speed;
@@ -699,7 +699,16 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
         double sl = con[i].e - cx;
         w[i] = sl > wfl ? sl : wfl; lm[i] = mu0 / w[i];
-        if (attempt < 0 && lam_keep[i] > lm[i]) lm[i] = lam_keep[i];
+        if (attempt < 0) {
+            /* first su-problem of a step: the multipliers are those of the previous STEP, whose stage t+1 is this step's stage t */
+            int src = i;
+            if (warm_shift) {
+                if (i < 4 * T) { int t = i / 4 + 1; if (t > T - 1) t = T - 1; src = 4 * t + i % 4; }
+                else if (i < 8 * T - 4) { int j = i - 4 * T, t = j / 4 + 1; if (t > T - 2) t = T - 2; src = 4 * T + 4 * t + j % 4; }
+                else { int j = i - (8 * T - 4), t = j / 2 + 1; if (t > T - 1) t = T - 1; src = 8 * T - 4 + 2 * t + j % 2; }
+            }
+            if (lam_keep[src] > lm[i]) lm[i] = lam_keep[src];
+        }
     }
     status = 1;
     for (it = 0; it < it_cap; ++it) {
@@ -784,7 +793,7 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                  double ref_speed, const double *a, const double *cc, const double *g,
                  const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters)
 {
-    return su_solve_impl(c, nom_s, nom_u, ref_s, ref_speed, a, cc, g, d0, s_out, u_out, d_out, ipm_iters, NULL, 0, 0, 0, 0);
+    return su_solve_impl(c, nom_s, nom_u, ref_s, ref_speed, a, cc, g, d0, s_out, u_out, d_out, ipm_iters, NULL, 0, 0, 0, 0, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -957,9 +966,10 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
     }
     int ipm = 0;
     /* ADMM iterations >= 1 start from the multipliers of the previous su-solve of this step, if that one converged */
-    const int warm = it > 0 && g_su_warm_mu0 > 0 && !((H->su_status >> (it - 1)) & 1);
+    /* ... and the first one from those of the previous step, shifted by one stage */
+    const int warm = g_su_warm_mu0 > 0 && (it > 0 ? !((H->su_status >> (it - 1)) & 1) : g_su_warm_first);
     int st = su_solve_impl(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm,
-                           H->su_lam_keep, warm, g_su_warm_wfl, g_su_warm_mu0, g_su_warm_cap);
+                           H->su_lam_keep, warm, g_su_warm_wfl, g_su_warm_mu0, g_su_warm_cap, it == 0);
     H->ipm_total += ipm;
     if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
     else H->su_status |= 1 << it;                 /* 'No update of state and control vector' :699 */

@@ -46,6 +46,7 @@ struct Dev {
     unsigned char muc[40]; int nmv;   // robot support candidates that survive the vertex test (host, rda_create)
     double rv[28][2]; int nrv;        // robot vertices of the surviving pairs (list order)
     double *su_lam_keep;               // inequality multipliers of the last converged su-solve [10*T] (interior-point warm start)
+    int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
     int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
@@ -118,6 +119,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
+    if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
     a.lam_keep = d.su_lam_keep;
     su::solve<TT>(a, smem_su);
     __syncthreads();
@@ -579,7 +581,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     { const char *w = getenv("RDA_LMZ_ROWS"); H->d.rows = (cfg->E + cfg->R + 1 <= 16) && (w ? atoi(w) != 0 : true); }
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
     H->d.centre = g_tie_centre;
-    H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30;
+    H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
     { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &H->d.su_warm_wfl, &H->d.su_warm_mu0, &H->d.su_warm_cap); }
     { const char *e = getenv("RDA_TIE_CENTRE"); if (e) H->d.centre = atoi(e) ? 1 : 0; }      // experiments only
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;

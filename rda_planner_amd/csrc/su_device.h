@@ -57,7 +57,7 @@ struct Args {
     // Warm start of the su-problems of ADMM iterations >= 1 (the problem differs from the previous iteration's only through the
     // duals, the linearisation point IS the previous solution): slack floor / barrier parameter of the start (0 = the cold
     // rule) and the multipliers of the previous converged solve [NC*T] (read when warm, written by every converged solve)
-    double warm_wfl = 0, warm_mu0 = 0; int warm_cap = 30;
+    double warm_wfl = 0, warm_mu0 = 0; int warm_cap = 30; int warm_shift = 0;
     double *lam_keep = nullptr;
 };
 
@@ -383,7 +383,9 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     const bool warm = a.warm_mu0 > 0 && a.lam_keep != nullptr;
     if (warm) {
         centre_duals(a.warm_wfl, a.warm_mu0);
-        for (int i = tid; i < NC * T; i += NT) { const double lp = a.lam_keep[i]; if (con_on(i / NC, i % NC) && lp > L.cl[i]) L.cl[i] = lp; }
+        for (int i = tid; i < NC * T; i += NT) {
+            const int t = i / NC, k = i % NC, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
+            const double lp = a.lam_keep[ts * NC + k]; if (con_on(t, k) && lp > L.cl[i]) L.cl[i] = lp; }
         __syncthreads();
     } else centre_duals(1e-2, 1.0);
     const double mcnt = (double)(6 * T + 4 * (T - 1));
