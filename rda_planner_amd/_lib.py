@@ -17,7 +17,7 @@ def build(force=False):
            [os.path.join(os.path.dirname(_HERE), "include", "rda_hip.h")]
     stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", src_dir, "-s"])
+        subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))   # -B: `force` must not depend on mtimes
     return SO_PATH
 
 

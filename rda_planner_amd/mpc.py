@@ -94,7 +94,9 @@ class MPC:
             self.rda.upload_obstacles(rda_obs)
 
     def _sync_path(self, cur_ref_path):
-        key = (id(cur_ref_path), len(cur_ref_path))
+        # keyed on content, not identity: the reference re-reads `ref_path` every tick (mpc.py:139-144), so a list that was
+        # replaced or edited in place without update_ref_path must reach the device too (a few us for a few hundred waypoints)
+        key = np.hstack(cur_ref_path)[0:3].tobytes()
         if key != self._dev_path_key:
             self.rda.upload_path(cur_ref_path)
             self._dev_path_key = key

@@ -185,7 +185,19 @@ class RDA_solver:
             if vel.shape != (n, 2):
                 raise ValueError
         except (ValueError, TypeError, np.exceptions.AxisError):
-            vel = np.asarray([o.velocity for o in objs], float).reshape(n, -1)[:, 0:2]
+            # anything else the reference accepts: it only ever takes np.linalg.norm(velocity) and `velocity * t`
+            # (mpc.py:447-456,465-472), so a scalar (the lidar examples pass 0) moves both coordinates alike
+            vel = np.empty((n, 2))
+            for i, o in enumerate(objs):
+                v = np.asarray(o.velocity, float).ravel()
+                if v.size == 1:
+                    vel[i] = v[0]
+                elif v.size >= 2:
+                    vel[i] = v[0:2]
+                else:
+                    return None
+        if vel.shape != (n, 2) or not np.all(np.isfinite(vel)):
+            return None                                                # host conversion decides (and reports) instead
         circ = np.flatnonzero(kind == 1)
         if circ.size:
             if E < 3:

@@ -57,20 +57,25 @@ class ShardedRDA:
         nom_s, nom_u = f64(nom_s, (3, T + 1)), f64(nom_u, (2, T))
         n_obs, A, b, cone, per_t = s._stage(obstacle_list)
         api, h = self.api, self.h
-        assert api.upload_obstacles(h, n_obs, dptr(A), dptr(b), iptr(cone), per_t) == 0
-        assert api.admm_begin(h, dptr(nom_s), dptr(nom_u), dptr(ref), float(ref_speed)) == 0
+
+        def ok(rc, what):           # never `assert` a call with side effects: python -O would drop the call itself
+            if rc != 0:
+                raise RuntimeError(f"{api.prefix}_{what} failed with code {rc}")
+        ok(api.upload_obstacles(h, n_obs, dptr(A), dptr(b), iptr(cone), per_t), "upload_obstacles")
+        ok(api.admm_begin(h, dptr(nom_s), dptr(nom_u), dptr(ref), float(ref_speed)), "admm_begin")
         stopped = C.c_int(0)
         mine = np.zeros(self.chunk)
         for it in range(s.iter_num):
-            assert api.admm_su(h, it, C.byref(stopped)) == 0
+            ok(api.admm_su(h, it, C.byref(stopped)), "admm_su")
             if stopped.value:
                 break
-            assert api.admm_lammuz(h) == 0
-            assert api.shard_get_chunk(h, dptr(mine)) == 0
+            ok(api.admm_lammuz(h), "admm_lammuz")
+            ok(api.shard_get_chunk(h, dptr(mine)), "shard_get_chunk")
             everyone = np.ascontiguousarray(self.all_gather(mine), dtype=np.float64)
-            assert everyone.size == self.chunk * self.world
-            assert api.shard_set_chunks(h, dptr(everyone)) == 0
+            if everyone.size != self.chunk * self.world:
+                raise RuntimeError(f"all_gather returned {everyone.size} doubles, expected {self.chunk * self.world}")
+            ok(api.shard_set_chunks(h, dptr(everyone)), "shard_set_chunks")
         u, so, info = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
-        assert api.admm_finish(h, dptr(u), dptr(so), C.byref(info)) == 0
+        ok(api.admm_finish(h, dptr(u), dptr(so), C.byref(info)), "admm_finish")
         return u, {"opt_state_list": [so[:, i:i + 1].copy() for i in range(T + 1)], "ref_traj_list": ref_states,
                    "resi_dual": info.resi_dual, "resi_pri": info.resi_pri, "iters": info.iters, "status": info.su_status}

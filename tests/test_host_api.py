@@ -397,3 +397,24 @@ def test_flatten_scene_matches_object_by_object_packing():
     assert RDA_solver.flatten_scene(Host, poly) is None            # a pentagon does not fit: the caller converts on the host
     Host.max_edge_num = 2
     assert RDA_solver.flatten_scene(Host, circ) is None            # a circle needs three rows
+
+
+def test_flatten_scene_scalar_velocity_like_the_lidar_examples():
+    """the reference's lidar examples build `obs(None, None, vertices, 'Rpositive', 0)` (example/lidar_nav/lidar_path_track.py:55-58):
+    a SCALAR velocity, which the reference only ever feeds to np.linalg.norm and to `velocity * t` (mpc.py:447-472).  The flat
+    scene must carry two numbers per obstacle for it (the (n, 1) array made rda_upload_scene read out of bounds)."""
+    from collections import namedtuple
+
+    class Host:
+        max_edge_num = 4
+    obs = namedtuple("obs", "center radius vertex cone_type velocity")
+    V = np.array([[0.0, 1.0, 1.0, 0.0], [0.0, 0.0, 1.0, 1.0]])
+    scalar = [obs(None, None, V + k, "Rpositive", 0) for k in range(3)]
+    n, kind, nvert, geom, vel = RDA_solver.flatten_scene(Host, scalar)
+    assert n == 3 and vel.shape == (3, 2) and vel.flags["C_CONTIGUOUS"] and not vel.any()
+    mixed = [obs(None, None, V, "Rpositive", 0.5), obs(None, None, V, "Rpositive", np.array([[0.1], [0.2]])),
+             obs(None, None, V, "Rpositive", [0.3, -0.4]), obs(np.array([[1.0], [2.0]]), 0.5, None, "norm2", np.float64(0.0))]
+    n, kind, nvert, geom, vel = RDA_solver.flatten_scene(Host, mixed)
+    assert vel.shape == (4, 2) and np.array_equal(vel, [[0.5, 0.5], [0.1, 0.2], [0.3, -0.4], [0.0, 0.0]])
+    assert RDA_solver.flatten_scene(Host, [obs(None, None, V, "Rpositive", np.zeros(0))]) is None       # host conversion reports it
+    assert RDA_solver.flatten_scene(Host, [obs(None, None, V, "Rpositive", np.nan)]) is None
