@@ -9,17 +9,24 @@ One "step" = one RDA_solver.iterative_solve (reference rda_solver.py:573-610): u
 ADMM iterations with early stop.  Workload (north-star point of BASELINE.json / SURVEY.md 8d):
 Ackermann rectangle robot, T=20, N_obs=200 static polygons, E=4, synthetic seeded scene.
 
-Protocol: a closed-loop run (solver in the loop, kinematic robot model) records the inputs of
-W+K consecutive MPC steps; obstacles and that trace are then uploaded once, the solver state is
-reset, W steps are replayed untimed and EXACTLY K steps are enqueued back-to-back on the device
-(no host synchronisation inside or between steps) between two barriers + device synchronisation.
-`value` is therefore the device-resident rate; the host-synchronous closed-loop rate (H2D of the
-nominal, D2H of the control every step) is reported next to it as `closed_loop_steps_per_s`.
+Protocol: closed loop, W warm-up steps, then EXACTLY K steps, each one a C-ABI call that takes the
+robot state and returns the control with ONE host synchronisation at its end (`rda_step_tracked`: MPC.pre_process, the
+ADMM loop and the D2H of the control on the device; the host applies the control to the kinematic model and calls
+again).  The obstacle scene is resident in HBM when the timed region starts (static scene: staged once with
+`rda_upload_scene`).  `value` = K / wall time of those K steps (max over ranks); `median_ms_per_step` is the median of
+the K per-step wall times.  Reported beside it, never as `value`:
+  * `pcie_inclusive`        - the same loop with the raw scene (vertices, velocities) handed over from host memory on
+                              every tick (`rda_tracked_begin` + `rda_upload_scene_async` + `rda_tracked_finish`);
+  * `device_resident_replay`- the recorded step inputs replayed back-to-back with no per-step synchronisation
+                              (throughput of the device pipeline, what round 1 reported as the headline);
+  * the same closed loop through the Python `MPC.control` API with host / device obstacle staging.
+A Python closed loop first records the W+K step inputs; every other leg must reproduce its controls.
 
 N > 1: one process per GPU, independent ego replicas (BASELINE config "batched multi-ego":
 scenario batch sharded, no data-path collective) - weak scaling, value = sum over ranks.
 """
 import os
+os.environ.setdefault("OMP_PROC_BIND", "close")   # cpu_baseline leg: keep the oracle's OpenMP threads on neighbouring cores (read when libgomp loads)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # the multi-ego leg runs one HIP stream per ego; the default 4 hardware queues serialise them
 import argparse
 import ctypes as C
@@ -181,21 +188,110 @@ def main():
         # ... and with MPC.pre_process on the device as well (rda_step_tracked): state in, control out
         cl_trk = closed_loop(True)
 
-    # ---- device-resident replay -------------------------------------------------------------------
     from rda_planner_amd.rda_solver import RDA_solver
-    solver = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1,
-                        time_print=False, ro1=kw["ro1"])
-    make_sharded(solver)
+    from rda_planner_amd import scenarios as sc
+
+    def barrier_all():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+        tt = torch.tensor([x], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def new_solver():
+        sv = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+        make_sharded(sv)
+        return sv
+
+    # ---- HEADLINE: closed loop through the C-ABI, one host synchronisation per MPC step -------------------------------
+    def cabi_closed_loop(per_tick_scene):
+        """state in / control out per step; scene resident in HBM (per_tick_scene False) or handed over from host memory on every
+        tick (True, BASELINE.md 2.4 'including H2D of obstacles').  Returns (elapsed of the K timed steps, per-step times,
+        max |u - recorded Python closed loop|, iterations per step)."""
+        sv = new_solver()
+        hh = sv._be.handle
+        scene = sv.flatten_scene(list(obstacles))
+        n_sc, kind, nvert, geom, vel = scene
+        kind, nvert = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(nvert, np.int32)
+        geom, vel = np.ascontiguousarray(geom, float), np.ascontiguousarray(vel, float)
+        geom0 = geom.copy()
+        P = np.ascontiguousarray(np.hstack(path)[0:3, :].T, dtype=float)
+        assert api.upload_path(hh, int(P.shape[0]), dptr(P)) == 0
+        state = np.ascontiguousarray(path[0], float).ravel()[0:3].copy()
+        out_u, out_s, inf = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+        mi, eh = np.zeros(1, np.int32), np.zeros(1)
+        nom_u0 = np.zeros((2, T))
+        order = int(bool(kw_rec["obstacle_order"]))
+        if not per_tick_scene:
+            assert api.upload_scene(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(state), order, None) == 0
+        cur, du, its, times = 0, 0.0, [], []
+        L, wb = car_t.wheelbase, car_t.dynamics
+        t_start = 0.0
+        for k in range(W + K):
+            if k == W:
+                api.lib.rda_sync(hh)
+                barrier_all()
+                t_start = time.perf_counter()
+            t0 = time.perf_counter()
+            nu = dptr(nom_u0) if k == 0 else None          # afterwards the previous controls are resident (MPC.cur_vel_array)
+            if per_tick_scene:
+                if args.moving:                             # obstacles advance every tick like in the dynamic_obs example
+                    geom[:, :, :] = geom0 + (vel * (0.1 * k))[:, None, :] * (np.arange(geom.shape[1])[None, :, None] < nvert[:, None, None])
+                rc = api.tracked_begin(hh, dptr(state), 4.0, int(cur), 0.1, 10, nu)
+                rc |= api.upload_scene_async(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(state), order)
+                rc |= api.tracked_finish(hh, dptr(out_u), dptr(out_s), C.byref(inf), None, None, iptr(mi), dptr(eh))
+            else:
+                rc = api.step_tracked(hh, dptr(state), 4.0, int(cur), 0.1, 10, nu, dptr(out_u), dptr(out_s), C.byref(inf), None, None,
+                                      iptr(mi), dptr(eh))
+            assert rc >= 0, rc
+            cur = int(mi[0])
+            assert cur < len(path) - 1, "workload invalid: the robot reached the goal inside the timed region"
+            # the host side of the loop: apply the first control to the kinematic model (what ir-sim's env.step does)
+            v, w, phi = float(out_u[0, 0]), float(out_u[1, 0]), float(state[2])
+            if wb == "acker":
+                state += 0.1 * np.array([v * np.cos(phi), v * np.sin(phi), v * np.tan(w) / L])
+            elif wb == "diff":
+                state += 0.1 * np.array([v * np.cos(phi), v * np.sin(phi), w])
+            else:
+                state += 0.1 * np.array([v * np.cos(w), v * np.sin(w), 0.0])
+            if k >= W:
+                times.append(time.perf_counter() - t0)
+                its.append(inf.iters)
+            if not args.moving:
+                du = max(du, float(np.abs(out_u[:, 0] - trace["u"][k].ravel()).max()))
+        api.lib.rda_sync(hh)
+        barrier_all()
+        el = max_over_ranks(time.perf_counter() - t_start)
+        return el, np.array(times), du, its
+
+    head = None
+    if not shard:
+        el_h, times_h, du_h, its_h = cabi_closed_loop(per_tick_scene=bool(args.moving))
+        head = {"elapsed": el_h, "median_ms": float(np.median(times_h) * 1e3), "du": du_h, "iters": its_h}
+        pcie = None
+        if rank == 0 and not args.moving:
+            el_p, times_p, du_p, _ = cabi_closed_loop(per_tick_scene=True) if world == 1 else (None, None, None, None)
+            if el_p is not None:
+                pcie = {"steps_per_s": round(K / el_p, 2), "median_ms_per_step": round(float(np.median(times_p) * 1e3), 5),
+                        "max_du_vs_python_closed_loop": du_p,
+                        "what": "raw scene (vertices, velocities) handed over from host memory every tick: rda_tracked_begin + rda_upload_scene_async + rda_tracked_finish"}
+
+    # ---- device-resident replay: the recorded step inputs back-to-back, no per-step synchronisation ---------------------
+    solver = new_solver()
     h = solver._be.handle
     assert api.lib.rda_upload_obstacles(h, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"]) == 0
     assert api.lib.rda_upload_trace(h, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"])) == 0
 
     def barrier():
         api.lib.rda_sync(h)
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        barrier_all()
 
     for k in range(W):
         api.lib.rda_enqueue_step(h, k)
@@ -205,46 +301,32 @@ def main():
     for k in range(W, W + K):
         api.lib.rda_enqueue_step(h, k)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # per-kernel GPU time from the events recorded inside the timed region
+    # per-launch GPU times from the events recorded inside that region, in launch order
     kt = {}
     for which, name in ((0, "k_lammuz"), (1, "k_su")):
-        ms = C.c_double(0)
+        cap = K * kw["iter_num"] + 8
+        buf = np.zeros(cap)
         n = C.c_int(0)
-        api.lib.rda_timing_read(h, which, C.cast(C.byref(ms), C.POINTER(C.c_double)), C.cast(C.byref(n), C.POINTER(C.c_int)))
-        kt[name] = (ms.value, n.value)
+        api.lib.rda_timing_launches(h, which, dptr(buf), cap, C.cast(C.byref(n), C.POINTER(C.c_int)))
+        kt[name] = buf[:min(n.value, cap)].copy()
     api.lib.rda_timing_reset(h, 0)
-    # un-instrumented pass for the headline number (events perturb the stream slightly)
-    solver2 = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
-    make_sharded(solver2)
+    # un-instrumented pass (events perturb the stream slightly)
+    solver2 = new_solver()
     h2 = solver2._be.handle
     api.lib.rda_upload_obstacles(h2, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
     api.lib.rda_upload_trace(h2, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"]))
     for k in range(W):
         api.lib.rda_enqueue_step(h2, k)
     api.lib.rda_sync(h2)
-    if dist is not None:
-        dist.barrier()
+    barrier_all()
     t0 = time.perf_counter()
     for k in range(W, W + K):
         api.lib.rda_enqueue_step(h2, k)
     api.lib.rda_sync(h2)
-    if dist is not None:
-        import torch
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed2 = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed2], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed2 = float(tt.item())
+    barrier_all()
+    elapsed2 = max_over_ranks(time.perf_counter() - t0)
 
     # replay must reproduce the recorded closed loop (same inputs, same initial state)
     u_last = np.zeros((2, T))
@@ -327,73 +409,107 @@ def main():
 
     E, R = kw["max_edge_num"], 4
     unit_bytes = 8 * (5 * E + 2 * R + 8)                 # 288 B per (obstacle, stage) at E=R=4
-    lm_ms, lm_n = kt["k_lammuz"]
-    su_ms, su_n = kt["k_su"]
-    lm_avg = lm_ms / max(lm_n, 1) * 1e-3
-    su_avg = su_ms / max(su_n, 1) * 1e-3
     peak = 8000.0
+    n_exec = int(np.sum(iters))                          # executed ADMM iterations of the timed replay = executed launches per kernel
 
-    def roof(name, avg_s, bytes_per_launch, launches, total_ms):
+    def roof(name, ms, bytes_per_launch):
+        """per EXECUTED launch: launches queued behind the device early-stop flag return at once (no bytes, ~3 us) and are
+        separated from the executed ones by their count (sum of rda_info.iters) - the n_exec longest launches are the executed ones"""
+        ms = np.sort(np.asarray(ms, float))
+        n_noop = max(ms.size - n_exec, 0)
+        ex, noop = ms[n_noop:], ms[:n_noop]
+        avg_s = float(ex.mean()) * 1e-3 if ex.size else 0.0
         ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 3), "peak": peak, "unit": "GB/s",
                 "frac": round(ach / peak, 6), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
-                "launches": launches, "total_ms": round(total_ms, 3), "algorithmic_bytes_per_launch": bytes_per_launch}
+                "launches": int(ex.size), "total_ms": round(float(ex.sum()), 3), "algorithmic_bytes_per_launch": bytes_per_launch,
+                "skipped_launches": int(noop.size), "skipped_avg_us": round(float(noop.mean()) * 1e3, 2) if noop.size else None,
+                "avg_us_over_all_launches": round(float(ms.mean()) * 1e3, 2) if ms.size else None}
     # the LamMuZ kernel that was actually launched (rda_hip.hip launch_lammuz): packed rows when E+R+1 <= 16, the two-workgroup
     # build above 256 workgroups; RDA_LMZ_ROWS=0 selects the one-sub-problem-per-wave kernel
     lm_kernel = "k_lammuz"
+    n_loc = N // world if shard else N
     if E + R + 1 <= 16 and os.environ.get("RDA_LMZ_ROWS", "1") != "0":
-        n_loc = N // world if shard else N
         lm_kernel = "k_lammuz_rows_dense" if (n_loc * T + 15) // 16 > int(os.environ.get("RDA_LMZ_DENSE_FROM", "256")) else "k_lammuz_rows"
-    r_lm = roof(lm_kernel, lm_avg, unit_bytes * N * T, lm_n, lm_ms)
-    r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", su_avg, 48 * N * T + 8 * (8 * (T + 1) + 5 * T), su_n, su_ms)
+    r_lm = roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T)
+    r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", kt["k_su"], 48 * N * T + 8 * (8 * (T + 1) + 5 * T))
+    # latency roof of the su kernel: ONE workgroup (4 waves) on one CU walks a dependent chain; what bounds it is the length of
+    # that chain, not bytes - stated next to the HBM fraction so the fraction is not read as a bandwidth problem
+    r_su["cus_occupied"], r_lm["cus_occupied"] = 1, min(256, (n_loc * T + 15) // 16 if lm_kernel != "k_lammuz" else (n_loc * T + 3) // 4)
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file):
         try:
             tj = json.load(open(tr_file))
-            if tj.get("workload") == {"n_obs": N, "horizon": T}:       # PMC bytes are per launch of THIS workload only
+            if tj.get("workload") == {"n_obs": N, "horizon": T}:       # PMC bytes are per executed launch of THIS workload only
                 r_lm["traffic"] = tj.get("k_lammuz")
                 r_su["traffic"] = tj.get("k_su")
+                r_su["traffic_source"] = r_lm["traffic_source"] = tj.get("source")
         except Exception:
             pass
-    dominant, secondary = (r_su, r_lm) if su_ms >= lm_ms else (r_lm, r_su)
+    dominant, secondary = (r_su, r_lm) if r_su["total_ms"] >= r_lm["total_ms"] else (r_lm, r_su)
 
     kind_word = "moving" if args.moving else "static"
+    env_switches = {k: v for k, v in os.environ.items() if k.startswith("RDA_")}
+    replay = {"steps_per_s": round(K * (1 if shard else world) / elapsed2, 3), "ms_per_step": round(elapsed2 / K * 1e3, 5),
+              "instrumented_ms_per_step": round(elapsed / K * 1e3, 5), "max_du_vs_python_closed_loop": replay_err,
+              "what": "recorded step inputs replayed back-to-back on the device, no per-step host synchronisation"}
+    if head is not None:
+        value, ms_step = K * world / head["elapsed"], head["elapsed"] / K * 1e3
+        protocol = ("closed loop through the C-ABI: per step rda_step_tracked(state) -> control, one host sync per step, host applies the "
+                    "control to the kinematic model; scene resident in HBM" if not args.moving else
+                    "closed loop through the C-ABI, obstacles advance every tick: rda_tracked_begin + rda_upload_scene_async + rda_tracked_finish per step")
+    else:                   # obstacle shards: the RCCL path is driven by the replay (every rank enqueues the same steps)
+        value, ms_step, protocol = replay["steps_per_s"], replay["ms_per_step"], replay["what"]
     out = {
-        "metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(K * (1 if shard else world) / elapsed2, 3), "unit": "steps/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed2 / K * 1e3, 5),
+        "metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(value, 3), "unit": "steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_step, 5),
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} {kind_word} seeded polygons, E={E}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
-                   "parallelism": "single GPU" if world == 1 else (f"one ego, obstacles sharded {world}-way, RCCL all-gather per ADMM iteration" if shard else f"{world} independent ego replicas (no collective)")},
-        "mean_admm_iters": round(mean_iters, 3), "replay_vs_closed_loop_max_du": replay_err,
-        "closed_loop_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
-        "closed_loop_device_obstacles": cl_dev,
-        "closed_loop_device_resident": cl_trk,
+                   "parallelism": "single GPU" if world == 1 else (f"one ego, obstacles sharded {world}-way, RCCL all-gather per ADMM iteration" if shard else f"{world} independent ego replicas (no collective)"),
+                   "protocol": protocol, "env_switches": env_switches},
+        "median_ms_per_step": round(head["median_ms"], 5) if head else None,
+        "max_du_vs_python_closed_loop": head["du"] if head and not args.moving else None,
+        "mean_admm_iters": round(float(np.mean(head["iters"])) if head else mean_iters, 3),
+        "pcie_inclusive": pcie if head else None,
+        "device_resident_replay": replay,
+        "python_api_closed_loop": {"host_obstacle_staging_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
+                                   "device_obstacles": cl_dev, "device_obstacles_and_tracking": cl_trk},
         "multi_ego_one_gpu": multi,
         "multi_ego_fleet": fleet,
-        "instrumented_ms_per_step": round(elapsed / K * 1e3, 5),
         "roofline": dominant, "roofline_secondary": secondary,
     }
 
     if not args.no_cpu_baseline and world == 1:
         from oracle.oracle_backend import oracle_backend, api as orc_api
         ncore = os.cpu_count() or 1
-        orc_api().lib.orc_set_threads(ncore)
         cpu = RDA_solver(T, car_t, E, N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"], _backend=oracle_backend)
         info_c = Info()
         ou = np.zeros((2, T))
         os_ = np.zeros((3, T + 1))
-        n_cpu, budget, t_cpu = 0, 15.0, 0.0
-        err = 0.0
-        while n_cpu < W + K and (t_cpu < budget or n_cpu < 3):
-            k = n_cpu
-            t1 = time.perf_counter()
-            cpu._be.api.step(cpu._be.handle, dptr(trace["nom_s"][k]), dptr(trace["nom_u"][k]), dptr(trace["ref"][k]), float(trace["speed"][k]),
-                             staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"], dptr(ou), dptr(os_), C.byref(info_c))
-            t_cpu += time.perf_counter() - t1
-            err = max(err, float(np.abs(ou - trace["u_solver"][k]).max()))
-            n_cpu += 1
-        out["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 3), "unit": "steps/s", "cores": ncore, "kind": "port",
-                               "sample": f"first {n_cpu} steps of the same recorded trace (oracle/rda_oracle.c, OpenMP over obstacles; su-problem serial)",
+        sweep, err, n_total = {}, 0.0, 0
+        k = 0
+        for nthr in sorted({t for t in (1, 8, 16, 32, 64, ncore) if t <= ncore}):
+            orc_api().lib.orc_set_threads(nthr)
+            n_cpu, t_cpu = 0, 0.0
+            while t_cpu < 2.5 or n_cpu < 3:                  # consecutive steps of ONE closed loop (the duals stay warm) ...
+                kk = k % (W + K)                             # ... wrapping around the recorded trace when it is used up
+                t1 = time.perf_counter()
+                cpu._be.api.step(cpu._be.handle, dptr(trace["nom_s"][kk]), dptr(trace["nom_u"][kk]), dptr(trace["ref"][kk]), float(trace["speed"][kk]),
+                                 staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"], dptr(ou), dptr(os_), C.byref(info_c))
+                t_cpu += time.perf_counter() - t1
+                if k < W + K:                                # first pass only: the same state history as the GPU run
+                    err = max(err, float(np.abs(ou - trace["u_solver"][kk]).max()))
+                n_cpu += 1
+                k += 1
+            sweep[nthr] = round(n_cpu / t_cpu, 3)
+            n_total += n_cpu
+        best = max(sweep, key=sweep.get)
+        out["cpu_baseline"] = {"value": sweep[best], "unit": "steps/s", "cores": best, "kind": "port",
+                               "single_thread": sweep.get(1), "thread_sweep": sweep, "host_cores": ncore,
+                               "sample": f"{n_total} steps of the same recorded closed loop (consecutive, wrapping around), ~2.5 s per thread count (oracle/rda_oracle.c: OpenMP over "
+                                         "obstacles, OMP_PROC_BIND=close, su-problem serial); best thread count reported",
+                               "note": "a restatement of the ADMM in C, NOT the reference's CVXPY+ECOS+pathos path (not installable here): the "
+                                       "north-star '>=100x the reference CPU path' cannot be measured against this number",
                                "max_du_vs_gpu": err}
     print(json.dumps(out))
     if dist is not None:

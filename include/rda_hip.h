@@ -120,6 +120,10 @@ int  rda_fetch_result(rda_handle *h, int k, double *out_u, double *out_s, rda_in
  * steps enqueued since the last rda_timing_reset, and the number of launches */
 int  rda_timing_reset(rda_handle *h, int enable);
 int  rda_timing_read(rda_handle *h, int which, double *total_ms, int *launches);
+/* the same per launch, in launch order: ms_out[i] for i < min(cap, *launches).  The early stop of rda_solver.py:594 is a
+ * device flag, so launches queued behind it return at once; a caller that knows the executed ADMM iterations (rda_info.iters)
+ * separates the two populations with this (bench.py: roofline per EXECUTED launch) */
+int  rda_timing_launches(rda_handle *h, int which, double *ms_out, int cap, int *launches);
 
 /* ---- caller-side nominal roll-out + reference sampling on the device ------------------------------
  * What MPC.pre_process (mpc.py:251-291) with closest_point / inter_point / range_cir_seg / wraptopi and the three

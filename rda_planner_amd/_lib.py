@@ -48,12 +48,13 @@ def hip_api():
         lib.rda_fetch_result.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, C.c_void_p]
         lib.rda_timing_reset.argtypes = [C.c_void_p, C.c_int]
         lib.rda_timing_read.argtypes = [C.c_void_p, C.c_int, c_double_p, c_int_p]
+        lib.rda_timing_launches.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, c_int_p]
         lib.rda_lammuz_batch.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p,
                                          c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double,
                                          C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
         lib.rda_su_solve.argtypes = [C.POINTER(Cfg)] + [c_double_p] * 3 + [C.c_double] + [c_double_p] * 7 + [c_int_p]
         for name in ("upload_trace", "enqueue_step", "sync", "fetch_result", "timing_reset",
-                     "timing_read", "lammuz_batch", "su_solve"):
+                     "timing_read", "timing_launches", "lammuz_batch", "su_solve"):
             getattr(lib, "rda_" + name).restype = C.c_int
         if lib.rda_device_count() < 1:
             raise RuntimeError("librda_hip.so loaded but no HIP device is visible; rda_planner_amd has no CPU fallback")

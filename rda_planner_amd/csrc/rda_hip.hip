@@ -1081,6 +1081,20 @@ extern "C" int rda_timing_read(rda_handle *H, int which, double *total_ms, int *
     return RDA_OK;
 }
 
+extern "C" int rda_timing_launches(rda_handle *H, int which, double *ms_out, int cap, int *launches)
+{
+    if (!H || which < 0 || which > 1 || (cap > 0 && !ms_out)) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    int n = 0;
+    for (size_t i = 0; i + 1 < H->ev_used[which]; i += 2, ++n) {
+        if (n >= cap) continue;
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev[which][i], H->ev[which][i + 1]));
+        ms_out[n] = ms;
+    }
+    if (launches) *launches = n;
+    return RDA_OK;
+}
+
 extern "C" int rda_get_state(rda_handle *H, double *lam, double *mu, double *z, double *xi, double *zeta,
                              double *dis, double *a_lam, double *b_lam)
 {
