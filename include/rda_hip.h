@@ -73,7 +73,10 @@ int  rda_set_device(int dev);
 /* Tie-break T1 for the (degenerate) slack regime of the LamMuZ problem, where every (lam, mu) with H = 0 and m >= 0 is
  * optimal: 1 (default) = duals of the unit normal in the middle of the arc of separating directions, 0 = max-clearance
  * duals.  Process-wide; read by rda_create and rda_lammuz_batch. */
-void rda_set_tie_centre(int on);     /* device used by handles created afterwards (one process per GPU) */
+void rda_set_tie_centre(int on);
+/* Interior-point stop of the su-problem: |r_dual|_inf <= rd (1 + |grad|_inf), |r_prim|_inf <= rp, mean complementarity
+ * <= mu (1 + |grad|_inf).  Process-wide default for handles created afterwards and for rda_su_solve. */
+void rda_set_su_tol(double rd, double rp, double mu);     /* device used by handles created afterwards (one process per GPU) */
 
 /* One MPC step, host buffers: nom_s 3x(T+1), nom_u 2xT, ref_s 3x(T+1) row-major;
  * obstacles A [n_obs][per_t? T+1 : 1][E][2], b [n_obs][per_t? T+1 : 1][E], cone [n_obs] (0 Rpositive, 1 norm2);

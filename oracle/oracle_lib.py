@@ -8,7 +8,7 @@ _SO = os.path.join(_HERE, "librda_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("rda_oracle.c", "rda_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("rda_oracle.c", "lmz_ipm.c", "rda_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO

@@ -34,6 +34,10 @@
 static int g_threads = 1;
 static double g_su_warm_wfl = 1e-3, g_su_warm_mu0 = 1e-3; static int g_su_warm_cap = 30, g_su_warm_first = 1;   /* su warm start (orc_set_su_warm(0,0,0): cold) */
 void orc_set_su_warm(double wfl, double mu0, int cap) { g_su_warm_wfl = wfl; g_su_warm_mu0 = mu0; g_su_warm_cap = cap; }
+static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};   /* interior-point stop of the su-problem: rd, rp, mu */
+void orc_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
+static int g_lmz_mode = 0;   /* 0: support enumeration + tie-breaks T1-T3, 1: interior point (oracle/lmz_ipm.c) */
+void orc_set_lmz_mode(int mode) { g_lmz_mode = mode ? 1 : 0; }
 static int g_centre = 1;     /* tie-break T1: central separating normal in the slack regime (orc_set_centre(0): max clearance) */
 void orc_set_centre(int on) { g_centre = on; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
@@ -48,7 +52,7 @@ struct orc_handle {
     int obstacle_num;
     double *resp;                  /* [N*T][2] residual partials of the last LamMuZ pass */
     double *ref, ref_speed;        /* step inputs */
-    int stop, iters, su_status, ipm_total; double resi_dual, resi_pri;
+    int stop, iters, su_status, ipm_total, lmz_fail; double resi_dual, resi_pri;
     double *su_lam_keep;          /* inequality multipliers of the last converged su-solve (10T - 4 rows) */
     int P, rank, Nloc, have_gath; size_t chunk; double *gath;      /* obstacle sharding */
 };
@@ -727,10 +731,10 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
 #ifdef ORC_DEBUG
         fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
 #endif
-        if (rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) { status = 0; break; }
+        if (rdn <= g_su_tol[0] * sc && rpn <= g_su_tol[1] && mu <= g_su_tol[2] * sc) { status = 0; break; }
         /* past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
          * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
-        if (rdn <= 1e-7 * sc && rpn <= 1e-10 && mu <= 1e-12 * sc) { status = 0; break; }
+        if (rdn <= 100 * g_su_tol[0] * sc && rpn <= g_su_tol[1] && mu <= 0.1 * g_su_tol[2] * sc) { status = 0; break; }
         /* K = H + C' diag(lm/w) C */
         memcpy(K, Hm, sizeof(double) * n * n);
         for (int i = 0; i < mc; ++i) {
@@ -799,7 +803,8 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
 /* ------------------------------------------------------------------------------------------ */
 int orc_create(const orc_cfg *cfg, const double *G, const double *h, orc_handle **out)
 {
-    if (cfg->E > EMAX || cfg->R > RMAX || cfg->N < 1 || cfg->T < 1 || cfg->robot_norm2) return -1;
+    if (cfg->E > EMAX || cfg->R > RMAX || cfg->N < 1 || cfg->T < 1) return -1;
+    if (cfg->robot_norm2 && !g_lmz_mode) return -2;      /* the enumeration has no norm2 robot candidates: interior-point mode only */
     orc_handle *H = calloc(1, sizeof(*H));
     H->c = *cfg;
     int T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
@@ -924,7 +929,7 @@ int orc_admm_begin(orc_handle *H, const double *nom_s, const double *nom_u, cons
     int T = H->c.T;
     memcpy(H->s, nom_s, sizeof(double) * 3 * (T + 1)); memcpy(H->u, nom_u, sizeof(double) * 2 * T);
     memcpy(H->ref, ref_s, sizeof(double) * 3 * (T + 1)); H->ref_speed = ref_speed;
-    H->stop = 0; H->iters = 0; H->su_status = 0; H->ipm_total = 0; H->resi_dual = 0; H->resi_pri = 0;
+    H->stop = 0; H->iters = 0; H->su_status = 0; H->ipm_total = 0; H->lmz_fail = 0; H->resi_dual = 0; H->resi_pri = 0;
     return 0;
 }
 static void admm_residuals(orc_handle *H)
@@ -1000,6 +1005,14 @@ int orc_admm_lammuz(orc_handle *H)
             const double *At = &H->A[o * E * 2], *bt = &H->b[o * E];
             double p[2] = { H->s[t + 1], H->s[(T + 1) + t + 1] }, phi = H->s[2 * (T + 1) + t];
             double lam[EMAX], mu[RMAX], z, res = 0;
+            int fail = 0;
+            if (g_lmz_mode) {
+                int st = orc_lammuz_ipm_one(E, R, At, bt, H->cone[n], c->robot_norm2, p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
+                                            H->dis[t], c->ro2, c->accelerated, lam, mu, &z, NULL, NULL);
+                /* the reference accepts OPTIMAL only (rda_solver.py:781,816; Q8): anything else keeps the previous duals and the
+                 * residual of the obstacle becomes inf, which blocks the early stop (:791-793) */
+                if (st != 0) { fail = 1; memcpy(lam, &H->lam[o * E], sizeof(double) * E); memcpy(mu, &H->mu[o * R], sizeof(double) * R); z = H->z[n * T + t]; }
+            } else
             orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
                            H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, NULL);
             double cs = cos(phi), sn = sin(phi);
@@ -1018,12 +1031,19 @@ int orc_admm_lammuz(orc_handle *H)
             H->xi[o * 2] += hx; H->xi[o * 2 + 1] += hy;                               /* :683 */
             im += ax * p[0] + ay * p[1] - bl;                                         /* :659 */
             H->zeta[n * T + t] += im - H->dis[t] - z;                                 /* :666 */
-            H->resp[2 * (n * T + t)] = res; H->resp[2 * (n * T + t) + 1] = hx * hx + hy * hy;
+            H->resp[2 * (n * T + t)] = fail ? INFINITY : res; H->resp[2 * (n * T + t) + 1] = hx * hx + hy * hy;
+            if (fail) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                H->lmz_fail++;
+            }
         }
     }
     H->have_gath = 0;       /* the gathered copy is stale until the next exchange */
     return 0;
 }
+int orc_lmz_failures(orc_handle *H) { return H ? H->lmz_fail : -1; }
 int orc_admm_finish(orc_handle *H, double *out_u, double *out_s, orc_info *info)
 {
     int T = H->c.T;

@@ -48,6 +48,14 @@ void orc_destroy(orc_handle *h);
 int  orc_set_adjust(orc_handle *h, double slack_gain, double max_sd, double min_sd, double ro1, double ro2);
 int  orc_reset(orc_handle *h);      /* rda_solver.py:1060-1068 */
 void orc_set_threads(int n);
+void orc_set_lmz_mode(int mode);   /* LamMuZ sub-problems of orc_step: 0 support enumeration (tie-breaks T1-T3), 1 interior point (lmz_ipm.c) */
+int  orc_lmz_failures(orc_handle *h);   /* sub-problems of the last step whose solve was not OPTIMAL (previous duals kept, residual inf) */
+void orc_set_lmz_ipm_tol(double tol);
+void orc_set_lmz_ipm_mu(double mu);
+int  orc_lammuz_ipm_one(int E, int R, const double *A, const double *b, int cone_norm2, int robot_norm2,
+                        const double *p, double phi, const double *G, const double *h,
+                        const double *xi, double zeta, double dbar, double ro2, int accelerated,
+                        double *lam, double *mu, double *z, double *cost_m_H /*4*/, int *iters);
 void orc_set_centre(int on);   /* tie-break T1: 1 (default) central separating normal in the slack regime, 0 max clearance */
 
 /* One MPC step == RDA_solver.iterative_solve (rda_solver.py:573-610).
@@ -92,6 +100,8 @@ int  orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_nor
 /* interior-point start of the su-problems of ADMM iterations >= 1 inside orc_step / orc_admm_su (defaults 1e-3, 1e-3, 30; 0,0,0 = cold);
  * orc_su_solve itself always starts cold */
 void orc_set_su_warm(double wfl, double mu0, int cap);
+/* interior-point stop of the su-problem: |r_dual| <= rd (1+|g|), |r_prim| <= rp, mean complementarity <= mu (1+|g|) */
+void orc_set_su_tol(double rd, double rp, double mu);
 int  orc_su_solve(const orc_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
                   double ref_speed, const double *a, const double *cc, const double *g,
                   const double *d0, double *s, double *u, double *d, int *ipm_iters);

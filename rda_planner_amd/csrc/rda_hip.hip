@@ -48,6 +48,7 @@ struct Dev {
     double *su_lam_keep;               // inequality multipliers of the last converged su-solve [10*T] (interior-point warm start)
     int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
+    double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
     double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
     int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
     int obstacle_num;        // 0 or N
@@ -110,7 +111,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
     a.c.ab0 = d.c.acce_bound[0]; a.c.ab1 = d.c.acce_bound[1]; a.c.ws = d.c.ws; a.c.wu = d.c.wu;
     a.c.slack_gain = d.c.slack_gain; a.c.max_sd = d.c.max_sd; a.c.min_sd = d.c.min_sd; a.c.ro1 = d.c.ro1; a.c.ro2 = d.c.ro2;
-    a.c.eps_u = d.c.eps_u;
+    a.c.eps_u = d.c.eps_u; a.c.tol_rd = d.su_tol[0]; a.c.tol_rp = d.su_tol[1]; a.c.tol_mu = d.su_tol[2];
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
     a.ref = ref; a.ref_speed = ref_speed;
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
@@ -544,6 +545,9 @@ template <typename Tp> static int dalloc(Tp **p, size_t n)
 // the empty support (same rule and order as the lam lists built per wave in lmz::solve_wave)
 static int g_tie_centre = 1;
 extern "C" void rda_set_tie_centre(int on) { g_tie_centre = on ? 1 : 0; }
+// interior-point stop of the su-problem (process-wide default, read by rda_create and rda_su_solve)
+static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};
+extern "C" void rda_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
 
 static int robot_candidates(int R, const double *G, const double *h, unsigned char *out, double (*rv)[2], int *nrv)
 {
@@ -583,6 +587,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     H->d.centre = g_tie_centre;
     H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
     { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &H->d.su_warm_wfl, &H->d.su_warm_mu0, &H->d.su_warm_cap); }
+    for (int i = 0; i < 3; ++i) H->d.su_tol[i] = g_su_tol[i];
+    { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &H->d.su_tol[0], &H->d.su_tol[1], &H->d.su_tol[2]); }
     { const char *e = getenv("RDA_TIE_CENTRE"); if (e) H->d.centre = atoi(e) ? 1 : 0; }      // experiments only
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
@@ -1612,7 +1618,8 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     ar.c.dt = cfg->dt; ar.c.L = cfg->L; ar.c.umax0 = cfg->max_speed[0]; ar.c.umax1 = cfg->max_speed[1];
     ar.c.ab0 = cfg->acce_bound[0]; ar.c.ab1 = cfg->acce_bound[1]; ar.c.ws = cfg->ws; ar.c.wu = cfg->wu;
     ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
-    ar.c.eps_u = cfg->eps_u;
+    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = g_su_tol[0]; ar.c.tol_rp = g_su_tol[1]; ar.c.tol_mu = g_su_tol[2];
+    { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &ar.c.tol_rd, &ar.c.tol_rp, &ar.c.tol_mu); }
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.blam = dsoa + 2 * T * N; ar.ee = dsoa + 3 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;

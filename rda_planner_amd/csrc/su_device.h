@@ -39,6 +39,8 @@ constexpr int NC = 10;           // inequality rows per stage
 struct Cfg {
     int T, N, dynamics, accelerated;
     double dt, L, umax0, umax1, ab0, ab1, ws, wu, slack_gain, max_sd, min_sd, ro1, ro2, eps_u;
+    // interior-point stop: |r_dual|_inf <= tol_rd (1 + |g|_inf), |r_prim|_inf <= tol_rp, mean complementarity <= tol_mu (1 + |g|_inf)
+    double tol_rd = 1e-9, tol_rp = 1e-10, tol_mu = 1e-11;
 };
 
 struct Args {
@@ -766,7 +768,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
             {
                 const double gn_ = *(volatile double *)&L.red[9], rpn_ = *(volatile double *)&L.red[10];
                 const double mu_ = *(volatile double *)&L.red[11] / mcnt, sc_ = 1 + gn_;
-                if ((rd <= 1e-9 * sc_ && rpn_ <= 1e-10 && mu_ <= 1e-11 * sc_) || (rd <= 1e-7 * sc_ && rpn_ <= 1e-10 && mu_ <= 1e-12 * sc_))
+                if ((rd <= c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= c.tol_mu * sc_) || (rd <= 100 * c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= 0.1 * c.tol_mu * sc_))
                     if (lane == 0) __atomic_store_n(flag_stop, seq, __ATOMIC_RELAXED);
             }
         } else if (wave == 2) {
@@ -815,7 +817,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         double sc = 1 + gn;
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
-        if ((rdn <= 1e-9 * sc && rpn <= 1e-10 && mu <= 1e-11 * sc) || (rdn <= 1e-7 * sc && rpn <= 1e-10 && mu <= 1e-12 * sc)) {
+        if ((rdn <= c.tol_rd * sc && rpn <= c.tol_rp && mu <= c.tol_mu * sc) || (rdn <= 100 * c.tol_rd * sc && rpn <= c.tol_rp && mu <= 0.1 * c.tol_mu * sc)) {
             if (screened) {        // the positions must have stayed within DELTA of the screening reference
                 double dv = 0;
                 if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
