@@ -57,6 +57,8 @@ typedef struct rda_info {
     int32_t iters;                /* ADMM iterations executed (early stop, :594) */
     int32_t su_status;            /* bit i: su-solve of iteration i not converged -> nominal kept (:699) */
     int32_t su_ipm_iters;         /* interior-point iterations, summed */
+    int32_t lmz_fail;             /* (obstacle, stage) sub-problems that kept their previous duals - non-finite data or result; their
+                                     residual is inf, which blocks the early stop like a non-OPTIMAL solve does (:781-793, :816-826) */
 } rda_info;
 
 typedef struct rda_handle rda_handle;

@@ -1012,9 +1012,24 @@ int orc_admm_lammuz(orc_handle *H)
                 /* the reference accepts OPTIMAL only (rda_solver.py:781,816; Q8): anything else keeps the previous duals and the
                  * residual of the obstacle becomes inf, which blocks the early stop (:791-793) */
                 if (st != 0) { fail = 1; memcpy(lam, &H->lam[o * E], sizeof(double) * E); memcpy(mu, &H->mu[o * R], sizeof(double) * R); z = H->z[n * T + t]; }
-            } else
-            orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
-                           H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, NULL);
+            } else {
+                double cmh[4] = {0, 0, 0, 0};
+                int finite_in = isfinite(p[0]) && isfinite(p[1]) && isfinite(phi) && isfinite(H->xi[o * 2]) && isfinite(H->xi[o * 2 + 1])
+                                && isfinite(H->zeta[n * T + t]) && isfinite(H->dis[t]);
+                for (int i = 0; i < E; ++i) finite_in = finite_in && isfinite(At[2 * i]) && isfinite(At[2 * i + 1]) && isfinite(bt[i]);
+                if (finite_in) orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
+                                              H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, cmh);
+                if (!finite_in || !isfinite(cmh[0]) || !isfinite(cmh[1]) || !isfinite(cmh[2]) || !isfinite(cmh[3])) fail = 2;
+            }
+            if (fail == 2) {    /* non-finite data or result: previous lam, mu, z, xi, zeta stay, the stage drops out of the su hinge */
+                H->a_lam[o * 2] = H->a_lam[o * 2 + 1] = 0; H->b_lam[o] = 0;
+                H->resp[2 * (n * T + t)] = INFINITY; H->resp[2 * (n * T + t) + 1] = 0;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                H->lmz_fail++;
+                continue;
+            }
             double cs = cos(phi), sn = sin(phi);
             double ax = 0, ay = 0, bl = 0, im = 0, gx = 0, gy = 0;
             for (int i = 0; i < E; ++i) {
@@ -1049,7 +1064,7 @@ int orc_admm_finish(orc_handle *H, double *out_u, double *out_s, orc_info *info)
     int T = H->c.T;
     if (!H->stop) admm_residuals(H);
     memcpy(out_u, H->u, sizeof(double) * 2 * T); memcpy(out_s, H->s, sizeof(double) * 3 * (T + 1));
-    if (info) { info->resi_dual = H->resi_dual; info->resi_pri = H->resi_pri; info->iters = H->iters; info->su_status = H->su_status; info->su_ipm_iters = H->ipm_total; }
+    if (info) { info->resi_dual = H->resi_dual; info->resi_pri = H->resi_pri; info->iters = H->iters; info->su_status = H->su_status; info->su_ipm_iters = H->ipm_total; info->lmz_fail = H->lmz_fail; }
     return 0;
 }
 

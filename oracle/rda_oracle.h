@@ -39,6 +39,7 @@ typedef struct {
     int iters;          /* ADMM iterations executed */
     int su_status;      /* bit i set: su solve of iteration i did not converge (kept nominal) */
     int su_ipm_iters;   /* total IPM iterations */
+    int lmz_fail;       /* sub-problems that kept their previous duals (non-finite data / not OPTIMAL), residual inf */
 } orc_info;
 
 typedef struct orc_handle orc_handle;

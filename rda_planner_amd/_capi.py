@@ -25,7 +25,7 @@ class Cfg(C.Structure):
 
 class Info(C.Structure):
     _fields_ = [("resi_dual", C.c_double), ("resi_pri", C.c_double), ("iters", C.c_int),
-                ("su_status", C.c_int), ("su_ipm_iters", C.c_int)]
+                ("su_status", C.c_int), ("su_ipm_iters", C.c_int), ("lmz_fail", C.c_int)]
 
 
 DYNAMICS = {"acker": 0, "diff": 1, "omni": 2}

@@ -29,6 +29,7 @@
 
 struct Ctrl {
     int stop, iters, su_status, ipm_iters, st_tmp, it_tmp;
+    int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -93,7 +94,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     const int tid = threadIdx.x;
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
         if (tid == 0) {
-            d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0;
+            d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
             d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
         }
         __syncthreads();
@@ -148,6 +149,7 @@ __device__ __forceinline__ void finish_body(const Dev &d, double *out_u, double 
     if (tid == 0) {
         info->resi_dual = d.ctrl->resi_dual; info->resi_pri = d.ctrl->resi_pri;
         info->iters = d.ctrl->iters; info->su_status = d.ctrl->su_status; info->su_ipm_iters = d.ctrl->ipm_iters;
+        info->lmz_fail = d.ctrl->lmz_fail;
     }
 }
 
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double 
 __device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
-        d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0;
+        d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
         d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
     }
 }
@@ -230,6 +232,19 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     double prev = 0.0;
     if (lane < E) prev = d.lam[o * E + lane];
     else if (lane < E + R) prev = d.mu[o * R + lane - E];
+    // A sub-problem whose data are not finite cannot be solved: like a LamMuZ solve of the reference that does not end OPTIMAL
+    // (rda_solver.py:781-793) it keeps its previous duals and its residual is inf (no early stop).  The solver below is run on
+    // harmless stand-in data instead (its loops then see no NaN) and its answer is dropped.
+    bool bad = !isfinite(P.px + P.py + P.cs + P.sn + P.xi0 + P.xi1 + P.kappa0);
+    if (lane < 2 * E) bad = bad || !isfinite(W.A[lane >> 1][lane & 1]);
+    if (lane < E) bad = bad || !isfinite(W.b[lane]);
+    bad = __ballot(bad) != 0;
+    if (bad) {
+        if (lane < 2 * E) W.A[lane >> 1][lane & 1] = 0;
+        if (lane < E) W.b[lane] = 0;
+        P.px = P.py = P.sn = P.xi0 = P.xi1 = P.kappa0 = 0; P.cs = 1;
+        lmz::wave_sync();
+    }
     lmz::pose_products(W, P, lane);
     {   // candidate list and vertices of this slot from the upload-time cache
         const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
@@ -241,6 +256,17 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     if (!d.warm || !lmz::solve_wave_warm<64>(W, rb, P, lane, d.hint[n * T + t], best)) lmz::solve_wave(W, rb, P, lane, best);
     if (lane == 0) d.hint[n * T + t] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave<64>(W, rb, P, lane, best);
+    bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));
+    if (bad) {              // previous lam, mu, z, xi, zeta stay; the stage drops out of the su hinge (a = 0); residual inf
+        if (lane == 0) {
+            const int k = t * d.Nloc + nl;
+            coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
+            coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
+            d.hint[n * T + t] = -1;
+            atomicAdd(&d.ctrl->lmz_fail, 1);
+        }
+        return;
+    }
     // ---- fused dual / residual updates (every lane holds the winner) ----------------------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
     double res = 0;
@@ -323,6 +349,17 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     double prev = 0.0;
     if (gl < E) prev = d.lam[o * E + gl];
     else if (gl < E + R) prev = d.mu[o * R + gl - E];
+    // non-finite data: see lammuz_body (the row solves harmless stand-in data, keeps its previous duals, residual inf)
+    bool bad = !isfinite(P.px + P.py + P.cs + P.sn + P.xi0 + P.xi1 + P.kappa0);
+    if (gl < 2 * E) bad = bad || !isfinite(W.A[gl >> 1][gl & 1]);
+    if (gl < E) bad = bad || !isfinite(W.b[gl]);
+    bad = ((__ballot(bad) >> (16 * row)) & 0xffffull) != 0;
+    if (bad) {
+        if (gl < 2 * E) W.A[gl >> 1][gl & 1] = 0;
+        if (gl < E) W.b[gl] = 0;
+        P.px = P.py = P.sn = P.xi0 = P.xi1 = P.kappa0 = 0; P.cs = 1;
+    }
+    lmz::wave_sync();
     lmz::pose_products(W, P, gl);
     {
         const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
@@ -355,23 +392,32 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     }
     if (gl == 0 && live) d.hint[n * T + t] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave<16>(W, rb, P, lane, best);
+    bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));      // uniform over the row
     // ---- fused dual / residual updates (every lane of the row holds the row's winner) ----------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
     double res = 0;
+    const bool wr = live && !bad;
     if (gl < E) {
         double v = lmz::lam_of(best, P.norm2, gl);
-        res = (v - prev) * (v - prev); if (live) d.lam[o * E + gl] = v;
+        res = (v - prev) * (v - prev); if (wr) d.lam[o * E + gl] = v;
     } else if (gl < E + R) {
         int j = gl - E;
         double v = lmz::mu_of(best, j);
-        res = (v - prev) * (v - prev); if (live) d.mu[o * R + j] = v;
+        res = (v - prev) * (v - prev); if (wr) d.mu[o * R + j] = v;
     } else if (gl == E + R) {
         double old = d.z[n * T + t];
-        res = (znew - old) * (znew - old); if (live) d.z[n * T + t] = znew;
+        res = (znew - old) * (znew - old); if (wr) d.z[n * T + t] = znew;
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) res += __shfl_xor(res, off, 16);
-    if (gl == 0 && live) {
+    if (gl == 0 && live && bad) {       // previous lam, mu, z, xi, zeta stay; the stage drops out of the su hinge; residual inf
+        const int k = t * d.Nloc + nl;
+        coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
+        coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
+        d.hint[n * T + t] = -1;
+        atomicAdd(&d.ctrl->lmz_fail, 1);
+    }
+    if (gl == 0 && wr) {
         double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
         for (int i = 0; i < E; ++i) {
             double v = lmz::lam_of(best, P.norm2, i);

@@ -268,10 +268,12 @@ class RDA_solver:
     def pack_info(self, ref_states, out_s, info_c, start):
         """the `info` dict of the reference (:603-608) plus the solver counters"""
         opt_state_list = [out_s[:, i:i + 1] for i in range(self.T + 1)]      # columns of an array this call owns (no copies)
+        if info_c.lmz_fail:
+            print("Update Lam Mu Fail")                               # reference :792,825 (printed unconditionally there too)
         return {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
                 "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
                 "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,
-                "su_ipm_iters": info_c.su_ipm_iters}
+                "su_ipm_iters": info_c.su_ipm_iters, "lmz_fail": info_c.lmz_fail}
 
     # ---- caller-side pre_process on the device ------------------------------------------------------
     @property

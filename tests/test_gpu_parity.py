@@ -522,3 +522,28 @@ def test_packed_rows_kernel_equals_one_per_wave_kernel(monkeypatch, E, dyn, movi
     assert np.array_equal(ua, ub), np.abs(ua - ub).max()
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_failure_semantics_degenerate_obstacles_gpu_equals_oracle():
+    """NaN / zero-area / non-convex / zero-radius obstacles through the default HIP path (device-side conversion, packed rows)
+    and through the one-sub-problem-per-wave kernel: the NaN slot keeps its duals, residual inf, no early stop, counted in
+    info['lmz_fail']; everything else as the oracle computes it"""
+    from oracle.oracle_backend import oracle_backend
+    from test_host_api import _run_degenerate
+    want, mc, _ = _run_degenerate({"_backend": oracle_backend})
+    for env in ({}, {"RDA_LMZ_ROWS": "0"}, {"device_obstacles": False}):
+        kw = {k: v for k, v in env.items() if not k.startswith("RDA_")}
+        old = {k: os.environ.get(k) for k in env if k.startswith("RDA_")}
+        os.environ.update({k: v for k, v in env.items() if k.startswith("RDA_")})
+        try:
+            got, mg, printed = _run_degenerate(kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert "Update Lam Mu Fail" in printed
+        for (uc, ic), (ug, ig) in zip(want, got):
+            assert ig["lmz_fail"] == ic["lmz_fail"] == 24 and ig["resi_dual"] == np.inf and ig["iters"] == ic["iters"] == 3
+            assert np.abs(uc - ug).max() < 1e-6 and abs(ic["resi_pri"] - ig["resi_pri"]) < 1e-6
+        sc_, sg_ = mc.rda.get_state(), mg.rda.get_state()
+        for k in sc_:
+            assert np.isfinite(sg_[k]).all() and np.abs(sc_[k] - sg_[k]).max() < 1e-5, (env, k)

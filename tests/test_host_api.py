@@ -418,3 +418,50 @@ def test_flatten_scene_scalar_velocity_like_the_lidar_examples():
     assert vel.shape == (4, 2) and np.array_equal(vel, [[0.5, 0.5], [0.1, 0.2], [0.3, -0.4], [0.0, 0.0]])
     assert RDA_solver.flatten_scene(Host, [obs(None, None, V, "Rpositive", np.zeros(0))]) is None       # host conversion reports it
     assert RDA_solver.flatten_scene(Host, [obs(None, None, V, "Rpositive", np.nan)]) is None
+
+
+def _degenerate_scene():
+    """a healthy box, a NaN polygon, a zero-area polygon (all vertices equal), a non-convex quadrilateral, a circle of radius 0"""
+    good = sc.box(12, 27, 3, 2, 0.3)
+    nan = sc.box(14, 22, 2, 2, 0.0)
+    nan = nan._replace(vertex=nan.vertex * np.array([[np.nan, 1, 1, 1], [1, 1, 1, 1]]))
+    point = good._replace(vertex=np.tile(np.array([[18.0], [23.0]]), (1, 4)))
+    dart = good._replace(vertex=np.array([[20.0, 23.0, 21.0, 21.5], [26.0, 27.0, 28.5, 27.0]]))       # reflex corner
+    dot = sc.circle(16, 29, 0.0)
+    return [good, nan, point, dart, dot]
+
+
+def _run_degenerate(backend_kw, steps=4):
+    import contextlib
+    import io
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
+    mpc = MPC(car_t, [p.copy() for p in path], receding=8, iter_num=3, max_edge_num=4, max_obs_num=5, obstacle_order=False,
+              time_print=False, **backend_kw)
+    state = path[0].copy().reshape(3, 1)
+    out = []
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        for _ in range(steps):
+            u, info = mpc.control(state, 4.0, _degenerate_scene())
+            out.append((u.copy(), dict(info)))
+            state = sc.kinematic_step(state, u, car_t, 0.1)
+    return out, mpc, buf.getvalue()
+
+
+def test_failure_semantics_with_degenerate_obstacles():
+    """VERDICT r01 missing #3: a LamMuZ sub-problem that cannot be solved (NaN data) keeps its previous duals and makes the dual
+    residual inf, which blocks the early stop - rda_solver.py:781-793 - and is counted in info['lmz_fail']; zero-area,
+    non-convex and zero-radius obstacles are ordinary (solvable) inputs for the reference and stay so here"""
+    from oracle.oracle_backend import oracle_backend
+    out, mpc, printed = _run_degenerate({"_backend": oracle_backend})
+    T = 8
+    for u, info in out:
+        assert np.isfinite(u).all() and np.isfinite(np.hstack(info["opt_state_list"])).all()
+        assert info["lmz_fail"] == 3 * T          # the NaN slot, every stage, every one of the iter_num iterations (no early stop)
+        assert info["resi_dual"] == np.inf and info["iters"] == 3 and np.isfinite(info["resi_pri"])
+    assert "Update Lam Mu Fail" in printed
+    st = mpc.rda.get_state()
+    assert not st["lam"][1].any() and not st["mu"][1].any() and not st["z"][1].any()       # slot 1 kept its (zero) duals
+    assert all(np.isfinite(st[k]).all() for k in st)
+    assert st["mu"][0].any() and st["mu"][3].any()                                         # the healthy and the non-convex slot are solved
