@@ -206,9 +206,10 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * su-problem needs (8 doubles per (obstacle, stage): a(2), lam'b, mu'h+z-zeta, G'mu+xi (2), two residual
  * partials) form one contiguous chunk per rank, replicated to every rank by ONE all-gather per ADMM iteration
  * (replaces the pool.map scatter/gather of rda_solver.py:706-725); every rank then solves the identical
- * su-problem.  rda_shard_config must precede the first step; N must be divisible by world. */
+ * su-problem.  rda_shard_config must precede the first step.  N need not be divisible by world: the shards have
+ * ceil(N / world) slots, the slots past the last obstacle carry terms the su-problem ignores (accelerated cost only). */
 int  rda_shard_config(rda_handle *h, int rank, int world);
-int  rda_shard_chunk_doubles(rda_handle *h);                       /* 8*T*N/world */
+int  rda_shard_chunk_doubles(rda_handle *h);                       /* 8*T*ceil(N/world) */
 int  rda_shard_get_chunk(rda_handle *h, double *host_chunk);       /* this rank's chunk  */
 int  rda_shard_set_chunks(rda_handle *h, const double *host_all);  /* all `world` chunks, rank-major */
 /* RCCL exchange over xGMI: rank 0 calls rda_shard_unique_id and ships the 128 bytes to the other ranks (any

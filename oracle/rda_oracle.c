@@ -896,6 +896,7 @@ static void stage_obstacles(orc_handle *H, int n_obs, const double *A, const dou
 static void shard_chunk_of(orc_handle *H, int n, int t, double *o8)
 {   /* the 8 numbers per (obstacle, stage) the su-problem and the residual test need */
     const orc_cfg *c = &H->c; int T = c->T, R = c->R;
+    if (n >= c->N) { for (int k = 0; k < 8; ++k) o8[k] = 0; o8[3] = -1e30; return; }    /* padding slot of an uneven shard: never an active hinge */
     const double *mu = &H->mu[(size_t)(n * (T + 1) + t + 1) * R];
     double muh = 0, gx = H->xi[(n * (T + 1) + t + 1) * 2], gy = H->xi[(n * (T + 1) + t + 1) * 2 + 1];
     for (int j = 0; j < R; ++j) { muh += mu[j] * H->h[j]; gx += mu[j] * H->G[2 * j]; gy += mu[j] * H->G[2 * j + 1]; }
@@ -906,8 +907,9 @@ static void shard_chunk_of(orc_handle *H, int n, int t, double *o8)
 
 int orc_shard_config(orc_handle *H, int rank, int world)
 {
-    if (!H || world < 1 || rank < 0 || rank >= world || H->c.N % world) return -1;
-    H->P = world; H->rank = rank; H->Nloc = H->c.N / world; H->chunk = (size_t)8 * H->c.T * H->Nloc;
+    if (!H || world < 1 || rank < 0 || rank >= world) return -1;
+    if (H->c.N % world && !H->c.accelerated) return -2;
+    H->P = world; H->rank = rank; H->Nloc = (H->c.N + world - 1) / world; H->chunk = (size_t)8 * H->c.T * H->Nloc;
     free(H->gath); H->gath = calloc(H->chunk * world, sizeof(double)); H->have_gath = 0;
     return 0;
 }
@@ -988,14 +990,14 @@ int orc_admm_lammuz(orc_handle *H)
     const orc_cfg *c = &H->c; int T = c->T, N = c->N, E = c->E, R = c->R;
     if (H->stop) return 0;
     if (H->obstacle_num == 0) {                   /* Q9: only the last slot is cleared, :564-568 */
-        if (H->rank == H->P - 1) {
+        if (H->rank == (N - 1) / H->Nloc) {
             int n = N - 1;
             for (int t = 0; t < T; ++t) { H->a_lam[(n * (T + 1) + t + 1) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1] = 0; H->b_lam[n * (T + 1) + t + 1] = 0; }
         }
         return 0;
     }
     /* ---- LamMuZ problems + dual updates of this rank's shard (rda_solver.py:628-635) ----------------- */
-    const int n0 = H->rank * H->Nloc, n1 = n0 + H->Nloc;
+    const int n0 = H->rank * H->Nloc, n1 = n0 + H->Nloc < N ? n0 + H->Nloc : N;      /* the last shard may be short (N % P != 0) */
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(g_threads) schedule(static)
 #endif

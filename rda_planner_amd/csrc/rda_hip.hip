@@ -63,6 +63,7 @@ struct Dev {
     //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0..5 -> ax ay blam ee gx gy,  k = 6,7 -> residual partials
     // chunk r is produced by rank r's k_lammuz and replicated by one all-gather per ADMM iteration.
     double *coef; int P, rank, Nloc; size_t chunk;
+    int Nlive;                                // obstacle slots of THIS rank's shard that exist (< Nloc on the last ranks when N % P != 0)
     double *s, *u;                            // nominal (para_s, para_u)
     double *ref, *ref_speed;                  // current step reference (device)
     Ctrl *ctrl;
@@ -195,9 +196,9 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (d.obstacle_num == 0) {
         // quirk Q9 (rda_solver.py:564-568): only slot N-1 loses its lam'A / lam'b products
-        if (block == 0 && d.rank == d.P - 1)
+        if (block == 0 && d.rank == (N - 1) / d.Nloc)
             for (int t = threadIdx.x; t < T; t += 256) {
-                int i = t * d.Nloc + (d.Nloc - 1);
+                int i = t * d.Nloc + (N - 1) % d.Nloc;
                 coef_arr(d, d.rank, 0)[i] = 0; coef_arr(d, d.rank, 1)[i] = 0; coef_arr(d, d.rank, 2)[i] = 0;
             }
         return;
@@ -208,7 +209,7 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int w = block * 4 + wv;
-    const bool live = w < d.Nloc * T;
+    const bool live = w < d.Nlive * T;
     const int nl = live ? w / T : 0, t = live ? w % T : 0;
     const int n = d.rank * d.Nloc + nl;                        // this rank's obstacle shard [rank*Nloc, (rank+1)*Nloc)
     lmz::WaveLDS &W = wl[wv];
@@ -327,7 +328,7 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int w0 = block * 16 + wv * 4 + row;
-    const bool live = w0 < d.Nloc * T;
+    const bool live = w0 < d.Nlive * T;
     const int w = live ? w0 : block * 16;                      // a row past the end shadows a live one and writes nothing
     const int nl = w / T, t = w % T;
     const int n = d.rank * d.Nloc + nl;
@@ -525,8 +526,8 @@ __global__ void k_products_set(Dev d, const double *a_lam, const double *b_lam)
 }
 __global__ void k_reset(Dev d)
 {
-    const int T = d.c.T, N = d.c.N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) {
+    const int T = d.c.T;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.P * d.Nloc * T; i += gridDim.x * blockDim.x) {     // incl. padding slots (zero anyway)
         int r = i / (d.Nloc * T), k = i % (d.Nloc * T);
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
     }
@@ -543,6 +544,7 @@ struct rda_handle {
     double *d_step;                                       // device copy of the above (slot 0 of the step path)
     double *d_out_u, *d_out_s; rda_info *d_info;          // result slot of the step path
     double *h_out; rda_info *h_info;                      // pinned
+    int *h_stop = nullptr;                                // pinned copy of the early-stop flag (sharded handles with a communicator)
     // trace path
     int K; double *d_tr_s, *d_tr_u, *d_tr_ref, *d_tr_speed, *d_tr_out_u, *d_tr_out_s; rda_info *d_tr_info;
     // obstacle-shard exchange (RCCL, resolved lazily with dlopen so that single-GPU use has no rccl dependency)
@@ -650,7 +652,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
-    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.chunk = 8 * T * N;
+    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.chunk = 8 * T * N;
     rc |= dalloc(&d.coef, d.chunk);
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
     rc |= dalloc(&d.ctrl, 1);
@@ -698,6 +700,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->h_step) (void)hipHostFree(H->h_step);
     if (H->h_out) (void)hipHostFree(H->h_out);
     if (H->h_sc) (void)hipHostFree(H->h_sc);
+    if (H->h_stop) (void)hipHostFree(H->h_stop);
     for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
     if (H->stream2) { (void)hipStreamSynchronize(H->stream2); (void)hipStreamDestroy(H->stream2); }
     if (H->ev_tick) (void)hipEventDestroy(H->ev_tick);
@@ -862,7 +865,8 @@ static hipEvent_t next_event(rda_handle *H, int which)
 // one sub-problem per wave (also the no-obstacle case, quirk Q9)
 static void launch_lammuz(rda_handle *H, const Dev &d)
 {
-    const int units = d.Nloc * d.c.T;
+    const int units = d.Nlive * d.c.T;
+    if (units == 0) return;                      // a shard without obstacles (N < P)
     if (d.rows && d.obstacle_num) {
         const int nb = (units + 15) / 16;
         if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d);
@@ -896,6 +900,15 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     for (int it = 0; it < d.c.iter_num; ++it) {
         if (it > 0) launch_su(H, d, it, in_s, in_u);
+        if (it > 0 && H->comm) {
+            // The early stop (rda_solver.py:594) is a device flag and kernels queued behind it return at once - a collective
+            // cannot: with a communicator the host reads the flag after the su-problem (one small D2H + sync per iteration,
+            // every rank reads the same value: the su-problems are bitwise identical) and stops queueing, so no all-gather is
+            // issued for an iteration that does not run.
+            HIPCHK(hipMemcpyAsync(H->h_stop, &d.ctrl->stop, sizeof(int), hipMemcpyDeviceToHost, H->stream));
+            HIPCHK(hipStreamSynchronize(H->stream));
+            if (*H->h_stop) break;
+        }
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         launch_lammuz(H, d);
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
@@ -1195,14 +1208,30 @@ extern "C" int rda_set_state(rda_handle *H, const double *lam, const double *mu,
 
 
 // ---- obstacle sharding ------------------------------------------------------------------------------
+// shard slots past the last obstacle (N % P != 0): terms the su-problem must not see.  a = g = 0 and the offset `ee` so low that
+// the hinge margin a'p - (blam + ee) - d is astronomically positive: never active, screened out, no rotation term, no residual.
+__global__ void k_dead_slots(Dev d)
+{
+    const int T = d.c.T;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.P * d.Nloc * T; i += gridDim.x * blockDim.x) {
+        const int r = i / (d.Nloc * T), k = i % (d.Nloc * T), nl = k % d.Nloc;
+        if (r * d.Nloc + nl >= d.c.N) coef_arr(d, r, 3)[k] = -1e30;
+    }
+}
 extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
 {
-    if (!H || world < 1 || rank < 0 || rank >= world || H->d.c.N % world != 0) return RDA_ERR_ARG;
+    if (!H || world < 1 || rank < 0 || rank >= world) return RDA_ERR_ARG;
+    if (H->d.c.N % world != 0 && !H->d.c.accelerated) return RDA_ERR_UNSUPPORTED;    // padded shards rely on the hinge of the accelerated cost
     HIPCHK(hipStreamSynchronize(H->stream));
     Dev &d = H->d;
     dev_free(d.coef); d.coef = nullptr;
-    d.P = world; d.rank = rank; d.Nloc = d.c.N / world; d.chunk = (size_t)8 * d.c.T * d.Nloc;
+    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.chunk = (size_t)8 * d.c.T * d.Nloc;
+    const int first = rank * d.Nloc;
+    d.Nlive = first >= d.c.N ? 0 : (d.c.N - first < d.Nloc ? d.c.N - first : d.Nloc);
     if (dalloc(&d.coef, d.chunk * world)) return RDA_ERR_HIP;
+    HIPCHK(hipMemsetAsync(d.coef, 0, d.chunk * world * sizeof(double), H->stream));
+    if (d.Nloc * world != d.c.N) hipLaunchKernelGGL(k_dead_slots, dim3(64), dim3(256), 0, H->stream, d);
+    HIPCHK(hipStreamSynchronize(H->stream));
     return RDA_OK;
 }
 extern "C" int rda_shard_chunk_doubles(rda_handle *H) { return H ? (int)H->d.chunk : RDA_ERR_ARG; }
@@ -1249,6 +1278,7 @@ extern "C" int rda_shard_comm_init(rda_handle *H, const void *uid128)
     if (!f || !H->p_allgather) return RDA_ERR_UNSUPPORTED;
     int rc = f(&H->comm, H->d.P, uid, H->d.rank);
     if (rc != 0) { fprintf(stderr, "librda_hip: ncclCommInitRank failed (%d)\n", rc); H->comm = nullptr; return RDA_ERR_HIP; }
+    if (!H->h_stop) HIPCHK(hipHostMalloc((void **)&H->h_stop, sizeof(int)));
     return RDA_OK;
 }
 

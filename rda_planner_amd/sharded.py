@@ -26,7 +26,7 @@ def enable_rccl(solver, rank, world, broadcast_bytes):
     api, h = solver._be.api, solver._be.handle
     rc = api.shard_config(h, rank, world)
     if rc != 0:
-        raise RuntimeError(f"shard_config failed ({rc}); max_obs_num must be divisible by the world size")
+        raise RuntimeError(f"shard_config failed ({rc})")
     uid = C.create_string_buffer(128)
     if rank == 0:
         rc = api.lib.rda_shard_unique_id(h, uid)
@@ -47,7 +47,7 @@ class ShardedRDA:
         self.api, self.h = solver._be.api, solver._be.handle
         rc = self.api.shard_config(self.h, rank, world)
         if rc != 0:
-            raise RuntimeError(f"shard_config failed ({rc}); max_obs_num must be divisible by the world size")
+            raise RuntimeError(f"shard_config failed ({rc})")
         self.chunk = self.api.shard_chunk_doubles(self.h)
 
     def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list):

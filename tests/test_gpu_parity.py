@@ -232,60 +232,62 @@ def test_error_codes(hip):
     assert b"unsupported" in hip.lib.rda_strerror(-2)
 
 
-def test_obstacle_shards_two_handles_one_gpu(hip):
-    """N>1 path of the HIP library on one device: two handles act as rank 0 / rank 1 of a 2-way obstacle
-    shard, the per-iteration all-gather is emulated on the host (rda_shard_get_chunk / set_chunks).  Both
-    ranks must agree bit for bit with each other, and with the un-sharded solve up to the summation order of
-    the su-problem's obstacle reductions."""
+@pytest.mark.parametrize("world,n_obs", [(2, 6), (2, 5), (3, 7)])
+def test_obstacle_shards_emulated_ranks_one_gpu(hip, world, n_obs):
+    """N>1 path of the HIP library on one device: `world` handles act as the ranks of an obstacle shard, the per-iteration
+    all-gather is emulated on the host (rda_shard_get_chunk / set_chunks).  All ranks must agree bit for bit with each
+    other, and with the un-sharded solve up to the summation order of the su-problem's obstacle reductions.  Uneven shards
+    (N % world != 0): ceil(N / world) slots per rank, the padding slots must be invisible."""
     from rda_planner_amd.rda_solver import RDA_solver
     from rda_planner_amd.sharded import ShardedRDA
     from test_sharded_gloo import _problem
-    car_t, T, N, rl, steps = _problem()
+    import ctypes
+    car_t, T, N, rl, steps = _problem(n_obs)
     single = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
-    ranks = [RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False) for _ in range(2)]
-    pending = {}
-
-    class Emu:        # lock-step emulation: rank 0 deposits its chunk and waits for rank 1
-        def __init__(self, r): self.r = r
-        def __call__(self, chunk):
-            pending[self.r] = chunk.copy()
-            return None
-    sh = [ShardedRDA(ranks[r], r, 2, Emu(r)) for r in range(2)]
+    ranks = [RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False) for _ in range(world)]
+    sh = [ShardedRDA(ranks[r], r, world, lambda c: c) for r in range(world)]
     api = hip
     for nom_s, nom_u, ref in steps:
         us, infos = [], []
-        # drive both ranks iteration by iteration (what two processes would do concurrently)
-        import ctypes
-        for r in range(2):
+        # drive the ranks iteration by iteration (what `world` processes would do concurrently)
+        for r in range(world):
             s = ranks[r]
-            n_obs, A, b, cone, per_t = s._stage(list(rl))
-            assert api.upload_obstacles(sh[r].h, n_obs, dptr(A), dptr(b), iptr(cone), per_t) == 0
+            n_obs_, A, b, cone, per_t = s._stage(list(rl))
+            assert api.upload_obstacles(sh[r].h, n_obs_, dptr(A), dptr(b), iptr(cone), per_t) == 0
             refa = np.ascontiguousarray(np.hstack(ref)[0:3, :])
             assert api.admm_begin(sh[r].h, dptr(np.ascontiguousarray(nom_s)), dptr(np.ascontiguousarray(nom_u)), dptr(refa), 4.0) == 0
         for it in range(3):
-            stop = [ctypes.c_int(0), ctypes.c_int(0)]
-            for r in range(2):
+            stop = [ctypes.c_int(0) for _ in range(world)]
+            for r in range(world):
                 assert api.admm_su(sh[r].h, it, ctypes.byref(stop[r])) == 0
-            assert stop[0].value == stop[1].value
+            assert len({s_.value for s_ in stop}) == 1
             if stop[0].value:
                 break
             chunks = []
-            for r in range(2):
+            for r in range(world):
                 assert api.admm_lammuz(sh[r].h) == 0
                 c = np.zeros(sh[r].chunk)
                 assert api.shard_get_chunk(sh[r].h, dptr(c)) == 0
                 chunks.append(c)
-            both = np.concatenate(chunks)
-            for r in range(2):
-                assert api.shard_set_chunks(sh[r].h, dptr(both)) == 0
-        for r in range(2):
+            everyone = np.concatenate(chunks)
+            for r in range(world):
+                assert api.shard_set_chunks(sh[r].h, dptr(everyone)) == 0
+        for r in range(world):
             u = np.zeros((2, T)); so = np.zeros((3, T + 1)); info = Info()
             assert api.admm_finish(sh[r].h, dptr(u), dptr(so), C.byref(info)) == 0
             us.append(u); infos.append((info.iters, info.resi_dual, info.resi_pri))
-        assert np.array_equal(us[0], us[1]) and infos[0] == infos[1]
+        assert all(np.array_equal(us[0], u) for u in us) and all(infos[0] == i for i in infos)
         u1, i1 = single.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
         assert i1["iters"] == infos[0][0]
         assert np.abs(u1 - us[0]).max() < 1e-8 and abs(i1["resi_dual"] - infos[0][1]) < 1e-9
+    # the duals of every obstacle live on exactly one rank and equal the un-sharded ones
+    st1 = single.get_state()
+    nloc = -(-N // world)
+    for r in range(world):
+        st = ranks[r].get_state()
+        lo, hi = r * nloc, min((r + 1) * nloc, N)
+        for k in ("lam", "mu", "z", "xi", "zeta"):
+            assert np.abs(st[k][lo:hi] - st1[k][lo:hi]).max(initial=0) < 1e-7, (r, k)
 
 
 def test_obstacle_shards_rccl_two_gpus():
@@ -547,3 +549,22 @@ def test_failure_semantics_degenerate_obstacles_gpu_equals_oracle():
         sc_, sg_ = mc.rda.get_state(), mg.rda.get_state()
         for k in sc_:
             assert np.isfinite(sg_[k]).all() and np.abs(sc_[k] - sg_[k]).max() < 1e-5, (env, k)
+
+
+def test_bench_shard_mode_two_ranks_oversubscribed():
+    """`bench.py --gpus 2 --mode shard` launched the way the driver launches it, on however many GPUs the box has: with one
+    GPU the two ranks share it and exchange their shard chunks over gloo (plumbing of the N > 1 strong-scaling path, uneven
+    shards included); with two or more the in-library RCCL all-gather runs"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "shard", "--steps", "6", "--warmup", "2",
+                          "--n-obs", "21", "--horizon", "10"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    err = d.get("max_du_vs_unsharded_closed_loop", d.get("device_resident_replay", {}).get("max_du_vs_python_closed_loop"))
+    assert err is not None and err < 1e-8, d

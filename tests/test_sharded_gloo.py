@@ -11,11 +11,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _problem():
+def _problem(N=6):
     from rda_planner_amd import scenarios as sc
     from rda_planner_amd.mpc import MPC
     car_t = sc.rectangle_robot(dynamics="acker")
-    T, N = 8, 6
+    T = 8
     obstacles = sc.scene_polygons(N, lo=(4, -6), hi=(16, 6), seed=11)
     conv = MPC.__new__(MPC)
     conv.receding, conv.dt, conv.state = T, 0.1, np.zeros((3, 1))
@@ -32,7 +32,7 @@ def _problem():
     return car_t, T, N, rl, steps
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, n_obs):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -41,7 +41,7 @@ def _worker(rank, world, port, out):
     from rda_planner_amd.sharded import ShardedRDA
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    car_t, T, N, rl, steps = _problem()
+    car_t, T, N, rl, steps = _problem(n_obs)
     solver = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False, _backend=oracle_backend)
 
     def all_gather(chunk):
@@ -64,15 +64,17 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_shards_equal_single_process(tmp_path):
+@pytest.mark.parametrize("world,n_obs", [(2, 6), (2, 5), (3, 7)])
+def test_gloo_shards_equal_single_process(tmp_path, world, n_obs):
+    """even shards, and N % world != 0: shards of ceil(N / world) slots, the last one short (VERDICT r01 #8)"""
     import torch.multiprocessing as mp
     from oracle.oracle_backend import oracle_backend
     from rda_planner_amd.rda_solver import RDA_solver
     out = str(tmp_path / "sharded.npy")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * world + n_obs
+    mp.spawn(_worker, args=(world, port, out, n_obs), nprocs=world, join=True)
     got = np.load(out)
-    car_t, T, N, rl, steps = _problem()
+    car_t, T, N, rl, steps = _problem(n_obs)
     single = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False, _backend=oracle_backend)
     want = []
     for nom_s, nom_u, ref in steps:
@@ -82,11 +84,13 @@ def test_two_rank_gloo_shards_equal_single_process(tmp_path):
     assert np.array_equal(got, want), np.abs(got - want).max()
 
 
-def test_shard_config_rejects_indivisible():
+def test_shard_config_rejects_uneven_shards_of_the_non_accelerated_cost():
+    """the padding slots of an uneven shard rely on the hinge (accelerated) form of the cost"""
     from oracle.oracle_backend import oracle_backend
     from rda_planner_amd.rda_solver import RDA_solver
     from rda_planner_amd.sharded import ShardedRDA
     car_t, T, N, rl, steps = _problem()
-    solver = RDA_solver(T, car_t, 4, 5, iter_num=2, time_print=False, _backend=oracle_backend)
+    solver = RDA_solver(T, car_t, 4, 5, iter_num=2, time_print=False, accelerated=False, _backend=oracle_backend)
     with pytest.raises(RuntimeError):
         ShardedRDA(solver, 0, 2, lambda c: c)
+    ShardedRDA(RDA_solver(T, car_t, 4, 5, iter_num=2, time_print=False, _backend=oracle_backend), 1, 2, lambda c: c)

@@ -23,7 +23,7 @@ def main():
     from rda_planner_amd.mpc import MPC
     hip_api().lib.rda_set_device(local)
     car_t = sc.rectangle_robot(dynamics="acker")
-    T, N = 12, 8 * world
+    T, N = 12, 8 * world + int(os.environ.get("RDA_SHARD_EXTRA", "1"))      # default: N % world != 0 (padded last shard)
     obstacles = sc.scene_polygons(N, lo=(4, -8), hi=(24, 8), seed=3)
     conv = MPC.__new__(MPC)
     conv.receding, conv.dt, conv.state = T, 0.1, np.zeros((3, 1))
