@@ -239,6 +239,7 @@ class RDA_solver:
         info_c = Info()
         kind = np.ascontiguousarray(kind, np.int32); nvert = np.ascontiguousarray(nvert, np.int32)
         geom = f64(geom); vel = f64(vel)
+        self._timing_begin()
         rc = self._be.api.step_scene(self._be.handle, dptr(nom_s), dptr(nom_u), dptr(ref), float(ref_speed), int(n),
                                      iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(rob), int(bool(order)),
                                      dptr(out_u), dptr(out_s), C.byref(info_c))
@@ -246,6 +247,7 @@ class RDA_solver:
             raise RuntimeError(f"{self._be.api.prefix}_step_scene failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
+        self._timing_report(info_c, start)
         return out_u, self.pack_info(ref_states, out_s, info_c, start)
 
     # ---- staging only (the solve is then issued by a Fleet for all of its members at once) -----------
@@ -297,12 +299,14 @@ class RDA_solver:
         out_u, out_s, ref = np.zeros((2, T)), np.zeros((3, T + 1)), np.zeros((3, T + 1))
         info_c, mi, eh = Info(), np.zeros(1, np.int32), np.zeros(1)
         un = f64(nom_u, (2, T)) if nom_u is not None else None
+        self._timing_begin()
         rc = self._be.api.step_tracked(self._be.handle, dptr(st), float(ref_speed), int(cur_index), float(threshold), int(ind_range),
                                        dptr(un), dptr(out_u), dptr(out_s), C.byref(info_c), None, dptr(ref), iptr(mi), dptr(eh))
         if rc < 0:
             raise RuntimeError(f"{self._be.api.prefix}_step_tracked failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
+        self._timing_report(info_c, start)
         ref_states = [ref[:, i:i + 1] for i in range(T + 1)]
         return out_u, self.pack_info(ref_states, out_s, info_c, start), int(mi[0]), float(eh[0])
 
@@ -317,6 +321,7 @@ class RDA_solver:
         self._tick_start = time.time()
         st = f64(np.asarray(state, float).ravel()[0:3])
         un = f64(nom_u, (2, self.T)) if nom_u is not None else None
+        self._timing_begin()
         rc = self._be.api.tracked_begin(self._be.handle, dptr(st), float(ref_speed), int(cur_index), float(threshold),
                                         int(ind_range), dptr(un))
         if rc < 0:
@@ -345,8 +350,40 @@ class RDA_solver:
             raise RuntimeError(f"{self._be.api.prefix}_tracked_finish failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
+        self._timing_report(info_c, self._tick_start)
         ref_states = [ref[:, i:i + 1] for i in range(T + 1)]
         return out_u, self.pack_info(ref_states, out_s, info_c, self._tick_start), int(mi[0]), float(eh[0])
+
+    # ---- the reference's timing printout (rda_solver.py:587-601, `time_print`) ---------------------------------------------
+    def _timing_begin(self):
+        """per-kernel GPU events for this step (only when time_print is set: the events cost a few microseconds per launch)"""
+        lib = self._be.api.lib
+        self._timed = bool(self.time_print) and hasattr(lib, "rda_timing_launches")
+        if self._timed:
+            lib.rda_timing_reset(self._be.handle, 1)
+
+    def _timing_report(self, info_c, start):
+        """'iteration i time: ...' for every executed ADMM iteration (GPU time of its su + LamMuZ kernels), 'iteration early
+        stop: i' when the residual test of :594 ended the loop, then the total - the lines the reference prints"""
+        if not self.time_print:
+            return
+        if getattr(self, "_timed", False):
+            lib, h = self._be.api.lib, self._be.handle
+            cap = self.iter_num + 1
+            per = []
+            for which in (1, 0):                                   # su, LamMuZ launches in launch order
+                buf, n = np.zeros(cap), C.c_int(0)
+                lib.rda_timing_launches(h, which, dptr(buf), cap, C.cast(C.byref(n), C.POINTER(C.c_int)))
+                per.append(buf[:min(n.value, cap)])
+            lib.rda_timing_reset(h, 0)
+            for i in range(info_c.iters):
+                t_i = (per[0][i] if i < per[0].size else 0.0) + (per[1][i] if i < per[1].size else 0.0)
+                print("iteration " + str(i) + " time: ", t_i * 1e-3)
+        if info_c.resi_dual < self.iter_threshold and info_c.resi_pri < self.iter_threshold:
+            print("iteration early stop: " + str(info_c.iters - 1))
+        print("-----------------------------------------------")
+        print("iteration time:", time.time() - start)
+        print("==============================================")
 
     # ---- one MPC step (reference iterative_solve :573-610) --------------------------------
     def iterative_solve(self, nom_s, nom_u, ref_states, ref_speed, obstacle_list, **kwargs):
@@ -359,6 +396,7 @@ class RDA_solver:
         out_u = np.zeros((2, T))
         out_s = np.zeros((3, T + 1))
         info_c = Info()
+        self._timing_begin()
         rc = self._be.api.step(self._be.handle, dptr(nom_s), dptr(nom_u), dptr(ref), float(ref_speed),
                                n_obs, dptr(A), dptr(b), iptr(cone), per_t, dptr(out_u), dptr(out_s),
                                C.byref(info_c))
@@ -366,10 +404,7 @@ class RDA_solver:
             raise RuntimeError(f"{self._be.api.prefix}_step failed with code {rc}")
         if info_c.su_status and self.time_print:
             print("No update of state and control vector")        # reference :699
-        if self.time_print:
-            print("-----------------------------------------------")
-            print("iteration time:", time.time() - start)
-            print("==============================================")
+        self._timing_report(info_c, start)
         return out_u, self.pack_info(ref_states, out_s, info_c, start)
 
     # ---- state access for tests -----------------------------------------------------------

@@ -89,11 +89,12 @@ def line_path(start, goal, step=0.1):
 
 
 def path_track_ref():
-    """The (137,3,1) reference path shipped as example/path_track/path_track_ref.npy is an input
-    fixture of the reference; a copy of its numbers lives in tests/golden/path_track_ref.npy."""
+    """The (137,3,1) reference path of the reference's path_track examples (an INPUT fixture there:
+    example/path_track/path_track_ref.npy, byte-identical copies under lidar_nav/ and dynamic_obs/); the numbers
+    ship with this package as rda_planner_amd/data/path_track_ref.npy."""
     import os
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "path_track_ref.npy")
-    return [np.array(x, float) for x in np.load(p)]
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "path_track_ref.npy")
+    return [np.array(x, float) for x in np.load(p, allow_pickle=False)]
 
 
 # ---------------------------------------------------------------------------------------------

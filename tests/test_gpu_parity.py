@@ -568,3 +568,23 @@ def test_bench_shard_mode_two_ranks_oversubscribed():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     err = d.get("max_du_vs_unsharded_closed_loop", d.get("device_resident_replay", {}).get("max_du_vs_python_closed_loop"))
     assert err is not None and err < 1e-8, d
+
+
+def test_time_print_surface_of_the_reference(capsys):
+    """rda_solver.py:587-601 with time_print=True: one 'iteration i time:' line per EXECUTED ADMM iteration (here: the GPU time
+    of that iteration's su + LamMuZ kernels), 'iteration early stop: i' when the residual test ended the loop, the total"""
+    from rda_planner_amd.rda_solver import RDA_solver
+    from test_sharded_gloo import _problem
+    car_t, T, N, rl, steps = _problem()
+    solver = RDA_solver(T, car_t, 4, N, iter_num=4, time_print=True)
+    for nom_s, nom_u, ref in steps:
+        capsys.readouterr()
+        u, info = solver.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+        out = capsys.readouterr().out
+        lines = [ln for ln in out.splitlines() if ln.startswith("iteration ") and " time: " in ln and not ln.startswith("iteration time")]
+        assert len(lines) == info["iters"], out
+        assert [int(ln.split()[1]) for ln in lines] == list(range(info["iters"]))
+        assert all(0 < float(ln.split()[-1]) < 0.1 for ln in lines)
+        assert "iteration time:" in out
+        stopped = info["resi_dual"] < 0.2 and info["resi_pri"] < 0.2
+        assert (f"iteration early stop: {info['iters'] - 1}" in out) == stopped
