@@ -34,6 +34,9 @@
 static int g_threads = 1;
 static double g_su_warm_wfl = 1e-3, g_su_warm_mu0 = 1e-3; static int g_su_warm_cap = 30, g_su_warm_first = 1;   /* su warm start (orc_set_su_warm(0,0,0): cold) */
 void orc_set_su_warm(double wfl, double mu0, int cap) { g_su_warm_wfl = wfl; g_su_warm_mu0 = mu0; g_su_warm_cap = cap; }
+/* end game of a WARM-started su solve: floor of the fraction to the boundary and of the centering parameter (cold: 0.995, 1e-3) */
+static double g_su_warm_tau = 0.9999, g_su_warm_sig = 1e-5;
+void orc_set_su_warm_endgame(double tau, double sig) { g_su_warm_tau = tau; g_su_warm_sig = sig; }
 static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};   /* interior-point stop of the su-problem: rd, rp, mu */
 void orc_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
 static int g_lmz_mode = 0;   /* 0: support enumeration + tie-breaks T1-T3, 1: interior point (oracle/lmz_ipm.c) */
@@ -767,13 +770,14 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
                 mu_aff /= mc;
                 /* centering parameter from the predictor step length, floored: the classical (mu_aff/mu)^3
                  * rule can cycle on the piecewise-quadratic hinge terms (observed with ro1 = 1) */
-                { double q = 1 - al, fl = al >= 0.95 ? SIGMA_FLOOR : 0.03;
+                { double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? g_su_warm_sig : SIGMA_FLOOR) : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl; }
             }
         }
         /* fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game) */
-        double al = 1.0, tau = 1.0 - mu; if (tau < 0.995) tau = 0.995;
+        const double tau_min = attempt < 0 ? g_su_warm_tau : 0.995;
+        double al = 1.0, tau = 1.0 - mu; if (tau < tau_min) tau = tau_min;
         for (int i = 0; i < mc; ++i) {
             if (dw[i] < 0 && -tau * w[i] / dw[i] < al) al = -tau * w[i] / dw[i];
             if (dl[i] < 0 && -tau * lm[i] / dl[i] < al) al = -tau * lm[i] / dl[i];

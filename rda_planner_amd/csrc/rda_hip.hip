@@ -50,6 +50,7 @@ struct Dev {
     int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
+    double su_warm_tau, su_warm_sig;   // end game of the warm attempt (RDA_SU_WARM_ENDGAME="tau,sigma" floors; cold solves: 0.995, 1e-3)
     double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
     int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
     int obstacle_num;        // 0 or N
@@ -123,7 +124,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
-    a.lam_keep = d.su_lam_keep;
+    a.lam_keep = d.su_lam_keep; a.warm_tau = d.su_warm_tau; a.warm_sig = d.su_warm_sig;
     su::solve<TT>(a, smem_su);
     __syncthreads();
     if (tid == 0) {
@@ -210,7 +211,9 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int w = block * 4 + wv;
     const bool live = w < d.Nlive * T;
-    const int nl = live ? w / T : 0, t = live ? w % T : 0;
+    // unit w -> (stage, slot) with the SLOT fastest: the rows of a wave / the waves of a block then write neighbouring entries of
+    // the [T][Nloc] condensed-term arrays (an 8-byte store per array and row; with the stage fastest every store was its own sector)
+    const int nl = live ? w % d.Nlive : 0, t = live ? w / d.Nlive : 0;
     const int n = d.rank * d.Nloc + nl;                        // this rank's obstacle shard [rank*Nloc, (rank+1)*Nloc)
     lmz::WaveLDS &W = wl[wv];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
@@ -330,7 +333,7 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     const int w0 = block * 16 + wv * 4 + row;
     const bool live = w0 < d.Nlive * T;
     const int w = live ? w0 : block * 16;                      // a row past the end shadows a live one and writes nothing
-    const int nl = w / T, t = w % T;
+    const int nl = w % d.Nlive, t = w / d.Nlive;             // slot fastest: see lammuz_body
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
@@ -634,6 +637,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
     H->d.centre = g_tie_centre;
     H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
+    H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5;
+    { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &H->d.su_warm_tau, &H->d.su_warm_sig); }
     { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &H->d.su_warm_wfl, &H->d.su_warm_mu0, &H->d.su_warm_cap); }
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = g_su_tol[i];
     { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &H->d.su_tol[0], &H->d.su_tol[1], &H->d.su_tol[2]); }

@@ -60,6 +60,10 @@ struct Args {
     // duals, the linearisation point IS the previous solution): slack floor / barrier parameter of the start (0 = the cold
     // rule) and the multipliers of the previous converged solve [NC*T] (read when warm, written by every converged solve)
     double warm_wfl = 0, warm_mu0 = 0; int warm_cap = 30; int warm_shift = 0;
+    // end game of the warm attempt: floors of the fraction to the boundary and of the centering parameter.  A warm start begins next
+    // to the solution (the dual residual is at rounding level after one step), what is left is driving the complementarity down;
+    // with the cold floors (0.995, 1e-3) that takes three iterations from mu ~ 1e-2, with these two.
+    double warm_tau = 0.9999, warm_sig = 1e-5;
     double *lam_keep = nullptr;
 };
 
@@ -583,6 +587,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         status = 1;
     }
     const int it_cap = attempt < 0 ? a.warm_cap : 100;
+    const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
     for (it = 0; it < it_cap; ++it) {
         seq += 1;
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
@@ -859,14 +864,14 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                 L.dw[i] = dwv; L.dl[i] = dlv;
                 // fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
                 double fr = 1.0;
-                if (pass) { fr = 1.0 - mu; if (fr < 0.995) fr = 0.995; }
+                if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; }
                 if (dwv < 0) { double x = -fr * L.cw[i] / dwv; if (x < al) al = x; }
                 if (dlv < 0) { double x = -fr * L.cl[i] / dlv; if (x < al) al = x; }
             }
             al = -block_reduce(-al, L.red, tid, true);
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
-                double q = 1 - al, fl = al >= 0.95 ? SIGMA_FLOOR : 0.03;
+                double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? a.warm_sig : SIGMA_FLOOR) : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl;
             } else {
