@@ -41,7 +41,7 @@ typedef struct rda_cfg {
     int32_t dynamics;     /* 0 acker, 1 diff, 2 omni       rda_solver.py:446 */
     int32_t accelerated;  /*                               rda_solver.py:47  */
     int32_t iter_num;     /*                               rda_solver.py:42  */
-    int32_t robot_norm2;  /* car_tuple.cone_type=='norm2' -> RDA_ERR_UNSUPPORTED */
+    int32_t robot_norm2;  /* car_tuple.cone_type=='norm2' (rda_solver.py:1034-1039): solved by the interior-point LamMuZ kernel */
     double dt, L;
     double max_speed[2];  /* rda_solver.py:37 */
     double acce_bound[2]; /* max_acce*dt, rda_solver.py:44 */
@@ -76,6 +76,11 @@ int  rda_set_device(int dev);
  * optimal: 1 (default) = duals of the unit normal in the middle of the arc of separating directions, 0 = max-clearance
  * duals.  Process-wide; read by rda_create and rda_lammuz_batch. */
 void rda_set_tie_centre(int on);
+/* Which solver the LamMuZ sub-problems of handles created afterwards use: mode 0 (default) the support enumeration with the
+ * tie-breaks T1-T3 of DESIGN.md; mode 1 an interior-point method that returns the point of the central path of the reference's
+ * own cone program at barrier parameter `mu` (default 1e-6; interior duals like the reference's interior-point solver returns,
+ * any combination of cones, ~100x slower than mode 0).  Handles with a norm2 robot always use mode 1.  Process-wide. */
+void rda_set_lmz_mode(int mode, double mu);
 /* Interior-point stop of the su-problem: |r_dual|_inf <= rd (1 + |grad|_inf), |r_prim|_inf <= rp, mean complementarity
  * <= mu (1 + |grad|_inf).  Process-wide default for handles created afterwards and for rda_su_solve. */
 void rda_set_su_tol(double rd, double rp, double mu);     /* device used by handles created afterwards (one process per GPU) */

@@ -285,7 +285,9 @@ int orc_lammuz_ipm_one(int E, int R, const double *A, const double *b, int cone_
     }
     c.G[r][itn] = 1; c.G[r][imm] = -1; c.h[r] = 0; ++r;                                    /* tn <= mm */
     c.G[r][imm] = 1; c.h[r] = 1; ++r;                                                      /* mm <= 1 */
-    if (!cone_norm2) for (int i = 0; i < E; ++i) { c.G[r][i] = -1; c.h[r] = 0; ++r; }
+    /* zero-padded edge rows (A_i = 0, b_i = 0: rda_solver.py:507-508,520-521) carry a multiplier that enters nothing; the reference
+     * still constrains it (lam_i >= 0), which leaves it without a central value (its dual is 0) - here it is simply left at 0 */
+    if (!cone_norm2) for (int i = 0; i < E; ++i) { if (A[2 * i] == 0 && A[2 * i + 1] == 0 && b[i] == 0) continue; c.G[r][i] = -1; c.h[r] = 0; ++r; }
     else for (int i = 0; i < E; ++i) { c.G[r][itl] = 1; c.G[r][2] = 1; c.h[r] = 0; ++r; }  /* tl + lam_2 <= 0, E identical rows (:1044-1048) */
     if (!robot_norm2) for (int j = 0; j < R; ++j) { c.G[r][E + j] = -1; c.h[r] = 0; ++r; }
     else { c.G[r][itr] = 1; c.G[r][E + R - 1] = 1; c.h[r] = 0; ++r; }                      /* tr + mu_{R-1} <= 0 (:1039) */

@@ -1012,7 +1012,11 @@ int orc_admm_lammuz(orc_handle *H)
             double p[2] = { H->s[t + 1], H->s[(T + 1) + t + 1] }, phi = H->s[2 * (T + 1) + t];
             double lam[EMAX], mu[RMAX], z, res = 0;
             int fail = 0;
-            if (g_lmz_mode) {
+            int finite_in = isfinite(p[0]) && isfinite(p[1]) && isfinite(phi) && isfinite(H->xi[o * 2]) && isfinite(H->xi[o * 2 + 1])
+                            && isfinite(H->zeta[n * T + t]) && isfinite(H->dis[t]);
+            for (int i = 0; i < E; ++i) finite_in = finite_in && isfinite(At[2 * i]) && isfinite(At[2 * i + 1]) && isfinite(bt[i]);
+            if (!finite_in) fail = 2;
+            else if (g_lmz_mode) {
                 int st = orc_lammuz_ipm_one(E, R, At, bt, H->cone[n], c->robot_norm2, p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
                                             H->dis[t], c->ro2, c->accelerated, lam, mu, &z, NULL, NULL);
                 /* the reference accepts OPTIMAL only (rda_solver.py:781,816; Q8): anything else keeps the previous duals and the
@@ -1020,12 +1024,9 @@ int orc_admm_lammuz(orc_handle *H)
                 if (st != 0) { fail = 1; memcpy(lam, &H->lam[o * E], sizeof(double) * E); memcpy(mu, &H->mu[o * R], sizeof(double) * R); z = H->z[n * T + t]; }
             } else {
                 double cmh[4] = {0, 0, 0, 0};
-                int finite_in = isfinite(p[0]) && isfinite(p[1]) && isfinite(phi) && isfinite(H->xi[o * 2]) && isfinite(H->xi[o * 2 + 1])
-                                && isfinite(H->zeta[n * T + t]) && isfinite(H->dis[t]);
-                for (int i = 0; i < E; ++i) finite_in = finite_in && isfinite(At[2 * i]) && isfinite(At[2 * i + 1]) && isfinite(bt[i]);
-                if (finite_in) orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
+                orc_lammuz_one(E, R, At, bt, H->cone[n], p, phi, H->G, H->h, &H->xi[o * 2], H->zeta[n * T + t],
                                               H->dis[t], c->ro2, c->delta, c->accelerated, lam, mu, &z, cmh);
-                if (!finite_in || !isfinite(cmh[0]) || !isfinite(cmh[1]) || !isfinite(cmh[2]) || !isfinite(cmh[3])) fail = 2;
+                if (!isfinite(cmh[0]) || !isfinite(cmh[1]) || !isfinite(cmh[2]) || !isfinite(cmh[3])) fail = 2;
             }
             if (fail == 2) {    /* non-finite data or result: previous lam, mu, z, xi, zeta stay, the stage drops out of the su hinge */
                 H->a_lam[o * 2] = H->a_lam[o * 2 + 1] = 0; H->b_lam[o] = 0;

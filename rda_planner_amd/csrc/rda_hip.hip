@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include "../../include/rda_hip.h"
 #include "lammuz_device.h"
+#include "lammuz_cp_device.h"
 #include "su_device.h"
 #include "scene_device.h"
 #include "track_device.h"
@@ -52,6 +53,8 @@ struct Dev {
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
     double su_warm_tau, su_warm_sig;   // end game of the warm attempt (RDA_SU_WARM_ENDGAME="tau,sigma" floors; cold solves: 0.995, 1e-3)
     double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
+    int lmz_mode;            // 0: support enumeration + tie-breaks T1-T3 (default), 1: interior point, central path at lmz_mu (norm2 robots: always)
+    double lmz_mu;           // barrier parameter of the returned central-path point (mode 1)
     int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
     int obstacle_num;        // 0 or N
     double *G, *h;
@@ -449,6 +452,78 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
 __global__ __launch_bounds__(256) void k_lammuz_rows(Dev d) { lammuz_body_rows(d, blockIdx.x); }
 __global__ __launch_bounds__(256, 2) void k_lammuz_rows_dense(Dev d) { lammuz_body_rows(d, blockIdx.x); }
 
+// K1, interior-point variant (lammuz_cp_device.h): one (obstacle, stage) sub-problem per thread, same fused dual / residual
+// updates as lammuz_body.  A solve that does not end on the central path keeps the previous duals of its stage and makes the
+// residual inf (rda_solver.py:781-793); unlike non-finite data (where everything of the stage is left alone) the xi / zeta
+// updates then run with the kept duals, as the reference's do.
+template <int NX, int MX> __device__ __forceinline__ void lammuz_cp_body(const Dev &d)
+{
+    const int T = d.c.T, E = d.c.E, R = d.c.R;
+    if (d.ctrl->stop) return;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.obstacle_num == 0) {          // quirk Q9, as in lammuz_body
+        if (w < T && d.rank == (d.c.N - 1) / d.Nloc) {
+            const int i = w * d.Nloc + (d.c.N - 1) % d.Nloc;
+            coef_arr(d, d.rank, 0)[i] = 0; coef_arr(d, d.rank, 1)[i] = 0; coef_arr(d, d.rank, 2)[i] = 0;
+        }
+        return;
+    }
+    if (w >= d.Nlive * T) return;
+    const int nl = w % d.Nlive, t = w / d.Nlive, n = d.rank * d.Nloc + nl;
+    const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E, o = (size_t)n * (T + 1) + t + 1;
+    const int k = t * d.Nloc + nl;
+    double A[16], b[8];
+    for (int i = 0; i < 2 * E; ++i) A[i] = d.A[ao * 2 + i];
+    for (int i = 0; i < E; ++i) b[i] = d.b[ao + i];
+    cpq::Problem p;
+    p.E = E; p.R = R; p.cone_norm2 = d.cone[n]; p.robot_norm2 = d.c.robot_norm2; p.accelerated = d.c.accelerated;
+    p.A = A; p.b = b; p.G = d.G; p.h = d.h;
+    p.px = d.s[t + 1]; p.py = d.s[(T + 1) + t + 1];
+    const double phi = d.s[2 * (T + 1) + t];                  // heading of column t (quirk Q1)
+    p.cs = cos(phi); p.sn = sin(phi);
+    p.xi0 = d.xi[2 * o]; p.xi1 = d.xi[2 * o + 1];
+    const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
+    p.kappa0 = zeta - dbar; p.ro2 = d.c.ro2; p.mu_target = d.lmz_mu;
+    bool finite_in = isfinite(p.px + p.py + p.cs + p.sn + p.xi0 + p.xi1 + p.kappa0);
+    for (int i = 0; i < 2 * E; ++i) finite_in = finite_in && isfinite(A[i]);
+    for (int i = 0; i < E; ++i) finite_in = finite_in && isfinite(b[i]);
+    if (!finite_in) {
+        coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
+        coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
+        atomicAdd(&d.ctrl->lmz_fail, 1);
+        return;
+    }
+    cpq::Result rs;
+    {
+        cpq::Solver<NX, MX> sv;
+        sv.run(p, rs);
+    }
+    const bool fail = rs.status != 0;
+    double res = 0, lam[8], mu[8], znew;
+    for (int i = 0; i < E; ++i) { const double old = d.lam[o * E + i]; lam[i] = fail ? old : rs.lam[i]; res += (lam[i] - old) * (lam[i] - old); }
+    for (int j = 0; j < R; ++j) { const double old = d.mu[o * R + j]; mu[j] = fail ? old : rs.mu[j]; res += (mu[j] - old) * (mu[j] - old); }
+    { const double old = d.z[n * T + t]; znew = fail ? old : rs.z; res += (znew - old) * (znew - old); }
+    if (!fail) {
+        for (int i = 0; i < E; ++i) d.lam[o * E + i] = lam[i];
+        for (int j = 0; j < R; ++j) d.mu[o * R + j] = mu[j];
+        d.z[n * T + t] = znew;
+    } else atomicAdd(&d.ctrl->lmz_fail, 1);
+    double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
+    for (int i = 0; i < E; ++i) { ax += lam[i] * A[2 * i]; ay += lam[i] * A[2 * i + 1]; bl += lam[i] * b[i]; }
+    for (int j = 0; j < R; ++j) { mh += mu[j] * d.h[j]; gx += mu[j] * d.G[2 * j]; gy += mu[j] * d.G[2 * j + 1]; }
+    const double hx = gx + p.cs * ax + p.sn * ay, hy = gy - p.sn * ax + p.cs * ay;      // Hm, :682
+    const double xin0 = p.xi0 + hx, xin1 = p.xi1 + hy;                                  // :683
+    d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
+    const double im = ax * p.px + ay * p.py - bl - mh;                                  // :659
+    const double zetan = zeta + im - dbar - znew;                                       // :666
+    d.zeta[n * T + t] = zetan;
+    coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
+    coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
+    coef_arr(d, d.rank, 6)[k] = fail ? INFINITY : res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
+}
+__global__ __launch_bounds__(64) void k_lammuz_cp_small(Dev d) { lammuz_cp_body<16, 24>(d); }      // E, R <= 4
+__global__ __launch_bounds__(64) void k_lammuz_cp_large(Dev d) { lammuz_cp_body<24, 36>(d); }      // E, R <= 8
+
 struct RobotCands { unsigned char muc[40]; int nmv; double rv[28][2]; int nrv; int centre; };
 
 // pure-function batch hook (rda_lammuz_batch)
@@ -574,7 +649,7 @@ extern "C" const char *rda_strerror(int code)
     switch (code) {
         case RDA_OK: return "ok";
         case RDA_ERR_ARG: return "invalid argument";
-        case RDA_ERR_UNSUPPORTED: return "unsupported configuration (norm2 robot, E/R/T above the compiled limits, non-canonical circle)";
+        case RDA_ERR_UNSUPPORTED: return "unsupported configuration (E/R/T above the compiled limits, non-canonical circle obstacle, interior-point mode in a fleet)";
         case RDA_ERR_HIP: return "HIP runtime error";
         case RDA_ERR_NODEVICE: return "no HIP device";
         default: return code > 0 ? "soft status" : "unknown error";
@@ -597,6 +672,10 @@ template <typename Tp> static int dalloc(Tp **p, size_t n)
 static int g_tie_centre = 1;
 extern "C" void rda_set_tie_centre(int on) { g_tie_centre = on ? 1 : 0; }
 // interior-point stop of the su-problem (process-wide default, read by rda_create and rda_su_solve)
+// LamMuZ solver of handles created afterwards: 0 support enumeration (tie-breaks T1-T3), 1 interior point ending on the central
+// path at barrier parameter mu (lammuz_cp_device.h); norm2 robots always use 1
+static int g_lmz_mode = 0; static double g_lmz_mu = 1e-6;
+extern "C" void rda_set_lmz_mode(int mode, double mu) { g_lmz_mode = mode ? 1 : 0; if (mu > 0) g_lmz_mu = mu; }
 static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};
 extern "C" void rda_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
 
@@ -624,7 +703,7 @@ static int robot_candidates(int R, const double *G, const double *h, unsigned ch
 extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out)
 {
     if (!cfg || !G || !h || !out) return RDA_ERR_ARG;
-    if (cfg->robot_norm2) return RDA_ERR_UNSUPPORTED;
+    if (cfg->robot_norm2 && cfg->R < 2) return RDA_ERR_UNSUPPORTED;
     if (cfg->E < 1 || cfg->E > RDA_EMAX || cfg->R < 1 || cfg->R > RDA_RMAX || cfg->T < 1 || cfg->T > RDA_TMAX || cfg->N < 1) return RDA_ERR_UNSUPPORTED;
     if (cfg->E + cfg->R + 1 > 64) return RDA_ERR_UNSUPPORTED;
     if (rda_device_count() < 1) return RDA_ERR_NODEVICE;
@@ -636,6 +715,9 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     { const char *w = getenv("RDA_LMZ_ROWS"); H->d.rows = (cfg->E + cfg->R + 1 <= 16) && (w ? atoi(w) != 0 : true); }
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
     H->d.centre = g_tie_centre;
+    H->d.lmz_mode = (g_lmz_mode || cfg->robot_norm2) ? 1 : 0; H->d.lmz_mu = g_lmz_mu;      // the enumeration has no norm2-robot candidates
+    { const char *e = getenv("RDA_LMZ_MODE"); if (e && !cfg->robot_norm2) H->d.lmz_mode = atoi(e) ? 1 : 0; }
+    { const char *e = getenv("RDA_LMZ_MU"); if (e) H->d.lmz_mu = atof(e); }
     H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
     H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5;
     { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &H->d.su_warm_tau, &H->d.su_warm_sig); }
@@ -872,6 +954,12 @@ static void launch_lammuz(rda_handle *H, const Dev &d)
 {
     const int units = d.Nlive * d.c.T;
     if (units == 0) return;                      // a shard without obstacles (N < P)
+    if (d.lmz_mode) {
+        const int nb = d.obstacle_num ? (units + 63) / 64 : (d.c.T + 63) / 64;
+        if (d.c.E <= 4 && d.c.R <= 4) hipLaunchKernelGGL(k_lammuz_cp_small, dim3(nb), dim3(64), 0, H->stream, d);
+        else hipLaunchKernelGGL(k_lammuz_cp_large, dim3(nb), dim3(64), 0, H->stream, d);
+        return;
+    }
     if (d.rows && d.obstacle_num) {
         const int nb = (units + 15) / 16;
         if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d);
@@ -1411,6 +1499,7 @@ extern "C" int rda_fleet_create(rda_handle *const *egos, int B, rda_fleet **out)
         // one grid for all members: the problem SHAPE must agree (weights, bounds, kinematics and robots may differ)
         if (a.T != b.T || a.N != b.N || a.E != b.E || a.R != b.R || a.iter_num != b.iter_num) return RDA_ERR_UNSUPPORTED;
         if (egos[i]->comm || egos[i]->d.P != 1) return RDA_ERR_UNSUPPORTED;        // egos are replicas, obstacle shards are not
+        if (egos[i]->d.lmz_mode) return RDA_ERR_UNSUPPORTED;                       // the fused fleet launches run the enumeration kernels
     }
     rda_fleet *F = new rda_fleet();
     F->B = B; F->egos.assign(egos, egos + B);

@@ -101,9 +101,26 @@ class RDA_solver:
         cfg.eps_u = kwargs.get("tie_control", 1e-8)
         self._cfg = cfg
         make = kwargs.get("_backend", _hip_backend)
-        self._be = make(cfg, G, h)
+        # LamMuZ solver (not a reference argument): None / 0 = support enumeration with the tie-breaks of DESIGN.md 2 (default),
+        # lmz_central = mu > 0 selects the interior-point kernel that returns the central-path point of the reference's cone
+        # program at barrier parameter mu; a norm2 (circle) robot always uses it (default mu 1e-6)
+        self.lmz_central = kwargs.get("lmz_central", None)
+        self._be = make(cfg, G, h) if not self.lmz_central else self._make_central(make, cfg, G, h, float(self.lmz_central))
         self._R = G.shape[0]
         self.pipeline = True        # MPC overlaps its per-tick obstacle staging with the first su-problem (set False to serialise)
+
+    @staticmethod
+    def _make_central(make, cfg, G, h, mu):
+        """create the handle with the process-wide LamMuZ mode switched to the interior-point kernel, then switch it back"""
+        from ._lib import hip_api
+        if make is _hip_backend:
+            lib = hip_api().lib
+            lib.rda_set_lmz_mode(1, mu)
+            try:
+                return make(cfg, G, h)
+            finally:
+                lib.rda_set_lmz_mode(0, 1e-6)
+        return make(cfg, G, h)              # test backends select the mode themselves
 
     # ---- runtime tunables (reference :426-434, :1055-1056) ------------------------------
     def assign_adjust_parameter(self, **kwargs):

@@ -49,6 +49,14 @@ def rectangle_robot(length=4.6, width=1.6, wheelbase=3.0, dynamics="acker",
     return car(G, h, "Rpositive", wheelbase, list(max_speed), list(max_acce), dynamics)
 
 
+def circle_robot(radius=0.8, dynamics="diff", max_speed=(10, 1), max_acce=(10, 0.5)):
+    """Circle robot in the form the reference expects for `cone_type == 'norm2'` (rda_solver.py:1034-1039: ||mu[0:-1]|| <= -mu[-1];
+    the body {x: G x <=_K h} is the disc of `radius` around the origin, the same encoding mpc.py:440-446 uses for circle obstacles)."""
+    G = np.array([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0]])
+    h = np.array([[0.0], [0.0], [-float(radius)]])
+    return car(G, h, "norm2", 0, list(max_speed), list(max_acce), dynamics)
+
+
 def robot_vertices(car_tuple, state):
     """world-frame vertices (2xk) of a polygon robot at state (x, y, phi)"""
     G, h = np.asarray(car_tuple.G), np.asarray(car_tuple.h).ravel()
@@ -174,6 +182,26 @@ def _poly_sep(P, Q):
 
 def clearance(car_tuple, state, obstacles, t=0.0):
     """conservative robot/obstacle clearance (separating-axis for polygons, vertex/edge for circles)"""
+    if car_tuple.cone_type == "norm2":                     # circle robot: centre distance minus the radii
+        c0 = np.asarray(state, float).ravel()[0:2]
+        r0 = -float(np.asarray(car_tuple.h).ravel()[-1])
+        out = np.inf
+        for o in obstacles:
+            if o.cone_type == "norm2":
+                out = min(out, np.linalg.norm((o.center + o.velocity * t).ravel() - c0) - o.radius - r0)
+            else:
+                V = o.vertex + o.velocity * t
+                k = V.shape[1]
+                inside = True
+                d = np.inf
+                for i in range(k):
+                    a, b2 = V[:, i], V[:, (i + 1) % k]
+                    ab = b2 - a
+                    s_ = np.clip((c0 - a) @ ab / (ab @ ab), 0, 1)
+                    d = min(d, np.linalg.norm(a + s_ * ab - c0))
+                    inside = inside and (ab[0] * (c0[1] - a[1]) - ab[1] * (c0[0] - a[0])) >= 0
+                out = min(out, (-d if inside else d) - r0)
+        return out
     RV = robot_vertices(car_tuple, np.asarray(state, float).ravel())
     out = np.inf
     for o in obstacles:

@@ -222,10 +222,9 @@ def test_device_resident_replay_equals_host_steps(hip):
 
 def test_error_codes(hip):
     from rda_planner_amd._capi import Cfg
-    cfg = hp.make_cfg(T=10, N=4)
-    cfg.robot_norm2 = 1
+    cfg = hp.make_cfg(T=10, N=4, E=9)
     hnd = C.c_void_p()
-    assert hip.create(C.byref(cfg), dptr(hp.G), dptr(hp.H), C.byref(hnd)) == -2      # RDA_ERR_UNSUPPORTED
+    assert hip.create(C.byref(cfg), dptr(hp.G), dptr(hp.H), C.byref(hnd)) == -2      # RDA_ERR_UNSUPPORTED (E above the compiled limit)
     cfg = hp.make_cfg(T=200, N=4)
     assert hip.create(C.byref(cfg), dptr(hp.G), dptr(hp.H), C.byref(hnd)) == -2
     assert hip.lib.rda_enqueue_step(None, 0) == -1                                    # RDA_ERR_ARG

@@ -288,3 +288,49 @@ def test_golden_vectors(orc):
     ok = np.array(gold["unique"], bool)
     assert np.abs(lam - np.array(gold["lam"]))[ok].max() < 1e-8
     assert np.abs(mu - np.array(gold["mu"]))[ok].max() < 1e-8
+
+
+def test_ipm_norm2_robot_certifies_exactly_the_geometric_distance(orc):
+    """Known-answer test of the cone conventions of the interior-point restatement (oracle/lmz_ipm.c) for a CIRCLE robot
+    (car_tuple.cone_type == 'norm2', rda_solver.py:1034-1039): the sub-problem has optimal value 0 iff duals exist that certify
+    `distance(robot, obstacle) >= dbar` (Im >= 0 with H = 0), so the value must be ~0 for dbar just below the true distance and
+    positive just above it - for polygon and circle obstacles, any heading."""
+    import ctypes as C
+    from rda_planner_amd._capi import c_double_p, c_int_p, dptr
+    L = orc.lib
+    L.orc_lammuz_ipm_one.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, C.c_int, c_double_p, C.c_double, c_double_p,
+                                     c_double_p, c_double_p, C.c_double, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p,
+                                     c_double_p, c_double_p, c_int_p]
+    L.orc_lammuz_ipm_one.restype = C.c_int
+    L.orc_set_lmz_ipm_mu.argtypes = [C.c_double]
+    L.orc_set_lmz_ipm_mu(0.0)
+    r = 0.8
+    G = np.ascontiguousarray([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0]])
+    h = np.ascontiguousarray([0.0, 0.0, -r])
+    rng = np.random.default_rng(2)
+    for trial in range(12):
+        p = rng.uniform(-3, 3, 2)
+        phi = rng.uniform(-3, 3)
+        if trial % 2 == 0:          # polygon obstacle: distance from the centre to the polygon minus r
+            V = np.array([[4.0, 6.0, 6.5, 4.5], [-1.0, -1.5, 1.0, 1.5]]) + rng.uniform(-1, 1, (2, 1))
+            A, b = sc.polygon_halfspaces(V)
+            A, b, cone = np.ascontiguousarray(A), np.ascontiguousarray(b.ravel()), 0
+            k = V.shape[1]
+            dist = min(np.linalg.norm(V[:, i] + np.clip((p - V[:, i]) @ (V[:, (i + 1) % k] - V[:, i]) / np.sum((V[:, (i + 1) % k] - V[:, i]) ** 2), 0, 1)
+                                      * (V[:, (i + 1) % k] - V[:, i]) - p) for i in range(k)) - r
+            E = 4
+        else:                       # circle obstacle
+            c0, ro = rng.uniform(4, 7, 2), rng.uniform(0.3, 1.2)
+            A = np.ascontiguousarray([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0]]); b = np.ascontiguousarray([c0[0], c0[1], -ro]); cone = 1
+            dist = np.linalg.norm(c0 - p) - ro - r
+            E = 3
+        vals = []
+        for dbar in (dist - 0.01, dist + 0.01):
+            lo, mo, zo, cmh, it = np.zeros(E), np.zeros(3), C.c_double(0), np.zeros(4), C.c_int(0)
+            st = L.orc_lammuz_ipm_one(E, 3, dptr(A), dptr(b), cone, 1, dptr(np.ascontiguousarray(p)), float(phi), dptr(G), dptr(h), dptr(np.zeros(2)),
+                                      0.0, float(dbar), 50.0, 1, dptr(lo), dptr(mo), C.cast(C.byref(zo), c_double_p), dptr(cmh), C.cast(C.byref(it), c_int_p))
+            assert st in (0, 1), (trial, st)
+            assert np.hypot(mo[0], mo[1]) <= -mo[2] + 1e-7                      # mu in the robot's cone
+            vals.append(cmh[0])
+        assert vals[0] < 1e-9 and vals[1] > 2e-5, (trial, dist, vals)
+    L.orc_set_lmz_ipm_mu(1e-6)
