@@ -467,14 +467,17 @@ def main():
     # the LamMuZ kernel that was actually launched (rda_hip.hip launch_lammuz): packed rows when E+R+1 <= 16, the two-workgroup
     # build above 256 workgroups; RDA_LMZ_ROWS=0 selects the one-sub-problem-per-wave kernel
     lm_kernel = "k_lammuz"
-    n_loc = N // world if shard else N
-    if E + R + 1 <= 16 and os.environ.get("RDA_LMZ_ROWS", "1") != "0":
+    n_loc = -(-N // world) if shard else N
+    if os.environ.get("RDA_LMZ_MODE", "0") not in ("", "0"):
+        lm_kernel = "k_lammuz_cp_small" if E <= 4 and R <= 4 else "k_lammuz_cp_large"      # interior-point LamMuZ kernel (experiments)
+    elif E + R + 1 <= 16 and os.environ.get("RDA_LMZ_ROWS", "1") != "0":
         lm_kernel = "k_lammuz_rows_dense" if (n_loc * T + 15) // 16 > int(os.environ.get("RDA_LMZ_DENSE_FROM", "256")) else "k_lammuz_rows"
     r_lm = roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T)
     r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", kt["k_su"], 48 * N * T + 8 * (8 * (T + 1) + 5 * T))
     # latency roof of the su kernel: ONE workgroup (4 waves) on one CU walks a dependent chain; what bounds it is the length of
     # that chain, not bytes - stated next to the HBM fraction so the fraction is not read as a bandwidth problem
-    r_su["cus_occupied"], r_lm["cus_occupied"] = 1, min(256, (n_loc * T + 15) // 16 if lm_kernel != "k_lammuz" else (n_loc * T + 3) // 4)
+    r_su["cus_occupied"] = 1
+    r_lm["cus_occupied"] = min(256, {"k_lammuz": (n_loc * T + 3) // 4, "k_lammuz_cp_small": (n_loc * T + 63) // 64, "k_lammuz_cp_large": (n_loc * T + 63) // 64}.get(lm_kernel, (n_loc * T + 15) // 16))
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file):
         try:

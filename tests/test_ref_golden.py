@@ -1,0 +1,168 @@
+"""Reference-generated golden vectors (tests/golden/ref_*.npz, made by tests/golden/make_ref_golden.py from the UNMODIFIED
+reference running in the build container) against the oracle (CPU) and the HIP library (-m gpu).  Needs no reference checkout.
+
+ref_plumbing : every parameter of the reference's RDA_solver after every ADMM iteration of closed loops on C1, a padded scene,
+               C2, a C4-shaped moving scene and the north-star size (digests), with the two `prob.solve` calls answered by the
+               oracle's cold argmins.  The library under test is driven through the same C-ABI pieces as `rda_step`
+               (`*_upload_obstacles`, `*_admm_begin / su / lammuz / finish`, `*_get_state`).
+ref_problems : LamMuZ / su problems built by the reference's own construction code and solved by the generic interior-point
+               stand-in: the unique part of the answer.
+
+Tolerances: oracle vs fixture 1e-9 (same argmin functions, reference plumbing vs restated plumbing); HIP vs fixture 1e-4 on the
+state with the default (warm-started) su solve, the stated closed-loop tolerance of tests/test_gpu_baseline_sizes.py, and 5e-6
+with the su warm start switched off (cold against cold).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers as hp
+from rda_planner_amd import scenarios as sc
+from rda_planner_amd._capi import Info, dptr, iptr, f64
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = ("lam", "mu", "z", "xi", "zeta", "a_lam", "b_lam")
+SCENES = ("c1", "pad", "c2", "c4", "ns")
+
+
+def _projections(shape, seed=7):
+    return np.random.default_rng(seed).standard_normal((8, int(np.prod(shape))))
+
+
+def _car(dyn):
+    name = ["acker", "diff", "omni"][dyn]
+    return sc.rectangle_robot(dynamics=name, wheelbase=3.0 if name == "acker" else 0)
+
+
+def _replay(make_solver, name, tol_state, tol_u, digest_tol):
+    from rda_planner_amd.rda_solver import RDA_solver
+    g = np.load(os.path.join(GOLD, "ref_plumbing.npz"))
+    T, N, E, iter_num, ro1, dyn = (int(v) if i != 4 else float(v) for i, v in enumerate(g[f"{name}.cfg"]))
+    solver = make_solver(RDA_solver, T, _car(dyn), E, N, iter_num, ro1)
+    api, hd = solver._be.api, solver._be.handle
+    full = name != "ns"
+    worst = {}
+    for k in range(int(g[f"{name}.steps"])):
+        pre = f"{name}.{k}"
+        n_obs = int(g[f"{pre}.n_obs"])
+        if n_obs:
+            A, b, cone = f64(g[f"{pre}.A"]), f64(g[f"{pre}.b"]), np.ascontiguousarray(g[f"{pre}.cone"], np.int32)
+            assert api.upload_obstacles(hd, n_obs, dptr(A), dptr(b), iptr(cone), int(g[f"{pre}.per_t"])) == 0
+        else:
+            assert api.upload_obstacles(hd, 0, None, None, None, 0) == 0
+        assert api.admm_begin(hd, dptr(f64(g[f"{pre}.nom_s"])), dptr(f64(g[f"{pre}.nom_u"])), dptr(f64(g[f"{pre}.ref"])), float(g[f"{pre}.speed"])) == 0
+        want_iters, nit = int(g[f"{pre}.iters"]), 0
+        for it in range(iter_num):
+            stopped = C.c_int(0)
+            assert api.admm_su(hd, it, C.byref(stopped)) == 0
+            if stopped.value:
+                break
+            assert api.admm_lammuz(hd) == 0
+            out_u, out_s, inf = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+            assert api.admm_finish(hd, dptr(out_u), dptr(out_s), C.byref(inf)) == 0
+            assert it < want_iters, f"{pre}: iteration {it} runs here, the reference stopped after {want_iters}"
+            q = f"{pre}.it{it}"
+            st = solver.get_state()
+            worst["u"] = max(worst.get("u", 0), float(np.abs(out_u - g[f"{q}.u"]).max()), float(np.abs(out_s - g[f"{q}.s"]).max()),
+                             float(np.abs(st["dis"] - g[f"{q}.dis"]).max()))
+            rd, rp = g[f"{q}.resi"]
+            worst["resi"] = max(worst.get("resi", 0), abs(inf.resi_dual - rd) / (1 + abs(rd)), abs(inf.resi_pri - rp))
+            for key in KEYS:
+                v = st[key][:, 1:] if key in ("lam", "mu", "xi", "a_lam", "b_lam") else st[key]
+                if full:
+                    worst[key] = max(worst.get(key, 0), float(np.abs(v - g[f"{q}.{key}"]).max()))
+                else:
+                    P = _projections(v.shape)
+                    d = np.abs(P @ v.ravel() - g[f"{q}.{key}"]) / np.sqrt(v.size)          # per-entry scale of a random projection
+                    worst[key] = max(worst.get(key, 0), float(d.max()))
+            nit += 1
+        assert nit == want_iters, f"{pre}: {nit} iterations here, {want_iters} in the reference run"
+    bad = {k_: v for k_, v in worst.items() if v > (tol_u if k_ in ("u", "resi") else (tol_state if full else digest_tol))}
+    assert not bad, (name, bad)
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU: the oracle against the reference-generated vectors
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def cold_orc(orc):
+    orc.lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
+    orc.lib.orc_set_su_warm(0.0, 0.0, 0)
+    yield orc
+    orc.lib.orc_set_su_warm(1e-3, 1e-3, 30)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_reproduces_reference_plumbing(cold_orc, name):
+    from oracle.oracle_backend import oracle_backend
+
+    def make(RDA_solver, T, car_t, E, N, iter_num, ro1):
+        return RDA_solver(T, car_t, E, N, iter_num=iter_num, time_print=False, ro1=ro1, _backend=oracle_backend)
+    _replay(make, name, 1e-9, 1e-9, 1e-9)
+
+
+def test_oracle_argmins_on_reference_built_problems(orc):
+    g = np.load(os.path.join(GOLD, "ref_problems.npz"))
+    inp = {k: np.ascontiguousarray(g[f"lmz.{k}"]) for k in ("A", "b", "p", "phi", "xi", "zeta", "dbar")}
+    inp["cone"] = np.ascontiguousarray(g["lmz.cone"], np.int32)
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, inp, G=np.ascontiguousarray(g["lmz.G"]), h=np.ascontiguousarray(g["lmz.h"]))
+    _check_lmz(g, z, cmh)
+    for k in range(int(g["su.count"])):
+        cfg, si = _su_case(g, k)
+        st, s, u, d, it = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+        assert st == 0 and max(np.abs(s - g[f"su.{k}.s"]).max(), np.abs(u - g[f"su.{k}.u"]).max(), np.abs(d - g[f"su.{k}.d"]).max()) < 2e-6
+
+
+def _check_lmz(g, z, cmh):
+    m = cmh[:, 1] - z
+    cost = 0.5 * np.minimum(m, 0.0) ** 2 + 0.5 * (cmh[:, 2] ** 2 + cmh[:, 3] ** 2)
+    assert np.abs(cost - g["lmz.cost"]).max() < 1e-6
+    assert np.abs(np.minimum(m, 0.0) - g["lmz.mneg"]).max() < 2e-5 and np.abs(cmh[:, 2:4] - g["lmz.H"]).max() < 2e-5    # delta = 1e-6 clearance reward
+
+
+def _su_case(g, k):
+    dyn = int(g[f"su.{k}.dyn"])
+    T, N = g[f"su.{k}.nom_u"].shape[1], g[f"su.{k}.a"].shape[0]
+    cfg = hp.make_cfg(T=T, N=N, dynamics=dyn, ro1=200, L=3.0 if dyn == 0 else 0.0)
+    si = {key: np.ascontiguousarray(g[f"su.{k}.{key}"], float) for key in ("nom_s", "nom_u", "ref", "a", "cc", "g", "d0")}
+    si["vref"] = 4.0
+    return cfg, si
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP library against the same vectors
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_hip_reproduces_reference_plumbing(name):
+    def make(RDA_solver, T, car_t, E, N, iter_num, ro1):
+        return RDA_solver(T, car_t, E, N, iter_num=iter_num, time_print=False, ro1=ro1)
+    w = _replay(make, name, 1e-4, 1e-4, 1e-4)
+    print(name, {k: f"{v:.1e}" for k, v in w.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_hip_reproduces_reference_plumbing_cold_su(name, monkeypatch):
+    """interior-point warm start of the su-problem off (RDA_SU_WARM=0,0,0, read at rda_create): cold against cold"""
+    monkeypatch.setenv("RDA_SU_WARM", "0,0,0")
+
+    def make(RDA_solver, T, car_t, E, N, iter_num, ro1):
+        return RDA_solver(T, car_t, E, N, iter_num=iter_num, time_print=False, ro1=ro1)
+    _replay(make, name, 5e-6, 5e-6, 5e-6)
+
+
+@pytest.mark.gpu
+def test_hip_argmins_on_reference_built_problems(hip):
+    g = np.load(os.path.join(GOLD, "ref_problems.npz"))
+    inp = {k: np.ascontiguousarray(g[f"lmz.{k}"]) for k in ("A", "b", "p", "phi", "xi", "zeta", "dbar")}
+    inp["cone"] = np.ascontiguousarray(g["lmz.cone"], np.int32)
+    lam, mu, z, cmh = hp.hip_lammuz_batch(hip, inp, G=np.ascontiguousarray(g["lmz.G"]), h=np.ascontiguousarray(g["lmz.h"]))
+    _check_lmz(g, z, cmh)
+    for k in range(int(g["su.count"])):
+        cfg, si = _su_case(g, k)
+        st, s, u, d, it = hp.su_solve(hip.lib.rda_su_solve, cfg, si)
+        assert st == 0 and max(np.abs(s - g[f"su.{k}.s"]).max(), np.abs(u - g[f"su.{k}.u"]).max(), np.abs(d - g[f"su.{k}.d"]).max()) < 2e-6
