@@ -4,10 +4,13 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
  * product path (rda_planner_amd/) never does.
  *
- * PARITY UNPINNED: the reference solves its two convex sub-problems with CVXPY 1.5.2 ->
- * ECOS (rda_solver.py:693,768,800); neither is installable in the build image and the
- * reference ships no tests / golden vectors.  The restatement is pinned
- * instead by KKT certificates and scipy cross-checks (tests/test_oracle_*.py).
+ * PARITY (round 2): the reference solves its two convex sub-problems with CVXPY 1.5.2 -> ECOS (rda_solver.py:693,768,800),
+ * neither installable in the build image, and ships no tests / golden vectors.  The restatement is pinned on the
+ * UNMODIFIED reference modules executing in the build container on a cvxpy / pathos stand-in (oracle/refshim, ref_harness.py,
+ * tests/test_reference_pinned.py, fixtures tests/golden/ref_*.npz): the ADMM plumbing per iteration (<= 1e-11) and both argmins
+ * in everything that is unique (su: s, u, d; LamMuZ: value, min(Im, 0), Hm).  What stays unpinned BY CONSTRUCTION is the non-unique
+ * part of the LamMuZ answer (lam, mu, z individually in the slack regime): no two interior-point solvers agree on it.
+ * Also pinned by KKT certificates, scipy cross-checks and geometric known-answer tests (tests/test_oracle_*.py).
  */
 #ifndef RDA_ORACLE_H
 #define RDA_ORACLE_H
@@ -23,7 +26,7 @@ typedef struct {
     int dynamics;     /* 0 acker, 1 diff, 2 omni       rda_solver.py:446-451 */
     int accelerated;  /*                               rda_solver.py:47  */
     int iter_num;     /*                               rda_solver.py:42  */
-    int robot_norm2;  /* car_tuple.cone_type=='norm2'  (unsupported -> error) */
+    int robot_norm2;  /* car_tuple.cone_type=='norm2'  (interior-point LamMuZ mode only, orc_set_lmz_mode(1)) */
     double dt, L;
     double max_speed[2];   /* rda_solver.py:37 */
     double acce_bound[2];  /* max_acce*dt, rda_solver.py:44 */

@@ -214,9 +214,11 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int w = block * 4 + wv;
     const bool live = w < d.Nlive * T;
-    // unit w -> (stage, slot) with the SLOT fastest: the rows of a wave / the waves of a block then write neighbouring entries of
-    // the [T][Nloc] condensed-term arrays (an 8-byte store per array and row; with the stage fastest every store was its own sector)
-    const int nl = live ? w % d.Nlive : 0, t = live ? w / d.Nlive : 0;
+    // unit w -> (slot, stage) with the STAGE fastest: a wave's rows then read neighbouring (n, t) rows of the reference-shaped dual
+    // arrays.  Measured alternative (slot fastest, so that the [T][Nloc] condensed-term stores of a block form whole lines): WRITE_SIZE
+    // 1.48 -> 1.04 MB per launch but FETCH_SIZE 0.71 -> 1.87 MB (the 128-byte lines of lam / mu / xi are then shared by blocks on
+    // different XCDs and fetched once per L2), same launch time - the kernel is latency-bound either way
+    const int nl = live ? w / T : 0, t = live ? w % T : 0;
     const int n = d.rank * d.Nloc + nl;                        // this rank's obstacle shard [rank*Nloc, (rank+1)*Nloc)
     lmz::WaveLDS &W = wl[wv];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
@@ -336,7 +338,7 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     const int w0 = block * 16 + wv * 4 + row;
     const bool live = w0 < d.Nlive * T;
     const int w = live ? w0 : block * 16;                      // a row past the end shadows a live one and writes nothing
-    const int nl = w % d.Nlive, t = w / d.Nlive;             // slot fastest: see lammuz_body
+    const int nl = w / T, t = w % T;                          // stage fastest: see lammuz_body
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
