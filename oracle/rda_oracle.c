@@ -37,6 +37,13 @@ void orc_set_su_warm(double wfl, double mu0, int cap) { g_su_warm_wfl = wfl; g_s
 /* end game of a WARM-started su solve: floor of the fraction to the boundary and of the centering parameter (cold: 0.995, 1e-3) */
 static double g_su_warm_tau = 0.9999, g_su_warm_sig = 1e-5;
 void orc_set_su_warm_endgame(double tau, double sig) { g_su_warm_tau = tau; g_su_warm_sig = sig; }
+/* relative margin by which the start of a WARM attempt is pulled inside the control / distance boxes (cold: 0.01) */
+static double g_su_warm_clip = 0.01;
+void orc_set_su_warm_clip(double m) { g_su_warm_clip = m; }
+/* start used while the su-solves are easy (the last one took <= max iterations): wfl, mu0, clip, tau, sigma; max = 0 disables */
+static double g_su_easy[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; static int g_su_easy_max = 2;
+static double cur_warm_tau = 0.9999, cur_warm_sig = 1e-5, cur_warm_clip = 0.01;     /* what the warm attempt of the solve in progress uses */
+void orc_set_su_easy(double wfl, double mu0, double clip, double tau, double sig, int max) { g_su_easy[0] = wfl; g_su_easy[1] = mu0; g_su_easy[2] = clip; g_su_easy[3] = tau; g_su_easy[4] = sig; g_su_easy_max = max; }
 static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};   /* interior-point stop of the su-problem: rd, rp, mu */
 void orc_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
 static int g_lmz_mode = 0;   /* 0: support enumeration + tie-breaks T1-T3, 1: interior point (oracle/lmz_ipm.c) */
@@ -57,6 +64,7 @@ struct orc_handle {
     double *ref, ref_speed;        /* step inputs */
     int stop, iters, su_status, ipm_total, lmz_fail; double resi_dual, resi_pri;
     double *su_lam_keep;          /* inequality multipliers of the last converged su-solve (10T - 4 rows) */
+    int su_last;                  /* interior-point iterations of the last su-solve (99: none / not converged): picks the next warm start */
     int P, rank, Nloc, have_gath; size_t chunk; double *gath;      /* obstacle sharding */
 };
 
@@ -695,11 +703,13 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
     const double wfl = attempt < 0 ? warm_wfl : (attempt ? 1e-1 : 1e-2), mu0 = attempt < 0 ? warm_mu0 : (attempt ? 10.0 : 1.0);
     const int it_cap = attempt < 0 ? warm_cap : 100;
     for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
-        double v = nom_u[i * T + t], lim = 0.99 * c->max_speed[i];
+        const double clipm = attempt < 0 ? cur_warm_clip : 0.01;
+        double v = nom_u[i * T + t], lim = (1.0 - clipm) * c->max_speed[i];
         x[2 * t + i] = v > lim ? lim : (v < -lim ? -lim : v);
     }
     for (int t = 0; t < T; ++t) {
-        double v = d0 ? d0[t] : c->max_sd, lo = c->min_sd + 0.01 * (c->max_sd - c->min_sd), hi = c->max_sd - 0.01 * (c->max_sd - c->min_sd);
+        const double clipm = attempt < 0 ? cur_warm_clip : 0.01;
+        double v = d0 ? d0[t] : c->max_sd, lo = c->min_sd + clipm * (c->max_sd - c->min_sd), hi = c->max_sd - clipm * (c->max_sd - c->min_sd);
         x[2 * T + t] = v > hi ? hi : (v < lo ? lo : v);
     }
     for (int i = 0; i < mc; ++i) {
@@ -770,13 +780,13 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
                 mu_aff /= mc;
                 /* centering parameter from the predictor step length, floored: the classical (mu_aff/mu)^3
                  * rule can cycle on the piecewise-quadratic hinge terms (observed with ro1 = 1) */
-                { double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? g_su_warm_sig : SIGMA_FLOOR) : 0.03;
+                { double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? cur_warm_sig : SIGMA_FLOOR) : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl; }
             }
         }
         /* fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game) */
-        const double tau_min = attempt < 0 ? g_su_warm_tau : 0.995;
+        const double tau_min = attempt < 0 ? cur_warm_tau : 0.995;
         double al = 1.0, tau = 1.0 - mu; if (tau < tau_min) tau = tau_min;
         for (int i = 0; i < mc; ++i) {
             if (dw[i] < 0 && -tau * w[i] / dw[i] < al) al = -tau * w[i] / dw[i];
@@ -828,7 +838,7 @@ int orc_create(const orc_cfg *cfg, const double *G, const double *h, orc_handle 
     H->s = calloc(3 * (T + 1), sizeof(double)); H->u = calloc(2 * T, sizeof(double));
     H->resp = calloc((size_t)2 * N * T, sizeof(double)); H->ref = calloc(3 * (T + 1), sizeof(double));
     H->P = 1; H->rank = 0; H->Nloc = N; H->chunk = (size_t)8 * T * N; H->gath = NULL; H->have_gath = 0;
-    H->su_lam_keep = calloc((size_t)10 * T, sizeof(double));
+    H->su_lam_keep = calloc((size_t)10 * T, sizeof(double)); H->su_last = 99;
     *out = H; return 0;
 }
 void orc_destroy(orc_handle *H)
@@ -979,8 +989,13 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
     /* ADMM iterations >= 1 start from the multipliers of the previous su-solve of this step, if that one converged */
     /* ... and the first one from those of the previous step, shifted by one stage */
     const int warm = g_su_warm_mu0 > 0 && (it > 0 ? !((H->su_status >> (it - 1)) & 1) : g_su_warm_first);
+    /* while the su-solves are easy (the last one took <= max iterations) the warm attempt starts 1e-6 from the previous solution's
+     * active bounds and takes near-full steps - the same rule as csrc/rda_hip.hip su_body */
+    const int easy = warm && g_su_easy_max > 0 && H->su_last <= g_su_easy_max;
+    cur_warm_clip = easy ? g_su_easy[2] : g_su_warm_clip; cur_warm_tau = easy ? g_su_easy[3] : g_su_warm_tau; cur_warm_sig = easy ? g_su_easy[4] : g_su_warm_sig;
     int st = su_solve_impl(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm,
-                           H->su_lam_keep, warm, g_su_warm_wfl, g_su_warm_mu0, g_su_warm_cap, it == 0);
+                           H->su_lam_keep, warm, easy ? g_su_easy[0] : g_su_warm_wfl, easy ? g_su_easy[1] : g_su_warm_mu0, g_su_warm_cap, it == 0);
+    H->su_last = st == 0 ? ipm : 99;
     H->ipm_total += ipm;
     if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
     else H->su_status |= 1 << it;                 /* 'No update of state and control vector' :699 */

@@ -104,7 +104,9 @@ int  orc_lammuz_one(int E, int R, const double *A, const double *b, int cone_nor
 /* interior-point start of the su-problems of ADMM iterations >= 1 inside orc_step / orc_admm_su (defaults 1e-3, 1e-3, 30; 0,0,0 = cold);
  * orc_su_solve itself always starts cold */
 void orc_set_su_warm(double wfl, double mu0, int cap);
-void orc_set_su_warm_endgame(double tau_floor, double sigma_floor);   /* warm attempts only; cold solves keep 0.995 / 1e-3 */
+void orc_set_su_warm_endgame(double tau_floor, double sigma_floor);
+void orc_set_su_warm_clip(double margin);
+void orc_set_su_easy(double wfl, double mu0, double clip, double tau, double sig, int max_iters);   /* mirror of RDA_SU_EASY */   /* warm attempts: relative margin of the start inside the boxes (cold: 0.01) */   /* warm attempts only; cold solves keep 0.995 / 1e-3 */
 /* interior-point stop of the su-problem: |r_dual| <= rd (1+|g|), |r_prim| <= rp, mean complementarity <= mu (1+|g|) */
 void orc_set_su_tol(double rd, double rp, double mu);
 int  orc_su_solve(const orc_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,

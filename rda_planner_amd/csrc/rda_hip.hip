@@ -30,6 +30,7 @@
 
 struct Ctrl {
     int stop, iters, su_status, ipm_iters, st_tmp, it_tmp;
+    int su_last;             // interior-point iterations of the last su-solve of this handle (99 = it did not converge): picks the next start
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
 #ifdef RDA_LMZ_STATS
@@ -51,6 +52,9 @@ struct Dev {
     int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
+    double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
+                                       // interior-point iterations; RDA_SU_EASY="wfl,mu0,clip,tau,sigma,max", max = 0 disables)
+    double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (RDA_SU_WARM_CLIP; cold 0.01)
     double su_warm_tau, su_warm_sig;   // end game of the warm attempt (RDA_SU_WARM_ENDGAME="tau,sigma" floors; cold solves: 0.995, 1e-3)
     double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
     int lmz_mode;            // 0: support enumeration + tie-breaks T1-T3 (default), 1: interior point, central path at lmz_mu (norm2 robots: always)
@@ -127,13 +131,20 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
-    a.lam_keep = d.su_lam_keep; a.warm_tau = d.su_warm_tau; a.warm_sig = d.su_warm_sig;
+    a.lam_keep = d.su_lam_keep; a.warm_tau = d.su_warm_tau; a.warm_sig = d.su_warm_sig; a.warm_clip = d.su_warm_clip;
+    // While consecutive su-problems are close (static scenes: the previous solve needed one or two iterations) the warm attempt starts
+    // 1e-6 from the previous solution's active bounds with its multipliers and takes near-full steps: ONE iteration + the
+    // convergence pass.  After a solve that needed more (moving obstacles, a changed active set) the moderate start above is used.
+    if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
+        a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
+    }
     su::solve<TT>(a, smem_su);
     __syncthreads();
     if (tid == 0) {
         d.ctrl->iters = it + 1;
         if (d.ctrl->st_tmp != 0) d.ctrl->su_status |= 1 << it;
         d.ctrl->ipm_iters += d.ctrl->it_tmp;
+        d.ctrl->su_last = d.ctrl->st_tmp == 0 ? d.ctrl->it_tmp : 99;
     }
 }
 
@@ -721,7 +732,10 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     { const char *e = getenv("RDA_LMZ_MODE"); if (e && !cfg->robot_norm2) H->d.lmz_mode = atoi(e) ? 1 : 0; }
     { const char *e = getenv("RDA_LMZ_MU"); if (e) H->d.lmz_mu = atof(e); }
     H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
-    H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5;
+    H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5; H->d.su_warm_clip = 0.01;
+    { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) H->d.su_easy[i] = ez[i]; H->d.su_easy_max = 2; }
+    { const char *e = getenv("RDA_SU_EASY"); if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%d", &H->d.su_easy[0], &H->d.su_easy[1], &H->d.su_easy[2], &H->d.su_easy[3], &H->d.su_easy[4], &H->d.su_easy_max); }
+    { const char *e = getenv("RDA_SU_WARM_CLIP"); if (e) H->d.su_warm_clip = atof(e); }
     { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &H->d.su_warm_tau, &H->d.su_warm_sig); }
     { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &H->d.su_warm_wfl, &H->d.su_warm_mu0, &H->d.su_warm_cap); }
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = g_su_tol[i];
@@ -753,6 +767,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     rc |= dalloc(&H->d_out_u, res_doubles(T));
     if (!rc) { H->d_out_s = H->d_out_u + 2 * T; H->d_info = (rda_info *)(H->d_out_s + 3 * (T + 1)); H->d_trk = (track::Out *)(H->d_out_s + 3 * (T + 1) + 4); }
     if (rc) { rda_destroy(H); return RDA_ERR_HIP; }
+    { const int hard = 99; HIPCHK(hipMemcpy(&d.ctrl->su_last, &hard, sizeof(int), hipMemcpyHostToDevice)); }     // no su history yet
     HIPCHK(hipMemcpy(d.G, G, 2 * R * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d.h, h, R * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double> ones(T, 1.0);                                       // para_dis init, rda_solver.py:119

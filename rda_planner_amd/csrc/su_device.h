@@ -64,6 +64,7 @@ struct Args {
     // to the solution (the dual residual is at rounding level after one step), what is left is driving the complementarity down;
     // with the cold floors (0.995, 1e-3) that takes three iterations from mu ~ 1e-2, with these two.
     double warm_tau = 0.9999, warm_sig = 1e-5;
+    double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
     double *lam_keep = nullptr;
 };
 
@@ -323,20 +324,22 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     }
     mark(12);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
-    auto clip_controls = [&]() {
+    auto clip_controls = [&](const double clipm) {
         if (tid < T) {
             int t = tid;
-            double lim0 = 0.99 * c.umax0, lim1 = 0.99 * c.umax1;
+            double lim0 = (1.0 - clipm) * c.umax0, lim1 = (1.0 - clipm) * c.umax1;
             double v0 = a.in_u[t], v1 = a.in_u[T + t];
             L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
             L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
-            double lo = c.min_sd + 0.01 * (c.max_sd - c.min_sd), hi = c.max_sd - 0.01 * (c.max_sd - c.min_sd);
+            double lo = c.min_sd + clipm * (c.max_sd - c.min_sd), hi = c.max_sd - clipm * (c.max_sd - c.min_sd);
             double dv = a.d_in ? a.d_in[t] : c.max_sd;
             L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
         }
         __syncthreads();
     };
-    clip_controls();
+    // a warm attempt starts next to the previous solution: pulled inside the boxes by warm_clip only (a cold start by 1 %), so that the
+    // kept multipliers of the active rows meet slacks of that size and the start is already nearly complementary
+    clip_controls(a.warm_mu0 > 0 && a.lam_keep != nullptr ? a.warm_clip : 0.01);
     // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
     // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
     // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
@@ -579,7 +582,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     for (int attempt = warm ? -1 : 0; attempt < 2 && status != 0; ++attempt) {
     if (attempt == 1 || (attempt == 0 && warm)) {
         __syncthreads();
-        clip_controls();
+        clip_controls(0.01);
         rollout();
         __syncthreads();
         if (attempt == 1) { screened = false; centre_duals(1e-1, 10.0); }
