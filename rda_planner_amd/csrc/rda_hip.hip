@@ -52,6 +52,7 @@ struct Dev {
     int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
+    int su_light;                        // su_device Cfg::light_check
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
                                        // interior-point iterations; RDA_SU_EASY="wfl,mu0,clip,tau,sigma,max", max = 0 disables)
     double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (RDA_SU_WARM_CLIP; cold 0.01)
@@ -121,7 +122,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
     a.c.ab0 = d.c.acce_bound[0]; a.c.ab1 = d.c.acce_bound[1]; a.c.ws = d.c.ws; a.c.wu = d.c.wu;
     a.c.slack_gain = d.c.slack_gain; a.c.max_sd = d.c.max_sd; a.c.min_sd = d.c.min_sd; a.c.ro1 = d.c.ro1; a.c.ro2 = d.c.ro2;
-    a.c.eps_u = d.c.eps_u; a.c.tol_rd = d.su_tol[0]; a.c.tol_rp = d.su_tol[1]; a.c.tol_mu = d.su_tol[2];
+    a.c.eps_u = d.c.eps_u; a.c.tol_rd = d.su_tol[0]; a.c.tol_rp = d.su_tol[1]; a.c.tol_mu = d.su_tol[2]; a.c.light_check = d.su_light;
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
     a.ref = ref; a.ref_speed = ref_speed;
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
@@ -734,6 +735,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
     H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5; H->d.su_warm_clip = 0.01;
     { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) H->d.su_easy[i] = ez[i]; H->d.su_easy_max = 2; }
+    H->d.su_light = 1;
+    { const char *e = getenv("RDA_SU_LIGHT"); if (e) H->d.su_light = atoi(e); }
     { const char *e = getenv("RDA_SU_EASY"); if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%d", &H->d.su_easy[0], &H->d.su_easy[1], &H->d.su_easy[2], &H->d.su_easy[3], &H->d.su_easy[4], &H->d.su_easy_max); }
     { const char *e = getenv("RDA_SU_WARM_CLIP"); if (e) H->d.su_warm_clip = atof(e); }
     { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &H->d.su_warm_tau, &H->d.su_warm_sig); }
