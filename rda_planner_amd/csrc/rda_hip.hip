@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
 #include <dlfcn.h>
 #include "../../include/rda_hip.h"
 #include "lammuz_device.h"
@@ -170,7 +171,20 @@ __device__ __forceinline__ void finish_body(const Dev &d, double *out_u, double 
     }
 }
 
-__global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double *out_s, rda_info *info) { finish_body(d, out_u, out_s, info); }
+// `mirror` (pinned host memory, may be null): the whole result slot [u | s | info | track out] is also written straight into the
+// caller-visible host block and published with a sequence number (system-scope release) - the host polls that word instead of
+// queueing a device-to-host copy and waiting for the stream (rda_handle::wait_result).
+__global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double *out_s, rda_info *info, double *mirror, unsigned long long seq)
+{
+    finish_body(d, out_u, out_s, info);
+    if (!mirror) return;
+    __syncthreads();
+    const int n = 2 * d.c.T + 3 * (d.c.T + 1) + 6;          // out_u, out_s, info (4 doubles) and the track::Out (2) are one contiguous slot
+    for (int i = threadIdx.x; i < n; i += su::NT) mirror[i] = out_u[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long *)(mirror + n), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ void begin_body(const Dev &d)
 {
@@ -636,6 +650,7 @@ struct rda_handle {
     double *d_step;                                       // device copy of the above (slot 0 of the step path)
     double *d_out_u, *d_out_s; rda_info *d_info;          // result slot of the step path
     double *h_out; rda_info *h_info;                      // pinned
+    unsigned long long res_seq; int zero_copy;           // result mirror written by k_finish (see there); RDA_ZERO_COPY=0: D2H copy + stream sync
     int *h_stop = nullptr;                                // pinned copy of the early-stop flag (sharded handles with a communicator)
     // trace path
     int K; double *d_tr_s, *d_tr_u, *d_tr_ref, *d_tr_speed, *d_tr_out_u, *d_tr_out_s; rda_info *d_tr_info;
@@ -782,6 +797,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     HIPCHK(hipHostMalloc((void **)&H->h_stage_cone, N * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&H->h_step, step_n * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&H->h_out, res_doubles(T) * sizeof(double)));
+    memset(H->h_out, 0, res_doubles(T) * sizeof(double)); H->res_seq = 0; H->zero_copy = 1;
+    { const char *e = getenv("RDA_ZERO_COPY"); if (e) H->zero_copy = atoi(e); }
     H->h_info = (rda_info *)(H->h_out + 2 * T + 3 * (T + 1)); H->h_trk = (track::Out *)(H->h_out + 2 * T + 3 * (T + 1) + 4);
     H->su_lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds)));
@@ -998,6 +1015,37 @@ static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, c
     RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
     if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
 }
+// Final kernel of a step and the hand-over of its result slot to the host block h_out.  Zero-copy form: k_finish writes the block
+// itself and the host polls the sequence word behind it (everything queued before k_finish on the stream has completed by then);
+// after 20 ms without it - or with the timing events on, or RDA_ZERO_COPY=0 - the stream is synchronised the ordinary way, which
+// also surfaces a device fault.
+static int launch_finish(rda_handle *H, const Dev &d, double *out_u, double *out_s, rda_info *info)
+{
+    const bool zc = H->zero_copy && !H->timing && out_u == H->d_out_u;
+    if (zc) H->res_seq += 1;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, out_u, out_s, info, zc ? H->h_out : nullptr, H->res_seq);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+static int fetch_result(rda_handle *H)
+{
+    const size_t T = H->d.c.T;
+    if (H->zero_copy && !H->timing) {
+        volatile unsigned long long *flag = (volatile unsigned long long *)(H->h_out + 2 * T + 3 * (T + 1) + 6);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            if (*flag == H->res_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return RDA_OK; }
+            __builtin_ia32_pause();
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        HIPCHK(hipStreamSynchronize(H->stream));
+        if (*flag == H->res_seq) return RDA_OK;
+        return RDA_ERR_HIP;
+    }
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    return RDA_OK;
+}
 static int enqueue_admm_head(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed)
 {
     Dev d = H->d;
@@ -1030,9 +1078,7 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
             if (nrc != 0) { fprintf(stderr, "librda_hip: ncclAllGather failed (%d)\n", nrc); return RDA_ERR_HIP; }
         }
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, out_u, out_s, info);
-    HIPCHK(hipGetLastError());
-    return RDA_OK;
+    return launch_finish(H, d, out_u, out_s, info);
 }
 static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
                         double *out_u, double *out_s, rda_info *info)
@@ -1061,8 +1107,8 @@ static int step_common(rda_handle *H, const double *nom_s, const double *nom_u, 
     HIPCHK(hipMemcpyAsync(H->d_step, H->h_step, (2 * ns + nu + 1) * sizeof(double), hipMemcpyHostToDevice, H->stream));
     rc = enqueue_admm(H, H->d_step, H->d_step + ns, H->d_step + ns + nu, H->d_step + ns + nu + ns, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) return rc;
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipStreamSynchronize(H->stream));
+    rc = fetch_result(H);
+    if (rc != RDA_OK) return rc;
     memcpy(out_u, H->h_out, nu * sizeof(double));
     memcpy(out_s, H->h_out + nu, ns * sizeof(double));
     if (info) *info = *H->h_info;
@@ -1160,9 +1206,12 @@ extern "C" int rda_tracked_finish(rda_handle *H, double *out_u, double *out_s, r
     H->pending = 0; H->pending_scene = 0; H->scene_on_s2 = 0;
     int rc = enqueue_admm_tail(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu, H->d_out_u, H->d_out_s, H->d_info);
     if (rc != RDA_OK) { (void)hipStreamSynchronize(H->stream); return rc; }
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    if (nom_s_out || ref_out) HIPCHK(hipMemcpyAsync(H->h_step, H->d_step, (2 * ns + nu) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipStreamSynchronize(H->stream));
+    if (nom_s_out || ref_out) {
+        HIPCHK(hipMemcpyAsync(H->h_step, H->d_step, (2 * ns + nu) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+        HIPCHK(hipStreamSynchronize(H->stream));
+    }
+    rc = fetch_result(H);
+    if (rc != RDA_OK) return rc;
     if (out_u) memcpy(out_u, H->h_out, nu * sizeof(double));
     if (out_s) memcpy(out_s, H->h_out + nu, ns * sizeof(double));
     if (info) *info = *H->h_info;
@@ -1439,10 +1488,8 @@ extern "C" int rda_admm_finish(rda_handle *H, double *out_u, double *out_s, rda_
     if (!H || !out_u || !out_s) return RDA_ERR_ARG;
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     Dev d = H->d;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, H->d_out_u, H->d_out_s, H->d_info);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
-    HIPCHK(hipStreamSynchronize(H->stream));
+    { int rc = launch_finish(H, d, H->d_out_u, H->d_out_s, H->d_info); if (rc != RDA_OK) return rc; }
+    { int rc = fetch_result(H); if (rc != RDA_OK) return rc; }
     memcpy(out_u, H->h_out, nu * sizeof(double));
     memcpy(out_s, H->h_out + nu, ns * sizeof(double));
     if (info) *info = *H->h_info;
