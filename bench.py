@@ -12,7 +12,9 @@ Ackermann rectangle robot, T=20, N_obs=200 static polygons, E=4, synthetic seede
 Protocol: closed loop, W warm-up steps, then EXACTLY K steps, each one a C-ABI call that takes the
 robot state and returns the control with ONE host synchronisation at its end (`rda_step_tracked`: MPC.pre_process, the
 ADMM loop and the D2H of the control on the device; the host applies the control to the kinematic model and calls
-again).  The obstacle scene is resident in HBM when the timed region starts (static scene: staged once with
+again).  The caller of those K steps is C (tools/closed_loop_host.c, loaded here): C-ABI calls and the kinematic model only, no
+interpreter objects between two steps; `python_caller_closed_loop` is the same loop written with ctypes / numpy.
+The obstacle scene is resident in HBM when the timed region starts (static scene: staged once with
 `rda_upload_scene`).  `value` = K / wall time of those K steps (max over ranks); `median_ms_per_step` is the median of
 the K per-step wall times.  Reported beside it, never as `value`:
   * `pcie_inclusive`        - the same loop with the raw scene (vertices, velocities) handed over from host memory on
@@ -244,16 +246,38 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def closed_loop_host():
+        """tools/libclosed_loop_host.so (built by __graft_entry__.build()): the caller's loop in C, entry points of librda_hip.so handed over"""
+        so = os.path.join(ROOT, "tools", "libclosed_loop_host.so")
+        if not os.path.exists(so):
+            import __graft_entry__
+            __graft_entry__.build_host_driver()
+        lib = C.CDLL(so)
+
+        class Api(C.Structure):
+            _fields_ = [(n_, C.c_void_p) for n_ in ("step_tracked", "tracked_begin", "upload_scene_async", "tracked_finish")]
+
+        class Scene(C.Structure):
+            _fields_ = [("n", C.c_int32), ("maxv", C.c_int32), ("order", C.c_int32), ("moving", C.c_int32), ("kind", C.POINTER(C.c_int32)),
+                        ("nvert", C.POINTER(C.c_int32)), ("geom", C.POINTER(C.c_double)), ("geom0", C.POINTER(C.c_double)), ("vel", C.POINTER(C.c_double))]
+        a = Api(*[C.cast(getattr(api.lib, "rda_" + n_), C.c_void_p).value for n_ in ("step_tracked", "tracked_begin", "upload_scene_async", "tracked_finish")])
+        lib.closed_loop_run.restype = C.c_int
+        lib.closed_loop_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        return type("Host", (), {"run": lib.closed_loop_run, "api": a, "Scene": Scene})
+
     def new_solver():
         sv = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
         make_sharded(sv)
         return sv
 
     # ---- HEADLINE: closed loop through the C-ABI, one host synchronisation per MPC step -------------------------------
-    def cabi_closed_loop(per_tick_scene):
+    def cabi_closed_loop(per_tick_scene, driver="c"):
         """state in / control out per step; scene resident in HBM (per_tick_scene False) or handed over from host memory on every
-        tick (True, BASELINE.md 2.4 'including H2D of obstacles').  Returns (elapsed of the K timed steps, per-step times,
-        max |u - recorded Python closed loop|, iterations per step)."""
+        tick (True, BASELINE.md 2.4 'including H2D of obstacles').  driver "c": the loop is tools/closed_loop_host.c (C-ABI calls and the
+        kinematic model in C, nothing of the interpreter between two steps); "python": the same loop written with ctypes / numpy.
+        Returns (elapsed of the K timed steps, per-step times, max |u - recorded Python closed loop|, iterations per step)."""
         sv = new_solver()
         hh = sv._be.handle
         scene = sv.flatten_scene(list(obstacles))
@@ -273,6 +297,29 @@ def main():
         cur, du, its, times = 0, 0.0, [], []
         L, wb = car_t.wheelbase, car_t.dynamics
         t_start = 0.0
+        if driver == "c":
+            host = closed_loop_host()
+            scn = host.Scene(int(n_sc) if per_tick_scene else 0, int(geom.shape[1]), order, int(bool(args.moving)), iptr(kind), iptr(nvert),
+                             dptr(geom), dptr(geom0), dptr(vel))
+            cur_c = C.c_int32(0)
+            u_log, t_log, it_log = np.zeros((W + K, 2)), np.zeros(W + K), np.zeros(W + K, np.int32)
+            dyn = {"acker": 0, "diff": 1, "omni": 2}[wb]
+
+            def run(k0, n):
+                rc = host.run(C.byref(host.api), hh, C.byref(scn), T, dyn, float(L or 0.0), 0.1, 4.0, 0.1, 10, len(path), k0, n, dptr(nom_u0),
+                              dptr(state), C.byref(cur_c), dptr(u_log[k0:]), dptr(t_log[k0:]), iptr(it_log[k0:]), None)
+                assert rc == 0, ("workload invalid: the robot reached the goal inside the timed region" if rc == 1 else rc)
+            run(0, W)
+            api.lib.rda_sync(hh)
+            barrier_all()
+            t_start = time.perf_counter()
+            run(W, K)
+            api.lib.rda_sync(hh)
+            barrier_all()
+            el = max_over_ranks(time.perf_counter() - t_start)
+            if not args.moving:
+                du = float(np.abs(u_log - np.array([trace["u"][k].ravel() for k in range(W + K)])).max())
+            return el, t_log[W:].copy(), du, [int(v) for v in it_log[W:]]
         for k in range(W + K):
             if k == W:
                 api.lib.rda_sync(hh)
@@ -315,6 +362,12 @@ def main():
         el_h, times_h, du_h, its_h = cabi_closed_loop(per_tick_scene=bool(args.moving))
         head = {"elapsed": el_h, "median_ms": float(np.median(times_h) * 1e3), "du": du_h, "iters": its_h}
         pcie = None
+        pydrv = None
+        if rank == 0 and world == 1:
+            el_y, times_y, du_y, _ = cabi_closed_loop(per_tick_scene=bool(args.moving), driver="python")
+            pydrv = {"steps_per_s": round(K / el_y, 2), "median_ms_per_step": round(float(np.median(times_y) * 1e3), 5),
+                     "max_du_vs_python_closed_loop": du_y if not args.moving else None,
+                     "what": "the headline loop with the caller written in Python (ctypes calls + numpy kinematics between two steps)"}
         if rank == 0 and not args.moving:
             el_p, times_p, du_p, _ = cabi_closed_loop(per_tick_scene=True) if world == 1 else (None, None, None, None)
             if el_p is not None:
@@ -497,9 +550,10 @@ def main():
               "what": "recorded step inputs replayed back-to-back on the device, no per-step host synchronisation"}
     if head is not None:
         value, ms_step = K * world / head["elapsed"], head["elapsed"] / K * 1e3
-        protocol = ("closed loop through the C-ABI: per step rda_step_tracked(state) -> control, one host sync per step, host applies the "
-                    "control to the kinematic model; scene resident in HBM" if not args.moving else
-                    "closed loop through the C-ABI, obstacles advance every tick: rda_tracked_begin + rda_upload_scene_async + rda_tracked_finish per step")
+        protocol = ("closed loop through the C-ABI, caller in C (tools/closed_loop_host.c): per step rda_step_tracked(state) -> control, one host "
+                    "sync per step, host applies the control to the kinematic model; scene resident in HBM" if not args.moving else
+                    "closed loop through the C-ABI, caller in C (tools/closed_loop_host.c), obstacles advance every tick: rda_tracked_begin + "
+                    "rda_upload_scene_async + rda_tracked_finish per step")
     else:                   # obstacle shards: the RCCL path is driven by the replay (every rank enqueues the same steps)
         value, ms_step, protocol = replay["steps_per_s"], replay["ms_per_step"], replay["what"]
     out = {
@@ -513,6 +567,7 @@ def main():
         "max_du_vs_python_closed_loop": head["du"] if head and not args.moving else None,
         "mean_admm_iters": round(float(np.mean(head["iters"])) if head else mean_iters, 3),
         "pcie_inclusive": pcie if head else None,
+        "python_caller_closed_loop": pydrv if head else None,
         "device_resident_replay": replay,
         "python_api_closed_loop": {"host_obstacle_staging_steps_per_s": round(1.0 / trace["closed_loop_s_per_step"], 2),
                                    "device_obstacles": cl_dev, "device_obstacles_and_tracking": cl_trk},
