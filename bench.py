@@ -420,6 +420,26 @@ def main():
     barrier_all()
     elapsed2 = max_over_ranks(time.perf_counter() - t0)
 
+    # the same replay with one host synchronisation per step: how long the host needs to queue a step (all launches of one MPC step)
+    # and what a step costs when the device starts from an empty stream - the latency floor of the closed loop
+    solver3 = new_solver()
+    h3 = solver3._be.handle
+    api.lib.rda_upload_obstacles(h3, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+    api.lib.rda_upload_trace(h3, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"]))
+    t_enq, t_tot = [], []
+    for k in range(W + K):
+        ta = time.perf_counter()
+        api.lib.rda_enqueue_step(h3, k)
+        tb = time.perf_counter()
+        api.lib.rda_sync(h3)
+        tc = time.perf_counter()
+        if k >= W:
+            t_enq.append(tb - ta)
+            t_tot.append(tc - ta)
+    sync_replay = {"median_ms_per_step": round(float(np.median(t_tot)) * 1e3, 5), "median_host_enqueue_ms": round(float(np.median(t_enq)) * 1e3, 5),
+                   "what": "replay with rda_sync after every step: host time to queue one step's launches, and the step latency from an idle stream"}
+    del solver3
+
     # replay must reproduce the recorded closed loop (same inputs, same initial state)
     u_last = np.zeros((2, T))
     s_last = np.zeros((3, T + 1))
@@ -547,7 +567,8 @@ def main():
     env_switches = {k: v for k, v in os.environ.items() if k.startswith("RDA_")}
     replay = {"steps_per_s": round(K * (1 if shard else world) / elapsed2, 3), "ms_per_step": round(elapsed2 / K * 1e3, 5),
               "instrumented_ms_per_step": round(elapsed / K * 1e3, 5), "max_du_vs_python_closed_loop": replay_err,
-              "what": "recorded step inputs replayed back-to-back on the device, no per-step host synchronisation"}
+              "what": "recorded step inputs replayed back-to-back on the device, no per-step host synchronisation",
+              "synchronised_per_step": sync_replay}
     if head is not None:
         value, ms_step = K * world / head["elapsed"], head["elapsed"] / K * 1e3
         protocol = ("closed loop through the C-ABI, caller in C (tools/closed_loop_host.c): per step rda_step_tracked(state) -> control, one host "

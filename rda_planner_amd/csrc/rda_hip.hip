@@ -34,6 +34,7 @@ struct Ctrl {
     int su_last;             // interior-point iterations of the last su-solve of this handle (99 = it did not converge): picks the next start
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
+    unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
 #endif
@@ -100,7 +101,8 @@ __device__ void reduce_residuals(const Dev &d, double *red, int tid)
 extern __shared__ __attribute__((aligned(16))) double smem_su[];
 
 template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s, const double *in_u,
-                                                           const double *ref, const double *ref_speed)
+                                                           const double *ref, const double *ref_speed,
+                                                           const unsigned long long *ref_flag = nullptr, unsigned long long ref_seq = 0)
 {
     const int tid = threadIdx.x;
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
@@ -125,7 +127,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.c.slack_gain = d.c.slack_gain; a.c.max_sd = d.c.max_sd; a.c.min_sd = d.c.min_sd; a.c.ro1 = d.c.ro1; a.c.ro2 = d.c.ro2;
     a.c.eps_u = d.c.eps_u; a.c.tol_rd = d.su_tol[0]; a.c.tol_rp = d.su_tol[1]; a.c.tol_mu = d.su_tol[2]; a.c.light_check = d.su_light;
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
-    a.ref = ref; a.ref_speed = ref_speed;
+    a.ref = ref; a.ref_speed = ref_speed; a.ref_flag = ref_flag; a.ref_seq = ref_seq;
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
@@ -604,6 +606,9 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a
                                                     case 25: { constexpr int TT = 25; CALL; } break; case 30: { constexpr int TT = 30; CALL; } break; \
                                                     default: { constexpr int TT = 0; CALL; } break; } } while (0)
 
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su_tracked(Dev d, track::In in, double *path, int L, const double *nom_u, double *step,
+                                                                          track::Out *out, unsigned long long seq);
+
 // [N][T+1][2] / [N][T+1] <-> [T][N] transposes for the state accessors
 __global__ void k_products_get(Dev d, double *a_lam, double *b_lam)
 {
@@ -660,6 +665,8 @@ struct rda_handle {
     int (*p_comm_destroy)(void *);
     // a tick opened by rda_tracked_begin and not yet closed by rda_tracked_finish
     int pending, pending_scene; const double *pending_in_u;
+    int tick_stages, tick_has_event;     // see rda_tracked_begin
+    int fuse_track; size_t su_trk_lds; unsigned long long trk_seq;    // k_su_tracked (RDA_FUSE_TRACK=0: k_track and k_su as two launches)
     hipStream_t stream2; hipEvent_t ev_tick, ev_scene; int scene_on_s2;   // in-tick scene staging runs beside the first su-problem
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
@@ -803,6 +810,10 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     H->su_lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds)));
     HIPCHK(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
+    H->su_trk_lds = H->su_lds > track::LDS_DOUBLES * sizeof(double) ? H->su_lds : track::LDS_DOUBLES * sizeof(double);
+    RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_tracked<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_trk_lds)));
+    H->fuse_track = 1; H->tick_stages = 0; H->tick_has_event = 0; H->trk_seq = 0;
+    { const char *e = getenv("RDA_FUSE_TRACK"); if (e) H->fuse_track = atoi(e); }
     *out = H;
     return RDA_OK;
 }
@@ -1144,6 +1155,32 @@ __global__ void k_track(Dev d, track::In in, double *path, int L, const double *
     track::run(e, in, *out, win, threadIdx.x);
 }
 
+// k_track and the first su-problem of the step as ONE launch of two workgroups.  Workgroup 0: wave 0 rolls the nominal out (the
+// only part of pre_process the su set-up needs), then the su-problem starts; workgroup 1 samples the reference from the path
+// meanwhile (closest_point, inter_point: 20 dependent searches, ~12 us) and publishes it under the tick number; the solve picks it
+// up after its set-up (su::Args::ref_flag).  Same arithmetic as k_track followed by k_su<TT>(it = 0).
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su_tracked(Dev d, track::In in, double *path, int L, const double *nom_u, double *step,
+                                                                          track::Out *out, unsigned long long seq)
+{
+    const int T = d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    track::Ego e;
+    e.path = path; e.L = L; e.nom_u = nom_u; e.nom_s = step; e.ref = step + ns + nu; e.speed = step + 2 * ns + nu;
+    e.T = T; e.dynamics = d.c.dynamics; e.dt = d.c.dt; e.wheelbase = d.c.L;
+    if (blockIdx.x == 1) {
+        if (threadIdx.x < 64) {
+            track::run(e, in, *out, smem_su, threadIdx.x, 2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (threadIdx.x == 0) __hip_atomic_store(&d.ctrl->ref_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (threadIdx.x < 64) track::run(e, in, *out, smem_su, threadIdx.x, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    su_body<TT>(d, 0, step, nom_u, d.ref, d.ref_speed, &d.ctrl->ref_seq, seq);
+}
+
 extern "C" int rda_upload_path(rda_handle *H, int L, const double *path)
 {
     if (!H || L < 1 || !path) return RDA_ERR_ARG;
@@ -1168,10 +1205,26 @@ extern "C" int rda_tracked_begin(rda_handle *H, const double *state, double ref_
     }
     track::In in; in.sx = state[0]; in.sy = state[1]; in.sth = state[2]; in.speed = ref_speed; in.threshold = threshold;
     in.cur_index = cur_index; in.ind_range = ind_range;
-    HIPCHK(hipEventRecord(H->ev_tick, H->stream));      // everything queued before this tick: the in-tick scene staging starts behind it
-    hipLaunchKernelGGL(k_track, dim3(1), dim3(64), 0, H->stream, H->d, in, H->d_path, H->path_len, in_u, H->d_step, H->d_trk);
-    int rc = enqueue_admm_head(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu);
-    if (rc != RDA_OK) return rc;
+    // everything queued before this tick: an in-tick scene staging (rda_upload_scene_async) starts behind this event, beside the first
+    // su-problem.  Recorded only for callers that stage inside their ticks (learned from the previous tick); a first in-tick staging
+    // without it orders itself behind the head of the tick instead.
+    H->tick_has_event = 0;
+    if (H->tick_stages) { HIPCHK(hipEventRecord(H->ev_tick, H->stream)); H->tick_has_event = 1; }
+    H->tick_stages = 0;
+    if (H->fuse_track) {
+        Dev d = H->d;
+        d.ref = H->d_step + ns + nu; d.ref_speed = H->d_step + 2 * ns + nu;
+        if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
+        H->trk_seq += 1;
+        RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su_tracked<TT>, dim3(2), dim3(su::NT), H->su_trk_lds, H->stream, d, in, H->d_path, H->path_len,
+                                                   in_u, H->d_step, H->d_trk, H->trk_seq));
+        if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
+        HIPCHK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_track, dim3(1), dim3(64), 0, H->stream, H->d, in, H->d_path, H->path_len, in_u, H->d_step, H->d_trk);
+        int rc = enqueue_admm_head(H, H->d_step, in_u, H->d_step + ns + nu, H->d_step + 2 * ns + nu);
+        if (rc != RDA_OK) return rc;
+    }
     H->pending = 1; H->pending_in_u = in_u;
     return RDA_OK;
 }
@@ -1190,6 +1243,8 @@ extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind,
     }
     // inside a tick: the copy and the conversion kernels touch only the obstacle slots, which nothing of the head (k_track,
     // the first su-problem) reads - they run on the second stream BESIDE the first su-problem; rda_tracked_finish joins
+    if (!H->tick_has_event) { HIPCHK(hipEventRecord(H->ev_tick, H->stream)); H->tick_has_event = 1; }
+    H->tick_stages = 1;
     HIPCHK(hipStreamWaitEvent(H->stream2, H->ev_tick, 0));
     int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false, H->stream2);
     if (rc == RDA_OK && n > 0) { HIPCHK(hipEventRecord(H->ev_scene, H->stream2)); H->pending_scene = 1; H->scene_on_s2 = 1; }

@@ -67,6 +67,9 @@ struct Args {
     double warm_tau = 0.9999, warm_sig = 1e-5;
     double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
     double *lam_keep = nullptr;
+    // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
+    // fetched after the set-up, once *ref_flag == ref_seq (agent scope)
+    const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
 };
 
 __device__ __forceinline__ void wsync()
@@ -235,7 +238,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     const bool ract = rt < T;
 
     // ---- load nominal, reference; linearise -------------------------------------------------
-    for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; L.ref[i] = a.ref[i]; }
+    for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; if (!a.ref_flag) L.ref[i] = a.ref[i]; }
     for (int i = tid; i < 2 * T; i += NT) L.u[i] = a.in_u[i];
     for (int i = tid; i < 2 * T; i += NT) L.p0[i] = a.in_s[(i / T) * (T + 1) + (i % T) + 1];      // nominal positions of stages 1..T
     __syncthreads();
@@ -575,6 +578,13 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     // 0.1, mu0 = 10) and every hinge term in play.
     int status = 1, it = 0, used = 0;
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
+    if (a.ref_flag) {
+        if (tid == 0) while (__hip_atomic_load(a.ref_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.ref_seq) __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int i = tid; i < 3 * (T + 1); i += NT) L.ref[i] = a.ref[i];
+        __syncthreads();
+    }
     mark(9);
     // Attempts: [-1: the warm start, at most warm_cap = 30 iterations.  Where consecutive su-problems are close (static scenes) it
     // converges within 3-4; with many moving obstacles it needs as many iterations as the cold start (8-20) but does arrive:
