@@ -34,6 +34,7 @@ struct Ctrl {
     int su_last;             // interior-point iterations of the last su-solve of this handle (99 = it did not converge): picks the next start
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
+    int finished, pad_;           // the result slot of this step has been written (by the su launch that detected the early stop)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -100,15 +101,42 @@ __device__ void reduce_residuals(const Dev &d, double *red, int tid)
 
 extern __shared__ __attribute__((aligned(16))) double smem_su[];
 
+// Where a step's result goes: the device slot [u | s | info | track out] (one contiguous block starting at out_u), and optionally
+// `mirror` (pinned host memory): the same block written straight into the caller-visible host buffer and published with a
+// sequence number (system-scope release) - the host polls that word instead of queueing a device-to-host copy and waiting for
+// the stream (fetch_result).
+struct Fin { double *out_u, *out_s; rda_info *info; double *mirror; unsigned long long seq; };
+
+// all threads of a 256-thread workgroup; the residuals in d.ctrl are final
+__device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
+{
+    const int tid = threadIdx.x, T = d.c.T;
+    for (int i = tid; i < 2 * T; i += su::NT) f.out_u[i] = d.u[i];
+    for (int i = tid; i < 3 * (T + 1); i += su::NT) f.out_s[i] = d.s[i];
+    if (tid == 0) {
+        f.info->resi_dual = d.ctrl->resi_dual; f.info->resi_pri = d.ctrl->resi_pri;
+        f.info->iters = d.ctrl->iters; f.info->su_status = d.ctrl->su_status; f.info->su_ipm_iters = d.ctrl->ipm_iters;
+        f.info->lmz_fail = d.ctrl->lmz_fail;
+    }
+    if (!f.mirror) return;
+    __syncthreads();
+    const int n = 2 * T + 3 * (T + 1) + 6;                   // out_u, out_s, info (4 doubles) and the track::Out (2)
+    for (int i = tid; i < n; i += su::NT) f.mirror[i] = f.out_u[i];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store((unsigned long long *)(f.mirror + n), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s, const double *in_u,
                                                            const double *ref, const double *ref_speed,
-                                                           const unsigned long long *ref_flag = nullptr, unsigned long long ref_seq = 0)
+                                                           const unsigned long long *ref_flag = nullptr, unsigned long long ref_seq = 0,
+                                                           const Fin *fin = nullptr)
 {
     const int tid = threadIdx.x;
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
         if (tid == 0) {
             d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
+            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0;
         }
         __syncthreads();
     } else if (d.ctrl->stop) return;
@@ -117,6 +145,12 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
         if (d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold) {   // rda_solver.py:594
             __syncthreads();
             if (tid == 0) d.ctrl->stop = 1;
+            // The step ends here (rda_solver.py:594-596): hand the result over now - the launches still queued behind this one return
+            // at once and k_finish finds the slot written.
+            if (fin && fin->out_u) {
+                publish_result(d, *fin);
+                if (tid == 0) d.ctrl->finished = 1;
+            }
             return;
         }
     }
@@ -152,47 +186,27 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     }
 }
 
-template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u)
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u, Fin fin)
 {
-    su_body<TT>(d, it, in_s, in_u, d.ref, d.ref_speed);
+    su_body<TT>(d, it, in_s, in_u, d.ref, d.ref_speed, nullptr, 0, &fin);
 }
 
-// final bookkeeping of a step: residuals of the last executed iteration, result slot
-__device__ __forceinline__ void finish_body(const Dev &d, double *out_u, double *out_s, rda_info *info)
+// final bookkeeping of a step that ran all its iterations: residuals of the last one, result slot
+__device__ __forceinline__ void finish_body(const Dev &d, const Fin &f)
 {
-    const int tid = threadIdx.x;
-    if (!d.ctrl->stop) reduce_residuals(d, smem_su, tid);
+    if (d.ctrl->finished) return;                   // (uniform) the early stop already handed the result over
+    if (!d.ctrl->stop) reduce_residuals(d, smem_su, threadIdx.x);
     __syncthreads();
-    const int T = d.c.T;
-    for (int i = tid; i < 2 * T; i += su::NT) out_u[i] = d.u[i];
-    for (int i = tid; i < 3 * (T + 1); i += su::NT) out_s[i] = d.s[i];
-    if (tid == 0) {
-        info->resi_dual = d.ctrl->resi_dual; info->resi_pri = d.ctrl->resi_pri;
-        info->iters = d.ctrl->iters; info->su_status = d.ctrl->su_status; info->su_ipm_iters = d.ctrl->ipm_iters;
-        info->lmz_fail = d.ctrl->lmz_fail;
-    }
+    publish_result(d, f);
 }
 
-// `mirror` (pinned host memory, may be null): the whole result slot [u | s | info | track out] is also written straight into the
-// caller-visible host block and published with a sequence number (system-scope release) - the host polls that word instead of
-// queueing a device-to-host copy and waiting for the stream (rda_handle::wait_result).
-__global__ __launch_bounds__(su::NT) void k_finish(Dev d, double *out_u, double *out_s, rda_info *info, double *mirror, unsigned long long seq)
-{
-    finish_body(d, out_u, out_s, info);
-    if (!mirror) return;
-    __syncthreads();
-    const int n = 2 * d.c.T + 3 * (d.c.T + 1) + 6;          // out_u, out_s, info (4 doubles) and the track::Out (2) are one contiguous slot
-    for (int i = threadIdx.x; i < n; i += su::NT) mirror[i] = out_u[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long *)(mirror + n), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+__global__ __launch_bounds__(su::NT) void k_finish(Dev d, Fin f) { finish_body(d, f); }
 
 __device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
         d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0;
+        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0;
     }
 }
 
@@ -666,7 +680,8 @@ struct rda_handle {
     // a tick opened by rda_tracked_begin and not yet closed by rda_tracked_finish
     int pending, pending_scene; const double *pending_in_u;
     int tick_stages, tick_has_event;     // see rda_tracked_begin
-    int fuse_track; size_t su_trk_lds; unsigned long long trk_seq;    // k_su_tracked (RDA_FUSE_TRACK=0: k_track and k_su as two launches)
+    int fuse_track; size_t su_trk_lds; unsigned long long trk_seq;
+    int early_finish;                     // the su launch that detects the early stop writes the result slot (RDA_EARLY_FINISH=0: k_finish does)    // k_su_tracked (RDA_FUSE_TRACK=0: k_track and k_su as two launches)
     hipStream_t stream2; hipEvent_t ev_tick, ev_scene; int scene_on_s2;   // in-tick scene staging runs beside the first su-problem
     // timing
     int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
@@ -814,6 +829,8 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_tracked<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_trk_lds)));
     H->fuse_track = 1; H->tick_stages = 0; H->tick_has_event = 0; H->trk_seq = 0;
     { const char *e = getenv("RDA_FUSE_TRACK"); if (e) H->fuse_track = atoi(e); }
+    H->early_finish = 1;
+    { const char *e = getenv("RDA_EARLY_FINISH"); if (e) H->early_finish = atoi(e); }
     *out = H;
     return RDA_OK;
 }
@@ -1019,22 +1036,27 @@ static void launch_lammuz(rda_handle *H, const Dev &d)
 // The ADMM loop of one MPC step in two parts.  The HEAD (the first su-problem, which also resets the step's control block) reads the nominal trajectory and the
 // condensed terms of the PREVIOUS step (quirk Q4) but nothing of the staged obstacles, so a caller may stage this tick's
 // obstacles on the stream between head and tail while the first su-problem is being solved (rda_tracked_begin/_finish).
-static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, const double *in_u)
+static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, const double *in_u, const Fin &fin = Fin{nullptr, nullptr, nullptr, nullptr, 0})
 {
     const int T = d.c.T;
     if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
-    RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u));
+    RDA_SU_DISPATCH(T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, in_s, in_u, fin));
     if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
 }
-// Final kernel of a step and the hand-over of its result slot to the host block h_out.  Zero-copy form: k_finish writes the block
-// itself and the host polls the sequence word behind it (everything queued before k_finish on the stream has completed by then);
-// after 20 ms without it - or with the timing events on, or RDA_ZERO_COPY=0 - the stream is synchronised the ordinary way, which
-// also surfaces a device fault.
-static int launch_finish(rda_handle *H, const Dev &d, double *out_u, double *out_s, rda_info *info)
+// Hand-over of a step's result slot to the host block h_out.  Zero-copy form: the launch that ends the step (the su launch that
+// detects the early stop, else k_finish) writes the block itself and the host polls the sequence word behind it.  Everything the
+// step queued before that launch has completed by then; what is still queued behind it are launches that return at once.
+// After 20 ms without the word - or with the timing events on, or RDA_ZERO_COPY=0 - the stream is synchronised the ordinary
+// way, which also surfaces a device fault.
+static Fin make_fin(rda_handle *H, double *out_u, double *out_s, rda_info *info)
 {
     const bool zc = H->zero_copy && !H->timing && out_u == H->d_out_u;
     if (zc) H->res_seq += 1;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, out_u, out_s, info, zc ? H->h_out : nullptr, H->res_seq);
+    return Fin{ out_u, out_s, info, zc ? H->h_out : nullptr, H->res_seq };
+}
+static int launch_finish(rda_handle *H, const Dev &d, const Fin &fin)
+{
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, fin);
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
@@ -1070,8 +1092,9 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
 {
     Dev d = H->d;                                     // taken AFTER the obstacles of this tick were staged (nt, obstacle_num)
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
+    const Fin fin = make_fin(H, out_u, out_s, info);  // the su launch that detects the early stop hands the result over itself
     for (int it = 0; it < d.c.iter_num; ++it) {
-        if (it > 0) launch_su(H, d, it, in_s, in_u);
+        if (it > 0) launch_su(H, d, it, in_s, in_u, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0});
         if (it > 0 && H->comm) {
             // The early stop (rda_solver.py:594) is a device flag and kernels queued behind it return at once - a collective
             // cannot: with a communicator the host reads the flag after the su-problem (one small D2H + sync per iteration,
@@ -1089,7 +1112,7 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
             if (nrc != 0) { fprintf(stderr, "librda_hip: ncclAllGather failed (%d)\n", nrc); return RDA_ERR_HIP; }
         }
     }
-    return launch_finish(H, d, out_u, out_s, info);
+    return launch_finish(H, d, fin);
 }
 static int enqueue_admm(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed,
                         double *out_u, double *out_s, rda_info *info)
@@ -1520,7 +1543,7 @@ extern "C" int rda_admm_su(rda_handle *H, int it, int *stopped)
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     Dev d = H->d;
     d.ref = H->d_step + ns + nu; d.ref_speed = H->d_step + ns + nu + ns;
-    RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns));
+    RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns, Fin{nullptr, nullptr, nullptr, nullptr, 0}));
     HIPCHK(hipGetLastError());
     if (stopped) {
         Ctrl c;
@@ -1543,7 +1566,7 @@ extern "C" int rda_admm_finish(rda_handle *H, double *out_u, double *out_s, rda_
     if (!H || !out_u || !out_s) return RDA_ERR_ARG;
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     Dev d = H->d;
-    { int rc = launch_finish(H, d, H->d_out_u, H->d_out_s, H->d_info); if (rc != RDA_OK) return rc; }
+    { int rc = launch_finish(H, d, make_fin(H, H->d_out_u, H->d_out_s, H->d_info)); if (rc != RDA_OK) return rc; }
     { int rc = fetch_result(H); if (rc != RDA_OK) return rc; }
     memcpy(out_u, H->h_out, nu * sizeof(double));
     memcpy(out_s, H->h_out + nu, ns * sizeof(double));
@@ -1579,7 +1602,8 @@ __global__ __launch_bounds__(su::NT) void k_finish_fleet(const Dev *devs, const 
     const Dev &d = devs[blockIdx.x];
     const EgoIO e = io[blockIdx.x];
     const size_t ns = 3 * (d.c.T + 1), nu = 2 * d.c.T;
-    finish_body(d, e.out_u + k * nu, e.out_s + k * ns, e.info + k);
+    const Fin f = { e.out_u + k * nu, e.out_s + k * ns, e.info + k, nullptr, 0 };
+    finish_body(d, f);
 }
 
 struct rda_fleet {
