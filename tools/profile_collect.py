@@ -16,30 +16,26 @@ for name in os.listdir(src):
     if name.endswith((".csv", ".txt", ".json")) and os.path.getsize(os.path.join(src, name)) > 0:
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 
-# HBM traffic per executed launch: PMC totals over ALL dispatches of the pass / the executed dispatches of that pass
+# HBM traffic per EXECUTED launch: rocprofv3 lists the counter per dispatch; tools/profile_round.sh separates the dispatches that
+# ran (moved more than a fifth of the largest one) from those queued behind the early-stop flag, which move nothing
 pm = open(os.path.join(src, "pmc_fetch_write.txt")).read()
 detail, out = {}, {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    bj = json.loads(open(os.path.join(src, f"bench_pmc_{counter}.json")).read())
-    for key, roof in (("k_su", bj["roofline"]), ("k_lammuz", bj["roofline_secondary"])):
-        if not roof["kernel"].startswith(key):
-            roof = bj["roofline_secondary"] if roof is bj["roofline"] else bj["roofline"]
-        frac = roof["launches"] / max(roof["launches"] + roof["skipped_launches"], 1)
-        m = re.search(rf"{counter} (?:void )?{re.escape(roof['kernel'])}: dispatches (\d+) total ([\d.]+)", pm)
+    for key, pat in (("k_su", r"k_su<\d+>"), ("k_lammuz", r"k_lammuz\w*")):
+        m = re.search(rf"{counter} (?:void )?({pat}): dispatches (\d+) total ([\d.]+) per-dispatch [\d.]+ executed (\d+) per-executed ([\d.]+)", pm)
         if not m:
             continue
-        disp, total_kb = int(m.group(1)), float(m.group(2))
-        executed = disp * frac
-        d = detail.setdefault(roof["kernel"], {})
-        d[counter.lower() + "_kb_total"], d["dispatches"], d["executed_fraction"] = total_kb, disp, round(frac, 4)
-        d[counter.lower() + "_bytes_per_executed_launch"] = round(total_kb * 1024 / executed)
+        d = detail.setdefault(m.group(1), {})
+        d["dispatches"], d["executed_" + counter.lower()] = int(m.group(2)), int(m.group(4))
+        d[counter.lower() + "_kb_total"] = float(m.group(3))
+        d[counter.lower() + "_bytes_per_executed_launch"] = round(float(m.group(5)) * 1024)
         out[key] = out.get(key, 0) + d[counter.lower() + "_bytes_per_executed_launch"]
 nj = json.loads(open(os.path.join(src, "bench_pmc_FETCH_SIZE.json")).read())
 m = re.search(r"T=(\d+), N_obs=(\d+)", nj["metric"])
 traffic = {
     "_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each with --kernel-trace only (tools/profile_round.sh). rocprofv3 reports KB; "
-                "bytes per EXECUTED launch = counter total over all dispatches of the pass / (dispatches x executed fraction): launches queued "
-                "behind the early-stop flag move no data. The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to wide (16 B/lane) "
+                "bytes per EXECUTED launch = mean over the dispatches that moved more than a fifth of the largest dispatch of that kernel (launches queued "
+                "behind the early-stop flag move no data). The first su-problem of a tracked tick is the kernel k_su_tracked<T> (listed in the pmc file, same solve). The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to wide (16 B/lane) "
                 "streaming reads only; these kernels read 8 B/lane, so the raw value is kept (uncalibrated for this width). Working set << L2, "
                 "Infinity-Cache hits are counted by these counters.",
     "source": f"profiles/{tag}_pmc_fetch_write.txt",

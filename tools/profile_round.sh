@@ -26,14 +26,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python - "$D/counters.csv" $C >> "$OUT/pmc_fetch_write.txt" <<'PY'
 import csv, sys, collections
 path, cname = sys.argv[1], sys.argv[2]
-tot = collections.defaultdict(float); cnt = collections.Counter()
+vals = collections.defaultdict(list)
 try:
     for row in csv.DictReader(open(path)):
         if row.get("Counter_Name") == cname:
-            k = row["Kernel_Name"].split("(")[0]
-            tot[k] += float(row["Counter_Value"]); cnt[k] += 1
-    for k in tot:
-        print(f"{cname} {k}: dispatches {cnt[k]} total {tot[k]:.1f} per-dispatch {tot[k]/cnt[k]:.3f}")
+            vals[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+    for k, v in vals.items():
+        # launches queued behind the early-stop flag return at once and move (almost) nothing: an EXECUTED dispatch is one that
+        # moved more than a fifth of the largest dispatch of that kernel
+        ex = [x for x in v if x > 0.2 * max(v)] or v
+        print(f"{cname} {k}: dispatches {len(v)} total {sum(v):.1f} per-dispatch {sum(v)/len(v):.3f} executed {len(ex)} per-executed {sum(ex)/len(ex):.3f}")
 except Exception as e:
     print("parse failed", e)
 PY
