@@ -145,6 +145,10 @@ int  rda_timing_launches(rda_handle *h, int which, double *ms_out, int cap, int 
  * nom_u: the nominal controls [2][T] (MPC.cur_vel_array), or NULL = the controls of the previous solve, which are
  * still resident (what cur_vel_array holds unless the caller replaced it).  min_index = the new MPC.cur_index.
  * nom_s_out / ref_out (may be NULL) return the 3x(T+1) nominal states / reference the solver was given. */
+/* Number of polygons of the scene the LAST completed step ran on that fail the reference's convexity test (mpc.py:476-549 prints
+ * "Warning: The polygon constructed by vertex is not convex" for each); 0 when the obstacles were staged as (A, b) slots.  Travels
+ * with the step's result, costs no synchronisation (rda_upload_scene's n_nonconvex is the synchronous form). */
+int  rda_last_nonconvex(rda_handle *h);
 int  rda_upload_path(rda_handle *h, int L, const double *path /*L*3*/);
 int  rda_step_tracked(rda_handle *h, const double *state /*3*/, double ref_speed, int cur_index, double threshold, int ind_range,
                       const double *nom_u, double *out_u, double *out_s, rda_info *info,

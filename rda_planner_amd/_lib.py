@@ -40,6 +40,8 @@ def hip_api():
         lib.rda_strerror.argtypes = [C.c_int]
         lib.rda_set_lmz_mode.argtypes = [C.c_int, C.c_double]
         lib.rda_set_lmz_mode.restype = None
+        lib.rda_last_nonconvex.argtypes = [C.c_void_p]
+        lib.rda_last_nonconvex.restype = C.c_int
         lib.rda_set_su_tol.argtypes = [C.c_double] * 3
         lib.rda_set_su_tol.restype = None
         lib.rda_shard_unique_id.argtypes = [C.c_void_p, C.c_void_p]

@@ -56,6 +56,7 @@ struct Dev {
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
     int su_light;                        // su_device Cfg::light_check
+    int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
                                        // interior-point iterations; RDA_SU_EASY="wfl,mu0,clip,tau,sigma,max", max = 0 disables)
     double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (RDA_SU_WARM_CLIP; cold 0.01)
@@ -105,7 +106,7 @@ extern __shared__ __attribute__((aligned(16))) double smem_su[];
 // `mirror` (pinned host memory): the same block written straight into the caller-visible host buffer and published with a
 // sequence number (system-scope release) - the host polls that word instead of queueing a device-to-host copy and waiting for
 // the stream (fetch_result).
-struct Fin { double *out_u, *out_s; rda_info *info; double *mirror; unsigned long long seq; };
+struct Fin { double *out_u, *out_s; rda_info *info; double *mirror; unsigned long long seq; int slot; };   // slot: out_u is the handle's contiguous result slot
 
 // all threads of a 256-thread workgroup; the residuals in d.ctrl are final
 __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
@@ -118,9 +119,11 @@ __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
         f.info->iters = d.ctrl->iters; f.info->su_status = d.ctrl->su_status; f.info->su_ipm_iters = d.ctrl->ipm_iters;
         f.info->lmz_fail = d.ctrl->lmz_fail;
     }
+    // polygons of the staged scene that failed the reference's convexity test (mpc.py:476-549 prints a warning per polygon)
+    if (f.slot && tid == 1) *(long long *)(f.out_u + 2 * T + 3 * (T + 1) + 6) = d.sc_bad ? (long long)*d.sc_bad : 0ll;
     if (!f.mirror) return;
     __syncthreads();
-    const int n = 2 * T + 3 * (T + 1) + 6;                   // out_u, out_s, info (4 doubles) and the track::Out (2)
+    const int n = 2 * T + 3 * (T + 1) + 7;                   // out_u, out_s, info (4 doubles), the track::Out (2), the non-convex count
     for (int i = tid; i < n; i += su::NT) f.mirror[i] = f.out_u[i];
     __threadfence_system();
     __syncthreads();
@@ -751,7 +754,18 @@ static int robot_candidates(int R, const double *G, const double *h, unsigned ch
     return n;
 }
 
+static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out, rda_handle **partial);
+extern "C" void rda_destroy(rda_handle *H);
+
 extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out)
+{
+    rda_handle *partial = nullptr;                      // a failure half-way releases what was built (rda_destroy takes partial handles)
+    const int rc = create_impl(cfg, G, h, out, &partial);
+    if (rc != RDA_OK && partial) { rda_destroy(partial); if (out) *out = nullptr; }
+    return rc;
+}
+
+static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out, rda_handle **partial)
 {
     if (!cfg || !G || !h || !out) return RDA_ERR_ARG;
     if (cfg->robot_norm2 && cfg->R < 2) return RDA_ERR_UNSUPPORTED;
@@ -759,6 +773,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
     if (cfg->E + cfg->R + 1 > 64) return RDA_ERR_UNSUPPORTED;
     if (rda_device_count() < 1) return RDA_ERR_NODEVICE;
     rda_handle *H = new rda_handle();
+    *partial = H;
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
     { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
@@ -838,7 +853,7 @@ extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, 
 extern "C" void rda_destroy(rda_handle *H)
 {
     if (!H) return;
-    (void)hipStreamSynchronize(H->stream);
+    if (H->stream) (void)hipStreamSynchronize(H->stream);
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
     void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
@@ -857,7 +872,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->stream2) { (void)hipStreamSynchronize(H->stream2); (void)hipStreamDestroy(H->stream2); }
     if (H->ev_tick) (void)hipEventDestroy(H->ev_tick);
     if (H->ev_scene) (void)hipEventDestroy(H->ev_scene);
-    (void)hipStreamDestroy(H->stream);
+    if (H->stream) (void)hipStreamDestroy(H->stream);
     delete H;
 }
 
@@ -885,6 +900,7 @@ static int obstacles_stage(rda_handle *H, int n_obs, const double *A, const doub
     const size_t T = d.c.T, N = d.c.N, E = d.c.E;
     if (n_obs <= 0) { d.obstacle_num = 0; return RDA_OK; }       // nothing written: stale A, b stay
     if (!A || !b || !cone) return RDA_ERR_ARG;
+    d.sc_bad = nullptr;
     const size_t nt = per_t ? T + 1 : 1;
     for (size_t n = 0; n < N; ++n) {
         size_t src = n < (size_t)n_obs ? n : (size_t)n_obs - 1;   // quirk Q3: duplicate the last obstacle
@@ -967,6 +983,7 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     memcpy((int *)(hb + o_int) + n, nvert, (size_t)n * sizeof(int));
     HIPCHK(hipMemcpyAsync(db, hb, scene_block_bytes((size_t)n, (size_t)E), hipMemcpyHostToDevice, st));
     int *const d_bad = (int *)(db + o_bad);
+    d.sc_bad = d_bad;
     scene::Args a;
     a.n = n; a.N = N; a.E = E; a.T = T; a.nt = any_moving ? T + 1 : 1; a.order = order; a.dt = d.c.dt;
     a.kind = (int *)(db + o_int); a.nvert = (int *)(db + o_int) + n; a.geom = db; a.vel = db + o_vel; a.robot = db + o_rob;
@@ -985,6 +1002,13 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
         HIPCHK(hipStreamSynchronize(st));                  // the staging block is reused by the next call
     }
     return RDA_OK;
+}
+
+extern "C" int rda_last_nonconvex(rda_handle *H)
+{
+    if (!H) return RDA_ERR_ARG;
+    const size_t T = H->d.c.T;
+    return (int)*(const long long *)(H->h_out + 2 * T + 3 * (T + 1) + 6);
 }
 
 extern "C" int rda_upload_scene(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
@@ -1036,7 +1060,7 @@ static void launch_lammuz(rda_handle *H, const Dev &d)
 // The ADMM loop of one MPC step in two parts.  The HEAD (the first su-problem, which also resets the step's control block) reads the nominal trajectory and the
 // condensed terms of the PREVIOUS step (quirk Q4) but nothing of the staged obstacles, so a caller may stage this tick's
 // obstacles on the stream between head and tail while the first su-problem is being solved (rda_tracked_begin/_finish).
-static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, const double *in_u, const Fin &fin = Fin{nullptr, nullptr, nullptr, nullptr, 0})
+static void launch_su(rda_handle *H, const Dev &d, int it, const double *in_s, const double *in_u, const Fin &fin = Fin{nullptr, nullptr, nullptr, nullptr, 0, 0})
 {
     const int T = d.c.T;
     if (H->timing) (void)hipEventRecord(next_event(H, 1), H->stream);
@@ -1052,7 +1076,7 @@ static Fin make_fin(rda_handle *H, double *out_u, double *out_s, rda_info *info)
 {
     const bool zc = H->zero_copy && !H->timing && out_u == H->d_out_u;
     if (zc) H->res_seq += 1;
-    return Fin{ out_u, out_s, info, zc ? H->h_out : nullptr, H->res_seq };
+    return Fin{ out_u, out_s, info, zc ? H->h_out : nullptr, H->res_seq, out_u == H->d_out_u ? 1 : 0 };
 }
 static int launch_finish(rda_handle *H, const Dev &d, const Fin &fin)
 {
@@ -1064,7 +1088,7 @@ static int fetch_result(rda_handle *H)
 {
     const size_t T = H->d.c.T;
     if (H->zero_copy && !H->timing) {
-        volatile unsigned long long *flag = (volatile unsigned long long *)(H->h_out + 2 * T + 3 * (T + 1) + 6);
+        volatile unsigned long long *flag = (volatile unsigned long long *)(H->h_out + 2 * T + 3 * (T + 1) + 7);
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spin = 0;; ++spin) {
             if (*flag == H->res_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return RDA_OK; }
@@ -1094,7 +1118,7 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     const Fin fin = make_fin(H, out_u, out_s, info);  // the su launch that detects the early stop hands the result over itself
     for (int it = 0; it < d.c.iter_num; ++it) {
-        if (it > 0) launch_su(H, d, it, in_s, in_u, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0});
+        if (it > 0) launch_su(H, d, it, in_s, in_u, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
         if (it > 0 && H->comm) {
             // The early stop (rda_solver.py:594) is a device flag and kernels queued behind it return at once - a collective
             // cannot: with a communicator the host reads the flag after the su-problem (one small D2H + sync per iteration,
@@ -1543,7 +1567,7 @@ extern "C" int rda_admm_su(rda_handle *H, int it, int *stopped)
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     Dev d = H->d;
     d.ref = H->d_step + ns + nu; d.ref_speed = H->d_step + ns + nu + ns;
-    RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns, Fin{nullptr, nullptr, nullptr, nullptr, 0}));
+    RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}));
     HIPCHK(hipGetLastError());
     if (stopped) {
         Ctrl c;
@@ -1602,7 +1626,7 @@ __global__ __launch_bounds__(su::NT) void k_finish_fleet(const Dev *devs, const 
     const Dev &d = devs[blockIdx.x];
     const EgoIO e = io[blockIdx.x];
     const size_t ns = 3 * (d.c.T + 1), nu = 2 * d.c.T;
-    const Fin f = { e.out_u + k * nu, e.out_s + k * ns, e.info + k, nullptr, 0 };
+    const Fin f = { e.out_u + k * nu, e.out_s + k * ns, e.info + k, nullptr, 0, 0 };
     finish_body(d, f);
 }
 

@@ -289,6 +289,11 @@ class RDA_solver:
         opt_state_list = [out_s[:, i:i + 1] for i in range(self.T + 1)]      # columns of an array this call owns (no copies)
         if info_c.lmz_fail:
             print("Update Lam Mu Fail")                               # reference :792,825 (printed unconditionally there too)
+        last_nonconvex = getattr(self._be.api.lib, "rda_last_nonconvex", None)
+        if last_nonconvex is not None:
+            bad = last_nonconvex(self._be.handle)                     # polygons of the device-staged scene this step ran on
+            if bad > 0:                                               # reference mpc.py:524 (one line per polygon there, with its vertices)
+                print(f"Warning: {bad} polygon(s) constructed by vertex are not convex. Please check the vertex")
         return {"ref_traj_list": ref_states, "opt_state_list": opt_state_list,
                 "iteration_time": time.time() - start, "resi_dual": info_c.resi_dual,
                 "resi_pri": info_c.resi_pri, "iters": info_c.iters, "status": info_c.su_status,

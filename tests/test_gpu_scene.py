@@ -97,6 +97,17 @@ def test_ordering_ties_are_stable_and_nonconvex_is_reported():
     assert bad == 1 and np.array_equal(Ah, Ad) and np.array_equal(bh, bd) and np.array_equal(ch, cd)
 
 
+def test_nonconvex_warning_travels_with_the_step_result(capsys):
+    """the default (device-staged, no extra synchronisation) control path prints the reference's convexity warning (mpc.py:524)"""
+    mpc = _mpc(4)
+    state = np.array([[0.0], [20.0], [0.0]])
+    dart = sc.Obstacle(None, None, np.array([[15.0, 17.0, 15.5, 17.0], [25.0, 26.0, 26.0, 24.0]]), "Rpositive", np.zeros((2, 1)))
+    mpc.control(state, 4.0, [dart, sc.circle(19, 29, 1.0)])
+    assert "not convex" in capsys.readouterr().out
+    mpc.control(state, 4.0, [sc.circle(19, 29, 1.0)])
+    assert "not convex" not in capsys.readouterr().out
+
+
 def test_empty_scene_skips_dual_side():
     mpc = _mpc(5)
     state = np.array([[0.0], [20.0], [0.0]])
