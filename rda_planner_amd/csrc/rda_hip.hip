@@ -57,6 +57,7 @@ struct Dev {
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
     int su_light;                        // su_device Cfg::light_check
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
+    int su_easy_nopred;
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
                                        // interior-point iterations; RDA_SU_EASY="wfl,mu0,clip,tau,sigma,max", max = 0 disables)
     double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (RDA_SU_WARM_CLIP; cold 0.01)
@@ -178,6 +179,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     // convergence pass.  After a solve that needed more (moving obstacles, a changed active set) the moderate start above is used.
     if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
+        a.warm_nopred = d.su_easy_nopred;
     }
     su::solve<TT>(a, smem_su);
     __syncthreads();
@@ -787,6 +789,8 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
     H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5; H->d.su_warm_clip = 0.01;
     { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) H->d.su_easy[i] = ez[i]; H->d.su_easy_max = 2; }
+    H->d.su_easy_nopred = 1;
+    { const char *e = getenv("RDA_SU_EASY_NOPRED"); if (e) H->d.su_easy_nopred = atoi(e); }
     H->d.su_light = 1;
     { const char *e = getenv("RDA_SU_LIGHT"); if (e) H->d.su_light = atoi(e); }
     { const char *e = getenv("RDA_SU_EASY"); if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%d", &H->d.su_easy[0], &H->d.su_easy[1], &H->d.su_easy[2], &H->d.su_easy[3], &H->d.su_easy[4], &H->d.su_easy_max); }

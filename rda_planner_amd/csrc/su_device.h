@@ -65,6 +65,7 @@ struct Args {
     // to the solution (the dual residual is at rounding level after one step), what is left is driving the complementarity down;
     // with the cold floors (0.995, 1e-3) that takes three iterations from mu ~ 1e-2, with these two.
     double warm_tau = 0.9999, warm_sig = 1e-5;
+    int warm_nopred = 0;             // the first iteration of the warm attempt is a plain Newton step towards sigma*mu (no predictor)
     double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
     double *lam_keep = nullptr;
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
@@ -862,9 +863,16 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         mark(5);
 
         double sigma = 0;
-        for (int pass = 0; pass < 2; ++pass) {
+        // The first iteration of an easy-mode warm attempt skips the predictor (a.warm_nopred): next to the solution the affine step
+        // is a full step, so sigma ends at its floor anyway and the second-order term dl*dw is O(error^2) - one sweep pair instead of
+        // two.  Should that iteration not finish the solve, the following ones are ordinary predictor-corrector iterations.
+        const bool nopred = attempt < 0 && a.warm_nopred != 0 && it == 0;
+        if (nopred) sigma = a.warm_sig;
+        for (int pass = nopred ? 1 : 0; pass < 2; ++pass) {
             if (pass == 1) {
                 // corrector right-hand side
+                if (nopred) for (int i = tid; i < NC * T; i += NT) L.rc[i] = L.cl[i] * L.cw[i] - sigma * mu;
+                else
                 for (int i = tid; i < NC * T; i += NT) L.rc[i] = L.cl[i] * L.cw[i] + L.dl[i] * L.dw[i] - sigma * mu;
                 __syncthreads();
                 if (tid < T) build_gh(tid);

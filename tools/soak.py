@@ -23,8 +23,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tol", type=float, default=1e-5)
+    ap.add_argument("--only", type=int, default=-1, help="run this scene only (the random draws of the others are still made)")
     a = ap.parse_args()
-    orc_api().lib.orc_set_threads(os.cpu_count() or 1)
+    orc_api().lib.orc_set_threads(min(16, os.cpu_count() or 1))      # more threads than that slow the oracle down (bench.py thread sweep)
     rng = np.random.default_rng(a.seed)
     tot = bad_u = bad_it = failed = 0
     worst = 0.0
@@ -51,6 +52,8 @@ def main():
         if dyn == "omni":
             st[2, 0] = 0.0
         speed = float(rng.uniform(2.5, 4.5))
+        if a.only >= 0 and s != a.only:
+            continue
         for k in range(a.steps):
             cur = [o if not np.any(o.velocity) else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
                                                      else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in scene]
@@ -61,6 +64,7 @@ def main():
             worst = max(worst, du)
             if ig["status"] or ic["status"]:
                 failed += 1
+                print(f"scene {s} ({dyn} T={T} N={N}) step {k}: su status gpu {ig['status']} (ipm {ig['su_ipm_iters']}), oracle {ic['status']} (ipm {ic['su_ipm_iters']})")
             if ig["iters"] != ic["iters"]:
                 bad_it += 1
                 print(f"scene {s} ({dyn} T={T} N={N}) step {k}: iterations {ig['iters']} vs {ic['iters']}, du {du:.2e}")
