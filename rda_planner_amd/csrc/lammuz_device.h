@@ -17,6 +17,12 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+// Floating-point contraction: `on` (a product is fused with the sum it feeds only inside ONE source expression, decided by the
+// front end) instead of the HIP default `fast` (the backend fuses opportunistically, across statements, depending on what else was
+// inlined around the code).  The same device functions are compiled into several kernels (one sub-problem per wave / four per
+// wave / common path only / work list; single ego / fleet) and their results must not depend on which kernel solved a row.
+#pragma clang fp contract(on)
+
 namespace lmz {
 
 constexpr int EMAX = 8;
@@ -694,3 +700,5 @@ __device__ __forceinline__ double lam_of(const Sol &s, int norm2, int e)
 __device__ __forceinline__ double mu_of(const Sol &s, int j) { return j == s.j1 ? s.g1 : (j == s.j2 ? s.g2 : 0.0); }
 
 }  // namespace lmz
+
+#pragma clang fp contract(fast)      // back to the HIP default for whatever is compiled after this header

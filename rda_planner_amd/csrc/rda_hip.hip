@@ -34,7 +34,8 @@ struct Ctrl {
     int su_last;             // interior-point iterations of the last su-solve of this handle (99 = it did not converge): picks the next start
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
-    int finished, pad_;           // the result slot of this step has been written (by the su launch that detected the early stop)
+    int finished;                 // the result slot of this step has been written (by the su launch that detected the early stop)
+    int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -56,6 +57,7 @@ struct Dev {
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
     int su_light;                        // su_device Cfg::light_check
+    int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
@@ -158,6 +160,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
             return;
         }
     }
+    if (tid == 0) d.ctrl->wl_count = 0;           // the LamMuZ launches of this iteration start with an empty work list
     su::Args a;
     a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
@@ -211,7 +214,7 @@ __device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
         d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0;
+        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0;
     }
 }
 
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(256) void k_prepare(Dev d)
 
 __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
 {
+#pragma clang fp contract(on)          // see lammuz_device.h: results independent of the kernel the body is compiled into
     __shared__ lmz::WaveLDS wl[4];
     __shared__ lmz::RobotLDS rb;
     const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
@@ -370,8 +374,14 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx
 // (DESIGN.md section 5): the rows run it side by side.  Only a row whose certificate fails needs the 64-lane enumeration;
 // those rows are served one after the other by the whole wave.  Same device functions, same arithmetic, same results as
 // lammuz_body.  Requires E + R + 1 <= 16 (else the one-per-wave body is launched).
-__device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
+// MODE 0: everything in one kernel (single ego, latency).  Dense grids are served by two launches instead:
+// MODE 1: the common path only - 154 registers, three waves per SIMD, no spills; a row whose warm candidate fails its certificate
+//         goes on the handle's work list (Dev::wl) and writes nothing;
+// MODE 2: the rows on the work list, ONE per wave (row 0 of the wave; rows 1-3 idle) and pass, straight to the enumeration, then
+//         the very same 16-lane code as modes 0 / 1 - so the results do not depend on which launch solved a row.
+template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks = 1)
 {
+#pragma clang fp contract(on)          // see lammuz_device.h
     __shared__ lmz::WaveLDS wl[16];
     __shared__ lmz::RobotLDS rb;
     const int T = d.c.T, E = d.c.E, R = d.c.R;
@@ -382,9 +392,14 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
     if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = d.muc[threadIdx.x - 128];
     if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
-    const int w0 = block * 16 + wv * 4 + row;
-    const bool live = w0 < d.Nlive * T;
-    const int w = live ? w0 : block * 16;                      // a row past the end shadows a live one and writes nothing
+    const int cnt = MODE == 2 ? d.ctrl->wl_count : 1;
+    for (int base = MODE == 2 ? block * 4 : 0; base < cnt; base += MODE == 2 ? nblocks * 4 : 1) {       // modes 0, 1: one pass
+    if (MODE == 2) __syncthreads();                            // the slabs of the previous pass are free again
+    const int w0 = MODE == 2 ? 0 : block * 16 + wv * 4 + row;
+    const bool entry = MODE == 2 && base + wv < cnt;            // (wave-uniform) this wave has a work-list entry in this pass
+    const bool live = MODE == 2 ? (entry && row == 0) : w0 < d.Nlive * T;
+    // a row past the end (an idle row of mode 2) shadows a live one and writes nothing
+    const int w = MODE == 2 ? d.wl[entry ? base + wv : base] : (live ? w0 : block * 16);
     const int nl = w / T, t = w % T;                          // stage fastest: see lammuz_body
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
@@ -424,8 +439,15 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
         if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
-    const bool ok = d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[n * T + t], best);
+    const bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[n * T + t], best);
     unsigned long long need = __ballot(!ok);                   // rows that need the enumeration (wave-uniform from here)
+    if (MODE == 2) {
+        need = entry ? 0xffffull : 0ull;                        // row 0 only
+        if (!live) {                                            // idle rows: nothing of `best` is used below
+            best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
+            best.l1 = best.l2 = best.g1 = best.g2 = 0;
+        }
+    }
 #ifdef RDA_LMZ_STATS
     if (lane == 0) {
         const int nf = __popcll(need) >> 4;
@@ -433,6 +455,16 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
         atomicAdd(&d.ctrl->lmz_stat[1], (unsigned)nf); atomicAdd(&d.ctrl->lmz_stat[2 + nf], 1u);
     }
 #endif
+    bool defer = false;
+    if (MODE == 1) {
+        defer = ((need >> (16 * row)) & 1) != 0 && !bad;
+        if ((need >> (16 * row)) & 1) {     // nothing of `best` is used below (deferred, or a non-finite row): a harmless value
+            best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
+            best.l1 = best.l2 = best.g1 = best.g2 = 0;
+        }
+        if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = w;
+        need = 0;
+    }
     while (need) {
         const int g = (__ffsll((long long)need) - 1) >> 4;
         need &= ~(0xffffull << (16 * g));
@@ -446,13 +478,13 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
         lmz::solve_wave(wl[wv * 4 + g], rb, Pg, lane, bg);
         if (row == g) best = bg;
     }
-    if (gl == 0 && live) d.hint[n * T + t] = best.id >> 1;
+    if (gl == 0 && live && !defer) d.hint[n * T + t] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave<16>(W, rb, P, lane, best);
     bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));      // uniform over the row
     // ---- fused dual / residual updates (every lane of the row holds the row's winner) ----------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
     double res = 0;
-    const bool wr = live && !bad;
+    const bool wr = live && !bad && !defer;
     if (gl < E) {
         double v = lmz::lam_of(best, P.norm2, gl);
         res = (v - prev) * (v - prev); if (wr) d.lam[o * E + gl] = v;
@@ -494,12 +526,15 @@ __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block)
         coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
         coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
     }
+    }
 }
 
 // two builds: all registers and one workgroup per CU (no spills: the shorter critical path a single ego wants), or two
 // workgroups per CU with a few spilled registers (more sub-problems in flight: what a full chip wants)
 __global__ __launch_bounds__(256) void k_lammuz_rows(Dev d) { lammuz_body_rows(d, blockIdx.x); }
 __global__ __launch_bounds__(256, 2) void k_lammuz_rows_dense(Dev d) { lammuz_body_rows(d, blockIdx.x); }
+__global__ __launch_bounds__(256, 3) void k_lammuz_rows_fast(Dev d) { lammuz_body_rows<1>(d, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_lammuz_enum(Dev d) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x); }
 
 // K1, interior-point variant (lammuz_cp_device.h): one (obstacle, stage) sub-problem per thread, same fused dual / residual
 // updates as lammuz_body.  A solve that does not end on the central path keeps the previous duals of its stage and makes the
@@ -686,6 +721,7 @@ struct rda_handle {
     int pending, pending_scene; const double *pending_in_u;
     int tick_stages, tick_has_event;     // see rda_tracked_begin
     int fuse_track; size_t su_trk_lds; unsigned long long trk_seq;
+    int lmz_split;                        // dense LamMuZ grids as two launches: common path, then the deferred rows (RDA_LMZ_SPLIT=0: one fused kernel)
     int early_finish;                     // the su launch that detects the early stop writes the result slot (RDA_EARLY_FINISH=0: k_finish does)    // k_su_tracked (RDA_FUSE_TRACK=0: k_track and k_su as two launches)
     hipStream_t stream2; hipEvent_t ev_tick, ev_scene; int scene_on_s2;   // in-tick scene staging runs beside the first su-problem
     // timing
@@ -811,7 +847,7 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
-    rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
+    rc |= dalloc(&d.wl, N * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
     d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.chunk = 8 * T * N;
@@ -849,6 +885,8 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     H->fuse_track = 1; H->tick_stages = 0; H->tick_has_event = 0; H->trk_seq = 0;
     { const char *e = getenv("RDA_FUSE_TRACK"); if (e) H->fuse_track = atoi(e); }
     H->early_finish = 1;
+    H->lmz_split = 1;
+    { const char *e = getenv("RDA_LMZ_SPLIT"); if (e) H->lmz_split = atoi(e); }
     { const char *e = getenv("RDA_EARLY_FINISH"); if (e) H->early_finish = atoi(e); }
     *out = H;
     return RDA_OK;
@@ -860,7 +898,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->stream) (void)hipStreamSynchronize(H->stream);
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
-    void *ptrs[] = { d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
+    void *ptrs[] = { d.wl, d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
                      d.s, d.u, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
@@ -1055,7 +1093,12 @@ static void launch_lammuz(rda_handle *H, const Dev &d)
     }
     if (d.rows && d.obstacle_num) {
         const int nb = (units + 15) / 16;
-        if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d);
+        if (nb > H->dense_from && H->lmz_split) {
+            // dense grid: common path with three waves per SIMD, then the deferred rows one per wave (see lammuz_body_rows<false>)
+            hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(256), 0, H->stream, d);
+            int ne = units / 64; if (ne < 32) ne = 32; if (ne > 1024) ne = 1024;
+            hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(256), 0, H->stream, d);
+        } else if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d);
         else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(256), 0, H->stream, d);
     } else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
 }
@@ -1624,6 +1667,8 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su_fleet(const Dev
 // of the (packed-size) grid... kept simple: the fleet uses the packed kernel only when every member can
 __global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs) { lammuz_body(devs[blockIdx.y], blockIdx.x); }
 __global__ __launch_bounds__(256, 2) void k_lammuz_fleet_rows(const Dev *devs) { lammuz_body_rows(devs[blockIdx.y], blockIdx.x); }
+__global__ __launch_bounds__(256, 3) void k_lammuz_fleet_rows_fast(const Dev *devs) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x); }
+__global__ __launch_bounds__(256) void k_lammuz_fleet_enum(const Dev *devs) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x); }
 
 __global__ __launch_bounds__(su::NT) void k_finish_fleet(const Dev *devs, const EgoIO *io, int k)
 {
@@ -1644,7 +1689,7 @@ struct rda_fleet {
     double *h_out, *d_out;                // per ego: u | s
     rda_info *h_info, *d_info;
     hipEvent_t ev;
-    int T, iter_num, blocks, rows;
+    int T, iter_num, blocks, rows, lmz_split;
     size_t su_lds;
     // tracked stepping (device-side pre_process), allocated on first use
     track::In *h_trk_in, *d_trk_in; track::Out *h_trk_out, *d_trk_out;
@@ -1717,6 +1762,8 @@ static int fleet_refresh(rda_fleet *F)
         HIPCHK(hipStreamWaitEvent(F->stream, F->ev, 0));
     }
     F->rows = 1;
+    F->lmz_split = 1;
+    for (int i = 0; i < F->B; ++i) if (!F->egos[i]->lmz_split) F->lmz_split = 0;
     for (int i = 0; i < F->B; ++i) if (!F->egos[i]->d.rows || !F->egos[i]->d.obstacle_num) F->rows = 0;
     if (changed) {
         HIPCHK(hipStreamSynchronize(F->stream));            // an earlier copy out of the pinned mirror may still be queued
@@ -1731,7 +1778,11 @@ static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
     const int B = F->B;
     for (int it = 0; it < F->iter_num; ++it) {          // iteration 0 resets every member's control block (su_body)
         RDA_SU_DISPATCH(F->T, hipLaunchKernelGGL(k_su_fleet<TT>, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, it, k));
-        if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
+        if (F->rows && F->lmz_split) {
+            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
+            int ne = F->blocks / 16; if (ne < 4) ne = 4; if (ne > 64) ne = 64;
+            hipLaunchKernelGGL(k_lammuz_fleet_enum, dim3(ne, B), dim3(256), 0, F->stream, F->d_devs);
+        } else if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
         else hipLaunchKernelGGL(k_lammuz_fleet, dim3(F->blocks, B), dim3(256), 0, F->stream, F->d_devs);
     }
     hipLaunchKernelGGL(k_finish_fleet, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, k);
