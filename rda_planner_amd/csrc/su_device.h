@@ -31,6 +31,10 @@
 #ifndef SIGMA_FLOOR
 #define SIGMA_FLOOR 1e-3
 #endif
+// fp contraction per source expression, not per optimiser context: see lammuz_device.h (k_su, k_su_tracked, k_su_fleet and the
+// rda_su_solve hook inline the same solve and must round alike)
+#pragma clang fp contract(on)
+
 namespace su {
 
 constexpr int NT = 256;          // workgroup size
@@ -961,3 +965,5 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
 #undef LDS_DRAIN
 
 }  // namespace su
+
+#pragma clang fp contract(fast)
