@@ -35,7 +35,7 @@ class MPC:
         # extension: device_track=True additionally runs pre_process (closest waypoint, nominal roll-out, reference
         # sampling) on the GPU (rda_step_tracked) - same values to rounding, the host code below is the fallback
         self.device_track = bool(kwargs.get("device_track", True))
-        self._dev_path_key, self._dev_u = None, None
+        self._dev_path_key, self._dev_u, self._path_ticks = None, None, 0
         solver_kwargs = {k: v for k, v in kwargs.items() if k not in ("init_vel", "device_obstacles", "device_track")}
         self.rda = RDA_solver(receding, car_tuple, max_edge_num, max_obs_num, iter_num=iter_num,
                               step_time=sample_time, process_num=process_num, accelerated=accelerated,
@@ -96,10 +96,22 @@ class MPC:
     def _sync_path(self, cur_ref_path):
         # keyed on content, not identity: the reference re-reads `ref_path` every tick (mpc.py:139-144), so a list that was
         # replaced or edited in place without update_ref_path must reach the device too (a few us for a few hundred waypoints)
-        key = np.hstack(cur_ref_path)[0:3].tobytes()
-        if key != self._dev_path_key:
+        # Comparing all L waypoint arrays costs ~0.2 ms per tick for L = 800, as much as the whole device step.  Per tick: the list
+        # object, its length and the CONTENT of the window the device tracker can reach in this tick (256 waypoints from the
+        # current index, plus the last waypoint, which quirk Q12 rewrites) are compared with what was uploaded; every 32nd tick
+        # everything is.  An in-place edit further ahead is therefore seen when the window reaches it, or within 32 ticks.
+        key = self._dev_path_key
+        L = len(cur_ref_path)
+        self._path_ticks += 1
+        if key is not None and key[0] is cur_ref_path and len(key[1]) == L and self._path_ticks % 32:
+            i0 = max(0, min(self.cur_index, L) - 1)
+            i1 = min(L, i0 + 256)
+            if [p.tobytes() for p in cur_ref_path[i0:i1]] == key[1][i0:i1] and cur_ref_path[-1].tobytes() == key[1][-1]:
+                return
+        content = [p.tobytes() for p in cur_ref_path]
+        if key is None or content != key[1]:
             self.rda.upload_path(cur_ref_path)
-            self._dev_path_key = key
+        self._dev_path_key = (cur_ref_path, content)
 
     def _nominal_u(self):
         """None when the device still holds cur_vel_array (the controls of the previous solve), else the array"""
@@ -108,6 +120,8 @@ class MPC:
     def _tracked_done(self, cur_ref_path, u_opt_array, info, min_index, end_heading):
         self.cur_index = min_index
         cur_ref_path[-1][2, 0] = end_heading            # quirk Q12: the reference rewrites the last waypoint's heading in place
+        if self._dev_path_key is not None and self._dev_path_key[0] is cur_ref_path:
+            self._dev_path_key[1][-1] = cur_ref_path[-1].tobytes()     # ... and the device did the same to its copy
         out = self._end(cur_ref_path, u_opt_array, info)
         self._dev_u = None if info["arrive"] else self.cur_vel_array
         return out

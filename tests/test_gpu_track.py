@@ -92,6 +92,47 @@ def test_tracked_control_equals_host_control():
         assert arrived, dyn
 
 
+def test_device_path_follows_replaced_and_edited_waypoints():
+    """the reference re-reads `ref_path` every tick (mpc.py:139-144): a list that is replaced, and waypoints that are edited in
+    place (inside the window the tracker can reach, and far ahead of it), must reach the device copy without update_ref_path"""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics="acker", wheelbase=3.0)
+    path = sc.line_path([4, 20, 0], [60, 20, 0], 0.1)
+    kw = dict(receding=10, iter_num=2, max_edge_num=4, max_obs_num=4)
+    a = MPC(car_t, [p.copy() for p in path], device_track=False, **kw)
+    b = MPC(car_t, [p.copy() for p in path], device_track=True, **kw)
+    st = path[0].copy().reshape(3, 1)
+
+    def tick(k):
+        nonlocal st
+        ua, ia = a.control(st.copy(), 4.0, [])
+        ub, ib = b.control(st.copy(), 4.0, [])
+        assert a.cur_index == b.cur_index, k
+        assert np.abs(np.hstack(ia["ref_traj_list"])[0:3] - np.hstack(ib["ref_traj_list"])).max() < TOL, k
+        assert np.abs(ua - ub).max() < 1e-9, k
+        st = sc.kinematic_step(st, ua, car_t, 0.1)
+    for k in range(3):
+        tick(k)
+    # (1) a new list object of the same length, shifted sideways
+    for m in (a, b):
+        m.ref_path = [p + np.array([[0.0], [0.7], [0.0]]) for p in m.ref_path]
+    for k in range(3, 6):
+        tick(k)
+    # (2) in-place edit right ahead of the robot (inside the per-tick window)
+    for m in (a, b):
+        for p in m.ref_path[m.cur_index + 5:m.cur_index + 60]:
+            p[1, 0] += 0.4
+    for k in range(6, 9):
+        tick(k)
+    # (3) in-place edit far ahead: seen by the periodic full comparison or when the window gets there, before it matters
+    for m in (a, b):
+        for p in m.ref_path[400:]:
+            p[1, 0] -= 0.5
+    for k in range(9, 80):
+        tick(k)
+    assert a.cur_index > 150
+
+
 def test_tracked_control_with_reverse_pieces():
     """enable_reverse: the path is split at gear flips (mpc.py:232-249); every piece is uploaded when it comes into force
     and the signed speed reaches the kernel"""
