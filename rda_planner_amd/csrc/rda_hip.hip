@@ -35,6 +35,7 @@ struct Ctrl {
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
     int finished;                 // the result slot of this step has been written (by the su launch that detected the early stop)
+    int su_probe;                 // consecutive su-solves in the hard regime (see su_body)
     int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
@@ -60,6 +61,8 @@ struct Dev {
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
+    int su_cold_probe;
+    int su_cold_from;                  // a solve that follows one with more interior-point iterations than this starts cold (0 = never)
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
                                        // interior-point iterations; RDA_SU_EASY="wfl,mu0,clip,tau,sigma,max", max = 0 disables)
     double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (RDA_SU_WARM_CLIP; cold 0.01)
@@ -184,6 +187,10 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
         a.warm_nopred = d.su_easy_nopred;
     }
+    // Hard regime (many moving obstacles: consecutive su-problems are far apart): a warm attempt then needs MORE iterations than a cold
+    // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
+    // warm start again, so that the handle finds its way back when the scene calms down.
+    if (a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
     su::solve<TT>(a, smem_su);
     __syncthreads();
     if (tid == 0) {
@@ -191,6 +198,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
         if (d.ctrl->st_tmp != 0) d.ctrl->su_status |= 1 << it;
         d.ctrl->ipm_iters += d.ctrl->it_tmp;
         d.ctrl->su_last = d.ctrl->st_tmp == 0 ? d.ctrl->it_tmp : 99;
+        d.ctrl->su_probe = (d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99) ? d.ctrl->su_probe + 1 : 0;
     }
 }
 
@@ -827,6 +835,9 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5; H->d.su_warm_clip = 0.01;
     { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) H->d.su_easy[i] = ez[i]; H->d.su_easy_max = 2; }
     H->d.su_easy_nopred = 1;
+    H->d.su_cold_from = 7; H->d.su_cold_probe = 8;
+    { const char *e = getenv("RDA_SU_COLD_FROM"); if (e) sscanf(e, "%d,%d", &H->d.su_cold_from, &H->d.su_cold_probe); }
+    if (H->d.su_cold_probe < 1) H->d.su_cold_probe = 1;
     { const char *e = getenv("RDA_SU_EASY_NOPRED"); if (e) H->d.su_easy_nopred = atoi(e); }
     H->d.su_light = 1;
     { const char *e = getenv("RDA_SU_LIGHT"); if (e) H->d.su_light = atoi(e); }
