@@ -43,6 +43,7 @@ struct Ctrl {
 #endif
 };
 
+constexpr int NCOEF = 11;     // arrays per obstacle-shard chunk of Dev::coef
 struct Dev;
 __host__ __device__ inline double *coef_arr(const Dev &d, int r, int k);
 
@@ -61,6 +62,7 @@ struct Dev {
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
+    int su_pre;                        // k_lammuz writes su::term_pre for the next su-problem (RDA_SU_PRE=0: the su set-up evaluates all terms itself)
     int su_cold_probe;
     int su_cold_from;                  // a solve that follows one with more interior-point iterations than this starts cold (0 = never)
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
@@ -81,6 +83,7 @@ struct Dev {
     // Condensed su terms + residual partials, one chunk per obstacle shard (P = 1 on a single GPU):
     //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0..5 -> ax ay blam ee gx gy,  k = 6,7 -> residual partials
     // chunk r is produced by rank r's k_lammuz and replicated by one all-gather per ADMM iteration.
+    //   k = 8,9,10 -> su::term_pre of the term at the pose k_lammuz saw (= the nominal of the NEXT su-problem): e0, e1, e2 (negated = far)
     double *coef; int P, rank, Nloc; size_t chunk;
     int Nlive;                                // obstacle slots of THIS rank's shard that exist (< Nloc on the last ranks when N % P != 0)
     double *s, *u;                            // nominal (para_s, para_u)
@@ -174,6 +177,8 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.ref = ref; a.ref_speed = ref_speed; a.ref_flag = ref_flag; a.ref_seq = ref_seq;
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
+    // iterations >= 1 are linearised about the previous solution, which is the pose the LamMuZ launch in between worked with
+    if (it > 0 && d.su_pre && d.obstacle_num > 0 && !d.lmz_mode) { a.pre0 = coef_arr(d, 0, 8); a.pre1 = coef_arr(d, 0, 9); a.pre2 = coef_arr(d, 0, 10); }
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
@@ -303,6 +308,7 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     // A sub-problem whose data are not finite cannot be solved: like a LamMuZ solve of the reference that does not end OPTIMAL
     // (rda_solver.py:781-793) it keeps its previous duals and its residual is inf (no early stop).  The solver below is run on
     // harmless stand-in data instead (its loops then see no NaN) and its answer is dropped.
+    const double px0 = P.px, py0 = P.py, cs0 = P.cs, sn0 = P.sn;       // (the pose as read: a failed row overwrites it with stand-ins)
     bool bad = !isfinite(P.px + P.py + P.cs + P.sn + P.xi0 + P.xi1 + P.kappa0);
     if (lane < 2 * E) bad = bad || !isfinite(W.A[lane >> 1][lane & 1]);
     if (lane < E) bad = bad || !isfinite(W.b[lane]);
@@ -330,6 +336,11 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
             const int k = t * d.Nloc + nl;
             coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
             coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
+            if (d.su_pre) {      // the term as the next su-problem will see it: a = 0, the previous offset and g
+                const su::TermPre tp = su::term_pre(0.0, 0.0, coef_arr(d, d.rank, 4)[k], coef_arr(d, d.rank, 5)[k], 0.0 + coef_arr(d, d.rank, 3)[k],
+                                                    cs0, sn0, px0, py0, d.c.max_sd);
+                coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
+            }
             d.hint[n * T + t] = -1;
             atomicAdd(&d.ctrl->lmz_fail, 1);
         }
@@ -371,6 +382,11 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
         coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
         coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
         coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
+        if (d.su_pre) {      // what this term adds to the set-up of the NEXT su-problem, which is linearised about the pose used here
+            const double c3 = mh + znew - zetan, c4 = gx + xin0, c5 = gy + xin1;
+            const su::TermPre tp = su::term_pre(ax, ay, c4, c5, bl + c3, P.cs, P.sn, P.px, P.py, d.c.max_sd);
+            coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
+        }
     }
 }
 
@@ -429,6 +445,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     if (gl < E) prev = d.lam[o * E + gl];
     else if (gl < E + R) prev = d.mu[o * R + gl - E];
     // non-finite data: see lammuz_body (the row solves harmless stand-in data, keeps its previous duals, residual inf)
+    const double px0 = P.px, py0 = P.py, cs0 = P.cs, sn0 = P.sn;       // (the pose as read: a failed row overwrites it with stand-ins)
     bool bad = !isfinite(P.px + P.py + P.cs + P.sn + P.xi0 + P.xi1 + P.kappa0);
     if (gl < 2 * E) bad = bad || !isfinite(W.A[gl >> 1][gl & 1]);
     if (gl < E) bad = bad || !isfinite(W.b[gl]);
@@ -510,6 +527,11 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         const int k = t * d.Nloc + nl;
         coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
         coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
+        if (d.su_pre) {      // the term as the next su-problem will see it: a = 0, the previous offset and g
+            const su::TermPre tp = su::term_pre(0.0, 0.0, coef_arr(d, d.rank, 4)[k], coef_arr(d, d.rank, 5)[k], 0.0 + coef_arr(d, d.rank, 3)[k],
+                                                cs0, sn0, px0, py0, d.c.max_sd);
+            coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
+        }
         d.hint[n * T + t] = -1;
         atomicAdd(&d.ctrl->lmz_fail, 1);
     }
@@ -533,6 +555,11 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
         coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
         coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
+        if (d.su_pre) {      // what this term adds to the set-up of the NEXT su-problem, which is linearised about the pose used here
+            const double c3 = mh + znew - zetan, c4 = gx + xin0, c5 = gy + xin1;
+            const su::TermPre tp = su::term_pre(ax, ay, c4, c5, bl + c3, P.cs, P.sn, P.px, P.py, d.c.max_sd);
+            coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
+        }
     }
     }
 }
@@ -835,6 +862,8 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5; H->d.su_warm_clip = 0.01;
     { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) H->d.su_easy[i] = ez[i]; H->d.su_easy_max = 2; }
     H->d.su_easy_nopred = 1;
+    H->d.su_pre = 1;
+    { const char *e = getenv("RDA_SU_PRE"); if (e) H->d.su_pre = atoi(e); }
     H->d.su_cold_from = 7; H->d.su_cold_probe = 8;
     { const char *e = getenv("RDA_SU_COLD_FROM"); if (e) sscanf(e, "%d,%d", &H->d.su_cold_from, &H->d.su_cold_probe); }
     if (H->d.su_cold_probe < 1) H->d.su_cold_probe = 1;
@@ -862,7 +891,7 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     rc |= dalloc(&d.wl, N * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
-    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.chunk = 8 * T * N;
+    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.chunk = NCOEF * T * N;
     rc |= dalloc(&d.coef, d.chunk);
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
     rc |= dalloc(&d.ctrl, 1);
@@ -1538,7 +1567,7 @@ __global__ void k_dead_slots(Dev d)
     const int T = d.c.T;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.P * d.Nloc * T; i += gridDim.x * blockDim.x) {
         const int r = i / (d.Nloc * T), k = i % (d.Nloc * T), nl = k % d.Nloc;
-        if (r * d.Nloc + nl >= d.c.N) coef_arr(d, r, 3)[k] = -1e30;
+        if (r * d.Nloc + nl >= d.c.N) { coef_arr(d, r, 3)[k] = -1e30; coef_arr(d, r, 10)[k] = -0.0; }      // (far)
     }
 }
 extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
@@ -1548,7 +1577,7 @@ extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
     HIPCHK(hipStreamSynchronize(H->stream));
     Dev &d = H->d;
     dev_free(d.coef); d.coef = nullptr;
-    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.chunk = (size_t)8 * d.c.T * d.Nloc;
+    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.chunk = (size_t)NCOEF * d.c.T * d.Nloc;
     const int first = rank * d.Nloc;
     d.Nlive = first >= d.c.N ? 0 : (d.c.N - first < d.Nloc ? d.c.N - first : d.Nloc);
     if (dalloc(&d.coef, d.chunk * world)) return RDA_ERR_HIP;

@@ -48,12 +48,31 @@ struct Cfg {
     int light_check = 1;             // convergence pass without the factorisation when the step predicts convergence (RDA_SU_LIGHT=0: off)
 };
 
+// One condensed obstacle term (a, g, cb) at the nominal pose of its stage: the three numbers it adds to the stage's rotation-consistency
+// quadratic and the screening verdict (`far`: its hinge cannot become active while the position stays within
+// SCREEN_DELTA of the nominal one).  ONE definition, because the set-up of the solve evaluates it (first su-problem of a step) and
+// k_lammuz's epilogue evaluates it for the next solve (iterations >= 1 read the three numbers instead of the six arrays).
+constexpr double SCREEN_DELTA = 1.0;
+struct TermPre { double e0, e1, e2; bool far; };
+__device__ __forceinline__ TermPre term_pre(double ax, double ay, double gx, double gy, double cb, double cs, double sn,
+                                            double p0x, double p0y, double max_sd)
+{
+    TermPre r;
+    double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
+    double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
+    r.e0 = k0x * k0x + k0y * k0y; r.e1 = 2 * (k0x * k1x + k0y * k1y); r.e2 = k1x * k1x + k1y * k1y;
+    double margin = ax * p0x + ay * p0y - cb - max_sd;
+    r.far = margin > 0 && margin * margin > SCREEN_DELTA * SCREEN_DELTA * (ax * ax + ay * ay);
+    return r;
+}
+
 struct Args {
     Cfg c;
     const double *in_s, *in_u;       // linearisation point (3x(T+1), 2xT)
     const double *ref;               // 3x(T+1)
     const double *ref_speed;         // scalar on device
     const double *ax, *ay, *blam, *ee, *gx, *gy;   // condensed obstacle terms of obstacle shard 0, each [T][Nloc]
+    const double *pre0 = nullptr, *pre1 = nullptr, *pre2 = nullptr;   // term_pre of every term at THIS solve's nominal, written by k_lammuz (e2 negated = far); null: evaluate here
     int P, Nloc; size_t chunk;       // P obstacle shards (N = P*Nloc); shard r's arrays start `chunk` doubles after shard r-1's
     const double *d_in;              // [T] initial guess for d
     double *out_s, *out_u, *out_d;   // results (may alias in_*)
@@ -272,7 +291,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     // the converged iterate; if violated the iteration continues with all terms.  Excluded terms are inactive at the
     // verified solution, so it satisfies the optimality conditions of the full problem.
     constexpr int MW = 4;
-    constexpr double DELTA = 1.0;
+    constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
     const int KS = (a.Nloc + nch - 1) / nch;                    // terms per shard in one thread's slice
     bool screened = c.accelerated && a.P * KS <= 64 * MW;
@@ -291,18 +310,32 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                     switch (curw) { case 0: amask[0] |= cur; break; case 1: amask[1] |= cur; break; case 2: amask[2] |= cur; break; default: amask[3] |= cur; break; }
                     cur = 0;
                 };
-                auto term = [&](double ax, double ay, double gx, double gy, double cb) {
-                    double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
-                    double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
-                    q0 += k0x * k0x + k0y * k0y; q1 += 2 * (k0x * k1x + k0y * k1y); q2 += k1x * k1x + k1y * k1y;
-                    double margin = ax * p0x + ay * p0y - cb - c.max_sd;
-                    const bool may = screened && !(margin > 0 && margin * margin > DELTA * DELTA * (ax * ax + ay * ay));
+                auto account = [&](double e0, double e1, double e2, bool far) {
+                    q0 += e0; q1 += e1; q2 += e2;
+                    const bool may = screened && !far;
                     if ((bit >> 6) != curw) { flush(); curw = bit >> 6; }
                     cur |= may ? 1ull << (bit & 63) : 0ull;
                     ++bit;
                 };
-                const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o, *pb = a.blam + o, *pe = a.ee + o;
+                auto term = [&](double ax, double ay, double gx, double gy, double cb) {
+                    const TermPre tp = term_pre(ax, ay, gx, gy, cb, cs, sn, p0x, p0y, c.max_sd);
+                    account(tp.e0, tp.e1, tp.e2, tp.far);
+                };
                 int n = rc_;
+                if (a.pre0) {
+                    // iterations >= 1: k_lammuz evaluated term_pre of every term at this nominal (the previous solution) while it
+                    // had the numbers in registers - three arrays to sum instead of six to evaluate (e2 negated = far)
+                    const double *p0 = a.pre0 + o, *p1 = a.pre1 + o, *p2 = a.pre2 + o;
+                    for (; n + 7 * nch < a.Nloc; n += 8 * nch) {
+                        double x[8], y[8], g[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { x[k] = p0[n + k * nch]; y[k] = p1[n + k * nch]; g[k] = p2[n + k * nch]; }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) account(x[k], y[k], fabs(g[k]), signbit(g[k]));
+                    }
+                    for (; n < a.Nloc; n += nch) { const double g = p2[n]; account(p0[n], p1[n], fabs(g), signbit(g)); }
+                } else {
+                const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o, *pb = a.blam + o, *pe = a.ee + o;
                 for (; n + 7 * nch < a.Nloc; n += 8 * nch) {      // eight independent loads in flight per array
                     double x[8], y[8], g[8], h[8], cb[8], ce[8];
 #pragma unroll
@@ -312,6 +345,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
                     for (int k = 0; k < 8; ++k) term(x[k], y[k], g[k], h[k], cb[k] + ce[k]);
                 }
                 for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n], pb[n] + pe[n]);
+                }
                 flush();
             }
         }
