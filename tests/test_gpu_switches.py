@@ -1,0 +1,60 @@
+"""-m gpu : the restructurings of round 2 change WHERE and WHEN work is done, never its result.  Each one has an environment switch
+(read at rda_create) that restores the plain form; a closed loop with the switch thrown must reproduce the default closed loop bit
+for bit: controls, states, residuals, iteration counts.
+
+  RDA_LMZ_DENSE_FROM=0   every LamMuZ launch in the split form (common-path kernel + work-list kernel) instead of the fused kernel
+  RDA_LMZ_SPLIT=0        (with DENSE_FROM=0) every launch as the fused two-workgroups-per-CU kernel
+  RDA_SU_PRE=0           the su set-up evaluates all condensed terms itself (no pre-evaluated arrays from k_lammuz)
+  RDA_SU_LIGHT=0         convergence pass with the factorisation
+  RDA_ZERO_COPY=0        result through a D2H copy + stream synchronise
+  RDA_EARLY_FINISH=0     k_finish hands the result over, not the su launch that detects the early stop
+  RDA_FUSE_TRACK=0       k_track and k_su as two launches
+"""
+import numpy as np
+import pytest
+
+from rda_planner_amd import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = [{"RDA_LMZ_DENSE_FROM": "0"}, {"RDA_LMZ_DENSE_FROM": "0", "RDA_LMZ_SPLIT": "0"}, {"RDA_SU_PRE": "0"}, {"RDA_SU_LIGHT": "0"},
+            {"RDA_ZERO_COPY": "0"}, {"RDA_EARLY_FINISH": "0"}, {"RDA_FUSE_TRACK": "0"},
+            {"RDA_ZERO_COPY": "0", "RDA_EARLY_FINISH": "0", "RDA_FUSE_TRACK": "0", "RDA_SU_PRE": "0", "RDA_LMZ_DENSE_FROM": "0"}]
+
+
+def _loop(dyn, moving, steps=45):
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+    path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    scene = sc.scene_polygons(30, lo=(8, 14), hi=(40, 36), seed=5, keep_clear=clear, clear_radius=3.0, moving=moving)
+    scene.append(sc.circle(20.0, 29.5, 0.9, (0.0, -0.1)))
+    mpc = MPC(car_t, [p.copy() for p in path], receding=12, iter_num=4, max_edge_num=4, max_obs_num=32, time_print=False)
+    st = path[0].copy().reshape(3, 1)
+    if dyn == "omni":
+        st[2, 0] = 0.0
+    out = []
+    for k in range(steps):
+        cur = [o if not np.any(o.velocity) else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
+                                                 else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in scene]
+        u, info = mpc.control(st.copy(), 4.0, cur)
+        out.append((u.copy(), np.hstack(info["opt_state_list"]).copy(), info["resi_dual"], info["resi_pri"], info["iters"], info["su_ipm_iters"]))
+        st = sc.kinematic_step(st, u, car_t, 0.1)
+    return out
+
+
+@pytest.fixture(scope="module")
+def defaults():
+    return {(dyn, mv): _loop(dyn, mv) for dyn, mv in (("acker", False), ("diff", True))}
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: "+".join(f"{k[4:]}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("case", [("acker", False), ("diff", True)], ids=["acker-static", "diff-moving"])
+def test_switch_reproduces_the_default_closed_loop(defaults, monkeypatch, env, case):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got, want = _loop(*case), defaults[case]
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g[4] == w[4] and g[5] == w[5], (k, g[4:], w[4:])
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), (k, float(np.abs(g[0] - w[0]).max()))
+        assert g[2] == w[2] and g[3] == w[3], (k, g[2:4], w[2:4])
