@@ -546,7 +546,11 @@ def main():
     elif E + R + 1 <= 16 and os.environ.get("RDA_LMZ_ROWS", "1") != "0":
         lm_kernel = "k_lammuz_rows_dense" if (n_loc * T + 15) // 16 > int(os.environ.get("RDA_LMZ_DENSE_FROM", "256")) else "k_lammuz_rows"
     r_lm = roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T)
-    r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", kt["k_su"], 48 * N * T + 8 * (8 * (T + 1) + 5 * T))
+    # k_su reads the condensed terms once: six [T][N] arrays in the first solve of a step, three pre-evaluated ones (su::term_pre, written
+    # by k_lammuz) in the later ones - the mean over the executed launches of the timed replay (K first solves among n_exec)
+    later = 24 if os.environ.get("RDA_SU_PRE", "1") != "0" else 48
+    su_bytes = int(round((K * 48 + max(n_exec - K, 0) * later) * N * T / max(n_exec, 1))) + 8 * (8 * (T + 1) + 5 * T)
+    r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", kt["k_su"], su_bytes)
     # latency roof of the su kernel: ONE workgroup (4 waves) on one CU walks a dependent chain; what bounds it is the length of
     # that chain, not bytes - stated next to the HBM fraction so the fraction is not read as a bandwidth problem
     r_su["cus_occupied"] = 1

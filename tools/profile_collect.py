@@ -17,7 +17,7 @@ for name in os.listdir(src):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 
 # HBM traffic per EXECUTED launch: rocprofv3 lists the counter per dispatch; tools/profile_round.sh separates the dispatches that
-# ran (moved more than a fifth of the largest one) from those queued behind the early-stop flag, which move nothing
+# ran (moved more than 0.4 of the largest one) from those queued behind the early-stop flag, which move nothing
 pm = open(os.path.join(src, "pmc_fetch_write.txt")).read()
 detail, out = {}, {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -34,7 +34,7 @@ nj = json.loads(open(os.path.join(src, "bench_pmc_FETCH_SIZE.json")).read())
 m = re.search(r"T=(\d+), N_obs=(\d+)", nj["metric"])
 traffic = {
     "_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each with --kernel-trace only (tools/profile_round.sh). rocprofv3 reports KB; "
-                "bytes per EXECUTED launch = mean over the dispatches that moved more than a fifth of the largest dispatch of that kernel (launches queued "
+                "bytes per EXECUTED launch = mean over the dispatches that moved more than 0.4 of the largest dispatch of that kernel (launches queued "
                 "behind the early-stop flag move no data). The first su-problem of a tracked tick is the kernel k_su_tracked<T> (listed in the pmc file, same solve). The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to wide (16 B/lane) "
                 "streaming reads only; these kernels read 8 B/lane, so the raw value is kept (uncalibrated for this width). Working set << L2, "
                 "Infinity-Cache hits are counted by these counters.",

@@ -32,9 +32,10 @@ try:
         if row.get("Counter_Name") == cname:
             vals[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
     for k, v in vals.items():
-        # launches queued behind the early-stop flag return at once and move (almost) nothing: an EXECUTED dispatch is one that
-        # moved more than a fifth of the largest dispatch of that kernel
-        ex = [x for x in v if x > 0.2 * max(v)] or v
+        # launches queued behind the early-stop flag return at once and move (almost) nothing, the su launch that detects the stop reads
+        # the two residual arrays (a third of a first solve): an EXECUTED dispatch is one that moved more than 0.4 of the largest
+        # dispatch of that kernel (a later su solve reads half of what a first one reads)
+        ex = [x for x in v if x > 0.4 * max(v)] or v
         print(f"{cname} {k}: dispatches {len(v)} total {sum(v):.1f} per-dispatch {sum(v)/len(v):.3f} executed {len(ex)} per-executed {sum(ex)/len(ex):.3f}")
 except Exception as e:
     print("parse failed", e)
