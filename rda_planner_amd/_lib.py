@@ -18,7 +18,23 @@ def build(force=False):
     stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))   # -B: `force` must not depend on mtimes
+    build_flatten_ext(force)
     return SO_PATH
+
+
+def build_flatten_ext(force=False):
+    """csrc/flatten_ext.c -> rda_planner_amd/_flatten.so (CPython extension, plain gcc): the optional accelerator of
+    RDA_solver.flatten_scene.  A failure here is not fatal - the numpy implementation is used."""
+    import sysconfig
+    src, so = os.path.join(_HERE, "csrc", "flatten_ext.c"), os.path.join(_HERE, "_flatten.so")
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
+        return so
+    try:
+        subprocess.check_call(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], "-o", so, src])
+    except (OSError, subprocess.CalledProcessError) as e:
+        print(f"rda_planner_amd: _flatten extension not built ({e}); flatten_scene uses numpy")
+        return None
+    return so
 
 
 def load_library():

@@ -97,7 +97,7 @@ class MPC:
         # keyed on content, not identity: the reference re-reads `ref_path` every tick (mpc.py:139-144), so a list that was
         # replaced or edited in place without update_ref_path must reach the device too (a few us for a few hundred waypoints)
         # Comparing all L waypoint arrays costs ~0.2 ms per tick for L = 800, as much as the whole device step.  Per tick: the list
-        # object, its length and the CONTENT of the window the device tracker can reach in this tick (256 waypoints from the
+        # object, its length and the CONTENT of the window the device tracker can reach in this tick (128 waypoints from the
         # current index, plus the last waypoint, which quirk Q12 rewrites) are compared with what was uploaded; every 32nd tick
         # everything is.  An in-place edit further ahead is therefore seen when the window reaches it, or within 32 ticks.
         key = self._dev_path_key
@@ -105,7 +105,7 @@ class MPC:
         self._path_ticks += 1
         if key is not None and key[0] is cur_ref_path and len(key[1]) == L and self._path_ticks % 32:
             i0 = max(0, min(self.cur_index, L) - 1)
-            i1 = min(L, i0 + 256)
+            i1 = min(L, i0 + 128)
             if [p.tobytes() for p in cur_ref_path[i0:i1]] == key[1][i0:i1] and cur_ref_path[-1].tobytes() == key[1][-1]:
                 return
         content = [p.tobytes() for p in cur_ref_path]

@@ -485,3 +485,58 @@ def test_failure_semantics_with_degenerate_obstacles():
     assert not st["lam"][1].any() and not st["mu"][1].any() and not st["z"][1].any()       # slot 1 kept its (zero) duals
     assert all(np.isfinite(st[k]).all() for k in st)
     assert st["mu"][0].any() and st["mu"][3].any()                                         # the healthy and the non-convex slot are solved
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# flatten_scene: the C walk over the obstacle objects (csrc/flatten_ext.c) against the numpy implementation it accelerates
+# ---------------------------------------------------------------------------------------------------------------------------
+def _flat_solver(E=4):
+    from rda_planner_amd.rda_solver import RDA_solver
+    s = RDA_solver.__new__(RDA_solver)
+    s.max_edge_num = E
+    return s
+
+
+def _same_scene(a, b):
+    assert (a is None) == (b is None)
+    if a is not None:
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
+
+
+def test_flatten_extension_equals_numpy_flatten():
+    import rda_planner_amd.rda_solver as rs
+    from rda_planner_amd import _lib
+    if rs._flatten is None:
+        _lib.build_flatten_ext(force=True)
+        import importlib
+        rs._flatten = importlib.import_module("rda_planner_amd._flatten")
+    sv = _flat_solver(5)
+    rng = np.random.default_rng(3)
+    obs = sc.scene_polygons(40, lo=(0, 0), hi=(50, 50), seed=4, moving=True)
+    obs += [sc.circle(float(rng.uniform(0, 50)), float(rng.uniform(0, 50)), float(rng.uniform(0.3, 2)), (0.1 * i, -0.2)) for i in range(7)]
+    obs.append(sc.Obstacle(None, None, np.array([[1.0, 3.0, 3.0, 1.0, 0.5], [1.0, 1.0, 2.0, 2.5, 1.5]]), "Rpositive", 0))          # scalar velocity (lidar examples)
+    obs.append(sc.Obstacle(None, None, np.asfortranarray(np.array([[5.0, 7.0, 6.0], [5.0, 5.0, 7.0]])), "Rpositive", np.zeros((2, 1))))   # Fortran order
+    obs.append(sc.Obstacle(None, None, np.array([[9.0, 8.0, 8.0, 9.0], [9.0, 9.0, 8.0, 8.0]])[:, ::-1], "Rpositive", np.array([0.3, 0.1])))  # reversed view, 1-D velocity
+    obs.append(sc.Obstacle(None, None, np.array([[2.0, 4.0, 3.0], [2.0, 2.0, 4.0]]), "Rpositive", np.zeros((3, 1))))           # 3x1 velocity
+    rng.shuffle(obs)
+    fast = sv.flatten_scene(list(obs))
+    assert rs._flatten.flatten(list(obs), 5, np.zeros(len(obs), np.int32), np.zeros(len(obs), np.int32), np.zeros((len(obs), 5, 2)), np.zeros((len(obs), 2))) == 0
+    _same_scene(fast, sv._flatten_scene_numpy(list(obs)))
+    assert fast[4].flags["C_CONTIGUOUS"] and fast[3].flags["C_CONTIGUOUS"]
+    _same_scene(sv.flatten_scene(tuple(obs)), fast)
+    # inputs the C walk declines: the numpy code decides (same answer through the public entry point)
+    odd = [
+        [sc.Obstacle(None, None, np.array([[1, 3, 3], [1, 1, 2]]), "Rpositive", np.zeros((2, 1)))],                   # integer vertices
+        [sc.Obstacle(None, None, [[1.0, 3.0, 3.0], [1.0, 1.0, 2.0]], "Rpositive", np.zeros((2, 1)))],                 # nested lists
+        [sc.Obstacle(None, None, np.zeros((2, 7)), "Rpositive", np.zeros((2, 1)))],                                    # more vertices than E
+        [sc.Obstacle(None, None, np.array([[1.0, 3.0, 3.0], [1.0, 1.0, 2.0]]), "Rpositive", np.array([[np.nan], [0.0]]))],   # non-finite velocity
+        [sc.circle(1, 2, 0.5), sc.Obstacle(None, None, None, "exponential", np.zeros((2, 1)))],                       # a cone type the reference skips
+    ]
+    for lst in odd:
+        n = len(lst)
+        assert rs._flatten.flatten(lst, 5, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, 5, 2)), np.zeros((n, 2))) == -1
+        _same_scene(sv.flatten_scene(list(lst)), sv._flatten_scene_numpy(list(lst)))
+    assert _flat_solver(2).flatten_scene([sc.circle(1, 2, 0.5)]) is None                                               # circles need E >= 3
+    _same_scene(sv.flatten_scene([]), sv._flatten_scene_numpy([]))
