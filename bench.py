@@ -247,25 +247,10 @@ def main():
         return float(tt.item())
 
     def closed_loop_host():
-        """tools/libclosed_loop_host.so (built by __graft_entry__.build()): the caller's loop in C, entry points of librda_hip.so handed over"""
-        so = os.path.join(ROOT, "tools", "libclosed_loop_host.so")
-        if not os.path.exists(so):
-            import __graft_entry__
-            __graft_entry__.build_host_driver()
-        lib = C.CDLL(so)
-
-        class Api(C.Structure):
-            _fields_ = [(n_, C.c_void_p) for n_ in ("step_tracked", "tracked_begin", "upload_scene_async", "tracked_finish")]
-
-        class Scene(C.Structure):
-            _fields_ = [("n", C.c_int32), ("maxv", C.c_int32), ("order", C.c_int32), ("moving", C.c_int32), ("kind", C.POINTER(C.c_int32)),
-                        ("nvert", C.POINTER(C.c_int32)), ("geom", C.POINTER(C.c_double)), ("geom0", C.POINTER(C.c_double)), ("vel", C.POINTER(C.c_double))]
-        a = Api(*[C.cast(getattr(api.lib, "rda_" + n_), C.c_void_p).value for n_ in ("step_tracked", "tracked_begin", "upload_scene_async", "tracked_finish")])
-        lib.closed_loop_run.restype = C.c_int
-        lib.closed_loop_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
-                                        C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
-                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
-        return type("Host", (), {"run": lib.closed_loop_run, "api": a, "Scene": Scene})
+        """tools/libclosed_loop_host.so: the caller's loop in C, entry points of librda_hip.so handed over (tools/closed_loop_host.py)"""
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import closed_loop_host as clh
+        return clh.Host(api.lib)
 
     def new_solver():
         sv = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])

@@ -215,3 +215,51 @@ def test_pipelined_tick_closes_on_caller_error():
         m.control(st.copy(), 2.0, list(scene) + [Broken()])
     u, info = m.control(st.copy(), 2.0, list(scene))
     assert np.isfinite(u).all() and info["iters"] >= 1
+
+
+@pytest.mark.parametrize("per_tick_scene", [False, True], ids=["resident-scene", "scene-every-tick"])
+def test_c_caller_closed_loop_equals_python_closed_loop(per_tick_scene):
+    """tools/closed_loop_host.c (the loop bench.py times: C-ABI calls + the kinematic model in C, rda_step_tracked or the two-call tick with
+    rda_upload_scene_async) against `MPC.control` driven from Python on the same scene: same controls, bit for bit"""
+    import ctypes as C
+    import os
+    import sys
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd._capi import dptr, iptr
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import closed_loop_host as clh
+    T, N, K = 12, 20, 40
+    car_t = sc.rectangle_robot(dynamics="acker", wheelbase=3.0)
+    path = sc.line_path([4, 20, 0], [40, 20, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    scene = sc.scene_polygons(N, lo=(6, 10), hi=(40, 30), seed=21, keep_clear=clear, clear_radius=3.0)
+    # obstacle_order off: with a resident scene the slots keep the order of the one staging, a per-tick staging would re-sort them by distance
+    kw = dict(receding=T, iter_num=3, max_edge_num=4, max_obs_num=N, time_print=False, obstacle_order=False)
+    py = MPC(car_t, [p.copy() for p in path], **kw)
+    st = path[0].copy().reshape(3, 1)
+    want = []
+    for k in range(K):
+        u, info = py.control(st.copy(), 4.0, list(scene))
+        want.append(u[:, 0].copy())
+        st = sc.kinematic_step(st, u, car_t, 0.1)
+    cm = MPC(car_t, [p.copy() for p in path], **kw)
+    api, hh = cm.rda._be.api, cm.rda._be.handle
+    host = clh.Host(api.lib)
+    n_sc, kind, nvert, geom, vel = cm.rda.flatten_scene(list(scene))
+    kind, nvert = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(nvert, np.int32)
+    geom, vel = np.ascontiguousarray(geom, float), np.ascontiguousarray(vel, float)
+    geom0 = geom.copy()
+    P = np.ascontiguousarray(np.hstack(path)[0:3, :].T, dtype=float)
+    assert api.upload_path(hh, int(P.shape[0]), dptr(P)) == 0
+    state = np.ascontiguousarray(path[0], float).ravel()[0:3].copy()
+    order = int(bool(cm.obstacle_order))
+    if not per_tick_scene:
+        assert api.upload_scene(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(state), order, None) == 0
+    scn = host.Scene(int(n_sc) if per_tick_scene else 0, int(geom.shape[1]), order, 0, iptr(kind), iptr(nvert), dptr(geom), dptr(geom0), dptr(vel))
+    cur = C.c_int32(0)
+    u_log, t_log, it_log, nom_u0 = np.zeros((K, 2)), np.zeros(K), np.zeros(K, np.int32), np.zeros((2, T))
+    rc = host.run(C.byref(host.api), hh, C.byref(scn), T, 0, 3.0, 0.1, 4.0, 0.1, 10, len(path), 0, K, dptr(nom_u0), dptr(state),
+                  C.byref(cur), dptr(u_log), dptr(t_log), iptr(it_log), None)
+    assert rc == 0
+    assert np.array_equal(u_log, np.array(want)), float(np.abs(u_log - np.array(want)).max())
+    assert cur.value == py.cur_index and (t_log > 0).all() and (it_log >= 1).all()
