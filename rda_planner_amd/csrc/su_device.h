@@ -246,7 +246,8 @@ __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return
 
 // The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).  TT > 0 fixes the horizon
 // at compile time (every LDS offset becomes an immediate, the stage loops get constant bounds); TT == 0 reads it from c.T.
-template <int TT> __device__ inline void solve(const Args &a, double *smem)
+struct NoGate { __device__ __forceinline__ bool operator()(double *) const { return true; } };
+template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Args &a, double *smem, Gate gate = Gate())
 {
     const Cfg &c = a.c;
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,6 +284,84 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     }
     __syncthreads();
     mark(11);
+    // ---- initial point (same rule as the oracle) ------------------------------------------------
+    auto clip_controls = [&](const double clipm) {
+        if (tid < T) {
+            int t = tid;
+            double lim0 = (1.0 - clipm) * c.umax0, lim1 = (1.0 - clipm) * c.umax1;
+            double v0 = a.in_u[t], v1 = a.in_u[T + t];
+            L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
+            L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
+            double lo = c.min_sd + clipm * (c.max_sd - c.min_sd), hi = c.max_sd - clipm * (c.max_sd - c.min_sd);
+            double dv = a.d_in ? a.d_in[t] : c.max_sd;
+            L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
+        }
+        __syncthreads();
+    };
+    // a warm attempt starts next to the previous solution: pulled inside the boxes by warm_clip only (a cold start by 1 %), so that the
+    // kept multipliers of the active rows meet slacks of that size and the start is already nearly complementary
+    clip_controls(a.warm_mu0 > 0 && a.lam_keep != nullptr ? a.warm_clip : 0.01);
+    // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
+    // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
+    // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
+    // on values that were fetched in one go (wave 0 only).
+    auto rollout = [&]() {
+        if (wave == 0) {
+            double *inc = L.dy;                         // scratch: dy is dead outside the sweeps
+            for (int t = lane; t < T; t += 64) {
+                const double *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
+                const double u0 = L.u[t], u1 = L.u[T + t];
+                inc[3 * t + 2] = (B[4] * u0 + B[5] * u1) + C[2];
+                inc[3 * t] = (B[0] * u0 + B[1] * u1) + C[0];
+                inc[3 * t + 1] = (B[2] * u0 + B[3] * u1) + C[1];
+            }
+            wsync();
+            if (lane == 0) {
+                double ph = L.s[2 * (T + 1)];
+                for (int t = 0; t < T; ++t) { ph += inc[3 * t + 2]; L.s[2 * (T + 1) + t + 1] = ph; }
+            }
+            wsync();
+            for (int t = lane; t < T; t += 64) {        // x, y increments need the heading of their own stage
+                const double ph = L.s[2 * (T + 1) + t];
+                inc[3 * t] += L.Ak[9 * t + 2] * ph; inc[3 * t + 1] += L.Ak[9 * t + 5] * ph;
+            }
+            wsync();
+            if (lane == 0) {
+                double x = L.s[0], y = L.s[T + 1];
+                for (int t = 0; t < T; ++t) { x += inc[3 * t]; y += inc[3 * t + 1]; L.s[t + 1] = x; L.s[(T + 1) + t + 1] = y; }
+            }
+        }
+    };
+    rollout();
+    mark(13);
+    // slacks floored at wfl, multipliers lam = mu0 / w  (first attempt: 1e-2 and 1)
+    auto centre_duals = [&](double wfl, double mu0) {
+        for (int i = tid; i < NC * T; i += NT) {
+            int t = i / NC, k = i % NC;
+            double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
+            double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
+            bool on = con_on(t, k);
+            L.cw[i] = on ? (sl > wfl ? sl : wfl) : 1.0;
+            L.cl[i] = on ? mu0 / L.cw[i] : 0.0;
+        }
+        __syncthreads();
+    };
+    // Start.  Cold: slacks floored at 1e-2, lam = 1/w (mu0 = 1).  Warm (ADMM iterations >= 1): the primal point is the previous
+    // solution, so the slacks are the previous ones; they are floored at warm_wfl, the multipliers are the larger of the centred
+    // ones (warm_mu0 / w) and those the previous solve ended with.  Starting with a small mu0 WITHOUT the old multipliers costs
+    // iterations (measured: 75 -> 92 us per launch), with them it saves about one per solve (75 -> 67 us).
+    const bool warm = a.warm_mu0 > 0 && a.lam_keep != nullptr;
+    if (warm) {
+        centre_duals(a.warm_wfl, a.warm_mu0);
+        for (int i = tid; i < NC * T; i += NT) {
+            const int t = i / NC, k = i % NC, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
+            const double lp = a.lam_keep[ts * NC + k]; if (con_on(t, k) && lp > L.cl[i]) L.cl[i] = lp; }
+        __syncthreads();
+    } else centre_duals(1e-2, 1.0);
+    // ---- gate (fused launch, k_lmz_su): everything above depends on the nominal trajectory only; what follows reads the condensed obstacle
+    //      terms.  The caller's gate waits until the LamMuZ workgroups of this launch have finished, reduces their residuals and decides
+    //      the early stop (false = the step is over: leave without touching any output).  L.part is free scratch here.
+    if (!gate(L.part)) return false;
     // ---- rotation-consistency penalty -> scalar quadratic per stage, fused with the HINGE SCREENING:
     // Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so an obstacle term whose margin at the nominal
     // position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Each thread
@@ -366,80 +445,6 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
         }
     }
     mark(12);
-    // ---- initial point (same rule as the oracle) ------------------------------------------------
-    auto clip_controls = [&](const double clipm) {
-        if (tid < T) {
-            int t = tid;
-            double lim0 = (1.0 - clipm) * c.umax0, lim1 = (1.0 - clipm) * c.umax1;
-            double v0 = a.in_u[t], v1 = a.in_u[T + t];
-            L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
-            L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
-            double lo = c.min_sd + clipm * (c.max_sd - c.min_sd), hi = c.max_sd - clipm * (c.max_sd - c.min_sd);
-            double dv = a.d_in ? a.d_in[t] : c.max_sd;
-            L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
-        }
-        __syncthreads();
-    };
-    // a warm attempt starts next to the previous solution: pulled inside the boxes by warm_clip only (a cold start by 1 %), so that the
-    // kept multipliers of the active rows meet slacks of that size and the start is already nearly complementary
-    clip_controls(a.warm_mu0 > 0 && a.lam_keep != nullptr ? a.warm_clip : 0.01);
-    // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
-    // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
-    // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
-    // on values that were fetched in one go (wave 0 only).
-    auto rollout = [&]() {
-        if (wave == 0) {
-            double *inc = L.dy;                         // scratch: dy is dead outside the sweeps
-            for (int t = lane; t < T; t += 64) {
-                const double *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
-                const double u0 = L.u[t], u1 = L.u[T + t];
-                inc[3 * t + 2] = (B[4] * u0 + B[5] * u1) + C[2];
-                inc[3 * t] = (B[0] * u0 + B[1] * u1) + C[0];
-                inc[3 * t + 1] = (B[2] * u0 + B[3] * u1) + C[1];
-            }
-            wsync();
-            if (lane == 0) {
-                double ph = L.s[2 * (T + 1)];
-                for (int t = 0; t < T; ++t) { ph += inc[3 * t + 2]; L.s[2 * (T + 1) + t + 1] = ph; }
-            }
-            wsync();
-            for (int t = lane; t < T; t += 64) {        // x, y increments need the heading of their own stage
-                const double ph = L.s[2 * (T + 1) + t];
-                inc[3 * t] += L.Ak[9 * t + 2] * ph; inc[3 * t + 1] += L.Ak[9 * t + 5] * ph;
-            }
-            wsync();
-            if (lane == 0) {
-                double x = L.s[0], y = L.s[T + 1];
-                for (int t = 0; t < T; ++t) { x += inc[3 * t]; y += inc[3 * t + 1]; L.s[t + 1] = x; L.s[(T + 1) + t + 1] = y; }
-            }
-        }
-    };
-    rollout();
-    mark(13);
-    // slacks floored at wfl, multipliers lam = mu0 / w  (first attempt: 1e-2 and 1)
-    auto centre_duals = [&](double wfl, double mu0) {
-        for (int i = tid; i < NC * T; i += NT) {
-            int t = i / NC, k = i % NC;
-            double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-            double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
-            bool on = con_on(t, k);
-            L.cw[i] = on ? (sl > wfl ? sl : wfl) : 1.0;
-            L.cl[i] = on ? mu0 / L.cw[i] : 0.0;
-        }
-        __syncthreads();
-    };
-    // Start.  Cold: slacks floored at 1e-2, lam = 1/w (mu0 = 1).  Warm (ADMM iterations >= 1): the primal point is the previous
-    // solution, so the slacks are the previous ones; they are floored at warm_wfl, the multipliers are the larger of the centred
-    // ones (warm_mu0 / w) and those the previous solve ended with.  Starting with a small mu0 WITHOUT the old multipliers costs
-    // iterations (measured: 75 -> 92 us per launch), with them it saves about one per solve (75 -> 67 us).
-    const bool warm = a.warm_mu0 > 0 && a.lam_keep != nullptr;
-    if (warm) {
-        centre_duals(a.warm_wfl, a.warm_mu0);
-        for (int i = tid; i < NC * T; i += NT) {
-            const int t = i / NC, k = i % NC, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
-            const double lp = a.lam_keep[ts * NC + k]; if (con_on(t, k) && lp > L.cl[i]) L.cl[i] = lp; }
-        __syncthreads();
-    } else centre_duals(1e-2, 1.0);
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
@@ -993,6 +998,7 @@ template <int TT> __device__ inline void solve(const Args &a, double *smem)
     if (tid == 0) { *a.status = status; *a.ipm_iters = used; }
     mark(10);
     if (prof_on && tid == 0) for (int k = 0; k < 16; ++k) a.prof[k] += pacc[k];
+    return true;
 }
 #undef RW
 #undef R5
