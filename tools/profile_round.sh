@@ -4,6 +4,7 @@
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each (kernel-trace only) -> gpurun_out/prof_<tag>/pmc_fetch_write.txt
 #   3. SQ issue counters, four passes                                            -> gpurun_out/prof_<tag>/issue_counters.txt
 #   4. the other BASELINE configurations, plain bench runs                       -> gpurun_out/prof_<tag>/bench_<config>.json
+#   5. rocprofv3 kernel stats of the C5 fleet and of N=2000 (split LamMuZ launch)  -> gpurun_out/prof_<tag>/kernel_stats_{c5_fleet,n2000}.csv
 # then `python tools/profile_collect.py <tag>` (CPU) turns that into the committed summaries under profiles/.
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
@@ -72,4 +73,11 @@ timeout 200 $BENCH --n-obs 20 2> /dev/null | grep '^{' > "$OUT/bench_n20.json"
 timeout 300 $BENCH --n-obs 2000 --steps 60 2> /dev/null | grep '^{' > "$OUT/bench_n2000.json"
 timeout 300 $BENCH --moving --horizon 30 --steps 60 2> /dev/null | grep '^{' > "$OUT/bench_dynamic_obs.json"
 timeout 300 python bench.py --no-cpu-baseline --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 2> /dev/null | grep '^{' > "$OUT/bench_c5_fleet.json"
+# 5. per-kernel times of the fleet / dense-grid form (split LamMuZ launch): BASELINE C5 (64 egos x 100 obstacles, T=25) and N=2000
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -o f -- python bench.py --no-cpu-baseline --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 --steps 100 > /dev/null 2>&1 || true
+find "$OUT/stats_c5" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_c5_fleet.csv" \;
+rm -rf "$OUT/stats_c5"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_n2000" -o f -- $BENCH --n-obs 2000 --steps 60 > /dev/null 2>&1 || true
+find "$OUT/stats_n2000" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_n2000.csv" \;
+rm -rf "$OUT/stats_n2000"
 ls -la "$OUT"; head -12 "$OUT/kernel_stats.csv"
