@@ -33,7 +33,7 @@ def test_product_path_has_no_oracle_dependency():
     pkg = os.path.join(ROOT, "rda_planner_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".c")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "librda_oracle" not in text, f
 
@@ -50,3 +50,21 @@ def test_no_device_is_a_loud_error():
     from rda_planner_amd.rda_solver import RDA_solver
     with pytest.raises(RuntimeError):
         RDA_solver(5, sc.rectangle_robot(), time_print=False)
+
+
+def test_host_side_helpers_build_and_load():
+    """the C caller bench.py times (tools/closed_loop_host.c) and the flatten accelerator of the Python API (csrc/flatten_ext.c) are plain gcc
+    builds: they compile, load and expose what their ctypes / import users expect (no GPU needed)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop_host as clh
+    lib = ctypes.CDLL(clh.build())
+    assert hasattr(lib, "closed_loop_run")
+    assert ctypes.sizeof(clh.Api) == 4 * 8 and ctypes.sizeof(clh.Scene) == 4 * 4 + 5 * 8        # struct closed_loop_api / closed_loop_scene
+    src = open(os.path.join(ROOT, "tools", "closed_loop_host.c")).read()
+    assert '#include "../include/rda_hip.h"' in src and "oracle" not in src                     # a caller of the C-ABI and of nothing else
+    from rda_planner_amd import _lib
+    assert _lib.build_flatten_ext(force=True) is not None
+    import importlib
+    mod = importlib.import_module("rda_planner_amd._flatten")
+    assert callable(mod.flatten)
