@@ -1072,7 +1072,7 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     a.kind = (int *)(db + o_int); a.nvert = (int *)(db + o_int) + n; a.geom = db; a.vel = db + o_vel; a.robot = db + o_rob;
     a.key = H->d_sc_key; a.sel = H->d_sc_sel; a.A = d.A; a.b = d.b; a.cone = d.cone; a.nonconvex = d_bad;
     hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(scene::k_rank, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scene::k_rank, dim3((n + 15) / 16), dim3(256), 0, st, a);
     hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
     d.nt = a.nt; d.obstacle_num = N;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);

@@ -50,14 +50,18 @@ __global__ void k_keys(Args a)
 }
 
 // stable rank by key (Python's list.sort is stable); the first min(n, N) survive (rda_solver.py:491-493)
+// O(n^2) compares spread over 16 lanes per key (256-thread blocks = 16 keys; launch with (n + 15) / 16 blocks): a count, so the
+// result does not depend on how the compares are split
 __global__ void k_rank(Args a)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const double ki = a.key[i];
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const bool live = i < a.n;
+    const double ki = live ? a.key[i] : 0.0;
     int r = 0;
-    for (int j = 0; j < a.n; ++j) { double kj = a.key[j]; r += (kj < ki) || (kj == ki && j < i); }
-    if (r < a.N) a.sel[r] = i;
+    if (live) for (int j = l; j < a.n; j += 16) { double kj = a.key[j]; r += (kj < ki) || (kj == ki && j < i); }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) r += __shfl_xor(r, off, 16);
+    if (live && l == 0 && r < a.N) a.sel[r] = i;
 }
 
 // one thread per (slot, time slot): half-space form of the selected obstacle at time t
