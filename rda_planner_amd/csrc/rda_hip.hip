@@ -7,8 +7,12 @@
 //                               <<<N*T/4, 256>>>: one per wavefront, for E+R+1 > 16), fused with
 //                               the lam'A / lam'b products, the xi / zeta updates and the residual
 //                               partials (reference rda_solver.py:529-542, 639-690, 781-793)
-// In front of them, optional: scene::k_* (the caller's obstacle conversion / ordering) and k_track (the caller's
-// pre_process); rda_fleet_* launches the same bodies once for B egos.
+// Dense grids (more than 256 workgroups per ego, fleets) run the LamMuZ step as two launches: k_lammuz_rows_fast (the common path
+// only, three waves per SIMD) and k_lammuz_enum (the rows whose warm candidate failed its certificate).
+// In front of them, optional: scene::k_* (the caller's obstacle conversion / ordering) and the caller's pre_process, which
+// shares a launch with the first su-problem of the tick (k_su_tracked: two workgroups); rda_fleet_* launches the same bodies
+// once for B egos.  The launch that ends a step (the su launch that detects the early stop, else k_finish) writes the result
+// slot into pinned host memory and publishes a sequence word the host polls.
 // All solver state (duals, products, nominal trajectory, staged obstacles) stays resident in HBM
 // between iterations and between MPC steps, exactly like the reference keeps it in CVXPY Parameter
 // values (quirks Q4-Q6 come for free).
