@@ -7,11 +7,14 @@
  * pointers unless the name says `dev`.  The library owns all device memory and keeps no
  * caller pointer past a call.  Return value: 0 ok, >0 soft status, <0 hard error
  * (rda_strerror).  One HIP stream per handle; a handle is not thread-safe, distinct handles
- * are independent; no global state.
+ * are independent; no global state: everything that configures a solver travels in rda_cfg (the
+ * reference's constructor arguments) and rda_opts (solver options that are not reference arguments),
+ * both copied into the handle at creation.  RDA_* environment variables are read by rda_opts_init
+ * only, as overrides of its defaults (experiments, A/B runs).
  *
  * reference interface replaced                       | entry point
  * ---------------------------------------------------+-------------------------------------
- * RDA_solver.__init__            rda_solver.py:18-61 | rda_create
+ * RDA_solver.__init__            rda_solver.py:18-61 | rda_create / rda_create_opts
  * assign_adjust_parameter        rda_solver.py:426   | rda_set_adjust
  * reset                          rda_solver.py:1060  | rda_reset
  * iterative_solve                rda_solver.py:573   | rda_step (host buffers in/out)
@@ -65,25 +68,56 @@ typedef struct rda_handle rda_handle;
 
 enum { RDA_OK = 0, RDA_ERR_ARG = -1, RDA_ERR_UNSUPPORTED = -2, RDA_ERR_HIP = -3, RDA_ERR_NODEVICE = -4 };
 
-int  rda_create(const rda_cfg *cfg, const double *G /*R*2*/, const double *h /*R*/, rda_handle **out);
+/* Solver options that are NOT arguments of the reference's constructor.  rda_opts_init fills the defaults below and then applies
+ * the RDA_* environment overrides (DESIGN.md 7 lists them); a caller changes what it wants and hands the struct to rda_create_opts,
+ * which copies it.  The first block is what a user may want to choose; the rest are the A/B switches of the kernels' restructurings -
+ * every one of them changes where / when work is done, never the result (tests/test_gpu_switches.py). */
+typedef struct rda_opts {
+    int32_t lmz_mode;        /* 0 (default) support enumeration with the tie-breaks T1-T3 of DESIGN.md 2; 1 interior point ending on the
+                                central path of the reference's own cone program at barrier parameter lmz_mu (interior duals like the
+                                reference's solver returns, any combination of cones).  A norm2 robot always uses 1.     RDA_LMZ_MODE */
+    int32_t tie_centre;      /* tie-break T1 in the slack regime: 1 (default) duals of the central separating normal, 0 max clearance.  RDA_TIE_CENTRE */
+    double  lmz_mu;          /* 1e-6                                                                                      RDA_LMZ_MU */
+    double  su_tol[3];       /* interior-point stop of the su-problem: |r_dual|_inf <= [0] (1+|grad|_inf), |r_prim|_inf <= [1], mean
+                                complementarity <= [2] (1+|grad|_inf); 1e-9, 1e-10, 1e-11                                  RDA_SU_TOL */
+    /* ---- A/B switches (defaults in brackets) ---- */
+    int32_t lmz_warm;        /* [1] try the remembered support first                                                   RDA_LMZ_WARM */
+    int32_t lmz_rows;        /* [1] four sub-problems per wave when E+R+1 <= 16                                        RDA_LMZ_ROWS */
+    int32_t lmz_dense_from;  /* [256] workgroup count above which the dense (split) form of the LamMuZ launch is used  RDA_LMZ_DENSE_FROM */
+    int32_t lmz_split;       /* [1] dense grids: common-path kernel + work-list kernel + finalize                      RDA_LMZ_SPLIT */
+    int32_t lmz_tail;        /* [1] the last-arriving LamMuZ workgroup reduces the residuals, takes the early-stop verdict and hands the
+                                result over (0: the next su launch / k_finish do)                                       RDA_LMZ_TAIL */
+    int32_t lmz_ip_rows;     /* [1] interior-point mode: the row-parallel kernel (16 lanes per sub-problem) when the shape allows
+                                (0: one sub-problem per thread)                                                         RDA_LMZ_IP_ROWS */
+    int32_t su_pre;          /* [1] the su set-up reads the block sums / near masks the LamMuZ launch wrote (0: evaluates every term) RDA_SU_PRE */
+    int32_t su_light;        /* [1] convergence pass without the factorisation when the last step predicts convergence  RDA_SU_LIGHT */
+    int32_t su_warm_first;   /* [1] the first su-problem of a step starts from the previous step's multipliers          RDA_SU_WARM_FIRST */
+    int32_t su_warm_cap;     /* [30] iterations granted to a warm attempt                                               RDA_SU_WARM (3rd) */
+    int32_t su_easy_max;     /* [2] easy mode while the last su-solve needed <= this many iterations (0 = never)        RDA_SU_EASY (6th) */
+    int32_t su_easy_nopred;  /* [1] first iteration of an easy attempt without the predictor                            RDA_SU_EASY_NOPRED */
+    int32_t su_cold_from;    /* [7] cold start after a solve with more iterations than this (0 = never) ...              RDA_SU_COLD_FROM */
+    int32_t su_cold_probe;   /* [8] ... every this-many-th such solve tries the warm start                              RDA_SU_COLD_FROM (2nd) */
+    int32_t zero_copy;       /* [1] result slot written into pinned host memory by the kernel, host polls a sequence word  RDA_ZERO_COPY */
+    int32_t early_finish;    /* [1] the launch that detects the early stop hands the result over (0: k_finish does)      RDA_EARLY_FINISH */
+    int32_t fuse_track;      /* [1] k_su_tracked (tracking beside su-problem 0; 0: k_track then k_su)                   RDA_FUSE_TRACK */
+    int32_t su_prof;         /* [0] phase cycle counters of the su-solves (rda_debug_su_prof)                           RDA_SU_PROF */
+    double  su_warm[2];      /* [1e-3, 1e-3] slack floor / barrier parameter of a warm start ("0,0" = always cold)      RDA_SU_WARM */
+    double  su_warm_endgame[2]; /* [0.9999, 1e-5] floors of the fraction to the boundary / centering parameter, warm attempts  RDA_SU_WARM_ENDGAME */
+    double  su_warm_clip;    /* [0.01]                                                                                  RDA_SU_WARM_CLIP */
+    double  su_easy[5];      /* [1e-6, 1e-6, 1e-6, 0.999999, 1e-7] wfl, mu0, clip, tau, sigma of the easy start        RDA_SU_EASY */
+} rda_opts;
+void rda_opts_init(rda_opts *o);
+
+int  rda_create(const rda_cfg *cfg, const double *G /*R*2*/, const double *h /*R*/, rda_handle **out);   /* = rda_create_opts(cfg, NULL, ...) */
+int  rda_create_opts(const rda_cfg *cfg, const rda_opts *opts /* NULL: rda_opts_init */, const double *G, const double *h, rda_handle **out);
 void rda_destroy(rda_handle *h);
 int  rda_set_adjust(rda_handle *h, double slack_gain, double max_sd, double min_sd, double ro1, double ro2);
+/* reset() of the reference (rda_solver.py:1060-1068): clears the lam'A / lam'b products, NOT the duals (quirk Q6); also clears the
+ * handle's solver history (rda_get_su_history) */
 int  rda_reset(rda_handle *h);
 const char *rda_strerror(int code);
 int  rda_device_count(void);
-int  rda_set_device(int dev);
-/* Tie-break T1 for the (degenerate) slack regime of the LamMuZ problem, where every (lam, mu) with H = 0 and m >= 0 is
- * optimal: 1 (default) = duals of the unit normal in the middle of the arc of separating directions, 0 = max-clearance
- * duals.  Process-wide; read by rda_create and rda_lammuz_batch. */
-void rda_set_tie_centre(int on);
-/* Which solver the LamMuZ sub-problems of handles created afterwards use: mode 0 (default) the support enumeration with the
- * tie-breaks T1-T3 of DESIGN.md; mode 1 an interior-point method that returns the point of the central path of the reference's
- * own cone program at barrier parameter `mu` (default 1e-6; interior duals like the reference's interior-point solver returns,
- * any combination of cones, ~100x slower than mode 0).  Handles with a norm2 robot always use mode 1.  Process-wide. */
-void rda_set_lmz_mode(int mode, double mu);
-/* Interior-point stop of the su-problem: |r_dual|_inf <= rd (1 + |grad|_inf), |r_prim|_inf <= rp, mean complementarity
- * <= mu (1 + |grad|_inf).  Process-wide default for handles created afterwards and for rda_su_solve. */
-void rda_set_su_tol(double rd, double rp, double mu);     /* device used by handles created afterwards (one process per GPU) */
+int  rda_set_device(int dev);     /* device used by handles created afterwards (one process per GPU) */
 
 /* One MPC step, host buffers: nom_s 3x(T+1), nom_u 2xT, ref_s 3x(T+1) row-major;
  * obstacles A [n_obs][per_t? T+1 : 1][E][2], b [n_obs][per_t? T+1 : 1][E], cone [n_obs] (0 Rpositive, 1 norm2);
@@ -209,16 +243,26 @@ int  rda_get_state(rda_handle *h, double *lam, double *mu, double *z, double *xi
 int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const double *z,
                    const double *xi, const double *zeta, const double *dis,
                    const double *a_lam, const double *b_lam);
+/* Solver history of a handle: not reference-visible state, but it picks the START of the next su interior-point solve (easy /
+ * moderate / cold), so two handles return bit-identical controls only if it agrees too.  hist[0] = interior-point
+ * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime; lam_keep [10*T] = the inequality
+ * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
+int  rda_get_su_history(rda_handle *h, int32_t *hist /*2*/, double *lam_keep /*10*T*/);
+int  rda_set_su_history(rda_handle *h, const int32_t *hist /*2*/, const double *lam_keep /*10*T*/);
+/* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
+int  rda_debug_su_prof(rda_handle *h, long long *out16);
 
-/* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns obstacle slots
- * [r*N/world, (r+1)*N/world): it solves their LamMuZ problems and keeps their duals; the condensed terms the
- * su-problem needs (8 doubles per (obstacle, stage): a(2), lam'b, mu'h+z-zeta, G'mu+xi (2), two residual
- * partials) form one contiguous chunk per rank, replicated to every rank by ONE all-gather per ADMM iteration
- * (replaces the pool.map scatter/gather of rda_solver.py:706-725); every rank then solves the identical
- * su-problem.  rda_shard_config must precede the first step.  N need not be divisible by world: the shards have
- * ceil(N / world) slots, the slots past the last obstacle carry terms the su-problem ignores (accelerated cost only). */
+/* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns the obstacle slots
+ * [r*ceil(N/world), (r+1)*ceil(N/world)): it solves their LamMuZ problems and keeps their duals.  What the su-problem needs of
+ * them forms one contiguous chunk per rank - 9 doubles per (slot, stage): a(2), lam'b, mu'h+z-zeta, G'mu+xi (2), the two residual
+ * partials, the hinge offset; plus, per (stage, 16-slot block), the 5 reduced sums and the near mask the su set-up reads instead
+ * of passing over the terms - replicated to every rank by ONE all-gather per ADMM iteration (replaces the pool.map scatter/gather
+ * of rda_solver.py:706-725); every rank then solves the identical su-problem.  rda_shard_config must precede the first step.
+ * N need not be divisible by world: the shards have ceil(N / world) slots, the slots past the last obstacle carry terms the
+ * su-problem ignores - this relies on the hinge of the accelerated cost: with accelerated = 0 and N % world != 0
+ * rda_shard_config returns RDA_ERR_UNSUPPORTED. */
 int  rda_shard_config(rda_handle *h, int rank, int world);
-int  rda_shard_chunk_doubles(rda_handle *h);                       /* 8*T*ceil(N/world) */
+int  rda_shard_chunk_doubles(rda_handle *h);                       /* 9*T*Nloc + 6*T*ceil(Nloc/16), Nloc = ceil(N/world) */
 int  rda_shard_get_chunk(rda_handle *h, double *host_chunk);       /* this rank's chunk  */
 int  rda_shard_set_chunks(rda_handle *h, const double *host_all);  /* all `world` chunks, rank-major */
 /* RCCL exchange over xGMI: rank 0 calls rda_shard_unique_id and ships the 128 bytes to the other ranks (any

@@ -23,6 +23,18 @@ class Cfg(C.Structure):
                 ("delta", C.c_double), ("eps_u", C.c_double)]
 
 
+class Opts(C.Structure):
+    """rda_opts of include/rda_hip.h: per-handle solver options that are not reference arguments (filled by rda_opts_init)"""
+    _fields_ = [("lmz_mode", C.c_int), ("tie_centre", C.c_int), ("lmz_mu", C.c_double), ("su_tol", C.c_double * 3),
+                ("lmz_warm", C.c_int), ("lmz_rows", C.c_int), ("lmz_dense_from", C.c_int), ("lmz_split", C.c_int),
+                ("lmz_tail", C.c_int), ("lmz_ip_rows", C.c_int), ("su_pre", C.c_int), ("su_light", C.c_int),
+                ("su_warm_first", C.c_int), ("su_warm_cap", C.c_int), ("su_easy_max", C.c_int), ("su_easy_nopred", C.c_int),
+                ("su_cold_from", C.c_int), ("su_cold_probe", C.c_int), ("zero_copy", C.c_int), ("early_finish", C.c_int),
+                ("fuse_track", C.c_int), ("su_prof", C.c_int),
+                ("su_warm", C.c_double * 2), ("su_warm_endgame", C.c_double * 2), ("su_warm_clip", C.c_double),
+                ("su_easy", C.c_double * 5)]
+
+
 class Info(C.Structure):
     _fields_ = [("resi_dual", C.c_double), ("resi_pri", C.c_double), ("iters", C.c_int),
                 ("su_status", C.c_int), ("su_ipm_iters", C.c_int), ("lmz_fail", C.c_int)]
@@ -54,6 +66,15 @@ class CApi:
         f = self._f
         f("create").argtypes = [C.POINTER(Cfg), c_double_p, c_double_p, C.POINTER(C.c_void_p)]
         f("create").restype = C.c_int
+        self.has_opts = hasattr(lib, f"{prefix}_create_opts")
+        if self.has_opts:
+            f("opts_init").argtypes = [C.POINTER(Opts)]
+            f("opts_init").restype = None
+            f("create_opts").argtypes = [C.POINTER(Cfg), C.POINTER(Opts), c_double_p, c_double_p, C.POINTER(C.c_void_p)]
+            f("create_opts").restype = C.c_int
+            f("get_su_history").argtypes = [C.c_void_p, c_int_p, c_double_p]
+            f("set_su_history").argtypes = [C.c_void_p, c_int_p, c_double_p]
+            f("get_su_history").restype = f("set_su_history").restype = C.c_int
         f("destroy").argtypes = [C.c_void_p]
         f("destroy").restype = None
         f("set_adjust").argtypes = [C.c_void_p] + [C.c_double] * 5

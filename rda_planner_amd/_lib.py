@@ -54,12 +54,10 @@ def hip_api():
         lib.rda_set_device.restype = C.c_int
         lib.rda_strerror.restype = C.c_char_p
         lib.rda_strerror.argtypes = [C.c_int]
-        lib.rda_set_lmz_mode.argtypes = [C.c_int, C.c_double]
-        lib.rda_set_lmz_mode.restype = None
         lib.rda_last_nonconvex.argtypes = [C.c_void_p]
         lib.rda_last_nonconvex.restype = C.c_int
-        lib.rda_set_su_tol.argtypes = [C.c_double] * 3
-        lib.rda_set_su_tol.restype = None
+        lib.rda_debug_su_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        lib.rda_debug_su_prof.restype = C.c_int
         lib.rda_shard_unique_id.argtypes = [C.c_void_p, C.c_void_p]
         lib.rda_shard_comm_init.argtypes = [C.c_void_p, C.c_void_p]
         lib.rda_shard_unique_id.restype = C.c_int

@@ -35,19 +35,23 @@
 
 struct Ctrl {
     int stop, iters, su_status, ipm_iters, st_tmp, it_tmp;
-    int su_last;             // interior-point iterations of the last su-solve of this handle (99 = it did not converge): picks the next start
+    int su_last;             // interior-point iterations of the last su-solve of this handle (99 = none / it did not converge): picks the next start
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
-    int finished;                 // the result slot of this step has been written (by the su launch that detected the early stop)
+    int finished;                 // the result slot of this step has been written (by the launch that ended the step)
     int su_probe;                 // consecutive su-solves in the hard regime (see su_body)
     int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
+    unsigned ticket;              // workgroups of the LamMuZ launch of this iteration that have published their partials (reset by k_su)
+    int resi_iter;                // ADMM iterations of this step whose residuals are in resi_dual / resi_pri (LamMuZ tail, else k_su / k_finish)
+    int pose_ok;                  // Dev::pose and the near masks of Dev::coef describe the same terms (a LamMuZ launch / k_lmz_finalize made them)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
 #endif
 };
 
-constexpr int NCOEF = 11;     // arrays per obstacle-shard chunk of Dev::coef
+constexpr int NCOEF = 9;      // per-(slot, stage) arrays of an obstacle-shard chunk of Dev::coef
+constexpr int NBS = su::NBS;  // doubles per (stage, 16-slot block) partial; one more 8-byte word per block carries the near mask
 struct Dev;
 __host__ __device__ inline double *coef_arr(const Dev &d, int r, int k);
 
@@ -61,55 +65,71 @@ struct Dev {
     double *su_lam_keep;               // inequality multipliers of the last converged su-solve [10*T] (interior-point warm start)
     int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
-    double su_tol[3];                  // interior-point stop of the su-problem (rda_set_su_tol / RDA_SU_TOL="rd,rp,mu")
+    double su_tol[3];                  // interior-point stop of the su-problem (rda_opts::su_tol)
     int su_light;                        // su_device Cfg::light_check
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
-    int su_pre;                        // k_lammuz writes su::term_pre for the next su-problem (RDA_SU_PRE=0: the su set-up evaluates all terms itself)
+    int su_pre;                        // the su set-up reads the block sums / near masks of the LamMuZ launch (0: it evaluates every term itself)
+    int lmz_tail;                      // the last-arriving LamMuZ workgroup reduces the residuals, decides the early stop and hands the result over (P == 1)
     int su_cold_probe;
     int su_cold_from;                  // a solve that follows one with more interior-point iterations than this starts cold (0 = never)
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
-                                       // interior-point iterations; RDA_SU_EASY="wfl,mu0,clip,tau,sigma,max", max = 0 disables)
-    double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (RDA_SU_WARM_CLIP; cold 0.01)
-    double su_warm_tau, su_warm_sig;   // end game of the warm attempt (RDA_SU_WARM_ENDGAME="tau,sigma" floors; cold solves: 0.995, 1e-3)
-    double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 (RDA_SU_WARM="wfl,mu0", "0,0" = cold)
+                                       // interior-point iterations; max = 0 disables)
+    double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (cold 0.01)
+    double su_warm_tau, su_warm_sig;   // end game of the warm attempt (floors; cold solves: 0.995, 1e-3)
+    double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 ("0,0" = cold)
     int lmz_mode;            // 0: support enumeration + tie-breaks T1-T3 (default), 1: interior point, central path at lmz_mu (norm2 robots: always)
     double lmz_mu;           // barrier parameter of the returned central-path point (mode 1)
-    int centre;              // tie-break T1: central separating normal in the slack regime (rda_set_tie_centre)
+    int centre;              // tie-break T1: central separating normal in the slack regime
     int obstacle_num;        // 0 or N
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
     // per (slot, time slot) candidate list and vertices of the staged obstacle (pose independent): k_prepare, at upload
     unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][40], [N*nt][28][2], [N*nt][2] = (npv, nlv)
-    int *hint;                                // [N][T] support (candidate index) of the last max-clearance optimum, -1 = none
-    double *lam, *mu, *z, *xi, *zeta, *dis;   // reference-shaped dual state
+    int *hint;                                // [T][N] support (candidate index) of the last max-clearance optimum, -1 = none
+    // Dual state, STAGE-MAJOR: lam [T+1][N][E], mu [T+1][N][R], xi [T+1][N][2], z / zeta [T][N] - a LamMuZ workgroup owns 16 consecutive
+    // slots of one stage, so what it reads and writes are whole lines (the accessors rda_get_state / rda_set_state speak the
+    // reference's [N][T+1][.] shapes)
+    double *lam, *mu, *z, *xi, *zeta, *dis;
     // Condensed su terms + residual partials, one chunk per obstacle shard (P = 1 on a single GPU):
-    //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0..5 -> ax ay blam ee gx gy,  k = 6,7 -> residual partials
-    // chunk r is produced by rank r's k_lammuz and replicated by one all-gather per ADMM iteration.
-    //   k = 8,9,10 -> su::term_pre of the term at the pose k_lammuz saw (= the nominal of the NEXT su-problem): e0, e1, e2 (negated = far)
-    double *coef; int P, rank, Nloc; size_t chunk;
+    //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0 ax, 1 ay, 2 lam'b, 3 mu'h + z - zeta, 4 / 5 G'mu + xi, 6 dual residual, 7 |Hm|^2,
+    //                                            8 cb = [2] + [3] (the offset of the su hinge)
+    //   bsum : coef[r*chunk + NCOEF*T*Nloc + ((t*J + j)*NBS + q)]   sums over the slots 16j .. 16j+15 of stage t (su::row_term; [6], [7])
+    //   bmask: the 8-byte words behind bsum, [t*J + j]: bit r = slot 16j+r is NEAR (su hinge screening) at the pose table's position
+    // chunk r is produced by rank r's LamMuZ launch and replicated by one all-gather per ADMM iteration.
+    double *coef; int P, rank, Nloc, J; size_t chunk;
     int Nlive;                                // obstacle slots of THIS rank's shard that exist (< Nloc on the last ranks when N % P != 0)
     double *s, *u;                            // nominal (para_s, para_u)
+    double *pose;                             // [T][4] px, py (column t+1), cos, sin (heading of column t) of Dev::s: written by every su launch,
+                                              // read by the LamMuZ rows (no trigonometry per row) and by the next su set-up
     double *ref, *ref_speed;                  // current step reference (device)
     Ctrl *ctrl;
+    long long *su_prof;                       // optional phase cycle counters of the su-solves of this handle (RDA_SU_PROF), else null
 };
 
 __host__ __device__ inline double *coef_arr(const Dev &d, int r, int k) { return d.coef + (size_t)r * d.chunk + (size_t)k * d.c.T * d.Nloc; }
+__host__ __device__ inline double *bsum_arr(const Dev &d, int r) { return d.coef + (size_t)r * d.chunk + (size_t)NCOEF * d.c.T * d.Nloc; }
+__host__ __device__ inline unsigned long long *bmask_arr(const Dev &d, int r) { return (unsigned long long *)(bsum_arr(d, r) + (size_t)NBS * d.c.T * d.J); }
+__host__ __device__ inline size_t chunk_doubles(int T, int Nloc) { const size_t J = (Nloc + 15) / 16; return (size_t)NCOEF * T * Nloc + (size_t)(NBS + 1) * T * J; }
+// row index of (slot n, dual column tt) / (slot n, stage t) in the stage-major dual arrays
+__host__ __device__ inline size_t drow(const Dev &d, int n, int tt) { return (size_t)tt * d.c.N + n; }
 
 // ------------------------------------------------------------------------------------------------
+// resi_dual (mean over the slots of the squared dual change, rda_solver.py:735-737) and resi_pri (|stack(Hm)|, :688) from the block
+// partials of every shard; fixed order -> identical on every rank.  All NT threads; `red` = NT doubles of LDS.
 __device__ void reduce_residuals(const Dev &d, double *red, int tid)
 {
     const int T = d.c.T, N = d.c.N;
     double rd = 0, rp = 0;
     if (d.obstacle_num != 0)
         for (int r = 0; r < d.P; ++r) {
-            const double *r0 = coef_arr(d, r, 6), *r1 = coef_arr(d, r, 7);
-            for (int i = tid; i < d.Nloc * T; i += su::NT) { rd += r0[i]; rp += r1[i]; }
+            const double *bs = bsum_arr(d, r);
+            for (int i = tid; i < d.J * T; i += su::NT) { rd += bs[(size_t)i * NBS + 3]; rp += bs[(size_t)i * NBS + 4]; }
         }
     rd = su::block_reduce(rd, red, tid, false);
     rp = su::block_reduce(rp, red, tid, false);
-    if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); }
+    if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); d.ctrl->resi_iter = d.ctrl->iters; }
     __syncthreads();
 }
 
@@ -143,20 +163,24 @@ __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
     if (tid == 0) __hip_atomic_store((unsigned long long *)(f.mirror + n), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s, const double *in_u,
-                                                           const double *ref, const double *ref_speed,
-                                                           const unsigned long long *ref_flag = nullptr, unsigned long long ref_seq = 0,
-                                                           const Fin *fin = nullptr)
+template <int TT, typename RefWait = su::NoRefWait>
+__device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s, const double *in_u,
+                                        const double *ref, const double *ref_speed,
+                                        const unsigned long long *ref_flag = nullptr, unsigned long long ref_seq = 0,
+                                        const Fin *fin = nullptr, RefWait ref_wait = RefWait())
 {
     const int tid = threadIdx.x;
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
         if (tid == 0) {
             d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0;
+            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0;
         }
         __syncthreads();
     } else if (d.ctrl->stop) return;
-    if (it > 0) {
+    // The early stop of rda_solver.py:594 after iteration it-1.  Normally the LamMuZ launch of that iteration has taken the verdict in
+    // its tail (lmz_tail: residuals reduced, stop flag set, result handed over) and nothing is left to do here; with obstacle shards
+    // (the residual partials of the other ranks arrive with the all-gather) or with the tail switched off it is taken here.
+    if (it > 0 && d.ctrl->resi_iter != it) {
         reduce_residuals(d, smem_su, tid);
         if (d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold) {   // rda_solver.py:594
             __syncthreads();
@@ -170,7 +194,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
             return;
         }
     }
-    if (tid == 0) d.ctrl->wl_count = 0;           // the LamMuZ launches of this iteration start with an empty work list
+    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->ticket = 0; }     // the LamMuZ launches of this iteration start with an empty work list / ticket
     su::Args a;
     a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
@@ -179,12 +203,15 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     a.c.eps_u = d.c.eps_u; a.c.tol_rd = d.su_tol[0]; a.c.tol_rp = d.su_tol[1]; a.c.tol_mu = d.su_tol[2]; a.c.light_check = d.su_light;
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
     a.ref = ref; a.ref_speed = ref_speed; a.ref_flag = ref_flag; a.ref_seq = ref_seq;
-    a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.blam = coef_arr(d, 0, 2); a.ee = coef_arr(d, 0, 3); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
+    a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.cb = coef_arr(d, 0, 8); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
-    // iterations >= 1 are linearised about the previous solution, which is the pose the LamMuZ launch in between worked with
-    if (it > 0 && d.su_pre && d.obstacle_num > 0 && !d.lmz_mode) { a.pre0 = coef_arr(d, 0, 8); a.pre1 = coef_arr(d, 0, 9); a.pre2 = coef_arr(d, 0, 10); }
+    // the reduced form of the terms (block sums, near masks at the pose table's positions): no pass over the N terms in the set-up
+    if (d.su_pre) { a.bsum = bsum_arr(d, 0); a.bmask = bmask_arr(d, 0); a.J = d.J; a.pose = d.pose; a.pose_ok = d.ctrl->pose_ok; }
+    // iterations >= 1 are linearised about the previous solution, whose pose table the previous su launch wrote
+    if (it > 0) { a.pose = d.pose; a.pose_lin = 1; }
+    a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
-    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = nullptr;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = d.su_prof;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
@@ -192,6 +219,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     // While consecutive su-problems are close (static scenes: the previous solve needed one or two iterations) the warm attempt starts
     // 1e-6 from the previous solution's active bounds with its multipliers and takes near-full steps: ONE iteration + the
     // convergence pass.  After a solve that needed more (moving obstacles, a changed active set) the moderate start above is used.
+    // (su_last / su_probe / su_lam_keep are solver history of the handle: rda_reset clears them, rda_get/set_su_history carry them.)
     if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
         a.warm_nopred = d.su_easy_nopred;
@@ -200,7 +228,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
     if (a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
-    su::solve<TT>(a, smem_su);
+    su::solve<TT>(a, smem_su, ref_wait);
     __syncthreads();
     if (tid == 0) {
         d.ctrl->iters = it + 1;
@@ -208,6 +236,7 @@ template <int TT> __device__ __forceinline__ void su_body(const Dev &d, int it, 
         d.ctrl->ipm_iters += d.ctrl->it_tmp;
         d.ctrl->su_last = d.ctrl->st_tmp == 0 ? d.ctrl->it_tmp : 99;
         d.ctrl->su_probe = (d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99) ? d.ctrl->su_probe + 1 : 0;
+        d.ctrl->pose_ok = 0;          // the pose table has moved on; the LamMuZ launch that follows makes the masks that go with it
     }
 }
 
@@ -219,8 +248,8 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, 
 // final bookkeeping of a step that ran all its iterations: residuals of the last one, result slot
 __device__ __forceinline__ void finish_body(const Dev &d, const Fin &f)
 {
-    if (d.ctrl->finished) return;                   // (uniform) the early stop already handed the result over
-    if (!d.ctrl->stop) reduce_residuals(d, smem_su, threadIdx.x);
+    if (d.ctrl->finished) return;                   // (uniform) the launch that ended the step already handed the result over
+    if (!d.ctrl->stop && d.ctrl->resi_iter != d.ctrl->iters) reduce_residuals(d, smem_su, threadIdx.x);
     __syncthreads();
     publish_result(d, f);
 }
@@ -258,6 +287,80 @@ __global__ __launch_bounds__(256) void k_prepare(Dev d)
     if (lane == 0) { d.oc_cnt[2 * w] = W.npv; d.oc_cnt[2 * w + 1] = W.nlv; }
 }
 
+// Unit w of a rank's LamMuZ grid -> (stage t, local slot nl): the SLOT runs fastest and a stage is padded to 16 J units, so a
+// workgroup of the packed kernels (16 rows) owns the slots 16j .. 16j+15 of ONE stage: with the stage-major dual arrays and the
+// [T][Nloc] condensed-term arrays everything it reads and writes are whole lines, and its 16 rows reduce to one block partial.
+__device__ __forceinline__ void unit_of(const Dev &d, int w, int &t, int &nl) { const int S = 16 * d.J; t = w / S; nl = w - t * S; }
+
+// What one solved (or failed) row hands to the su-problem and to the residuals, as stored in the coef arrays
+struct RowOut { double ax, ay, bl, c3, c4, c5, res, hh; };
+__device__ __forceinline__ void store_row(const Dev &d, int k, const RowOut &o)
+{
+    coef_arr(d, d.rank, 0)[k] = o.ax; coef_arr(d, d.rank, 1)[k] = o.ay; coef_arr(d, d.rank, 2)[k] = o.bl;   // rda_solver.py:541-542
+    coef_arr(d, d.rank, 3)[k] = o.c3; coef_arr(d, d.rank, 4)[k] = o.c4; coef_arr(d, d.rank, 5)[k] = o.c5;
+    coef_arr(d, d.rank, 6)[k] = o.res; coef_arr(d, d.rank, 7)[k] = o.hh; coef_arr(d, d.rank, 8)[k] = o.bl + o.c3;
+}
+// a row that cannot be solved (non-finite data or result): previous lam, mu, z, xi, zeta stay; the stage drops out of the su hinge
+// (a = 0, offset and g as they were); its residual is inf (rda_solver.py:781-793)
+__device__ __forceinline__ RowOut failed_row(const Dev &d, int k)
+{
+    RowOut o; o.ax = 0; o.ay = 0; o.bl = 0; o.c3 = coef_arr(d, d.rank, 3)[k]; o.c4 = coef_arr(d, d.rank, 4)[k]; o.c5 = coef_arr(d, d.rank, 5)[k];
+    o.res = INFINITY; o.hh = 0;
+    return o;
+}
+
+// 16 row records [16][6] = (|a|^2, g.a, g x a, dual residual, |Hm|^2, near) in LDS -> the block partial of (stage t, block j): threads
+// q = 0..4 sum one quantity over the rows IN ROW ORDER (dead rows hold zeros), thread 5 packs the near mask.  Stored write-through
+// (sc1: 8-byte agent-scope stores), so the last-arriving workgroup of the launch may read them without a release fence (lmz_tail).
+__device__ __forceinline__ void block_partial(const Dev &d, int t, int j, const double (*rowv)[6], int q)
+{
+    const size_t bi = (size_t)t * d.J + j;
+    if (q < NBS) {
+        double acc = 0;
+        for (int r = 0; r < 16; ++r) acc += rowv[r][q];
+        __hip_atomic_store(bsum_arr(d, d.rank) + bi * NBS + q, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (q == NBS) {
+        unsigned long long m = 0;
+        for (int r = 0; r < 16; ++r) m |= rowv[r][5] != 0.0 ? 1ull << r : 0ull;
+        __hip_atomic_store(bmask_arr(d, d.rank) + bi, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void row_record(double *rv, const Dev &d, const RowOut &o, double px, double py)
+{
+    const su::RowTerm q = su::row_term(o.ax, o.ay, o.c4, o.c5, o.bl + o.c3, px, py, d.c.max_sd, true);
+    rv[0] = q.aa; rv[1] = q.ga; rv[2] = q.gxa; rv[3] = o.res; rv[4] = o.hh; rv[5] = (!d.c.accelerated || q.near) ? 1.0 : 0.0;
+}
+
+// Tail of the LamMuZ step of ADMM iteration `it` on a single rank.  Every workgroup has published its block partials write-through;
+// it drains them and takes a ticket.  The LAST one to arrive acquires, reduces the residual partials of all blocks in a fixed order
+// (the values do not depend on which workgroup that is), takes the early-stop verdict of rda_solver.py:594 and - when the step ends
+// here (stop, or the last iteration) - hands the result over.  The su launch that used to detect the stop (and k_finish) leave the
+// critical path: a two-iteration step is su, lmz, su, lmz.  All 256 threads call; `red` >= 256 doubles of LDS, `flag` one LDS word.
+__device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, double *red, unsigned *flag, unsigned nblocks)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its sc1 stores ...
+    __syncthreads();
+    if (threadIdx.x == 0) {                                     // ... before the workgroup's ticket
+        const unsigned old = __hip_atomic_fetch_add(&d.ctrl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = old == nblocks - 1 ? 1u : 0u;
+        if (old == nblocks - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (threadIdx.x == 0) d.ctrl->pose_ok = 1;                  // masks and pose table describe the same terms from here on
+    reduce_residuals(d, red, threadIdx.x);
+    const bool last = it + 1 >= d.c.iter_num;
+    const bool stop = !last && d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;      // rda_solver.py:594
+    __syncthreads();
+    if (stop && threadIdx.x == 0) d.ctrl->stop = 1;
+    if ((stop || last) && fin.out_u) {
+        publish_result(d, fin);
+        if (threadIdx.x == 0) d.ctrl->finished = 1;
+    }
+}
+
+// K1, one (slot, stage) sub-problem per wavefront; 4 wavefronts per workgroup (shapes with E+R+1 > 16, RDA_LMZ_ROWS=0, and the
+// no-obstacle case).  Writes the per-row terms only: k_lmz_finalize forms the block partials and runs the tail behind it.
 __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
 {
 #pragma clang fp contract(on)          // see lammuz_device.h: results independent of the kernel the body is compiled into
@@ -272,6 +375,7 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
             for (int t = threadIdx.x; t < T; t += 256) {
                 int i = t * d.Nloc + (N - 1) % d.Nloc;
                 coef_arr(d, d.rank, 0)[i] = 0; coef_arr(d, d.rank, 1)[i] = 0; coef_arr(d, d.rank, 2)[i] = 0;
+                coef_arr(d, d.rank, 8)[i] = coef_arr(d, d.rank, 3)[i];
             }
         return;
     }
@@ -281,12 +385,9 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
     if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int w = block * 4 + wv;
-    const bool live = w < d.Nlive * T;
-    // unit w -> (slot, stage) with the STAGE fastest: a wave's rows then read neighbouring (n, t) rows of the reference-shaped dual
-    // arrays.  Measured alternative (slot fastest, so that the [T][Nloc] condensed-term stores of a block form whole lines): WRITE_SIZE
-    // 1.48 -> 1.04 MB per launch but FETCH_SIZE 0.71 -> 1.87 MB (the 128-byte lines of lam / mu / xi are then shared by blocks on
-    // different XCDs and fetched once per L2), same launch time - the kernel is latency-bound either way
-    const int nl = live ? w / T : 0, t = live ? w % T : 0;
+    int t, nl; unit_of(d, w, t, nl);
+    const bool live = t < T && nl < d.Nlive;
+    if (!live) { t = 0; nl = 0; }
     const int n = d.rank * d.Nloc + nl;                        // this rank's obstacle shard [rank*Nloc, (rank+1)*Nloc)
     lmz::WaveLDS &W = wl[wv];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
@@ -294,15 +395,13 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     if (lane < E) W.b[lane] = d.b[ao + lane];
     __syncthreads();
     if (!live) return;
-    (void)N;
     lmz::Params P;
     P.E = E; P.R = R; P.norm2 = d.cone[n];
-    P.px = d.s[t + 1]; P.py = d.s[(T + 1) + t + 1];
-    const double phi = d.s[2 * (T + 1) + t];                  // heading of column t (quirk Q1)
-    P.cs = cos(phi); P.sn = sin(phi);
-    const size_t o = (size_t)n * (T + 1) + t + 1;
+    const double *ps = d.pose + 4 * t;                        // position of column t+1, heading of column t (quirk Q1)
+    P.px = ps[0]; P.py = ps[1]; P.cs = ps[2]; P.sn = ps[3];
+    const size_t o = drow(d, n, t + 1), zi = drow(d, n, t);
     P.xi0 = d.xi[2 * o]; P.xi1 = d.xi[2 * o + 1];
-    const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
+    const double zeta = d.zeta[zi], dbar = d.dis[t];
     P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
     lmz::Sol best;
     // previous value of this lane's dual entry: warm start of the support + the dual residual below
@@ -312,7 +411,6 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     // A sub-problem whose data are not finite cannot be solved: like a LamMuZ solve of the reference that does not end OPTIMAL
     // (rda_solver.py:781-793) it keeps its previous duals and its residual is inf (no early stop).  The solver below is run on
     // harmless stand-in data instead (its loops then see no NaN) and its answer is dropped.
-    const double px0 = P.px, py0 = P.py, cs0 = P.cs, sn0 = P.sn;       // (the pose as read: a failed row overwrites it with stand-ins)
     bool bad = !isfinite(P.px + P.py + P.cs + P.sn + P.xi0 + P.xi1 + P.kappa0);
     if (lane < 2 * E) bad = bad || !isfinite(W.A[lane >> 1][lane & 1]);
     if (lane < E) bad = bad || !isfinite(W.b[lane]);
@@ -331,21 +429,15 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
         if (lane == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
-    if (!d.warm || !lmz::solve_wave_warm<64>(W, rb, P, lane, d.hint[n * T + t], best)) lmz::solve_wave(W, rb, P, lane, best);
-    if (lane == 0) d.hint[n * T + t] = best.id >> 1;
+    if (!d.warm || !lmz::solve_wave_warm<64>(W, rb, P, lane, d.hint[zi], best)) lmz::solve_wave(W, rb, P, lane, best);
+    if (lane == 0) d.hint[zi] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave<64>(W, rb, P, lane, best);
     bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));
-    if (bad) {              // previous lam, mu, z, xi, zeta stay; the stage drops out of the su hinge (a = 0); residual inf
+    const int k = t * d.Nloc + nl;
+    if (bad) {
         if (lane == 0) {
-            const int k = t * d.Nloc + nl;
-            coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
-            coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
-            if (d.su_pre) {      // the term as the next su-problem will see it: a = 0, the previous offset and g
-                const su::TermPre tp = su::term_pre(0.0, 0.0, coef_arr(d, d.rank, 4)[k], coef_arr(d, d.rank, 5)[k], 0.0 + coef_arr(d, d.rank, 3)[k],
-                                                    cs0, sn0, px0, py0, d.c.max_sd);
-                coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
-            }
-            d.hint[n * T + t] = -1;
+            store_row(d, k, failed_row(d, k));
+            d.hint[zi] = -1;
             atomicAdd(&d.ctrl->lmz_fail, 1);
         }
         return;
@@ -361,8 +453,8 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
         double v = lmz::mu_of(best, j);
         res = (v - prev) * (v - prev); d.mu[o * R + j] = v;
     } else if (lane == E + R) {
-        double old = d.z[n * T + t];
-        res = (znew - old) * (znew - old); d.z[n * T + t] = znew;
+        double old = d.z[zi];
+        res = (znew - old) * (znew - old); d.z[zi] = znew;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
@@ -381,16 +473,10 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
         d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
         const double im = ax * P.px + ay * P.py - bl - mh;                                  // :659
         const double zetan = zeta + im - dbar - znew;                                       // :666
-        d.zeta[n * T + t] = zetan;
-        const int k = t * d.Nloc + nl;
-        coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
-        coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
-        coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
-        if (d.su_pre) {      // what this term adds to the set-up of the NEXT su-problem, which is linearised about the pose used here
-            const double c3 = mh + znew - zetan, c4 = gx + xin0, c5 = gy + xin1;
-            const su::TermPre tp = su::term_pre(ax, ay, c4, c5, bl + c3, P.cs, P.sn, P.px, P.py, d.c.max_sd);
-            coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
-        }
+        d.zeta[zi] = zetan;
+        RowOut ro; ro.ax = ax; ro.ay = ay; ro.bl = bl; ro.c3 = mh + znew - zetan; ro.c4 = gx + xin0; ro.c5 = gy + xin1;
+        ro.res = res; ro.hh = hx * hx + hy * hy;
+        store_row(d, k, ro);
     }
 }
 
@@ -402,16 +488,21 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx
 // (DESIGN.md section 5): the rows run it side by side.  Only a row whose certificate fails needs the 64-lane enumeration;
 // those rows are served one after the other by the whole wave.  Same device functions, same arithmetic, same results as
 // lammuz_body.  Requires E + R + 1 <= 16 (else the one-per-wave body is launched).
-// MODE 0: everything in one kernel (single ego, latency).  Dense grids are served by two launches instead:
-// MODE 1: the common path only - 154 registers, three waves per SIMD, no spills; a row whose warm candidate fails its certificate
-//         goes on the handle's work list (Dev::wl) and writes nothing;
+// MODE 0: everything in one kernel (single ego, latency), INCLUDING the block partial of the workgroup's 16 slots and the tail of
+//         the step (lmz_tail).  Dense grids are served by three launches instead:
+// MODE 1: the common path only - three waves per SIMD, no spills; a row whose warm candidate fails its certificate goes on the
+//         handle's work list (Dev::wl) and writes nothing;
 // MODE 2: the rows on the work list, ONE per wave (row 0 of the wave; rows 1-3 idle) and pass, straight to the enumeration, then
-//         the very same 16-lane code as modes 0 / 1 - so the results do not depend on which launch solved a row.
-template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks = 1)
+//         the very same 16-lane code as modes 0 / 1 - so the results do not depend on which launch solved a row;
+//         then k_lmz_finalize: block partials from the stored terms (same function, same order as mode 0) and the tail.
+template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
 {
 #pragma clang fp contract(on)          // see lammuz_device.h
     __shared__ lmz::WaveLDS wl[16];
     __shared__ lmz::RobotLDS rb;
+    __shared__ double rowv[MODE == 0 ? 16 : 1][6];
+    __shared__ double tail_red[MODE == 0 ? 256 : 1];
+    __shared__ unsigned tail_flag;
     const int T = d.c.T, E = d.c.E, R = d.c.R;
     if (d.ctrl->stop) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4, gl = lane & 15;
@@ -423,12 +514,13 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     const int cnt = MODE == 2 ? d.ctrl->wl_count : 1;
     for (int base = MODE == 2 ? block * 4 : 0; base < cnt; base += MODE == 2 ? nblocks * 4 : 1) {       // modes 0, 1: one pass
     if (MODE == 2) __syncthreads();                            // the slabs of the previous pass are free again
-    const int w0 = MODE == 2 ? 0 : block * 16 + wv * 4 + row;
     const bool entry = MODE == 2 && base + wv < cnt;            // (wave-uniform) this wave has a work-list entry in this pass
-    const bool live = MODE == 2 ? (entry && row == 0) : w0 < d.Nlive * T;
-    // a row past the end (an idle row of mode 2) shadows a live one and writes nothing
-    const int w = MODE == 2 ? d.wl[entry ? base + wv : base] : (live ? w0 : block * 16);
-    const int nl = w / T, t = w % T;                          // stage fastest: see lammuz_body
+    // a row past the end (a dead slot of the padded stage, an idle row of mode 2) shadows unit (0, 0) and writes nothing
+    int t, nl;
+    unit_of(d, MODE == 2 ? d.wl[entry ? base + wv : base] : block * 16 + wv * 4 + row, t, nl);
+    const bool live = MODE == 2 ? (entry && row == 0) : (t < T && nl < d.Nlive);
+    const int tb = t, jb = nl >> 4;                            // (modes 0, 1) the workgroup's block: stage and 16-slot group
+    if (!live) { t = t < T ? t : 0; nl = 0; }
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
@@ -437,19 +529,18 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     __syncthreads();
     lmz::Params P;
     P.E = E; P.R = R; P.norm2 = d.cone[n];
-    P.px = d.s[t + 1]; P.py = d.s[(T + 1) + t + 1];
-    const double phi = d.s[2 * (T + 1) + t];                  // heading of column t (quirk Q1)
-    P.cs = cos(phi); P.sn = sin(phi);
-    const size_t o = (size_t)n * (T + 1) + t + 1;
+    const double *ps = d.pose + 4 * t;                        // position of column t+1, cos / sin of the heading of column t (quirk Q1)
+    P.px = ps[0]; P.py = ps[1]; P.cs = ps[2]; P.sn = ps[3];
+    const size_t o = drow(d, n, t + 1), zi = drow(d, n, t);
     P.xi0 = d.xi[2 * o]; P.xi1 = d.xi[2 * o + 1];
-    const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
+    const double zeta = d.zeta[zi], dbar = d.dis[t];
     P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
     lmz::Sol best;
     double prev = 0.0;
     if (gl < E) prev = d.lam[o * E + gl];
     else if (gl < E + R) prev = d.mu[o * R + gl - E];
     // non-finite data: see lammuz_body (the row solves harmless stand-in data, keeps its previous duals, residual inf)
-    const double px0 = P.px, py0 = P.py, cs0 = P.cs, sn0 = P.sn;       // (the pose as read: a failed row overwrites it with stand-ins)
+    const double px0 = P.px, py0 = P.py;                       // (the pose as read: a failed row overwrites it with stand-ins)
     bool bad = !isfinite(P.px + P.py + P.cs + P.sn + P.xi0 + P.xi1 + P.kappa0);
     if (gl < 2 * E) bad = bad || !isfinite(W.A[gl >> 1][gl & 1]);
     if (gl < E) bad = bad || !isfinite(W.b[gl]);
@@ -468,7 +559,12 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
-    const bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[n * T + t], best);
+    bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[zi], best);
+    if (MODE != 2 && !live && !ok) {                           // a dead row never asks for the enumeration; nothing of `best` is used
+        best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
+        best.l1 = best.l2 = best.g1 = best.g2 = 0;
+        ok = true;
+    }
     unsigned long long need = __ballot(!ok);                   // rows that need the enumeration (wave-uniform from here)
     if (MODE == 2) {
         need = entry ? 0xffffull : 0ull;                        // row 0 only
@@ -491,7 +587,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
             best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
             best.l1 = best.l2 = best.g1 = best.g2 = 0;
         }
-        if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = w;
+        if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = t * 16 * d.J + nl;
         need = 0;
     }
     while (need) {
@@ -507,7 +603,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         lmz::solve_wave(wl[wv * 4 + g], rb, Pg, lane, bg);
         if (row == g) best = bg;
     }
-    if (gl == 0 && live && !defer) d.hint[n * T + t] = best.id >> 1;
+    if (gl == 0 && live && !defer) d.hint[zi] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave<16>(W, rb, P, lane, best);
     bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));      // uniform over the row
     // ---- fused dual / residual updates (every lane of the row holds the row's winner) ----------------
@@ -522,59 +618,90 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         double v = lmz::mu_of(best, j);
         res = (v - prev) * (v - prev); if (wr) d.mu[o * R + j] = v;
     } else if (gl == E + R) {
-        double old = d.z[n * T + t];
-        res = (znew - old) * (znew - old); if (wr) d.z[n * T + t] = znew;
+        double old = d.z[zi];
+        res = (znew - old) * (znew - old); if (wr) d.z[zi] = znew;
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) res += __shfl_xor(res, off, 16);
-    if (gl == 0 && live && bad) {       // previous lam, mu, z, xi, zeta stay; the stage drops out of the su hinge; residual inf
+    if (gl == 0) {
         const int k = t * d.Nloc + nl;
-        coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
-        coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
-        if (d.su_pre) {      // the term as the next su-problem will see it: a = 0, the previous offset and g
-            const su::TermPre tp = su::term_pre(0.0, 0.0, coef_arr(d, d.rank, 4)[k], coef_arr(d, d.rank, 5)[k], 0.0 + coef_arr(d, d.rank, 3)[k],
-                                                cs0, sn0, px0, py0, d.c.max_sd);
-            coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
+        RowOut ro;
+        bool have = false;
+        if (live && bad) {
+            ro = failed_row(d, k); have = true;
+            store_row(d, k, ro);
+            d.hint[zi] = -1;
+            atomicAdd(&d.ctrl->lmz_fail, 1);
+        } else if (wr) {
+            double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
+            for (int i = 0; i < E; ++i) {
+                double v = lmz::lam_of(best, P.norm2, i);
+                ax += v * W.A[i][0]; ay += v * W.A[i][1]; bl += v * W.b[i];
+            }
+            for (int j = 0; j < R; ++j) {
+                double v = lmz::mu_of(best, j);
+                mh += v * rb.h[j]; gx += v * rb.G[j][0]; gy += v * rb.G[j][1];
+            }
+            const double hx = gx + P.cs * ax + P.sn * ay, hy = gy - P.sn * ax + P.cs * ay;      // Hm, :682
+            const double xin0 = P.xi0 + hx, xin1 = P.xi1 + hy;                                  // :683
+            d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
+            const double im = ax * P.px + ay * P.py - bl - mh;                                  // :659
+            const double zetan = zeta + im - dbar - znew;                                       // :666
+            d.zeta[zi] = zetan;
+            ro.ax = ax; ro.ay = ay; ro.bl = bl; ro.c3 = mh + znew - zetan; ro.c4 = gx + xin0; ro.c5 = gy + xin1;
+            ro.res = res; ro.hh = hx * hx + hy * hy; have = true;
+            store_row(d, k, ro);
         }
-        d.hint[n * T + t] = -1;
-        atomicAdd(&d.ctrl->lmz_fail, 1);
+        if (MODE == 0) {                  // this row's record for the block partial (a dead slot: zeros)
+            double *rv = rowv[wv * 4 + row];
+            if (have) row_record(rv, d, ro, px0, py0);
+            else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
+        }
     }
-    if (gl == 0 && wr) {
-        double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
-        for (int i = 0; i < E; ++i) {
-            double v = lmz::lam_of(best, P.norm2, i);
-            ax += v * W.A[i][0]; ay += v * W.A[i][1]; bl += v * W.b[i];
-        }
-        for (int j = 0; j < R; ++j) {
-            double v = lmz::mu_of(best, j);
-            mh += v * rb.h[j]; gx += v * rb.G[j][0]; gy += v * rb.G[j][1];
-        }
-        const double hx = gx + P.cs * ax + P.sn * ay, hy = gy - P.sn * ax + P.cs * ay;      // Hm, :682
-        const double xin0 = P.xi0 + hx, xin1 = P.xi1 + hy;                                  // :683
-        d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
-        const double im = ax * P.px + ay * P.py - bl - mh;                                  // :659
-        const double zetan = zeta + im - dbar - znew;                                       // :666
-        d.zeta[n * T + t] = zetan;
-        const int k = t * d.Nloc + nl;
-        coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
-        coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
-        coef_arr(d, d.rank, 6)[k] = res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
-        if (d.su_pre) {      // what this term adds to the set-up of the NEXT su-problem, which is linearised about the pose used here
-            const double c3 = mh + znew - zetan, c4 = gx + xin0, c5 = gy + xin1;
-            const su::TermPre tp = su::term_pre(ax, ay, c4, c5, bl + c3, P.cs, P.sn, P.px, P.py, d.c.max_sd);
-            coef_arr(d, d.rank, 8)[k] = tp.e0; coef_arr(d, d.rank, 9)[k] = tp.e1; coef_arr(d, d.rank, 10)[k] = tp.far ? -tp.e2 : tp.e2;
-        }
+    if (MODE == 0) {
+        __syncthreads();
+        if (tb < T) block_partial(d, tb, jb, rowv, threadIdx.x);
+        if (d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, tail_red, &tail_flag, (unsigned)nblocks);
+        else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
     }
     }
 }
 
 // two builds: all registers and one workgroup per CU (no spills: the shorter critical path a single ego wants), or two
 // workgroups per CU with a few spilled registers (more sub-problems in flight: what a full chip wants)
-__global__ __launch_bounds__(256) void k_lammuz_rows(Dev d) { lammuz_body_rows(d, blockIdx.x); }
-__global__ __launch_bounds__(256, 2) void k_lammuz_rows_dense(Dev d) { lammuz_body_rows(d, blockIdx.x); }
-__global__ __launch_bounds__(256, 3) void k_lammuz_rows_fast(Dev d) { lammuz_body_rows<1>(d, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
+__global__ __launch_bounds__(256, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
+__global__ __launch_bounds__(256, 3) void k_lammuz_rows_fast(Dev d) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 // (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower; the work list with two workgroups per CU is 4 % faster for fleets)
-__global__ __launch_bounds__(256, 2) void k_lammuz_enum(Dev d) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256, 2) void k_lammuz_enum(Dev d) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+
+// Block partials from the STORED terms - the same row_term, the same row order as mode 0 of the packed kernel forms them in flight - and
+// the tail of the step.  Runs behind every LamMuZ form that leaves its rows to more than one workgroup or launch (split launch, one
+// sub-problem per wave, the per-thread interior-point kernel), after the no-obstacle launch (quirk Q9 edits terms) and whenever the
+// host rewrites terms (rda_set_state, rda_reset, rda_shard_config).  One 16-slot block per 16-lane group; it < 0: no tail.
+__device__ __forceinline__ void finalize_body(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
+{
+#pragma clang fp contract(on)
+    __shared__ double rowv[16][16][6];
+    __shared__ double tail_red[256];
+    __shared__ unsigned tail_flag;
+    if (it >= 0 && d.ctrl->stop) return;
+    const int T = d.c.T, g = threadIdx.x >> 4, row = threadIdx.x & 15;
+    const int B = block * 16 + g, t = B / d.J, j = B - t * d.J, nl = 16 * j + row;
+    double *rv = rowv[g][row];
+    if (B < T * d.J && nl < d.Nlive) {
+        const int k = t * d.Nloc + nl;
+        RowOut ro; ro.ax = coef_arr(d, d.rank, 0)[k]; ro.ay = coef_arr(d, d.rank, 1)[k]; ro.bl = coef_arr(d, d.rank, 2)[k];
+        ro.c3 = coef_arr(d, d.rank, 3)[k]; ro.c4 = coef_arr(d, d.rank, 4)[k]; ro.c5 = coef_arr(d, d.rank, 5)[k];
+        ro.res = coef_arr(d, d.rank, 6)[k]; ro.hh = coef_arr(d, d.rank, 7)[k];
+        row_record(rv, d, ro, d.pose[4 * t], d.pose[4 * t + 1]);
+    } else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
+    __syncthreads();
+    if (B < T * d.J) block_partial(d, t, j, rowv[g], row);
+    if (it >= 0 && d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, tail_red, &tail_flag, (unsigned)nblocks);
+    else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
+}
+__global__ __launch_bounds__(256) void k_lmz_finalize(Dev d, int it, Fin fin) { finalize_body(d, blockIdx.x, gridDim.x, it, fin); }
 
 // K1, interior-point variant (lammuz_cp_device.h): one (obstacle, stage) sub-problem per thread, same fused dual / residual
 // updates as lammuz_body.  A solve that does not end on the central path keeps the previous duals of its stage and makes the
@@ -589,12 +716,13 @@ template <int NX, int MX> __device__ __forceinline__ void lammuz_cp_body(const D
         if (w < T && d.rank == (d.c.N - 1) / d.Nloc) {
             const int i = w * d.Nloc + (d.c.N - 1) % d.Nloc;
             coef_arr(d, d.rank, 0)[i] = 0; coef_arr(d, d.rank, 1)[i] = 0; coef_arr(d, d.rank, 2)[i] = 0;
+            coef_arr(d, d.rank, 8)[i] = coef_arr(d, d.rank, 3)[i];
         }
         return;
     }
     if (w >= d.Nlive * T) return;
     const int nl = w % d.Nlive, t = w / d.Nlive, n = d.rank * d.Nloc + nl;
-    const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E, o = (size_t)n * (T + 1) + t + 1;
+    const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E, o = drow(d, n, t + 1), zi = drow(d, n, t);
     const int k = t * d.Nloc + nl;
     double A[16], b[8];
     for (int i = 0; i < 2 * E; ++i) A[i] = d.A[ao * 2 + i];
@@ -602,18 +730,16 @@ template <int NX, int MX> __device__ __forceinline__ void lammuz_cp_body(const D
     cpq::Problem p;
     p.E = E; p.R = R; p.cone_norm2 = d.cone[n]; p.robot_norm2 = d.c.robot_norm2; p.accelerated = d.c.accelerated;
     p.A = A; p.b = b; p.G = d.G; p.h = d.h;
-    p.px = d.s[t + 1]; p.py = d.s[(T + 1) + t + 1];
-    const double phi = d.s[2 * (T + 1) + t];                  // heading of column t (quirk Q1)
-    p.cs = cos(phi); p.sn = sin(phi);
+    const double *ps = d.pose + 4 * t;                        // position of column t+1, heading of column t (quirk Q1)
+    p.px = ps[0]; p.py = ps[1]; p.cs = ps[2]; p.sn = ps[3];
     p.xi0 = d.xi[2 * o]; p.xi1 = d.xi[2 * o + 1];
-    const double zeta = d.zeta[n * T + t], dbar = d.dis[t];
+    const double zeta = d.zeta[zi], dbar = d.dis[t];
     p.kappa0 = zeta - dbar; p.ro2 = d.c.ro2; p.mu_target = d.lmz_mu;
     bool finite_in = isfinite(p.px + p.py + p.cs + p.sn + p.xi0 + p.xi1 + p.kappa0);
     for (int i = 0; i < 2 * E; ++i) finite_in = finite_in && isfinite(A[i]);
     for (int i = 0; i < E; ++i) finite_in = finite_in && isfinite(b[i]);
     if (!finite_in) {
-        coef_arr(d, d.rank, 0)[k] = 0; coef_arr(d, d.rank, 1)[k] = 0; coef_arr(d, d.rank, 2)[k] = 0;
-        coef_arr(d, d.rank, 6)[k] = INFINITY; coef_arr(d, d.rank, 7)[k] = 0;
+        store_row(d, k, failed_row(d, k));
         atomicAdd(&d.ctrl->lmz_fail, 1);
         return;
     }
@@ -626,11 +752,11 @@ template <int NX, int MX> __device__ __forceinline__ void lammuz_cp_body(const D
     double res = 0, lam[8], mu[8], znew;
     for (int i = 0; i < E; ++i) { const double old = d.lam[o * E + i]; lam[i] = fail ? old : rs.lam[i]; res += (lam[i] - old) * (lam[i] - old); }
     for (int j = 0; j < R; ++j) { const double old = d.mu[o * R + j]; mu[j] = fail ? old : rs.mu[j]; res += (mu[j] - old) * (mu[j] - old); }
-    { const double old = d.z[n * T + t]; znew = fail ? old : rs.z; res += (znew - old) * (znew - old); }
+    { const double old = d.z[zi]; znew = fail ? old : rs.z; res += (znew - old) * (znew - old); }
     if (!fail) {
         for (int i = 0; i < E; ++i) d.lam[o * E + i] = lam[i];
         for (int j = 0; j < R; ++j) d.mu[o * R + j] = mu[j];
-        d.z[n * T + t] = znew;
+        d.z[zi] = znew;
     } else atomicAdd(&d.ctrl->lmz_fail, 1);
     double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
     for (int i = 0; i < E; ++i) { ax += lam[i] * A[2 * i]; ay += lam[i] * A[2 * i + 1]; bl += lam[i] * b[i]; }
@@ -640,10 +766,10 @@ template <int NX, int MX> __device__ __forceinline__ void lammuz_cp_body(const D
     d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
     const double im = ax * p.px + ay * p.py - bl - mh;                                  // :659
     const double zetan = zeta + im - dbar - znew;                                       // :666
-    d.zeta[n * T + t] = zetan;
-    coef_arr(d, d.rank, 0)[k] = ax; coef_arr(d, d.rank, 1)[k] = ay; coef_arr(d, d.rank, 2)[k] = bl;   // :541-542
-    coef_arr(d, d.rank, 3)[k] = mh + znew - zetan; coef_arr(d, d.rank, 4)[k] = gx + xin0; coef_arr(d, d.rank, 5)[k] = gy + xin1;
-    coef_arr(d, d.rank, 6)[k] = fail ? INFINITY : res; coef_arr(d, d.rank, 7)[k] = hx * hx + hy * hy;
+    d.zeta[zi] = zetan;
+    RowOut ro; ro.ax = ax; ro.ay = ay; ro.bl = bl; ro.c3 = mh + znew - zetan; ro.c4 = gx + xin0; ro.c5 = gy + xin1;
+    ro.res = fail ? INFINITY : res; ro.hh = hx * hx + hy * hy;
+    store_row(d, k, ro);
 }
 __global__ __launch_bounds__(64) void k_lammuz_cp_small(Dev d) { lammuz_cp_body<16, 24>(d); }      // E, R <= 4
 __global__ __launch_bounds__(64) void k_lammuz_cp_large(Dev d) { lammuz_cp_body<24, 36>(d); }      // E, R <= 8
@@ -714,33 +840,46 @@ __global__ void k_products_get(Dev d, double *a_lam, double *b_lam)
         a_lam[2 * i] = ax; a_lam[2 * i + 1] = ay; b_lam[i] = bl;
     }
 }
-// rebuild every condensed term from the reference-shaped state (after rda_set_state)
+// rebuild every condensed term from the dual state (after rda_set_state); k_lmz_finalize then rebuilds the block partials
 __global__ void k_products_set(Dev d, const double *a_lam, const double *b_lam)
 {
     const int T = d.c.T, N = d.c.N, R = d.c.R;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * T; i += gridDim.x * blockDim.x) {
         int n = i / T, t = i % T, r = n / d.Nloc, k = t * d.Nloc + (n - r * d.Nloc);
-        size_t o = (size_t)n * (T + 1) + t + 1;
-        if (a_lam) { coef_arr(d, r, 0)[k] = a_lam[2 * o]; coef_arr(d, r, 1)[k] = a_lam[2 * o + 1]; }
-        if (b_lam) coef_arr(d, r, 2)[k] = b_lam[o];
+        const size_t o = drow(d, n, t + 1), zi = drow(d, n, t), oh = (size_t)n * (T + 1) + t + 1;     // oh: the caller's [N][T+1] layout
+        if (a_lam) { coef_arr(d, r, 0)[k] = a_lam[2 * oh]; coef_arr(d, r, 1)[k] = a_lam[2 * oh + 1]; }
+        if (b_lam) coef_arr(d, r, 2)[k] = b_lam[oh];
         double mh = 0, gx = 0, gy = 0;
         for (int j = 0; j < R; ++j) { double v = d.mu[o * R + j]; mh += v * d.h[j]; gx += v * d.G[2 * j]; gy += v * d.G[2 * j + 1]; }
-        coef_arr(d, r, 3)[k] = mh + d.z[n * T + t] - d.zeta[n * T + t];
+        coef_arr(d, r, 3)[k] = mh + d.z[zi] - d.zeta[zi];
         coef_arr(d, r, 4)[k] = gx + d.xi[2 * o]; coef_arr(d, r, 5)[k] = gy + d.xi[2 * o + 1];
+        coef_arr(d, r, 8)[k] = coef_arr(d, r, 2)[k] + coef_arr(d, r, 3)[k];
+        coef_arr(d, r, 6)[k] = 0; coef_arr(d, r, 7)[k] = 0;
     }
 }
+// reset() of the reference (rda_solver.py:1060-1068) clears the lam'A / lam'b products only - the duals stay (quirk Q6)
 __global__ void k_reset(Dev d)
 {
     const int T = d.c.T;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.P * d.Nloc * T; i += gridDim.x * blockDim.x) {     // incl. padding slots (zero anyway)
         int r = i / (d.Nloc * T), k = i % (d.Nloc * T);
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
+        coef_arr(d, r, 8)[k] = coef_arr(d, r, 3)[k];
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; }      // solver history of the handle
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
+}
+// the same rebuild for every shard of a handle (the host rewrote terms: all P chunks are local copies)
+__global__ __launch_bounds__(256) void k_lmz_finalize_all(Dev d)
+{
+    Dev q = d; q.rank = blockIdx.y; q.Nlive = d.c.N - q.rank * d.Nloc; if (q.Nlive > d.Nloc) q.Nlive = d.Nloc; if (q.Nlive < 0) q.Nlive = 0;
+    finalize_body(q, blockIdx.x, gridDim.x, -1, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
 }
 
 // ------------------------------------------------------------------------------------------------
 struct rda_handle {
     Dev d;
+    rda_opts opts;                                        // as handed to rda_create_opts (copied)
     hipStream_t stream;
     size_t su_lds;
     // staging
@@ -771,7 +910,9 @@ struct rda_handle {
     void *h_sc; size_t h_sc_bytes;
     // device-side pre_process (rda_upload_path / rda_step_tracked)
     double *d_path; int path_len; track::Out *d_trk, *h_trk;
-    int dense_from;          // grids above this many workgroups use k_lammuz_rows_dense (RDA_LMZ_DENSE_FROM)
+    int dense_from;          // grids above this many workgroups use the dense form of the LamMuZ launch (rda_opts::lmz_dense_from)
+    int ip_rows;             // interior-point mode runs the row-parallel kernel (shape allows it and rda_opts::lmz_ip_rows)
+    int admm_it;             // host-driven ADMM pieces (rda_admm_*): the iteration rda_admm_su was last called with
 };
 
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -790,7 +931,8 @@ extern "C" const char *rda_strerror(int code)
 extern "C" int rda_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int rda_set_device(int dev) { HIPCHK(hipSetDevice(dev)); return RDA_OK; }
 
-static size_t res_doubles(size_t T) { return 2 * T + 3 * (T + 1) + 8; }
+static size_t res_doubles(size_t T) { return 2 * T + 3 * (T + 1) + 8; }     // u | s | info (4) | track::Out (2) | non-convex count | sequence word
+static_assert(9 * su::NT >= track::LDS_DOUBLES, "TrackedRefWait runs track::run in the su solve's `part` scratch");
 
 template <typename Tp> static int dalloc(Tp **p, size_t n)
 {
@@ -799,18 +941,38 @@ template <typename Tp> static int dalloc(Tp **p, size_t n)
     return 0;
 }
 
+// Solver options: library defaults, then the RDA_* environment overrides (experiments and A/B runs; read HERE only)
+extern "C" void rda_opts_init(rda_opts *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
+    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11;
+    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 1; o->lmz_ip_rows = 1;
+    o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
+    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0;
+    o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
+    { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) o->su_easy[i] = ez[i]; }
+    auto geti = [](const char *name, int32_t *v) { const char *e = getenv(name); if (e && *e) *v = atoi(e); };
+    auto getd = [](const char *name, double *v) { const char *e = getenv(name); if (e && *e) *v = atof(e); };
+    geti("RDA_LMZ_MODE", &o->lmz_mode); geti("RDA_TIE_CENTRE", &o->tie_centre); getd("RDA_LMZ_MU", &o->lmz_mu);
+    { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol[0], &o->su_tol[1], &o->su_tol[2]); }
+    geti("RDA_LMZ_WARM", &o->lmz_warm); geti("RDA_LMZ_ROWS", &o->lmz_rows); geti("RDA_LMZ_DENSE_FROM", &o->lmz_dense_from);
+    geti("RDA_LMZ_SPLIT", &o->lmz_split); geti("RDA_LMZ_TAIL", &o->lmz_tail); geti("RDA_LMZ_IP_ROWS", &o->lmz_ip_rows);
+    geti("RDA_SU_PRE", &o->su_pre); geti("RDA_SU_LIGHT", &o->su_light);
+    geti("RDA_SU_WARM_FIRST", &o->su_warm_first); geti("RDA_SU_EASY_NOPRED", &o->su_easy_nopred);
+    { const char *e = getenv("RDA_SU_COLD_FROM"); if (e) sscanf(e, "%d,%d", &o->su_cold_from, &o->su_cold_probe); }
+    { const char *e = getenv("RDA_SU_EASY"); if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%d", &o->su_easy[0], &o->su_easy[1], &o->su_easy[2], &o->su_easy[3], &o->su_easy[4], &o->su_easy_max); }
+    getd("RDA_SU_WARM_CLIP", &o->su_warm_clip);
+    { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &o->su_warm_endgame[0], &o->su_warm_endgame[1]); }
+    { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &o->su_warm[0], &o->su_warm[1], &o->su_warm_cap); }
+    geti("RDA_ZERO_COPY", &o->zero_copy); geti("RDA_EARLY_FINISH", &o->early_finish); geti("RDA_FUSE_TRACK", &o->fuse_track);
+    { const char *e = getenv("RDA_SU_PROF"); if (e && *e) o->su_prof = 1; }
+    if (o->su_cold_probe < 1) o->su_cold_probe = 1;
+}
+
 // mu support candidates of a polygon robot: pairs whose intersection is a vertex of the robot, then the non-null rows, then
 // the empty support (same rule and order as the lam lists built per wave in lmz::solve_wave)
-static int g_tie_centre = 1;
-extern "C" void rda_set_tie_centre(int on) { g_tie_centre = on ? 1 : 0; }
-// interior-point stop of the su-problem (process-wide default, read by rda_create and rda_su_solve)
-// LamMuZ solver of handles created afterwards: 0 support enumeration (tie-breaks T1-T3), 1 interior point ending on the central
-// path at barrier parameter mu (lammuz_cp_device.h); norm2 robots always use 1
-static int g_lmz_mode = 0; static double g_lmz_mu = 1e-6;
-extern "C" void rda_set_lmz_mode(int mode, double mu) { g_lmz_mode = mode ? 1 : 0; if (mu > 0) g_lmz_mu = mu; }
-static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};
-extern "C" void rda_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
-
 static int robot_candidates(int R, const double *G, const double *h, unsigned char *out, double (*rv)[2], int *nrv)
 {
     int n = 0, p = 0;
@@ -832,18 +994,22 @@ static int robot_candidates(int R, const double *G, const double *h, unsigned ch
     return n;
 }
 
-static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out, rda_handle **partial);
+static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G, const double *h, rda_handle **out, rda_handle **partial);
+static int terms_rebuild(rda_handle *H);
 extern "C" void rda_destroy(rda_handle *H);
 
-extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out)
+extern "C" int rda_create_opts(const rda_cfg *cfg, const rda_opts *opts, const double *G, const double *h, rda_handle **out)
 {
     rda_handle *partial = nullptr;                      // a failure half-way releases what was built (rda_destroy takes partial handles)
-    const int rc = create_impl(cfg, G, h, out, &partial);
+    rda_opts def;
+    if (!opts) { rda_opts_init(&def); opts = &def; }
+    const int rc = create_impl(cfg, opts, G, h, out, &partial);
     if (rc != RDA_OK && partial) { rda_destroy(partial); if (out) *out = nullptr; }
     return rc;
 }
+extern "C" int rda_create(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out) { return rda_create_opts(cfg, nullptr, G, h, out); }
 
-static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda_handle **out, rda_handle **partial)
+static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G, const double *h, rda_handle **out, rda_handle **partial)
 {
     if (!cfg || !G || !h || !out) return RDA_ERR_ARG;
     if (cfg->robot_norm2 && cfg->R < 2) return RDA_ERR_UNSUPPORTED;
@@ -854,33 +1020,21 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     *partial = H;
     memset(&H->d, 0, sizeof(Dev));
     H->d.c = *cfg; H->d.nt = 1; H->d.obstacle_num = 0; H->K = 0; H->timing = 0;
-    { const char *w = getenv("RDA_LMZ_WARM"); H->d.warm = w ? atoi(w) : 1; }
-    { const char *w = getenv("RDA_LMZ_DENSE_FROM"); H->dense_from = w ? atoi(w) : 256; }
-    { const char *w = getenv("RDA_LMZ_ROWS"); H->d.rows = (cfg->E + cfg->R + 1 <= 16) && (w ? atoi(w) != 0 : true); }
+    H->opts = *opts;
+    const rda_opts &o = H->opts;
+    H->d.warm = o.lmz_warm; H->dense_from = o.lmz_dense_from;
+    H->d.rows = (cfg->E + cfg->R + 1 <= 16) && o.lmz_rows != 0;
     H->d.nmv = robot_candidates(cfg->R, G, h, H->d.muc, H->d.rv, &H->d.nrv);
-    H->d.centre = g_tie_centre;
-    H->d.lmz_mode = (g_lmz_mode || cfg->robot_norm2) ? 1 : 0; H->d.lmz_mu = g_lmz_mu;      // the enumeration has no norm2-robot candidates
-    { const char *e = getenv("RDA_LMZ_MODE"); if (e && !cfg->robot_norm2) H->d.lmz_mode = atoi(e) ? 1 : 0; }
-    { const char *e = getenv("RDA_LMZ_MU"); if (e) H->d.lmz_mu = atof(e); }
-    H->d.su_warm_wfl = 1e-3; H->d.su_warm_mu0 = 1e-3; H->d.su_warm_cap = 30; { const char *e = getenv("RDA_SU_WARM_FIRST"); H->d.su_warm_first = e ? atoi(e) : 1; }
-    H->d.su_warm_tau = 0.9999; H->d.su_warm_sig = 1e-5; H->d.su_warm_clip = 0.01;
-    { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) H->d.su_easy[i] = ez[i]; H->d.su_easy_max = 2; }
-    H->d.su_easy_nopred = 1;
-    H->d.su_pre = 1;
-    { const char *e = getenv("RDA_SU_PRE"); if (e) H->d.su_pre = atoi(e); }
-    H->d.su_cold_from = 7; H->d.su_cold_probe = 8;
-    { const char *e = getenv("RDA_SU_COLD_FROM"); if (e) sscanf(e, "%d,%d", &H->d.su_cold_from, &H->d.su_cold_probe); }
-    if (H->d.su_cold_probe < 1) H->d.su_cold_probe = 1;
-    { const char *e = getenv("RDA_SU_EASY_NOPRED"); if (e) H->d.su_easy_nopred = atoi(e); }
-    H->d.su_light = 1;
-    { const char *e = getenv("RDA_SU_LIGHT"); if (e) H->d.su_light = atoi(e); }
-    { const char *e = getenv("RDA_SU_EASY"); if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%d", &H->d.su_easy[0], &H->d.su_easy[1], &H->d.su_easy[2], &H->d.su_easy[3], &H->d.su_easy[4], &H->d.su_easy_max); }
-    { const char *e = getenv("RDA_SU_WARM_CLIP"); if (e) H->d.su_warm_clip = atof(e); }
-    { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &H->d.su_warm_tau, &H->d.su_warm_sig); }
-    { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &H->d.su_warm_wfl, &H->d.su_warm_mu0, &H->d.su_warm_cap); }
-    for (int i = 0; i < 3; ++i) H->d.su_tol[i] = g_su_tol[i];
-    { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &H->d.su_tol[0], &H->d.su_tol[1], &H->d.su_tol[2]); }
-    { const char *e = getenv("RDA_TIE_CENTRE"); if (e) H->d.centre = atoi(e) ? 1 : 0; }      // experiments only
+    H->d.centre = o.tie_centre ? 1 : 0;
+    H->d.lmz_mode = (o.lmz_mode || cfg->robot_norm2) ? 1 : 0; H->d.lmz_mu = o.lmz_mu > 0 ? o.lmz_mu : 1e-6;      // the enumeration has no norm2-robot candidates
+    H->d.su_warm_wfl = o.su_warm[0]; H->d.su_warm_mu0 = o.su_warm[1]; H->d.su_warm_cap = o.su_warm_cap; H->d.su_warm_first = o.su_warm_first;
+    H->d.su_warm_tau = o.su_warm_endgame[0]; H->d.su_warm_sig = o.su_warm_endgame[1]; H->d.su_warm_clip = o.su_warm_clip;
+    for (int i = 0; i < 5; ++i) H->d.su_easy[i] = o.su_easy[i];
+    H->d.su_easy_max = o.su_easy_max; H->d.su_easy_nopred = o.su_easy_nopred;
+    H->d.su_pre = o.su_pre; H->d.lmz_tail = o.lmz_tail;
+    H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
+    H->d.su_light = o.su_light;
+    for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
@@ -892,21 +1046,22 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
-    rc |= dalloc(&d.wl, N * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
+    rc |= dalloc(&d.wl, (N + 16) * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
-    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.chunk = NCOEF * T * N;
+    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.J = (int)((N + 15) / 16); d.chunk = chunk_doubles((int)T, (int)N);
     rc |= dalloc(&d.coef, d.chunk);
-    rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T);
+    rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T); rc |= dalloc(&d.pose, 4 * T);
     rc |= dalloc(&d.ctrl, 1);
     rc |= dalloc(&d.su_lam_keep, 10 * T);
+    if (o.su_prof) rc |= dalloc(&d.su_prof, 16);
     const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
     rc |= dalloc(&H->d_step, step_n);
     // result block, identical on the device and in pinned memory: u [2T] | s [3(T+1)] | rda_info (4 doubles) | track::Out (4 doubles):
     // ONE copy back per step
     rc |= dalloc(&H->d_out_u, res_doubles(T));
     if (!rc) { H->d_out_s = H->d_out_u + 2 * T; H->d_info = (rda_info *)(H->d_out_s + 3 * (T + 1)); H->d_trk = (track::Out *)(H->d_out_s + 3 * (T + 1) + 4); }
-    if (rc) { rda_destroy(H); return RDA_ERR_HIP; }
+    if (rc) { rda_destroy(H); *partial = nullptr; return RDA_ERR_HIP; }
     { const int hard = 99; HIPCHK(hipMemcpy(&d.ctrl->su_last, &hard, sizeof(int), hipMemcpyHostToDevice)); }     // no su history yet
     HIPCHK(hipMemcpy(d.G, G, 2 * R * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d.h, h, R * sizeof(double), hipMemcpyHostToDevice));
@@ -919,20 +1074,21 @@ static int create_impl(const rda_cfg *cfg, const double *G, const double *h, rda
     HIPCHK(hipHostMalloc((void **)&H->h_stage_cone, N * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&H->h_step, step_n * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&H->h_out, res_doubles(T) * sizeof(double)));
-    memset(H->h_out, 0, res_doubles(T) * sizeof(double)); H->res_seq = 0; H->zero_copy = 1;
-    { const char *e = getenv("RDA_ZERO_COPY"); if (e) H->zero_copy = atoi(e); }
+    memset(H->h_out, 0, res_doubles(T) * sizeof(double)); H->res_seq = 0; H->zero_copy = o.zero_copy;
     H->h_info = (rda_info *)(H->h_out + 2 * T + 3 * (T + 1)); H->h_trk = (track::Out *)(H->h_out + 2 * T + 3 * (T + 1) + 4);
     H->su_lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds)));
     HIPCHK(hipFuncSetAttribute((const void *)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_lds));
     H->su_trk_lds = H->su_lds > track::LDS_DOUBLES * sizeof(double) ? H->su_lds : track::LDS_DOUBLES * sizeof(double);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_tracked<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->su_trk_lds)));
-    H->fuse_track = 1; H->tick_stages = 0; H->tick_has_event = 0; H->trk_seq = 0;
-    { const char *e = getenv("RDA_FUSE_TRACK"); if (e) H->fuse_track = atoi(e); }
-    H->early_finish = 1;
-    H->lmz_split = 1;
-    { const char *e = getenv("RDA_LMZ_SPLIT"); if (e) H->lmz_split = atoi(e); }
-    { const char *e = getenv("RDA_EARLY_FINISH"); if (e) H->early_finish = atoi(e); }
+    H->fuse_track = o.fuse_track; H->tick_stages = 0; H->tick_has_event = 0; H->trk_seq = 0;
+    H->early_finish = o.early_finish;
+    H->lmz_split = o.lmz_split;
+    H->ip_rows = 0; H->admm_it = 0;
+    // the terms of a fresh handle are all zero: their block partials (zero sums, every slot NEAR: a = 0 puts the hinge at -d < 0)
+    int rcf = terms_rebuild(H);
+    if (rcf != RDA_OK) return rcf;
+    HIPCHK(hipStreamSynchronize(H->stream));
     *out = H;
     return RDA_OK;
 }
@@ -944,7 +1100,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
     void *ptrs[] = { d.wl, d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
-                     d.s, d.u, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
+                     d.s, d.u, d.pose, d.su_prof, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
     for (void *p : ptrs) dev_free(p);
@@ -970,12 +1126,57 @@ extern "C" int rda_set_adjust(rda_handle *H, double slack_gain, double max_sd, d
     return RDA_OK;
 }
 
+// block partials (sums, near masks) of every local chunk from the stored terms: after the host rewrote terms
+static int terms_rebuild(rda_handle *H)
+{
+    const Dev &d = H->d;
+    const int nb = (d.c.T * d.J + 15) / 16;
+    hipLaunchKernelGGL(k_lmz_finalize_all, dim3(nb, d.P), dim3(256), 0, H->stream, d);
+    HIPCHK(hipGetLastError());
+    return RDA_OK;
+}
+
 extern "C" int rda_reset(rda_handle *H)
 {
     if (!H) return RDA_ERR_ARG;
     hipLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, H->stream, H->d);
     HIPCHK(hipGetLastError());
+    int rc = terms_rebuild(H);
+    if (rc != RDA_OK) return rc;
     HIPCHK(hipStreamSynchronize(H->stream));
+    return RDA_OK;
+}
+
+extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep)
+{
+    if (!H) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (hist) {
+        Ctrl c;
+        HIPCHK(hipMemcpy(&c, H->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+        hist[0] = c.su_last; hist[1] = c.su_probe;
+    }
+    if (lam_keep) HIPCHK(hipMemcpy(lam_keep, H->d.su_lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
+extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const double *lam_keep)
+{
+    if (!H) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (hist) {
+        HIPCHK(hipMemcpy(&H->d.ctrl->su_last, &hist[0], sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(&H->d.ctrl->su_probe, &hist[1], sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
+    return RDA_OK;
+}
+extern "C" int rda_debug_su_prof(rda_handle *H, long long *out16)
+{
+    if (!H || !out16) return RDA_ERR_ARG;
+    if (!H->d.su_prof) return RDA_ERR_UNSUPPORTED;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(out16, H->d.su_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(H->d.su_prof, 0, 16 * sizeof(long long)));
     return RDA_OK;
 }
 
@@ -1124,28 +1325,42 @@ static hipEvent_t next_event(rda_handle *H, int which)
     return H->ev[which][H->ev_used[which]++];
 }
 
-// K1 launch: packed rows when the shape allows (small grids: the no-spill build, large grids: two workgroups per CU), else
-// one sub-problem per wave (also the no-obstacle case, quirk Q9)
-static void launch_lammuz(rda_handle *H, const Dev &d)
+// K1 launch of ADMM iteration `it`.  Packed rows when the shape allows: a small grid is ONE launch that also forms the block
+// partials and runs the tail of the step (residuals, early-stop verdict, hand-over of the result: lmz_tail); a dense grid is the
+// common-path kernel + the work-list kernel, with k_lmz_finalize (partials + tail) behind them.  One sub-problem per wave (big
+// shapes, the no-obstacle case of quirk Q9) and the per-thread interior-point kernel likewise end with k_lmz_finalize.
+static void launch_finalize(rda_handle *H, const Dev &d, int it, const Fin &fin)
 {
-    const int units = d.Nlive * d.c.T;
-    if (units == 0) return;                      // a shard without obstacles (N < P)
-    if (d.lmz_mode) {
-        const int nb = d.obstacle_num ? (units + 63) / 64 : (d.c.T + 63) / 64;
+    hipLaunchKernelGGL(k_lmz_finalize, dim3((d.c.T * d.J + 15) / 16), dim3(256), 0, H->stream, d, it, fin);
+}
+// (the row-parallel interior-point kernel: see k_lammuz_ip below)
+static void launch_lammuz_ip(rda_handle *H, const Dev &d, int it, const Fin &fin) { (void)H; (void)d; (void)it; (void)fin; }
+static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
+{
+    if (d.Nlive == 0) return;                    // a shard without obstacles (N < P)
+    const int units = d.c.T * 16 * d.J;          // rows of the grid (a stage is padded to whole 16-slot blocks)
+    if (d.lmz_mode && !(H->ip_rows && d.obstacle_num)) {
+        const int nth = d.Nlive * d.c.T, nb = d.obstacle_num ? (nth + 63) / 64 : (d.c.T + 63) / 64;
         if (d.c.E <= 4 && d.c.R <= 4) hipLaunchKernelGGL(k_lammuz_cp_small, dim3(nb), dim3(64), 0, H->stream, d);
         else hipLaunchKernelGGL(k_lammuz_cp_large, dim3(nb), dim3(64), 0, H->stream, d);
+        launch_finalize(H, d, it, fin);
         return;
     }
+    if (d.lmz_mode) { launch_lammuz_ip(H, d, it, fin); return; }
     if (d.rows && d.obstacle_num) {
-        const int nb = (units + 15) / 16;
+        const int nb = units / 16;
         if (nb > H->dense_from && H->lmz_split) {
-            // dense grid: common path with three waves per SIMD, then the deferred rows one per wave (see lammuz_body_rows<false>)
+            // dense grid: common path with three waves per SIMD, then the deferred rows one per wave (see lammuz_body_rows)
             hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(256), 0, H->stream, d);
             int ne = units / 64; if (ne < 32) ne = 32; if (ne > 1024) ne = 1024;
             hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(256), 0, H->stream, d);
-        } else if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d);
-        else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(256), 0, H->stream, d);
-    } else hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
+            launch_finalize(H, d, it, fin);
+        } else if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d, it, fin);
+        else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(256), 0, H->stream, d, it, fin);
+    } else {
+        hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
+        launch_finalize(H, d, it, fin);
+    }
 }
 
 // queue the whole ADMM loop of one MPC step (rda_solver.py:588-596) - no host synchronisation
@@ -1176,6 +1391,14 @@ static int launch_finish(rda_handle *H, const Dev &d, const Fin &fin)
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
 static int fetch_result(rda_handle *H)
 {
     const size_t T = H->d.c.T;
@@ -1184,19 +1407,27 @@ static int fetch_result(rda_handle *H)
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spin = 0;; ++spin) {
             if (*flag == H->res_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return RDA_OK; }
-            __builtin_ia32_pause();
-            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            cpu_relax();
+            if ((spin & 1023) == 1023) {
+                // a device fault never publishes the word: ask the stream now and then (hipErrorNotReady = still running, fine)
+                const hipError_t q = hipStreamQuery(H->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) { fprintf(stderr, "librda_hip: stream fault while waiting for a result: %s\n", hipGetErrorString(q)); return RDA_ERR_HIP; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
         }
         HIPCHK(hipStreamSynchronize(H->stream));
         if (*flag == H->res_seq) return RDA_OK;
         return RDA_ERR_HIP;
     }
-    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, res_doubles(T) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    // D2H form: the result block without the sequence word behind it (that word belongs to the zero-copy protocol)
+    HIPCHK(hipMemcpyAsync(H->h_out, H->d_out_u, (res_doubles(T) - 1) * sizeof(double), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipStreamSynchronize(H->stream));
     return RDA_OK;
 }
 static int enqueue_admm_head(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed)
 {
+    // the zero-copy hand-over returns before the launches queued behind it have drained: a fault in that tail surfaces here
+    { const hipError_t q = hipStreamQuery(H->stream); if (q != hipSuccess && q != hipErrorNotReady) { fprintf(stderr, "librda_hip: device fault in the previous step: %s\n", hipGetErrorString(q)); return RDA_ERR_HIP; } }
     Dev d = H->d;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     launch_su(H, d, 0, in_s, in_u);                    // resets the step's control block itself (su_body, it == 0)
@@ -1221,7 +1452,7 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
             if (*H->h_stop) break;
         }
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
-        launch_lammuz(H, d);
+        launch_lammuz(H, d, it, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         if (H->comm) {      // one exchange per ADMM iteration: every rank's chunk to every rank (in place)
             int nrc = H->p_allgather(d.coef + (size_t)d.rank * d.chunk, d.coef, d.chunk, /*ncclDouble*/ 8, H->comm, H->stream);
@@ -1298,6 +1529,33 @@ __global__ void k_track(Dev d, track::In in, double *path, int L, const double *
 // only part of pre_process the su set-up needs), then the su-problem starts; workgroup 1 samples the reference from the path
 // meanwhile (closest_point, inter_point: 20 dependent searches, ~12 us) and publishes it under the tick number; the solve picks it
 // up after its set-up (su::Args::ref_flag).  Same arithmetic as k_track followed by k_su<TT>(it = 0).
+// HIP does not promise that the two workgroups run concurrently (CU masking, a saturated GPU, a debugger): the wait is BOUNDED, and on
+// expiry workgroup 0 samples the reference itself (the same track::run part, the same values - should workgroup 1 still run later it
+// rewrites them identically).
+struct TrackedRefWait {
+    track::Ego e; track::In in; track::Out *out; const unsigned long long *flag; unsigned long long seq;
+    __device__ __forceinline__ void operator()(double *scratch) const
+    {
+        int *okw = reinterpret_cast<int *>(scratch);
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            for (int spin = 0; spin < 40000; ++spin) {            // ~ 20 ms at the slowest; a normal wait is 10 - 30 us
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            *okw = ok;
+        }
+        __syncthreads();
+        const int ok = *(volatile int *)okw;
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x < 64) track::run(e, in, *out, scratch, threadIdx.x, 2);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+    }
+};
 template <int TT> __global__ __launch_bounds__(su::NT) void k_su_tracked(Dev d, track::In in, double *path, int L, const double *nom_u, double *step,
                                                                           track::Out *out, unsigned long long seq)
 {
@@ -1309,7 +1567,8 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su_tracked(Dev d, 
         if (threadIdx.x < 64) {
             track::run(e, in, *out, smem_su, threadIdx.x, 2);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (threadIdx.x == 0) __hip_atomic_store(&d.ctrl->ref_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(&d.ctrl->ref_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -1317,7 +1576,7 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su_tracked(Dev d, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    su_body<TT>(d, 0, step, nom_u, d.ref, d.ref_speed, &d.ctrl->ref_seq, seq);
+    su_body<TT>(d, 0, step, nom_u, d.ref, d.ref_speed, &d.ctrl->ref_seq, seq, nullptr, TrackedRefWait{ e, in, out, &d.ctrl->ref_seq, seq });
 }
 
 extern "C" int rda_upload_path(rda_handle *H, int L, const double *path)
@@ -1516,17 +1775,34 @@ extern "C" int rda_timing_launches(rda_handle *H, int which, double *ms_out, int
     return RDA_OK;
 }
 
+// The dual state lives stage-major on the device ([T+1][N][.], [T][N]); the accessors speak the reference's shapes ([N][T+1][.],
+// [N][T]): transposed on the host (test / checkpoint path, not the hot path)
+static void tr_to_host(const std::vector<double> &dev, double *host, size_t N, size_t TT, size_t W)
+{
+    for (size_t n = 0; n < N; ++n) for (size_t t = 0; t < TT; ++t) memcpy(host + (n * TT + t) * W, dev.data() + (t * N + n) * W, W * sizeof(double));
+}
+static void tr_to_dev(const double *host, std::vector<double> &dev, size_t N, size_t TT, size_t W)
+{
+    for (size_t n = 0; n < N; ++n) for (size_t t = 0; t < TT; ++t) memcpy(dev.data() + (t * N + n) * W, host + (n * TT + t) * W, W * sizeof(double));
+}
 extern "C" int rda_get_state(rda_handle *H, double *lam, double *mu, double *z, double *xi, double *zeta,
                              double *dis, double *a_lam, double *b_lam)
 {
     if (!H) return RDA_ERR_ARG;
     Dev &d = H->d; const size_t T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
     HIPCHK(hipStreamSynchronize(H->stream));
-    if (lam) HIPCHK(hipMemcpy(lam, d.lam, N * (T + 1) * E * sizeof(double), hipMemcpyDeviceToHost));
-    if (mu) HIPCHK(hipMemcpy(mu, d.mu, N * (T + 1) * R * sizeof(double), hipMemcpyDeviceToHost));
-    if (z) HIPCHK(hipMemcpy(z, d.z, N * T * sizeof(double), hipMemcpyDeviceToHost));
-    if (xi) HIPCHK(hipMemcpy(xi, d.xi, N * (T + 1) * 2 * sizeof(double), hipMemcpyDeviceToHost));
-    if (zeta) HIPCHK(hipMemcpy(zeta, d.zeta, N * T * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> tmp;
+    auto get = [&](const double *dev, double *host, size_t TT, size_t W) -> int {
+        tmp.resize(N * TT * W);
+        HIPCHK(hipMemcpy(tmp.data(), dev, N * TT * W * sizeof(double), hipMemcpyDeviceToHost));
+        tr_to_host(tmp, host, N, TT, W);
+        return RDA_OK;
+    };
+    if (lam && get(d.lam, lam, T + 1, E)) return RDA_ERR_HIP;
+    if (mu && get(d.mu, mu, T + 1, R)) return RDA_ERR_HIP;
+    if (z && get(d.z, z, T, 1)) return RDA_ERR_HIP;
+    if (xi && get(d.xi, xi, T + 1, 2)) return RDA_ERR_HIP;
+    if (zeta && get(d.zeta, zeta, T, 1)) return RDA_ERR_HIP;
     if (dis) HIPCHK(hipMemcpy(dis, d.dis, T * sizeof(double), hipMemcpyDeviceToHost));
     if (a_lam || b_lam) {
         double *ta = nullptr, *tb = nullptr;
@@ -1547,19 +1823,27 @@ extern "C" int rda_set_state(rda_handle *H, const double *lam, const double *mu,
     if (!H) return RDA_ERR_ARG;
     Dev &d = H->d; const size_t T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
     HIPCHK(hipStreamSynchronize(H->stream));
-    if (lam) HIPCHK(hipMemcpy(d.lam, lam, N * (T + 1) * E * sizeof(double), hipMemcpyHostToDevice));
-    if (mu) HIPCHK(hipMemcpy(d.mu, mu, N * (T + 1) * R * sizeof(double), hipMemcpyHostToDevice));
-    if (z) HIPCHK(hipMemcpy(d.z, z, N * T * sizeof(double), hipMemcpyHostToDevice));
-    if (xi) HIPCHK(hipMemcpy(d.xi, xi, N * (T + 1) * 2 * sizeof(double), hipMemcpyHostToDevice));
-    if (zeta) HIPCHK(hipMemcpy(d.zeta, zeta, N * T * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> tmp;
+    auto put = [&](const double *host, double *dev, size_t TT, size_t W) -> int {
+        tmp.resize(N * TT * W);
+        tr_to_dev(host, tmp, N, TT, W);
+        HIPCHK(hipMemcpy(dev, tmp.data(), N * TT * W * sizeof(double), hipMemcpyHostToDevice));
+        return RDA_OK;
+    };
+    if (lam && put(lam, d.lam, T + 1, E)) return RDA_ERR_HIP;
+    if (mu && put(mu, d.mu, T + 1, R)) return RDA_ERR_HIP;
+    if (z && put(z, d.z, T, 1)) return RDA_ERR_HIP;
+    if (xi && put(xi, d.xi, T + 1, 2)) return RDA_ERR_HIP;
+    if (zeta && put(zeta, d.zeta, T, 1)) return RDA_ERR_HIP;
     if (dis) HIPCHK(hipMemcpy(d.dis, dis, T * sizeof(double), hipMemcpyHostToDevice));
     double *ta = nullptr, *tb = nullptr;
     if (a_lam) { if (dalloc(&ta, N * (T + 1) * 2)) return RDA_ERR_HIP; HIPCHK(hipMemcpy(ta, a_lam, N * (T + 1) * 2 * sizeof(double), hipMemcpyHostToDevice)); }
     if (b_lam) { if (dalloc(&tb, N * (T + 1))) return RDA_ERR_HIP; HIPCHK(hipMemcpy(tb, b_lam, N * (T + 1) * sizeof(double), hipMemcpyHostToDevice)); }
     hipLaunchKernelGGL(k_products_set, dim3(64), dim3(256), 0, H->stream, d, ta, tb);
+    int rc = terms_rebuild(H);                          // block sums / near masks of the rewritten terms
     HIPCHK(hipStreamSynchronize(H->stream));
     dev_free(ta); dev_free(tb);
-    return RDA_OK;
+    return rc;
 }
 
 
@@ -1571,7 +1855,7 @@ __global__ void k_dead_slots(Dev d)
     const int T = d.c.T;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.P * d.Nloc * T; i += gridDim.x * blockDim.x) {
         const int r = i / (d.Nloc * T), k = i % (d.Nloc * T), nl = k % d.Nloc;
-        if (r * d.Nloc + nl >= d.c.N) { coef_arr(d, r, 3)[k] = -1e30; coef_arr(d, r, 10)[k] = -0.0; }      // (far)
+        if (r * d.Nloc + nl >= d.c.N) { coef_arr(d, r, 3)[k] = -1e30; coef_arr(d, r, 8)[k] = -1e30; }      // (their block partials: zero sums, bit clear)
     }
 }
 extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
@@ -1581,12 +1865,14 @@ extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
     HIPCHK(hipStreamSynchronize(H->stream));
     Dev &d = H->d;
     dev_free(d.coef); d.coef = nullptr;
-    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.chunk = (size_t)NCOEF * d.c.T * d.Nloc;
+    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.J = (d.Nloc + 15) / 16; d.chunk = chunk_doubles(d.c.T, d.Nloc);
     const int first = rank * d.Nloc;
     d.Nlive = first >= d.c.N ? 0 : (d.c.N - first < d.Nloc ? d.c.N - first : d.Nloc);
     if (dalloc(&d.coef, d.chunk * world)) return RDA_ERR_HIP;
     HIPCHK(hipMemsetAsync(d.coef, 0, d.chunk * world * sizeof(double), H->stream));
     if (d.Nloc * world != d.c.N) hipLaunchKernelGGL(k_dead_slots, dim3(64), dim3(256), 0, H->stream, d);
+    int rc = terms_rebuild(H);                          // (the duals of a handle that is re-sharded are NOT re-condensed: shard before the first step)
+    if (rc != RDA_OK) return rc;
     HIPCHK(hipStreamSynchronize(H->stream));
     return RDA_OK;
 }
@@ -1657,6 +1943,7 @@ extern "C" int rda_admm_su(rda_handle *H, int it, int *stopped)
 {
     if (!H || it < 0) return RDA_ERR_ARG;
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    H->admm_it = it;
     Dev d = H->d;
     d.ref = H->d_step + ns + nu; d.ref_speed = H->d_step + ns + nu + ns;
     RDA_SU_DISPATCH((int)T, hipLaunchKernelGGL(k_su<TT>, dim3(1), dim3(su::NT), H->su_lds, H->stream, d, it, H->d_step, H->d_step + ns, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}));
@@ -1673,7 +1960,7 @@ extern "C" int rda_admm_lammuz(rda_handle *H)
 {
     if (!H) return RDA_ERR_ARG;
     Dev d = H->d;
-    launch_lammuz(H, d);
+    launch_lammuz(H, d, H->admm_it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
     HIPCHK(hipGetLastError());
     return RDA_OK;
 }
@@ -1710,10 +1997,22 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su_fleet(const Dev
 
 // a member without obstacles (Q9) or of a shape the packed body does not take runs the one-per-wave body on the first quarter
 // of the (packed-size) grid... kept simple: the fleet uses the packed kernel only when every member can
+__device__ __forceinline__ Fin fleet_fin(const Dev &d, const EgoIO &e, int k)
+{
+    const size_t ns = 3 * (d.c.T + 1), nu = 2 * d.c.T;
+    return Fin{ e.out_u + k * nu, e.out_s + k * ns, e.info + k, nullptr, 0, 0 };
+}
 __global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs) { lammuz_body(devs[blockIdx.y], blockIdx.x); }
-__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_rows(const Dev *devs) { lammuz_body_rows(devs[blockIdx.y], blockIdx.x); }
-__global__ __launch_bounds__(256, 3) void k_lammuz_fleet_rows_fast(const Dev *devs) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x); }
-__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_enum(const Dev *devs) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_rows(const Dev *devs, const EgoIO *io, int it, int k)
+{
+    lammuz_body_rows<0>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
+}
+__global__ __launch_bounds__(256, 3) void k_lammuz_fleet_rows_fast(const Dev *devs) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_enum(const Dev *devs) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(256) void k_lmz_finalize_fleet(const Dev *devs, const EgoIO *io, int it, int k)
+{
+    finalize_body(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
+}
 
 __global__ __launch_bounds__(su::NT) void k_finish_fleet(const Dev *devs, const EgoIO *io, int k)
 {
@@ -1734,7 +2033,7 @@ struct rda_fleet {
     double *h_out, *d_out;                // per ego: u | s
     rda_info *h_info, *d_info;
     hipEvent_t ev;
-    int T, iter_num, blocks, rows, lmz_split;
+    int T, iter_num, J, rows, lmz_split;
     size_t su_lds;
     // tracked stepping (device-side pre_process), allocated on first use
     track::In *h_trk_in, *d_trk_in; track::Out *h_trk_out, *d_trk_out;
@@ -1770,7 +2069,7 @@ extern "C" int rda_fleet_create(rda_handle *const *egos, int B, rda_fleet **out)
     F->d_devs = nullptr; F->d_io_step = F->d_io_trace = nullptr; F->d_in = F->d_out = nullptr; F->d_info = nullptr;
     F->h_devs = nullptr; F->h_io = nullptr; F->h_in = F->h_out = nullptr; F->h_info = nullptr;
     const rda_cfg &c = egos[0]->d.c;
-    F->T = c.T; F->iter_num = c.iter_num; F->blocks = (c.N * c.T + 3) / 4; F->su_lds = egos[0]->su_lds;
+    F->T = c.T; F->iter_num = c.iter_num; F->J = (c.N + 15) / 16; F->su_lds = egos[0]->su_lds;
     HIPCHK(hipStreamCreate(&F->stream));
     HIPCHK(hipEventCreateWithFlags(&F->ev, hipEventDisableTiming));
     const size_t T = c.T, ns = 3 * (T + 1), nu = 2 * T, nin = 2 * ns + nu + 1, nout = nu + ns;
@@ -1823,12 +2122,17 @@ static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
     const int B = F->B;
     for (int it = 0; it < F->iter_num; ++it) {          // iteration 0 resets every member's control block (su_body)
         RDA_SU_DISPATCH(F->T, hipLaunchKernelGGL(k_su_fleet<TT>, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, it, k));
+        const int nbr = F->T * F->J, nfin = (nbr + 15) / 16;       // packed grid: one workgroup per (stage, 16-slot block)
         if (F->rows && F->lmz_split) {
-            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
-            int ne = F->blocks / 16; if (ne < 4) ne = 4; if (ne > 64) ne = 64;
+            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3(nbr, B), dim3(256), 0, F->stream, F->d_devs);
+            int ne = nbr / 4; if (ne < 4) ne = 4; if (ne > 64) ne = 64;
             hipLaunchKernelGGL(k_lammuz_fleet_enum, dim3(ne, B), dim3(256), 0, F->stream, F->d_devs);
-        } else if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3((F->blocks + 3) / 4, B), dim3(256), 0, F->stream, F->d_devs);
-        else hipLaunchKernelGGL(k_lammuz_fleet, dim3(F->blocks, B), dim3(256), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lmz_finalize_fleet, dim3(nfin, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
+        } else if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3(nbr, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
+        else {
+            hipLaunchKernelGGL(k_lammuz_fleet, dim3(nbr * 4, B), dim3(256), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lmz_finalize_fleet, dim3(nfin, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
+        }
     }
     hipLaunchKernelGGL(k_finish_fleet, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, k);
     HIPCHK(hipGetLastError());
@@ -2008,7 +2312,8 @@ extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const doub
                  {(void **)&dzeta, zeta, sB * 8}, {(void **)&ddbar, dbar, sB * 8} };
     for (auto &c : ins) { HIPCHK(hipMalloc(c.dst, c.bytes)); HIPCHK(hipMemcpy(*c.dst, c.src, c.bytes, hipMemcpyHostToDevice)); }
     HIPCHK(hipMalloc((void **)&dlam, sB * E * 8)); HIPCHK(hipMalloc((void **)&dmu, sB * R * 8)); HIPCHK(hipMalloc((void **)&dz, sB * 8)); HIPCHK(hipMalloc((void **)&dcmh, sB * 4 * 8));
-    RobotCands rcands; rcands.nmv = robot_candidates(R, G, h, rcands.muc, rcands.rv, &rcands.nrv); rcands.centre = g_tie_centre;
+    rda_opts od; rda_opts_init(&od);                   // tie-break T1 of the defaults (RDA_TIE_CENTRE overrides)
+    RobotCands rcands; rcands.nmv = robot_candidates(R, G, h, rcands.muc, rcands.rv, &rcands.nrv); rcands.centre = od.tie_centre ? 1 : 0;
     long long *dprof = nullptr;
     if (getenv("RDA_LMZ_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 8 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 8 * sizeof(long long))); }
     hipLaunchKernelGGL(k_lammuz_batch, dim3((B + 3) / 4), dim3(256), 0, 0, B, E, R, dA, db, dcone, dp, dphi, dG, dh, dxi, dzeta, ddbar,
@@ -2058,10 +2363,10 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     ar.c.dt = cfg->dt; ar.c.L = cfg->L; ar.c.umax0 = cfg->max_speed[0]; ar.c.umax1 = cfg->max_speed[1];
     ar.c.ab0 = cfg->acce_bound[0]; ar.c.ab1 = cfg->acce_bound[1]; ar.c.ws = cfg->ws; ar.c.wu = cfg->wu;
     ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
-    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = g_su_tol[0]; ar.c.tol_rp = g_su_tol[1]; ar.c.tol_mu = g_su_tol[2];
-    { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &ar.c.tol_rd, &ar.c.tol_rp, &ar.c.tol_mu); }
+    rda_opts od; rda_opts_init(&od);                   // the stop tolerances of the defaults (RDA_SU_TOL overrides)
+    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2];
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
-    ar.ax = dsoa; ar.ay = dsoa + T * N; ar.blam = dsoa + 2 * T * N; ar.ee = dsoa + 3 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
+    ar.ax = dsoa; ar.ay = dsoa + T * N; ar.cb = dsoa + 2 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;
     ar.d_in = d0 ? dd0 : nullptr; ar.out_s = dos; ar.out_u = dou; ar.out_d = dod; ar.status = dst; ar.ipm_iters = dst + 1;
     long long *dprof = nullptr;

@@ -48,21 +48,22 @@ struct Cfg {
     int light_check = 1;             // convergence pass without the factorisation when the step predicts convergence (RDA_SU_LIGHT=0: off)
 };
 
-// One condensed obstacle term (a, g, cb) at the nominal pose of its stage: the three numbers it adds to the stage's rotation-consistency
-// quadratic and the screening verdict (`far`: its hinge cannot become active while the position stays within
-// SCREEN_DELTA of the nominal one).  ONE definition, because the set-up of the solve evaluates it (first su-problem of a step) and
-// k_lammuz's epilogue evaluates it for the next solve (iterations >= 1 read the three numbers instead of the six arrays).
-constexpr double SCREEN_DELTA = 1.0;
-struct TermPre { double e0, e1, e2; bool far; };
-__device__ __forceinline__ TermPre term_pre(double ax, double ay, double gx, double gy, double cb, double cs, double sn,
-                                            double p0x, double p0y, double max_sd)
+// One condensed obstacle term (a, g, cb) of an (obstacle slot, stage): what it adds to the three POSE-INDEPENDENT sums the stage's
+// rotation-consistency penalty reduces to (SURVEY A.3 gives Q1 = 2 sum k0.k1, Q2 = sum |k1|^2 with k0 = g + R'a, k1 = dR'a; expanding
+// in (cos, sin) of the nominal heading:  Q2 = sum |a|^2,  Q1 = 2 (cos sum g x a - sin sum g.a) - so the N-dependent part never sees
+// the pose), and the screening verdict of its hinge (`near`: it may become active while the stage position stays within SCREEN_DELTA of
+// the reference position (px, py)).  ONE definition: k_lammuz evaluates it per row right after the dual update (block partial sums
+// of 16 slots + a 16-bit near mask), k_lmz_finalize re-evaluates it from the stored terms, and the su set-up evaluates it itself when
+// it is handed raw terms only (rda_su_solve hook) - all three must round alike.
+constexpr double SCREEN_DELTA = 2.0;
+constexpr int NBS = 5;           // doubles per 16-slot block partial: sum |a|^2, sum g.a, sum g x a, dual residual, |Hm|^2
+struct RowTerm { double aa, ga, gxa; bool near; };
+__device__ __forceinline__ RowTerm row_term(double ax, double ay, double gx, double gy, double cb, double px, double py, double max_sd, bool pose_ok)
 {
-    TermPre r;
-    double k0x = gx + cs * ax + sn * ay, k0y = gy - sn * ax + cs * ay;
-    double k1x = -sn * ax + cs * ay, k1y = -cs * ax - sn * ay;
-    r.e0 = k0x * k0x + k0y * k0y; r.e1 = 2 * (k0x * k1x + k0y * k1y); r.e2 = k1x * k1x + k1y * k1y;
-    double margin = ax * p0x + ay * p0y - cb - max_sd;
-    r.far = margin > 0 && margin * margin > SCREEN_DELTA * SCREEN_DELTA * (ax * ax + ay * ay);
+    RowTerm r;
+    r.aa = ax * ax + ay * ay; r.ga = gx * ax + gy * ay; r.gxa = gx * ay - gy * ax;
+    const double margin = ax * px + ay * py - cb - max_sd;
+    r.near = !(pose_ok && margin > 0 && margin * margin > SCREEN_DELTA * SCREEN_DELTA * r.aa);
     return r;
 }
 
@@ -71,8 +72,14 @@ struct Args {
     const double *in_s, *in_u;       // linearisation point (3x(T+1), 2xT)
     const double *ref;               // 3x(T+1)
     const double *ref_speed;         // scalar on device
-    const double *ax, *ay, *blam, *ee, *gx, *gy;   // condensed obstacle terms of obstacle shard 0, each [T][Nloc]
-    const double *pre0 = nullptr, *pre1 = nullptr, *pre2 = nullptr;   // term_pre of every term at THIS solve's nominal, written by k_lammuz (e2 negated = far); null: evaluate here
+    const double *ax, *ay, *cb, *gx, *gy;   // condensed obstacle terms of obstacle shard 0, each [T][Nloc]: a = A'lam, cb = b'lam + mu'h + z - zeta, g = G'mu + xi
+    // reduced form of the terms, written by k_lammuz / k_lmz_finalize: per (stage, 16-slot block) NBS sums and a near mask (bit r = slot
+    // 16 j + r may become active within SCREEN_DELTA of the pose table's position).  null: the set-up evaluates row_term itself.
+    const double *bsum = nullptr; const unsigned long long *bmask = nullptr; int J = 0;
+    const double *pose = nullptr;    // [T][4] px, py (column t+1), cos, sin (heading of column t) of the trajectory the masks refer to
+    int pose_ok = 0;                 // the pose table is valid (a LamMuZ launch has run since the terms last changed)
+    int pose_lin = 0;                // the pose table IS the linearisation point (ADMM iterations >= 1): its cos / sin are reused
+    double *pose_out = nullptr;      // (may equal pose) pose table of the trajectory this solve hands back
     int P, Nloc; size_t chunk;       // P obstacle shards (N = P*Nloc); shard r's arrays start `chunk` doubles after shard r-1's
     const double *d_in;              // [T] initial guess for d
     double *out_s, *out_u, *out_d;   // results (may alias in_*)
@@ -103,24 +110,23 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// linearised motion models, rda_solver.py:949-994
-__device__ inline void lin_model(const Cfg &c, const double *st, const double *ut, double *A, double *B, double *C)
+// linearised motion models, rda_solver.py:949-994.  (cp, sp) = cos / sin of the state heading st[2] (the caller has them: the pose
+// table for ADMM iterations >= 1, one sincos otherwise); the omni model linearises about the VELOCITY heading ut[1] instead.
+__device__ inline void lin_model(const Cfg &c, const double *st, const double *ut, double cp, double sp, double *A, double *B, double *C)
 {
     double dt = c.dt;
     for (int i = 0; i < 9; ++i) A[i] = 0;
     for (int i = 0; i < 6; ++i) B[i] = 0;
     C[0] = C[1] = C[2] = 0;
     A[0] = A[4] = A[8] = 1;
-    // sin and cos of the heading from one sincos (shared argument reduction, same values)
     if (c.dynamics == 2) {
-        double phi = ut[1], v = ut[0], sp, cp;
+        double phi = ut[1], v = ut[0];
         sincos(phi, &sp, &cp);
         B[0] = cp * dt; B[1] = -v * sp * dt; B[2] = sp * dt; B[3] = v * cp * dt;
         C[0] = phi * v * sp * dt; C[1] = -phi * v * cp * dt;
         return;
     }
-    double phi = st[2], v = ut[0], sp, cp;
-    sincos(phi, &sp, &cp);
+    double phi = st[2], v = ut[0];
     A[2] = -v * dt * sp; A[5] = v * dt * cp;
     B[0] = cp * dt; B[2] = sp * dt;
     C[0] = phi * v * sp * dt; C[1] = -phi * v * cp * dt;
@@ -140,7 +146,7 @@ constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
 constexpr int MF = 36;   // forward sweep rows [6][6]
 __device__ __host__ inline int ev(int n) { return (n + 1) & ~1; }
 struct Lds {
-    double *s, *u, *d, *phin, *ref, *Ak, *Bk, *Ck, *Q0, *Q1, *Q2;
+    double *s, *u, *d, *phin, *ref, *Ak, *Bk, *Ck, *csn, *Q1, *Q2;   // csn: cos [T] | sin [T] of the nominal headings
     double *Ft;        // [T][FT]  (constant during the solve)
     double *part;      // [NT][9] partial sums of the chunked reductions (aliases Hb)
     double *hs;        // [T][9]  hinge sums
@@ -162,7 +168,7 @@ struct Lds {
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
-        Ak = p; p += ev(9 * T); Bk = p; p += 6 * T; Ck = p; p += ev(3 * T); Q0 = p; p += ev(T); Q1 = p; p += ev(T); Q2 = p; p += ev(T);
+        Ak = p; p += ev(9 * T); Bk = p; p += 6 * T; Ck = p; p += ev(3 * T); csn = p; p += 2 * T; Q1 = p; p += ev(T); Q2 = p; p += ev(T);
         Ft = p; p += FT * T; hs = p; Mf = p; p += ev(9 * T);      // Mf (after the matrix sweep) overlays hs|Hw|gw|bw|cy: 39T >= MF*T
         Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += ev(5 * T); cy = p; p += ev(5 * T);
         gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += ev(3 * T);
@@ -174,7 +180,7 @@ struct Lds {
 };
 inline size_t lds_bytes(int T)
 {
-    size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 3 * ev(T)
+    size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
              + WN * T + 16 * T + 6 * NC * T + 8 * T + 8 + NT + 2 * T;
     return n * sizeof(double);
@@ -246,8 +252,10 @@ __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return
 
 // The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).  TT > 0 fixes the horizon
 // at compile time (every LDS offset becomes an immediate, the stage loops get constant bounds); TT == 0 reads it from c.T.
-struct NoGate { __device__ __forceinline__ bool operator()(double *) const { return true; } };
-template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Args &a, double *smem, Gate gate = Gate())
+// RefWait: called by all threads once the set-up is done, when a.ref_flag is set - returns when the reference (a.ref) is complete
+// (k_su_tracked: another workgroup samples it meanwhile; the functor bounds the wait and samples it itself on expiry).
+struct NoRefWait { __device__ __forceinline__ void operator()(double *) const {} };
+template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(const Args &a, double *smem, RefWait ref_wait = RefWait())
 {
     const Cfg &c = a.c;
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -261,17 +269,23 @@ template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Arg
     const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
     const int rt = tid / nch, rc_ = tid % nch;    // this thread's stage and chunk
     const bool ract = rt < T;
+    const bool masks_in = a.bsum != nullptr;      // the reduced form of the terms is handed in (k_lammuz / k_lmz_finalize)
 
     // ---- load nominal, reference; linearise -------------------------------------------------
     for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; if (!a.ref_flag) L.ref[i] = a.ref[i]; }
     for (int i = tid; i < 2 * T; i += NT) L.u[i] = a.in_u[i];
-    for (int i = tid; i < 2 * T; i += NT) L.p0[i] = a.in_s[(i / T) * (T + 1) + (i % T) + 1];      // nominal positions of stages 1..T
+    // reference positions of the hinge screening: where the masks were made (pose table), else the nominal positions of stages 1..T
+    for (int i = tid; i < 2 * T; i += NT)
+        L.p0[i] = (masks_in && a.pose_ok) ? a.pose[4 * (i % T) + i / T] : a.in_s[(i / T) * (T + 1) + (i % T) + 1];
     __syncthreads();
     mark(0);
     if (tid < T) {
         int t = tid;
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
-        lin_model(c, st, ut, &L.Ak[9 * t], &L.Bk[6 * t], &L.Ck[3 * t]);
+        double cp, sp;
+        if (a.pose_lin) { cp = a.pose[4 * t + 2]; sp = a.pose[4 * t + 3]; } else sincos(st[2], &sp, &cp);
+        L.csn[t] = cp; L.csn[T + t] = sp;
+        lin_model(c, st, ut, cp, sp, &L.Ak[9 * t], &L.Bk[6 * t], &L.Ck[3 * t]);
         L.phin[t] = st[2];
         // F = [[A 0 B 0],[0 0 I2 0]]  (5x8), stored transposed and padded: Ft[q][i]
         double *F = &L.Ft[FT * t];
@@ -358,90 +372,70 @@ template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Arg
             const double lp = a.lam_keep[ts * NC + k]; if (con_on(t, k) && lp > L.cl[i]) L.cl[i] = lp; }
         __syncthreads();
     } else centre_duals(1e-2, 1.0);
-    // ---- gate (fused launch, k_lmz_su): everything above depends on the nominal trajectory only; what follows reads the condensed obstacle
-    //      terms.  The caller's gate waits until the LamMuZ workgroups of this launch have finished, reduces their residuals and decides
-    //      the early stop (false = the step is over: leave without touching any output).  L.part is free scratch here.
-    if (!gate(L.part)) return false;
-    // ---- rotation-consistency penalty -> scalar quadratic per stage, fused with the HINGE SCREENING:
-    // Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so an obstacle term whose margin at the nominal
-    // position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Each thread
-    // keeps a bit mask of the terms of ITS (stage, chunk) slice that may become active and only those are visited by
-    // the per-iteration hinge sums (same visiting order -> the sums are unchanged).  The assumption is verified on
-    // the converged iterate; if violated the iteration continues with all terms.  Excluded terms are inactive at the
-    // verified solution, so it satisfies the optimality conditions of the full problem.
+    // ---- rotation-consistency penalty -> scalar quadratic per stage from three POSE-INDEPENDENT sums over the terms (see
+    // row_term), and the HINGE SCREENING: Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so a term whose margin at the
+    // reference position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Both arrive in
+    // reduced form - per (stage, 16-slot block) partial sums and a 16-bit near mask, made by the LamMuZ launch that produced the terms
+    // (p0 = the trajectory it worked with: the pose table) - so this set-up has NO pass over the N terms; handed raw terms only
+    // (rda_su_solve) it evaluates them here in the same grouping, so both forms round alike.  Each thread keeps the near masks of the
+    // blocks of ITS (stage, chunk) slice in registers and only those terms are visited by the per-iteration hinge sums (same visiting
+    // order as the streaming loop -> the sums are unchanged).  The assumption |p - p0| <= DELTA is verified on the nominal and after
+    // every step; if violated the iteration continues with all terms.  Excluded terms are inactive at the verified solution, so it
+    // satisfies the optimality conditions of the full problem.
     constexpr int MW = 4;
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
-    const int KS = (a.Nloc + nch - 1) / nch;                    // terms per shard in one thread's slice
-    bool screened = c.accelerated && a.P * KS <= 64 * MW;
+    const int J = masks_in ? a.J : (a.Nloc + 15) / 16;         // 16-slot blocks per shard
+    const int KB = (J + nch - 1) / nch;                         // blocks per shard in one thread's slice: j = rc_ + kb nch
+    bool screened = c.accelerated && a.P * KB * 16 <= 64 * MW && (!masks_in || a.pose_ok);
     {
-        double q0 = 0, q1 = 0, q2 = 0;
+        double saa = 0, sga = 0, sgx = 0;
         if (ract) {
-            double cs = cos(L.phin[rt]), sn = sin(L.phin[rt]);
             const double p0x = L.p0[rt], p0y = L.p0[T + rt];
             for (int r = 0; r < a.P; ++r) {
-                const size_t o = r * a.chunk + (size_t)rt * a.Nloc;
-                // the bit position only depends on the loop counters, i.e. it is the same in every thread: the word index and
-                // the shift are scalar, the per-thread part is one select + or on a register (no indexed access to amask)
-                int bit = r * KS, curw = bit >> 6;
-                unsigned long long cur = 0;
-                auto flush = [&]() {
-                    switch (curw) { case 0: amask[0] |= cur; break; case 1: amask[1] |= cur; break; case 2: amask[2] |= cur; break; default: amask[3] |= cur; break; }
-                    cur = 0;
-                };
-                auto account = [&](double e0, double e1, double e2, bool far) {
-                    q0 += e0; q1 += e1; q2 += e2;
-                    const bool may = screened && !far;
-                    if ((bit >> 6) != curw) { flush(); curw = bit >> 6; }
-                    cur |= may ? 1ull << (bit & 63) : 0ull;
-                    ++bit;
-                };
-                auto term = [&](double ax, double ay, double gx, double gy, double cb) {
-                    const TermPre tp = term_pre(ax, ay, gx, gy, cb, cs, sn, p0x, p0y, c.max_sd);
-                    account(tp.e0, tp.e1, tp.e2, tp.far);
-                };
-                int n = rc_;
-                if (a.pre0) {
-                    // iterations >= 1: k_lammuz evaluated term_pre of every term at this nominal (the previous solution) while it
-                    // had the numbers in registers - three arrays to sum instead of six to evaluate (e2 negated = far)
-                    const double *p0 = a.pre0 + o, *p1 = a.pre1 + o, *p2 = a.pre2 + o;
-                    for (; n + 7 * nch < a.Nloc; n += 8 * nch) {
-                        double x[8], y[8], g[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) { x[k] = p0[n + k * nch]; y[k] = p1[n + k * nch]; g[k] = p2[n + k * nch]; }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) account(x[k], y[k], fabs(g[k]), signbit(g[k]));
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int j = rc_ + kb * nch;
+                    if (j >= J) break;
+                    unsigned long long m16 = 0;
+                    if (masks_in) {
+                        const double *p = a.bsum + r * a.chunk + ((size_t)rt * J + j) * NBS;
+                        saa += p[0]; sga += p[1]; sgx += p[2];
+                        m16 = a.bmask[r * a.chunk + (size_t)rt * J + j] & 0xffffull;
+                    } else {
+                        const size_t o = r * a.chunk + (size_t)rt * a.Nloc + 16 * j;
+                        double b0 = 0, b1 = 0, b2 = 0;
+                        for (int row = 0; row < 16 && 16 * j + row < a.Nloc; ++row) {
+                            const RowTerm q = row_term(a.ax[o + row], a.ay[o + row], a.gx[o + row], a.gy[o + row], a.cb[o + row], p0x, p0y, c.max_sd, true);
+                            b0 += q.aa; b1 += q.ga; b2 += q.gxa;
+                            m16 |= q.near ? 1ull << row : 0ull;
+                        }
+                        saa += b0; sga += b1; sgx += b2;
                     }
-                    for (; n < a.Nloc; n += nch) { const double g = p2[n]; account(p0[n], p1[n], fabs(g), signbit(g)); }
-                } else {
-                const double *pax = a.ax + o, *pay = a.ay + o, *pgx = a.gx + o, *pgy = a.gy + o, *pb = a.blam + o, *pe = a.ee + o;
-                for (; n + 7 * nch < a.Nloc; n += 8 * nch) {      // eight independent loads in flight per array
-                    double x[8], y[8], g[8], h[8], cb[8], ce[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { x[k] = pax[n + k * nch]; y[k] = pay[n + k * nch]; g[k] = pgx[n + k * nch]; h[k] = pgy[n + k * nch];
-                                                  cb[k] = pb[n + k * nch]; ce[k] = pe[n + k * nch]; }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) term(x[k], y[k], g[k], h[k], cb[k] + ce[k]);
+                    // the bit position only depends on the loop counters, i.e. it is the same in every thread (scalar word index and shift)
+                    const int bp = (r * KB + kb) * 16;
+                    const unsigned long long mm = screened ? m16 << (bp & 63) : 0ull;
+                    switch (bp >> 6) { case 0: amask[0] |= mm; break; case 1: amask[1] |= mm; break; case 2: amask[2] |= mm; break; default: amask[3] |= mm; break; }
                 }
-                for (; n < a.Nloc; n += nch) term(pax[n], pay[n], pgx[n], pgy[n], pb[n] + pe[n]);
-                }
-                flush();
             }
         }
         mark(3);
-        if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %
-            double cnt = 0;
+        if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %;
+            double cnt = 0;        // and the nominal itself must lie within DELTA of the screening reference
             for (int w = 0; w < MW; ++w) cnt += (double)__popcll(amask[w]);
             cnt = block_reduce(cnt, L.red, tid, false);
-            if (cnt > 0.3 * (double)a.P * a.Nloc * T) screened = false;
+            double dv = 0;
+            if (masks_in && tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
+            if (masks_in) dv = block_reduce(dv, L.red, tid, true);
+            if (cnt > 0.3 * (double)a.P * a.Nloc * T || dv > 0.5 * DELTA) screened = false;
         }
         mark(14);
-        L.part[tid * 9] = q0; L.part[tid * 9 + 1] = q1; L.part[tid * 9 + 2] = q2;
+        L.part[tid * 9] = saa; L.part[tid * 9 + 1] = sga; L.part[tid * 9 + 2] = sgx;
         __syncthreads();
         if (tid < T) {
             double s0 = 0, s1 = 0, s2 = 0;
             for (int k = 0; k < nch; ++k) { const double *pp = &L.part[(tid * nch + k) * 9]; s0 += pp[0]; s1 += pp[1]; s2 += pp[2]; }
-            L.Q0[tid] = s0; L.Q1[tid] = s1; L.Q2[tid] = s2;
+            // Q2 = sum |dR'a|^2 = sum |a|^2 ;  Q1 = 2 sum (g + R'a).(dR'a) = 2 (cos sum g x a - sin sum g.a)
+            L.Q2[tid] = s0; L.Q1[tid] = 2 * (L.csn[tid] * s2 - L.csn[T + tid] * s1);
         }
     }
     mark(12);
@@ -623,9 +617,8 @@ template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Arg
     int status = 1, it = 0, used = 0;
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
     if (a.ref_flag) {
-        if (tid == 0) while (__hip_atomic_load(a.ref_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.ref_seq) __builtin_amdgcn_s_sleep(2);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();                       // L.part (the functor's scratch) is free from here to phase 1
+        ref_wait(L.part);
         for (int i = tid; i < 3 * (T + 1); i += NT) L.ref[i] = a.ref[i];
         __syncthreads();
     }
@@ -669,30 +662,36 @@ template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Arg
                         while (m) {
                             size_t off[4]; int cnt = 0;
                             while (m && cnt < 4) {
-                                int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
-                                int r = a.P == 1 ? 0 : bit / KS, k = bit - r * KS;
-                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + rc_ + (size_t)k * nch;
+                                const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
+                                const int blk = bit >> 4, row = bit & 15;
+                                const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
+                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + 16 * (rc_ + kb * nch) + row;
                             }
                             double x[4], y[4], cb[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) if (q < cnt) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.blam[off[q]] + a.ee[off[q]]; }
+                            for (int q = 0; q < 4; ++q) if (q < cnt) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.cb[off[q]]; }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) if (q < cnt) term(x[q], y[q], cb[q]);
                         }
                     }
                 } else
-                for (int r = 0; r < a.P; ++r) {
-                    const size_t o = r * a.chunk + (size_t)rt * Nl;
-                    const double *pax = a.ax + o, *pay = a.ay + o, *pb = a.blam + o, *pe = a.ee + o;
-                    int n = rc_;
-                    for (; n + 7 * nch < Nl; n += 8 * nch) {      // eight independent loads in flight per array
-                        double x[8], y[8], cb[8], ce[8];
+                for (int r = 0; r < a.P; ++r) {                    // every term, in the same order: shard, block of the slice, slot
+                    for (int kb = 0; kb < KB; ++kb) {
+                        const int j = rc_ + kb * nch;
+                        if (j >= J) break;
+                        const size_t o = r * a.chunk + (size_t)rt * Nl + 16 * j;
+                        const double *pax = a.ax + o, *pay = a.ay + o, *pcb = a.cb + o;
+                        const int nr = Nl - 16 * j < 16 ? Nl - 16 * j : 16;
+                        int n = 0;
+                        for (; n + 8 <= nr; n += 8) {                  // eight independent loads in flight per array
+                            double x[8], y[8], cb[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) { x[k] = pax[n + k * nch]; y[k] = pay[n + k * nch]; cb[k] = pb[n + k * nch]; ce[k] = pe[n + k * nch]; }
+                            for (int k = 0; k < 8; ++k) { x[k] = pax[n + k]; y[k] = pay[n + k]; cb[k] = pcb[n + k]; }
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) term(x[k], y[k], cb[k] + ce[k]);
+                            for (int k = 0; k < 8; ++k) term(x[k], y[k], cb[k]);
+                        }
+                        for (; n < nr; ++n) term(pax[n], pay[n], pcb[n]);
                     }
-                    for (; n < Nl; n += nch) term(pax[n], pay[n], pb[n] + pe[n]);
                 }
             }
             double *pp = &L.part[tid * 9];
@@ -994,6 +993,15 @@ template <int TT, typename Gate = NoGate> __device__ inline bool solve(const Arg
         for (int i = tid; i < 3 * (T + 1); i += NT) a.out_s[i] = a.in_s[i];
         for (int i = tid; i < 2 * T; i += NT) a.out_u[i] = a.in_u[i];
         if (a.d_in) for (int i = tid; i < T; i += NT) a.out_d[i] = a.d_in[i];
+    }
+    // pose table of the trajectory handed back (the solution, or the nominal when the solve failed): position of column t+1,
+    // cos / sin of the heading of column t (quirk Q1) - what every LamMuZ row and the next su set-up would otherwise recompute
+    if (a.pose_out && tid < T) {
+        const bool okk = status == 0;
+        const double px = okk ? L.s[tid + 1] : a.in_s[tid + 1], py = okk ? L.s[(T + 1) + tid + 1] : a.in_s[(T + 1) + tid + 1];
+        const double ph = okk ? L.s[2 * (T + 1) + tid] : a.in_s[2 * (T + 1) + tid];
+        double sp, cp; sincos(ph, &sp, &cp);
+        a.pose_out[4 * tid] = px; a.pose_out[4 * tid + 1] = py; a.pose_out[4 * tid + 2] = cp; a.pose_out[4 * tid + 3] = sp;
     }
     if (tid == 0) { *a.status = status; *a.ipm_iters = used; }
     mark(10);

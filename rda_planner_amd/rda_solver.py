@@ -16,7 +16,7 @@ from math import inf  # noqa: F401  (kept for API parity with the reference modu
 
 import numpy as np
 
-from ._capi import Cfg, Info, DYNAMICS, dptr, iptr, f64
+from ._capi import Cfg, Info, Opts, DYNAMICS, dptr, iptr, f64
 import ctypes as C
 
 CONE_CODE = {"Rpositive": 0, "norm2": 1}
@@ -31,12 +31,15 @@ except ImportError:
 class _Backend:
     """A loaded C-ABI library plus one solver handle."""
 
-    def __init__(self, api, cfg, G, h):
+    def __init__(self, api, cfg, G, h, opts=None):
         self.api = api
         self.handle = C.c_void_p()
         G = f64(G)
         h = f64(h).ravel()
-        rc = api.create(C.byref(cfg), dptr(G), dptr(h), C.byref(self.handle))
+        if opts is not None:
+            rc = api.create_opts(C.byref(cfg), C.byref(opts), dptr(G), dptr(h), C.byref(self.handle))
+        else:
+            rc = api.create(C.byref(cfg), dptr(G), dptr(h), C.byref(self.handle))
         if rc != 0:
             raise RuntimeError(f"{api.prefix}_create failed with code {rc}")
 
@@ -52,9 +55,24 @@ class _Backend:
             pass
 
 
-def _hip_backend(cfg, G, h):
+def hip_options(**changes):
+    """rda_opts with the library defaults (and RDA_* environment overrides), then `changes` applied (field=value)"""
+    from ._lib import hip_api
+    o = Opts()
+    hip_api().opts_init(C.byref(o))
+    for k, v in changes.items():
+        cur = getattr(o, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def _hip_backend(cfg, G, h, opts=None):
     from ._lib import hip_api          # raises loudly when librda_hip.so / the GPU is missing
-    return _Backend(hip_api(), cfg, G, h)
+    return _Backend(hip_api(), cfg, G, h, opts)
 
 
 class RDA_solver:
@@ -111,22 +129,13 @@ class RDA_solver:
         # lmz_central = mu > 0 selects the interior-point kernel that returns the central-path point of the reference's cone
         # program at barrier parameter mu; a norm2 (circle) robot always uses it (default mu 1e-6)
         self.lmz_central = kwargs.get("lmz_central", None)
-        self._be = make(cfg, G, h) if not self.lmz_central else self._make_central(make, cfg, G, h, float(self.lmz_central))
+        opts = kwargs.get("hip_opts", None)            # an rda_opts (see hip_options) for the HIP backend; None = library defaults
+        if self.lmz_central and make is _hip_backend:
+            opts = opts if opts is not None else hip_options()
+            opts.lmz_mode, opts.lmz_mu = 1, float(self.lmz_central)
+        self._be = make(cfg, G, h, opts) if (make is _hip_backend and opts is not None) else make(cfg, G, h)   # test backends select the mode themselves
         self._R = G.shape[0]
         self.pipeline = True        # MPC overlaps its per-tick obstacle staging with the first su-problem (set False to serialise)
-
-    @staticmethod
-    def _make_central(make, cfg, G, h, mu):
-        """create the handle with the process-wide LamMuZ mode switched to the interior-point kernel, then switch it back"""
-        from ._lib import hip_api
-        if make is _hip_backend:
-            lib = hip_api().lib
-            lib.rda_set_lmz_mode(1, mu)
-            try:
-                return make(cfg, G, h)
-            finally:
-                lib.rda_set_lmz_mode(0, 1e-6)
-        return make(cfg, G, h)              # test backends select the mode themselves
 
     # ---- runtime tunables (reference :426-434, :1055-1056) ------------------------------
     def assign_adjust_parameter(self, **kwargs):
