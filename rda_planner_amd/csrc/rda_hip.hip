@@ -26,6 +26,7 @@
 #include "../../include/rda_hip.h"
 #include "lammuz_device.h"
 #include "lammuz_cp_device.h"
+#include "lammuz_ip_device.h"
 #include "su_device.h"
 #include "scene_device.h"
 #include "track_device.h"
@@ -50,8 +51,10 @@ struct Ctrl {
 #endif
 };
 
-constexpr int NCOEF = 9;      // per-(slot, stage) arrays of an obstacle-shard chunk of Dev::coef
-constexpr int NBS = su::NBS;  // doubles per (stage, 16-slot block) partial; one more 8-byte word per block carries the near mask
+constexpr int NCOEF = 9;      // per-(slot, stage) term arrays: NGATH of them travel with the shard chunk (Dev::coef), the rest stay local (Dev::coefL)
+constexpr int NGATH = 3;      // ax, ay, cb: what the su hinge reads per term
+constexpr int NBS = su::NBS;  // doubles per (stage, GS-slot block) partial; one more 8-byte word per block carries the near mask
+constexpr int GS = su::GS;    // slots per block partial = rows of a packed LamMuZ workgroup (2 waves x 4 rows of 16 lanes)
 struct Dev;
 __host__ __device__ inline double *coef_arr(const Dev &d, int r, int k);
 
@@ -88,17 +91,18 @@ struct Dev {
     // per (slot, time slot) candidate list and vertices of the staged obstacle (pose independent): k_prepare, at upload
     unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][40], [N*nt][28][2], [N*nt][2] = (npv, nlv)
     int *hint;                                // [T][N] support (candidate index) of the last max-clearance optimum, -1 = none
-    // Dual state, STAGE-MAJOR: lam [T+1][N][E], mu [T+1][N][R], xi [T+1][N][2], z / zeta [T][N] - a LamMuZ workgroup owns 16 consecutive
+    // Dual state, STAGE-MAJOR: lam [T+1][N][E], mu [T+1][N][R], xi [T+1][N][2], z / zeta [T][N] - a LamMuZ workgroup owns GS consecutive
     // slots of one stage, so what it reads and writes are whole lines (the accessors rda_get_state / rda_set_state speak the
     // reference's [N][T+1][.] shapes)
     double *lam, *mu, *z, *xi, *zeta, *dis;
-    // Condensed su terms + residual partials, one chunk per obstacle shard (P = 1 on a single GPU):
-    //   coef[r*chunk + k*T*Nloc + t*Nloc + nl],  k = 0 ax, 1 ay, 2 lam'b, 3 mu'h + z - zeta, 4 / 5 G'mu + xi, 6 dual residual, 7 |Hm|^2,
-    //                                            8 cb = [2] + [3] (the offset of the su hinge)
-    //   bsum : coef[r*chunk + NCOEF*T*Nloc + ((t*J + j)*NBS + q)]   sums over the slots 16j .. 16j+15 of stage t (su::row_term; [6], [7])
-    //   bmask: the 8-byte words behind bsum, [t*J + j]: bit r = slot 16j+r is NEAR (su hinge screening) at the pose table's position
-    // chunk r is produced by rank r's LamMuZ launch and replicated by one all-gather per ADMM iteration.
-    double *coef; int P, rank, Nloc, J; size_t chunk;
+    // Condensed su terms + residual partials per obstacle shard (P = 1 on a single GPU), arrays [T][Nloc] indexed t*Nloc + nl:
+    //   k = 0 ax, 1 ay (a = A'lam), 8 cb = lam'b + mu'h + z - zeta (the offset of the su hinge)      -> the shard CHUNK, coef[r*chunk + ..]
+    //   k = 2 lam'b, 3 mu'h + z - zeta, 4 / 5 G'mu + xi, 6 dual residual, 7 |Hm|^2                    -> local only, coefL[r*lchunk + ..]
+    //   bsum : coef[r*chunk + NGATH*T*Nloc + ((t*J + j)*NBS + q)]   sums over the slots GS j .. GS j + GS-1 of stage t (su::row_term; [6], [7])
+    //   bmask: the 8-byte words behind bsum, [t*J + j]: bit r = slot GS j + r is NEAR (su hinge screening) at the pose table's position
+    // chunk r (what the su-problem reads: three arrays + the reduced sums and masks) is produced by rank r's LamMuZ launch and replicated
+    // by one all-gather per ADMM iteration; the local arrays serve the state accessors, failed rows and k_lmz_finalize of the own rank.
+    double *coef, *coefL; int P, rank, Nloc, J; size_t chunk, lchunk;
     int Nlive;                                // obstacle slots of THIS rank's shard that exist (< Nloc on the last ranks when N % P != 0)
     double *s, *u;                            // nominal (para_s, para_u)
     double *pose;                             // [T][4] px, py (column t+1), cos, sin (heading of column t) of Dev::s: written by every su launch,
@@ -108,28 +112,46 @@ struct Dev {
     long long *su_prof;                       // optional phase cycle counters of the su-solves of this handle (RDA_SU_PROF), else null
 };
 
-__host__ __device__ inline double *coef_arr(const Dev &d, int r, int k) { return d.coef + (size_t)r * d.chunk + (size_t)k * d.c.T * d.Nloc; }
-__host__ __device__ inline double *bsum_arr(const Dev &d, int r) { return d.coef + (size_t)r * d.chunk + (size_t)NCOEF * d.c.T * d.Nloc; }
+__host__ __device__ inline double *coef_arr(const Dev &d, int r, int k)
+{
+    const size_t tn = (size_t)d.c.T * d.Nloc;
+    if (k < 2) return d.coef + (size_t)r * d.chunk + (size_t)k * tn;
+    if (k == 8) return d.coef + (size_t)r * d.chunk + 2 * tn;
+    return d.coefL + (size_t)r * d.lchunk + (size_t)(k - 2) * tn;
+}
+__host__ __device__ inline double *bsum_arr(const Dev &d, int r) { return d.coef + (size_t)r * d.chunk + (size_t)NGATH * d.c.T * d.Nloc; }
 __host__ __device__ inline unsigned long long *bmask_arr(const Dev &d, int r) { return (unsigned long long *)(bsum_arr(d, r) + (size_t)NBS * d.c.T * d.J); }
-__host__ __device__ inline size_t chunk_doubles(int T, int Nloc) { const size_t J = (Nloc + 15) / 16; return (size_t)NCOEF * T * Nloc + (size_t)(NBS + 1) * T * J; }
+__host__ __device__ inline size_t chunk_doubles(int T, int Nloc) { const size_t J = (Nloc + GS - 1) / GS; return (size_t)NGATH * T * Nloc + (size_t)(NBS + 1) * T * J; }
+__host__ __device__ inline size_t lchunk_doubles(int T, int Nloc) { return (size_t)(NCOEF - NGATH) * T * Nloc; }
 // row index of (slot n, dual column tt) / (slot n, stage t) in the stage-major dual arrays
 __host__ __device__ inline size_t drow(const Dev &d, int n, int tt) { return (size_t)tt * d.c.N + n; }
 
 // ------------------------------------------------------------------------------------------------
 // resi_dual (mean over the slots of the squared dual change, rda_solver.py:735-737) and resi_pri (|stack(Hm)|, :688) from the block
-// partials of every shard; fixed order -> identical on every rank.  All NT threads; `red` = NT doubles of LDS.
-__device__ void reduce_residuals(const Dev &d, double *red, int tid)
+// partials of every shard.  ONE wave (the first 64 threads of the calling workgroup), lane l sums the partials l, l+64, ... in that
+// order, then a wave reduction: the values do not depend on the kernel (or workgroup size) that takes the verdict, and they are
+// identical on every rank.  All threads of the workgroup call.
+__device__ void reduce_residuals(const Dev &d, int tid)
 {
     const int T = d.c.T, N = d.c.N;
-    double rd = 0, rp = 0;
-    if (d.obstacle_num != 0)
-        for (int r = 0; r < d.P; ++r) {
-            const double *bs = bsum_arr(d, r);
-            for (int i = tid; i < d.J * T; i += su::NT) { rd += bs[(size_t)i * NBS + 3]; rp += bs[(size_t)i * NBS + 4]; }
-        }
-    rd = su::block_reduce(rd, red, tid, false);
-    rp = su::block_reduce(rp, red, tid, false);
-    if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); d.ctrl->resi_iter = d.ctrl->iters; }
+    if (tid < 64) {
+        double rd = 0, rp = 0;
+        if (d.obstacle_num != 0)
+            for (int r = 0; r < d.P; ++r) {
+                const double *bs = bsum_arr(d, r);
+                const int nb = d.J * T;
+                for (int base = 0; base < nb; base += 64 * 16) {        // sixteen independent loads in flight per lane and quantity,
+                    double a[16], b[16];                                 // accumulated in the order of the plain loop
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { const int i = base + tid + 64 * k; const bool in = i < nb; a[k] = in ? bs[(size_t)i * NBS + 3] : 0.0; b[k] = in ? bs[(size_t)i * NBS + 4] : 0.0; }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) if (base + tid + 64 * k < nb) { rd += a[k]; rp += b[k]; }
+                }
+            }
+        rd = su::wave_allreduce(rd, false);
+        rp = su::wave_allreduce(rp, false);
+        if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); d.ctrl->resi_iter = d.ctrl->iters; }
+    }
     __syncthreads();
 }
 
@@ -139,14 +161,18 @@ extern __shared__ __attribute__((aligned(16))) double smem_su[];
 // `mirror` (pinned host memory): the same block written straight into the caller-visible host buffer and published with a
 // sequence number (system-scope release) - the host polls that word instead of queueing a device-to-host copy and waiting for
 // the stream (fetch_result).
-struct Fin { double *out_u, *out_s; rda_info *info; double *mirror; unsigned long long seq; int slot; };   // slot: out_u is the handle's contiguous result slot
+struct Fin { double *out_u, *out_s; rda_info *info; double *mirror; unsigned long long seq; int slot;   // slot: out_u is the handle's contiguous result slot
+             // obstacle shards: the su launch that takes the early-stop verdict itself publishes it (2 vseq + stop) in pinned host memory
+             // BEFORE it starts its solve - the host polls that word and queues the next LamMuZ launch + all-gather (or stops queueing)
+             // while the su-problem is still being solved: no stream synchronisation inside a step
+             unsigned long long *verdict = nullptr; unsigned long long vseq = 0; };
 
-// all threads of a 256-thread workgroup; the residuals in d.ctrl are final
+// all threads of the calling workgroup (any size); the residuals in d.ctrl are final
 __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
 {
-    const int tid = threadIdx.x, T = d.c.T;
-    for (int i = tid; i < 2 * T; i += su::NT) f.out_u[i] = d.u[i];
-    for (int i = tid; i < 3 * (T + 1); i += su::NT) f.out_s[i] = d.s[i];
+    const int tid = threadIdx.x, nth = blockDim.x, T = d.c.T;
+    for (int i = tid; i < 2 * T; i += nth) f.out_u[i] = d.u[i];
+    for (int i = tid; i < 3 * (T + 1); i += nth) f.out_s[i] = d.s[i];
     if (tid == 0) {
         f.info->resi_dual = d.ctrl->resi_dual; f.info->resi_pri = d.ctrl->resi_pri;
         f.info->iters = d.ctrl->iters; f.info->su_status = d.ctrl->su_status; f.info->su_ipm_iters = d.ctrl->ipm_iters;
@@ -157,7 +183,7 @@ __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
     if (!f.mirror) return;
     __syncthreads();
     const int n = 2 * T + 3 * (T + 1) + 7;                   // out_u, out_s, info (4 doubles), the track::Out (2), the non-convex count
-    for (int i = tid; i < n; i += su::NT) f.mirror[i] = f.out_u[i];
+    for (int i = tid; i < n; i += nth) f.mirror[i] = f.out_u[i];
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store((unsigned long long *)(f.mirror + n), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -181,8 +207,10 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // its tail (lmz_tail: residuals reduced, stop flag set, result handed over) and nothing is left to do here; with obstacle shards
     // (the residual partials of the other ranks arrive with the all-gather) or with the tail switched off it is taken here.
     if (it > 0 && d.ctrl->resi_iter != it) {
-        reduce_residuals(d, smem_su, tid);
-        if (d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold) {   // rda_solver.py:594
+        reduce_residuals(d, tid);
+        const bool stop_now = d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;   // rda_solver.py:594
+        if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + (stop_now ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (stop_now) {
             __syncthreads();
             if (tid == 0) d.ctrl->stop = 1;
             // The step ends here (rda_solver.py:594-596): hand the result over now - the launches still queued behind this one return
@@ -249,7 +277,7 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, 
 __device__ __forceinline__ void finish_body(const Dev &d, const Fin &f)
 {
     if (d.ctrl->finished) return;                   // (uniform) the launch that ended the step already handed the result over
-    if (!d.ctrl->stop && d.ctrl->resi_iter != d.ctrl->iters) reduce_residuals(d, smem_su, threadIdx.x);
+    if (!d.ctrl->stop && d.ctrl->resi_iter != d.ctrl->iters) reduce_residuals(d, threadIdx.x);
     __syncthreads();
     publish_result(d, f);
 }
@@ -287,10 +315,25 @@ __global__ __launch_bounds__(256) void k_prepare(Dev d)
     if (lane == 0) { d.oc_cnt[2 * w] = W.npv; d.oc_cnt[2 * w + 1] = W.nlv; }
 }
 
-// Unit w of a rank's LamMuZ grid -> (stage t, local slot nl): the SLOT runs fastest and a stage is padded to 16 J units, so a
-// workgroup of the packed kernels (16 rows) owns the slots 16j .. 16j+15 of ONE stage: with the stage-major dual arrays and the
-// [T][Nloc] condensed-term arrays everything it reads and writes are whole lines, and its 16 rows reduce to one block partial.
-__device__ __forceinline__ void unit_of(const Dev &d, int w, int &t, int &nl) { const int S = 16 * d.J; t = w / S; nl = w - t * S; }
+// Unit w of a rank's LamMuZ grid -> (stage t, local slot nl): the SLOT runs fastest and a stage is padded to GS J units, so a
+// workgroup of the packed kernels (GS = 8 rows: 2 waves x 4 rows) owns the slots GS j .. GS j + GS-1 of ONE stage: with the stage-major
+// dual arrays and the [T][Nloc] condensed-term arrays everything it reads and writes are whole 64-byte half lines, and its rows reduce
+// to one block partial.  (Two-wave workgroups: the north-star grid T J = 500 of them is ONE round on 256 CUs at one wave per SIMD.)
+__device__ __forceinline__ void unit_of(const Dev &d, int w, int &t, int &nl) { const int S = GS * d.J; t = w / S; nl = w - t * S; }
+// Launch index of a packed workgroup -> its block (stage t, GS-slot group j), or t = -1 for a filler.  Workgroups are handed to the
+// 8 XCDs round robin (block b runs on XCD b % 8 - observed, used for speed only), and each XCD has its own L2.  The T workgroups that
+// share the staged data of the same obstacles (half-spaces, candidate lists, vertices: ~0.5 KB per slot, read once per STAGE) should
+// meet in ONE L2, and every XCD must get the same number of workgroups (the north-star grid is exactly one round of the chip): the
+// blocks are numbered group-major (u = j T + t) and cut into 8 equal contiguous ranges, one per XCD - a group's stages land on one
+// XCD (two for the few groups a cut goes through), neighbouring groups (which share the 128-byte lines of the [T][N] arrays) too.
+//   b = 8 q + x ;  u = x per + q ,  per = ceil(T J / 8) ;  j = u / T ,  t = u % T
+__host__ __device__ inline int packed_grid(int T, int J) { return 8 * ((T * J + 7) / 8); }
+__device__ __forceinline__ void block_of(const Dev &d, int b, int &t, int &j)
+{
+    const int T = d.c.T, W = T * d.J, per = (W + 7) / 8, x = b & 7, q = b >> 3, u = x * per + q;
+    j = u / T; t = u - j * T;
+    if (u >= W) t = -1;
+}
 
 // What one solved (or failed) row hands to the su-problem and to the residuals, as stored in the coef arrays
 struct RowOut { double ax, ay, bl, c3, c4, c5, res, hh; };
@@ -309,7 +352,7 @@ __device__ __forceinline__ RowOut failed_row(const Dev &d, int k)
     return o;
 }
 
-// 16 row records [16][6] = (|a|^2, g.a, g x a, dual residual, |Hm|^2, near) in LDS -> the block partial of (stage t, block j): threads
+// GS row records [GS][6] = (|a|^2, g.a, g x a, dual residual, |Hm|^2, near) in LDS -> the block partial of (stage t, block j): threads
 // q = 0..4 sum one quantity over the rows IN ROW ORDER (dead rows hold zeros), thread 5 packs the near mask.  Stored write-through
 // (sc1: 8-byte agent-scope stores), so the last-arriving workgroup of the launch may read them without a release fence (lmz_tail).
 __device__ __forceinline__ void block_partial(const Dev &d, int t, int j, const double (*rowv)[6], int q)
@@ -317,11 +360,11 @@ __device__ __forceinline__ void block_partial(const Dev &d, int t, int j, const 
     const size_t bi = (size_t)t * d.J + j;
     if (q < NBS) {
         double acc = 0;
-        for (int r = 0; r < 16; ++r) acc += rowv[r][q];
+        for (int r = 0; r < GS; ++r) acc += rowv[r][q];
         __hip_atomic_store(bsum_arr(d, d.rank) + bi * NBS + q, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (q == NBS) {
         unsigned long long m = 0;
-        for (int r = 0; r < 16; ++r) m |= rowv[r][5] != 0.0 ? 1ull << r : 0ull;
+        for (int r = 0; r < GS; ++r) m |= rowv[r][5] != 0.0 ? 1ull << r : 0ull;
         __hip_atomic_store(bmask_arr(d, d.rank) + bi, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -335,8 +378,8 @@ __device__ __forceinline__ void row_record(double *rv, const Dev &d, const RowOu
 // it drains them and takes a ticket.  The LAST one to arrive acquires, reduces the residual partials of all blocks in a fixed order
 // (the values do not depend on which workgroup that is), takes the early-stop verdict of rda_solver.py:594 and - when the step ends
 // here (stop, or the last iteration) - hands the result over.  The su launch that used to detect the stop (and k_finish) leave the
-// critical path: a two-iteration step is su, lmz, su, lmz.  All 256 threads call; `red` >= 256 doubles of LDS, `flag` one LDS word.
-__device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, double *red, unsigned *flag, unsigned nblocks)
+// critical path: a two-iteration step is su, lmz, su, lmz.  All threads of the workgroup call; `flag` one LDS word.
+__device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, unsigned *flag, unsigned nblocks)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its sc1 stores ...
     __syncthreads();
@@ -348,7 +391,7 @@ __device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, d
     __syncthreads();
     if (!*flag) return;
     if (threadIdx.x == 0) d.ctrl->pose_ok = 1;                  // masks and pose table describe the same terms from here on
-    reduce_residuals(d, red, threadIdx.x);
+    reduce_residuals(d, threadIdx.x);
     const bool last = it + 1 >= d.c.iter_num;
     const bool stop = !last && d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;      // rda_solver.py:594
     __syncthreads();
@@ -488,7 +531,7 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx
 // (DESIGN.md section 5): the rows run it side by side.  Only a row whose certificate fails needs the 64-lane enumeration;
 // those rows are served one after the other by the whole wave.  Same device functions, same arithmetic, same results as
 // lammuz_body.  Requires E + R + 1 <= 16 (else the one-per-wave body is launched).
-// MODE 0: everything in one kernel (single ego, latency), INCLUDING the block partial of the workgroup's 16 slots and the tail of
+// MODE 0: everything in one kernel (single ego, latency), INCLUDING the block partial of the workgroup's GS slots and the tail of
 //         the step (lmz_tail).  Dense grids are served by three launches instead:
 // MODE 1: the common path only - three waves per SIMD, no spills; a row whose warm candidate fails its certificate goes on the
 //         handle's work list (Dev::wl) and writes nothing;
@@ -498,29 +541,31 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx
 template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
 {
 #pragma clang fp contract(on)          // see lammuz_device.h
-    __shared__ lmz::WaveLDS wl[16];
+    constexpr int WPB = GS / 4;        // waves per workgroup (4 rows each)
+    __shared__ lmz::WaveLDS wl[GS];
     __shared__ lmz::RobotLDS rb;
-    __shared__ double rowv[MODE == 0 ? 16 : 1][6];
-    __shared__ double tail_red[MODE == 0 ? 256 : 1];
+    __shared__ double rowv[MODE == 0 ? GS : 1][6];
     __shared__ unsigned tail_flag;
     const int T = d.c.T, E = d.c.E, R = d.c.R;
     if (d.ctrl->stop) return;
+    int tb = 0, jb = 0;                                        // (modes 0, 1) the workgroup's block: stage and GS-slot group
+    if (MODE != 2) { block_of(d, block, tb, jb); if (tb < 0) return; }      // a filler of the XCD-aware launch order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4, gl = lane & 15;
-    if (threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = d.G[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + R) rb.h[threadIdx.x - 64] = d.h[threadIdx.x - 64];
-    if (threadIdx.x >= 128 && threadIdx.x < 128 + 40) rb.muc[threadIdx.x - 128] = d.muc[threadIdx.x - 128];
-    if (threadIdx.x >= 192 && threadIdx.x < 192 + 56) (&rb.rv[0][0])[threadIdx.x - 192] = (&d.rv[0][0])[threadIdx.x - 192];
-    if (threadIdx.x == 255) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
+    for (int i = threadIdx.x; i < 2 * R; i += 64 * WPB) rb.G[i >> 1][i & 1] = d.G[i];
+    for (int i = threadIdx.x; i < R; i += 64 * WPB) rb.h[i] = d.h[i];
+    for (int i = threadIdx.x; i < 40; i += 64 * WPB) rb.muc[i] = d.muc[i];
+    for (int i = threadIdx.x; i < 56; i += 64 * WPB) (&rb.rv[0][0])[i] = (&d.rv[0][0])[i];
+    if (threadIdx.x == 0) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
     const int cnt = MODE == 2 ? d.ctrl->wl_count : 1;
-    for (int base = MODE == 2 ? block * 4 : 0; base < cnt; base += MODE == 2 ? nblocks * 4 : 1) {       // modes 0, 1: one pass
+    for (int base = MODE == 2 ? block * WPB : 0; base < cnt; base += MODE == 2 ? nblocks * WPB : 1) {       // modes 0, 1: one pass
     if (MODE == 2) __syncthreads();                            // the slabs of the previous pass are free again
     const bool entry = MODE == 2 && base + wv < cnt;            // (wave-uniform) this wave has a work-list entry in this pass
     // a row past the end (a dead slot of the padded stage, an idle row of mode 2) shadows unit (0, 0) and writes nothing
     int t, nl;
-    unit_of(d, MODE == 2 ? d.wl[entry ? base + wv : base] : block * 16 + wv * 4 + row, t, nl);
-    const bool live = MODE == 2 ? (entry && row == 0) : (t < T && nl < d.Nlive);
-    const int tb = t, jb = nl >> 4;                            // (modes 0, 1) the workgroup's block: stage and 16-slot group
-    if (!live) { t = t < T ? t : 0; nl = 0; }
+    if (MODE == 2) unit_of(d, d.wl[entry ? base + wv : base], t, nl);
+    else { t = tb; nl = jb * GS + wv * 4 + row; }
+    const bool live = MODE == 2 ? (entry && row == 0) : nl < d.Nlive;
+    if (!live) nl = 0;
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
@@ -587,7 +632,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
             best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
             best.l1 = best.l2 = best.g1 = best.g2 = 0;
         }
-        if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = t * 16 * d.J + nl;
+        if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = t * GS * d.J + nl;
         need = 0;
     }
     while (need) {
@@ -660,34 +705,35 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     }
     if (MODE == 0) {
         __syncthreads();
-        if (tb < T) block_partial(d, tb, jb, rowv, threadIdx.x);
-        if (d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, tail_red, &tail_flag, (unsigned)nblocks);
+        block_partial(d, tb, jb, rowv, threadIdx.x);
+        if (d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
         else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
     }
     }
 }
 
-// two builds: all registers and one workgroup per CU (no spills: the shorter critical path a single ego wants), or two
-// workgroups per CU with a few spilled registers (more sub-problems in flight: what a full chip wants)
-__global__ __launch_bounds__(256) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
-__global__ __launch_bounds__(256, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
-__global__ __launch_bounds__(256, 3) void k_lammuz_rows_fast(Dev d) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
-// (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower; the work list with two workgroups per CU is 4 % faster for fleets)
-__global__ __launch_bounds__(256, 2) void k_lammuz_enum(Dev d) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+// two builds: all registers and one wave per SIMD (no spills: the shorter critical path a single ego wants), or two
+// waves per SIMD with a few spilled registers (more sub-problems in flight: what a full chip wants)
+__global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
+__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
+__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_rows_fast(Dev d) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+// (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower; the work list with two waves per SIMD is 4 % faster for fleets)
+__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_enum(Dev d) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 
 // Block partials from the STORED terms - the same row_term, the same row order as mode 0 of the packed kernel forms them in flight - and
 // the tail of the step.  Runs behind every LamMuZ form that leaves its rows to more than one workgroup or launch (split launch, one
 // sub-problem per wave, the per-thread interior-point kernel), after the no-obstacle launch (quirk Q9 edits terms) and whenever the
-// host rewrites terms (rda_set_state, rda_reset, rda_shard_config).  One 16-slot block per 16-lane group; it < 0: no tail.
+// host rewrites terms (rda_set_state, rda_reset, rda_shard_config).  One GS-slot block per GS threads, 256 / GS blocks per workgroup;
+// it < 0: no tail.
+constexpr int FPB = 256 / GS;          // block partials per workgroup of k_lmz_finalize
 __device__ __forceinline__ void finalize_body(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
 {
 #pragma clang fp contract(on)
-    __shared__ double rowv[16][16][6];
-    __shared__ double tail_red[256];
+    __shared__ double rowv[FPB][GS][6];
     __shared__ unsigned tail_flag;
     if (it >= 0 && d.ctrl->stop) return;
-    const int T = d.c.T, g = threadIdx.x >> 4, row = threadIdx.x & 15;
-    const int B = block * 16 + g, t = B / d.J, j = B - t * d.J, nl = 16 * j + row;
+    const int T = d.c.T, g = threadIdx.x / GS, row = threadIdx.x % GS;
+    const int B = block * FPB + g, t = B / d.J, j = B - t * d.J, nl = GS * j + row;
     double *rv = rowv[g][row];
     if (B < T * d.J && nl < d.Nlive) {
         const int k = t * d.Nloc + nl;
@@ -698,7 +744,7 @@ __device__ __forceinline__ void finalize_body(const Dev &d, const int block, con
     } else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
     __syncthreads();
     if (B < T * d.J) block_partial(d, t, j, rowv[g], row);
-    if (it >= 0 && d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, tail_red, &tail_flag, (unsigned)nblocks);
+    if (it >= 0 && d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, &tail_flag, (unsigned)nblocks);
     else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
 }
 __global__ __launch_bounds__(256) void k_lmz_finalize(Dev d, int it, Fin fin) { finalize_body(d, blockIdx.x, gridDim.x, it, fin); }
@@ -773,6 +819,114 @@ template <int NX, int MX> __device__ __forceinline__ void lammuz_cp_body(const D
 }
 __global__ __launch_bounds__(64) void k_lammuz_cp_small(Dev d) { lammuz_cp_body<16, 24>(d); }      // E, R <= 4
 __global__ __launch_bounds__(64) void k_lammuz_cp_large(Dev d) { lammuz_cp_body<24, 36>(d); }      // E, R <= 8
+
+// K1, interior-point variant, ROW-PARALLEL (lammuz_ip_device.h): one sub-problem per 16-lane row, lane i = variable i of the cone
+// program, GS rows per workgroup in the launch order and with the epilogue of the packed enumeration kernel - duals, condensed terms,
+// block partial, tail of the step all in this ONE launch.  A solve that does not reach the central path keeps the previous duals of
+// its stage and makes the residual inf (rda_solver.py:781-793); unlike non-finite data (where everything of the stage is left alone)
+// the xi / zeta updates then run with the kept duals, as the reference's do.
+__device__ __forceinline__ void lammuz_ip_body(const Dev &d, const int block, const int it, const Fin &fin)
+{
+    constexpr int WPB = GS / 4;
+    __shared__ lmz::WaveLDS wl[GS];
+    __shared__ lmz::RobotLDS rb;
+    __shared__ double rowv[GS][6];
+    __shared__ unsigned tail_flag;
+    typedef rip::DevLanes L;
+    const int T = d.c.T, E = d.c.E, R = d.c.R;
+    if (d.ctrl->stop) return;
+    int t, jb; block_of(d, block, t, jb);
+    if (t < 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4, gl = lane & 15;
+    for (int i = threadIdx.x; i < 2 * R; i += 64 * WPB) rb.G[i >> 1][i & 1] = d.G[i];
+    for (int i = threadIdx.x; i < R; i += 64 * WPB) rb.h[i] = d.h[i];
+    int nl = jb * GS + wv * 4 + row;
+    const bool live = nl < d.Nlive;
+    if (!live) nl = 0;
+    const int n = d.rank * d.Nloc + nl;
+    lmz::WaveLDS &W = wl[wv * 4 + row];
+    const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
+    if (gl < 2 * E) W.A[gl >> 1][gl & 1] = d.A[ao * 2 + gl];
+    if (gl < E) W.b[gl] = d.b[ao + gl];
+    __syncthreads();
+    rip::Problem p;
+    p.E = E; p.R = R; p.cone_norm2 = d.cone[n]; p.robot_norm2 = d.c.robot_norm2; p.accelerated = d.c.accelerated;
+    p.A = &W.A[0][0]; p.b = W.b; p.G = &rb.G[0][0]; p.h = rb.h;
+    const double *ps = d.pose + 4 * t;                        // position of column t+1, cos / sin of the heading of column t (quirk Q1)
+    p.px = ps[0]; p.py = ps[1]; p.cs = ps[2]; p.sn = ps[3];
+    const size_t o = drow(d, n, t + 1), zi = drow(d, n, t);
+    p.xi0 = d.xi[2 * o]; p.xi1 = d.xi[2 * o + 1];
+    const double zeta = d.zeta[zi], dbar = d.dis[t];
+    p.kappa0 = zeta - dbar; p.ro2 = d.c.ro2; p.mu_target = d.lmz_mu;
+    double prev = 0.0;                                        // this lane's dual entry before the solve: lam | mu | z
+    if (gl < E) prev = d.lam[o * E + gl];
+    else if (gl < E + R) prev = d.mu[o * R + gl - E];
+    else if (gl == E + R) prev = d.z[zi];
+    bool bad = !isfinite(p.px + p.py + p.cs + p.sn + p.xi0 + p.xi1 + p.kappa0);
+    if (gl < 2 * E) bad = bad || !isfinite(W.A[gl >> 1][gl & 1]);
+    if (gl < E) bad = bad || !isfinite(W.b[gl]);
+    bad = ((__ballot(bad) >> (16 * row)) & 0xffffull) != 0;                      // uniform over the row
+    int status = 2;
+    double v = prev;
+    if (!bad) {
+        rip::Solver<L> sv;
+        sv.build(p);
+        status = sv.run(p.mu_target);
+        if (status == 0) {
+            v = sv.x;
+            if (gl < E) { if (!p.cone_norm2 && v < 0) v = 0; }
+            else if (gl < E + R) { if (!p.robot_norm2 && v < 0) v = 0; }
+            else if (gl == E + R) { if (!(v > 0)) v = 0; }
+            const bool fin_ok = gl > E + R || isfinite(v);
+            if (((__ballot(!fin_ok) >> (16 * row)) & 0xffffull) != 0) status = 2;
+        }
+    }
+    const bool fail = status != 0;                             // (row-uniform) previous duals kept
+    if (fail) v = prev;
+    const double dv = gl <= E + R ? v - prev : 0.0;
+    const double res = L::rsum(dv * dv);
+    const bool wr = live && !bad;
+    if (wr && !fail) {
+        if (gl < E) d.lam[o * E + gl] = v;
+        else if (gl < E + R) d.mu[o * R + gl - E] = v;
+        else if (gl == E + R) d.z[zi] = v;
+    }
+    // lam'A, lam'b, mu'h, G'mu with the duals in force (new, or kept): row reductions of the lanes' products
+    const double la = gl < E ? v : 0.0, ma = (gl >= E && gl < E + R) ? v : 0.0;
+    const int ie = gl < E ? gl : 0, jr = (gl >= E && gl < E + R) ? gl - E : 0;
+    const double ax = L::rsum(la * W.A[ie][0]), ay = L::rsum(la * W.A[ie][1]), bl = L::rsum(la * W.b[ie]);
+    const double mh = L::rsum(ma * rb.h[jr]), gx = L::rsum(ma * rb.G[jr][0]), gy = L::rsum(ma * rb.G[jr][1]);
+    const double znew = L::bc<0>(__shfl(v, (lane & 48) + E + R, 64));           // lane E+R of the row
+    if (gl == 0) {
+        const int k = t * d.Nloc + nl;
+        RowOut ro;
+        bool have = false;
+        if (live && bad) {
+            ro = failed_row(d, k); have = true;
+            store_row(d, k, ro);
+            atomicAdd(&d.ctrl->lmz_fail, 1);
+        } else if (wr) {
+            const double hx = gx + p.cs * ax + p.sn * ay, hy = gy - p.sn * ax + p.cs * ay;      // Hm, :682
+            const double xin0 = p.xi0 + hx, xin1 = p.xi1 + hy;                                  // :683
+            d.xi[2 * o] = xin0; d.xi[2 * o + 1] = xin1;
+            const double im = ax * p.px + ay * p.py - bl - mh;                                  // :659
+            const double zetan = zeta + im - dbar - znew;                                       // :666
+            d.zeta[zi] = zetan;
+            ro.ax = ax; ro.ay = ay; ro.bl = bl; ro.c3 = mh + znew - zetan; ro.c4 = gx + xin0; ro.c5 = gy + xin1;
+            ro.res = fail ? INFINITY : res; ro.hh = hx * hx + hy * hy; have = true;
+            store_row(d, k, ro);
+            if (fail) atomicAdd(&d.ctrl->lmz_fail, 1);
+        }
+        double *rv = rowv[wv * 4 + row];
+        if (have) row_record(rv, d, ro, p.px, p.py);
+        else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
+    }
+    __syncthreads();
+    block_partial(d, t, jb, rowv, threadIdx.x);
+    if (d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
+    else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
+}
+__global__ __launch_bounds__(64 * GS / 4) void k_lammuz_ip(Dev d, int it, Fin fin) { lammuz_ip_body(d, blockIdx.x, it, fin); }
 
 struct RobotCands { unsigned char muc[40]; int nmv; double rv[28][2]; int nrv; int centre; };
 
@@ -889,7 +1043,7 @@ struct rda_handle {
     double *d_out_u, *d_out_s; rda_info *d_info;          // result slot of the step path
     double *h_out; rda_info *h_info;                      // pinned
     unsigned long long res_seq; int zero_copy;           // result mirror written by k_finish (see there); RDA_ZERO_COPY=0: D2H copy + stream sync
-    int *h_stop = nullptr;                                // pinned copy of the early-stop flag (sharded handles with a communicator)
+    unsigned long long *h_verdict = nullptr; unsigned long long vseq = 0;   // pinned early-stop verdict word of the su launches (sharded handles with a communicator)
     // trace path
     int K; double *d_tr_s, *d_tr_u, *d_tr_ref, *d_tr_speed, *d_tr_out_u, *d_tr_out_s; rda_info *d_tr_info;
     // obstacle-shard exchange (RCCL, resolved lazily with dlopen so that single-GPU use has no rccl dependency)
@@ -1046,11 +1200,11 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
-    rc |= dalloc(&d.wl, (N + 16) * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
+    rc |= dalloc(&d.wl, (N + GS) * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
-    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.J = (int)((N + 15) / 16); d.chunk = chunk_doubles((int)T, (int)N);
-    rc |= dalloc(&d.coef, d.chunk);
+    d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.J = (int)((N + GS - 1) / GS); d.chunk = chunk_doubles((int)T, (int)N); d.lchunk = lchunk_doubles((int)T, (int)N);
+    rc |= dalloc(&d.coef, d.chunk); rc |= dalloc(&d.coefL, d.lchunk);
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T); rc |= dalloc(&d.pose, 4 * T);
     rc |= dalloc(&d.ctrl, 1);
     rc |= dalloc(&d.su_lam_keep, 10 * T);
@@ -1084,7 +1238,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->fuse_track = o.fuse_track; H->tick_stages = 0; H->tick_has_event = 0; H->trk_seq = 0;
     H->early_finish = o.early_finish;
     H->lmz_split = o.lmz_split;
-    H->ip_rows = 0; H->admm_it = 0;
+    H->ip_rows = o.lmz_ip_rows && rip::fits(cfg->E, cfg->R, cfg->E >= 3, cfg->robot_norm2, cfg->accelerated); H->admm_it = 0;
     // the terms of a fresh handle are all zero: their block partials (zero sums, every slot NEAR: a = 0 puts the hinge at -d < 0)
     int rcf = terms_rebuild(H);
     if (rcf != RDA_OK) return rcf;
@@ -1099,7 +1253,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->stream) (void)hipStreamSynchronize(H->stream);
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
-    void *ptrs[] = { d.wl, d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef,
+    void *ptrs[] = { d.wl, d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef, d.coefL,
                      d.s, d.u, d.pose, d.su_prof, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
@@ -1110,7 +1264,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->h_step) (void)hipHostFree(H->h_step);
     if (H->h_out) (void)hipHostFree(H->h_out);
     if (H->h_sc) (void)hipHostFree(H->h_sc);
-    if (H->h_stop) (void)hipHostFree(H->h_stop);
+    if (H->h_verdict) (void)hipHostFree(H->h_verdict);
     for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
     if (H->stream2) { (void)hipStreamSynchronize(H->stream2); (void)hipStreamDestroy(H->stream2); }
     if (H->ev_tick) (void)hipEventDestroy(H->ev_tick);
@@ -1130,7 +1284,7 @@ extern "C" int rda_set_adjust(rda_handle *H, double slack_gain, double max_sd, d
 static int terms_rebuild(rda_handle *H)
 {
     const Dev &d = H->d;
-    const int nb = (d.c.T * d.J + 15) / 16;
+    const int nb = (d.c.T * d.J + FPB - 1) / FPB;
     hipLaunchKernelGGL(k_lmz_finalize_all, dim3(nb, d.P), dim3(256), 0, H->stream, d);
     HIPCHK(hipGetLastError());
     return RDA_OK;
@@ -1331,14 +1485,17 @@ static hipEvent_t next_event(rda_handle *H, int which)
 // shapes, the no-obstacle case of quirk Q9) and the per-thread interior-point kernel likewise end with k_lmz_finalize.
 static void launch_finalize(rda_handle *H, const Dev &d, int it, const Fin &fin)
 {
-    hipLaunchKernelGGL(k_lmz_finalize, dim3((d.c.T * d.J + 15) / 16), dim3(256), 0, H->stream, d, it, fin);
+    hipLaunchKernelGGL(k_lmz_finalize, dim3((d.c.T * d.J + FPB - 1) / FPB), dim3(256), 0, H->stream, d, it, fin);
 }
 // (the row-parallel interior-point kernel: see k_lammuz_ip below)
-static void launch_lammuz_ip(rda_handle *H, const Dev &d, int it, const Fin &fin) { (void)H; (void)d; (void)it; (void)fin; }
+static void launch_lammuz_ip(rda_handle *H, const Dev &d, int it, const Fin &fin)
+{
+    hipLaunchKernelGGL(k_lammuz_ip, dim3(packed_grid(d.c.T, d.J)), dim3(64 * GS / 4), 0, H->stream, d, it, fin);
+}
 static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
 {
     if (d.Nlive == 0) return;                    // a shard without obstacles (N < P)
-    const int units = d.c.T * 16 * d.J;          // rows of the grid (a stage is padded to whole 16-slot blocks)
+    const int units = d.c.T * GS * d.J;          // rows of the grid (a stage is padded to whole GS-slot blocks)
     if (d.lmz_mode && !(H->ip_rows && d.obstacle_num)) {
         const int nth = d.Nlive * d.c.T, nb = d.obstacle_num ? (nth + 63) / 64 : (d.c.T + 63) / 64;
         if (d.c.E <= 4 && d.c.R <= 4) hipLaunchKernelGGL(k_lammuz_cp_small, dim3(nb), dim3(64), 0, H->stream, d);
@@ -1348,15 +1505,16 @@ static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
     }
     if (d.lmz_mode) { launch_lammuz_ip(H, d, it, fin); return; }
     if (d.rows && d.obstacle_num) {
-        const int nb = units / 16;
-        if (nb > H->dense_from && H->lmz_split) {
+        constexpr int NTH = 64 * GS / 4;             // threads of a packed workgroup (2 waves)
+        const int nb = packed_grid(d.c.T, d.J), cus = (units / GS * NTH + 255) / 256;      // launch indices (XCD-aware order, a few fillers); CUs the grid asks for at one wave per SIMD
+        if (cus > H->dense_from && H->lmz_split) {
             // dense grid: common path with three waves per SIMD, then the deferred rows one per wave (see lammuz_body_rows)
-            hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(256), 0, H->stream, d);
-            int ne = units / 64; if (ne < 32) ne = 32; if (ne > 1024) ne = 1024;
-            hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(256), 0, H->stream, d);
+            hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(NTH), 0, H->stream, d);
+            int ne = units / 32; if (ne < 64) ne = 64; if (ne > 2048) ne = 2048;
+            hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(NTH), 0, H->stream, d);
             launch_finalize(H, d, it, fin);
-        } else if (nb > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(256), 0, H->stream, d, it, fin);
-        else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(256), 0, H->stream, d, it, fin);
+        } else if (cus > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
+        else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
     } else {
         hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
         launch_finalize(H, d, it, fin);
@@ -1408,13 +1566,11 @@ static int fetch_result(rda_handle *H)
         for (unsigned spin = 0;; ++spin) {
             if (*flag == H->res_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return RDA_OK; }
             cpu_relax();
-            if ((spin & 1023) == 1023) {
-                // a device fault never publishes the word: ask the stream now and then (hipErrorNotReady = still running, fine)
-                const hipError_t q = hipStreamQuery(H->stream);
-                if (q != hipSuccess && q != hipErrorNotReady) { fprintf(stderr, "librda_hip: stream fault while waiting for a result: %s\n", hipGetErrorString(q)); return RDA_ERR_HIP; }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-            }
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
+        // 20 ms without the word (a healthy step takes a fraction of a millisecond): synchronise the ordinary way.  A device fault -
+        // in this step, or in the launches that were still queued behind the hand-over of the PREVIOUS step (the zero-copy hand-over
+        // returns before they have drained) - never publishes the word and surfaces here as the stream's error.
         HIPCHK(hipStreamSynchronize(H->stream));
         if (*flag == H->res_seq) return RDA_OK;
         return RDA_ERR_HIP;
@@ -1426,8 +1582,6 @@ static int fetch_result(rda_handle *H)
 }
 static int enqueue_admm_head(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed)
 {
-    // the zero-copy hand-over returns before the launches queued behind it have drained: a fault in that tail surfaces here
-    { const hipError_t q = hipStreamQuery(H->stream); if (q != hipSuccess && q != hipErrorNotReady) { fprintf(stderr, "librda_hip: device fault in the previous step: %s\n", hipGetErrorString(q)); return RDA_ERR_HIP; } }
     Dev d = H->d;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     launch_su(H, d, 0, in_s, in_u);                    // resets the step's control block itself (su_body, it == 0)
@@ -1441,15 +1595,28 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     const Fin fin = make_fin(H, out_u, out_s, info);  // the su launch that detects the early stop hands the result over itself
     for (int it = 0; it < d.c.iter_num; ++it) {
-        if (it > 0) launch_su(H, d, it, in_s, in_u, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
+        if (it > 0) {
+            Fin f = H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0, 0};
+            if (H->comm) { f.verdict = H->h_verdict; f.vseq = ++H->vseq; }
+            launch_su(H, d, it, in_s, in_u, f);
+        }
         if (it > 0 && H->comm) {
-            // The early stop (rda_solver.py:594) is a device flag and kernels queued behind it return at once - a collective
-            // cannot: with a communicator the host reads the flag after the su-problem (one small D2H + sync per iteration,
-            // every rank reads the same value: the su-problems are bitwise identical) and stops queueing, so no all-gather is
-            // issued for an iteration that does not run.
-            HIPCHK(hipMemcpyAsync(H->h_stop, &d.ctrl->stop, sizeof(int), hipMemcpyDeviceToHost, H->stream));
-            HIPCHK(hipStreamSynchronize(H->stream));
-            if (*H->h_stop) break;
+            // The early stop (rda_solver.py:594) is a device flag and kernels queued behind it return at once - a collective cannot, so
+            // with a communicator no all-gather may be queued for an iteration that does not run.  The su launch publishes its verdict
+            // in pinned host memory as soon as it has reduced the residuals (before its solve; every rank takes the same verdict: the
+            // su-problems are bitwise identical); the host polls that word - no copy, no stream synchronisation - and goes on queueing
+            // (or stops) while the su-problem is being solved.
+            volatile unsigned long long *vw = H->h_verdict;
+            const auto t0 = std::chrono::steady_clock::now();
+            bool seen = false;
+            for (unsigned spin = 0; !seen; ++spin) {
+                if ((*vw >> 1) == H->vseq) { seen = true; break; }
+                cpu_relax();
+                if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+            }
+            if (!seen) { HIPCHK(hipStreamSynchronize(H->stream)); if ((*vw >> 1) != H->vseq) return RDA_ERR_HIP; }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (*vw & 1ull) break;
         }
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         launch_lammuz(H, d, it, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
@@ -1864,12 +2031,12 @@ extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
     if (H->d.c.N % world != 0 && !H->d.c.accelerated) return RDA_ERR_UNSUPPORTED;    // padded shards rely on the hinge of the accelerated cost
     HIPCHK(hipStreamSynchronize(H->stream));
     Dev &d = H->d;
-    dev_free(d.coef); d.coef = nullptr;
-    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.J = (d.Nloc + 15) / 16; d.chunk = chunk_doubles(d.c.T, d.Nloc);
+    dev_free(d.coef); d.coef = nullptr; dev_free(d.coefL); d.coefL = nullptr;
+    d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.J = (d.Nloc + GS - 1) / GS; d.chunk = chunk_doubles(d.c.T, d.Nloc);
+    d.lchunk = lchunk_doubles(d.c.T, d.Nloc);
     const int first = rank * d.Nloc;
     d.Nlive = first >= d.c.N ? 0 : (d.c.N - first < d.Nloc ? d.c.N - first : d.Nloc);
-    if (dalloc(&d.coef, d.chunk * world)) return RDA_ERR_HIP;
-    HIPCHK(hipMemsetAsync(d.coef, 0, d.chunk * world * sizeof(double), H->stream));
+    if (dalloc(&d.coef, d.chunk * world) || dalloc(&d.coefL, d.lchunk * world)) return RDA_ERR_HIP;      // (dalloc zeroes)
     if (d.Nloc * world != d.c.N) hipLaunchKernelGGL(k_dead_slots, dim3(64), dim3(256), 0, H->stream, d);
     int rc = terms_rebuild(H);                          // (the duals of a handle that is re-sharded are NOT re-condensed: shard before the first step)
     if (rc != RDA_OK) return rc;
@@ -1920,7 +2087,7 @@ extern "C" int rda_shard_comm_init(rda_handle *H, const void *uid128)
     if (!f || !H->p_allgather) return RDA_ERR_UNSUPPORTED;
     int rc = f(&H->comm, H->d.P, uid, H->d.rank);
     if (rc != 0) { fprintf(stderr, "librda_hip: ncclCommInitRank failed (%d)\n", rc); H->comm = nullptr; return RDA_ERR_HIP; }
-    if (!H->h_stop) HIPCHK(hipHostMalloc((void **)&H->h_stop, sizeof(int)));
+    if (!H->h_verdict) { HIPCHK(hipHostMalloc((void **)&H->h_verdict, sizeof(unsigned long long))); *H->h_verdict = 0; }
     return RDA_OK;
 }
 
@@ -2003,12 +2170,12 @@ __device__ __forceinline__ Fin fleet_fin(const Dev &d, const EgoIO &e, int k)
     return Fin{ e.out_u + k * nu, e.out_s + k * ns, e.info + k, nullptr, 0, 0 };
 }
 __global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs) { lammuz_body(devs[blockIdx.y], blockIdx.x); }
-__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_rows(const Dev *devs, const EgoIO *io, int it, int k)
+__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_rows(const Dev *devs, const EgoIO *io, int it, int k)
 {
     lammuz_body_rows<0>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
 }
-__global__ __launch_bounds__(256, 3) void k_lammuz_fleet_rows_fast(const Dev *devs) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
-__global__ __launch_bounds__(256, 2) void k_lammuz_fleet_enum(const Dev *devs) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_fleet_rows_fast(const Dev *devs) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_enum(const Dev *devs) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 __global__ __launch_bounds__(256) void k_lmz_finalize_fleet(const Dev *devs, const EgoIO *io, int it, int k)
 {
     finalize_body(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
@@ -2069,7 +2236,7 @@ extern "C" int rda_fleet_create(rda_handle *const *egos, int B, rda_fleet **out)
     F->d_devs = nullptr; F->d_io_step = F->d_io_trace = nullptr; F->d_in = F->d_out = nullptr; F->d_info = nullptr;
     F->h_devs = nullptr; F->h_io = nullptr; F->h_in = F->h_out = nullptr; F->h_info = nullptr;
     const rda_cfg &c = egos[0]->d.c;
-    F->T = c.T; F->iter_num = c.iter_num; F->J = (c.N + 15) / 16; F->su_lds = egos[0]->su_lds;
+    F->T = c.T; F->iter_num = c.iter_num; F->J = (c.N + GS - 1) / GS; F->su_lds = egos[0]->su_lds;
     HIPCHK(hipStreamCreate(&F->stream));
     HIPCHK(hipEventCreateWithFlags(&F->ev, hipEventDisableTiming));
     const size_t T = c.T, ns = 3 * (T + 1), nu = 2 * T, nin = 2 * ns + nu + 1, nout = nu + ns;
@@ -2122,15 +2289,16 @@ static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
     const int B = F->B;
     for (int it = 0; it < F->iter_num; ++it) {          // iteration 0 resets every member's control block (su_body)
         RDA_SU_DISPATCH(F->T, hipLaunchKernelGGL(k_su_fleet<TT>, dim3(B), dim3(su::NT), F->su_lds, F->stream, F->d_devs, io, it, k));
-        const int nbr = F->T * F->J, nfin = (nbr + 15) / 16;       // packed grid: one workgroup per (stage, 16-slot block)
+        constexpr int NTH = 64 * GS / 4;
+        const int nbr = F->T * F->J, nfin = (nbr + FPB - 1) / FPB, nbp = packed_grid(F->T, F->J);       // one workgroup per (stage, GS-slot block), XCD-aware order
         if (F->rows && F->lmz_split) {
-            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3(nbr, B), dim3(256), 0, F->stream, F->d_devs);
-            int ne = nbr / 4; if (ne < 4) ne = 4; if (ne > 64) ne = 64;
-            hipLaunchKernelGGL(k_lammuz_fleet_enum, dim3(ne, B), dim3(256), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3(nbp, B), dim3(NTH), 0, F->stream, F->d_devs);
+            int ne = nbr / 8; if (ne < 8) ne = 8; if (ne > 128) ne = 128;
+            hipLaunchKernelGGL(k_lammuz_fleet_enum, dim3(ne, B), dim3(NTH), 0, F->stream, F->d_devs);
             hipLaunchKernelGGL(k_lmz_finalize_fleet, dim3(nfin, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
-        } else if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3(nbr, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
+        } else if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3(nbp, B), dim3(NTH), 0, F->stream, F->d_devs, io, it, k);
         else {
-            hipLaunchKernelGGL(k_lammuz_fleet, dim3(nbr * 4, B), dim3(256), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lammuz_fleet, dim3(nbr * GS / 4, B), dim3(256), 0, F->stream, F->d_devs);
             hipLaunchKernelGGL(k_lmz_finalize_fleet, dim3(nfin, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
         }
     }

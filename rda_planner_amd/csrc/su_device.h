@@ -53,10 +53,11 @@ struct Cfg {
 // in (cos, sin) of the nominal heading:  Q2 = sum |a|^2,  Q1 = 2 (cos sum g x a - sin sum g.a) - so the N-dependent part never sees
 // the pose), and the screening verdict of its hinge (`near`: it may become active while the stage position stays within SCREEN_DELTA of
 // the reference position (px, py)).  ONE definition: k_lammuz evaluates it per row right after the dual update (block partial sums
-// of 16 slots + a 16-bit near mask), k_lmz_finalize re-evaluates it from the stored terms, and the su set-up evaluates it itself when
+// of GS slots + a GS-bit near mask), k_lmz_finalize re-evaluates it from the stored terms, and the su set-up evaluates it itself when
 // it is handed raw terms only (rda_su_solve hook) - all three must round alike.
 constexpr double SCREEN_DELTA = 2.0;
-constexpr int NBS = 5;           // doubles per 16-slot block partial: sum |a|^2, sum g.a, sum g x a, dual residual, |Hm|^2
+constexpr int GS = 8;            // slots per block partial (one LamMuZ workgroup: 2 waves x 4 rows)
+constexpr int NBS = 5;           // doubles per block partial: sum |a|^2, sum g.a, sum g x a, dual residual, |Hm|^2
 struct RowTerm { double aa, ga, gxa; bool near; };
 __device__ __forceinline__ RowTerm row_term(double ax, double ay, double gx, double gy, double cb, double px, double py, double max_sd, bool pose_ok)
 {
@@ -73,8 +74,8 @@ struct Args {
     const double *ref;               // 3x(T+1)
     const double *ref_speed;         // scalar on device
     const double *ax, *ay, *cb, *gx, *gy;   // condensed obstacle terms of obstacle shard 0, each [T][Nloc]: a = A'lam, cb = b'lam + mu'h + z - zeta, g = G'mu + xi
-    // reduced form of the terms, written by k_lammuz / k_lmz_finalize: per (stage, 16-slot block) NBS sums and a near mask (bit r = slot
-    // 16 j + r may become active within SCREEN_DELTA of the pose table's position).  null: the set-up evaluates row_term itself.
+    // reduced form of the terms, written by k_lammuz / k_lmz_finalize: per (stage, GS-slot block) NBS sums and a near mask (bit r = slot
+    // GS j + r may become active within SCREEN_DELTA of the pose table's position).  null: the set-up evaluates row_term itself.
     const double *bsum = nullptr; const unsigned long long *bmask = nullptr; int J = 0;
     const double *pose = nullptr;    // [T][4] px, py (column t+1), cos, sin (heading of column t) of the trajectory the masks refer to
     int pose_ok = 0;                 // the pose table is valid (a LamMuZ launch has run since the terms last changed)
@@ -375,7 +376,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // ---- rotation-consistency penalty -> scalar quadratic per stage from three POSE-INDEPENDENT sums over the terms (see
     // row_term), and the HINGE SCREENING: Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so a term whose margin at the
     // reference position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Both arrive in
-    // reduced form - per (stage, 16-slot block) partial sums and a 16-bit near mask, made by the LamMuZ launch that produced the terms
+    // reduced form - per (stage, GS-slot block) partial sums and a GS-bit near mask, made by the LamMuZ launch that produced the terms
     // (p0 = the trajectory it worked with: the pose table) - so this set-up has NO pass over the N terms; handed raw terms only
     // (rda_su_solve) it evaluates them here in the same grouping, so both forms round alike.  Each thread keeps the near masks of the
     // blocks of ITS (stage, chunk) slice in registers and only those terms are visited by the per-iteration hinge sums (same visiting
@@ -385,9 +386,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     constexpr int MW = 4;
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
-    const int J = masks_in ? a.J : (a.Nloc + 15) / 16;         // 16-slot blocks per shard
+    const int J = masks_in ? a.J : (a.Nloc + GS - 1) / GS;     // GS-slot blocks per shard
     const int KB = (J + nch - 1) / nch;                         // blocks per shard in one thread's slice: j = rc_ + kb nch
-    bool screened = c.accelerated && a.P * KB * 16 <= 64 * MW && (!masks_in || a.pose_ok);
+    bool screened = c.accelerated && a.P * KB * GS <= 64 * MW && (!masks_in || a.pose_ok);
     {
         double saa = 0, sga = 0, sgx = 0;
         if (ract) {
@@ -396,24 +397,24 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 for (int kb = 0; kb < KB; ++kb) {
                     const int j = rc_ + kb * nch;
                     if (j >= J) break;
-                    unsigned long long m16 = 0;
+                    unsigned long long m8 = 0;
                     if (masks_in) {
                         const double *p = a.bsum + r * a.chunk + ((size_t)rt * J + j) * NBS;
                         saa += p[0]; sga += p[1]; sgx += p[2];
-                        m16 = a.bmask[r * a.chunk + (size_t)rt * J + j] & 0xffffull;
+                        m8 = a.bmask[r * a.chunk + (size_t)rt * J + j] & ((1ull << GS) - 1);
                     } else {
-                        const size_t o = r * a.chunk + (size_t)rt * a.Nloc + 16 * j;
+                        const size_t o = r * a.chunk + (size_t)rt * a.Nloc + GS * j;
                         double b0 = 0, b1 = 0, b2 = 0;
-                        for (int row = 0; row < 16 && 16 * j + row < a.Nloc; ++row) {
+                        for (int row = 0; row < GS && GS * j + row < a.Nloc; ++row) {
                             const RowTerm q = row_term(a.ax[o + row], a.ay[o + row], a.gx[o + row], a.gy[o + row], a.cb[o + row], p0x, p0y, c.max_sd, true);
                             b0 += q.aa; b1 += q.ga; b2 += q.gxa;
-                            m16 |= q.near ? 1ull << row : 0ull;
+                            m8 |= q.near ? 1ull << row : 0ull;
                         }
                         saa += b0; sga += b1; sgx += b2;
                     }
                     // the bit position only depends on the loop counters, i.e. it is the same in every thread (scalar word index and shift)
-                    const int bp = (r * KB + kb) * 16;
-                    const unsigned long long mm = screened ? m16 << (bp & 63) : 0ull;
+                    const int bp = (r * KB + kb) * GS;
+                    const unsigned long long mm = screened ? m8 << (bp & 63) : 0ull;
                     switch (bp >> 6) { case 0: amask[0] |= mm; break; case 1: amask[1] |= mm; break; case 2: amask[2] |= mm; break; default: amask[3] |= mm; break; }
                 }
             }
@@ -663,9 +664,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                             size_t off[4]; int cnt = 0;
                             while (m && cnt < 4) {
                                 const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
-                                const int blk = bit >> 4, row = bit & 15;
+                                const int blk = bit / GS, row = bit % GS;
                                 const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
-                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + 16 * (rc_ + kb * nch) + row;
+                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
                             }
                             double x[4], y[4], cb[4];
 #pragma unroll
@@ -679,9 +680,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                     for (int kb = 0; kb < KB; ++kb) {
                         const int j = rc_ + kb * nch;
                         if (j >= J) break;
-                        const size_t o = r * a.chunk + (size_t)rt * Nl + 16 * j;
+                        const size_t o = r * a.chunk + (size_t)rt * Nl + GS * j;
                         const double *pax = a.ax + o, *pay = a.ay + o, *pcb = a.cb + o;
-                        const int nr = Nl - 16 * j < 16 ? Nl - 16 * j : 16;
+                        const int nr = Nl - GS * j < GS ? Nl - GS * j : GS;
                         int n = 0;
                         for (; n + 8 <= nr; n += 8) {                  // eight independent loads in flight per array
                             double x[8], y[8], cb[8];
