@@ -114,6 +114,11 @@ def main():
     ap.add_argument("--moving", action="store_true", help="moving obstacles: per-stage (A, b) over the horizon (dynamic_obs config)")
     ap.add_argument("--egos", type=int, default=16, help="extra leg: this many independent egos concurrently on one GPU (0/1 = skip)")
     ap.add_argument("--fleet-egos", type=int, default=64, help="extra leg: this many egos stepped as one fleet (batched launches; 0/1 = skip)")
+    ap.add_argument("--no-ip-legs", action="store_true", help="skip the interior-point LamMuZ closed loops (extra keys)")
+    ap.add_argument("--no-shard-leg", action="store_true", help="N > 1, replica mode: skip the extra obstacle-shard leg (one ego, N_obs = --shard-n-obs)")
+    ap.add_argument("--force-shard-leg", action="store_true", help="run the obstacle-shard leg on ONE GPU with a one-rank communicator (plumbing check)")
+    ap.add_argument("--shard-n-obs", type=int, default=2000)
+    ap.add_argument("--shard-leg-timeout", type=float, default=240.0)
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="N>1: independent ego replicas (default, no collective) or ONE ego whose obstacles are sharded over the ranks "
                          "with an RCCL all-gather per ADMM iteration (strong scaling, --n-obs = total obstacles)")
@@ -252,19 +257,20 @@ def main():
         import closed_loop_host as clh
         return clh.Host(api.lib)
 
-    def new_solver():
-        sv = RDA_solver(T, car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+    def new_solver(car=None, **extra):
+        sv = RDA_solver(T, car or car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"], **extra)
         make_sharded(sv)
         return sv
 
     # ---- HEADLINE: closed loop through the C-ABI, one host synchronisation per MPC step -------------------------------
-    def cabi_closed_loop(per_tick_scene, driver="c"):
+    def cabi_closed_loop(per_tick_scene, driver="c", car=None, compare=True, **solver_kw):
         """state in / control out per step; scene resident in HBM (per_tick_scene False) or handed over from host memory on every
         tick (True, BASELINE.md 2.4 'including H2D of obstacles').  driver "c": the loop is tools/closed_loop_host.c (C-ABI calls and the
         kinematic model in C, nothing of the interpreter between two steps); "python": the same loop written with ctypes / numpy.
         Returns (elapsed of the K timed steps, per-step times, max |u - recorded Python closed loop|, iterations per step)."""
-        sv = new_solver()
+        sv = new_solver(car, **solver_kw)
         hh = sv._be.handle
+        car_l = car or car_t
         scene = sv.flatten_scene(list(obstacles))
         n_sc, kind, nvert, geom, vel = scene
         kind, nvert = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(nvert, np.int32)
@@ -280,7 +286,7 @@ def main():
         if not per_tick_scene:
             assert api.upload_scene(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(state), order, None) == 0
         cur, du, its, times = 0, 0.0, [], []
-        L, wb = car_t.wheelbase, car_t.dynamics
+        L, wb = car_l.wheelbase, car_l.dynamics
         t_start = 0.0
         if driver == "c":
             host = closed_loop_host()
@@ -302,7 +308,7 @@ def main():
             api.lib.rda_sync(hh)
             barrier_all()
             el = max_over_ranks(time.perf_counter() - t_start)
-            if not args.moving:
+            if not args.moving and compare:
                 du = float(np.abs(u_log - np.array([trace["u"][k].ravel() for k in range(W + K)])).max())
             return el, t_log[W:].copy(), du, [int(v) for v in it_log[W:]]
         for k in range(W + K):
@@ -359,6 +365,23 @@ def main():
                 pcie = {"steps_per_s": round(K / el_p, 2), "median_ms_per_step": round(float(np.median(times_p) * 1e3), 5),
                         "max_du_vs_python_closed_loop": du_p,
                         "what": "raw scene (vertices, velocities) handed over from host memory every tick: rda_tracked_begin + rda_upload_scene_async + rda_tracked_finish"}
+
+    # ---- interior-point LamMuZ mode (row-parallel kernel k_lammuz_ip): the robust setting lmz_central = 1e-3 on the headline scene, and a
+    #      CIRCLE robot (norm2 robot cone, rda_solver.py:1034-1039: always this mode).  Same closed-loop protocol as the headline.
+    ip_legs = None
+    if rank == 0 and world == 1 and not args.moving and not args.no_ip_legs:
+        ip_legs = {}
+        try:
+            el_i, times_i, _, its_i = cabi_closed_loop(per_tick_scene=False, compare=False, lmz_central=1e-3)
+            ip_legs["rectangle_robot_lmz_central_1e-3"] = {"steps_per_s": round(K / el_i, 2), "median_ms_per_step": round(float(np.median(times_i) * 1e3), 5),
+                                                           "mean_admm_iters": round(float(np.mean(its_i)), 3)}
+            from rda_planner_amd import scenarios as sc_
+            circ = sc_.circle_robot(radius=0.8, dynamics="diff")
+            el_c, times_c, _, its_c = cabi_closed_loop(per_tick_scene=False, compare=False, car=circ)
+            ip_legs["circle_robot_norm2_cone"] = {"steps_per_s": round(K / el_c, 2), "median_ms_per_step": round(float(np.median(times_c) * 1e3), 5),
+                                                  "mean_admm_iters": round(float(np.mean(its_c)), 3)}
+        except (AssertionError, RuntimeError) as e:          # (a robot that reaches the goal inside the timed region, ...)
+            ip_legs["error"] = str(e)
 
     # ---- device-resident replay: the recorded step inputs back-to-back, no per-step synchronisation ---------------------
     solver = new_solver()
@@ -499,7 +522,83 @@ def main():
         api.fleet_destroy(F)
         del members
 
+    def shard_leg():
+        """N > 1, default (replica) mode: the OTHER way to use the node - ONE ego whose obstacles are sharded over the ranks, the
+        north-star scaling point (T=20, N_obs=2000): every rank solves the LamMuZ problems of its slots, one in-library ncclAllGather
+        per ADMM iteration replicates what the su-problem reads (3 arrays + the reduced sums / masks: DESIGN.md 6), every rank solves
+        the identical su-problem.  Device-resident replay of a recorded closed loop, barrier + max over ranks like the headline.
+        All ranks call this at the same point; a watchdog bounds it (a collective that never completes must not cost the line)."""
+        import torch
+        from rda_planner_amd.sharded import enable_rccl
+        Ns, Ts = args.shard_n_obs, 20
+        Ks, Ws = min(K, 40), min(W, 4)
+        car_s, path_s, obs_s, kw_s = build_workload(seed_offset=0, n_obs=Ns, T=Ts, n_steps=Ks + Ws)
+        tr, stg, _ = record_trace(car_s, path_s, obs_s, dict(kw_s, obstacle_order=False), Ws + Ks)
+
+        def replay(sv):
+            hh = sv._be.handle
+            assert api.lib.rda_upload_obstacles(hh, stg["n"], dptr(stg["A"]), dptr(stg["b"]), iptr(stg["cone"]), stg["per_t"]) == 0
+            assert api.lib.rda_upload_trace(hh, Ws + Ks, dptr(tr["nom_s"]), dptr(tr["nom_u"]), dptr(tr["ref"]), dptr(tr["speed"])) == 0
+            for k in range(Ws):
+                api.lib.rda_enqueue_step(hh, k)
+            api.lib.rda_sync(hh); barrier_all()
+            api.lib.rda_timing_reset(hh, 1)
+            t0 = time.perf_counter()
+            for k in range(Ws, Ws + Ks):
+                assert api.lib.rda_enqueue_step(hh, k) == 0
+            api.lib.rda_sync(hh); barrier_all()
+            el = max_over_ranks(time.perf_counter() - t0)
+            per = {}
+            for which, name in ((0, "lammuz"), (1, "su"), (2, "gather")):
+                buf, n = np.zeros(Ks * kw_s["iter_num"] + 8), C.c_int(0)
+                api.lib.rda_timing_launches(hh, which, dptr(buf), buf.size, C.cast(C.byref(n), C.POINTER(C.c_int)))
+                v = buf[:min(n.value, buf.size)]
+                per[name] = v
+            api.lib.rda_timing_reset(hh, 0)
+            u_last, s_last, inf = np.zeros((2, Ts)), np.zeros((3, Ts + 1)), Info()
+            api.lib.rda_fetch_result(hh, Ws + Ks - 1, dptr(u_last), dptr(s_last), C.byref(inf))
+            its = []
+            for k in range(Ws, Ws + Ks):
+                api.lib.rda_fetch_result(hh, k, None, None, C.byref(inf)); its.append(inf.iters)
+            return el, per, float(np.abs(u_last - tr["u_solver"][Ws + Ks - 1]).max()), float(np.mean(its))
+        mk = lambda: RDA_solver(Ts, car_s, kw_s["max_edge_num"], Ns, iter_num=kw_s["iter_num"], step_time=0.1, time_print=False, ro1=kw_s["ro1"])
+        el1, per1, err1, _ = replay(mk())                    # every rank alone (unsharded): the one-GPU number of the same workload
+        sv = mk()
+
+        def bcast(buf):
+            if dist is None:                                 # (--force-shard-leg on one GPU: a one-rank communicator, plumbing only)
+                return bytes(buf)
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone().cuda()
+            dist.broadcast(t, 0)
+            return bytes(t.cpu().numpy().tobytes())
+        enable_rccl(sv, rank, world, bcast)
+        elP, perP, errP, itsP = replay(sv)
+        n_exec = int(round(itsP * Ks))
+        ex = lambda v: np.sort(v)[max(v.size - n_exec, 0):] if v.size else v        # the executed launches are the longest ones
+        return {"workload": f"T={Ts}, N_obs={Ns} static seeded polygons, obstacles sharded {world}-way ({-(-Ns // world)} slots per rank)",
+                "steps_per_s": round(Ks / elP, 2), "ms_per_step": round(elP / Ks * 1e3, 4), "mean_admm_iters": round(itsP, 3),
+                "unsharded_one_gpu_steps_per_s": round(Ks / el1, 2), "speedup_vs_one_gpu": round(el1 / elP, 3),
+                "gather_us_per_iteration": round(float(perP["gather"].mean()) * 1e3, 2) if perP["gather"].size else None,
+                "gathers": int(perP["gather"].size), "nccl_comm_count": int(api.lib.rda_shard_comm_count(sv._be.handle)),
+                "chunk_bytes_per_rank": int(api.shard_chunk_doubles(sv._be.handle)) * 8,
+                "lammuz_us_per_executed_launch": {"one_gpu": round(float(ex(per1["lammuz"]).mean()) * 1e3, 2), "sharded": round(float(ex(perP["lammuz"]).mean()) * 1e3, 2)},
+                "su_us_per_executed_launch": {"one_gpu": round(float(ex(per1["su"]).mean()) * 1e3, 2), "sharded": round(float(ex(perP["su"]).mean()) * 1e3, 2)},
+                "max_du_vs_recorded_closed_loop": {"one_gpu": err1, "sharded": errP}, "steps": Ks, "warmup": Ws,
+                "what": "device-resident replay, barrier + max over ranks; every rank enqueues the same steps, one ncclAllGather per executed ADMM iteration"}
+
+    want_shard_leg = (world > 1 and not shard and not oversub and not args.no_shard_leg) or (world == 1 and args.force_shard_leg)
     if rank != 0:
+        if want_shard_leg:
+            import threading
+            wd = threading.Timer(args.shard_leg_timeout, lambda: os._exit(0))
+            wd.daemon = True; wd.start()
+            try:
+                shard_leg()
+            except Exception:
+                pass
+            wd.cancel()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -522,24 +621,20 @@ def main():
                 "launches": int(ex.size), "total_ms": round(float(ex.sum()), 3), "algorithmic_bytes_per_launch": bytes_per_launch,
                 "skipped_launches": int(noop.size), "skipped_avg_us": round(float(noop.mean()) * 1e3, 2) if noop.size else None,
                 "avg_us_over_all_launches": round(float(ms.mean()) * 1e3, 2) if ms.size else None}
-    # the LamMuZ kernel that was actually launched (rda_hip.hip launch_lammuz): packed rows when E+R+1 <= 16, the two-workgroup
-    # build above 256 workgroups; RDA_LMZ_ROWS=0 selects the one-sub-problem-per-wave kernel
-    lm_kernel = "k_lammuz"
+    # the LamMuZ launch form that was actually used: asked of the library (rda_lammuz_kernel; a dense grid is three launches, timed together)
     n_loc = -(-N // world) if shard else N
-    if os.environ.get("RDA_LMZ_MODE", "0") not in ("", "0"):
-        lm_kernel = "k_lammuz_cp_small" if E <= 4 and R <= 4 else "k_lammuz_cp_large"      # interior-point LamMuZ kernel (experiments)
-    elif E + R + 1 <= 16 and os.environ.get("RDA_LMZ_ROWS", "1") != "0":
-        lm_kernel = "k_lammuz_rows_dense" if (n_loc * T + 15) // 16 > int(os.environ.get("RDA_LMZ_DENSE_FROM", "256")) else "k_lammuz_rows"
+    lm_kernel = api.lib.rda_lammuz_kernel(h).decode()
     r_lm = roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T)
-    # k_su reads the condensed terms once: six [T][N] arrays in the first solve of a step, three pre-evaluated ones (su::term_pre, written
-    # by k_lammuz) in the later ones - the mean over the executed launches of the timed replay (K first solves among n_exec)
-    later = 24 if os.environ.get("RDA_SU_PRE", "1") != "0" else 48
-    su_bytes = int(round((K * 48 + max(n_exec - K, 0) * later) * N * T / max(n_exec, 1))) + 8 * (8 * (T + 1) + 5 * T)
+    # k_su has NO pass over the N terms any more: its set-up reads the reduced form the LamMuZ launch leaves behind - per (stage, 8-slot
+    # block) three sums and a near mask (32 of the 48 bytes of a block record) - plus the nominal / reference / kept multipliers; per
+    # interior-point pass it visits the NEAR terms only (24 B each, data dependent: not counted, so the fraction is a lower bound)
+    J = -(-n_loc // 8)
+    su_bytes = 32 * T * J * (world if shard else 1) + 8 * (8 * (T + 1) + 5 * T + 10 * T + 4 * T)
     r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", kt["k_su"], su_bytes)
     # latency roof of the su kernel: ONE workgroup (4 waves) on one CU walks a dependent chain; what bounds it is the length of
     # that chain, not bytes - stated next to the HBM fraction so the fraction is not read as a bandwidth problem
     r_su["cus_occupied"] = 1
-    r_lm["cus_occupied"] = min(256, {"k_lammuz": (n_loc * T + 3) // 4, "k_lammuz_cp_small": (n_loc * T + 63) // 64, "k_lammuz_cp_large": (n_loc * T + 63) // 64}.get(lm_kernel, (n_loc * T + 15) // 16))
+    r_lm["cus_occupied"] = min(256, (T * J * 128 + 255) // 256) if "rows" in lm_kernel or "k_lammuz_ip" in lm_kernel else min(256, (n_loc * T + 63) // 64)
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file):
         try:
@@ -583,6 +678,7 @@ def main():
                                    "device_obstacles": cl_dev, "device_obstacles_and_tracking": cl_trk},
         "multi_ego_one_gpu": multi,
         "multi_ego_fleet": fleet,
+        "lammuz_interior_point_closed_loops": ip_legs,
         "roofline": dominant, "roofline_secondary": secondary,
     }
 
@@ -618,6 +714,20 @@ def main():
                                "note": "a restatement of the ADMM in C, NOT the reference's CVXPY+ECOS+pathos path (not installable here): the "
                                        "north-star '>=100x the reference CPU path' cannot be measured against this number",
                                "max_du_vs_gpu": err}
+    if want_shard_leg:
+        import threading
+
+        def give_up():
+            out["obstacle_shard_leg"] = {"error": f"no result within {args.shard_leg_timeout:.0f} s (collective did not complete)"}
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(args.shard_leg_timeout, give_up)
+        wd.daemon = True; wd.start()
+        try:
+            out["obstacle_shard_leg"] = shard_leg()
+        except Exception as e:                               # the headline line must not depend on this leg
+            out["obstacle_shard_leg"] = {"error": repr(e)}
+        wd.cancel()
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

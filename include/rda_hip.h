@@ -85,8 +85,11 @@ typedef struct rda_opts {
     int32_t lmz_rows;        /* [1] four sub-problems per wave when E+R+1 <= 16                                        RDA_LMZ_ROWS */
     int32_t lmz_dense_from;  /* [256] workgroup count above which the dense (split) form of the LamMuZ launch is used  RDA_LMZ_DENSE_FROM */
     int32_t lmz_split;       /* [1] dense grids: common-path kernel + work-list kernel + finalize                      RDA_LMZ_SPLIT */
-    int32_t lmz_tail;        /* [1] the last-arriving LamMuZ workgroup reduces the residuals, takes the early-stop verdict and hands the
-                                result over (0: the next su launch / k_finish do)                                       RDA_LMZ_TAIL */
+    int32_t lmz_tail;        /* [0] 1: the last-arriving LamMuZ workgroup of the iteration a step is expected to end in reduces the residuals,
+                                takes the early-stop verdict and hands the result over, instead of the next su launch / k_finish.  Built
+                                for VERDICT r02 #6 and measured SLOWER (-2 .. -4 % closed loop at the north-star size: draining the
+                                write-through stores + ticket + acquire cost more than the kernel boundary they replace);
+                                same values either way                                                                   RDA_LMZ_TAIL */
     int32_t lmz_ip_rows;     /* [1] interior-point mode: the row-parallel kernel (16 lanes per sub-problem) when the shape allows
                                 (0: one sub-problem per thread)                                                         RDA_LMZ_IP_ROWS */
     int32_t su_pre;          /* [1] the su set-up reads the block sums / near masks the LamMuZ launch wrote (0: evaluates every term) RDA_SU_PRE */
@@ -160,7 +163,7 @@ int  rda_enqueue_step(rda_handle *h, int k);
 int  rda_enqueue_range(rda_handle *h, int k0, int k1);      /* steps k0 .. k1-1, one host call */
 int  rda_sync(rda_handle *h);
 int  rda_fetch_result(rda_handle *h, int k, double *out_u, double *out_s, rda_info *info);
-/* elapsed GPU time (ms, hipEvent) of the kernels named `which` (0 = LamMuZ, 1 = su) over the
+/* elapsed GPU time (ms, hipEvent) of the launches named `which` (0 = LamMuZ, 1 = su, 2 = the shard all-gather) over the
  * steps enqueued since the last rda_timing_reset, and the number of launches */
 int  rda_timing_reset(rda_handle *h, int enable);
 int  rda_timing_read(rda_handle *h, int which, double *total_ms, int *launches);
@@ -168,6 +171,8 @@ int  rda_timing_read(rda_handle *h, int which, double *total_ms, int *launches);
  * device flag, so launches queued behind it return at once; a caller that knows the executed ADMM iterations (rda_info.iters)
  * separates the two populations with this (bench.py: roofline per EXECUTED launch) */
 int  rda_timing_launches(rda_handle *h, int which, double *ms_out, int cap, int *launches);
+/* the form of the LamMuZ launch the library uses for this handle's shape and staged obstacles (kernel names joined by '+') */
+const char *rda_lammuz_kernel(rda_handle *h);
 
 /* ---- caller-side nominal roll-out + reference sampling on the device ------------------------------
  * What MPC.pre_process (mpc.py:251-291) with closest_point / inter_point / range_cir_seg / wraptopi and the three
@@ -248,7 +253,7 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime; lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
 int  rda_get_su_history(rda_handle *h, int32_t *hist /*2*/, double *lam_keep /*10*T*/);
-int  rda_set_su_history(rda_handle *h, const int32_t *hist /*2*/, const double *lam_keep /*10*T*/);
+int  rda_set_su_history(rda_handle *h, const int32_t *hist /*16*/, const double *lam_keep /*10*T*/);
 /* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
 
@@ -270,6 +275,7 @@ int  rda_shard_set_chunks(rda_handle *h, const double *host_all);  /* all `world
  * one in-place ncclAllGather per ADMM iteration on the handle's stream. */
 int  rda_shard_unique_id(rda_handle *h, void *out128);
 int  rda_shard_comm_init(rda_handle *h, const void *uid128);
+int  rda_shard_comm_count(rda_handle *h);                          /* ncclCommCount of the handle's communicator; 0 without one */
 /* Host-driven ADMM iteration for callers that do the exchange themselves (tests, gloo, MPI):
  *   rda_admm_begin; for it: rda_admm_su(it,&stopped); if stopped break; rda_admm_lammuz; <exchange chunks>; rda_admm_finish */
 int  rda_admm_begin(rda_handle *h, const double *nom_s, const double *nom_u, const double *ref_s, double ref_speed);

@@ -56,6 +56,10 @@ def hip_api():
         lib.rda_strerror.argtypes = [C.c_int]
         lib.rda_last_nonconvex.argtypes = [C.c_void_p]
         lib.rda_last_nonconvex.restype = C.c_int
+        lib.rda_lammuz_kernel.argtypes = [C.c_void_p]
+        lib.rda_lammuz_kernel.restype = C.c_char_p
+        lib.rda_shard_comm_count.argtypes = [C.c_void_p]
+        lib.rda_shard_comm_count.restype = C.c_int
         lib.rda_debug_su_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         lib.rda_debug_su_prof.restype = C.c_int
         lib.rda_shard_unique_id.argtypes = [C.c_void_p, C.c_void_p]

@@ -37,6 +37,7 @@
 struct Ctrl {
     int stop, iters, su_status, ipm_iters, st_tmp, it_tmp;
     int su_last;             // interior-point iterations of the last su-solve of this handle (99 = none / it did not converge): picks the next start
+                             // (a history per ADMM iteration index was measured: no gain on dynamic_obs, and it leaves the oracle's mirrored path)
     int lmz_fail;            // sub-problems of this step that kept their previous duals (non-finite input or result), rda_solver.py:791-793
     double resi_dual, resi_pri;
     int finished;                 // the result slot of this step has been written (by the launch that ended the step)
@@ -44,7 +45,9 @@ struct Ctrl {
     int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
     unsigned ticket;              // workgroups of the LamMuZ launch of this iteration that have published their partials (reset by k_su)
     int resi_iter;                // ADMM iterations of this step whose residuals are in resi_dual / resi_pri (LamMuZ tail, else k_su / k_finish)
+    int verdict_iter;             // ... and for which the early-stop verdict has been TAKEN (by the LamMuZ tail; else the next su launch takes it)
     int pose_ok;                  // Dev::pose and the near masks of Dev::coef describe the same terms (a LamMuZ launch / k_lmz_finalize made them)
+    int prev_iters;               // ADMM iterations of the previous step: the LamMuZ tail runs where the step is expected to end (lmz_tail)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -177,6 +180,7 @@ __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
         f.info->resi_dual = d.ctrl->resi_dual; f.info->resi_pri = d.ctrl->resi_pri;
         f.info->iters = d.ctrl->iters; f.info->su_status = d.ctrl->su_status; f.info->su_ipm_iters = d.ctrl->ipm_iters;
         f.info->lmz_fail = d.ctrl->lmz_fail;
+        d.ctrl->prev_iters = d.ctrl->iters;
     }
     // polygons of the staged scene that failed the reference's convexity test (mpc.py:476-549 prints a warning per polygon)
     if (f.slot && tid == 1) *(long long *)(f.out_u + 2 * T + 3 * (T + 1) + 6) = d.sc_bad ? (long long)*d.sc_bad : 0ll;
@@ -199,15 +203,18 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
         if (tid == 0) {
             d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0;
+            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0; d.ctrl->verdict_iter = 0;
         }
         __syncthreads();
-    } else if (d.ctrl->stop) return;
+    } else if (d.ctrl->stop) {
+        if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     // The early stop of rda_solver.py:594 after iteration it-1.  Normally the LamMuZ launch of that iteration has taken the verdict in
     // its tail (lmz_tail: residuals reduced, stop flag set, result handed over) and nothing is left to do here; with obstacle shards
     // (the residual partials of the other ranks arrive with the all-gather) or with the tail switched off it is taken here.
-    if (it > 0 && d.ctrl->resi_iter != it) {
-        reduce_residuals(d, tid);
+    if (it > 0 && d.ctrl->verdict_iter != it) {
+        if (d.ctrl->resi_iter != it) reduce_residuals(d, tid);          // (k_finish of a host-driven caller may have reduced them already)
         const bool stop_now = d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;   // rda_solver.py:594
         if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + (stop_now ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (stop_now) {
@@ -222,6 +229,8 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
             return;
         }
     }
+    else if (it > 0 && fin && fin->verdict && tid == 0)        // (the LamMuZ tail has taken the verdict: not stopped)
+        __hip_atomic_store(fin->verdict, 2 * fin->vseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->ticket = 0; }     // the LamMuZ launches of this iteration start with an empty work list / ticket
     su::Args a;
     a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
@@ -288,7 +297,7 @@ __device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
         d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0;
+        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0; d.ctrl->resi_iter = 0; d.ctrl->verdict_iter = 0; d.ctrl->ticket = 0;
     }
 }
 
@@ -379,6 +388,15 @@ __device__ __forceinline__ void row_record(double *rv, const Dev &d, const RowOu
 // (the values do not depend on which workgroup that is), takes the early-stop verdict of rda_solver.py:594 and - when the step ends
 // here (stop, or the last iteration) - hands the result over.  The su launch that used to detect the stop (and k_finish) leave the
 // critical path: a two-iteration step is su, lmz, su, lmz.  All threads of the workgroup call; `flag` one LDS word.
+// The tail is an OPTIMISATION, never needed for correctness (a su launch that finds the residuals of the previous iteration not yet
+// reduced takes the verdict itself), and it costs ~4 us on the launch it runs in (drain the write-through stores, ticket, acquire,
+// reduce: measured at the north-star size) against ~8 us for the su launch it replaces - so it only runs where the step is EXPECTED to
+// end: from the iteration count of the previous step on (steps mostly repeat it), and in the last iteration.  Same reduction, same
+// values either way.
+__device__ __forceinline__ bool tail_here(const Dev &d, int it)
+{
+    return d.lmz_tail && d.P == 1 && (it + 1 >= d.c.iter_num || it + 1 >= d.ctrl->prev_iters);
+}
 __device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, unsigned *flag, unsigned nblocks)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its sc1 stores ...
@@ -395,7 +413,7 @@ __device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, u
     const bool last = it + 1 >= d.c.iter_num;
     const bool stop = !last && d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;      // rda_solver.py:594
     __syncthreads();
-    if (stop && threadIdx.x == 0) d.ctrl->stop = 1;
+    if (threadIdx.x == 0) { d.ctrl->verdict_iter = it + 1; if (stop) d.ctrl->stop = 1; }
     if ((stop || last) && fin.out_u) {
         publish_result(d, fin);
         if (threadIdx.x == 0) d.ctrl->finished = 1;
@@ -635,6 +653,35 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = t * GS * d.J + nl;
         need = 0;
     }
+    if (MODE == 0) {
+        // The rows of the WORKGROUP whose certificate failed are shared out over its waves: the launch time of a small grid is its
+        // slowest wave, and that was a wave with two failing rows (2 - 3 % of the rows fail; ~13 us common path + ~6 us per
+        // enumeration served one after the other) - with the list in LDS a workgroup's two waves take one each.  A row's result
+        // does not depend on which wave enumerated it (same function on the same slab).
+        struct Prm { int norm2; double px, py, cs, sn, xi0, xi1, kappa0; };
+        __shared__ int nfail; __shared__ unsigned char flist[GS]; __shared__ Prm prm[GS]; __shared__ lmz::Sol sol[GS];
+        if (threadIdx.x == 0) nfail = 0;
+        __syncthreads();
+        const bool mine = ((need >> (16 * row)) & 1) != 0;
+        if (mine && gl == 0) {
+            const int rid = wv * 4 + row; flist[atomicAdd(&nfail, 1)] = (unsigned char)rid;
+            Prm &q = prm[rid]; q.norm2 = P.norm2; q.px = P.px; q.py = P.py; q.cs = P.cs; q.sn = P.sn; q.xi0 = P.xi0; q.xi1 = P.xi1; q.kappa0 = P.kappa0;
+        }
+        __syncthreads();
+        const int nf = nfail;
+        for (int i = wv; i < nf; i += WPB) {
+            const int rid = flist[i];
+            lmz::Params Pg;
+            { const Prm &q = prm[rid]; Pg.E = E; Pg.R = R; Pg.norm2 = q.norm2; Pg.px = q.px; Pg.py = q.py; Pg.cs = q.cs; Pg.sn = q.sn; Pg.xi0 = q.xi0; Pg.xi1 = q.xi1;
+              Pg.kappa0 = q.kappa0; Pg.ro2 = P.ro2; Pg.delta = P.delta; }
+            lmz::Sol bg;
+            lmz::solve_wave(wl[rid], rb, Pg, lane, bg);
+            if (lane == 0) sol[rid] = bg;
+        }
+        __syncthreads();
+        if (mine) best = sol[wv * 4 + row];
+        need = 0;
+    }
     while (need) {
         const int g = (__ffsll((long long)need) - 1) >> 4;
         need &= ~(0xffffull << (16 * g));
@@ -706,7 +753,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     if (MODE == 0) {
         __syncthreads();
         block_partial(d, tb, jb, rowv, threadIdx.x);
-        if (d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
+        if (tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
         else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
     }
     }
@@ -744,7 +791,7 @@ __device__ __forceinline__ void finalize_body(const Dev &d, const int block, con
     } else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
     __syncthreads();
     if (B < T * d.J) block_partial(d, t, j, rowv[g], row);
-    if (it >= 0 && d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, &tail_flag, (unsigned)nblocks);
+    if (it >= 0 && tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)nblocks);
     else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
 }
 __global__ __launch_bounds__(256) void k_lmz_finalize(Dev d, int it, Fin fin) { finalize_body(d, blockIdx.x, gridDim.x, it, fin); }
@@ -923,7 +970,7 @@ __device__ __forceinline__ void lammuz_ip_body(const Dev &d, const int block, co
     }
     __syncthreads();
     block_partial(d, t, jb, rowv, threadIdx.x);
-    if (d.lmz_tail && d.P == 1) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
+    if (tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
     else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
 }
 __global__ __launch_bounds__(64 * GS / 4) void k_lammuz_ip(Dev d, int it, Fin fin) { lammuz_ip_body(d, blockIdx.x, it, fin); }
@@ -1058,7 +1105,7 @@ struct rda_handle {
     int early_finish;                     // the su launch that detects the early stop writes the result slot (RDA_EARLY_FINISH=0: k_finish does)    // k_su_tracked (RDA_FUSE_TRACK=0: k_track and k_su as two launches)
     hipStream_t stream2; hipEvent_t ev_tick, ev_scene; int scene_on_s2;   // in-tick scene staging runs beside the first su-problem
     // timing
-    int timing; std::vector<hipEvent_t> ev[2]; size_t ev_used[2];
+    int timing; std::vector<hipEvent_t> ev[3]; size_t ev_used[3];      // 0 LamMuZ launches, 1 su launches, 2 shard all-gathers
     // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
     int sc_cap; int *d_sc_sel; double *d_sc_blk, *d_sc_key;     // d_sc_blk mirrors the pinned block h_sc (ONE H2D copy per upload)
     void *h_sc; size_t h_sc_bytes;
@@ -1102,7 +1149,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     memset(o, 0, sizeof(*o));
     o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11;
-    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 1; o->lmz_ip_rows = 1;
+    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
@@ -1189,7 +1236,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
-    H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = 0;
+    H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = H->ev_used[2] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;
     HIPCHK(hipStreamCreate(&H->stream));
@@ -1265,7 +1312,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->h_out) (void)hipHostFree(H->h_out);
     if (H->h_sc) (void)hipHostFree(H->h_sc);
     if (H->h_verdict) (void)hipHostFree(H->h_verdict);
-    for (int w = 0; w < 2; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
+    for (int w = 0; w < 3; ++w) for (hipEvent_t e : H->ev[w]) (void)hipEventDestroy(e);
     if (H->stream2) { (void)hipStreamSynchronize(H->stream2); (void)hipStreamDestroy(H->stream2); }
     if (H->ev_tick) (void)hipEventDestroy(H->ev_tick);
     if (H->ev_scene) (void)hipEventDestroy(H->ev_scene);
@@ -1492,6 +1539,20 @@ static void launch_lammuz_ip(rda_handle *H, const Dev &d, int it, const Fin &fin
 {
     hipLaunchKernelGGL(k_lammuz_ip, dim3(packed_grid(d.c.T, d.J)), dim3(64 * GS / 4), 0, H->stream, d, it, fin);
 }
+// the LamMuZ launch form launch_lammuz picks for the handle's shape and staged obstacles (bench.py labels its per-launch times with it)
+extern "C" const char *rda_lammuz_kernel(rda_handle *H)
+{
+    if (!H) return "";
+    const Dev &d = H->d;
+    if (d.lmz_mode && !(H->ip_rows && d.obstacle_num)) return (d.c.E <= 4 && d.c.R <= 4) ? "k_lammuz_cp_small+k_lmz_finalize" : "k_lammuz_cp_large+k_lmz_finalize";
+    if (d.lmz_mode) return "k_lammuz_ip";
+    if (d.rows && d.obstacle_num) {
+        const int cus = (d.c.T * d.J * (64 * GS / 4) + 255) / 256;
+        if (cus > H->dense_from && H->lmz_split) return "k_lammuz_rows_fast+k_lammuz_enum+k_lmz_finalize";
+        return cus > H->dense_from ? "k_lammuz_rows_dense" : "k_lammuz_rows";
+    }
+    return "k_lammuz+k_lmz_finalize";
+}
 static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
 {
     if (d.Nlive == 0) return;                    // a shard without obstacles (N < P)
@@ -1622,7 +1683,9 @@ static int enqueue_admm_tail(rda_handle *H, const double *in_s, const double *in
         launch_lammuz(H, d, it, H->early_finish ? fin : Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
         if (H->timing) (void)hipEventRecord(next_event(H, 0), H->stream);
         if (H->comm) {      // one exchange per ADMM iteration: every rank's chunk to every rank (in place)
+            if (H->timing) (void)hipEventRecord(next_event(H, 2), H->stream);
             int nrc = H->p_allgather(d.coef + (size_t)d.rank * d.chunk, d.coef, d.chunk, /*ncclDouble*/ 8, H->comm, H->stream);
+            if (H->timing) (void)hipEventRecord(next_event(H, 2), H->stream);
             if (nrc != 0) { fprintf(stderr, "librda_hip: ncclAllGather failed (%d)\n", nrc); return RDA_ERR_HIP; }
         }
     }
@@ -1911,12 +1974,12 @@ extern "C" int rda_timing_reset(rda_handle *H, int enable)
 {
     if (!H) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
-    H->timing = enable; H->ev_used[0] = H->ev_used[1] = 0;
+    H->timing = enable; H->ev_used[0] = H->ev_used[1] = H->ev_used[2] = 0;
     return RDA_OK;
 }
 extern "C" int rda_timing_read(rda_handle *H, int which, double *total_ms, int *launches)
 {
-    if (!H || which < 0 || which > 1) return RDA_ERR_ARG;
+    if (!H || which < 0 || which > 2) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     double tot = 0; int n = 0;
     for (size_t i = 0; i + 1 < H->ev_used[which]; i += 2) {
@@ -1930,7 +1993,7 @@ extern "C" int rda_timing_read(rda_handle *H, int which, double *total_ms, int *
 
 extern "C" int rda_timing_launches(rda_handle *H, int which, double *ms_out, int cap, int *launches)
 {
-    if (!H || which < 0 || which > 1 || (cap > 0 && !ms_out)) return RDA_ERR_ARG;
+    if (!H || which < 0 || which > 2 || (cap > 0 && !ms_out)) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     int n = 0;
     for (size_t i = 0; i + 1 < H->ev_used[which]; i += 2, ++n) {
@@ -2042,6 +2105,18 @@ extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
     if (rc != RDA_OK) return rc;
     HIPCHK(hipStreamSynchronize(H->stream));
     return RDA_OK;
+}
+static void *rccl_sym(rda_handle *H, const char *name);
+// ranks of the handle's communicator as RCCL counts them (ncclCommCount); 0 without a communicator
+extern "C" int rda_shard_comm_count(rda_handle *H)
+{
+    if (!H) return RDA_ERR_ARG;
+    if (!H->comm) return 0;
+    typedef int (*fn)(void *, int *);
+    fn f = (fn)rccl_sym(H, "ncclCommCount");
+    int n = 0;
+    if (!f || f(H->comm, &n) != 0) return RDA_ERR_HIP;
+    return n;
 }
 extern "C" int rda_shard_chunk_doubles(rda_handle *H) { return H ? (int)H->d.chunk : RDA_ERR_ARG; }
 extern "C" int rda_shard_get_chunk(rda_handle *H, double *host)

@@ -271,10 +271,41 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     const int rt = tid / nch, rc_ = tid % nch;    // this thread's stage and chunk
     const bool ract = rt < T;
     const bool masks_in = a.bsum != nullptr;      // the reduced form of the terms is handed in (k_lammuz / k_lmz_finalize)
+    const bool warm = a.warm_mu0 > 0 && a.lam_keep != nullptr;
+    const int J = masks_in ? a.J : (a.Nloc + GS - 1) / GS;     // GS-slot blocks per shard
+    const int KB = (J + nch - 1) / nch;                         // blocks per shard in one thread's slice: j = rc_ + kb nch
+
+    // ---- EVERY global input of the set-up is requested now, into registers: the set-up's phases (nominal, linearisation, start of the
+    //      duals, term sums) each began with a dependent trip to memory (what the LamMuZ launch wrote sits in HBM / other XCDs' L2s:
+    //      ~1.5 us a trip); this way they overlap into one
+    double pf_u0 = 0, pf_u1 = 0, pf_d = c.max_sd, pf_cp = 0, pf_sp = 0;
+    if (tid < T) {
+        pf_u0 = a.in_u[tid]; pf_u1 = a.in_u[T + tid]; if (a.d_in) pf_d = a.d_in[tid];
+        if (a.pose_lin) { pf_cp = a.pose[4 * tid + 2]; pf_sp = a.pose[4 * tid + 3]; }
+    }
+    double pf_lk[2] = {0, 0};                      // kept multipliers of the rows i = tid, tid + NT (NC T <= 2 NT)
+    if (warm)
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * NT;
+            if (i < NC * T) { const int t = i / NC, kk = i % NC, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t; pf_lk[k] = a.lam_keep[ts * NC + kk]; }
+        }
+    // block partials / near masks of the thread's slice: eight blocks at a time, all their loads in flight together
+    double pq0[8], pq1[8], pq2[8]; unsigned long long pmk[8];
+    auto load_batch = [&](int r, int kb0, double *q0, double *q1, double *q2, unsigned long long *mk) {
+        const double *bs = a.bsum + r * a.chunk + (size_t)rt * J * NBS;
+        const unsigned long long *bm = a.bmask + r * a.chunk + (size_t)rt * J;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = rc_ + (kb0 + k) * nch; const bool in = kb0 + k < KB && j < J; const int jj = in ? j : 0;
+            q0[k] = bs[(size_t)jj * NBS]; q1[k] = bs[(size_t)jj * NBS + 1]; q2[k] = bs[(size_t)jj * NBS + 2]; mk[k] = bm[jj];
+            if (!in) { q0[k] = 0; q1[k] = 0; q2[k] = 0; mk[k] = 0; }
+        }
+    };
+    if (masks_in && ract) load_batch(0, 0, pq0, pq1, pq2, pmk);
 
     // ---- load nominal, reference; linearise -------------------------------------------------
     for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; if (!a.ref_flag) L.ref[i] = a.ref[i]; }
-    for (int i = tid; i < 2 * T; i += NT) L.u[i] = a.in_u[i];
+    if (tid < T) { L.u[tid] = pf_u0; L.u[T + tid] = pf_u1; }
     // reference positions of the hinge screening: where the masks were made (pose table), else the nominal positions of stages 1..T
     for (int i = tid; i < 2 * T; i += NT)
         L.p0[i] = (masks_in && a.pose_ok) ? a.pose[4 * (i % T) + i / T] : a.in_s[(i / T) * (T + 1) + (i % T) + 1];
@@ -284,7 +315,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         int t = tid;
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
         double cp, sp;
-        if (a.pose_lin) { cp = a.pose[4 * t + 2]; sp = a.pose[4 * t + 3]; } else sincos(st[2], &sp, &cp);
+        if (a.pose_lin) { cp = pf_cp; sp = pf_sp; } else sincos(st[2], &sp, &cp);
         L.csn[t] = cp; L.csn[T + t] = sp;
         lin_model(c, st, ut, cp, sp, &L.Ak[9 * t], &L.Bk[6 * t], &L.Ck[3 * t]);
         L.phin[t] = st[2];
@@ -300,22 +331,22 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     __syncthreads();
     mark(11);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
-    auto clip_controls = [&](const double clipm) {
+    auto clip_controls = [&](const double clipm) {          // (the nominal controls / distances: the registers prefetched above)
         if (tid < T) {
             int t = tid;
             double lim0 = (1.0 - clipm) * c.umax0, lim1 = (1.0 - clipm) * c.umax1;
-            double v0 = a.in_u[t], v1 = a.in_u[T + t];
+            double v0 = pf_u0, v1 = pf_u1;
             L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
             L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
             double lo = c.min_sd + clipm * (c.max_sd - c.min_sd), hi = c.max_sd - clipm * (c.max_sd - c.min_sd);
-            double dv = a.d_in ? a.d_in[t] : c.max_sd;
+            double dv = pf_d;
             L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
         }
         __syncthreads();
     };
     // a warm attempt starts next to the previous solution: pulled inside the boxes by warm_clip only (a cold start by 1 %), so that the
     // kept multipliers of the active rows meet slacks of that size and the start is already nearly complementary
-    clip_controls(a.warm_mu0 > 0 && a.lam_keep != nullptr ? a.warm_clip : 0.01);
+    clip_controls(warm ? a.warm_clip : 0.01);
     // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
     // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
     // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
@@ -365,12 +396,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // solution, so the slacks are the previous ones; they are floored at warm_wfl, the multipliers are the larger of the centred
     // ones (warm_mu0 / w) and those the previous solve ended with.  Starting with a small mu0 WITHOUT the old multipliers costs
     // iterations (measured: 75 -> 92 us per launch), with them it saves about one per solve (75 -> 67 us).
-    const bool warm = a.warm_mu0 > 0 && a.lam_keep != nullptr;
     if (warm) {
         centre_duals(a.warm_wfl, a.warm_mu0);
-        for (int i = tid; i < NC * T; i += NT) {
-            const int t = i / NC, k = i % NC, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
-            const double lp = a.lam_keep[ts * NC + k]; if (con_on(t, k) && lp > L.cl[i]) L.cl[i] = lp; }
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * NT;
+            if (i < NC * T) { const double lp = pf_lk[k]; if (con_on(i / NC, i % NC) && lp > L.cl[i]) L.cl[i] = lp; }
+        }
         __syncthreads();
     } else centre_duals(1e-2, 1.0);
     // ---- rotation-consistency penalty -> scalar quadratic per stage from three POSE-INDEPENDENT sums over the terms (see
@@ -386,36 +417,45 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     constexpr int MW = 4;
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
-    const int J = masks_in ? a.J : (a.Nloc + GS - 1) / GS;     // GS-slot blocks per shard
-    const int KB = (J + nch - 1) / nch;                         // blocks per shard in one thread's slice: j = rc_ + kb nch
     bool screened = c.accelerated && a.P * KB * GS <= 64 * MW && (!masks_in || a.pose_ok);
     {
         double saa = 0, sga = 0, sgx = 0;
         if (ract) {
             const double p0x = L.p0[rt], p0y = L.p0[T + rt];
+            auto place = [&](int r, int kb, unsigned long long m8) {
+                // the bit position only depends on the loop counters, i.e. it is the same in every thread (scalar word index and shift)
+                const int bp = (r * KB + kb) * GS;
+                const unsigned long long mm = screened ? m8 << (bp & 63) : 0ull;
+                switch (bp >> 6) { case 0: amask[0] |= mm; break; case 1: amask[1] |= mm; break; case 2: amask[2] |= mm; break; default: amask[3] |= mm; break; }
+            };
             for (int r = 0; r < a.P; ++r) {
+                if (masks_in) {
+                    for (int kb0 = 0; kb0 < KB; kb0 += 8) {
+                        double q0[8], q1[8], q2[8]; unsigned long long mk[8];
+                        if (r == 0 && kb0 == 0) {                 // (prefetched at kernel entry)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { q0[k] = pq0[k]; q1[k] = pq1[k]; q2[k] = pq2[k]; mk[k] = pmk[k]; }
+                        } else load_batch(r, kb0, q0, q1, q2, mk);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) if (kb0 + k < KB && rc_ + (kb0 + k) * nch < J) {
+                            saa += q0[k]; sga += q1[k]; sgx += q2[k];
+                            place(r, kb0 + k, mk[k] & ((1ull << GS) - 1));
+                        }
+                    }
+                } else
                 for (int kb = 0; kb < KB; ++kb) {
                     const int j = rc_ + kb * nch;
                     if (j >= J) break;
                     unsigned long long m8 = 0;
-                    if (masks_in) {
-                        const double *p = a.bsum + r * a.chunk + ((size_t)rt * J + j) * NBS;
-                        saa += p[0]; sga += p[1]; sgx += p[2];
-                        m8 = a.bmask[r * a.chunk + (size_t)rt * J + j] & ((1ull << GS) - 1);
-                    } else {
-                        const size_t o = r * a.chunk + (size_t)rt * a.Nloc + GS * j;
-                        double b0 = 0, b1 = 0, b2 = 0;
-                        for (int row = 0; row < GS && GS * j + row < a.Nloc; ++row) {
-                            const RowTerm q = row_term(a.ax[o + row], a.ay[o + row], a.gx[o + row], a.gy[o + row], a.cb[o + row], p0x, p0y, c.max_sd, true);
-                            b0 += q.aa; b1 += q.ga; b2 += q.gxa;
-                            m8 |= q.near ? 1ull << row : 0ull;
-                        }
-                        saa += b0; sga += b1; sgx += b2;
+                    const size_t o = r * a.chunk + (size_t)rt * a.Nloc + GS * j;
+                    double b0 = 0, b1 = 0, b2 = 0;
+                    for (int row = 0; row < GS && GS * j + row < a.Nloc; ++row) {
+                        const RowTerm q = row_term(a.ax[o + row], a.ay[o + row], a.gx[o + row], a.gy[o + row], a.cb[o + row], p0x, p0y, c.max_sd, true);
+                        b0 += q.aa; b1 += q.ga; b2 += q.gxa;
+                        m8 |= q.near ? 1ull << row : 0ull;
                     }
-                    // the bit position only depends on the loop counters, i.e. it is the same in every thread (scalar word index and shift)
-                    const int bp = (r * KB + kb) * GS;
-                    const unsigned long long mm = screened ? m8 << (bp & 63) : 0ull;
-                    switch (bp >> 6) { case 0: amask[0] |= mm; break; case 1: amask[1] |= mm; break; case 2: amask[2] |= mm; break; default: amask[3] |= mm; break; }
+                    saa += b0; sga += b1; sgx += b2;
+                    place(r, kb, m8);
                 }
             }
         }

@@ -3,8 +3,9 @@ Obstacle-sharded RDA solve across the GPUs of one node (include/rd
 
 The reference fans the N per-obstacle LamMuZ problems out over a `pathos` process pool and gathers
 `(lam, mu, z)` back through pipes once per ADMM iteration (rda_solver.py:706-725).  Here rank r owns the
-obstacle slots [r*N/P, (r+1)*N/P): their duals never leave that GPU; what is exchanged per iteration is the
-48+16 bytes per (obstacle, stage) the su-problem and the stopping test need, as ONE all-gather.  Every rank
+obstacle slots [r*ceil(N/P), (r+1)*ceil(N/P)): their duals never leave that GPU; what is exchanged per iteration is what the
+su-problem reads - 24 bytes per (slot, stage) (a, the hinge offset) plus 48 bytes per (stage, 8-slot block) of reduced sums,
+residual partials and the near mask - as ONE all-gather.  Every rank
 then solves the identical su-problem, so no broadcast is needed and all ranks take the same early-stop
 decision.
 

@@ -9,6 +9,7 @@ ref_plumbing.npz  - mode "oracle": closed loops of the reference `mpc.MPC` + `RD
                     reference's own `convert_rda_obstacle` produced, staged as dense arrays) and, after EVERY ADMM iteration, the
                     reference's parameter values: nominal s, u, `dis`, residuals in full; lam, mu, z, xi, zeta, obsA_lam, obsb_lam
                     in full for the small scenes and as 8 fixed random projections each for the large one.
+ref_problems_na.npz - the same for the NON-accelerated LamMuZ cost (accelerated=False, rda_solver.py:399-402)
 ref_problems.npz  - mode "ipm": LamMuZ and su problems BUILT BY THE REFERENCE's construction code and solved as they stand by the
                     generic interior-point stand-in: inputs in the layout of rda_lammuz_batch / rda_su_solve and the unique part
                     of the answers (LamMuZ: optimal value, min(Im, 0), Hm; su: s, u, d).
@@ -197,13 +198,75 @@ def problems(rs, mp):
     np.savez_compressed(os.path.join(HERE, "ref_problems.npz"), **out)
 
 
+
+def lammuz_problems_nonaccelerated(rs, mp):
+    """the NON-accelerated form of the LamMuZ cost (rda_solver.py:399-402: Im^2 instead of neg(Im)^2) as the reference's
+    construction code builds it, solved by the stand-in: its own file and its own random stream, so that ref_problems.npz stays as it is.
+    Here Im itself is unique (the cost is strictly convex in it), so it is stored in full."""
+    out = {}
+    rng = np.random.default_rng(20250510)
+    car_t = sc.rectangle_robot(dynamics="acker")
+    G, h = np.ascontiguousarray(car_t.G, float), np.ascontiguousarray(car_t.h, float).ravel()
+    T, N, E = 5, 6, 4
+    rows = {k: [] for k in ("A", "b", "cone", "p", "phi", "xi", "zeta", "dbar", "cost", "Im", "H")}
+    r = rs.RDA_solver(T, car_t, max_edge_num=E, max_obs_num=N, iter_num=2, step_time=0.1, process_num=1, time_print=False, ro2=1.0,
+                      accelerated=False)
+    for trial in range(4):
+        nom_u = np.vstack([rng.uniform(1, 4, T), rng.uniform(-0.3, 0.3, T)])
+        nom_s = np.zeros((3, T + 1))
+        nom_s[:, 0] = [rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-3, 3)]
+        for t in range(T):
+            nom_s[:, t + 1] = sc.kinematic_step(nom_s[:, t:t + 1], nom_u[:, t:t + 1], car_t, 0.1).ravel()
+        dis = rng.uniform(0.1, 1.0, (1, T))
+        obs = []
+        for n in range(N):
+            dist, th = rng.choice([1.0, 2.5, 4.0, 8.0, 20.0]), rng.uniform(0, 2 * np.pi)
+            cen = nom_s[0:2, T // 2] + dist * np.array([np.cos(th), np.sin(th)])
+            if rng.random() < 0.3:
+                obs.append(mp.rdaobs(np.array([[1, 0], [0, 1], [0, 0.0]]), np.array([[cen[0]], [cen[1]], [-rng.uniform(0.3, 1.5)]]), "norm2", None, None))
+            else:
+                k = int(rng.integers(3, E + 1))
+                A_, b_ = random_polygon(rng, cen, k, rng.uniform(0.5, 2.0), k)
+                obs.append(mp.rdaobs(A_, b_.reshape(-1, 1), "Rpositive", None, None))
+        r.assign_state_parameter(nom_s, nom_u, dis)
+        r.assign_obstacle_parameter(obs)
+        r.assign_combine_parameter_stateobs()
+        for n in range(N):
+            r.para_xi_list[n].value = np.vstack([np.zeros((1, 2)), rng.normal(0, rng.choice([0, 0.05, 0.5]), (T, 2))])
+            r.para_zeta_list[n].value = rng.normal(0, rng.choice([0, 0.3, 2.0]), (1, T))
+        for n in range(N):
+            prob = r.prob_LamMuZ_list[n]
+            prob.solve()
+            if prob.status != "optimal":
+                continue
+            Im, Hm = r.indep_Im_array_LamMuZ[n].value, r.indep_Hm_array_LamMuZ[n].value
+            for t in range(T):
+                rows["A"].append(np.array(r.para_obstacle_list[n]["A"][t + 1].value, float))
+                rows["b"].append(np.array(r.para_obstacle_list[n]["b"][t + 1].value, float).ravel())
+                rows["cone"].append(int(r.para_obstacle_list[n]["cone_type"].value[1] > 0.5))
+                rows["p"].append(nom_s[0:2, t + 1].copy()); rows["phi"].append(nom_s[2, t])
+                rows["xi"].append(np.array(r.para_xi_list[n].value[t + 1], float)); rows["zeta"].append(float(r.para_zeta_list[n].value[0, t]))
+                rows["dbar"].append(float(dis[0, t]))
+                rows["cost"].append(0.5 * float(Im[t]) ** 2 + 0.5 * float(np.sum(Hm[t] ** 2)))
+                rows["Im"].append(float(Im[t])); rows["H"].append(np.array(Hm[t], float))
+    for k, v in rows.items():
+        out[f"lmz.{k}"] = np.array(v)
+    out["lmz.G"], out["lmz.h"] = G, h
+    print("LamMuZ problems (not accelerated):", len(rows["cost"]), "sub-problems;", int(np.sum(np.array(rows["cost"]) > 1e-6)), "with a positive optimal value")
+    np.savez_compressed(os.path.join(HERE, "ref_problems_na.npz"), **out)
+
+
 if __name__ == "__main__":
     rs, mp, backend = rh.load()
     assert backend == "refshim" or True
     orc = orc_api()
     orc.lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
     orc.lib.orc_set_su_warm(0.0, 0.0, 0)
+    if "--only-na" in sys.argv:                     # add the non-accelerated LamMuZ fixtures without touching the other files
+        lammuz_problems_nonaccelerated(rs, mp)
+        sys.exit(0)
     plumbing(rs, mp, orc)
     problems(rs, mp)
-    for f in ("ref_plumbing.npz", "ref_problems.npz"):
+    lammuz_problems_nonaccelerated(rs, mp)
+    for f in ("ref_plumbing.npz", "ref_problems.npz", "ref_problems_na.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -123,6 +123,35 @@ def _check_lmz(g, z, cmh):
     assert np.abs(np.minimum(m, 0.0) - g["lmz.mneg"]).max() < 2e-5 and np.abs(cmh[:, 2:4] - g["lmz.H"]).max() < 2e-5    # delta = 1e-6 clearance reward
 
 
+def _check_lmz_na(g, z, cmh):
+    """non-accelerated cost (rda_solver.py:399-402): Im = m - z enters squared, so z = max(m, 0) and Im = min(m, 0) are unique"""
+    im = cmh[:, 1] - z
+    cost = 0.5 * im ** 2 + 0.5 * (cmh[:, 2] ** 2 + cmh[:, 3] ** 2)
+    assert np.abs(cost - g["lmz.cost"]).max() < 1e-6
+    assert np.abs(im - g["lmz.Im"]).max() < 2e-5 and np.abs(cmh[:, 2:4] - g["lmz.H"]).max() < 2e-5
+    assert np.abs(z - np.maximum(cmh[:, 1], 0.0)).max() < 1e-12          # tie-break T2, not accelerated: z = max(m, 0)
+
+
+def _lmz_inputs(g):
+    inp = {k: np.ascontiguousarray(g[f"lmz.{k}"]) for k in ("A", "b", "p", "phi", "xi", "zeta", "dbar")}
+    inp["cone"] = np.ascontiguousarray(g["lmz.cone"], np.int32)
+    return inp
+
+
+def test_oracle_argmins_on_reference_built_problems_not_accelerated(orc):
+    """the LamMuZ problems `construct_LamMuZ_prob` builds with accelerated=False"""
+    g = np.load(os.path.join(GOLD, "ref_problems_na.npz"))
+    lam, mu, z, cmh = hp.oracle_lammuz_batch(orc, _lmz_inputs(g), accelerated=0, G=np.ascontiguousarray(g["lmz.G"]), h=np.ascontiguousarray(g["lmz.h"]))
+    _check_lmz_na(g, z, cmh)
+
+
+@pytest.mark.gpu
+def test_hip_argmins_on_reference_built_problems_not_accelerated(hip):
+    g = np.load(os.path.join(GOLD, "ref_problems_na.npz"))
+    lam, mu, z, cmh = hp.hip_lammuz_batch(hip, _lmz_inputs(g), accelerated=0, G=np.ascontiguousarray(g["lmz.G"]), h=np.ascontiguousarray(g["lmz.h"]))
+    _check_lmz_na(g, z, cmh)
+
+
 def _su_case(g, k):
     dyn = int(g[f"su.{k}.dyn"])
     T, N = g[f"su.{k}.nom_u"].shape[1], g[f"su.{k}.a"].shape[0]

@@ -238,6 +238,76 @@ def test_reference_mpc_on_top_of_our_solver_class(ref, cold_orc):
         state = sc.kinematic_step(state, ua, car_t, 0.1)
 
 
+def _mirror_scene(name):
+    """(car_t, path, obstacles(k), MPC kwargs, steps) of the scenes the reference's mpc.MPC and this repo's mirror are compared on"""
+    if name == "c2_corridor_acker":                       # BASELINE C2: Ackermann, the corridor's boxes + seeded extras, T=20
+        car_t = sc.rectangle_robot(dynamics="acker")
+        path = sc.line_path([0, 20, 0], [60, 20, 0], 0.1)
+        obs = sc.scene_corridor()
+        return car_t, path, (lambda k: obs), dict(receding=20, iter_num=3, max_edge_num=4, max_obs_num=20, ro1=200, obstacle_order=True), 30
+    if name == "moving_omni":                             # moving polygons + a moving circle, omni kinematics
+        car_t = sc.rectangle_robot(dynamics="omni", wheelbase=0)
+        path = sc.line_path([4, 25, 0], [30, 25, 0], 0.1)
+        clear = np.array([[q[0, 0], q[1, 0]] for q in path[::10]])
+        scene = sc.scene_polygons(10, lo=(8, 16), hi=(30, 34), seed=9, keep_clear=clear, clear_radius=3.0, moving=True)
+        scene.append(sc.circle(18.0, 29.0, 0.9, (0.0, -0.2)))
+
+        def at(k):
+            return [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
+                    else o._replace(center=o.center + o.velocity * (0.1 * k)) for o in scene]
+        return car_t, path, at, dict(receding=10, iter_num=2, max_edge_num=4, max_obs_num=12, ro1=200, obstacle_order=True), 25
+    if name == "path_end_arrive":                         # short path: the horizon runs off its end (quirk Q12), then `arrive`
+        car_t = sc.rectangle_robot(dynamics="diff", wheelbase=0)
+        path = sc.line_path([0, 0, 0], [7, 0, 0], 0.2)
+        obs = sc.scene_polygons(4, lo=(2, 3), hi=(8, 8), seed=4)
+        return car_t, path, (lambda k: obs), dict(receding=8, iter_num=2, max_edge_num=4, max_obs_num=4, ro1=200, obstacle_order=True), 40
+    if name == "reverse_gear":                            # forward piece, then a backward piece (enable_reverse: split_path, gear flag)
+        car_t = sc.rectangle_robot(dynamics="acker")
+        fwd = sc.line_path([0, 0, 0], [3, 0, 0], 0.2)
+        back = [np.array([[3.0 - 0.2 * i], [0.3], [0.0]]) for i in range(1, 26)]          # heading unchanged, x decreasing: gear -1
+        path = fwd + back
+        obs = sc.scene_polygons(3, lo=(1, 4), hi=(8, 9), seed=5)
+        return car_t, path, (lambda k: obs), dict(receding=8, iter_num=2, max_edge_num=4, max_obs_num=3, ro1=200, obstacle_order=True,
+                                                  enable_reverse=True), 160
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["c2_corridor_acker", "moving_omni", "path_end_arrive", "reverse_gear"])
+def test_reference_mpc_equals_the_mirror_on_more_scenes(ref, cold_orc, name):
+    """the caller-side code of this repo (`rda_planner_amd/mpc.py`: pre_process, closest_point / inter_point, gear and
+    arrive logic, convert_rda_obstacle + sort) is a mirror of the reference's `mpc.MPC`, and the device-side pipelines (f1, f3) are
+    tested against THAT mirror - so the mirror itself is pinned on the reference: both MPC classes on the same solver backend must
+    return bit-identical controls, reference trajectories and `arrive` flags, step for step."""
+    rh, rs, mp, _ = ref
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.mpc import MPC as OurMPC
+    import functools
+    car_t, path, obs_at, kw, steps = _mirror_scene(name)
+    saved = mp.RDA_solver
+    mp.RDA_solver = functools.partial(RDA_solver, _backend=oracle_backend)
+    try:
+        a = mp.MPC(car_t, [q.copy() for q in path], sample_time=0.1, time_print=False, **kw)
+    finally:
+        mp.RDA_solver = saved
+    b = OurMPC(car_t, [q.copy() for q in path], sample_time=0.1, time_print=False, _backend=oracle_backend, **kw)
+    state = path[0].copy().reshape(3, 1)
+    arrived, reversed_ = 0, False
+    for k in range(steps):
+        ua, ia = a.control(state.copy(), 3.0, list(obs_at(k)))
+        ub, ib = b.control(state.copy(), 3.0, list(obs_at(k)))
+        assert np.array_equal(ua, ub), (name, k, float(np.abs(ua - ub).max()))
+        assert ia["arrive"] == ib["arrive"], (name, k)
+        assert len(ia["ref_traj_list"]) == len(ib["ref_traj_list"]) and all(np.array_equal(x, y) for x, y in zip(ia["ref_traj_list"], ib["ref_traj_list"])), (name, k)
+        assert a.cur_index == b.cur_index
+        arrived += int(ia["arrive"])
+        reversed_ = reversed_ or float(ua[0, 0]) < -0.05
+        state = sc.kinematic_step(state, ua, car_t, 0.1)
+    if name == "path_end_arrive":
+        assert arrived > 0, "the scene is meant to reach the end of its path"
+    if name == "reverse_gear":
+        assert reversed_, "the scene is meant to drive its second piece backwards"
+
+
 # ---------------------------------------------------------------------------------------------------------
 # mode "ipm": the reference's own problems, solved as they stand
 # ---------------------------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--moving", action="store_true")
     ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--order", action="store_true", help="re-sort the obstacles by distance every tick (MPC default; the headline loop of bench.py keeps the slot binding fixed)")
     args = ap.parse_args()
     import bench
     from rda_planner_amd.mpc import MPC
@@ -28,6 +29,7 @@ def main():
     from rda_planner_amd.rda_solver import hip_options
     from rda_planner_amd._lib import hip_api
     car_t, path, obstacles, kw = bench.build_workload(n_obs=args.n_obs, T=args.horizon, n_steps=args.steps + 20, moving=args.moving)
+    kw["obstacle_order"] = bool(args.order)
     mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, hip_opts=hip_options(su_prof=1), **kw)
     lib = hip_api().lib
     state = path[0].copy().reshape(3, 1)
