@@ -129,6 +129,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     oversub = False
+    if args.force_shard_leg:
+        import torch                               # torch (its HIP runtime, its RCCL) must be in the process BEFORE librda_hip.so is loaded
+        torch.cuda.init()
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -639,10 +642,11 @@ def main():
     if os.path.exists(tr_file):
         try:
             tj = json.load(open(tr_file))
-            if tj.get("workload") == {"n_obs": N, "horizon": T}:       # PMC bytes are per executed launch of THIS workload only
-                r_lm["traffic"] = tj.get("k_lammuz")
-                r_su["traffic"] = tj.get("k_su")
-                r_su["traffic_source"] = r_lm["traffic_source"] = tj.get("source")
+            mode_now = 1 if "k_lammuz_ip" in lm_kernel or "k_lammuz_cp" in lm_kernel else 0
+            for wl in tj.get("workloads", {}).values():            # PMC bytes per executed launch of THIS workload only
+                if (wl["n_obs"], wl["horizon"], bool(wl["moving"]), wl.get("lmz_mode", 0)) == (N, T, bool(args.moving), mode_now) and world == 1:
+                    r_lm["traffic"], r_su["traffic"] = wl.get("k_lammuz"), wl.get("k_su")
+                    r_su["traffic_source"] = r_lm["traffic_source"] = tj.get("source")
         except Exception:
             pass
     dominant, secondary = (r_su, r_lm) if r_su["total_ms"] >= r_lm["total_ms"] else (r_lm, r_su)

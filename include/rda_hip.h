@@ -92,6 +92,8 @@ typedef struct rda_opts {
                                 same values either way                                                                   RDA_LMZ_TAIL */
     int32_t lmz_ip_rows;     /* [1] interior-point mode: the row-parallel kernel (16 lanes per sub-problem) when the shape allows
                                 (0: one sub-problem per thread)                                                         RDA_LMZ_IP_ROWS */
+    int32_t lmz_ip_warm;     /* [1] interior-point mode, row-parallel kernel: every sub-problem starts from the central-path point its last
+                                solve ended on (same end point, 2 - 4 instead of ~9 iterations; solver history: rda_get_lmz_history) RDA_LMZ_IP_WARM */
     int32_t su_pre;          /* [1] the su set-up reads the block sums / near masks the LamMuZ launch wrote (0: evaluates every term) RDA_SU_PRE */
     int32_t su_light;        /* [1] convergence pass without the factorisation when the last step predicts convergence  RDA_SU_LIGHT */
     int32_t su_warm_first;   /* [1] the first su-problem of a step starts from the previous step's multipliers          RDA_SU_WARM_FIRST */
@@ -254,6 +256,13 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
 int  rda_get_su_history(rda_handle *h, int32_t *hist /*2*/, double *lam_keep /*10*T*/);
 int  rda_set_su_history(rda_handle *h, const int32_t *hist /*16*/, const double *lam_keep /*10*T*/);
+/* Interior-point LamMuZ mode: the central-path points the sub-problems last ended on ([T][N][5][16] doubles: x | s, z of the diagonal
+ * rows | s, z of the general rows, csrc/lammuz_ip_device.h) and their validity flags [T][N] - where each sub-problem's next solve starts.
+ * Solver history like the su history above: it moves a result only within the centring tolerance (1e-7 mu relative), rda_reset clears
+ * it.  rda_lmz_history_doubles = 80 N T, or 0 when the handle keeps none (enumeration mode, per-thread kernel, lmz_ip_warm = 0). */
+int  rda_lmz_history_doubles(rda_handle *h);
+int  rda_get_lmz_history(rda_handle *h, double *points, int32_t *valid);
+int  rda_set_lmz_history(rda_handle *h, const double *points, const int32_t *valid);
 /* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
 

@@ -85,6 +85,7 @@ template <class L> struct Solver {
     V pv[3]; double pw[3];            // P = sum_c pw[c] pv[c] pv[c]'   (pv[c] = entry of variable `lane`)
     V qx;                             // linear cost
     V dsg, dh; M dact;                // diagonal row of variable `lane`: sign, rhs, exists
+    M xdead;                          // variable `lane` enters nothing (beyond n, or the multiplier of a zero-padded edge row): stays 0
     V cvx; V qv_, mv0, mv1;           // Im = cv'x + kappa0 ; (q, M) of the lam entries (outputs)
     double kappa0, xi0, xi1;
     // ---- iterate ------------------------------------------------------------------------------------------------------------
@@ -340,6 +341,7 @@ template <class L> struct Solver {
         else { pv[2] = cvx; pw[2] = 1.0; qx = qx + cst(p.kappa0) * cvx; }
         // diagonal rows.  Zero-padded edge rows carry a multiplier that enters nothing and has no central value: left unconstrained at 0
         const M nullrow = islam && ai0 == zero && ai1 == zero && bi == zero;
+        xdead = nullrow || !L::lane_lt(n);
         dact = (islam && !nullrow && !cst_m(p.cone_norm2 != 0)) || (ismu && !cst_m(p.robot_norm2 != 0)) || lane_is(iz) || lane_is(ith) || lane_is(imm);
         dsg = L::sel(lane_is(imm), cst(1.0), cst(-1.0));
         dh = L::sel(lane_is(imm), cst(1.0), zero);
@@ -389,9 +391,28 @@ template <class L> struct Solver {
     RIP_HD V rdot(const RV &a, const RV &b) const { return L::rsum(a.d * b.d) + L::rsum(a.g * b.g * mult); }     // with multiplicity
     RIP_HD V rmaxabs(const RV &a) const { return L::fmax_(L::rmax(L::sel(dact, L::fabs_(a.d), cst(0.0))), L::rmax(L::sel(glp || gq, L::fabs_(a.g), cst(0.0)))); }
 
-    // returns 0 (on the central path at mu_target), 2 failed
-    RIP_HD int run(double mu_target)
+    // take over a kept central-path point as the start of a warm run (after build): entries that do not exist in THIS problem are
+    // cleared - the slot may have held another obstacle last time (re-ordered list: a triangle where a quadrilateral was, a circle
+    // where a polygon was); rows that exist now but did not then arrive as zeros, which nt_compute rejects -> cold start
+    RIP_HD void load(const V &x_, const V &sd, const V &zd, const V &sg, const V &zg)
     {
+        const V zero = cst(0.0);
+        x = L::sel(xdead, zero, x_);
+        s.d = L::sel(dact, sd, zero); z.d = L::sel(dact, zd, zero);
+        s.g = L::sel(glp || gq, sg, zero); z.g = L::sel(glp || gq, zg, zero);
+    }
+    // returns 0 (on the central path at mu_target), 2 failed.  warm: (x, s, z) hold an interior point - the central-path point of the
+    // previous solve of this (slot, stage): the cones are the same ones, so it is interior for the new data too, its gap is deg mu*,
+    // and the iteration is in its centring phase from the first step (one factorisation + ONE solve per iteration, Newton on the
+    // mu*-perturbed optimality conditions with full residual reduction): 2 - 4 iterations where consecutive problems are close.  A warm
+    // run that has not arrived after `warm_cap` iterations (or leaves the cone numerically) gives way to the cold start.
+    RIP_HD int run(double mu_target, bool warm = false, int *iters = nullptr)
+    {
+        if (iters) *iters = 0;
+        if (warm) {
+            const int st = iterate(mu_target, 12, iters);
+            if (st == 0) return 0;
+        }
         const RV e = evec(), h = hvec();
         // ---- starting point: x = argmin 1/2 x'Px + q'x + 1/2 |Gx - h|^2, z = Gx - h, s = -z, both shifted into the cone ------------
         if (!factor(false)) return 2;
@@ -403,10 +424,16 @@ template <class L> struct Solver {
             if (L::uni(ts >= thr)) s = axpy(cst(1.0) + ts, e, s);
             if (L::uni(tz >= thr)) z = axpy(cst(1.0) + tz, e, z);
         }
+        return iterate(mu_target, 60, iters);
+    }
+    RIP_HD int iterate(double mu_target, int it_cap, int *iters)
+    {
+        const RV e = evec(), h = hvec();
         const V nqn = L::rmax(L::sel(L::lane_lt(n), cst(1.0) + L::fabs_(qx), cst(1.0)));
         const V nhn = L::fmax_(cst(1.0), cst(1.0) + rmaxabs(h));
         const V mut = cst(mu_target);
-        for (int it = 0; it < 60; ++it) {
+        for (int it = 0; it < it_cap; ++it) {
+            if (iters) *iters += 1;
             const V rx = L::sel(L::lane_lt(n), qx + Pmul(x) + Gt(z), cst(0.0));
             RV rz; { const RV gx = Gx(x); rz.d = L::sel(dact, s.d - h.d + gx.d, cst(0.0)); rz.g = L::sel(glp || gq, s.g - h.g + gx.g, cst(0.0)); }
             const V gap = rdot(s, z);

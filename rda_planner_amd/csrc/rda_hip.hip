@@ -113,6 +113,9 @@ struct Dev {
     double *ref, *ref_speed;                  // current step reference (device)
     Ctrl *ctrl;
     long long *su_prof;                       // optional phase cycle counters of the su-solves of this handle (RDA_SU_PROF), else null
+    // interior-point LamMuZ mode, row-parallel kernel: the central-path point (x | s diag | z diag | s general | z general, 5 x 16 doubles)
+    // every (stage, slot) ended on and whether it is valid - the start of that sub-problem's next solve (solver history, like su_lam_keep)
+    double *ipw; int *ipf;                    // [T][N][5][16], [T][N]; null: always the cold start
 };
 
 __host__ __device__ inline double *coef_arr(const Dev &d, int r, int k)
@@ -915,10 +918,17 @@ __device__ __forceinline__ void lammuz_ip_body(const Dev &d, const int block, co
     bad = ((__ballot(bad) >> (16 * row)) & 0xffffull) != 0;                      // uniform over the row
     int status = 2;
     double v = prev;
+    double *const wst = d.ipw ? d.ipw + (zi * 5) * 16 : nullptr;      // this sub-problem's kept central-path point
     if (!bad) {
         rip::Solver<L> sv;
         sv.build(p);
-        status = sv.run(p.mu_target);
+        const bool warm = wst && d.ipf[zi] != 0;                      // (uniform over the row)
+        if (warm) sv.load(wst[gl], wst[16 + gl], wst[32 + gl], wst[48 + gl], wst[64 + gl]);
+        status = sv.run(p.mu_target, warm);
+        if (wst && live) {
+            if (status == 0) { wst[gl] = sv.x; wst[16 + gl] = sv.s.d; wst[32 + gl] = sv.z.d; wst[48 + gl] = sv.s.g; wst[64 + gl] = sv.z.g; }
+            if (gl == 0) d.ipf[zi] = status == 0 ? 1 : 0;
+        }
         if (status == 0) {
             v = sv.x;
             if (gl < E) { if (!p.cone_norm2 && v < 0) v = 0; }
@@ -1069,6 +1079,7 @@ __global__ void k_reset(Dev d)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; }      // solver history of the handle
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
+    if (d.ipf) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.c.N * T; i += gridDim.x * blockDim.x) d.ipf[i] = 0;
 }
 // the same rebuild for every shard of a handle (the host rewrote terms: all P chunks are local copies)
 __global__ __launch_bounds__(256) void k_lmz_finalize_all(Dev d)
@@ -1149,7 +1160,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     memset(o, 0, sizeof(*o));
     o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11;
-    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1;
+    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
@@ -1159,7 +1170,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     geti("RDA_LMZ_MODE", &o->lmz_mode); geti("RDA_TIE_CENTRE", &o->tie_centre); getd("RDA_LMZ_MU", &o->lmz_mu);
     { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol[0], &o->su_tol[1], &o->su_tol[2]); }
     geti("RDA_LMZ_WARM", &o->lmz_warm); geti("RDA_LMZ_ROWS", &o->lmz_rows); geti("RDA_LMZ_DENSE_FROM", &o->lmz_dense_from);
-    geti("RDA_LMZ_SPLIT", &o->lmz_split); geti("RDA_LMZ_TAIL", &o->lmz_tail); geti("RDA_LMZ_IP_ROWS", &o->lmz_ip_rows);
+    geti("RDA_LMZ_SPLIT", &o->lmz_split); geti("RDA_LMZ_TAIL", &o->lmz_tail); geti("RDA_LMZ_IP_ROWS", &o->lmz_ip_rows); geti("RDA_LMZ_IP_WARM", &o->lmz_ip_warm);
     geti("RDA_SU_PRE", &o->su_pre); geti("RDA_SU_LIGHT", &o->su_light);
     geti("RDA_SU_WARM_FIRST", &o->su_warm_first); geti("RDA_SU_EASY_NOPRED", &o->su_easy_nopred);
     { const char *e = getenv("RDA_SU_COLD_FROM"); if (e) sscanf(e, "%d,%d", &o->su_cold_from, &o->su_cold_probe); }
@@ -1286,6 +1297,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->early_finish = o.early_finish;
     H->lmz_split = o.lmz_split;
     H->ip_rows = o.lmz_ip_rows && rip::fits(cfg->E, cfg->R, cfg->E >= 3, cfg->robot_norm2, cfg->accelerated); H->admm_it = 0;
+    if (H->d.lmz_mode && H->ip_rows && o.lmz_ip_warm) { if (dalloc(&H->d.ipw, N * T * 80) || dalloc(&H->d.ipf, N * T)) return RDA_ERR_HIP; }
     // the terms of a fresh handle are all zero: their block partials (zero sums, every slot NEAR: a = 0 puts the hinge at -d < 0)
     int rcf = terms_rebuild(H);
     if (rcf != RDA_OK) return rcf;
@@ -1301,7 +1313,7 @@ extern "C" void rda_destroy(rda_handle *H)
     if (H->comm && H->p_comm_destroy) H->p_comm_destroy(H->comm);
     Dev &d = H->d;
     void *ptrs[] = { d.wl, d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef, d.coefL,
-                     d.s, d.u, d.pose, d.su_prof, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
+                     d.s, d.u, d.pose, d.su_prof, d.ipw, d.ipf, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
                      H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
     for (void *p : ptrs) dev_free(p);
@@ -1369,6 +1381,27 @@ extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const doub
         HIPCHK(hipMemcpy(&H->d.ctrl->su_probe, &hist[1], sizeof(int), hipMemcpyHostToDevice));
     }
     if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
+    return RDA_OK;
+}
+extern "C" int rda_lmz_history_doubles(rda_handle *H) { return !H ? RDA_ERR_ARG : (H->d.ipw ? 80 * H->d.c.N * H->d.c.T : 0); }
+extern "C" int rda_get_lmz_history(rda_handle *H, double *points, int32_t *valid)
+{
+    if (!H) return RDA_ERR_ARG;
+    if (!H->d.ipw) return RDA_ERR_UNSUPPORTED;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    const size_t nt = (size_t)H->d.c.N * H->d.c.T;
+    if (points) HIPCHK(hipMemcpy(points, H->d.ipw, nt * 80 * sizeof(double), hipMemcpyDeviceToHost));
+    if (valid) HIPCHK(hipMemcpy(valid, H->d.ipf, nt * sizeof(int), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
+extern "C" int rda_set_lmz_history(rda_handle *H, const double *points, const int32_t *valid)
+{
+    if (!H) return RDA_ERR_ARG;
+    if (!H->d.ipw) return RDA_ERR_UNSUPPORTED;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    const size_t nt = (size_t)H->d.c.N * H->d.c.T;
+    if (points) HIPCHK(hipMemcpy(H->d.ipw, points, nt * 80 * sizeof(double), hipMemcpyHostToDevice));
+    if (valid) HIPCHK(hipMemcpy(H->d.ipf, valid, nt * sizeof(int), hipMemcpyHostToDevice));
     return RDA_OK;
 }
 extern "C" int rda_debug_su_prof(rda_handle *H, long long *out16)
@@ -2136,9 +2169,13 @@ extern "C" int rda_shard_set_chunks(rda_handle *H, const double *host_all)
 static void *rccl_sym(rda_handle *H, const char *name)
 {
     if (!H->nccl_lib) {
-        H->nccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!H->nccl_lib) H->nccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!H->nccl_lib) H->nccl_lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // The RCCL the process ALREADY has, if any: a host that imported torch brought its own librccl.so.1 (and HIP runtime) with it,
+        // and a second copy next to it breaks - default-visibility symbols of the second resolve into the first (measured:
+        // ncclCommInitRank of /opt/rocm's copy fails with ncclUnhandledCudaError once torch's is mapped).  RTLD_NOLOAD matches by SONAME.
+        H->nccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!H->nccl_lib) H->nccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!H->nccl_lib) H->nccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!H->nccl_lib) H->nccl_lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
     }
     return H->nccl_lib ? dlsym(H->nccl_lib, name) : nullptr;
 }

@@ -51,7 +51,8 @@ extern "C" int rip_emu_fits(int E, int R, int cone_norm2, int robot_norm2, int a
 extern "C" int rip_emu_solve(int E, int R, const double *A, const double *b, int cone_norm2, int robot_norm2,
                              const double *p, double phi, const double *G, const double *h,
                              const double *xi, double zeta, double dbar, double ro2, int accelerated, double mu_target,
-                             double *lam_out, double *mu_out, double *z_out, double *x_out)
+                             double *lam_out, double *mu_out, double *z_out, double *x_out, double *state /* 80: x | s.d | z.d | s.g | z.g, in (if warm) / out */,
+                             int warm, int *iters)
 {
     rip::Problem pr;
     pr.E = E; pr.R = R; pr.cone_norm2 = cone_norm2; pr.robot_norm2 = robot_norm2; pr.accelerated = accelerated;
@@ -60,7 +61,13 @@ extern "C" int rip_emu_solve(int E, int R, const double *A, const double *b, int
     pr.kappa0 = zeta - dbar; pr.ro2 = ro2; pr.mu_target = mu_target;
     static rip::Solver<HostLanes> sv;
     sv.build(pr);
-    const int st = sv.run(mu_target);
+    if (warm) {
+        V16 a, b_, c_, d_, e_;
+        for (int i = 0; i < 16; ++i) { a.v[i] = state[i]; b_.v[i] = state[16 + i]; c_.v[i] = state[32 + i]; d_.v[i] = state[48 + i]; e_.v[i] = state[64 + i]; }
+        sv.load(a, b_, c_, d_, e_);
+    }
+    const int st = sv.run(mu_target, warm != 0, iters);
+    if (state && st == 0) for (int i = 0; i < 16; ++i) { state[i] = sv.x.v[i]; state[16 + i] = sv.s.d.v[i]; state[32 + i] = sv.z.d.v[i]; state[48 + i] = sv.s.g.v[i]; state[64 + i] = sv.z.g.v[i]; }
     if (x_out) for (int i = 0; i < 16; ++i) x_out[i] = sv.x.v[i];
     if (st != 0) return st;
     for (int i = 0; i < E; ++i) { double v = sv.x.v[i]; if (!cone_norm2 && v < 0) v = 0; lam_out[i] = v; }

@@ -12,6 +12,8 @@ import ctypes as C
 import json
 import os
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 
@@ -321,6 +323,38 @@ def test_rccl_path_with_a_one_rank_communicator():
     s0, s1 = plain.get_state(), comm.get_state()
     for k in s0:
         assert np.array_equal(s0[k], s1[k]), k
+
+
+def test_rccl_path_in_a_process_that_also_has_torch():
+    """what every multi-GPU run looks like (bench.py --gpus N, tools/rccl_shard_check.py): torch - which brings its OWN librccl.so.1 and
+    HIP runtime - is imported first, librda_hip.so is loaded into the same process afterwards (it binds to the HIP runtime that is
+    already there).  The library must then use the RCCL the process already has: a second copy of librccl next to torch's fails in
+    ncclCommInitRank (measured).  One-rank communicator, every step == the plain handle.  Own process: the import order matters.
+    (The opposite order - librda_hip.so first, torch second - is not supported by TORCH: it then finds no GPU; INTEGRATION.md.)"""
+    import subprocess
+    import sys
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np
+import torch; torch.cuda.init(); x = torch.zeros(4, device='cuda')
+from rda_planner_amd.rda_solver import RDA_solver
+from rda_planner_amd.sharded import enable_rccl
+from test_sharded_gloo import _problem
+car_t, T, N, rl, steps = _problem()
+plain = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+comm = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+enable_rccl(comm, 0, 1, lambda raw: raw)
+for nom_s, nom_u, ref in steps:
+    u0, i0 = plain.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+    u1, i1 = comm.iterative_solve(nom_s, nom_u, ref, 4.0, list(rl))
+    assert np.array_equal(u0, u1) and i0['iters'] == i1['iters']
+assert comm._be.api.lib.rda_shard_comm_count(comm._be.handle) == 1
+print('RCCL_WITH_TORCH_OK')
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert "RCCL_WITH_TORCH_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_full_size_step_properties():
