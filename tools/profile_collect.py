@@ -37,7 +37,7 @@ for cfg in ("ns", "n20", "n2000", "c4", "ip"):
             d["dispatches"] = int(mm.group(2))
             d[counter.lower() + "_bytes_per_executed_launch"] = round(float(mm.group(5)) * 1024)
     # the LamMuZ step of an iteration: one kernel on small grids, the common-path + work-list + finalize kernels on dense ones (summed)
-    lm = sum(sum(v for kk, v in d.items() if kk.endswith("_launch")) for k, d in detail.items() if k.startswith(("k_lammuz", "k_lmz")))
+    lm = sum(sum(v for kk, v in d.items() if kk.endswith("_launch")) for k, d in detail.items() if k.startswith(("k_lammuz", "k_lmz")) and k != "k_lmz_finalize_all")
     su = sum(sum(v for kk, v in d.items() if kk.endswith("_launch")) for k, d in detail.items() if re.fullmatch(r"k_su<\d+>", k))
     workloads[cfg] = {"n_obs": int(m.group(2)), "horizon": int(m.group(1)), "moving": "moving" in nj["config"]["workload"],
                       "lmz_mode": 1 if cfg == "ip" else 0, "k_lammuz": lm or None, "k_su": su or None, "detail": detail}
