@@ -94,6 +94,16 @@ def check_linearisation(r, tol=0.0):
     return True
 
 
+
+def _set_status(prob, status):
+    """`Problem.status` after a solve answered from outside: a plain attribute on the stand-in, a read-only property over `_status`
+    in cvxpy proper - so that this harness (and tests/golden/make_ref_golden.py) also runs on a machine that has the real cvxpy"""
+    try:
+        prob.status = status
+    except AttributeError:
+        prob._status = status
+
+
 class OracleAnswers:
     """mode "oracle": answer Problem.solve of a reference solver's problem objects with the oracle's argmins"""
 
@@ -127,10 +137,10 @@ class OracleAnswers:
                                        C.byref(it))
         self.su_iters.append(it.value)
         if st == 0:
-            r.indep_s._value, r.indep_u._value, r.indep_dis._value = s, u, d.reshape(1, T)
-            r.prob_su.status = "optimal"
+            r.indep_s.value, r.indep_u.value, r.indep_dis.value = s, u, d.reshape(1, T)      # (public cvxpy API: Leaf.value setter)
+            _set_status(r.prob_su, "optimal")
         else:
-            r.prob_su.status = "solver_error"
+            _set_status(r.prob_su, "solver_error")
         return None
 
     # ---- one obstacle's LamMuZ problem (rda_solver.py:743-826) -------------------------------------
@@ -165,8 +175,8 @@ class OracleAnswers:
                                         float(r.ro2.value), self.cfg.delta, int(bool(r.accelerated)), dptr(lo), dptr(mo),
                                         C.cast(C.byref(zo), C.POINTER(C.c_double)), None)
             lam[:, t + 1], mu[:, t + 1], z[0, t] = lo, mo, zo.value
-        r.indep_lam_list[n]._value, r.indep_mu_list[n]._value, r.indep_z_list[n]._value = lam, mu, z
-        prob.status = "optimal"
+        r.indep_lam_list[n].value, r.indep_mu_list[n].value, r.indep_z_list[n].value = lam, mu, z
+        _set_status(prob, "optimal")
         return None
 
 

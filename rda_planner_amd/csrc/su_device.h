@@ -100,7 +100,7 @@ struct Args {
     double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
     double *lam_keep = nullptr;
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
-    // fetched after the set-up, once *ref_flag == ref_seq (agent scope)
+    // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
 };
 
@@ -253,7 +253,7 @@ __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return
 
 // The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).  TT > 0 fixes the horizon
 // at compile time (every LDS offset becomes an immediate, the stage loops get constant bounds); TT == 0 reads it from c.T.
-// RefWait: called by all threads once the set-up is done, when a.ref_flag is set - returns when the reference (a.ref) is complete
+// RefWait: called by all threads before the first use of the reference, when a.ref_flag is set - returns when the reference (a.ref) is complete
 // (k_su_tracked: another workgroup samples it meanwhile; the functor bounds the wait and samples it itself on expiry).
 struct NoRefWait { __device__ __forceinline__ void operator()(double *) const {} };
 template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(const Args &a, double *smem, RefWait ref_wait = RefWait())
@@ -657,12 +657,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // 0.1, mu0 = 10) and every hinge term in play.
     int status = 1, it = 0, used = 0;
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
-    if (a.ref_flag) {
-        __syncthreads();                       // L.part (the functor's scratch) is free from here to phase 1
-        ref_wait(L.part);
-        for (int i = tid; i < 3 * (T + 1); i += NT) L.ref[i] = a.ref[i];
-        __syncthreads();
-    }
+    bool ref_pending = a.ref_flag != nullptr;      // the reference of a tracked tick is sampled by a second workgroup: picked up at its first use
     mark(9);
     // Attempts: [-1: the warm start, at most warm_cap = 30 iterations.  Where consecutive su-problems are close (static scenes) it
     // converges within 3-4; with many moving obstacles it needs as many iterations as the cold start (8-20) but does arrive:
@@ -747,6 +742,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         }
         __syncthreads();
         mark(1);
+        if (ref_pending) {                         // (uniform) first pass of a tracked tick: the hinge sums above did not need the reference,
+            ref_pending = false;                   // the stage gradients below do.  L.part (the functor's scratch) is free from here to the next phase 1
+            ref_wait(L.part);
+            for (int i = tid; i < 3 * (T + 1); i += NT) L.ref[i] = a.ref[i];
+            __syncthreads();
+            mark(9);
+        }
         // ---- (2) per-stage derivatives wrt w = (s_next, d)  (threads < T)  ||  inequality rows: barrier weight
         //          lam/w (kept in dw, which is dead here), primal residual, predictor target  (all threads) ------
         if (tid < T) {

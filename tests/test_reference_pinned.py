@@ -263,8 +263,9 @@ def _mirror_scene(name):
         return car_t, path, (lambda k: obs), dict(receding=8, iter_num=2, max_edge_num=4, max_obs_num=4, ro1=200, obstacle_order=True), 40
     if name == "reverse_gear":                            # forward piece, then a backward piece (enable_reverse: split_path, gear flag)
         car_t = sc.rectangle_robot(dynamics="acker")
-        fwd = sc.line_path([0, 0, 0], [3, 0, 0], 0.2)
-        back = [np.array([[3.0 - 0.2 * i], [0.3], [0.0]]) for i in range(1, 26)]          # heading unchanged, x decreasing: gear -1
+        # way-points carry the gear flag as a 4th row (mpc.py:232-249 splits the path where it flips, :131 takes the sign of the speed from it)
+        fwd = [np.vstack([q, [[1.0]]]) for q in sc.line_path([0, 0, 0], [3, 0, 0], 0.2)]
+        back = [np.array([[3.0 - 0.2 * i], [0.3], [0.0], [-1.0]]) for i in range(1, 26)]   # heading unchanged, x decreasing: gear -1
         path = fwd + back
         obs = sc.scene_polygons(3, lo=(1, 4), hi=(8, 9), seed=5)
         return car_t, path, (lambda k: obs), dict(receding=8, iter_num=2, max_edge_num=4, max_obs_num=3, ro1=200, obstacle_order=True,
@@ -290,7 +291,7 @@ def test_reference_mpc_equals_the_mirror_on_more_scenes(ref, cold_orc, name):
     finally:
         mp.RDA_solver = saved
     b = OurMPC(car_t, [q.copy() for q in path], sample_time=0.1, time_print=False, _backend=oracle_backend, **kw)
-    state = path[0].copy().reshape(3, 1)
+    state = path[0][0:3].copy().reshape(3, 1)
     arrived, reversed_ = 0, False
     for k in range(steps):
         ua, ia = a.control(state.copy(), 3.0, list(obs_at(k)))
@@ -302,6 +303,8 @@ def test_reference_mpc_equals_the_mirror_on_more_scenes(ref, cold_orc, name):
         arrived += int(ia["arrive"])
         reversed_ = reversed_ or float(ua[0, 0]) < -0.05
         state = sc.kinematic_step(state, ua, car_t, 0.1)
+        if ia["arrive"] and kw.get("enable_reverse"):      # (the reference indexes past its last gear piece when called again: mpc.py:140)
+            break
     if name == "path_end_arrive":
         assert arrived > 0, "the scene is meant to reach the end of its path"
     if name == "reverse_gear":
