@@ -109,7 +109,9 @@ typedef struct rda_opts {
     double  su_warm[2];      /* [1e-3, 1e-3] slack floor / barrier parameter of a warm start ("0,0" = always cold)      RDA_SU_WARM */
     double  su_warm_endgame[2]; /* [0.9999, 1e-5] floors of the fraction to the boundary / centering parameter, warm attempts  RDA_SU_WARM_ENDGAME */
     double  su_warm_clip;    /* [0.01]                                                                                  RDA_SU_WARM_CLIP */
-    double  su_easy[5];      /* [1e-6, 1e-6, 1e-6, 0.999999, 1e-7] wfl, mu0, clip, tau, sigma of the easy start        RDA_SU_EASY */
+    double  su_easy[5];      /* [1e-12, 1e-12, 1e-12, 0.999999, 1e-7] wfl, mu0, clip, tau, sigma of the easy start: the first three lie
+                                BELOW the stop tolerances, i.e. the easy start is the previous solution itself and the stop test may
+                                accept it without a Newton step when the new problem's optimality conditions hold there  RDA_SU_EASY */
 } rda_opts;
 void rda_opts_init(rda_opts *o);
 

@@ -41,7 +41,7 @@ void orc_set_su_warm_endgame(double tau, double sig) { g_su_warm_tau = tau; g_su
 static double g_su_warm_clip = 0.01;
 void orc_set_su_warm_clip(double m) { g_su_warm_clip = m; }
 /* start used while the su-solves are easy (the last one took <= max iterations): wfl, mu0, clip, tau, sigma; max = 0 disables */
-static double g_su_easy[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; static int g_su_easy_max = 2;
+static double g_su_easy[5] = {1e-12, 1e-12, 1e-12, 0.999999, 1e-7}; static int g_su_easy_max = 2;   /* = rda_opts_init (csrc/rda_hip.hip) */
 static double cur_warm_tau = 0.9999, cur_warm_sig = 1e-5, cur_warm_clip = 0.01;     /* what the warm attempt of the solve in progress uses */
 void orc_set_su_easy(double wfl, double mu0, double clip, double tau, double sig, int max) { g_su_easy[0] = wfl; g_su_easy[1] = mu0; g_su_easy[2] = clip; g_su_easy[3] = tau; g_su_easy[4] = sig; g_su_easy_max = max; }
 static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};   /* interior-point stop of the su-problem: rd, rp, mu */

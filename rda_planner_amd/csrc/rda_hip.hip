@@ -559,6 +559,10 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx
 // MODE 2: the rows on the work list, ONE per wave (row 0 of the wave; rows 1-3 idle) and pass, straight to the enumeration, then
 //         the very same 16-lane code as modes 0 / 1 - so the results do not depend on which launch solved a row;
 //         then k_lmz_finalize: block partials from the stored terms (same function, same order as mode 0) and the tail.
+#ifdef RDA_LMZ_CLK
+__device__ unsigned long long *g_lmz_clk = nullptr;
+__device__ int *g_lmz_faillog = nullptr;          // [0] count, then (old hint, new support id, circle?) triples of the rows whose certificate failed
+#endif
 template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
 {
 #pragma clang fp contract(on)          // see lammuz_device.h
@@ -568,7 +572,16 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     __shared__ double rowv[MODE == 0 ? GS : 1][6];
     __shared__ unsigned tail_flag;
     const int T = d.c.T, E = d.c.E, R = d.c.R;
+#ifdef RDA_LMZ_CLK
+    // debug build only (tools/lmz_wave_clocks.py): clock64 ticks per section of a wave, in the wave's own 16-word slot of g_lmz_clk
+    long long clk_prev = clock64(); const long long clk_in = clk_prev; bool clk_enum = false;
+    unsigned long long *const clk_slot = g_lmz_clk ? g_lmz_clk + 16 * (size_t)(block * (GS / 4) + (threadIdx.x >> 6)) : nullptr;
+#define LMZ_CLK(k) do { if (MODE == 0) { const long long now_ = clock64(); if (clk_slot && (threadIdx.x & 63) == 0) clk_slot[k] += (unsigned long long)(now_ - clk_prev); clk_prev = now_; } } while (0)
+#else
+#define LMZ_CLK(k) do { } while (0)
+#endif
     if (d.ctrl->stop) return;
+    LMZ_CLK(0);
     int tb = 0, jb = 0;                                        // (modes 0, 1) the workgroup's block: stage and GS-slot group
     if (MODE != 2) { block_of(d, block, tb, jb); if (tb < 0) return; }      // a filler of the XCD-aware launch order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4, gl = lane & 15;
@@ -593,6 +606,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     if (gl < 2 * E) W.A[gl >> 1][gl & 1] = d.A[ao * 2 + gl];
     if (gl < E) W.b[gl] = d.b[ao + gl];
     __syncthreads();
+    LMZ_CLK(1);
     lmz::Params P;
     P.E = E; P.R = R; P.norm2 = d.cone[n];
     const double *ps = d.pose + 4 * t;                        // position of column t+1, cos / sin of the heading of column t (quirk Q1)
@@ -625,7 +639,9 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
+    LMZ_CLK(2);
     bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[zi], best);
+    LMZ_CLK(3);
     if (MODE != 2 && !live && !ok) {                           // a dead row never asks for the enumeration; nothing of `best` is used
         best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
         best.l1 = best.l2 = best.g1 = best.g2 = 0;
@@ -684,7 +700,15 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         __syncthreads();
         if (mine) best = sol[wv * 4 + row];
         need = 0;
+#ifdef RDA_LMZ_CLK
+        clk_enum = nf > 0;
+        if (mine && gl == 0 && live && g_lmz_faillog) {
+            const int k = atomicAdd(&g_lmz_faillog[0], 1);
+            if (k < 200000) { g_lmz_faillog[1 + 3 * k] = d.hint[zi]; g_lmz_faillog[2 + 3 * k] = best.id >> 1; g_lmz_faillog[3 + 3 * k] = P.norm2; }
+        }
+#endif
     }
+    LMZ_CLK(4);
     while (need) {
         const int g = (__ffsll((long long)need) - 1) >> 4;
         need &= ~(0xffffull << (16 * g));
@@ -700,6 +724,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     }
     if (gl == 0 && live && !defer) d.hint[zi] = best.id >> 1;
     if (d.centre) lmz::central_normal_wave<16>(W, rb, P, lane, best);
+    LMZ_CLK(5);
     bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));      // uniform over the row
     // ---- fused dual / residual updates (every lane of the row holds the row's winner) ----------------
     const double znew = (d.c.accelerated ? 0.5 : 1.0) * (best.m > 0 ? best.m : 0.0);     // tie-break T2
@@ -753,13 +778,23 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
             else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
         }
     }
+    LMZ_CLK(6);
     if (MODE == 0) {
         __syncthreads();
         block_partial(d, tb, jb, rowv, threadIdx.x);
         if (tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
         else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
     }
+    LMZ_CLK(7);
+#ifdef RDA_LMZ_CLK
+    if (MODE == 0 && clk_slot && (threadIdx.x & 63) == 0) {
+        const unsigned long long tot = (unsigned long long)(clock64() - clk_in);
+        clk_slot[8] += 1; clk_slot[9] += tot; if (tot > clk_slot[10]) clk_slot[10] = tot;
+        if (clk_enum) { clk_slot[11] += 1; clk_slot[12] += tot; }
     }
+#endif
+    }
+#undef LMZ_CLK
 }
 
 // two builds: all registers and one wave per SIMD (no spills: the shorter critical path a single ego wants), or two
@@ -1164,7 +1199,10 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
-    { const double ez[5] = {1e-6, 1e-6, 1e-6, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) o->su_easy[i] = ez[i]; }
+    // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
+    // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
+    // conditions already hold there (a converging ADMM in a static scene: 57 % of the north-star solves) - zero Newton steps
+    { const double ez[5] = {1e-12, 1e-12, 1e-12, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) o->su_easy[i] = ez[i]; }
     auto geti = [](const char *name, int32_t *v) { const char *e = getenv(name); if (e && *e) *v = atoi(e); };
     auto getd = [](const char *name, double *v) { const char *e = getenv(name); if (e && *e) *v = atof(e); };
     geti("RDA_LMZ_MODE", &o->lmz_mode); geti("RDA_TIE_CENTRE", &o->tie_centre); getd("RDA_LMZ_MU", &o->lmz_mu);
@@ -1982,6 +2020,35 @@ extern "C" int rda_enqueue_range(rda_handle *H, int k0, int k1)
     return RDA_OK;
 }
 
+#ifdef RDA_LMZ_CLK
+extern "C" int rda_debug_lmz_clk(rda_handle *H, unsigned long long *out, int max_waves)     // out[max_waves][16]; reads and clears
+{
+    static unsigned long long *buf = nullptr; static int cap = 0;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (!buf) {
+        cap = max_waves;
+        HIPCHK(hipMalloc((void **)&buf, (size_t)cap * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(buf, 0, (size_t)cap * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lmz_clk), &buf, sizeof(buf)));
+        return RDA_OK;
+    }
+    if (max_waves < 0) {          // the fail log instead: out = int[1 + 3 * 200000]; first call arms it
+        static int *flog = nullptr;
+        if (!flog) {
+            HIPCHK(hipMalloc((void **)&flog, (1 + 3 * 200000) * sizeof(int))); HIPCHK(hipMemset(flog, 0, (1 + 3 * 200000) * sizeof(int)));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lmz_faillog), &flog, sizeof(flog)));
+            return RDA_OK;
+        }
+        HIPCHK(hipMemcpy(out, flog, (1 + 3 * 200000) * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(flog, 0, sizeof(int)));
+        return RDA_OK;
+    }
+    if (max_waves > cap) return RDA_ERR_ARG;
+    HIPCHK(hipMemcpy(out, buf, (size_t)max_waves * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(buf, 0, (size_t)cap * 16 * sizeof(unsigned long long)));
+    return RDA_OK;
+}
+#endif
 #ifdef RDA_LMZ_STATS
 extern "C" int rda_debug_lmz_stats(rda_handle *H, unsigned *out)
 {

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--moving", action="store_true")
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--order", action="store_true", help="re-sort the obstacles by distance every tick (MPC default; the headline loop of bench.py keeps the slot binding fixed)")
+    ap.add_argument("--iter-num", type=int, default=0, help="ADMM iterations per step (1: only the FIRST su-solve of every tick - the one inside k_su_tracked - is profiled)")
     args = ap.parse_args()
     import bench
     from rda_planner_amd.mpc import MPC
@@ -30,6 +31,8 @@ def main():
     from rda_planner_amd._lib import hip_api
     car_t, path, obstacles, kw = bench.build_workload(n_obs=args.n_obs, T=args.horizon, n_steps=args.steps + 20, moving=args.moving)
     kw["obstacle_order"] = bool(args.order)
+    if args.iter_num:
+        kw["iter_num"] = args.iter_num
     mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, hip_opts=hip_options(su_prof=1), **kw)
     lib = hip_api().lib
     state = path[0].copy().reshape(3, 1)
