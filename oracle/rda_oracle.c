@@ -50,6 +50,11 @@ static int g_lmz_mode = 0;   /* 0: support enumeration + tie-breaks T1-T3, 1: in
 void orc_set_lmz_mode(int mode) { g_lmz_mode = mode ? 1 : 0; }
 static int g_centre = 1;     /* tie-break T1: central separating normal in the slack regime (orc_set_centre(0): max clearance) */
 void orc_set_centre(int on) { g_centre = on; }
+/* debug aids of the su interior point (not used by any test's comparison): orc_set_su_dump(path) records every su-problem orc_admm_su
+ * solves (NULL / "": off), orc_set_su_trace(1) prints one line per interior-point iteration to stderr */
+static FILE *g_su_dump = NULL; static int g_su_trace = 0;
+void orc_set_su_dump(const char *path) { if (g_su_dump) fclose(g_su_dump); g_su_dump = (path && path[0]) ? fopen(path, "wb") : NULL; }
+void orc_set_su_trace(int on) { g_su_trace = on; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 
 struct orc_handle {
@@ -792,6 +797,20 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
             if (dw[i] < 0 && -tau * w[i] / dw[i] < al) al = -tau * w[i] / dw[i];
             if (dl[i] < 0 && -tau * lm[i] / dl[i] < al) al = -tau * lm[i] / dl[i];
         }
+        if (g_su_trace) {            /* residuals of this iterate, the step taken from it, active hinge terms, the row that blocks the step */
+            int nact = 0, blk = -1; double dxn = 0, bal = 2;
+            for (int t = 0; t < T; ++t) for (int nn = 0; nn < N; ++nn) {
+                const double *aa = &a[(nn * T + t) * 2];
+                nact += aa[0] * s[t + 1] + aa[1] * s[(T + 1) + t + 1] - cc[nn * T + t] - x[2 * T + t] < 0;
+            }
+            for (int i = 0; i < n; ++i) if (fabs(dx[i]) > dxn) dxn = fabs(dx[i]);
+            for (int i = 0; i < mc; ++i) {
+                if (dw[i] < 0 && -w[i] / dw[i] < bal) { bal = -w[i] / dw[i]; blk = i; }
+                if (dl[i] < 0 && -lm[i] / dl[i] < bal) { bal = -lm[i] / dl[i]; blk = -i - 1; }
+            }
+            fprintf(stderr, "it %2d rd %.2e rp %.2e mu %.2e sigma %.1e step %.4f active hinges %4d |dx| %.2e blocked by %s %d\n",
+                    it, rdn, rpn, mu, sigma, al, nact, dxn, blk < 0 ? "multiplier" : "slack", blk < 0 ? -blk - 1 : blk);
+        }
         for (int i = 0; i < n; ++i) x[i] += al * dx[i];
         for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += al * dl[i]; }
     }
@@ -986,6 +1005,13 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
         cg[(n * T + t) * 2] = o8[4]; cg[(n * T + t) * 2 + 1] = o8[5];
     }
     int ipm = 0;
+    if (g_su_dump) {            /* debug: every su-problem of a run, cfg + orc_su_solve's arguments (tools/su_replay.py replays them) */
+        double hd[4] = { (double)T, (double)N, H->ref_speed, (double)it };
+        fwrite(c, sizeof(orc_cfg), 1, g_su_dump); fwrite(hd, sizeof(double), 4, g_su_dump);
+        fwrite(H->s, sizeof(double), 3 * (T + 1), g_su_dump); fwrite(H->u, sizeof(double), 2 * T, g_su_dump);
+        fwrite(H->ref, sizeof(double), 3 * (T + 1), g_su_dump); fwrite(ca, sizeof(double), N * T * 2, g_su_dump); fwrite(cc, sizeof(double), N * T, g_su_dump);
+        fwrite(cg, sizeof(double), N * T * 2, g_su_dump); fwrite(H->dis, sizeof(double), T, g_su_dump); fflush(g_su_dump);
+    }
     /* ADMM iterations >= 1 start from the multipliers of the previous su-solve of this step, if that one converged */
     /* ... and the first one from those of the previous step, shifted by one stage */
     const int warm = g_su_warm_mu0 > 0 && (it > 0 ? !((H->su_status >> (it - 1)) & 1) : g_su_warm_first);

@@ -52,6 +52,8 @@ void orc_destroy(orc_handle *h);
 int  orc_set_adjust(orc_handle *h, double slack_gain, double max_sd, double min_sd, double ro1, double ro2);
 int  orc_reset(orc_handle *h);      /* rda_solver.py:1060-1068 */
 void orc_set_threads(int n);
+void orc_set_su_dump(const char *path);   /* debug: record every su-problem orc_admm_su solves (tools/su_replay.py) */
+void orc_set_su_trace(int on);            /* debug: one stderr line per interior-point iteration */
 void orc_set_lmz_mode(int mode);   /* LamMuZ sub-problems of orc_step: 0 support enumeration (tie-breaks T1-T3), 1 interior point (lmz_ipm.c) */
 int  orc_lmz_failures(orc_handle *h);   /* sub-problems of the last step whose solve was not OPTIMAL (previous duals kept, residual inf) */
 void orc_set_lmz_ipm_tol(double tol);
