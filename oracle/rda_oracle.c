@@ -797,7 +797,11 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
             if (dw[i] < 0 && -tau * w[i] / dw[i] < al) al = -tau * w[i] / dw[i];
             if (dl[i] < 0 && -tau * lm[i] / dl[i] < al) al = -tau * lm[i] / dl[i];
         }
-        if (g_su_trace) {            /* residuals of this iterate, the step taken from it, active hinge terms, the row that blocks the step */
+        if (g_su_trace == 2 && g_su_dump) {      /* (tools/experiments/scan_riccati.py) the iterate the factorisation of this iteration belongs to */
+            double hd[3] = { (double)it, (double)mc, (double)n };
+            fwrite(hd, sizeof(double), 3, g_su_dump); fwrite(x, sizeof(double), n, g_su_dump); fwrite(w, sizeof(double), mc, g_su_dump); fwrite(lm, sizeof(double), mc, g_su_dump);
+        }
+        if (g_su_trace == 1) {       /* residuals of this iterate, the step taken from it, active hinge terms, the row that blocks the step */
             int nact = 0, blk = -1; double dxn = 0, bal = 2;
             for (int t = 0; t < T; ++t) for (int nn = 0; nn < N; ++nn) {
                 const double *aa = &a[(nn * T + t) * 2];
