@@ -265,6 +265,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
     const bool prof_on = a.prof != nullptr;
     auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
+#ifdef SU_FINE      // one-off build for tools/su_phase_profile.py --fine: the set-up slots are re-used for sub-phases of the iteration
+#define MS(k) mark(10)
+#define MF(k) mark(k)
+#else
+#define MS(k) mark(k)
+#define MF(k)
+#endif
     const double vref = *a.ref_speed;
     // (stage, chunk) mapping of the obstacle reductions
     const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
@@ -310,7 +317,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     for (int i = tid; i < 2 * T; i += NT)
         L.p0[i] = (masks_in && a.pose_ok) ? a.pose[4 * (i % T) + i / T] : a.in_s[(i / T) * (T + 1) + (i % T) + 1];
     __syncthreads();
-    mark(0);
+    MS(0);
     if (tid < T) {
         int t = tid;
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
@@ -329,7 +336,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
     __syncthreads();
-    mark(11);
+    MS(11);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
     auto clip_controls = [&](const double clipm) {          // (the nominal controls / distances: the registers prefetched above)
         if (tid < T) {
@@ -379,7 +386,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         }
     };
     rollout();
-    mark(13);
+    MS(13);
     // slacks floored at wfl, multipliers lam = mu0 / w  (first attempt: 1e-2 and 1)
     auto centre_duals = [&](double wfl, double mu0) {
         for (int i = tid; i < NC * T; i += NT) {
@@ -459,7 +466,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 }
             }
         }
-        mark(3);
+        MS(3);
         if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %;
             double cnt = 0;        // and the nominal itself must lie within DELTA of the screening reference
             for (int w = 0; w < MW; ++w) cnt += (double)__popcll(amask[w]);
@@ -469,7 +476,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             if (masks_in) dv = block_reduce(dv, L.red, tid, true);
             if (cnt > 0.3 * (double)a.P * a.Nloc * T || dv > 0.5 * DELTA) screened = false;
         }
-        mark(14);
+        MS(14);
         L.part[tid * 9] = saa; L.part[tid * 9 + 1] = sga; L.part[tid * 9 + 2] = sgx;
         __syncthreads();
         if (tid < T) {
@@ -479,7 +486,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             L.Q2[tid] = s0; L.Q1[tid] = 2 * (L.csn[tid] * s2 - L.csn[T + tid] * s1);
         }
     }
-    mark(12);
+    MS(12);
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
@@ -523,32 +530,40 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // x+ = row . x[0..4] + c with x held by lanes 0..4 of the row: v_fmac_f64 with a DPP row_newbcast source operand
     // (gfx90a+ allows DPP on 64-bit VALU ops for row_newbcast) - one instruction per term instead of two v_readlane
     // and an FMA.  s_nop 1: a VGPR written by the previous VALU op needs two wait states before a DPP read.
+    // One accumulator: a single wave issues an instruction every ~6.4 cycles whether or not it depends on the previous one
+    // (tools/latency_micro.cpp), so a second accumulator only adds its initialisation and the final addition to the stage.
     auto affine = [&](const Row &k, double x) {
-        double e0 = RW(k, 5), e1 = 0.0;
+        double e0 = RW(k, 5);
         asm volatile("s_nop 1\n\t"
-                     "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf"
-                     : "+v"(e0), "+v"(e1) : "v"(x), "v"(RW(k, 0)), "v"(RW(k, 1)), "v"(RW(k, 2)), "v"(RW(k, 3)), "v"(RW(k, 4)));
-        return e0 + e1;
+                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(e0) : "v"(x), "v"(RW(k, 0)), "v"(RW(k, 1)), "v"(RW(k, 2)), "v"(RW(k, 3)), "v"(RW(k, 4)));
+        return e0;
     };
     // backward: [p ; kk] <- Mb [p] + cb   (lanes 0..4 carry p, lanes 5..7 deliver kk).  Only lanes 0..7 are active
     // (v_readlane ignores EXEC), so the per-stage stores need no predicate.
+    // The rows of a stage are requested PD stages ahead (a ring of PD register rows): one stage of the map is ~56 cycles of dependent
+    // FMAs (tools/dpp_micro.cpp) while an LDS read needs ~100 - with the rows of the NEXT stage only (round 1-2) every stage waited
+    // for its rows: 151 cycles per stage measured in the kernel.
+    constexpr int PD = 4;
     auto bwd_all = [&]() {
         if (lane < 8) {
             double pl = 0;
-            Row ka, kb;
-            ldrow(L.Hb + HB * (T - 1) + 6 * lane, ka);
-            for (int t = T - 1; t >= 0; t -= 2) {
-                if (t >= 1) ldrow(L.Hb + HB * (t - 1) + 6 * lane, kb);
-                pl = affine(ka, pl);
-                L.kk[8 * t + lane] = pl;
-                if (t >= 1) {
-                    if (t >= 2) ldrow(L.Hb + HB * (t - 2) + 6 * lane, ka);
-                    pl = affine(kb, pl);
-                    L.kk[8 * (t - 1) + lane] = pl;
+            Row k[PD];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) if (T - 1 - j >= 0) ldrow(L.Hb + HB * (T - 1 - j) + 6 * lane, k[j]);
+            for (int t0 = T - 1; t0 >= 0; t0 -= PD) {
+#pragma unroll
+                for (int j = 0; j < PD; ++j) {
+                    const int t = t0 - j;
+                    if (t >= 0) {
+                        pl = affine(k[j], pl);
+                        L.kk[8 * t + lane] = pl;
+                        if (t - PD >= 0) ldrow(L.Hb + HB * (t - PD) + 6 * lane, k[j]);
+                    }
                 }
             }
         }
@@ -566,18 +581,19 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         if (lane < 8) {
             const int row = lane < 6 ? lane : 5;
             double xl = 0;
-            Row ka, kb;
-            ldrow(L.Mf + 6 * row, ka);
-            for (int t = 0; t < T; t += 2) {
-                if (t + 1 < T) ldrow(L.Mf + MF * (t + 1) + 6 * row, kb);
-                L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
-                xl = affine(ka, xl);
-                L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
-                if (t + 1 < T) {
-                    if (t + 2 < T) ldrow(L.Mf + MF * (t + 2) + 6 * row, ka);
-                    L.dy[8 * (t + 1) + lane] = xl;
-                    xl = affine(kb, xl);
-                    L.vv[8 * (t + 1) + lane] = xl;
+            Row k[PD];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) if (j < T) ldrow(L.Mf + MF * j + 6 * row, k[j]);
+            for (int t0 = 0; t0 < T; t0 += PD) {
+#pragma unroll
+                for (int j = 0; j < PD; ++j) {
+                    const int t = t0 + j;
+                    if (t < T) {
+                        L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
+                        xl = affine(k[j], xl);
+                        L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
+                        if (t + PD < T) ldrow(L.Mf + MF * (t + PD) + 6 * row, k[j]);
+                    }
                 }
             }
             if (lane < 3) L.pv[lane] = xl;
@@ -658,7 +674,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     int status = 1, it = 0, used = 0;
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
     bool ref_pending = a.ref_flag != nullptr;      // the reference of a tracked tick is sampled by a second workgroup: picked up at its first use
-    mark(9);
+    MS(9);
     // Attempts: [-1: the warm start, at most warm_cap = 30 iterations.  Where consecutive su-problems are close (static scenes) it
     // converges within 3-4; with many moving obstacles it needs as many iterations as the cold start (8-20) but does arrive:
     // cutting it at 5 / 7 / 12 iterations and starting over cost +29 / +35 / +5 % on the dynamic_obs benchmark, 30 costs
@@ -747,7 +763,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             ref_wait(L.part);
             for (int i = tid; i < 3 * (T + 1); i += NT) L.ref[i] = a.ref[i];
             __syncthreads();
-            mark(9);
+            MS(9);
         }
         // ---- (2) per-stage derivatives wrt w = (s_next, d)  (threads < T)  ||  inequality rows: barrier weight
         //          lam/w (kept in dw, which is dead here), primal residual, predictor target  (all threads) ------
@@ -781,6 +797,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             L.rc[i] = l * w;                                          // affine (predictor) target
         }
         __syncthreads();
+        MF(14);
         // ---- (3) stage gradients and stage Hessian bases  J' Hw J + direct + barrier  (all threads) -------
         // J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
         for (int i = tid; i < 8 * T; i += NT) {
@@ -796,6 +813,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             else if (j == 7) v += lam[4] - lam[5];
             L.gst[i] = v;
         }
+        MF(12);
         // (skipped in a pass that is expected to be the convergence check only, see `expect_conv`)
         if (!expect_conv)
         for (int i = tid; i < 8 * T; i += NT) {               // one thread per (stage, row): Hw and the row's J column stay in registers
@@ -962,6 +980,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 __syncthreads();
                 if (tid < T) build_gh(tid);
                 __syncthreads();
+                MF(9);
             }
             build_cb();
             __syncthreads();
@@ -984,7 +1003,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 if (dwv < 0) { double x = -fr * L.cw[i] / dwv; if (x < al) al = x; }
                 if (dlv < 0) { double x = -fr * L.cl[i] / dlv; if (x < al) al = x; }
             }
+            MF(15);
             al = -block_reduce(-al, L.red, tid, true);
+            MF(0);
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
                 double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? a.warm_sig : SIGMA_FLOOR) : 0.03;
@@ -999,12 +1020,14 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 }
                 if (tid < 3) L.s[tid * (T + 1) + T] += al * L.pv[tid];
                 __syncthreads();
+                MF(11);
                 if (screened) {        // the screening holds only while every stage stays within DELTA of its reference position
                     double dv = 0;
                     if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
                     dv = block_reduce(dv, L.red, tid, true);
                     if (dv > DELTA) screened = false;      // from the next iteration on: every term (the streaming loop)
                 }
+                MF(13);
                 // Light convergence pass: the residuals of a Newton step of length al shrink by (1 - al) (the dynamics are
                 // eliminated exactly, the constraints are affine) and the new complementarity is known now.  When these predict
                 // that the stop test will hold, the next pass evaluates the TRUE measures only - no Hessian bases, no Riccati
@@ -1053,6 +1076,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
 }
 #undef RW
 #undef R5
+#undef MS
+#undef MF
 #undef LDS_DRAIN
 
 }  // namespace su

@@ -9,7 +9,8 @@ from pdas_su import lin_model
 def iterates(l, pr):
     """(x, w, lam) of every interior-point iteration of the cold solve of one recorded problem (oracle trace mode 2)"""
     import os
-    path = "scratch/_iter.bin"
+    from su_replay import SCRATCH
+    path = os.path.join(SCRATCH, "_iter.bin")
     l.orc_set_su_dump(path.encode()); l.orc_set_su_trace(2); solve(l, pr); l.orc_set_su_trace(0); l.orc_set_su_dump(b"")
     raw = np.fromfile(path); off = 0; out = []
     while off < len(raw):

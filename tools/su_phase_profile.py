@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--moving", action="store_true")
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--order", action="store_true", help="re-sort the obstacles by distance every tick (MPC default; the headline loop of bench.py keeps the slot binding fixed)")
+    ap.add_argument("--fine", action="store_true", help="the library was built with -DSU_FINE (make -C rda_planner_amd/csrc CXXFLAGS+=-DSU_FINE): the set-up slots carry sub-phases of the iteration, the whole set-up is booked under slot 10")
     ap.add_argument("--iter-num", type=int, default=0, help="ADMM iterations per step (1: only the FIRST su-solve of every tick - the one inside k_su_tracked - is profiled)")
     args = ap.parse_args()
     import bench
@@ -47,10 +48,14 @@ def main():
         elif k > 9:
             solves += info["iters"]; ipm += info["su_ipm_iters"]
     assert lib.rda_debug_su_prof(mpc.rda._be.handle, out) == 0
+    if args.fine:
+        NAMES.update({14: "(2) stage derivatives + inequality rows", 12: "(3a) stage gradients", 2: "(3b) Hessian bases", 9: "(6a) corrector rc + gh", 6: "(6b) sweep constants",
+                      15: "(8a) slack / multiplier rows", 0: "(8b) step-length reduction", 11: "(8c) update", 13: "(8d) reach check", 8: "(8e) sigma / light check",
+                      10: "set-up + final roll-out + write-back", 3: "-", })
     tot = sum(out)
     print(f"T={args.horizon} N={args.n_obs} moving={args.moving}: {solves} su-solves, {ipm / solves:.2f} interior-point iterations per solve, "
           f"{tot / solves:.0f} ticks per solve")
-    for k in (0, 11, 13, 9, 3, 14, 12, 1, 2, 4, 5, 6, 7, 8, 10):
+    for k in ((1, 14, 12, 2, 4, 5, 9, 6, 7, 15, 0, 11, 13, 8, 10) if args.fine else (0, 11, 13, 9, 3, 14, 12, 1, 2, 4, 5, 6, 7, 8, 10)):
         print(f"  [{k:2d}] {NAMES[k]:34s} {out[k] / solves:9.0f} ticks/solve  {100.0 * out[k] / tot:5.1f} %")
 
 

@@ -3,7 +3,7 @@
 replays them through `orc_su_solve` (the cold interior point the kernel's cold attempt mirrors), so that changes to the iteration can be
 counted in interior-point iterations before any GPU time is spent.
 
-    python tools/su_replay.py record c4 --n-obs 200 --horizon 30 --steps 30 --moving     # -> scratch/su_c4.bin (cfg + arguments per solve)
+    python tools/su_replay.py record c4 --n-obs 200 --horizon 30 --steps 30 --moving     # -> /tmp/rda_su_replay/su_c4.bin (cfg + arguments per solve)
     python tools/su_replay.py count c4                                                    # iterations per solve, by ADMM iteration index
     python tools/su_replay.py trace c4 40 41                                              # per-iteration trace of problems 40, 41 (stderr)
     python tools/su_replay.py distance c4          # how far a solution is from its nominal / from the previous step's solution (shifted)
@@ -36,9 +36,12 @@ def _lib():
     return l
 
 
+SCRATCH = os.environ.get("RDA_SU_REPLAY_DIR", "/tmp/rda_su_replay")     # recordings are tens of MB: kept out of the tree (it travels to the GPU box)
+
+
 def _path(name):
-    os.makedirs(os.path.join(ROOT, "scratch"), exist_ok=True)
-    return os.path.join(ROOT, "scratch", f"su_{name}.bin")
+    os.makedirs(SCRATCH, exist_ok=True)
+    return os.path.join(SCRATCH, f"su_{name}.bin")
 
 
 def record(name, n_obs, T, steps, moving):
