@@ -1618,12 +1618,17 @@ extern "C" const char *rda_lammuz_kernel(rda_handle *H)
     if (d.lmz_mode && !(H->ip_rows && d.obstacle_num)) return (d.c.E <= 4 && d.c.R <= 4) ? "k_lammuz_cp_small+k_lmz_finalize" : "k_lammuz_cp_large+k_lmz_finalize";
     if (d.lmz_mode) return "k_lammuz_ip";
     if (d.rows && d.obstacle_num) {
-        const int cus = (d.c.T * d.J * (64 * GS / 4) + 255) / 256;
-        if (cus > H->dense_from && H->lmz_split) return "k_lammuz_rows_fast+k_lammuz_enum+k_lmz_finalize";
-        return cus > H->dense_from ? "k_lammuz_rows_dense" : "k_lammuz_rows";
+        const int cus = (d.c.T * d.J * (64 * GS / 4) + 255) / 256, dense_from = d.nt > 1 ? H->dense_from * 7 / 4 : H->dense_from;
+        if (cus > dense_from && H->lmz_split) return "k_lammuz_rows_fast+k_lammuz_enum+k_lmz_finalize";
+        return cus > dense_from ? "k_lammuz_rows_dense" : "k_lammuz_rows";
     }
     return "k_lammuz+k_lmz_finalize";
 }
+// Grid size (in compute units at one wave per SIMD) from which the split form of the LamMuZ launch is used.  Scenes with per-stage
+// obstacle data (moving obstacles) lose the remembered support of more rows per launch, so the work list of the split form is longer and
+// the single launch stays ahead up to a larger grid: measured cross-over ~280 CUs for static scenes (N = 300, T = 20: 35.7 vs 38.7 us),
+// ~560 for moving ones (T = 30: N = 200 40.9 vs 47.1 us for the single launch, N = 300 52.2 vs 50.1, N = 400 60.7 vs 51.1).
+static inline int dense_threshold(const rda_handle *H, const Dev &d) { return d.nt > 1 ? H->dense_from * 7 / 4 : H->dense_from; }
 static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
 {
     if (d.Nlive == 0) return;                    // a shard without obstacles (N < P)
@@ -1639,13 +1644,14 @@ static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
     if (d.rows && d.obstacle_num) {
         constexpr int NTH = 64 * GS / 4;             // threads of a packed workgroup (2 waves)
         const int nb = packed_grid(d.c.T, d.J), cus = (units / GS * NTH + 255) / 256;      // launch indices (XCD-aware order, a few fillers); CUs the grid asks for at one wave per SIMD
-        if (cus > H->dense_from && H->lmz_split) {
+        const int dense_from = dense_threshold(H, d);
+        if (cus > dense_from && H->lmz_split) {
             // dense grid: common path with three waves per SIMD, then the deferred rows one per wave (see lammuz_body_rows)
             hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(NTH), 0, H->stream, d);
             int ne = units / 32; if (ne < 64) ne = 64; if (ne > 2048) ne = 2048;
             hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(NTH), 0, H->stream, d);
             launch_finalize(H, d, it, fin);
-        } else if (cus > H->dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
+        } else if (cus > dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
         else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
     } else {
         hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
