@@ -268,6 +268,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
     if (a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
+    a.term_cache = a.warm_mu0 == 0 || d.ctrl->su_last > 1;       // cold start or a hard predecessor: several interior-point iterations ahead
     su::solve<TT>(a, smem_su, ref_wait);
     __syncthreads();
     if (tid == 0) {

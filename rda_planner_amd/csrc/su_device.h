@@ -99,6 +99,9 @@ struct Args {
     int warm_nopred = 0;             // the first iteration of the warm attempt is a plain Newton step towards sigma*mu (no predictor)
     double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
     double *lam_keep = nullptr;
+    // keep the first near terms of every thread's slice in registers after the first pass that visits them (pays when the solve takes
+    // several interior-point iterations; a one-pass solve only sees the longer code: the caller says which it expects)
+    int term_cache = 1;
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
@@ -369,8 +372,19 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 inc[3 * t + 1] = (B[2] * u0 + B[3] * u1) + C[1];
             }
             wsync();
+            // (the increments are fetched into registers first: a load behind a store into the same LDS buffer cannot be hoisted by the
+            // compiler, and one LDS round trip per stage was two thirds of this roll-out)
             if (lane == 0) {
                 double ph = L.s[2 * (T + 1)];
+                if constexpr (TT > 0) {
+                    double v[TT];
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) v[t] = inc[3 * t + 2];
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) { ph += v[t]; v[t] = ph; }
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) L.s[2 * (TT + 1) + t + 1] = v[t];
+                } else
                 for (int t = 0; t < T; ++t) { ph += inc[3 * t + 2]; L.s[2 * (T + 1) + t + 1] = ph; }
             }
             wsync();
@@ -381,6 +395,15 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             wsync();
             if (lane == 0) {
                 double x = L.s[0], y = L.s[T + 1];
+                if constexpr (TT > 0) {
+                    double vx[TT], vy[TT];
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) { vx[t] = inc[3 * t]; vy[t] = inc[3 * t + 1]; }
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) { x += vx[t]; y += vy[t]; vx[t] = x; vy[t] = y; }
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) { L.s[t + 1] = vx[t]; L.s[(TT + 1) + t + 1] = vy[t]; }
+                } else
                 for (int t = 0; t < T; ++t) { x += inc[3 * t]; y += inc[3 * t + 1]; L.s[t + 1] = x; L.s[(T + 1) + t + 1] = y; }
             }
         }
@@ -424,6 +447,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     constexpr int MW = 4;
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
+    constexpr int KC = 6;                                       // near terms kept in registers (the rest of the mask: rmask, fetched per pass)
+    double cax[KC] = {0, 0, 0, 0, 0, 0}, cay[KC] = {0, 0, 0, 0, 0, 0}, ccb[KC] = {0, 0, 0, 0, 0, 0};
+    unsigned long long rmask[MW] = {0, 0, 0, 0}; int ncache = -1;      // -1: not fetched yet
     bool screened = c.accelerated && a.P * KB * GS <= 64 * MW && (!masks_in || a.pose_ok);
     {
         double saa = 0, sga = 0, sgx = 0;
@@ -707,10 +733,53 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                     }
                 };
                 const int Nl = a.Nloc;
-                if (screened) {
+                if (screened && !a.term_cache) {
                     // visit only the terms that may be active, four loads in flight
                     for (int w = 0; w < MW; ++w) {
                         unsigned long long m = amask[w];
+                        while (m) {
+                            size_t off[4]; int cnt = 0;
+                            while (m && cnt < 4) {
+                                const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
+                                const int blk = bit / GS, row = bit % GS;
+                                const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
+                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
+                            }
+                            double x[4], y[4], cb[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (q < cnt) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.cb[off[q]]; }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (q < cnt) term(x[q], y[q], cb[q]);
+                        }
+                    }
+                } else if (screened) {
+                    // (solves that take several interior-point iterations) the cached terms, then the rest of the mask with four loads in flight
+                    // The first KC near terms of the thread's slice are fetched by the first pass that visits them and stay in registers: every
+                    // later pass used to start with the same trip to the L2.  (Not fetched ahead in the set-up: a barrier waits for outstanding
+                    // loads, the trip would only move.)  Same terms, same order.
+                    if (ncache < 0) {
+                        unsigned long long m0 = amask[0], m1 = amask[1], m2 = amask[2], m3 = amask[3];
+                        ncache = 0;
+#pragma unroll
+                        for (int k = 0; k < KC; ++k) {
+                            int bit = -1;
+                            if (m0) { bit = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
+                            else if (m1) { bit = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
+                            else if (m2) { bit = 128 + __ffsll((long long)m2) - 1; m2 &= m2 - 1; }
+                            else if (m3) { bit = 192 + __ffsll((long long)m3) - 1; m3 &= m3 - 1; }
+                            if (bit >= 0) {
+                                const int blk = bit / GS, row = bit % GS;
+                                const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
+                                const size_t off = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
+                                cax[k] = a.ax[off]; cay[k] = a.ay[off]; ccb[k] = a.cb[off]; ncache = k + 1;
+                            }
+                        }
+                        rmask[0] = m0; rmask[1] = m1; rmask[2] = m2; rmask[3] = m3;
+                    }
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) if (k < ncache) term(cax[k], cay[k], ccb[k]);
+                    for (int w = 0; w < MW; ++w) {
+                        unsigned long long m = rmask[w];
                         while (m) {
                             size_t off[4]; int cnt = 0;
                             while (m && cnt < 4) {
@@ -1050,6 +1119,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // consistent final rollout (removes accumulated rounding in s)
     rollout();
     __syncthreads();
+    mark(15);
     if (status == 0 && a.lam_keep) for (int i = tid; i < NC * T; i += NT) a.lam_keep[i] = L.cl[i];
     if (status == 0) {       // otherwise keep the nominal (reference :696-700)
         for (int i = tid; i < 3 * (T + 1); i += NT) a.out_s[i] = L.s[i];

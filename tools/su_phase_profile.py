@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {0: "load nominal", 11: "linearise", 13: "clip + roll-out", 3: "term sums / masks", 14: "density + reach check", 12: "stage sums",
          9: "duals start + reference", 1: "hinge sums", 2: "gradients + Hessian bases", 4: "Riccati / adjoint / measures", 5: "closed-loop matrices + verdict",
-         6: "rhs", 7: "vector sweeps", 8: "slack / multiplier step", 10: "final roll-out + write-back"}
+         6: "rhs", 7: "vector sweeps", 8: "slack / multiplier step", 15: "final roll-out", 10: "write-back + pose table"}
 
 
 def main():
@@ -55,7 +55,7 @@ def main():
     tot = sum(out)
     print(f"T={args.horizon} N={args.n_obs} moving={args.moving}: {solves} su-solves, {ipm / solves:.2f} interior-point iterations per solve, "
           f"{tot / solves:.0f} ticks per solve")
-    for k in ((1, 14, 12, 2, 4, 5, 9, 6, 7, 15, 0, 11, 13, 8, 10) if args.fine else (0, 11, 13, 9, 3, 14, 12, 1, 2, 4, 5, 6, 7, 8, 10)):
+    for k in ((1, 14, 12, 2, 4, 5, 9, 6, 7, 15, 0, 11, 13, 8, 10) if args.fine else (0, 11, 13, 9, 3, 14, 12, 1, 2, 4, 5, 6, 7, 8, 15, 10)):
         print(f"  [{k:2d}] {NAMES[k]:34s} {out[k] / solves:9.0f} ticks/solve  {100.0 * out[k] / tot:5.1f} %")
 
 
