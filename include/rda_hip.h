@@ -83,7 +83,7 @@ typedef struct rda_opts {
     /* ---- A/B switches (defaults in brackets) ---- */
     int32_t lmz_warm;        /* [1] try the remembered support first                                                   RDA_LMZ_WARM */
     int32_t lmz_rows;        /* [1] four sub-problems per wave when E+R+1 <= 16                                        RDA_LMZ_ROWS */
-    int32_t lmz_dense_from;  /* [256] workgroup count above which the dense (split) form of the LamMuZ launch is used  RDA_LMZ_DENSE_FROM */
+    int32_t lmz_dense_from;  /* [256] grid size (CUs at one wave per SIMD) above which the split form of the LamMuZ launch is used; x 7/4 for moving scenes  RDA_LMZ_DENSE_FROM */
     int32_t lmz_split;       /* [1] dense grids: common-path kernel + work-list kernel + finalize                      RDA_LMZ_SPLIT */
     int32_t lmz_tail;        /* [0] 1: the last-arriving LamMuZ workgroup of the iteration a step is expected to end in reduces the residuals,
                                 takes the early-stop verdict and hands the result over, instead of the next su launch / k_finish.  Built
@@ -267,6 +267,7 @@ int  rda_get_lmz_history(rda_handle *h, double *points, int32_t *valid);
 int  rda_set_lmz_history(rda_handle *h, const double *points, const int32_t *valid);
 /* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
+int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ work list of the last executed iteration (split launch form) */
 
 /* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns the obstacle slots
  * [r*ceil(N/world), (r+1)*ceil(N/world)): it solves their LamMuZ problems and keeps their duals.  What the su-problem needs of

@@ -42,6 +42,7 @@ struct Ctrl {
     double resi_dual, resi_pri;
     int finished;                 // the result slot of this step has been written (by the launch that ended the step)
     int su_probe;                 // consecutive su-solves in the hard regime (see su_body)
+    int hint_par;                 // which of the two Dev::hint buffers the LamMuZ launch of this iteration WRITES (flipped by every executed su launch)
     int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
     unsigned ticket;              // workgroups of the LamMuZ launch of this iteration that have published their partials (reset by k_su)
     int resi_iter;                // ADMM iterations of this step whose residuals are in resi_dual / resi_pri (LamMuZ tail, else k_su / k_finish)
@@ -93,7 +94,15 @@ struct Dev {
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
     // per (slot, time slot) candidate list and vertices of the staged obstacle (pose independent): k_prepare, at upload
     unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][40], [N*nt][28][2], [N*nt][2] = (npv, nlv)
-    int *hint;                                // [T][N] support (candidate index) of the last max-clearance optimum, -1 = none
+    // Remembered supports (candidate index of the last max-clearance optimum, -1 = none) - a pure cache: whatever it holds is only the
+    // first candidate of a row, which is accepted on its certificate alone.  Two buffers of hint_len ints, [T][hint_stride] each: a
+    // LamMuZ launch reads the one the previous executed launch wrote and writes the other (Ctrl::hint_par, flipped by the su launch of
+    // the iteration), so that the FIRST launch of a tick can read stage t+1 of the previous tick - the horizon has moved on by one
+    // stage, that support belongs to this pose - without racing against the row that rewrites it.  Key of a row: the SOURCE obstacle
+    // of its slot when the scene was staged by the device pipeline (slot_src = its rank table: a re-sorted scene re-binds most slots
+    // every tick, the supports stay with their obstacles), else the slot itself (host-staged slots, padding copies).
+    int *hint; int hint_len, hint_stride, src_cap;
+    const int *slot_src; int src_used;        // slot -> index in the caller's raw scene, valid for slots < src_used (null: host-staged)
     // Dual state, STAGE-MAJOR: lam [T+1][N][E], mu [T+1][N][R], xi [T+1][N][2], z / zeta [T][N] - a LamMuZ workgroup owns GS consecutive
     // slots of one stage, so what it reads and writes are whole lines (the accessors rda_get_state / rda_set_state speak the
     // reference's [N][T+1][.] shapes)
@@ -234,7 +243,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     }
     else if (it > 0 && fin && fin->verdict && tid == 0)        // (the LamMuZ tail has taken the verdict: not stopped)
         __hip_atomic_store(fin->verdict, 2 * fin->vseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->ticket = 0; }     // the LamMuZ launches of this iteration start with an empty work list / ticket
+    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->ticket = 0; d.ctrl->hint_par ^= 1; }     // the LamMuZ launches of this iteration start with an empty work list / ticket and write the other support buffer
     su::Args a;
     a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
@@ -426,7 +435,20 @@ __device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, u
 
 // K1, one (slot, stage) sub-problem per wavefront; 4 wavefronts per workgroup (shapes with E+R+1 > 16, RDA_LMZ_ROWS=0, and the
 // no-obstacle case).  Writes the per-row terms only: k_lmz_finalize forms the block partials and runs the tail behind it.
-__device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
+__device__ __forceinline__ size_t hint_key(const Dev &d, int n, int t)
+{
+    int key = n;
+    if (d.slot_src && n < d.src_used) { const int src = d.slot_src[n]; if (src >= 0 && src < d.src_cap) key = d.c.N + src; }
+    return (size_t)t * d.hint_stride + key;
+}
+// `first` = first LamMuZ launch of a tick: the support remembered for stage t+1 of the previous tick
+__device__ __forceinline__ int hint_read(const Dev &d, int par, int n, int t, bool first)
+{
+    return d.hint[(size_t)(par ^ 1) * d.hint_len + hint_key(d, n, first && t + 1 < d.c.T ? t + 1 : t)];
+}
+__device__ __forceinline__ void hint_write(const Dev &d, int par, int n, int t, int v) { d.hint[(size_t)par * d.hint_len + hint_key(d, n, t)] = v; }
+
+__device__ __forceinline__ void lammuz_body(const Dev &d, const int block, const int it)
 {
 #pragma clang fp contract(on)          // see lammuz_device.h: results independent of the kernel the body is compiled into
     __shared__ lmz::WaveLDS wl[4];
@@ -494,15 +516,16 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
         if (lane == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
-    if (!d.warm || !lmz::solve_wave_warm<64>(W, rb, P, lane, d.hint[zi], best)) lmz::solve_wave(W, rb, P, lane, best);
-    if (lane == 0) d.hint[zi] = best.id >> 1;
+    const int hpar = d.ctrl->hint_par & 1;
+    if (!d.warm || !lmz::solve_wave_warm<64>(W, rb, P, lane, hint_read(d, hpar, n, t, it == 0), best)) lmz::solve_wave(W, rb, P, lane, best);
+    if (lane == 0) hint_write(d, hpar, n, t, best.id >> 1);
     if (d.centre) lmz::central_normal_wave<64>(W, rb, P, lane, best);
     bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));
     const int k = t * d.Nloc + nl;
     if (bad) {
         if (lane == 0) {
             store_row(d, k, failed_row(d, k));
-            d.hint[zi] = -1;
+            hint_write(d, hpar, n, t, -1);
             atomicAdd(&d.ctrl->lmz_fail, 1);
         }
         return;
@@ -545,7 +568,7 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block)
     }
 }
 
-__global__ __launch_bounds__(256) void k_lammuz(Dev d) { lammuz_body(d, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_lammuz(Dev d, int it) { lammuz_body(d, blockIdx.x, it); }
 
 // K1, packed: FOUR sub-problems per wavefront, one per 16-lane DPP row (16 per workgroup).  The warm-started path - one
 // candidate on two lanes, the optimality certificate on E+R lanes, the central-normal step on (vertex, vertex) pairs, the
@@ -641,7 +664,9 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     }
     lmz::wave_sync();
     LMZ_CLK(2);
-    bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, d.hint[zi], best);
+    const int hpar = d.ctrl->hint_par & 1;
+    const int hint_in = MODE != 2 ? hint_read(d, hpar, n, t, it == 0) : -1;
+    bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, hint_in, best);
     LMZ_CLK(3);
     if (MODE != 2 && !live && !ok) {                           // a dead row never asks for the enumeration; nothing of `best` is used
         best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
@@ -705,7 +730,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         clk_enum = nf > 0;
         if (mine && gl == 0 && live && g_lmz_faillog) {
             const int k = atomicAdd(&g_lmz_faillog[0], 1);
-            if (k < 200000) { g_lmz_faillog[1 + 3 * k] = d.hint[zi]; g_lmz_faillog[2 + 3 * k] = best.id >> 1; g_lmz_faillog[3 + 3 * k] = P.norm2; }
+            if (k < 200000) { g_lmz_faillog[1 + 3 * k] = hint_in; g_lmz_faillog[2 + 3 * k] = best.id >> 1; g_lmz_faillog[3 + 3 * k] = P.norm2; }
         }
 #endif
     }
@@ -723,7 +748,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         lmz::solve_wave(wl[wv * 4 + g], rb, Pg, lane, bg);
         if (row == g) best = bg;
     }
-    if (gl == 0 && live && !defer) d.hint[zi] = best.id >> 1;
+    if (gl == 0 && live && !defer) hint_write(d, hpar, n, t, best.id >> 1);
     if (d.centre) lmz::central_normal_wave<16>(W, rb, P, lane, best);
     LMZ_CLK(5);
     bad = bad || !(isfinite(best.cost) && isfinite(best.m) && isfinite(best.H0) && isfinite(best.H1));      // uniform over the row
@@ -751,7 +776,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         if (live && bad) {
             ro = failed_row(d, k); have = true;
             store_row(d, k, ro);
-            d.hint[zi] = -1;
+            hint_write(d, hpar, n, t, -1);
             atomicAdd(&d.ctrl->lmz_fail, 1);
         } else if (wr) {
             double ax = 0, ay = 0, bl = 0, mh = 0, gx = 0, gy = 0;
@@ -802,9 +827,9 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
 // waves per SIMD with a few spilled registers (more sub-problems in flight: what a full chip wants)
 __global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
-__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_rows_fast(Dev d) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_rows_fast(Dev d, int it) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 // (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower; the work list with two waves per SIMD is 4 % faster for fleets)
-__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_enum(Dev d) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_enum(Dev d, int it) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 
 // Block partials from the STORED terms - the same row_term, the same row order as mode 0 of the packed kernel forms them in flight - and
 // the tail of the step.  Runs behind every LamMuZ form that leaves its rows to more than one workgroup or launch (split launch, one
@@ -1297,7 +1322,8 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
-    rc |= dalloc(&d.wl, (N + GS) * T); rc |= dalloc(&d.hint, N * T); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
+    rc |= dalloc(&d.wl, (N + GS) * T); d.src_cap = (int)(4 * N + 256); d.hint_stride = (int)N + d.src_cap; d.hint_len = d.hint_stride * (int)T; d.slot_src = nullptr; d.src_used = 0;
+    rc |= dalloc(&d.hint, 2 * (size_t)d.hint_len); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
     d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.J = (int)((N + GS - 1) / GS); d.chunk = chunk_doubles((int)T, (int)N); d.lchunk = lchunk_doubles((int)T, (int)N);
@@ -1453,6 +1479,15 @@ extern "C" int rda_debug_su_prof(rda_handle *H, long long *out16)
     return RDA_OK;
 }
 
+// debug: rows the common-path LamMuZ kernel of the LAST executed iteration put on the work list (split launch form only)
+extern "C" int rda_debug_worklist(rda_handle *H, int *rows)
+{
+    if (!H || !rows) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(rows, &H->d.ctrl->wl_count, sizeof(int), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
+
 // assign_obstacle_parameter (rda_solver.py:483-526): pad / truncate into N slots, then upload
 static int obstacles_stage(rda_handle *H, int n_obs, const double *A, const double *b, const int32_t *cone, int per_t, bool sync)
 {
@@ -1479,6 +1514,7 @@ static int obstacles_stage(rda_handle *H, int n_obs, const double *A, const doub
     HIPCHK(hipMemcpyAsync(d.b, H->h_stage_b, N * nt * E * sizeof(double), hipMemcpyHostToDevice, H->stream));
     HIPCHK(hipMemcpyAsync(d.cone, H->h_stage_cone, N * sizeof(int), hipMemcpyHostToDevice, H->stream));
     d.nt = (int)nt; d.obstacle_num = (int)N;
+    d.slot_src = nullptr; d.src_used = 0;                    // host-staged slots: the remembered supports are keyed by slot
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * nt + 3) / 4)), dim3(256), 0, H->stream, d);
     if (sync) HIPCHK(hipStreamSynchronize(H->stream));      // staging buffers are reused by the next call
     return RDA_OK;
@@ -1553,6 +1589,7 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     hipLaunchKernelGGL(scene::k_rank, dim3((n + 15) / 16), dim3(256), 0, st, a);
     hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
     d.nt = a.nt; d.obstacle_num = N;
+    d.slot_src = H->d_sc_sel; d.src_used = n < N ? n : N;          // the remembered supports follow the obstacles through the re-binding (Dev::hint)
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);
     HIPCHK(hipGetLastError());
     if (n_nonconvex) {
@@ -1648,14 +1685,14 @@ static void launch_lammuz(rda_handle *H, const Dev &d, int it, const Fin &fin)
         const int dense_from = dense_threshold(H, d);
         if (cus > dense_from && H->lmz_split) {
             // dense grid: common path with three waves per SIMD, then the deferred rows one per wave (see lammuz_body_rows)
-            hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(NTH), 0, H->stream, d);
+            hipLaunchKernelGGL(k_lammuz_rows_fast, dim3(nb), dim3(NTH), 0, H->stream, d, it);
             int ne = units / 32; if (ne < 64) ne = 64; if (ne > 2048) ne = 2048;
-            hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(NTH), 0, H->stream, d);
+            hipLaunchKernelGGL(k_lammuz_enum, dim3(ne), dim3(NTH), 0, H->stream, d, it);
             launch_finalize(H, d, it, fin);
         } else if (cus > dense_from) hipLaunchKernelGGL(k_lammuz_rows_dense, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
         else hipLaunchKernelGGL(k_lammuz_rows, dim3(nb), dim3(NTH), 0, H->stream, d, it, fin);
     } else {
-        hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d);
+        hipLaunchKernelGGL(k_lammuz, dim3(d.obstacle_num ? (units + 3) / 4 : 1), dim3(256), 0, H->stream, d, it);
         launch_finalize(H, d, it, fin);
     }
 }
@@ -2355,13 +2392,13 @@ __device__ __forceinline__ Fin fleet_fin(const Dev &d, const EgoIO &e, int k)
     const size_t ns = 3 * (d.c.T + 1), nu = 2 * d.c.T;
     return Fin{ e.out_u + k * nu, e.out_s + k * ns, e.info + k, nullptr, 0, 0 };
 }
-__global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs) { lammuz_body(devs[blockIdx.y], blockIdx.x); }
+__global__ __launch_bounds__(256) void k_lammuz_fleet(const Dev *devs, int it) { lammuz_body(devs[blockIdx.y], blockIdx.x, it); }
 __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_rows(const Dev *devs, const EgoIO *io, int it, int k)
 {
     lammuz_body_rows<0>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
 }
-__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_fleet_rows_fast(const Dev *devs) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
-__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_enum(const Dev *devs) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, 0, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_fleet_rows_fast(const Dev *devs, int it) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_enum(const Dev *devs, int it) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 __global__ __launch_bounds__(256) void k_lmz_finalize_fleet(const Dev *devs, const EgoIO *io, int it, int k)
 {
     finalize_body(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
@@ -2478,13 +2515,13 @@ static int fleet_enqueue(rda_fleet *F, const EgoIO *io, int k)
         constexpr int NTH = 64 * GS / 4;
         const int nbr = F->T * F->J, nfin = (nbr + FPB - 1) / FPB, nbp = packed_grid(F->T, F->J);       // one workgroup per (stage, GS-slot block), XCD-aware order
         if (F->rows && F->lmz_split) {
-            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3(nbp, B), dim3(NTH), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lammuz_fleet_rows_fast, dim3(nbp, B), dim3(NTH), 0, F->stream, F->d_devs, it);
             int ne = nbr / 8; if (ne < 8) ne = 8; if (ne > 128) ne = 128;
-            hipLaunchKernelGGL(k_lammuz_fleet_enum, dim3(ne, B), dim3(NTH), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lammuz_fleet_enum, dim3(ne, B), dim3(NTH), 0, F->stream, F->d_devs, it);
             hipLaunchKernelGGL(k_lmz_finalize_fleet, dim3(nfin, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
         } else if (F->rows) hipLaunchKernelGGL(k_lammuz_fleet_rows, dim3(nbp, B), dim3(NTH), 0, F->stream, F->d_devs, io, it, k);
         else {
-            hipLaunchKernelGGL(k_lammuz_fleet, dim3(nbr * GS / 4, B), dim3(256), 0, F->stream, F->d_devs);
+            hipLaunchKernelGGL(k_lammuz_fleet, dim3(nbr * GS / 4, B), dim3(256), 0, F->stream, F->d_devs, it);
             hipLaunchKernelGGL(k_lmz_finalize_fleet, dim3(nfin, B), dim3(256), 0, F->stream, F->d_devs, io, it, k);
         }
     }

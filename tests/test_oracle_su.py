@@ -218,3 +218,26 @@ def test_warm_started_su_reaches_the_cold_solution():
             assert ipm_w <= 1.05 * ipm_c, (dyn, ipm_w, ipm_c)
     finally:
         lib.orc_set_su_warm(1e-3, 1e-3, 30)
+
+
+def test_su_replay_tool_records_and_replays(tmp_path, monkeypatch):
+    """tools/su_replay.py (the CPU study aid of DESIGN section 9): the su-problems an oracle closed loop records are the ones orc_su_solve
+    gets - replayed cold they converge, and the iteration trace hook prints one line per interior-point iteration"""
+    import importlib, os, sys
+    monkeypatch.setenv("RDA_SU_REPLAY_DIR", str(tmp_path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "tools"))
+    sys.modules.pop("su_replay", None)
+    su_replay = importlib.import_module("su_replay")
+    try:
+        su_replay.record("t", n_obs=12, T=8, steps=3, moving=True)
+        probs = su_replay.load("t")
+        assert 3 <= len(probs) <= 12 and probs[0]["T"] == 8 and probs[0]["N"] == 12 and probs[0]["it"] == 0
+        lib = su_replay._lib()
+        for pr in probs:
+            st, its, so, uo, do = su_replay.solve(lib, pr)
+            assert st == 0 and 1 <= its <= 40
+            assert np.all(np.isfinite(uo)) and np.all(do <= pr["cfg"].max_sd + 1e-9) and np.all(do >= pr["cfg"].min_sd - 1e-9)
+    finally:                                   # the recording run switched the oracle's su start rules and thread count: back to the defaults
+        lib = su_replay._lib()
+        lib.orc_set_su_warm(1e-3, 1e-3, 30); lib.orc_set_threads(1); lib.orc_set_su_dump(b""); lib.orc_set_su_trace(0)

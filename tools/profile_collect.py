@@ -29,13 +29,18 @@ for cfg in ("ns", "n20", "n2000", "c4", "ip"):
     m = re.search(r"T=(\d+), N_obs=(\d+)", nj["metric"])
     detail = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        for mm in re.finditer(rf"^{cfg} {counter} (?:void )?([\w<>]+): dispatches (\d+) total ([\d.]+) per-dispatch [\d.]+ executed (\d+) per-executed ([\d.]+)", pm, re.M):
+        found = {}
+        for mm in re.finditer(rf"^{cfg} {counter} (?:void )?([\w<>]+): dispatches (\d+) total ([\d.]+) per-dispatch [\d.]+ executed (\d+) per-executed ([\d.]+)(?: steady-total ([\d.]+))?", pm, re.M):
             k = mm.group(1)
             if not (k.startswith("k_su") or k.startswith("k_lammuz") or k.startswith("k_lmz")):
                 continue
+            found[k] = mm
             d = detail.setdefault(k, {})
             d["dispatches"] = int(mm.group(2))
             d[counter.lower() + "_bytes_per_executed_launch"] = round(float(mm.group(5)) * 1024)
+        # the work-list kernel: steady-state bytes per executed ITERATION (= per executed launch of the common-path kernel), see profile_round.sh
+        if "k_lammuz_enum" in found and "k_lammuz_rows_fast" in found and found["k_lammuz_enum"].group(6):
+            detail["k_lammuz_enum"][counter.lower() + "_bytes_per_executed_launch"] = round(float(found["k_lammuz_enum"].group(6)) * 1024 / max(1, int(found["k_lammuz_rows_fast"].group(4))))
     # the LamMuZ step of an iteration: one kernel on small grids, the common-path + work-list + finalize kernels on dense ones (summed)
     lm = sum(sum(v for kk, v in d.items() if kk.endswith("_launch")) for k, d in detail.items() if k.startswith(("k_lammuz", "k_lmz")) and k != "k_lmz_finalize_all")
     su = sum(sum(v for kk, v in d.items() if kk.endswith("_launch")) for k, d in detail.items() if re.fullmatch(r"k_su<\d+>", k))

@@ -43,7 +43,12 @@ try:
         # outlier (no remembered supports: every row goes through the enumeration, the work-list kernel moves 100 x its usual bytes)
         top = sorted(v)[max(0, int(0.98 * len(v)) - 1)]
         ex = [x for x in v if x > 0.4 * top and x <= 1.5 * top] or v
-        print(f"{cfg} {cname} {k}: dispatches {len(v)} total {sum(v):.1f} per-dispatch {sum(v)/len(v):.3f} executed {len(ex)} per-executed {sum(ex)/len(ex):.3f}")
+        # `steady`: everything except the first-step outliers (> 3 x the 90th percentile).  The work-list kernel of the split LamMuZ form
+        # moves next to nothing in steady state (empty or short list) and 100 x that on a handle's first step, which then IS its 98th
+        # percentile: its bytes per executed iteration are steady-total / executed launches of the common-path kernel (profile_collect.py)
+        p90 = sorted(v)[max(0, int(0.90 * len(v)) - 1)]
+        st = [x for x in v if x <= 3.0 * p90] or v
+        print(f"{cfg} {cname} {k}: dispatches {len(v)} total {sum(v):.1f} per-dispatch {sum(v)/len(v):.3f} executed {len(ex)} per-executed {sum(ex)/len(ex):.3f} steady-total {sum(st):.1f}")
 except Exception as e:
     print(cfg, "parse failed", e)
 PY
