@@ -521,6 +521,25 @@ template <int GW> struct Grp {
 // (sign, tolerance, circle obstacle, no hint yet) falls back to solve_wave.  Call after prepare_wave.  `hint` is the
 // candidate index il*n_mu + im remembered from the last solve of this (n, t) (-1: none); it is only a hint - whatever it
 // is, a result is accepted on the certificate alone.
+// k-th neighbour of a support candidate c in the list cand[0..ncand) of n rows (0 = empty, 1..n = one row, beyond = a pair that meets in
+// a vertex): the supports that differ from it by ONE row - a pair's two rows, a row's pairs and the empty support, the empty support's
+// rows.  -1 when there is no k-th one.
+__device__ __forceinline__ int support_neighbour(int c, int n, const unsigned char *cand, int ncand, int k)
+{
+    if (c == 0) { int seen = 0; for (int q = 0; q < ncand; ++q) { const int v = cand[q]; if (v >= 1 && v <= n) { if (seen == k) return v; ++seen; } } return -1; }
+    if (c <= n) {
+        if (k == 0) return 0;
+        int seen = 1;
+        for (int q = 0; q < ncand; ++q) {
+            const int v = cand[q];
+            if (v > n) { int a, b; decode_pair(v - 1 - n, n, a, b); if (a == c - 1 || b == c - 1) { if (seen == k) return v; ++seen; } }
+        }
+        return -1;
+    }
+    int a, b; decode_pair(c - 1 - n, n, a, b);
+    return k == 0 ? 1 + a : (k == 1 ? 1 + b : -1);
+}
+
 template <int GW> __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int wlane, int hint, Sol &best)
 {
     const int lane = wlane & (GW - 1);                          // lane inside the group
@@ -528,57 +547,96 @@ template <int GW> __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, co
     const int R = P.R, E = P.E, nm0 = 1 + R + R * (R - 1) / 2;
     const int il = hint / nm0, im = hint - il * nm0;            // support of the last max-clearance optimum of this (n, t)
     if (il >= 1 + E + E * (E - 1) / 2) return false;
+    // ---- optimality conditions of the full problem for the (group-uniform) point in `best` -------------------------------------------
+    auto certify = [&]() -> bool {
+        double ax = 0, ay = 0;
+        if (best.i1 >= 0) { ax += best.l1 * W.A[best.i1][0]; ay += best.l1 * W.A[best.i1][1]; }
+        if (best.i2 >= 0) { ax += best.l2 * W.A[best.i2][0]; ay += best.l2 * W.A[best.i2][1]; }
+        const double na = sqrt(ax * ax + ay * ay);
+        if (na > 1.0 + 1e-12) return false;
+        const double phim = (best.m < 0 ? best.m : 0.0) - P.delta;          // d cost / d m
+        const bool tight = na >= 1.0 - 1e-9;
+        const double ux = tight ? ax / na : 0.0, uy = tight ? ay / na : 0.0;
+        auto glam = [&](int i) { return phim * W.q[i] + P.ro2 * (W.M[i][0] * best.H0 + W.M[i][1] * best.H1); };
+        double nu = 0.0;
+        if (tight) {           // multiplier of |A'lam| <= 1 from the support row with the larger A_i'a^
+            int ib = best.i1;
+            double d1 = best.i1 >= 0 ? W.A[best.i1][0] * ux + W.A[best.i1][1] * uy : 0.0;
+            double d2 = best.i2 >= 0 ? W.A[best.i2][0] * ux + W.A[best.i2][1] * uy : 0.0;
+            double db = d1;
+            if (fabs(d2) > fabs(d1)) { ib = best.i2; db = d2; }
+            if (ib < 0 || !(fabs(db) > 1e-12)) return false;
+            nu = -glam(ib) / db;
+            if (!(nu >= -1e-10)) return false;
+        }
+        bool pass = true;
+        if (lane < E) {
+            const double gi = glam(lane) + nu * (W.A[lane][0] * ux + W.A[lane][1] * uy);
+            const double tol = 1e-10 * (1.0 + fabs(phim * W.q[lane]) + P.ro2 * (fabs(W.M[lane][0] * best.H0) + fabs(W.M[lane][1] * best.H1)));
+            // complementarity: a support entry that came out at its bound (0) is just an inactive-side constraint
+            const bool pos = (lane == best.i1 && best.l1 > 0) || (lane == best.i2 && best.l2 > 0);
+            pass = pos ? fabs(gi) <= 1e3 * tol : gi >= -tol;
+        } else if (lane < E + R) {
+            const int j = lane - E;
+            const double gj = -phim * Rb.h[j] + P.ro2 * (Rb.G[j][0] * best.H0 + Rb.G[j][1] * best.H1);
+            const double tol = 1e-10 * (1.0 + fabs(phim * Rb.h[j]) + P.ro2 * (fabs(Rb.G[j][0] * best.H0) + fabs(Rb.G[j][1] * best.H1)));
+            const bool pos = (j == best.j1 && best.g1 > 0) || (j == best.j2 && best.g2 > 0);
+            pass = pos ? fabs(gj) <= 1e3 * tol : gj >= -tol;
+        }
+        return Grp<GW>::ballot(!pass, wlane) == 0;
+    };
+    auto take = [&](const Sol &s, int src, int cid) {          // the solution lane `src` holds becomes the group's `best`
+        best.cost = Grp<GW>::bcast(s.cost, src); best.id = cid;
+        best.m = Grp<GW>::bcast(s.m, src); best.H0 = Grp<GW>::bcast(s.H0, src); best.H1 = Grp<GW>::bcast(s.H1, src);
+        best.i1 = Grp<GW>::bcast(s.i1, src); best.i2 = Grp<GW>::bcast(s.i2, src);
+        best.j1 = Grp<GW>::bcast(s.j1, src); best.j2 = Grp<GW>::bcast(s.j2, src);
+        best.l1 = Grp<GW>::bcast(s.l1, src); best.l2 = Grp<GW>::bcast(s.l2, src);
+        best.g1 = Grp<GW>::bcast(s.g1, src); best.g2 = Grp<GW>::bcast(s.g2, src);
+    };
     Sol s; s.m = 0; s.H0 = s.H1 = 0; s.i1 = s.i2 = s.j1 = s.j2 = -1; s.l1 = s.l2 = s.g1 = s.g2 = 0; s.cost = 0; s.id = 0;
-    bool ok = false;
-    if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);
-    // hinge-inactive solution with m >= 0, else hinge-active solution with m < 0
-    const double m0 = Grp<GW>::bcast(s.m, 0), m1 = Grp<GW>::bcast(s.m, 1);
-    const unsigned long long okb = Grp<GW>::ballot(ok, wlane);
-    int src;
-    if ((okb & 1) && m0 >= 0) src = 0; else if ((okb & 2) && m1 < 0) src = 1; else return false;
-    best.m = src ? m1 : m0;
-    best.cost = Grp<GW>::bcast(s.cost, src); best.id = 2 * (il * (1 + R + R * (R - 1) / 2) + im) + src;
-    best.H0 = Grp<GW>::bcast(s.H0, src); best.H1 = Grp<GW>::bcast(s.H1, src);
-    best.i1 = Grp<GW>::bcast(s.i1, src); best.i2 = Grp<GW>::bcast(s.i2, src);
-    best.j1 = Grp<GW>::bcast(s.j1, src); best.j2 = Grp<GW>::bcast(s.j2, src);
-    best.l1 = Grp<GW>::bcast(s.l1, src); best.l2 = Grp<GW>::bcast(s.l2, src);
-    best.g1 = Grp<GW>::bcast(s.g1, src); best.g2 = Grp<GW>::bcast(s.g2, src);
-    // ---- optimality conditions of the full problem ---------------------------------------------------------------
-    double ax = 0, ay = 0;
-    if (best.i1 >= 0) { ax += best.l1 * W.A[best.i1][0]; ay += best.l1 * W.A[best.i1][1]; }
-    if (best.i2 >= 0) { ax += best.l2 * W.A[best.i2][0]; ay += best.l2 * W.A[best.i2][1]; }
-    const double na = sqrt(ax * ax + ay * ay);
-    if (na > 1.0 + 1e-12) return false;
-    const double phim = (best.m < 0 ? best.m : 0.0) - P.delta;          // d cost / d m
-    const bool tight = na >= 1.0 - 1e-9;
-    const double ux = tight ? ax / na : 0.0, uy = tight ? ay / na : 0.0;
-    auto glam = [&](int i) { return phim * W.q[i] + P.ro2 * (W.M[i][0] * best.H0 + W.M[i][1] * best.H1); };
-    double nu = 0.0;
-    if (tight) {           // multiplier of |A'lam| <= 1 from the support row with the larger A_i'a^
-        int ib = best.i1;
-        double d1 = best.i1 >= 0 ? W.A[best.i1][0] * ux + W.A[best.i1][1] * uy : 0.0;
-        double d2 = best.i2 >= 0 ? W.A[best.i2][0] * ux + W.A[best.i2][1] * uy : 0.0;
-        double db = d1;
-        if (fabs(d2) > fabs(d1)) { ib = best.i2; db = d2; }
-        if (ib < 0 || !(fabs(db) > 1e-12)) return false;
-        nu = -glam(ib) / db;
-        if (!(nu >= -1e-10)) return false;
+    // ---- round 1: the remembered support, lanes 0 / 1 = hinge inactive / active ------------------------------------------------------
+    {
+        bool ok = false;
+        if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);
+        // hinge-inactive solution with m >= 0, else hinge-active solution with m < 0
+        const double m0 = Grp<GW>::bcast(s.m, 0), m1 = Grp<GW>::bcast(s.m, 1);
+        const unsigned long long okb = Grp<GW>::ballot(ok, wlane);
+        int src = -1;
+        if ((okb & 1) && m0 >= 0) src = 0; else if ((okb & 2) && m1 < 0) src = 1;
+        if (src >= 0) {
+            take(s, src, 2 * (il * nm0 + im) + src);
+            if (certify()) return true;
+        }
     }
-    bool pass = true;
-    if (lane < E) {
-        const double gi = glam(lane) + nu * (W.A[lane][0] * ux + W.A[lane][1] * uy);
-        const double tol = 1e-10 * (1.0 + fabs(phim * W.q[lane]) + P.ro2 * (fabs(W.M[lane][0] * best.H0) + fabs(W.M[lane][1] * best.H1)));
-        // complementarity: a support entry that came out at its bound (0) is just an inactive-side constraint
-        const bool pos = (lane == best.i1 && best.l1 > 0) || (lane == best.i2 && best.l2 > 0);
-        pass = pos ? fabs(gi) <= 1e3 * tol : gi >= -tol;
-    } else if (lane < E + R) {
-        const int j = lane - E;
-        const double gj = -phim * Rb.h[j] + P.ro2 * (Rb.G[j][0] * best.H0 + Rb.G[j][1] * best.H1);
-        const double tol = 1e-10 * (1.0 + fabs(phim * Rb.h[j]) + P.ro2 * (fabs(Rb.G[j][0] * best.H0) + fabs(Rb.G[j][1] * best.H1)));
-        const bool pos = (j == best.j1 && best.g1 > 0) || (j == best.j2 && best.g2 > 0);
-        pass = pos ? fabs(gj) <= 1e3 * tol : gj >= -tol;
+    // ---- round 2: the supports ONE row away from the remembered one (what a row that loses its support usually moves to: a vertex
+    // contact becomes an edge contact or the other way round, on the obstacle's side or on the robot's - 99 % of the failures of a
+    // closed loop, tools/lmz_wave_clocks.py).  Lane 2 q + c: neighbour q (0..3: a lam row changes, 4..7: a mu row), hinge state c;
+    // every neighbour's own valid point (inactive with m >= 0, else active with m < 0), the cheapest of them, ONE more certificate.
+    // Only a point that passes it is taken (the problem is convex: it is then a global minimiser); anything else goes to the enumeration.
+    if (GW >= 16) {
+        const int q = (lane >> 1) & 7, c = lane & 1;
+        int nil = -1, nim = -1;
+        if (lane < 16) {
+            if (q < 4) { nil = support_neighbour(il, E, W.lamc, W.nlv, q); nim = im; }
+            else { nil = il; nim = support_neighbour(im, R, Rb.muc, Rb.nmv, q - 4); }
+        }
+        bool ok = false;
+        if (lane < 16 && nil >= 0 && nim >= 0) ok = eval_candidate(W, Rb, P, nil, nim, c, s);
+        const bool valid = ok && (c == 0 ? s.m >= 0 : s.m < 0);
+        // a support whose hinge-inactive point is valid does not also offer its hinge-active one (same rule as round 1)
+        const unsigned long long vb = Grp<GW>::ballot(valid, wlane);
+        const bool use = valid && !(c == 1 && ((vb >> (lane - 1)) & 1ull));
+        const double cost = use ? s.cost : INFINITY;
+        const double cmin = -Grp<GW>::max(-cost);
+        if (cmin < INFINITY) {
+            const unsigned long long wb = Grp<GW>::ballot(use && cost == cmin, wlane);
+            const int src = __ffsll((long long)wb) - 1;
+            const int cid = Grp<GW>::bcast(2 * (nil * nm0 + nim) + c, src);
+            take(s, src, cid);
+            if (certify()) return true;
+        }
     }
-    return Grp<GW>::ballot(!pass, wlane) == 0;
+    return false;
 }
 
 // Tie-break T1 in the slack regime (every (lam, mu) with H = 0, m >= 0 is optimal for the reference's problem): replace
