@@ -598,7 +598,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     const int T = d.c.T, E = d.c.E, R = d.c.R;
 #ifdef RDA_LMZ_CLK
     // debug build only (tools/lmz_wave_clocks.py): clock64 ticks per section of a wave, in the wave's own 16-word slot of g_lmz_clk
-    long long clk_prev = clock64(); const long long clk_in = clk_prev; bool clk_enum = false;
+    long long clk_prev = clock64(); const long long clk_in = clk_prev; bool clk_enum = false; const unsigned long long clk_wall_in = (unsigned long long)wall_clock64();
     unsigned long long *const clk_slot = g_lmz_clk ? g_lmz_clk + 16 * (size_t)(block * (GS / 4) + (threadIdx.x >> 6)) : nullptr;
 #define LMZ_CLK(k) do { if (MODE == 0) { const long long now_ = clock64(); if (clk_slot && (threadIdx.x & 63) == 0) clk_slot[k] += (unsigned long long)(now_ - clk_prev); clk_prev = now_; } } while (0)
 #else
@@ -816,6 +816,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     if (MODE == 0 && clk_slot && (threadIdx.x & 63) == 0) {
         const unsigned long long tot = (unsigned long long)(clock64() - clk_in);
         clk_slot[8] += 1; clk_slot[9] += tot; if (tot > clk_slot[10]) clk_slot[10] = tot;
+        clk_slot[13] = clk_wall_in; clk_slot[14] = (unsigned long long)wall_clock64();      // (last launch) start / end on the device-wide 100 MHz clock
         if (clk_enum) { clk_slot[11] += 1; clk_slot[12] += tot; }
     }
 #endif

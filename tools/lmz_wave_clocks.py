@@ -96,6 +96,11 @@ def main():
           f"slowest wave {int(out[:, 10].max())} ticks; {int(out[:, 11].sum())} wave-runs in a workgroup that enumerated ({out[:, 12].sum() / max(out[:, 11].sum(), 1):.0f} ticks each)")
     for k, name in enumerate(NAMES):
         print(f"  [{k}] {name:58s} {per[k]:8.0f} ticks/wave")
+    # the LAST executed launch on the device-wide 100 MHz clock: when its waves started and ended
+    st, en = out[:, 13] * 0.01, out[:, 14] * 0.01      # us
+    t0 = st.min()
+    print(f"  last launch: waves start {np.percentile(st - t0, 50):.2f} us (median) / {np.percentile(st - t0, 99):.2f} (99 %) / {(st - t0).max():.2f} (last) after the first one; "
+          f"wave duration median {np.median(en - st):.2f} us, 99 % {np.percentile(en - st, 99):.2f}, max {(en - st).max():.2f}; last wave ends {(en - t0).max():.2f} us after the first start")
     # the slowest wave slot on average: the launch ends with it
     avg = out[:, 9] / out[:, 8]
     print(f"  per-slot average: min {avg.min():.0f}  median {np.median(avg):.0f}  max {avg.max():.0f}")
