@@ -604,11 +604,38 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
 #else
 #define LMZ_CLK(k) do { } while (0)
 #endif
-    if (d.ctrl->stop) return;
-    LMZ_CLK(0);
     int tb = 0, jb = 0;                                        // (modes 0, 1) the workgroup's block: stage and GS-slot group
     if (MODE != 2) { block_of(d, block, tb, jb); if (tb < 0) return; }      // a filler of the XCD-aware launch order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4, gl = lane & 15;
+    // MODE 0 (one ego, one wave per SIMD: the launch IS the dependent chain of one wave, and six of its links were trips to the L2 -
+    // stop flag, half-spaces, pose / duals, support cache, slot -> obstacle, remembered support): everything a row reads is requested
+    // here, in two batches, before the first of them is waited for.  The throughput forms (modes 1, 2) keep their loads where the
+    // values are used: there the registers are worth more than the latency (three waves per SIMD hide it).
+    struct Early { double px, py, cs, sn, xi0, xi1, zeta, dbar, prev, vtx[4]; int cone, src, hpar, hint, npv, nlv; unsigned char lamc[3]; } ey;
+    if (MODE == 0) {
+        const int nl0 = jb * GS + wv * 4 + row, nl = nl0 < d.Nlive ? nl0 : 0, n = d.rank * d.Nloc + nl;
+        ey.src = (d.slot_src && n < d.src_used) ? d.slot_src[n] : -1;
+        ey.hpar = d.ctrl->hint_par & 1;
+    }
+    if (d.ctrl->stop) return;                                 // (not merged into the batch below: launches behind the stop flag are on the next tick's way and must stay short - measured)
+    LMZ_CLK(0);
+    if (MODE == 0) {
+        const int t = tb, nl0 = jb * GS + wv * 4 + row, nl = nl0 < d.Nlive ? nl0 : 0, n = d.rank * d.Nloc + nl;
+        const double *ps = d.pose + 4 * t;
+        const size_t o = drow(d, n, t + 1), zi = drow(d, n, t), oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
+        ey.px = ps[0]; ey.py = ps[1]; ey.cs = ps[2]; ey.sn = ps[3];
+        ey.xi0 = d.xi[2 * o]; ey.xi1 = d.xi[2 * o + 1]; ey.zeta = d.zeta[zi]; ey.dbar = d.dis[t]; ey.cone = d.cone[n];
+        ey.prev = gl < E ? d.lam[o * E + gl] : (gl < E + R ? d.mu[o * R + gl - E] : 0.0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ey.lamc[k] = gl + 16 * k < 40 ? d.oc_lamc[oc * 40 + gl + 16 * k] : (unsigned char)0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ey.vtx[k] = gl + 16 * k < 56 ? d.oc_vtx[oc * 56 + gl + 16 * k] : 0.0;
+        ey.npv = d.oc_cnt[2 * oc]; ey.nlv = d.oc_cnt[2 * oc + 1];
+        {   // the remembered support (hint_read with the slot's source already at hand)
+            const int key = (ey.src >= 0 && ey.src < d.src_cap) ? d.c.N + ey.src : n, tr = (it == 0 && t + 1 < T) ? t + 1 : t;
+            ey.hint = d.hint[(size_t)(ey.hpar ^ 1) * d.hint_len + (size_t)tr * d.hint_stride + key];
+        }
+    }
     for (int i = threadIdx.x; i < 2 * R; i += 64 * WPB) rb.G[i >> 1][i & 1] = d.G[i];
     for (int i = threadIdx.x; i < R; i += 64 * WPB) rb.h[i] = d.h[i];
     for (int i = threadIdx.x; i < 40; i += 64 * WPB) rb.muc[i] = d.muc[i];
@@ -632,16 +659,18 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     __syncthreads();
     LMZ_CLK(1);
     lmz::Params P;
-    P.E = E; P.R = R; P.norm2 = d.cone[n];
+    P.E = E; P.R = R; P.norm2 = MODE == 0 ? ey.cone : d.cone[n];
     const double *ps = d.pose + 4 * t;                        // position of column t+1, cos / sin of the heading of column t (quirk Q1)
-    P.px = ps[0]; P.py = ps[1]; P.cs = ps[2]; P.sn = ps[3];
+    if (MODE == 0) { P.px = ey.px; P.py = ey.py; P.cs = ey.cs; P.sn = ey.sn; }
+    else { P.px = ps[0]; P.py = ps[1]; P.cs = ps[2]; P.sn = ps[3]; }
     const size_t o = drow(d, n, t + 1), zi = drow(d, n, t);
-    P.xi0 = d.xi[2 * o]; P.xi1 = d.xi[2 * o + 1];
-    const double zeta = d.zeta[zi], dbar = d.dis[t];
+    if (MODE == 0) { P.xi0 = ey.xi0; P.xi1 = ey.xi1; } else { P.xi0 = d.xi[2 * o]; P.xi1 = d.xi[2 * o + 1]; }
+    const double zeta = MODE == 0 ? ey.zeta : d.zeta[zi], dbar = MODE == 0 ? ey.dbar : d.dis[t];
     P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
     lmz::Sol best;
     double prev = 0.0;
-    if (gl < E) prev = d.lam[o * E + gl];
+    if (MODE == 0) prev = ey.prev;
+    else if (gl < E) prev = d.lam[o * E + gl];
     else if (gl < E + R) prev = d.mu[o * R + gl - E];
     // non-finite data: see lammuz_body (the row solves harmless stand-in data, keeps its previous duals, residual inf)
     const double px0 = P.px, py0 = P.py;                       // (the pose as read: a failed row overwrites it with stand-ins)
@@ -658,14 +687,22 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     lmz::pose_products(W, P, gl);
     {
         const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
-        for (int i = gl; i < 40; i += 16) W.lamc[i] = d.oc_lamc[oc * 40 + i];
-        for (int i = gl; i < 56; i += 16) (&W.vtx[0][0])[i] = d.oc_vtx[oc * 56 + i];
-        if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (gl + 16 * k < 40) W.lamc[gl + 16 * k] = ey.lamc[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (gl + 16 * k < 56) (&W.vtx[0][0])[gl + 16 * k] = ey.vtx[k];
+            if (gl == 0) { W.npv = ey.npv; W.nlv = ey.nlv; }
+        } else {
+            for (int i = gl; i < 40; i += 16) W.lamc[i] = d.oc_lamc[oc * 40 + i];
+            for (int i = gl; i < 56; i += 16) (&W.vtx[0][0])[i] = d.oc_vtx[oc * 56 + i];
+            if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
+        }
     }
     lmz::wave_sync();
     LMZ_CLK(2);
-    const int hpar = d.ctrl->hint_par & 1;
-    const int hint_in = MODE != 2 ? hint_read(d, hpar, n, t, it == 0) : -1;
+    const int hpar = MODE == 0 ? ey.hpar : (d.ctrl->hint_par & 1);
+    const int hint_in = MODE == 0 ? ey.hint : (MODE != 2 ? hint_read(d, hpar, n, t, it == 0) : -1);
     bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, hint_in, best);
     LMZ_CLK(3);
     if (MODE != 2 && !live && !ok) {                           // a dead row never asks for the enumeration; nothing of `best` is used
