@@ -645,6 +645,10 @@ static void chol_solve(const double *K, int n, double *rhs)
 #ifndef SIGMA_FLOOR
 #define SIGMA_FLOOR 1e-3
 #endif
+#define SU_CENTRE_GAMMA 1e-5      /* = su_device.h */
+#ifndef SU_CENTRE_FROM
+#define SU_CENTRE_FROM 25         /* = su_device.h */
+#endif
 /* Warm start of the su-problems of ADMM iterations >= 1 (same rule as csrc/su_device.h): lam_keep[mc] = the inequality multipliers
  * the last converged solve ended with (this function's own row order); warm != 0: the slacks of the start are floored at warm_wfl
  * and the multipliers are the larger of warm_mu0 / w and lam_keep; the warm attempt gets warm_cap iterations, then the cold rule. */
@@ -817,6 +821,18 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         }
         for (int i = 0; i < n; ++i) x[i] += al * dx[i];
         for (int i = 0; i < mc; ++i) { w[i] += al * dw[i]; lm[i] += al * dl[i]; }
+        /* A cold attempt that is still running after SU_CENTRE_FROM iterations is cycling (same cue as the centring floor above): from
+         * there on every pair is kept inside a (very) wide neighbourhood of the central path, lam_i w_i >= SU_CENTRE_GAMMA mu after the
+         * step, by raising the multiplier.  The cycle it breaks: two neighbouring rate rows, both active at the solution, trade places
+         * for ever - one iterate has w_63 = 1e-8 with lam_63 w_63 / mu = 4e-7, the next one the same for row 66, mu stays at 3e-6 and
+         * the controls jump by 1e-2 (soak scene 30, step 39: the cold attempt AND the central restart ran into their caps;
+         * tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz: 200 iterations and status 1 -> 32 iterations).  Solves that end
+         * earlier - all of a recorded C4 / north-star closed loop (tools/su_replay.py) - are untouched. */
+        if (attempt >= 0 && it >= SU_CENTRE_FROM) {
+            double mun = 0; for (int i = 0; i < mc; ++i) mun += lm[i] * w[i];
+            mun /= mc;
+            for (int i = 0; i < mc; ++i) if (lm[i] * w[i] < SU_CENTRE_GAMMA * mun) lm[i] = SU_CENTRE_GAMMA * mun / w[i];
+        }
     }
     used += it;
     }

@@ -31,6 +31,8 @@
 #ifndef SIGMA_FLOOR
 #define SIGMA_FLOOR 1e-3
 #endif
+#define SU_CENTRE_GAMMA 1e-5     // cold attempts still running after SU_CENTRE_FROM iterations: lam w >= SU_CENTRE_GAMMA mu after every step (= oracle/rda_oracle.c)
+#define SU_CENTRE_FROM 25
 // fp contraction per source expression, not per optimiser context: see lammuz_device.h (k_su, k_su_tracked, k_su_fleet and the
 // rda_su_solve hook inline the same solve and must round alike)
 #pragma clang fp contract(on)
@@ -1101,13 +1103,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 // eliminated exactly, the constraints are affine) and the new complementarity is known now.  When these predict
                 // that the stop test will hold, the next pass evaluates the TRUE measures only - no Hessian bases, no Riccati
                 // recursion, no sweep matrices - and is repeated in full should the test fail after all.
-                if (c.light_check) {
+                // A cold attempt that is still running after SU_CENTRE_FROM iterations is cycling: from there on every pair is kept inside a
+                // (very) wide neighbourhood of the central path, lam w >= SU_CENTRE_GAMMA mu after the step, by raising the multiplier
+                // (same rule and reason as the oracle's su_solve_impl: two neighbouring rate rows traded places for ever,
+                // tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz).  The mean complementarity it needs is the one the light
+                // convergence pass computes anyway.
+                const bool recentre = attempt >= 0 && it >= SU_CENTRE_FROM;
+                if (c.light_check || recentre) {
                     double m_ = 0;
                     for (int i = tid; i < NC * T; i += NT) m_ += L.cl[i] * L.cw[i];
                     m_ = block_reduce(m_, L.red, tid, false) / mcnt;
+                    if (recentre) {
+                        const double floor_ = SU_CENTRE_GAMMA * m_;
+                        for (int i = tid; i < NC * T; i += NT)
+                            if (con_on(i / NC, i % NC) && L.cl[i] * L.cw[i] < floor_) L.cl[i] = floor_ / L.cw[i];
+                        __syncthreads();
+                    }
                     const double prd = (1 - al) * rdn, prp = (1 - al) * rpn;
-                    expect_conv = (prd <= c.tol_rd * sc && prp <= c.tol_rp && m_ <= c.tol_mu * sc) ||
-                                  (prd <= 100 * c.tol_rd * sc && prp <= c.tol_rp && m_ <= 0.1 * c.tol_mu * sc);
+                    expect_conv = c.light_check && ((prd <= c.tol_rd * sc && prp <= c.tol_rp && m_ <= c.tol_mu * sc) ||
+                                                    (prd <= 100 * c.tol_rd * sc && prp <= c.tol_rp && m_ <= 0.1 * c.tol_mu * sc));
                 }
             }
             mark(8);

@@ -24,7 +24,17 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tol", type=float, default=1e-5)
     ap.add_argument("--only", type=int, default=-1, help="run this scene only (the random draws of the others are still made)")
+    ap.add_argument("--dump", default="", help="record the oracle's su-problems (same state as the GPU's: re-synchronised every step) for tools/su_replay.py")
+    ap.add_argument("--so", default="", help="another build of librda_hip.so (A/B against an older commit)")
     a = ap.parse_args()
+    if a.so:
+        from rda_planner_amd import _lib
+        _lib.SO_PATH = os.path.abspath(a.so)
+    if a.dump:
+        import ctypes as C
+        orc_api().lib.orc_set_su_dump.argtypes = [C.c_char_p]
+        os.makedirs(os.path.dirname(os.path.abspath(a.dump)), exist_ok=True)
+        orc_api().lib.orc_set_su_dump(os.path.abspath(a.dump).encode())
     orc_api().lib.orc_set_threads(min(16, os.cpu_count() or 1))      # more threads than that slow the oracle down (bench.py thread sweep)
     rng = np.random.default_rng(a.seed)
     tot = bad_u = bad_it = failed = 0
