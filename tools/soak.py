@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tol", type=float, default=1e-5)
     ap.add_argument("--only", type=int, default=-1, help="run this scene only (the random draws of the others are still made)")
+    ap.add_argument("--lmz-central", type=float, default=0.0, help="interior-point LamMuZ mode on both sides (central-path point at this barrier parameter, e.g. 1e-3)")
     ap.add_argument("--dump", default="", help="record the oracle's su-problems (same state as the GPU's: re-synchronised every step) for tools/su_replay.py")
     ap.add_argument("--so", default="", help="another build of librda_hip.so (A/B against an older commit)")
     a = ap.parse_args()
@@ -35,6 +36,10 @@ def main():
         orc_api().lib.orc_set_su_dump.argtypes = [C.c_char_p]
         os.makedirs(os.path.dirname(os.path.abspath(a.dump)), exist_ok=True)
         orc_api().lib.orc_set_su_dump(os.path.abspath(a.dump).encode())
+    if a.lmz_central > 0:
+        import ctypes as C
+        orc_api().lib.orc_set_lmz_ipm_mu.argtypes = [C.c_double]
+        orc_api().lib.orc_set_lmz_mode(1); orc_api().lib.orc_set_lmz_ipm_mu(a.lmz_central)
     orc_api().lib.orc_set_threads(min(16, os.cpu_count() or 1))      # more threads than that slow the oracle down (bench.py thread sweep)
     rng = np.random.default_rng(a.seed)
     tot = bad_u = bad_it = failed = 0
@@ -56,6 +61,8 @@ def main():
                                    float(rng.uniform(0.4, 1.2)), (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))))
         kw = dict(receding=T, iter_num=int(rng.integers(2, 5)), max_edge_num=4, max_obs_num=int(rng.integers(max(4, N // 2), N + 6)),
                   ro1=float(rng.choice([200, 300])), time_print=False)
+        if a.lmz_central > 0:
+            kw["lmz_central"] = a.lmz_central
         gpu = MPC(car_t, [p.copy() for p in path], **kw)
         cpu = MPC(car_t, [p.copy() for p in path], _backend=oracle_backend, **kw)
         st = path[0].copy().reshape(3, 1)
