@@ -648,6 +648,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     double *const Px = L.red + 16, *const Ms = L.red + 80;
     unsigned long long stopf = 0, seq = 0;               // seq = tag of the current interior-point iteration (early-verdict flags)
     unsigned long long *const flag_meas = reinterpret_cast<unsigned long long *>(L.red + 12), *const flag_stop = flag_meas + 1;
+    double okmin = 1.0, lastp = 0.0;
     auto mat_step = [&](int t, const MatK &k) {
         // X = P F : lane (q,i) needs row i of P
         Row5 pr; ldrow5(Px + 8 * mr_, pr);
@@ -691,9 +692,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         double pn = m - (w0 * b0 + w1 * b1 + w2 * b2);
         Px[8 * mr_ + mq_] = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
         double *o = &L.Wn[WN * t];
-        if (mr_ < 5 && mq_ < 3) o[3 * mr_ + mq_] = mq_ == 0 ? w0 : (mq_ == 1 ? w1 : w2);
+        if (mq_ == 0 && mr_ < 5) { o[3 * mr_] = w0; o[3 * mr_ + 1] = w1; o[3 * mr_ + 2] = w2; }      // (the q = 0 lane of a row holds its whole W row: no selects)
         if (lane == 63) { o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22; }
-        return (m00 > 0) && (c22 > 0) && (det > 0);
+        // breakdown check: the running minimum of the three leading minors' signs (one v_min each; a NaN shows in the last P instead)
+        okmin = fmin(okmin, fmin(m00, fmin(c22, det)));
+        lastp = pn;
+        return true;
     };
 
     // Two attempts (same rule as the oracle): when the first one ends without convergence -- the iteration cap, ~0.1 % of
@@ -920,7 +924,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
           if (!expect_conv) {
             Px[lane] = 0.0;                               // P_T = 0
             MatK ka, kb;
-            bool ok = true;
+            bool ok = true; okmin = 1.0; lastp = 0.0;
             ldmat(T - 1, ka);
             // The termination measures do not need the factorisation: waves 1 and 3 evaluate the test while this wave
             // factorises and raise *flag_stop = seq when the iterate has converged; the recursion of that (last, unused)
@@ -934,6 +938,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                     ok = mat_step(t - 1, kb) && ok;
                 }
             }
+            ok = ok && okmin > 0 && lastp == lastp;
             fail = !ok && stopf != seq;
           }
         } else if (wave == 1) {
