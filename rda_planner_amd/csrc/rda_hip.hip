@@ -618,6 +618,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
         ey.hpar = d.ctrl->hint_par & 1;
     }
     if (d.ctrl->stop) return;                                 // (not merged into the batch below: launches behind the stop flag are on the next tick's way and must stay short - measured)
+    if (MODE == 2 && block * WPB >= d.ctrl->wl_count) return;  // work-list form: nothing for this workgroup (the list is short or empty since round 3: no trip for the robot data)
     LMZ_CLK(0);
     if (MODE == 0) {
         const int t = tb, nl0 = jb * GS + wv * 4 + row, nl = nl0 < d.Nlive ? nl0 : 0, n = d.rank * d.Nloc + nl;
