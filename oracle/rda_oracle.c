@@ -552,6 +552,7 @@ static void su_rollout(const su_ctx *S, const double *x, double *s /*3x(T+1) row
     }
 }
 
+static __thread double t_su_eps = 0.0;       /* smoothing width of the hinge terms in su_eval: 0 except in the rescue phase below */
 /* objective, gradient (n) and generalised Hessian (n x n) at x */
 static double su_eval(const su_ctx *S, const double *x, double *s, double *grad, double *Hm)
 {
@@ -576,6 +577,14 @@ static double su_eval(const su_ctx *S, const double *x, double *s, double *grad,
         for (int nn = 0; nn < N; ++nn) {
             const double *a = &S->a[(nn * T + t) * 2];
             double Im = a[0] * st[0] + a[1] * st[1] - S->cc[nn * T + t] - dt_;
+            if (c->accelerated && t_su_eps > 0) {       /* rescue phase of a cycling cold attempt (su_solve_impl): neg(Im) -> (sqrt(Im^2 + 4 eps^2) - Im) / 2 */
+                const double e2 = 4 * t_su_eps * t_su_eps, rt = sqrt(Im * Im + e2), sv = 0.5 * (rt - Im), ds = 0.5 * (Im / rt - 1.0), d2 = 0.5 * e2 / (rt * rt * rt);
+                const double c1 = c->ro1 * sv * ds, c2 = c->ro1 * (ds * ds + sv * d2);
+                f += 0.5 * c->ro1 * sv * sv;
+                gs[0] += c1 * a[0]; gs[1] += c1 * a[1]; gd -= c1;
+                Hs[0][0] += c2 * a[0] * a[0]; Hs[0][1] += c2 * a[0] * a[1]; Hs[1][1] += c2 * a[1] * a[1];
+                Hsd[0] -= c2 * a[0]; Hsd[1] -= c2 * a[1]; Hdd += c2;
+            } else
             if (!c->accelerated || Im < 0) {
                 f += 0.5 * c->ro1 * Im * Im;
                 gs[0] += c->ro1 * Im * a[0]; gs[1] += c->ro1 * Im * a[1]; gd -= c->ro1 * Im;
@@ -646,6 +655,7 @@ static void chol_solve(const double *K, int n, double *rhs)
 #define SIGMA_FLOOR 1e-3
 #endif
 #define SU_CENTRE_GAMMA 1e-5      /* = su_device.h */
+#define SU_SMOOTH_K 0.1           /* = su_device.h */
 #ifndef SU_CENTRE_FROM
 #define SU_CENTRE_FROM 25         /* = su_device.h */
 #endif
@@ -737,8 +747,16 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         }
     }
     status = 1;
+    double mu_prev = 1.0;
     for (it = 0; it < it_cap; ++it) {
+        /* ... and in that rescue phase the hinge terms are smoothed over a width eps = SU_SMOOTH_K sqrt(mu) (mu of the previous iterate;
+         * -> 0 with the complementarity: 3e-6 at the stop, 2e-8 in the controls): the other cycle of the semismooth iteration is a hinge
+         * term that switches on and off - 5 <-> 6 active terms, period 3, steps of 0.005 along a direction of length 1 (soak of the
+         * interior-point LamMuZ mode, scene 56 step 61: 200 iterations / status 1 on both sides -> 37 iterations; another problem of
+         * that loop 79 -> 42) */
+        t_su_eps = (attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;
         su_eval(&S, x, s, grad, Hm);
+        t_su_eps = 0.0;
         double gn = 0, rdn = 0, rpn = 0, mu = 0;
         for (int i = 0; i < n; ++i) { if (fabs(grad[i]) > gn) gn = fabs(grad[i]); rhs[i] = grad[i]; }
         for (int i = 0; i < mc; ++i) {
@@ -747,7 +765,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
             rp[i] = cx + w[i] - con[i].e; if (fabs(rp[i]) > rpn) rpn = fabs(rp[i]);
             mu += lm[i] * w[i];
         }
-        mu /= mc;
+        mu /= mc; mu_prev = mu;
         for (int i = 0; i < n; ++i) if (fabs(rhs[i]) > rdn) rdn = fabs(rhs[i]);
         double sc = 1 + gn;
 #ifdef ORC_DEBUG

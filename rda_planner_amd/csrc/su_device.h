@@ -33,6 +33,7 @@
 #endif
 #define SU_CENTRE_GAMMA 1e-5     // cold attempts still running after SU_CENTRE_FROM iterations: lam w >= SU_CENTRE_GAMMA mu after every step (= oracle/rda_oracle.c)
 #define SU_CENTRE_FROM 25
+#define SU_SMOOTH_K 0.1          // ... and smooths its hinge terms over SU_SMOOTH_K sqrt(mu)
 // fp contraction per source expression, not per optimiser context: see lammuz_device.h (k_su, k_su_tracked, k_su_fleet and the
 // rda_su_solve hook inline the same solve and must round alike)
 #pragma clang fp contract(on)
@@ -724,15 +725,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     const int it_cap = attempt < 0 ? a.warm_cap : 100;
     const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
     bool expect_conv = false;
+    double mu_prev = 1.0;
     for (it = 0; it < it_cap; ++it) {
         seq += 1;
+        const double heps = (attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
         {
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
             if (ract) {
                 const double px = L.s[rt + 1], py = L.s[(T + 1) + rt + 1], dd = L.d[rt];
+                // (rescue phase of a cycling cold attempt: the hinge terms are smoothed over a width heps = SU_SMOOTH_K sqrt(mu), same rule
+                // and reason as the oracle's su_solve_impl - a term that switches on and off for ever; heps = 0 otherwise)
                 auto term = [&](double ax, double ay, double cb) {
                     double Im = ax * px + ay * py - cb - dd;
+                    if (c.accelerated && heps > 0) {
+                        const double e2 = 4 * heps * heps, rt = sqrt(Im * Im + e2), sv = 0.5 * (rt - Im), ds = 0.5 * (Im / rt - 1.0), d2 = 0.5 * e2 / (rt * rt * rt);
+                        const double c1 = sv * ds, c2 = ds * ds + sv * d2;
+                        sxx += c2 * ax * ax; sxy += c2 * ax * ay; syy += c2 * ay * ay; sx += c2 * ax; sy += c2 * ay; s1 += c2;
+                        ix += c1 * ax; iy += c1 * ay; i1 += c1;
+                    } else
                     if (!c.accelerated || Im < 0) {
                         sxx += ax * ax; sxy += ax * ay; syy += ay * ay; sx += ax; sy += ay; s1 += 1.0;
                         ix += Im * ax; iy += Im * ay; i1 += Im;
@@ -1038,6 +1049,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         if (expect_conv) {         // the prediction was wrong: repeat this pass with the factorisation (same iteration number)
             expect_conv = false; __syncthreads(); --it; continue;
         }
+        mu_prev = mu;              // (after the repeat decision: the repeated pass smooths with the same width as the light one)
         if (__syncthreads_or(fail ? 1 : 0)) { status = 2; break; }
         mark(5);
 

@@ -431,14 +431,16 @@ def test_warm_started_lammuz_equals_enumeration(monkeypatch):
         assert np.abs(sa[k] - sb[k]).max() < 5e-5, (k, np.abs(sa[k] - sb[k]).max())
 
 
-@pytest.mark.parametrize("name", ["omni_T15_N13", "diff_T10_N13", "omni_T10_N33_restart", "omni_T25_N26_stagnating_dual", "acker_T15_N45_rate_rows_cycle"])
+@pytest.mark.parametrize("name", ["omni_T15_N13", "diff_T10_N13", "omni_T10_N33_restart", "omni_T25_N26_stagnating_dual", "acker_T15_N45_rate_rows_cycle",
+                                  "omni_T15_N40_hinge_flips"])
 def test_su_hard_instances_from_the_soak_run(orc, hip, name):
     """two su-problems on which an earlier kernel left the oracle's iteration path (the hinge screening was only verified
     at convergence and the late fallback restarted from a badly centred point): 44 and 10 interior-point iterations in
     the oracle, the kernel must follow.  The third one used to cycle (100 iterations, then the restart from a more central
     point) until the fraction to the boundary became adaptive; on the fourth the dual residual stagnates at 1e-7 relative
     while the complementarity falls to 1e-17 (the second termination clause accepts it at 1e-12); on the fifth two rate rows traded
-    places for ever until cold attempts that pass 25 iterations kept every pair at lam w >= 1e-5 mu (round 3)"""
+    places for ever until cold attempts that pass 25 iterations kept every pair at lam w >= 1e-5 mu, on the sixth a hinge term switched
+    on and off for ever until such attempts smooth the hinge terms over 0.1 sqrt(mu) (round 3)"""
     cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", name + ".npz"))
     so = hp.su_solve(orc.lib.orc_su_solve, cfg, inp)
     sh = hp.su_solve(hip.lib.rda_su_solve, cfg, inp)

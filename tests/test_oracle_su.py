@@ -177,6 +177,33 @@ def test_su_rate_rows_trading_places_instance(orc):
         assert _objective(cfg, si, roll(U2), U2, D2) >= f0 - 1e-7 * (1 + abs(f0))
 
 
+def test_su_hinge_term_switching_on_and_off_instance(orc):
+    """recorded by the soak of the interior-point LamMuZ mode (omni, T=15, 40 obstacles, scene 56 step 61): a hinge term switches on and
+    off for ever (5 <-> 6 active terms, period 3, steps of 0.005 along a direction of length 1) - 200 iterations and status 1 in kernel
+    AND oracle.  With the hinge terms smoothed over 0.1 sqrt(mu) once a cold attempt has passed 25 iterations the solve converges (37)."""
+    import os
+    cfg, si = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", "omni_T15_N40_hinge_flips.npz"))
+    st, s, u, d, it = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+    assert st == 0 and it <= 45, (st, it)
+    si = dict(si, nom_u=si["nom_u"].reshape(2, -1))
+    f0 = _objective(cfg, si, s, u, d)
+    rng = np.random.default_rng(0)
+
+    def roll(U):
+        S = np.zeros((3, cfg.T + 1)); S[:, 0] = si["nom_s"][:, 0]
+        for t in range(cfg.T):
+            A, B, Cc = _lin(2, si["nom_s"][:, t], si["nom_u"][:, t], cfg.dt, cfg.L)
+            S[:, t + 1] = A @ S[:, t] + B @ U[:, t] + Cc
+        return S
+    assert np.abs(roll(u) - s).max() < 1e-9
+    for k in range(20):
+        U2 = np.clip(u + rng.normal(0, 1e-4, u.shape), -np.array([[10.0], [1.0]]), np.array([[10.0], [1.0]]))
+        for t in range(1, cfg.T):
+            U2[:, t] = np.clip(U2[:, t], U2[:, t - 1] - [1.0, 0.05], U2[:, t - 1] + [1.0, 0.05])
+        D2 = np.clip(d + rng.normal(0, 1e-4, d.shape), cfg.min_sd, cfg.max_sd)
+        assert _objective(cfg, si, roll(U2), U2, D2) >= f0 - 1e-7 * (1 + abs(f0))
+
+
 def test_su_stagnating_dual_residual_is_accepted(orc):
     """recorded instance (omni, T=25, 26 obstacles): with barrier weights lam/w of 1e10 the dual residual cannot fall below
     ~5e-8 relative while the complementarity keeps shrinking until the factorisation breaks down; the second termination
