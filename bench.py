@@ -119,10 +119,16 @@ def main():
     ap.add_argument("--force-shard-leg", action="store_true", help="run the obstacle-shard leg on ONE GPU with a one-rank communicator (plumbing check)")
     ap.add_argument("--shard-n-obs", type=int, default=2000)
     ap.add_argument("--shard-leg-timeout", type=float, default=240.0)
+    ap.add_argument("--no-sizes", action="store_true", help="skip the `sizes` legs (N=20, N=2000, C4, C5 shape: one short sub-run of this script each)")
+    ap.add_argument("--sizes-budget-s", type=float, default=75.0, help="wall-clock budget of the `sizes` legs; a leg that would start after it is skipped (and says so)")
+    ap.add_argument("--size-leg", action="store_true", help="(internal) reduced set of legs: what one entry of `sizes` needs")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline with this one thread count instead of the sweep")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="N>1: independent ego replicas (default, no collective) or ONE ego whose obstacles are sharded over the ranks "
                          "with an RCCL all-gather per ADMM iteration (strong scaling, --n-obs = total obstacles)")
     args = ap.parse_args()
+    if args.size_leg:                                   # one entry of `sizes`: the closed loops, the timed replay, one cpu_baseline sample
+        args.egos, args.no_ip_legs, args.no_sizes = 0, True, True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -153,6 +159,7 @@ def main():
     K, W = args.steps, args.warmup
     shard = args.mode == "shard" and world > 1
     car_t, path, obstacles, kw = build_workload(seed_offset=0 if shard else rank, n_obs=args.n_obs, T=args.horizon, n_steps=K + W, moving=args.moving)
+    path_length = max(40.0, 0.4 * (K + W) + 12.0)
 
     def make_sharded(solver):
         """obstacle shards + in-library ncclAllGather; the 128-byte unique id travels over torch.distributed"""
@@ -175,6 +182,7 @@ def main():
     trace, staged, mpc_rec = record_trace(car_t, path, obstacles, kw_rec, W + K, post_init=make_sharded)
     # the same closed loop with the caller-side obstacle pipeline on the device (rda_step_scene)
     cl_dev = cl_trk = None
+    u_ord = None
     if rank == 0 and not shard:
         from rda_planner_amd.mpc import MPC
         from rda_planner_amd import scenarios as sc
@@ -195,9 +203,23 @@ def main():
                 st = sc.kinematic_step(st, u, car_t, 0.1)
             return {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": None if args.moving else du,
                     "obstacles_advance_every_tick": bool(args.moving)}
-        cl_dev = closed_loop(False)
-        # ... and with MPC.pre_process on the device as well (rda_step_tracked): state in, control out
-        cl_trk = closed_loop(True)
+        if not args.size_leg:
+            cl_dev = closed_loop(False)
+            # ... and with MPC.pre_process on the device as well (rda_step_tracked): state in, control out
+            cl_trk = closed_loop(True)
+        if not args.moving:
+            # the reference's default: obstacle_order=True, the list re-sorted by distance on EVERY tick (mpc.py:205-206).  Controls of that
+            # closed loop through the Python API (device obstacle pipeline + tracking): what the ordered C-ABI legs must reproduce
+            mpc_o = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw)
+            if mpc_o.rda.has_scene and mpc_o.rda.has_track:
+                st = path[0].copy().reshape(3, 1)
+                u_ord = []
+                for k in range(W + K):
+                    u, _ = mpc_o.control(st, 4.0, list(obstacles))
+                    u_ord.append(u.ravel().copy())
+                    st = sc.kinematic_step(st, u, car_t, 0.1)
+                u_ord = np.array(u_ord)
+            del mpc_o
 
     from rda_planner_amd.rda_solver import RDA_solver
     from rda_planner_amd import scenarios as sc
@@ -266,10 +288,13 @@ def main():
         return sv
 
     # ---- HEADLINE: closed loop through the C-ABI, one host synchronisation per MPC step -------------------------------
-    def cabi_closed_loop(per_tick_scene, driver="c", car=None, compare=True, **solver_kw):
+    def cabi_closed_loop(per_tick_scene, driver="c", car=None, compare=True, ordered=False, **solver_kw):
         """state in / control out per step; scene resident in HBM (per_tick_scene False) or handed over from host memory on every
         tick (True, BASELINE.md 2.4 'including H2D of obstacles').  driver "c": the loop is tools/closed_loop_host.c (C-ABI calls and the
         kinematic model in C, nothing of the interpreter between two steps); "python": the same loop written with ctypes / numpy.
+        ordered: the reference's default obstacle_order=True - the scene is re-sorted by distance to the robot on EVERY tick and the nearest
+        max_obs_num are staged (mpc.py:205-206): per_tick_scene -> rda_upload_scene_async(order = 1), resident scene -> rda_scene_resort (the
+        same conversion kernels on the resident raw scene, no copy); compared with the ordered Python closed loop.
         Returns (elapsed of the K timed steps, per-step times, max |u - recorded Python closed loop|, iterations per step)."""
         sv = new_solver(car, **solver_kw)
         hh = sv._be.handle
@@ -285,7 +310,10 @@ def main():
         out_u, out_s, inf = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
         mi, eh = np.zeros(1, np.int32), np.zeros(1)
         nom_u0 = np.zeros((2, T))
-        order = int(bool(kw_rec["obstacle_order"]))
+        order = 1 if ordered else int(bool(kw_rec["obstacle_order"]))
+        want_u = (u_ord if ordered else np.array([trace["u"][k].ravel() for k in range(W + K)])) if (compare and not args.moving) else None
+        if ordered and want_u is None and not args.moving:
+            compare = False
         if not per_tick_scene:
             assert api.upload_scene(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(state), order, None) == 0
         cur, du, its, times = 0, 0.0, [], []
@@ -296,7 +324,10 @@ def main():
             scn = host.Scene(int(n_sc) if per_tick_scene else 0, int(geom.shape[1]), order, int(bool(args.moving)), iptr(kind), iptr(nvert),
                              dptr(geom), dptr(geom0), dptr(vel))
             cur_c = C.c_int32(0)
-            u_log, t_log, it_log = np.zeros((W + K, 2)), np.zeros(W + K), np.zeros(W + K, np.int32)
+            # a second window of K steps right behind the timed one, when the path is long enough (the driver's 20-step window after 5
+            # warm-up steps is all start-up: no solver history yet, 2.0 instead of ~2.6 ADMM iterations per step)
+            K2 = K if 0.4 * (W + 2 * K) + 8.0 <= path_length else 0
+            u_log, t_log, it_log = np.zeros((W + K + K2, 2)), np.zeros(W + K + K2), np.zeros(W + K + K2, np.int32)
             dyn = {"acker": 0, "diff": 1, "omni": 2}[wb]
 
             def run(k0, n):
@@ -311,9 +342,18 @@ def main():
             api.lib.rda_sync(hh)
             barrier_all()
             el = max_over_ranks(time.perf_counter() - t_start)
-            if not args.moving and compare:
-                du = float(np.abs(u_log - np.array([trace["u"][k].ravel() for k in range(W + K)])).max())
-            return el, t_log[W:].copy(), du, [int(v) for v in it_log[W:]]
+            cabi_closed_loop.second_window = None
+            if K2 and world == 1:
+                t2 = time.perf_counter()
+                run(W + K, K2)
+                api.lib.rda_sync(hh)
+                el2 = time.perf_counter() - t2
+                cabi_closed_loop.second_window = {"steps": K2, "after_steps": W + K, "steps_per_s": round(K2 / el2, 2),
+                                                  "median_ms_per_step": round(float(np.median(t_log[W + K:]) * 1e3), 5),
+                                                  "mean_admm_iters": round(float(np.mean(it_log[W + K:])), 3)}
+            if want_u is not None:
+                du = float(np.abs(u_log[:W + K] - want_u[:W + K]).max())
+            return el, t_log[W:W + K].copy(), du, [int(v) for v in it_log[W:W + K]]
         for k in range(W + K):
             if k == W:
                 api.lib.rda_sync(hh)
@@ -326,6 +366,10 @@ def main():
                     geom[:, :, :] = geom0 + (vel * (0.1 * k))[:, None, :] * (np.arange(geom.shape[1])[None, :, None] < nvert[:, None, None])
                 rc = api.tracked_begin(hh, dptr(state), 4.0, int(cur), 0.1, 10, nu)
                 rc |= api.upload_scene_async(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(state), order)
+                rc |= api.tracked_finish(hh, dptr(out_u), dptr(out_s), C.byref(inf), None, None, iptr(mi), dptr(eh))
+            elif ordered:
+                rc = api.tracked_begin(hh, dptr(state), 4.0, int(cur), 0.1, 10, nu)
+                rc |= api.scene_resort(hh, dptr(state))
                 rc |= api.tracked_finish(hh, dptr(out_u), dptr(out_s), C.byref(inf), None, None, iptr(mi), dptr(eh))
             else:
                 rc = api.step_tracked(hh, dptr(state), 4.0, int(cur), 0.1, 10, nu, dptr(out_u), dptr(out_s), C.byref(inf), None, None,
@@ -344,8 +388,8 @@ def main():
             if k >= W:
                 times.append(time.perf_counter() - t0)
                 its.append(inf.iters)
-            if not args.moving:
-                du = max(du, float(np.abs(out_u[:, 0] - trace["u"][k].ravel()).max()))
+            if want_u is not None:
+                du = max(du, float(np.abs(out_u[:, 0] - want_u[k]).max()))
         api.lib.rda_sync(hh)
         barrier_all()
         el = max_over_ranks(time.perf_counter() - t_start)
@@ -353,21 +397,30 @@ def main():
 
     head = None
     if not shard:
-        el_h, times_h, du_h, its_h = cabi_closed_loop(per_tick_scene=bool(args.moving))
-        head = {"elapsed": el_h, "median_ms": float(np.median(times_h) * 1e3), "du": du_h, "iters": its_h}
+        # HEADLINE = the reference's default semantics: obstacle_order=True, the scene re-sorted about the robot on every tick
+        el_h, times_h, du_h, its_h = cabi_closed_loop(per_tick_scene=bool(args.moving), ordered=True)
+        head = {"elapsed": el_h, "median_ms": float(np.median(times_h) * 1e3), "du": du_h, "iters": its_h, "second_window": cabi_closed_loop.second_window}
         pcie = None
         pydrv = None
+        fixed = None
         if rank == 0 and world == 1:
-            el_y, times_y, du_y, _ = cabi_closed_loop(per_tick_scene=bool(args.moving), driver="python")
+            # the protocol of rounds 2-3: slots bound once (obstacle_order=False), no conversion kernel inside the timed region
+            el_f, times_f, du_f, its_f = cabi_closed_loop(per_tick_scene=bool(args.moving))
+            fixed = {"steps_per_s": round(K / el_f, 2), "median_ms_per_step": round(float(np.median(times_f) * 1e3), 5),
+                     "mean_admm_iters": round(float(np.mean(its_f)), 3), "max_du_vs_python_closed_loop": du_f if not args.moving else None,
+                     "second_window": cabi_closed_loop.second_window,
+                     "what": "obstacle_order=False: slots bound once at staging, rda_step_tracked per step (the headline protocol of rounds 2-3; the reference's default re-sorts every tick)"}
+        if rank == 0 and world == 1 and not args.size_leg:
+            el_y, times_y, du_y, _ = cabi_closed_loop(per_tick_scene=bool(args.moving), driver="python", ordered=True)
             pydrv = {"steps_per_s": round(K / el_y, 2), "median_ms_per_step": round(float(np.median(times_y) * 1e3), 5),
                      "max_du_vs_python_closed_loop": du_y if not args.moving else None,
                      "what": "the headline loop with the caller written in Python (ctypes calls + numpy kinematics between two steps)"}
         if rank == 0 and not args.moving:
-            el_p, times_p, du_p, _ = cabi_closed_loop(per_tick_scene=True) if world == 1 else (None, None, None, None)
+            el_p, times_p, du_p, _ = cabi_closed_loop(per_tick_scene=True, ordered=True) if world == 1 else (None, None, None, None)
             if el_p is not None:
                 pcie = {"steps_per_s": round(K / el_p, 2), "median_ms_per_step": round(float(np.median(times_p) * 1e3), 5),
                         "max_du_vs_python_closed_loop": du_p,
-                        "what": "raw scene (vertices, velocities) handed over from host memory every tick: rda_tracked_begin + rda_upload_scene_async + rda_tracked_finish"}
+                        "what": "raw scene (vertices, velocities) handed over from host memory AND re-sorted every tick: rda_tracked_begin + rda_upload_scene_async(order=1) + rda_tracked_finish"}
 
     # ---- interior-point LamMuZ mode (row-parallel kernel k_lammuz_ip): the robust setting lmz_central = 1e-3 on the headline scene, and a
     #      CIRCLE robot (norm2 robot cone, rda_solver.py:1034-1039: always this mode).  Same closed-loop protocol as the headline.
@@ -433,23 +486,25 @@ def main():
 
     # the same replay with one host synchronisation per step: how long the host needs to queue a step (all launches of one MPC step)
     # and what a step costs when the device starts from an empty stream - the latency floor of the closed loop
-    solver3 = new_solver()
-    h3 = solver3._be.handle
-    api.lib.rda_upload_obstacles(h3, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
-    api.lib.rda_upload_trace(h3, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"]))
-    t_enq, t_tot = [], []
-    for k in range(W + K):
-        ta = time.perf_counter()
-        api.lib.rda_enqueue_step(h3, k)
-        tb = time.perf_counter()
-        api.lib.rda_sync(h3)
-        tc = time.perf_counter()
-        if k >= W:
-            t_enq.append(tb - ta)
-            t_tot.append(tc - ta)
-    sync_replay = {"median_ms_per_step": round(float(np.median(t_tot)) * 1e3, 5), "median_host_enqueue_ms": round(float(np.median(t_enq)) * 1e3, 5),
-                   "what": "replay with rda_sync after every step: host time to queue one step's launches, and the step latency from an idle stream"}
-    del solver3
+    sync_replay = None
+    if not args.size_leg:
+        solver3 = new_solver()
+        h3 = solver3._be.handle
+        api.lib.rda_upload_obstacles(h3, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+        api.lib.rda_upload_trace(h3, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"]))
+        t_enq, t_tot = [], []
+        for k in range(W + K):
+            ta = time.perf_counter()
+            api.lib.rda_enqueue_step(h3, k)
+            tb = time.perf_counter()
+            api.lib.rda_sync(h3)
+            tc = time.perf_counter()
+            if k >= W:
+                t_enq.append(tb - ta)
+                t_tot.append(tc - ta)
+        sync_replay = {"median_ms_per_step": round(float(np.median(t_tot)) * 1e3, 5), "median_host_enqueue_ms": round(float(np.median(t_enq)) * 1e3, 5),
+                       "what": "replay with rda_sync after every step: host time to queue one step's launches, and the step latency from an idle stream"}
+        del solver3
 
     # replay must reproduce the recorded closed loop (same inputs, same initial state)
     u_last = np.zeros((2, T))
@@ -649,6 +704,42 @@ def main():
                     r_su["traffic_source"] = r_lm["traffic_source"] = tj.get("source")
         except Exception:
             pass
+    # What actually bounds these kernels: instruction issue, not bytes.  From the SQ counters of the committed profile of
+    # this workload (profiles/issue.json, written by tools/profile_collect.py from the --pmc passes of tools/profile_round.sh; per dispatch,
+    # averaged over executed and skipped launches alike, so every figure is a RATIO of two counters of the same pass):
+    #   ipc_per_wave  = (VALU + SALU + LDS + VMEM wave-instructions) / (4 SQ_WAVE_CYCLES)   (SQ_WAVE_CYCLES counts quad-cycles summed over the
+    #                   waves: 4 x 51.8 k / 4 waves = 51.8 k cycles = 21.6 us at 2.4 GHz for k_su<20>, rocprofv3's average launch is 20.6 us;
+    #                   1 = a wave issuing every cycle it is resident)
+    #   fp64_frac     = fp64 FLOP (2 FMA + MUL + ADD, x 64 lanes = upper bound) per launch / measured launch time / 78.6 TFLOP/s (vector fp64)
+    #   serial_cycles = k_su only: instructions of ONE wave x 6.4 cycles (measured issue interval of a lone wave, tools/latency_micro.cpp)
+    #                   = the length of the dependent chain the launch walks; serial_frac = that / the measured launch time at 2.4 GHz
+    is_file = os.path.join(ROOT, "profiles", "issue.json")
+    if os.path.exists(is_file):
+        try:
+            ij = json.load(open(is_file))
+            for wl in ij.get("workloads", {}).values():
+                if (wl["n_obs"], wl["horizon"], bool(wl["moving"])) != (N, T, bool(args.moving)) or world != 1:
+                    continue
+                for r in (r_su, r_lm):
+                    c = wl["kernels"].get(r["kernel"].split("+")[0])
+                    if not c:
+                        continue
+                    insts = c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_LDS", 0) + c.get("SQ_INSTS_VMEM_RD", 0)
+                    if c.get("SQ_WAVE_CYCLES"):
+                        r["ipc_per_wave"] = round(insts / (4.0 * c["SQ_WAVE_CYCLES"]), 4)
+                    flop = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0))
+                    t_all = (r["avg_us_over_all_launches"] or 0) * 1e-6
+                    if flop and t_all:
+                        r["fp64_gflops"] = round(flop / t_all / 1e9, 2)
+                        r["fp64_frac"] = round(flop / t_all / 78.6e12, 6)
+                    if r is r_su and c.get("SQ_WAVES"):
+                        per_wave = insts / c["SQ_WAVES"]
+                        r["serial_cycles"] = round(per_wave * 6.4)
+                        if t_all:
+                            r["serial_frac"] = round(per_wave * 6.4 / (t_all * 2.4e9), 4)
+                    r["issue_source"] = ij.get("source")
+        except Exception:
+            pass
     dominant, secondary = (r_su, r_lm) if r_su["total_ms"] >= r_lm["total_ms"] else (r_lm, r_su)
 
     kind_word = "moving" if args.moving else "static"
@@ -659,10 +750,12 @@ def main():
               "synchronised_per_step": sync_replay}
     if head is not None:
         value, ms_step = K * world / head["elapsed"], head["elapsed"] / K * 1e3
-        protocol = ("closed loop through the C-ABI, caller in C (tools/closed_loop_host.c): per step rda_step_tracked(state) -> control, one host "
-                    "sync per step, host applies the control to the kinematic model; scene resident in HBM" if not args.moving else
-                    "closed loop through the C-ABI, caller in C (tools/closed_loop_host.c), obstacles advance every tick: rda_tracked_begin + "
-                    "rda_upload_scene_async + rda_tracked_finish per step")
+        protocol = ("closed loop through the C-ABI, caller in C (tools/closed_loop_host.c), the reference's default obstacle_order=True: per step "
+                    "rda_tracked_begin(state) + rda_scene_resort(state) + rda_tracked_finish -> control (the resident scene is re-sorted about the robot "
+                    "and the nearest max_obs_num re-staged by k_keys / k_rank / k_build / k_prepare INSIDE the timed region, mpc.py:205-206), one host "
+                    "sync per step, host applies the control to the kinematic model; raw scene resident in HBM" if not args.moving else
+                    "closed loop through the C-ABI, caller in C (tools/closed_loop_host.c), obstacles advance every tick and are re-sorted "
+                    "(obstacle_order=True): rda_tracked_begin + rda_upload_scene_async(order=1) + rda_tracked_finish per step")
     else:                   # obstacle shards: the RCCL path is driven by the replay (every rank enqueues the same steps)
         value, ms_step, protocol = replay["steps_per_s"], replay["ms_per_step"], replay["what"]
     out = {
@@ -675,6 +768,8 @@ def main():
         "median_ms_per_step": round(head["median_ms"], 5) if head else None,
         "max_du_vs_python_closed_loop": head["du"] if head and not args.moving else None,
         "mean_admm_iters": round(float(np.mean(head["iters"])) if head else mean_iters, 3),
+        "second_window": head["second_window"] if head else None,
+        "fixed_slot_binding": fixed if head else None,
         "pcie_inclusive": pcie if head else None,
         "python_caller_closed_loop": pydrv if head else None,
         "device_resident_replay": replay,
@@ -695,7 +790,8 @@ def main():
         os_ = np.zeros((3, T + 1))
         sweep, err, n_total = {}, 0.0, 0
         k = 0
-        for nthr in sorted({t for t in (1, 8, 16, 32, 64, ncore) if t <= ncore}):
+        counts = sorted({t for t in (1, 8, 16, 32, 64, ncore) if t <= ncore}) if not args.cpu_threads else [min(args.cpu_threads, ncore)]
+        for nthr in counts:
             orc_api().lib.orc_set_threads(nthr)
             n_cpu, t_cpu = 0, 0.0
             while t_cpu < 2.5 or n_cpu < 3:                  # consecutive steps of ONE closed loop (the duals stay warm) ...
@@ -718,6 +814,44 @@ def main():
                                "note": "a restatement of the ADMM in C, NOT the reference's CVXPY+ECOS+pathos path (not installable here): the "
                                        "north-star '>=100x the reference CPU path' cannot be measured against this number",
                                "max_du_vs_gpu": err}
+    # ---- every size the metric names + the moving-obstacle and multi-ego configurations, in the SAME driver-run line: one short sub-run of
+    #      this script each (own process: a fresh HIP context per shape; --size-leg keeps the closed loops, the timed replay and one
+    #      16-thread cpu_baseline sample).  BASELINE.json: N in {20, 200, 2000} at T=20; C4 = 200 moving polygons, T=30; C5 = 64 egos x 100
+    #      obstacles, T=25.
+    if world == 1 and not args.no_sizes and (N, T, bool(args.moving)) == (200, 20, False):
+        import subprocess
+        legs = [("n20_T20", ["--n-obs", "20", "--steps", "40", "--warmup", "10", "--fleet-egos", "0"]),
+                ("n2000_T20", ["--n-obs", "2000", "--steps", "30", "--warmup", "8", "--fleet-egos", "0"]),
+                ("c4_dynamic_obs_n200_T30_moving", ["--n-obs", "200", "--horizon", "30", "--moving", "--steps", "30", "--warmup", "8", "--fleet-egos", "0"]),
+                ("c5_shape_n100_T25_fleet64", ["--n-obs", "100", "--horizon", "25", "--steps", "30", "--warmup", "8", "--fleet-egos", "64"])]
+        t_sz, sizes = time.perf_counter(), {}
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        for name, extra in legs:
+            left = args.sizes_budget_s - (time.perf_counter() - t_sz)
+            if left < 8.0:
+                sizes[name] = {"skipped": f"sizes budget of {args.sizes_budget_s:.0f} s used up"}
+                continue
+            try:
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--size-leg", "--cpu-threads", "16"] + extra,
+                                    capture_output=True, text=True, timeout=left + 20.0, env=env)
+                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                j = json.loads(line[-1])
+                keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_ms_per_step", "mean_admm_iters", "max_du_vs_python_closed_loop",
+                        "second_window", "roofline", "roofline_secondary", "cpu_baseline", "multi_ego_fleet")
+                e = {k: j.get(k) for k in keep}
+                e["workload"] = j["config"]["workload"]
+                e["fixed_slot_binding_steps_per_s"] = (j.get("fixed_slot_binding") or {}).get("steps_per_s")
+                e["pcie_inclusive_steps_per_s"] = (j.get("pcie_inclusive") or {}).get("steps_per_s")
+                e["replay_steps_per_s"] = j["device_resident_replay"]["steps_per_s"]
+                if e.get("cpu_baseline"):
+                    e["cpu_baseline"] = {k: e["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "max_du_vs_gpu")}
+                    e["gpu_over_cpu_port"] = round(j["value"] / e["cpu_baseline"]["value"], 1) if e["cpu_baseline"]["value"] else None
+                e["leg_wall_s"] = None
+                sizes[name] = e
+            except Exception as ex:                         # the headline must not depend on these legs
+                sizes[name] = {"error": repr(ex)[:300]}
+        out["sizes"] = sizes
+        out["sizes_wall_s"] = round(time.perf_counter() - t_sz, 1)
     if want_shard_leg:
         import threading
 

@@ -216,6 +216,14 @@ int  rda_upload_scene_async(rda_handle *h, int n, const int32_t *kind, const int
                             const double *vel, const double *robot_xy, int order);
 int  rda_tracked_finish(rda_handle *h, double *out_u, double *out_s, rda_info *info,
                         double *nom_s_out, double *ref_out, int32_t *min_index, double *end_heading);
+/* The reference re-sorts the caller's obstacle list by distance to the robot on EVERY tick (MPC.convert_rda_obstacle with
+ * obstacle_order=True, its default: mpc.py:205-206) and stages the first max_obs_num.  For a raw scene that is already resident
+ * (rda_upload_scene / rda_upload_scene_async) rda_scene_resort re-ranks it about robot_xy and rebuilds the obstacle slots with the same
+ * kernels (k_keys / k_rank / k_build / k_prepare): the position travels in the kernel arguments, nothing is copied.  Asynchronous like
+ * rda_upload_scene_async and usable between rda_tracked_begin and rda_tracked_finish.  Slots come out bit-identical to uploading the
+ * same scene again with order = 1.  A scene whose obstacles MOVE between ticks has to be uploaded again instead (the prediction over
+ * the horizon starts from the uploaded geometry).  RDA_ERR_ARG without a resident raw scene. */
+int  rda_scene_resort(rda_handle *h, const double *robot_xy /*2*/);
 
 /* ---- Fleet: B independent egos advanced together (BASELINE config C5, "batched multi-ego") -------------------
  * The reference plans one robot per RDA_solver object (rda_solver.py:54-109) and a multi-robot user loops over
@@ -260,7 +268,7 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime; lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
 int  rda_get_su_history(rda_handle *h, int32_t *hist /*2*/, double *lam_keep /*10*T*/);
-int  rda_set_su_history(rda_handle *h, const int32_t *hist /*16*/, const double *lam_keep /*10*T*/);
+int  rda_set_su_history(rda_handle *h, const int32_t *hist /*2*/, const double *lam_keep /*10*T*/);
 /* Interior-point LamMuZ mode: the central-path points the sub-problems last ended on ([T][N][5][16] doubles: x | s, z of the diagonal
  * rows | s, z of the general rows, csrc/lammuz_ip_device.h) and their validity flags [T][N] - where each sub-problem's next solve starts.
  * Solver history like the su history above: it moves a result only within the centring tolerance (1e-7 mu relative), rda_reset clears
@@ -274,15 +282,20 @@ int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ 
 
 /* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns the obstacle slots
  * [r*ceil(N/world), (r+1)*ceil(N/world)): it solves their LamMuZ problems and keeps their duals.  What the su-problem needs of
- * them forms one contiguous chunk per rank - 9 doubles per (slot, stage): a(2), lam'b, mu'h+z-zeta, G'mu+xi (2), the two residual
- * partials, the hinge offset; plus, per (stage, 16-slot block), the 5 reduced sums and the near mask the su set-up reads instead
- * of passing over the terms - replicated to every rank by ONE all-gather per ADMM iteration (replaces the pool.map scatter/gather
- * of rda_solver.py:706-725); every rank then solves the identical su-problem.  rda_shard_config must precede the first step.
+ * them forms one contiguous chunk per rank - 3 doubles per (slot, stage): a = A'lam (2) and the hinge offset lam'b + mu'h + z - zeta;
+ * plus, per (stage, 8-slot block), the 5 reduced sums (sum |a|^2, sum g.a, sum g x a, the two residual partials) and one 8-byte word
+ * with the near mask the su set-up reads instead of passing over the terms - replicated to every rank by ONE all-gather per ADMM
+ * iteration (replaces the pool.map scatter/gather of rda_solver.py:706-725); every rank then solves the identical su-problem.  The
+ * other per-row records (lam'b, mu'h + z - zeta, G'mu + xi, residual records) stay on the owning rank; for that reason
+ *   - rda_opts::su_pre = 0 (the su set-up evaluating raw terms) is overridden to 1 when world > 1, and
+ *   - rda_reset / rda_set_state return RDA_ERR_UNSUPPORTED on a handle with world > 1 once it has stepped (the remote slots' terms
+ *     cannot be rebuilt locally; reset / restore the state BEFORE the first step, or re-create the handles).
+ * rda_shard_config must precede the first step.
  * N need not be divisible by world: the shards have ceil(N / world) slots, the slots past the last obstacle carry terms the
  * su-problem ignores - this relies on the hinge of the accelerated cost: with accelerated = 0 and N % world != 0
  * rda_shard_config returns RDA_ERR_UNSUPPORTED. */
 int  rda_shard_config(rda_handle *h, int rank, int world);
-int  rda_shard_chunk_doubles(rda_handle *h);                       /* 9*T*Nloc + 6*T*ceil(Nloc/16), Nloc = ceil(N/world) */
+int  rda_shard_chunk_doubles(rda_handle *h);                       /* 3*T*Nloc + 6*T*ceil(Nloc/8), Nloc = ceil(N/world) */
 int  rda_shard_get_chunk(rda_handle *h, double *host_chunk);       /* this rank's chunk  */
 int  rda_shard_set_chunks(rda_handle *h, const double *host_all);  /* all `world` chunks, rank-major */
 /* RCCL exchange over xGMI: rank 0 calls rda_shard_unique_id and ships the 128 bytes to the other ranks (any

@@ -131,6 +131,9 @@ class CApi:
                                                 c_int_p, c_double_p]
                 for name in ("tracked_begin", "upload_scene_async", "tracked_finish"):
                     f(name).restype = C.c_int
+                if hasattr(lib, f"{prefix}_scene_resort"):
+                    f("scene_resort").argtypes = [C.c_void_p, c_double_p]
+                    f("scene_resort").restype = C.c_int
             if hasattr(lib, f"{prefix}_fleet_step_tracked"):
                 f("fleet_step_tracked").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, C.c_double, C.c_int, c_double_p,
                                                     c_double_p, c_double_p, C.POINTER(Info), c_double_p, c_int_p, c_double_p]

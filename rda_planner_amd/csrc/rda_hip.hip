@@ -1219,12 +1219,14 @@ struct rda_handle {
     int timing; std::vector<hipEvent_t> ev[3]; size_t ev_used[3];      // 0 LamMuZ launches, 1 su launches, 2 shard all-gathers
     // device-side obstacle pipeline (rda_upload_scene): scene description and scratch, grown on demand
     int sc_cap; int *d_sc_sel; double *d_sc_blk, *d_sc_key;     // d_sc_blk mirrors the pinned block h_sc (ONE H2D copy per upload)
+    scene::Args sc_args; int sc_n;                              // the resident raw scene as the conversion kernels were last given it (sc_n = 0: none)
     void *h_sc; size_t h_sc_bytes;
     // device-side pre_process (rda_upload_path / rda_step_tracked)
     double *d_path; int path_len; track::Out *d_trk, *h_trk;
     int dense_from;          // grids above this many workgroups use the dense form of the LamMuZ launch (rda_opts::lmz_dense_from)
     int ip_rows;             // interior-point mode runs the row-parallel kernel (shape allows it and rda_opts::lmz_ip_rows)
     int admm_it;             // host-driven ADMM pieces (rda_admm_*): the iteration rda_admm_su was last called with
+    int stepped;             // a step has been queued on this handle (sharded handles: rda_reset / rda_set_state are refused from then on)
 };
 
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -1453,9 +1455,14 @@ static int terms_rebuild(rda_handle *H)
     return RDA_OK;
 }
 
+// Obstacle shards: the local term arrays (hinge offsets, G'mu + xi) of the OTHER ranks' slots are never populated on this rank, so the
+// terms of remote slots cannot be rebuilt here once the ranks have stepped - a reset / state rewrite would leave every rank with a
+// different su-problem (and different early-stop verdicts: the next all-gather would hang).  Refused from the first step on.
+static inline bool shard_frozen(const rda_handle *H) { return H->d.P > 1 && H->stepped; }
 extern "C" int rda_reset(rda_handle *H)
 {
     if (!H) return RDA_ERR_ARG;
+    if (shard_frozen(H)) return RDA_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, H->stream, H->d);
     HIPCHK(hipGetLastError());
     int rc = terms_rebuild(H);
@@ -1573,7 +1580,7 @@ static int scene_reserve(rda_handle *H, int n)
     const size_t E = H->d.c.E;
     if (n > H->sc_cap) {
         dev_free(H->d_sc_blk); dev_free(H->d_sc_sel); dev_free(H->d_sc_key);
-        H->d_sc_blk = nullptr; H->d_sc_sel = nullptr; H->d_sc_key = nullptr; H->sc_cap = 0;
+        H->d_sc_blk = nullptr; H->d_sc_sel = nullptr; H->d_sc_key = nullptr; H->sc_cap = 0; H->sc_n = 0;
         int cap = n + n / 2 + 16, rc = 0;
         rc |= dalloc(&H->d_sc_blk, scene_block_bytes((size_t)cap, E) / sizeof(double) + 1);
         rc |= dalloc(&H->d_sc_sel, (size_t)cap); rc |= dalloc(&H->d_sc_key, (size_t)cap);
@@ -1588,6 +1595,19 @@ static int scene_reserve(rda_handle *H, int n)
         H->h_sc_bytes = need * 2;
     }
     return RDA_OK;
+}
+
+// the conversion kernels on a raw scene that is in device memory: distance keys, stable rank, half-space slots, candidate lists
+static void scene_kernels(rda_handle *H, const scene::Args &a, hipStream_t st)
+{
+    Dev &d = H->d;
+    const int n = a.n, N = a.N;
+    hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scene::k_rank, dim3((n + 15) / 16), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
+    d.nt = a.nt; d.obstacle_num = N;
+    d.slot_src = H->d_sc_sel; d.src_used = n < N ? n : N;          // the remembered supports follow the obstacles through the re-binding (Dev::hint)
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);
 }
 
 static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
@@ -1624,12 +1644,9 @@ static int scene_stage(rda_handle *H, int n, const int32_t *kind, const int32_t 
     a.n = n; a.N = N; a.E = E; a.T = T; a.nt = any_moving ? T + 1 : 1; a.order = order; a.dt = d.c.dt;
     a.kind = (int *)(db + o_int); a.nvert = (int *)(db + o_int) + n; a.geom = db; a.vel = db + o_vel; a.robot = db + o_rob;
     a.key = H->d_sc_key; a.sel = H->d_sc_sel; a.A = d.A; a.b = d.b; a.cone = d.cone; a.nonconvex = d_bad;
-    hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(scene::k_rank, dim3((n + 15) / 16), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
-    d.nt = a.nt; d.obstacle_num = N;
-    d.slot_src = H->d_sc_sel; d.src_used = n < N ? n : N;          // the remembered supports follow the obstacles through the re-binding (Dev::hint)
-    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);
+    a.rx = 0; a.ry = 0; a.robot_val = 0;
+    H->sc_args = a; H->sc_n = n;
+    scene_kernels(H, a, st);
     HIPCHK(hipGetLastError());
     if (n_nonconvex) {
         HIPCHK(hipMemcpyAsync(H->h_sc, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1798,6 +1815,7 @@ static int fetch_result(rda_handle *H)
 static int enqueue_admm_head(rda_handle *H, const double *in_s, const double *in_u, const double *ref, const double *speed)
 {
     Dev d = H->d;
+    H->stepped = 1;
     d.ref = const_cast<double *>(ref); d.ref_speed = const_cast<double *>(speed);
     launch_su(H, d, 0, in_s, in_u);                    // resets the step's control block itself (su_body, it == 0)
     HIPCHK(hipGetLastError());
@@ -2011,16 +2029,15 @@ extern "C" int rda_tracked_begin(rda_handle *H, const double *state, double ref_
     return RDA_OK;
 }
 
-extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
-                                      const double *vel, const double *robot_xy, int order)
+// asynchronous scene work (stage(stream) -> rc; `live`: it queued something), outside or inside a tick
+template <typename Stage> static int scene_async(rda_handle *H, bool live, Stage stage)
 {
-    if (!H) return RDA_ERR_ARG;
     // one pinned staging block per handle: a second upload before the caller's synchronising call (rda_tracked_finish,
     // rda_sync, a fleet step) has to wait for the first one to have been copied
     if (H->pending_scene) { HIPCHK(hipStreamSynchronize(H->stream)); HIPCHK(hipStreamSynchronize(H->stream2)); H->pending_scene = 0; H->scene_on_s2 = 0; }
     if (!H->pending) {
-        int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false);
-        if (rc == RDA_OK && n > 0) H->pending_scene = 1;
+        int rc = stage(H->stream);
+        if (rc == RDA_OK && live) H->pending_scene = 1;
         return rc;
     }
     // inside a tick: the copy and the conversion kernels touch only the obstacle slots, which nothing of the head (k_track,
@@ -2028,9 +2045,35 @@ extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind,
     if (!H->tick_has_event) { HIPCHK(hipEventRecord(H->ev_tick, H->stream)); H->tick_has_event = 1; }
     H->tick_stages = 1;
     HIPCHK(hipStreamWaitEvent(H->stream2, H->ev_tick, 0));
-    int rc = scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false, H->stream2);
-    if (rc == RDA_OK && n > 0) { HIPCHK(hipEventRecord(H->ev_scene, H->stream2)); H->pending_scene = 1; H->scene_on_s2 = 1; }
+    int rc = stage(H->stream2);
+    if (rc == RDA_OK && live) { HIPCHK(hipEventRecord(H->ev_scene, H->stream2)); H->pending_scene = 1; H->scene_on_s2 = 1; }
     return rc;
+}
+
+extern "C" int rda_upload_scene_async(rda_handle *H, int n, const int32_t *kind, const int32_t *nvert, const double *geom,
+                                      const double *vel, const double *robot_xy, int order)
+{
+    if (!H) return RDA_ERR_ARG;
+    return scene_async(H, n > 0, [&](hipStream_t st) -> int { return scene_stage(H, n, kind, nvert, geom, vel, robot_xy, order, nullptr, false, st); });
+}
+
+// The reference re-sorts the obstacle list by distance on EVERY tick (mpc.py:205-206, obstacle_order=True) before the first max_obs_num
+// are staged.  For a scene that is already resident (rda_upload_scene*) this re-ranks it about a new robot position and rebuilds the
+// slots - the same three kernels, the position travels in the kernel arguments: no host-to-device copy.  Asynchronous like
+// rda_upload_scene_async (inside a tick it runs beside the first su-problem).  Obstacles with a velocity are predicted from the
+// geometry that was uploaded, i.e. a scene that MOVES between ticks has to be uploaded again instead.
+extern "C" int rda_scene_resort(rda_handle *H, const double *robot_xy)
+{
+    if (!H || !robot_xy) return RDA_ERR_ARG;
+    if (H->sc_n <= 0 || H->d.obstacle_num == 0) return RDA_ERR_ARG;              // no resident raw scene
+    return scene_async(H, true, [&](hipStream_t st) -> int {
+        scene::Args a = H->sc_args;
+        a.order = 1; a.robot_val = 1; a.rx = robot_xy[0]; a.ry = robot_xy[1];
+        HIPCHK(hipMemsetAsync(a.nonconvex, 0, sizeof(int), st));
+        scene_kernels(H, a, st);
+        HIPCHK(hipGetLastError());
+        return (int)RDA_OK;
+    });
 }
 
 extern "C" int rda_tracked_finish(rda_handle *H, double *out_u, double *out_s, rda_info *info,
@@ -2234,6 +2277,7 @@ extern "C" int rda_set_state(rda_handle *H, const double *lam, const double *mu,
                              const double *a_lam, const double *b_lam)
 {
     if (!H) return RDA_ERR_ARG;
+    if (shard_frozen(H)) return RDA_ERR_UNSUPPORTED;
     Dev &d = H->d; const size_t T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
     HIPCHK(hipStreamSynchronize(H->stream));
     std::vector<double> tmp;
@@ -2278,6 +2322,9 @@ extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
     HIPCHK(hipStreamSynchronize(H->stream));
     Dev &d = H->d;
     dev_free(d.coef); d.coef = nullptr; dev_free(d.coefL); d.coefL = nullptr;
+    // su_pre = 0 (the su set-up evaluates every term itself) reads g = G'mu + xi of every slot, which lives in the LOCAL chunk and is
+    // never gathered: with more than one rank the reduced form (block sums / near masks, part of the gathered chunk) is the only one
+    if (world > 1) d.su_pre = 1;
     d.P = world; d.rank = rank; d.Nloc = (d.c.N + world - 1) / world; d.J = (d.Nloc + GS - 1) / GS; d.chunk = chunk_doubles(d.c.T, d.Nloc);
     d.lchunk = lchunk_doubles(d.c.T, d.Nloc);
     const int first = rank * d.Nloc;
@@ -2358,6 +2405,7 @@ extern "C" int rda_admm_begin(rda_handle *H, const double *nom_s, const double *
 {
     if (!H || !nom_s || !nom_u || !ref_s) return RDA_ERR_ARG;
     const size_t T = H->d.c.T, ns = 3 * (T + 1), nu = 2 * T;
+    H->stepped = 1;
     HIPCHK(hipStreamSynchronize(H->stream));
     memcpy(H->h_step, nom_s, ns * sizeof(double));
     memcpy(H->h_step + ns, nom_u, nu * sizeof(double));

@@ -21,6 +21,7 @@ struct Args {
     const double *geom;     // [n][E][2]: polygon vertices | circle: centre, (radius, -)
     const double *vel;      // [n][2]
     const double *robot;    // [2] robot position used for the distance ordering
+    double rx, ry; int robot_val;   // robot_val != 0: the position travels in the kernel arguments (rda_scene_resort: a resident scene re-ranked without a copy)
     double *key; int *sel;  // [n] scratch
     double *A, *b; int *cone;
     int *nonconvex;         // count of polygons failing is_convex_and_ordered (the reference prints a warning)
@@ -33,7 +34,7 @@ __global__ void k_keys(Args a)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (!a.order) { a.key[i] = (double)i; return; }
-    const double x = a.robot[0], y = a.robot[1];
+    const double x = a.robot_val ? a.rx : a.robot[0], y = a.robot_val ? a.ry : a.robot[1];
     const double *g = a.geom + (size_t)i * a.E * 2;
     if (a.kind[i] == 1) {
         double dx = x - g[0], dy = y - g[1];

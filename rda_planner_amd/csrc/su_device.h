@@ -729,6 +729,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     for (it = 0; it < it_cap; ++it) {
         seq += 1;
         const double heps = (attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;
+        // (rescue phase: the smoothed hinge is non-zero for EVERY term - the oracle sums them all, so does this pass; such iterations are rare)
+        const bool screened_now = screened && !(heps > 0);
         // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
         {
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
@@ -739,7 +741,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 auto term = [&](double ax, double ay, double cb) {
                     double Im = ax * px + ay * py - cb - dd;
                     if (c.accelerated && heps > 0) {
-                        const double e2 = 4 * heps * heps, rt = sqrt(Im * Im + e2), sv = 0.5 * (rt - Im), ds = 0.5 * (Im / rt - 1.0), d2 = 0.5 * e2 / (rt * rt * rt);
+                        const double e2 = 4 * heps * heps, rr = sqrt(Im * Im + e2), sv = 0.5 * (rr - Im), ds = 0.5 * (Im / rr - 1.0), d2 = 0.5 * e2 / (rr * rr * rr);
                         const double c1 = sv * ds, c2 = ds * ds + sv * d2;
                         sxx += c2 * ax * ax; sxy += c2 * ax * ay; syy += c2 * ay * ay; sx += c2 * ax; sy += c2 * ay; s1 += c2;
                         ix += c1 * ax; iy += c1 * ay; i1 += c1;
@@ -750,7 +752,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                     }
                 };
                 const int Nl = a.Nloc;
-                if (screened && !a.term_cache) {
+                if (screened_now && !a.term_cache) {
                     // visit only the terms that may be active, four loads in flight
                     for (int w = 0; w < MW; ++w) {
                         unsigned long long m = amask[w];
@@ -769,7 +771,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                             for (int q = 0; q < 4; ++q) if (q < cnt) term(x[q], y[q], cb[q]);
                         }
                     }
-                } else if (screened) {
+                } else if (screened_now) {
                     // (solves that take several interior-point iterations) the cached terms, then the rest of the mask with four loads in flight
                     // The first KC near terms of the thread's slice are fetched by the first pass that visits them and stay in registers: every
                     // later pass used to start with the same trip to the L2.  (Not fetched ahead in the set-up: a barrier waits for outstanding

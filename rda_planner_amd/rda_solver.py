@@ -60,12 +60,20 @@ def hip_options(**changes):
     from ._lib import hip_api
     o = Opts()
     hip_api().opts_init(C.byref(o))
+    known = {f[0] for f in Opts._fields_}
     for k, v in changes.items():
+        if k not in known:
+            raise TypeError(f"hip_options: unknown rda_opts field {k!r} (include/rda_hip.h lists them)")
         cur = getattr(o, k)
         if hasattr(cur, "__len__"):
+            v = list(v)
+            if len(v) != len(cur):
+                raise ValueError(f"hip_options: {k} takes {len(cur)} values, got {len(v)}")
             for i, x in enumerate(v):
                 cur[i] = x
         else:
+            if isinstance(cur, int) and int(v) != v:
+                raise ValueError(f"hip_options: {k} is an integer switch, got {v!r}")
             setattr(o, k, v)
     return o
 
@@ -131,7 +139,8 @@ class RDA_solver:
         self.lmz_central = kwargs.get("lmz_central", None)
         opts = kwargs.get("hip_opts", None)            # an rda_opts (see hip_options) for the HIP backend; None = library defaults
         if self.lmz_central and make is _hip_backend:
-            opts = opts if opts is not None else hip_options()
+            # (a copy: the caller's struct may configure a second solver that is not in interior-point mode)
+            opts = Opts.from_buffer_copy(opts) if opts is not None else hip_options()
             opts.lmz_mode, opts.lmz_mu = 1, float(self.lmz_central)
         self._be = make(cfg, G, h, opts) if (make is _hip_backend and opts is not None) else make(cfg, G, h)   # test backends select the mode themselves
         self._R = G.shape[0]
@@ -385,6 +394,14 @@ class RDA_solver:
                                              int(bool(order)))
         if rc < 0:
             raise RuntimeError(f"{self._be.api.prefix}_upload_scene_async failed with code {rc}")
+
+    def scene_resort(self, robot_xy):
+        """re-rank the RESIDENT raw scene by distance to `robot_xy` and rebuild the obstacle slots on the device (the reference's per-tick
+        `obstacle_list.sort(key=rda_obs_distance)`, mpc.py:205-206) - no host-to-device copy; asynchronous like `upload_scene_async`"""
+        rob = f64(np.asarray(robot_xy, float).ravel()[0:2])
+        rc = self._be.api.scene_resort(self._be.handle, dptr(rob))
+        if rc < 0:
+            raise RuntimeError(f"{self._be.api.prefix}_scene_resort failed with code {rc}")
 
     def tracked_finish(self, discard=False):
         """queue the rest of the ADMM loop, wait, return what `iterative_solve_tracked` returns"""

@@ -60,7 +60,7 @@ def test_host_side_helpers_build_and_load():
     import closed_loop_host as clh
     lib = ctypes.CDLL(clh.build())
     assert hasattr(lib, "closed_loop_run")
-    assert ctypes.sizeof(clh.Api) == 4 * 8 and ctypes.sizeof(clh.Scene) == 4 * 4 + 5 * 8        # struct closed_loop_api / closed_loop_scene
+    assert ctypes.sizeof(clh.Api) == 5 * 8 and ctypes.sizeof(clh.Scene) == 4 * 4 + 5 * 8        # struct closed_loop_api / closed_loop_scene
     src = open(os.path.join(ROOT, "tools", "closed_loop_host.c")).read()
     assert '#include "../include/rda_hip.h"' in src and "oracle" not in src                     # a caller of the C-ABI and of nothing else
     from rda_planner_amd import _lib

@@ -233,19 +233,22 @@ def test_error_codes(hip):
     assert b"unsupported" in hip.lib.rda_strerror(-2)
 
 
-@pytest.mark.parametrize("world,n_obs", [(2, 6), (2, 5), (3, 7)])
-def test_obstacle_shards_emulated_ranks_one_gpu(hip, world, n_obs):
+@pytest.mark.parametrize("world,n_obs,su_pre", [(2, 6, 1), (2, 5, 1), (3, 7, 1), (2, 6, 0)])
+def test_obstacle_shards_emulated_ranks_one_gpu(hip, world, n_obs, su_pre):
     """N>1 path of the HIP library on one device: `world` handles act as the ranks of an obstacle shard, the per-iteration
     all-gather is emulated on the host (rda_shard_get_chunk / set_chunks).  All ranks must agree bit for bit with each
     other, and with the un-sharded solve up to the summation order of the su-problem's obstacle reductions.  Uneven shards
-    (N % world != 0): ceil(N / world) slots per rank, the padding slots must be invisible."""
-    from rda_planner_amd.rda_solver import RDA_solver
+    (N % world != 0): ceil(N / world) slots per rank, the padding slots must be invisible.
+    su_pre = 0: the raw-term su set-up reads g = G'mu + xi, which is local to the owning rank - rda_shard_config forces
+    the reduced form for world > 1, so a handle created with su_pre = 0 must give the same answers.  And: rda_reset / rda_set_state on
+    a sharded handle that has stepped are refused (the remote slots' local terms cannot be rebuilt on this rank)."""
+    from rda_planner_amd.rda_solver import RDA_solver, hip_options
     from rda_planner_amd.sharded import ShardedRDA
     from test_sharded_gloo import _problem
     import ctypes
     car_t, T, N, rl, steps = _problem(n_obs)
     single = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
-    ranks = [RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False) for _ in range(world)]
+    ranks = [RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False, hip_opts=hip_options(su_pre=su_pre)) for _ in range(world)]
     sh = [ShardedRDA(ranks[r], r, world, lambda c: c) for r in range(world)]
     api = hip
     for nom_s, nom_u, ref in steps:
@@ -289,6 +292,8 @@ def test_obstacle_shards_emulated_ranks_one_gpu(hip, world, n_obs):
         lo, hi = r * nloc, min((r + 1) * nloc, N)
         for k in ("lam", "mu", "z", "xi", "zeta"):
             assert np.abs(st[k][lo:hi] - st1[k][lo:hi]).max(initial=0) < 1e-7, (r, k)
+    assert api.lib.rda_reset(sh[0].h) == -2                  # RDA_ERR_UNSUPPORTED: sharded and stepped
+    assert single.reset() is None                             # (an unsharded handle resets as before)
 
 
 def test_obstacle_shards_rccl_two_gpus():

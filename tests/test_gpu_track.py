@@ -217,10 +217,14 @@ def test_pipelined_tick_closes_on_caller_error():
     assert np.isfinite(u).all() and info["iters"] >= 1
 
 
-@pytest.mark.parametrize("per_tick_scene", [False, True], ids=["resident-scene", "scene-every-tick"])
-def test_c_caller_closed_loop_equals_python_closed_loop(per_tick_scene):
+@pytest.mark.parametrize("per_tick_scene,ordered", [(False, False), (True, False), (False, True), (True, True)],
+                         ids=["resident-scene", "scene-every-tick", "resident-scene-resorted-every-tick", "scene-every-tick-sorted"])
+def test_c_caller_closed_loop_equals_python_closed_loop(per_tick_scene, ordered):
     """tools/closed_loop_host.c (the loop bench.py times: C-ABI calls + the kinematic model in C, rda_step_tracked or the two-call tick with
-    rda_upload_scene_async) against `MPC.control` driven from Python on the same scene: same controls, bit for bit"""
+    rda_upload_scene_async) against `MPC.control` driven from Python on the same scene: same controls, bit for bit.
+    ordered: the reference's default obstacle_order=True - MPC.control re-sorts the list by distance on every tick (mpc.py:205-206); the C
+    caller either hands the scene over every tick with order = 1 or keeps it resident and calls rda_scene_resort (no copy) - same slots,
+    same duals-by-slot semantics (quirk Q5), same controls"""
     import ctypes as C
     import os
     import sys
@@ -234,7 +238,8 @@ def test_c_caller_closed_loop_equals_python_closed_loop(per_tick_scene):
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
     scene = sc.scene_polygons(N, lo=(6, 10), hi=(40, 30), seed=21, keep_clear=clear, clear_radius=3.0)
     # obstacle_order off: with a resident scene the slots keep the order of the one staging, a per-tick staging would re-sort them by distance
-    kw = dict(receding=T, iter_num=3, max_edge_num=4, max_obs_num=N, time_print=False, obstacle_order=False)
+    # (max_obs_num < the scene when ordered: the re-sort then also changes WHICH obstacles are staged)
+    kw = dict(receding=T, iter_num=3, max_edge_num=4, max_obs_num=N - 6 if ordered else N, time_print=False, obstacle_order=ordered)
     py = MPC(car_t, [p.copy() for p in path], **kw)
     st = path[0].copy().reshape(3, 1)
     want = []

@@ -17,15 +17,19 @@ typedef int (*step_tracked_fn)(rda_handle *, const double *, double, int, double
 typedef int (*tracked_begin_fn)(rda_handle *, const double *, double, int, double, int, const double *);
 typedef int (*upload_scene_async_fn)(rda_handle *, int, const int32_t *, const int32_t *, const double *, const double *, const double *, int);
 typedef int (*tracked_finish_fn)(rda_handle *, double *, double *, rda_info *, double *, double *, int32_t *, double *);
+typedef int (*scene_resort_fn)(rda_handle *, const double *);
 
 struct closed_loop_api {
     step_tracked_fn step_tracked;
     tracked_begin_fn tracked_begin;
     upload_scene_async_fn upload_scene_async;
     tracked_finish_fn tracked_finish;
+    scene_resort_fn scene_resort;
 };
 
-struct closed_loop_scene {          /* raw scene handed over on every tick (n == 0: the scene is resident, rda_step_tracked is used) */
+struct closed_loop_scene {          /* raw scene handed over on every tick (n == 0: the scene is resident, rda_step_tracked is used - or, with
+                                     * order != 0, the resident scene is re-sorted about the robot on every tick like MPC.control does,
+                                     * mpc.py:205-206: rda_tracked_begin + rda_scene_resort + rda_tracked_finish) */
     int32_t n, maxv, order, moving;
     const int32_t *kind, *nvert;
     double *geom;                   /* [n][maxv][2], advanced in place when `moving` */
@@ -61,6 +65,11 @@ int closed_loop_run(const struct closed_loop_api *api, rda_handle *h, const stru
             rc = api->tracked_begin(h, state, ref_speed, *cur_index, threshold, ind_range, nu);
             if (begin_log) begin_log[k - k0] = now_s() - t0;
             if (rc >= 0) rc = api->upload_scene_async(h, sc->n, sc->kind, sc->nvert, sc->geom, sc->vel, state, sc->order);
+            if (rc >= 0) rc = api->tracked_finish(h, out_u, out_s, &inf, 0, 0, &mi, &eh);
+        } else if (sc && sc->order && api->scene_resort) {
+            rc = api->tracked_begin(h, state, ref_speed, *cur_index, threshold, ind_range, nu);
+            if (begin_log) begin_log[k - k0] = now_s() - t0;
+            if (rc >= 0) rc = api->scene_resort(h, state);
             if (rc >= 0) rc = api->tracked_finish(h, out_u, out_s, &inf, 0, 0, &mi, &eh);
         } else {
             rc = api->step_tracked(h, state, ref_speed, *cur_index, threshold, ind_range, nu, out_u, out_s, &inf, 0, 0, &mi, &eh);

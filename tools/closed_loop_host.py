@@ -14,7 +14,7 @@ def build():
 
 
 class Api(C.Structure):        # struct closed_loop_api
-    _fields_ = [(n_, C.c_void_p) for n_ in ("step_tracked", "tracked_begin", "upload_scene_async", "tracked_finish")]
+    _fields_ = [(n_, C.c_void_p) for n_ in ("step_tracked", "tracked_begin", "upload_scene_async", "tracked_finish", "scene_resort")]
 
 
 class Scene(C.Structure):      # struct closed_loop_scene

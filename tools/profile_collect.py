@@ -57,4 +57,22 @@ traffic = {
     "workloads": workloads,
 }
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+
+# SQ issue counters per dispatch (averaged over executed and skipped launches alike) -> profiles/issue.json: bench.py derives
+# roofline.ipc_per_wave / fp64_frac / serial_cycles from RATIOS of these (the figures that move with kernel quality)
+issue = {}
+for cfg in ("ns", "n20", "n2000", "c4", "ip"):
+    f = os.path.join(src, f"{cfg}_issue_counters.txt")
+    if not os.path.exists(f) or cfg not in workloads:
+        continue
+    kern = {}
+    for mm in re.finditer(r"^(?:void )?([\w<>]+)\s+(SQ_\w+)\s+dispatches\s+(\d+) per-dispatch\s+([\d.]+)", open(f).read(), re.M):
+        kern.setdefault(mm.group(1), {"dispatches": int(mm.group(3))})[mm.group(2)] = float(mm.group(4))
+    if kern:
+        issue[cfg] = {k: workloads[cfg][k] for k in ("n_obs", "horizon", "moving", "lmz_mode")}
+        issue[cfg]["kernels"] = kern
+if issue:
+    json.dump({"_comment": "rocprofv3 --pmc SQ_* (four passes per configuration, tools/profile_round.sh), wave-instructions / cycles per dispatch averaged over all "
+                           "dispatches of the kernel in the pass (executed and skipped).  Use ratios within a kernel.",
+               "source": f"profiles/{tag}_<cfg>_issue_counters.txt", "workloads": issue}, open(os.path.join(dst, "issue.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "detail"} for k, v in workloads.items()}, indent=1))
