@@ -57,8 +57,9 @@ def build_workload(seed_offset=0, n_obs=200, T=20, n_steps=110, moving=False):
     return car_t, path, obstacles, kw
 
 
-def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=None):
-    """closed loop with the solver in the loop; returns per-step inputs and the staged obstacle arrays"""
+def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=None, stage_every_step=False, moving=False):
+    """closed loop with the solver in the loop; returns per-step inputs and the staged obstacle arrays (of the first step, or - for
+    a scene that is re-sorted every tick - of every step: trace["staged"])"""
     from rda_planner_amd.mpc import MPC
     from rda_planner_amd import scenarios as sc
     extra = {"_backend": backend} if backend is not None else {}
@@ -72,15 +73,19 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=No
     arrived = 0
     orig = mpc.rda.iterative_solve
     staged = {}
+    per_step = []
 
     def spy(nom_s, nom_u, ref_states, ref_speed, obstacle_list, **k):
         tr["nom_s"].append(np.array(nom_s, float).reshape(3, T + 1))
         tr["nom_u"].append(np.array(nom_u, float).reshape(2, T))
         tr["ref"].append(np.array(np.hstack(ref_states)[0:3, :], float))
         tr["speed"].append(float(ref_speed))
-        if not staged:
+        if not staged or stage_every_step:
             n, A, b, cone, per_t = mpc.rda._stage(list(obstacle_list))
-            staged.update(n=n, A=A, b=b, cone=cone, per_t=per_t)
+            if not staged:
+                staged.update(n=n, A=A, b=b, cone=cone, per_t=per_t)
+            if stage_every_step:
+                per_step.append((n, A.copy(), b.copy(), cone.copy(), per_t))
         u_sol, info_sol = orig(nom_s, nom_u, ref_states, ref_speed, obstacle_list, **k)
         tr["u_solver"].append(np.array(u_sol, float))
         return u_sol, info_sol
@@ -88,9 +93,10 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=No
     mpc.rda.iterative_solve = spy
     t0 = time.perf_counter()
     min_clear = np.inf
-    for _ in range(n_steps):
+    for k_ in range(n_steps):
         # static obstacles + obstacle_order=False semantics for the replay: keep slot binding fixed
-        u, info = mpc.control(state, 4.0, list(obstacles))
+        cur = obstacles if not moving else [o._replace(vertex=o.vertex + o.velocity * (0.1 * k_)) for o in obstacles]
+        u, info = mpc.control(state, 4.0, list(cur))
         tr["u"].append(u.copy())
         arrived += int(info["arrive"])
         state = sc.kinematic_step(state, u, car_t, 0.1)
@@ -100,6 +106,7 @@ def record_trace(car_t, path, obstacles, kw, n_steps, backend=None, post_init=No
     out["closed_loop_s_per_step"] = dt / n_steps
     out["final_clearance"] = float(min_clear)
     out["arrived_steps"] = arrived
+    out["staged"] = per_step
     return out, staged, mpc
 
 
@@ -207,19 +214,14 @@ def main():
             cl_dev = closed_loop(False)
             # ... and with MPC.pre_process on the device as well (rda_step_tracked): state in, control out
             cl_trk = closed_loop(True)
+        # the reference's default: obstacle_order=True, the list re-sorted by distance on EVERY tick (mpc.py:205-206).  That closed loop
+        # through the Python API with host-side staging: the controls the ordered C-ABI legs must reproduce, and the staged slots of
+        # every step for the cpu_baseline leg (the oracle is timed on the SAME ordered workload)
+        trace_o, _, _ = record_trace(car_t, path, obstacles, kw, W + K, stage_every_step=True, moving=args.moving)
         if not args.moving:
-            # the reference's default: obstacle_order=True, the list re-sorted by distance on EVERY tick (mpc.py:205-206).  Controls of that
-            # closed loop through the Python API (device obstacle pipeline + tracking): what the ordered C-ABI legs must reproduce
-            mpc_o = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw)
-            if mpc_o.rda.has_scene and mpc_o.rda.has_track:
-                st = path[0].copy().reshape(3, 1)
-                u_ord = []
-                for k in range(W + K):
-                    u, _ = mpc_o.control(st, 4.0, list(obstacles))
-                    u_ord.append(u.ravel().copy())
-                    st = sc.kinematic_step(st, u, car_t, 0.1)
-                u_ord = np.array(u_ord)
-            del mpc_o
+            u_ord = np.array([u.ravel() for u in trace_o["u"]])
+    else:
+        trace_o = None
 
     from rda_planner_amd.rda_solver import RDA_solver
     from rda_planner_amd import scenarios as sc
@@ -288,7 +290,7 @@ def main():
         return sv
 
     # ---- HEADLINE: closed loop through the C-ABI, one host synchronisation per MPC step -------------------------------
-    def cabi_closed_loop(per_tick_scene, driver="c", car=None, compare=True, ordered=False, **solver_kw):
+    def cabi_closed_loop(per_tick_scene, driver="c", car=None, compare=True, ordered=False, timing=False, **solver_kw):
         """state in / control out per step; scene resident in HBM (per_tick_scene False) or handed over from host memory on every
         tick (True, BASELINE.md 2.4 'including H2D of obstacles').  driver "c": the loop is tools/closed_loop_host.c (C-ABI calls and the
         kinematic model in C, nothing of the interpreter between two steps); "python": the same loop written with ctypes / numpy.
@@ -337,12 +339,25 @@ def main():
             run(0, W)
             api.lib.rda_sync(hh)
             barrier_all()
+            if timing:                                   # hipEvents around every solver launch of the timed steps (switches the zero-copy hand-over off:
+                api.lib.rda_timing_reset(hh, 1)          # a pass of its own, never the one `value` comes from)
             t_start = time.perf_counter()
             run(W, K)
             api.lib.rda_sync(hh)
             barrier_all()
             el = max_over_ranks(time.perf_counter() - t_start)
             cabi_closed_loop.second_window = None
+            if timing:
+                kt_ = {}
+                for which, name in ((0, "k_lammuz"), (1, "k_su")):
+                    cap = K * (kw["iter_num"] + 1) + 8
+                    buf, n_ = np.zeros(cap), C.c_int(0)
+                    api.lib.rda_timing_launches(hh, which, dptr(buf), cap, C.cast(C.byref(n_), C.POINTER(C.c_int)))
+                    kt_[name] = buf[:min(n_.value, cap)].copy()
+                api.lib.rda_timing_reset(hh, 0)
+                cabi_closed_loop.kernel_ms = kt_
+                cabi_closed_loop.lmz_kernel = api.lib.rda_lammuz_kernel(hh).decode()
+                return el, t_log[W:W + K].copy(), 0.0, [int(v) for v in it_log[W:W + K]]
             if K2 and world == 1:
                 t2 = time.perf_counter()
                 run(W + K, K2)
@@ -421,6 +436,12 @@ def main():
                 pcie = {"steps_per_s": round(K / el_p, 2), "median_ms_per_step": round(float(np.median(times_p) * 1e3), 5),
                         "max_du_vs_python_closed_loop": du_p,
                         "what": "raw scene (vertices, velocities) handed over from host memory AND re-sorted every tick: rda_tracked_begin + rda_upload_scene_async(order=1) + rda_tracked_finish"}
+
+    # per-launch GPU times of the HEADLINE loop (ordered): one more pass of the same closed loop with hipEvents around every launch
+    head_kt = None
+    if head is not None and rank == 0 and world == 1:
+        _, _, _, its_t = cabi_closed_loop(per_tick_scene=bool(args.moving), ordered=True, timing=True, compare=False)
+        head_kt = {"kt": cabi_closed_loop.kernel_ms, "lmz_kernel": cabi_closed_loop.lmz_kernel, "n_exec": int(np.sum(its_t))}
 
     # ---- interior-point LamMuZ mode (row-parallel kernel k_lammuz_ip): the robust setting lmz_central = 1e-3 on the headline scene, and a
     #      CIRCLE robot (norm2 robot cone, rda_solver.py:1034-1039: always this mode).  Same closed-loop protocol as the headline.
@@ -666,7 +687,7 @@ def main():
     peak = 8000.0
     n_exec = int(np.sum(iters))                          # executed ADMM iterations of the timed replay = executed launches per kernel
 
-    def roof(name, ms, bytes_per_launch):
+    def roof(name, ms, bytes_per_launch, n_exec=n_exec):
         """per EXECUTED launch: launches queued behind the device early-stop flag return at once (no bytes, ~3 us) and are
         separated from the executed ones by their count (sum of rda_info.iters) - the n_exec longest launches are the executed ones"""
         ms = np.sort(np.asarray(ms, float))
@@ -682,13 +703,20 @@ def main():
     # the LamMuZ launch form that was actually used: asked of the library (rda_lammuz_kernel; a dense grid is three launches, timed together)
     n_loc = -(-N // world) if shard else N
     lm_kernel = api.lib.rda_lammuz_kernel(h).decode()
-    r_lm = roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T)
+    su_name = f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>"
+    J = -(-n_loc // 8)
+    su_bytes = 32 * T * J * (world if shard else 1) + 8 * (8 * (T + 1) + 5 * T + 10 * T + 4 * T)
+    # the same two kernels in the fixed-slot-binding replay (the loop the rooflines of rounds 1-3 were taken from)
+    replay_roofs = {"k_su": roof(su_name, kt["k_su"], su_bytes), "k_lammuz": roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T),
+                    "what": "device-resident replay of the recorded closed loop with obstacle_order=False (slots bound once)"}
+    if head_kt is not None:                              # the rooflines of the line: the launches of the HEADLINE loop (re-sorted every tick)
+        kt, lm_kernel, n_exec = head_kt["kt"], head_kt["lmz_kernel"], head_kt["n_exec"]
+    r_lm = roof(lm_kernel, kt["k_lammuz"], unit_bytes * n_loc * T, n_exec)
     # k_su has NO pass over the N terms any more: its set-up reads the reduced form the LamMuZ launch leaves behind - per (stage, 8-slot
     # block) three sums and a near mask (32 of the 48 bytes of a block record) - plus the nominal / reference / kept multipliers; per
     # interior-point pass it visits the NEAR terms only (24 B each, data dependent: not counted, so the fraction is a lower bound)
-    J = -(-n_loc // 8)
-    su_bytes = 32 * T * J * (world if shard else 1) + 8 * (8 * (T + 1) + 5 * T + 10 * T + 4 * T)
-    r_su = roof(f"k_su<{T}>" if T in (10, 20, 25, 30) else "k_su<0>", kt["k_su"], su_bytes)
+    r_su = roof(su_name, kt["k_su"], su_bytes, n_exec)
+    r_su["includes"] = f"k_su_tracked<{T}> (first solve of every tick) and {su_name} launches of the timed closed loop"
     # latency roof of the su kernel: ONE workgroup (4 waves) on one CU walks a dependent chain; what bounds it is the length of
     # that chain, not bytes - stated next to the HBM fraction so the fraction is not read as a bandwidth problem
     r_su["cus_occupied"] = 1
@@ -779,6 +807,9 @@ def main():
         "multi_ego_fleet": fleet,
         "lammuz_interior_point_closed_loops": ip_legs,
         "roofline": dominant, "roofline_secondary": secondary,
+        "roofline_fixed_slot_binding_replay": {k: ({kk: v[kk] for kk in ("kernel", "avg_launch_us", "launches", "skipped_launches", "frac", "achieved")} if isinstance(v, dict) else v)
+                                               for k, v in replay_roofs.items()},
+        "parity": {"stated_tolerance_applied_control": 5e-4, "where": "tests/helpers.py TOL_U; asserted by tests/test_gpu_soak.py (random scenes) and tests/test_gpu_baseline_sizes.py; DESIGN.md 7"},
     }
 
     if not args.no_cpu_baseline and world == 1:
@@ -796,12 +827,14 @@ def main():
             n_cpu, t_cpu = 0, 0.0
             while t_cpu < 2.5 or n_cpu < 3:                  # consecutive steps of ONE closed loop (the duals stay warm) ...
                 kk = k % (W + K)                             # ... wrapping around the recorded trace when it is used up
+                tr_c = trace_o if trace_o is not None else trace     # the headline workload: the scene re-sorted on every tick
+                n_c, A_c, b_c, cone_c, pt_c = tr_c["staged"][kk] if tr_c.get("staged") else (staged["n"], staged["A"], staged["b"], staged["cone"], staged["per_t"])
                 t1 = time.perf_counter()
-                cpu._be.api.step(cpu._be.handle, dptr(trace["nom_s"][kk]), dptr(trace["nom_u"][kk]), dptr(trace["ref"][kk]), float(trace["speed"][kk]),
-                                 staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"], dptr(ou), dptr(os_), C.byref(info_c))
+                cpu._be.api.step(cpu._be.handle, dptr(tr_c["nom_s"][kk]), dptr(tr_c["nom_u"][kk]), dptr(tr_c["ref"][kk]), float(tr_c["speed"][kk]),
+                                 n_c, dptr(A_c), dptr(b_c), iptr(cone_c), pt_c, dptr(ou), dptr(os_), C.byref(info_c))
                 t_cpu += time.perf_counter() - t1
                 if k < W + K:                                # first pass only: the same state history as the GPU run
-                    err = max(err, float(np.abs(ou - trace["u_solver"][kk]).max()))
+                    err = max(err, float(np.abs(ou - tr_c["u_solver"][kk]).max()))
                 n_cpu += 1
                 k += 1
             sweep[nthr] = round(n_cpu / t_cpu, 3)
@@ -809,8 +842,8 @@ def main():
         best = max(sweep, key=sweep.get)
         out["cpu_baseline"] = {"value": sweep[best], "unit": "steps/s", "cores": best, "kind": "port",
                                "single_thread": sweep.get(1), "thread_sweep": sweep, "host_cores": ncore,
-                               "sample": f"{n_total} steps of the same recorded closed loop (consecutive, wrapping around), ~2.5 s per thread count (oracle/rda_oracle.c: OpenMP over "
-                                         "obstacles, OMP_PROC_BIND=close, su-problem serial); best thread count reported",
+                               "sample": f"{n_total} steps of the headline closed loop (obstacle_order=True: the staged slots of every tick as the GPU run had them; consecutive, "
+                                         "wrapping around), ~2.5 s per thread count (oracle/rda_oracle.c: OpenMP over obstacles, OMP_PROC_BIND=close, su-problem serial); best thread count reported",
                                "note": "a restatement of the ADMM in C, NOT the reference's CVXPY+ECOS+pathos path (not installable here): the "
                                        "north-star '>=100x the reference CPU path' cannot be measured against this number",
                                "max_du_vs_gpu": err}

@@ -6,7 +6,8 @@ import subprocess
 from ._capi import CApi, Cfg, c_double_p, c_int_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librda_hip.so")
+_BUILT_SO = os.path.join(_HERE, "librda_hip.so")
+SO_PATH = os.environ.get("RDA_HIP_SO") or _BUILT_SO     # RDA_HIP_SO: another build of the SAME library (A/B runs of tools/)
 _api = None
 
 
@@ -15,11 +16,11 @@ def build(force=False):
     src_dir = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + \
            [os.path.join(os.path.dirname(_HERE), "include", "rda_hip.h")]
-    stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    stale = force or not os.path.exists(_BUILT_SO) or any(os.path.getmtime(s) > os.path.getmtime(_BUILT_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))   # -B: `force` must not depend on mtimes
     build_flatten_ext(force)
-    return SO_PATH
+    return _BUILT_SO
 
 
 def build_flatten_ext(force=False):

@@ -6,10 +6,7 @@ Test infrastructure (it drives oracle/): used by tests/test_gpu_soak.py (the -m 
 What is compared per step
     du_raw   max |u_gpu - u_oracle| of the APPLIED control (u[:, 0]) in the solver's own coordinates
     du_body  the same control expressed in what the robot does with it (`body_rates`): linear velocity and yaw rate for acker / diff,
-             the Cartesian velocity for omni.  The solver's second coordinate is a steering angle (acker) or a velocity HEADING (omni);
-             with |v| ~ 0 the su cost does not depend on it beyond the regulariser eps_u = 1e-8 (the column of the input matrix is
-             v dt (...)), so two interior-point solves that both satisfy the 1e-9 KKT stop may differ in it by far more than in any
-             quantity the trajectory depends on.  du_body is the well-posed statement, du_raw is reported beside it.
+             the Cartesian velocity for omni - reported, not asserted (for omni it is |v| times the heading difference)
     iters    ADMM iteration counts (early stop, rda_solver.py:594)
     status   su-solves that did not converge (either side)
 """

@@ -6,20 +6,19 @@ su-problem starts cold, like ECOS in the reference (no warm start, rda_solver.py
 (unique) su solution along DIFFERENT iteration paths, which is what makes this an accuracy statement rather than a
 same-code-path identity (that identity is `tests/test_gpu_parity.py`, warm oracle, rounding level).
 
-Stated fp64 tolerance of the closed-loop parity (state re-synchronised to the oracle every step):
-    applied control  |u_gpu - u_oracle|  <=  TOL_U = 1e-4   (speed, m/s; steering / yaw rate / heading, rad)
-    whole horizon    2 x T controls       <=  1e-4
+Stated fp64 tolerance of the closed-loop parity (state re-synchronised to the oracle every step), ONE number for every closed-loop
+HIP-vs-oracle test (tests/helpers.py, where the reason for its size is written down; tests/test_gpu_soak.py asserts it on random scenes):
+    applied control  |u_gpu - u_oracle|  <=  TOL_U = 5e-4   (speed, m/s; steering / yaw rate / heading, rad)
+    whole horizon    2 x T controls       <=  TOL_U
     residuals        relative             <=  1e-4
+  (measured on THESE fixed scenes: <= 3e-5; the tests print their values with -s)
     ADMM iteration counts equal on >= 95 % of the steps (the early-stop test `resi < 0.2` may flip when a residual
     sits within 1e-6 of the threshold).  A step on which the counts differ is NOT skipped: its applied control must agree
     to TOL_U_FLIP = 5e-2 (the two sides ended one ADMM iteration apart; below the stop threshold one more iteration moves
     the control by that order), and the `..._every_iteration` variants run the same loops with the early stop switched
     off (iter_threshold = 0: both sides run all iter_num iterations on every step), so that EVERY step of the loop is
     compared at TOL_U with no exclusion.
-Why 1e-4 and not rounding level: both interior-point iterations stop at a 1e-9 relative KKT residual; in directions the
-su cost is almost flat in (steering at low speed: the curvature is the regulariser eps_u = 1e-8 plus what the obstacles
-add) a 1e-9 residual leaves up to ~3e-5 in the control, and the reference's own solver (ECOS, 1e-8 class tolerances)
-cannot pin those directions any better.  Measured values are printed by the tests (run with -s).
+Measured values are printed by the tests (run with -s).
 """
 import ctypes as C
 
@@ -29,10 +28,9 @@ import pytest
 from rda_planner_amd import scenarios as sc
 from rda_planner_amd._capi import Info, dptr
 
-pytestmark = pytest.mark.gpu
+from helpers import TOL_U, TOL_U_FLIP
 
-TOL_U = 1e-4
-TOL_U_FLIP = 5e-2
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture()

@@ -230,6 +230,37 @@ def test_su_stagnating_dual_residual_is_accepted(orc):
         assert _objective(cfg, si, roll(U2), U2, D2) >= f0 - 1e-7 * (1 + abs(f0))
 
 
+WEAK = ["omni_T15_N30_weakly_active_a", "omni_T15_N13_weakly_active_b", "acker_T15_N27_weakly_active_c"]
+
+
+@pytest.mark.parametrize("name", WEAK)
+def test_stop_tolerance_vs_weakly_active_rows(orc, name):
+    """Where the stated closed-loop tolerance TOL_U (tests/helpers.py) comes from.  Three su-problems recorded on the steps of the round-4
+    soak (GPU vs cold oracle, 9600 steps) with the largest control differences: each has inequality rows that are only just active at
+    the solution (multipliers ~1e-4), so the central-path point at complementarity mu lies ~mu / lam* from the solution and the answer
+    moves with the STOP tolerance: against a solve at 1e-12 / 1e-12 / 1e-15 the default stop (1e-9 / 1e-10 / 1e-11) lands within 5e-5
+    (this is what two different interior-point paths - kernel and oracle - can differ by per su-problem), while a solve at the ECOS-class
+    tolerances of the reference's solver (1e-8 throughout) lands 2e-4 ... 3e-3 away.  TOL_U = 5e-4 sits between the two."""
+    import os
+    import ctypes as C
+    orc.lib.orc_set_su_tol.argtypes = [C.c_double] * 3
+    cfg, si = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", name + ".npz"))
+    try:
+        orc.lib.orc_set_su_tol(1e-12, 1e-12, 1e-15)
+        st_t, _, u_t, _, it_t = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+        orc.lib.orc_set_su_tol(1e-9, 1e-10, 1e-11)
+        st_d, _, u_d, _, it_d = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+        orc.lib.orc_set_su_tol(1e-8, 1e-8, 1e-8)
+        st_e, _, u_e, _, it_e = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+    finally:
+        orc.lib.orc_set_su_tol(1e-9, 1e-10, 1e-11)
+    assert st_t == 0 and st_d == 0 and st_e == 0 and it_e <= it_d <= it_t
+    d_def, d_ecos = float(np.abs(u_d - u_t).max()), float(np.abs(u_e - u_t).max())
+    print(f"{name}: default stop {it_d} iterations, |u - u_tight| {d_def:.2e}; ECOS-class stop {it_e} iterations, {d_ecos:.2e}; tight {it_t}")
+    assert d_def <= 5e-5 < hp.TOL_U
+    assert d_ecos >= 2e-4
+
+
 def test_warm_started_su_reaches_the_cold_solution():
     """Inside an MPC step the su-problems of ADMM iterations >= 1 start from the previous multipliers (oracle and kernel share the
     rule).  The su solution is unique, so a step solved with the warm start (default) and without it (orc_set_su_warm(0, 0, 0))

@@ -13,7 +13,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 OUT="gpurun_out/prof_${TAG}"
 mkdir -p "$OUT" "$OUT/scratch"
 SCR="$OUT/scratch"
-BENCH="python bench.py --no-cpu-baseline --egos 0 --fleet-egos 0 --no-ip-legs"
+BENCH="python bench.py --no-cpu-baseline --no-sizes --egos 0 --fleet-egos 0 --no-ip-legs"
 declare -A ARGS=( [ns]="--steps 200 --warmup 10" [n20]="--n-obs 20 --steps 100 --warmup 10" [n2000]="--n-obs 2000 --steps 60 --warmup 5" [c4]="--moving --horizon 30 --steps 60 --warmup 5" [ip]="--steps 60 --warmup 5" )
 declare -A ENVS=( [ip]="RDA_LMZ_MODE=1 RDA_LMZ_MU=1e-3" )
 
