@@ -158,17 +158,16 @@ struct Lds {
     double *part;      // [NT][9] partial sums of the chunked reductions (aliases Hb)
     double *hs;        // [T][9]  hinge sums
     double *Hw, *gw;   // [T][16], [T][4]
-    double *bw;        // [T][5]  barrier weights (u0 box, u1 box, d box, rate u0, rate u1)
-    double *cy;        // [T][5]  C'lam per stage (entries 3..7 of y)
+    double *bw;        // [T][5]  barrier weights lam/w of the inequality pairs, + and - row summed (u0 box, u1 box, d box, rate u0, rate u1)
+    double *cy;        // [T][5]  lam+ - lam- of the pairs (C'lam of the stage gradient)
     double *gst;       // [T][8]  stage gradient (objective + C'lam)
-    double *gh;        // [T][8]  Newton right-hand side gradient
     double *gad;       // [T][3]  reduced gradient (adjoint sweep)
     double *Hb;        // [T][HB]  stage Hessian base -> (after the matrix sweep) backward rows Mb [8][6]
     double *Wn;        // [T][WN]
     double *Mf;        // [T][MF]  (overlays hs..cy, which are dead once the stage Hessians are assembled)
     double *kk;        // [T][8]   backward sweep outputs per stage: p (5) | feed-forward kk (3)
     double *vv;        // [T][8]   forward sweep outputs per stage: dx+ (5) | v_2 ; v = entries 3..5
-    double *cw, *cl, *rp, *rc, *dw, *dl;   // [T][NC]
+    double *xd, *lw, *ra;                  // [T][5] per inequality PAIR (see the pair threads in solve): x+ - x-, lam w (+ and -), max |r_p|
     double *dy;                            // [T][8]
     double *pv, *red;                      // 8, NT
     double *p0;                            // [2][T] reference positions of the hinge screening
@@ -178,18 +177,18 @@ struct Lds {
         Ak = p; p += ev(9 * T); Bk = p; p += 6 * T; Ck = p; p += ev(3 * T); csn = p; p += 2 * T; Q1 = p; p += ev(T); Q2 = p; p += ev(T);
         Ft = p; p += FT * T; hs = p; Mf = p; p += ev(9 * T);      // Mf (after the matrix sweep) overlays hs|Hw|gw|bw|cy: 39T >= MF*T
         Hw = p; p += 16 * T; gw = p; p += 4 * T; bw = p; p += ev(5 * T); cy = p; p += ev(5 * T);
-        gst = p; p += 8 * T; gh = p; p += 8 * T; gad = p; p += ev(3 * T);
+        gst = p; p += 8 * T; gad = p; p += ev(3 * T);
         Hb = p; part = p; p += (HB * T > 9 * NT ? HB * T : 9 * NT);    // part (phase 1) is dead before Hb is written (phase 3)
         Wn = p; p += WN * T; kk = p; p += 8 * T; vv = p; p += 8 * T;
-        cw = p; p += NC * T; cl = p; p += NC * T; rp = p; p += NC * T; rc = p; p += NC * T; dw = p; p += NC * T; dl = p; p += NC * T;
+        xd = p; p += ev(5 * T); lw = p; p += ev(5 * T); ra = p; p += ev(5 * T);
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT; p0 = p; p += 2 * T;
     }
 };
 inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
-             + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
-             + WN * T + 16 * T + 6 * NC * T + 8 * T + 8 + NT + 2 * T;
+             + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
+             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 + NT + 2 * T;
     return n * sizeof(double);
 }
 
@@ -296,11 +295,14 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         pf_u0 = a.in_u[tid]; pf_u1 = a.in_u[T + tid]; if (a.d_in) pf_d = a.d_in[tid];
         if (a.pose_lin) { pf_cp = a.pose[4 * tid + 2]; pf_sp = a.pose[4 * tid + 3]; }
     }
-    double pf_lk[2] = {0, 0};                      // kept multipliers of the rows i = tid, tid + NT (NC T <= 2 NT)
+    double pf_lkp[2] = {0, 0}, pf_lkm[2] = {0, 0};           // kept multipliers of this thread's inequality pairs (+ row, - row; see the pair threads below)
     if (warm)
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid + k * NT;
-            if (i < NC * T) { const int t = i / NC, kk = i % NC, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t; pf_lk[k] = a.lam_keep[ts * NC + kk]; }
+        for (int j = 0; j < 2; ++j) {
+            const int pi = tid + j * NT;
+            if (pi < 5 * T) {
+                const int t = pi / 5, kk = pi % 5, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
+                pf_lkp[j] = a.lam_keep[ts * NC + 2 * kk]; pf_lkm[j] = a.lam_keep[ts * NC + 2 * kk + 1];
+            }
         }
     // block partials / near masks of the thread's slice: eight blocks at a time, all their loads in flight together
     double pq0[8], pq1[8], pq2[8]; unsigned long long pmk[8];
@@ -413,17 +415,60 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     };
     rollout();
     MS(13);
+    // ---- the inequality rows live in REGISTERS.  The 10 rows of a stage are 5 pairs (+val <= e+, -val <= e-) of one linear form each
+    // (k = 0 u0, 1 u1, 2 d, 3 u0 - up0, 4 u1 - up1; the rate pairs exist for t >= 1): pair p = 5 t + k is owned by thread p (5 T <= 256
+    // for T <= 51; the generic instantiation takes two per thread), which keeps the pair's slacks and multipliers (w+, w-, lam+, lam-),
+    // residuals, targets and steps for the whole solve.  What the other phases need of the rows travels through three small [T][5]
+    // arrays per pass (barrier weights and lam+ - lam- for the stage Hessians / gradients, x+ - x- for the Newton right-hand side) and
+    // two for the termination measures - instead of six [T][10] arrays read and written by every phase (round 3: the row phases were
+    // ~40 % of an interior-point iteration, all LDS trips and divisions; reciprocals of w and lam are now formed once per iteration).
+    constexpr int NPR = TT > 0 ? (5 * TT + NT - 1) / NT : 2;
+    int  p_t[NPR], p_k[NPR]; bool p_ok[NPR], p_on[NPR];
+    double p_ep[NPR], p_em[NPR];                              // right-hand sides of the + and - row
+    double Pwp[NPR], Pwm[NPR], Plp[NPR], Plm[NPR];            // slacks, multipliers
+    double Prpp[NPR], Prpm[NPR], Prcp[NPR], Prcm[NPR];        // primal residuals, complementarity targets of the current right-hand side
+    double Piwp[NPR], Piwm[NPR], Pilp[NPR], Pilm[NPR];        // reciprocals (once per iteration)
+    double Pdwp[NPR], Pdwm[NPR], Pdlp[NPR], Pdlm[NPR];        // steps
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) {
+        const int pi = tid + j * NT;
+        p_ok[j] = pi < 5 * T; p_t[j] = p_ok[j] ? pi / 5 : 0; p_k[j] = p_ok[j] ? pi % 5 : 0;
+        p_on[j] = p_ok[j] && (p_k[j] < 3 || p_t[j] >= 1);
+        p_ep[j] = con_rhs(c, 2 * p_k[j]); p_em[j] = con_rhs(c, 2 * p_k[j] + 1);
+        Pwp[j] = Pwm[j] = 1.0; Plp[j] = Plm[j] = 0.0; Prpp[j] = Prpm[j] = Prcp[j] = Prcm[j] = 0.0;
+        Piwp[j] = Piwm[j] = 1.0; Pilp[j] = Pilm[j] = 0.0; Pdwp[j] = Pdwm[j] = Pdlp[j] = Pdlm[j] = 0.0;
+    }
+    auto frcp = [](double x) {                                 // 1 / x: v_rcp_f64 + two Newton steps (full precision for normal x > 0)
+        double r = __builtin_amdgcn_rcp(x);
+        r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+        return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    };
+    // value of pair (t, k)'s linear form at the current controls / distances (con_val of its + row)
+    auto pair_val = [&](int t, int k) {
+        if (k == 2) return L.d[t];
+        const double *uu = (k == 1 || k == 4) ? &L.u[T] : &L.u[0];       // k = 0, 3: u0 ; k = 1, 4: u1
+        const double v = uu[t];
+        return k < 3 ? v : v - (t ? uu[t - 1] : 0.0);
+    };
+    // ... and of a step: [dx (5) | .] in dy, v = (du0, du1, dd) in vv[3..5]
+    auto pair_step = [&](int t, int k) {
+        const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
+        if (k == 2) return v[2];
+        const bool second = k == 1 || k == 4;
+        const double dv = second ? v[1] : v[0];
+        return k < 3 ? dv : dv - (second ? y[4] : y[3]);
+    };
     // slacks floored at wfl, multipliers lam = mu0 / w  (first attempt: 1e-2 and 1)
     auto centre_duals = [&](double wfl, double mu0) {
-        for (int i = tid; i < NC * T; i += NT) {
-            int t = i / NC, k = i % NC;
-            double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-            double sl = con_rhs(c, k) - con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]);
-            bool on = con_on(t, k);
-            L.cw[i] = on ? (sl > wfl ? sl : wfl) : 1.0;
-            L.cl[i] = on ? mu0 / L.cw[i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            if (p_on[j]) {
+                const double cv = pair_val(p_t[j], p_k[j]);
+                const double sp = p_ep[j] - cv, sm = p_em[j] + cv;
+                Pwp[j] = sp > wfl ? sp : wfl; Pwm[j] = sm > wfl ? sm : wfl;
+                Plp[j] = mu0 / Pwp[j]; Plm[j] = mu0 / Pwm[j];
+            } else { Pwp[j] = Pwm[j] = 1.0; Plp[j] = Plm[j] = 0.0; }
         }
-        __syncthreads();
     };
     // Start.  Cold: slacks floored at 1e-2, lam = 1/w (mu0 = 1).  Warm (ADMM iterations >= 1): the primal point is the previous
     // solution, so the slacks are the previous ones; they are floored at warm_wfl, the multipliers are the larger of the centred
@@ -431,12 +476,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // iterations (measured: 75 -> 92 us per launch), with them it saves about one per solve (75 -> 67 us).
     if (warm) {
         centre_duals(a.warm_wfl, a.warm_mu0);
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid + k * NT;
-            if (i < NC * T) { const double lp = pf_lk[k]; if (con_on(i / NC, i % NC) && lp > L.cl[i]) L.cl[i] = lp; }
-        }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NPR; ++j)
+            if (p_on[j]) { if (pf_lkp[j] > Plp[j]) Plp[j] = pf_lkp[j]; if (pf_lkm[j] > Plm[j]) Plm[j] = pf_lkm[j]; }
     } else centre_duals(1e-2, 1.0);
+    __syncthreads();                                          // (the roll-out of wave 0 is visible to everybody from here on)
     // ---- rotation-consistency penalty -> scalar quadratic per stage from three POSE-INDEPENDENT sums over the terms (see
     // row_term), and the HINGE SCREENING: Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so a term whose margin at the
     // reference position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Both arrive in
@@ -519,28 +563,24 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
-    // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w)   (one stage per thread of `base`..)
-    auto build_gh = [&](int t) {
-        double x[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) { int i = t * NC + k; x[k] = (L.cl[i] * L.rp[i] - L.rc[i]) / L.cw[i]; }
-        double y3, y4, y5, y6, y7; con_T(x, t, y3, y4, y5, y6, y7);
-        const double *g = &L.gst[8 * t]; double *o = &L.gh[8 * t];
-        o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3] + y3; o[4] = g[4] + y4; o[5] = g[5] + y5; o[6] = g[6] + y6; o[7] = g[7] + y7;
-    };
+    // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w): with xd = x+ - x- per pair (L.xd, written by the pair threads for the
+    // current right-hand side) the entries 3..7 of a stage are -xd3, -xd4, xd0 + xd3, xd1 + xd4, xd2 - formed where they are used
     // constants of the backward affine map for the current right-hand side: cb = [g_x - W g_v ; -Minv g_v]
     auto build_cb = [&]() {
         for (int i = tid; i < 8 * T; i += NT) {
             int t = i >> 3, r = i & 7;
-            const double *g = &L.gh[8 * t], *wn = &L.Wn[WN * t];
+            const double *gs = &L.gst[8 * t], *xd = &L.xd[5 * t], *wn = &L.Wn[WN * t];
+            const double g5 = gs[5] + (xd[0] + xd[3]), g6 = gs[6] + (xd[1] + xd[4]), g7 = gs[7] + xd[2];
             double v;
-            if (r < 5) v = g[r] - (wn[3 * r] * g[5] + wn[3 * r + 1] * g[6] + wn[3 * r + 2] * g[7]);
-            else {
+            if (r < 5) {
+                const double gr = r < 3 ? gs[r] : (r == 3 ? gs[3] - xd[3] : gs[4] - xd[4]);
+                v = gr - (wn[3 * r] * g5 + wn[3 * r + 1] * g6 + wn[3 * r + 2] * g7);
+            } else {
                 int k = r - 5;
                 double n0 = k == 0 ? wn[15] : (k == 1 ? wn[16] : wn[17]);
                 double n1 = k == 0 ? wn[16] : (k == 1 ? wn[18] : wn[19]);
                 double n2 = k == 0 ? wn[17] : (k == 1 ? wn[19] : wn[20]);
-                v = -(n0 * g[5] + n1 * g[6] + n2 * g[7]);
+                v = -(n0 * g5 + n1 * g6 + n2 * g7);
             }
             L.Hb[HB * t + 6 * r + 5] = v;
         }
@@ -720,6 +760,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         __syncthreads();
         if (attempt == 1) { screened = false; centre_duals(1e-1, 10.0); }
         else centre_duals(1e-2, 1.0);
+        __syncthreads();
         status = 1;
     }
     const int it_cap = attempt < 0 ? a.warm_cap : 100;
@@ -855,8 +896,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         }
         // ---- (2) per-stage derivatives wrt w = (s_next, d)  (threads < T)  ||  inequality rows: barrier weight
         //          lam/w (kept in dw, which is dead here), primal residual, predictor target  (all threads) ------
-        if (tid < T) {
-            int t = tid;
+        if (NT - 1 - tid < T) {                    // (the HIGH thread ids: the pair threads are the low ones - 5 T <= 150 of 256 for T <= 30)
+            int t = NT - 1 - tid;
             const double *h = &L.hs[9 * t];
             double st[3] = { L.s[t + 1], L.s[(T + 1) + t + 1], L.s[2 * (T + 1) + t + 1] };
             double w3[3] = { 1, 1, wz };
@@ -875,14 +916,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             Hw[12] = hsd0; Hw[13] = hsd1; Hw[14] = 0; Hw[15] = c.ro1 * h[5];
             gw[0] = gs[0]; gw[1] = gs[1]; gw[2] = gs[2]; gw[3] = -c.ro1 * h[8] - c.slack_gain;
         }
-        for (int i = tid; i < NC * T; i += NT) {
-            int t = i / NC, k = i % NC;
-            bool on = con_on(t, k);
-            double up0 = t ? L.u[t - 1] : 0, up1 = t ? L.u[T + t - 1] : 0;
-            double w = L.cw[i], l = L.cl[i];
-            L.dw[i] = on ? l / w : 0.0;
-            L.rp[i] = on ? con_val(k, L.u[t], L.u[T + t], up0, up1, L.d[t]) + w - con_rhs(c, k) : 0.0;
-            L.rc[i] = l * w;                                          // affine (predictor) target
+        // pair threads: primal residuals, reciprocals, affine (predictor) targets; what the stage phases need goes to the [T][5] arrays
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            if (p_ok[j]) {
+                const int o = 5 * p_t[j] + p_k[j];
+                if (p_on[j]) {
+                    const double cv = pair_val(p_t[j], p_k[j]);
+                    const double wp = Pwp[j], wm = Pwm[j], lp = Plp[j], lm = Plm[j];
+                    Prpp[j] = cv + wp - p_ep[j]; Prpm[j] = wm - cv - p_em[j];
+                    const double iwp = frcp(wp), iwm = frcp(wm);
+                    Piwp[j] = iwp; Piwm[j] = iwm; Pilp[j] = frcp(lp); Pilm[j] = frcp(lm);
+                    Prcp[j] = lp * wp; Prcm[j] = lm * wm;
+                    L.bw[o] = lp * iwp + lm * iwm;
+                    L.cy[o] = lp - lm;
+                    L.xd[o] = (lp * Prpp[j] - Prcp[j]) * iwp - (lm * Prpm[j] - Prcm[j]) * iwm;
+                    L.lw[o] = Prcp[j] + Prcm[j];
+                    L.ra[o] = fmax(fabs(Prpp[j]), fabs(Prpm[j]));
+                } else { L.bw[o] = 0; L.cy[o] = 0; L.xd[o] = 0; L.lw[o] = 0; L.ra[o] = 0; }
+            }
         }
         __syncthreads();
         MF(14);
@@ -890,15 +942,15 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         // J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
         for (int i = tid; i < 8 * T; i += NT) {
             int t = i >> 3, j = i & 7;
-            const double *F = &L.Ft[FT * t], *gw = &L.gw[4 * t], *lam = &L.cl[NC * t];
+            const double *F = &L.Ft[FT * t], *gw = &L.gw[4 * t], *ld = &L.cy[5 * t];        // ld = lam+ - lam- per pair
             double v = Fel(F, 0, j) * gw[0] + Fel(F, 1, j) * gw[1] + Fel(F, 2, j) * gw[2] + (j == 7 ? gw[3] : 0.0);
-            // + direct control cost + C' lam   (rate rows 6..9 exist for t >= 1; their multipliers are 0 at t = 0)
-            const double r0 = lam[6] - lam[7], r1 = lam[8] - lam[9];
+            // + direct control cost + C' lam   (the rate pairs exist for t >= 1; their multipliers are 0 at t = 0)
+            const double r0 = ld[3], r1 = ld[4];
             if (j == 3) v -= r0;
             else if (j == 4) v -= r1;
-            else if (j == 5) v += lam[0] - lam[1] + r0 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t];
-            else if (j == 6) v += lam[2] - lam[3] + r1 + c.eps_u * L.u[T + t];
-            else if (j == 7) v += lam[4] - lam[5];
+            else if (j == 5) v += ld[0] + r0 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t];
+            else if (j == 6) v += ld[1] + r1 + c.eps_u * L.u[T + t];
+            else if (j == 7) v += ld[2];
             L.gst[i] = v;
         }
         MF(12);
@@ -906,12 +958,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         if (!expect_conv)
         for (int i = tid; i < 8 * T; i += NT) {               // one thread per (stage, row): Hw and the row's J column stay in registers
             int t = i >> 3, r = i & 7;
-            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *dg = &L.dw[NC * t];
+            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *dg = &L.bw[5 * t];
             const double h00 = Hw[0], h01 = Hw[1], hd0 = Hw[3], h11 = Hw[5], hd1 = Hw[7], h22 = Hw[10], hdd = Hw[15];
             const double a0 = Fel(F, 0, r), a1 = Fel(F, 1, r), a2 = Fel(F, 2, r), a3 = r == 7 ? 1.0 : 0.0;
             // v = Hw J[:, r]
             const double v0 = h00 * a0 + h01 * a1 + hd0 * a3, v1 = h01 * a0 + h11 * a1 + hd1 * a3, v2 = h22 * a2, v3 = hd0 * a0 + hd1 * a1 + hdd * a3;
-            const double bu0 = dg[0] + dg[1], bu1 = dg[2] + dg[3], bd = dg[4] + dg[5], br0 = dg[6] + dg[7], br1 = dg[8] + dg[9];
+            const double bu0 = dg[0], bu1 = dg[1], bd = dg[2], br0 = dg[3], br1 = dg[4];
             double *row = &L.Hb[HB * t + 8 * r];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -989,12 +1041,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                     if (lane == 0) __atomic_store_n(flag_stop, seq, __ATOMIC_RELAXED);
             }
         } else if (wave == 2) {
-            if (!expect_conv) for (int t = lane; t < T; t += 64) build_gh(t);
+            // (the Newton right-hand side is formed inside build_cb since round 4: nothing to prepare here)
         } else {
             // termination measures that do not depend on the sweeps
             double g = 0, rp_ = 0, m_ = 0;
             for (int i = lane; i < 4 * T; i += 64) { double v = fabs(L.gw[i]); if (v > g) g = v; }
-            for (int i = lane; i < NC * T; i += 64) { double v = fabs(L.rp[i]); if (v > rp_) rp_ = v; m_ += L.cl[i] * L.cw[i]; }
+            for (int i = lane; i < 5 * T; i += 64) { double v = L.ra[i]; if (v > rp_) rp_ = v; m_ += L.lw[i]; }
             g = wave_allreduce(g, true); rp_ = wave_allreduce(rp_, true); m_ = wave_allreduce(m_, false);
             if (lane == 0) {
                 L.red[9] = g; L.red[10] = rp_; L.red[11] = m_;
@@ -1063,12 +1115,15 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         if (nopred) sigma = a.warm_sig;
         for (int pass = nopred ? 1 : 0; pass < 2; ++pass) {
             if (pass == 1) {
-                // corrector right-hand side
-                if (nopred) for (int i = tid; i < NC * T; i += NT) L.rc[i] = L.cl[i] * L.cw[i] - sigma * mu;
-                else
-                for (int i = tid; i < NC * T; i += NT) L.rc[i] = L.cl[i] * L.cw[i] + L.dl[i] * L.dw[i] - sigma * mu;
-                __syncthreads();
-                if (tid < T) build_gh(tid);
+                // corrector right-hand side: targets lam w + dlam dw - sigma mu (no second-order term without a predictor), new x+ - x-
+                const double smu = sigma * mu;
+#pragma unroll
+                for (int j = 0; j < NPR; ++j)
+                    if (p_on[j]) {
+                        Prcp[j] = Plp[j] * Pwp[j] + (nopred ? 0.0 : Pdlp[j] * Pdwp[j]) - smu;
+                        Prcm[j] = Plm[j] * Pwm[j] + (nopred ? 0.0 : Pdlm[j] * Pdwm[j]) - smu;
+                        L.xd[5 * p_t[j] + p_k[j]] = (Plp[j] * Prpp[j] - Prcp[j]) * Piwp[j] - (Plm[j] * Prpm[j] - Prcm[j]) * Piwm[j];
+                    }
                 __syncthreads();
                 MF(9);
             }
@@ -1078,31 +1133,34 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             if (wave == 0) { bwd_all(); fwd_all(); }
             __syncthreads();
             mark(7);
-            // ---- slack / multiplier steps, step length ------------------------------------------------
-            double al = 1.0;
-            for (int i = tid; i < NC * T; i += NT) {
-                int t = i / NC, k = i % NC;
-                if (!con_on(t, k)) { L.dw[i] = 0; L.dl[i] = 0; continue; }
-                const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
-                double cdx = con_val(k, v[0], v[1], y[3], y[4], v[2]);
-                double dwv = -L.rp[i] - cdx, dlv = -(L.rc[i] + L.cl[i] * dwv) / L.cw[i];
-                L.dw[i] = dwv; L.dl[i] = dlv;
-                // fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
-                double fr = 1.0;
-                if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; }
-                if (dwv < 0) { double x = -fr * L.cw[i] / dwv; if (x < al) al = x; }
-                if (dlv < 0) { double x = -fr * L.cl[i] / dlv; if (x < al) al = x; }
-            }
+            // ---- slack / multiplier steps (pair threads, registers), step length ---------------------------------------
+            // step to the boundary: the largest ratio -dx / x over all slacks and multipliers; al = min(1, fr / ratio)
+            double ratio = 0.0;
+#pragma unroll
+            for (int j = 0; j < NPR; ++j)
+                if (p_on[j]) {
+                    const double cdx = pair_step(p_t[j], p_k[j]);
+                    const double dwp = -Prpp[j] - cdx, dwm = -Prpm[j] + cdx;
+                    const double dlp = -(Prcp[j] + Plp[j] * dwp) * Piwp[j], dlm = -(Prcm[j] + Plm[j] * dwm) * Piwm[j];
+                    Pdwp[j] = dwp; Pdwm[j] = dwm; Pdlp[j] = dlp; Pdlm[j] = dlm;
+                    ratio = fmax(ratio, fmax(fmax(-dwp * Piwp[j], -dwm * Piwm[j]), fmax(-dlp * Pilp[j], -dlm * Pilm[j])));
+                }
             MF(15);
-            al = -block_reduce(-al, L.red, tid, true);
+            ratio = block_reduce(ratio, L.red, tid, true);
             MF(0);
+            // fraction to the boundary: 1 for the predictor; corrector: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
+            double fr = 1.0;
+            if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; }
+            const double al = ratio > fr ? fr / ratio : 1.0;
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
                 double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? a.warm_sig : SIGMA_FLOOR) : 0.03;
                 if (it >= 25) fl = it >= 50 ? 0.3 : 0.1;      /* a solve that is still running is cycling: centre harder */
                 sigma = q * q * q; if (sigma < fl) sigma = fl;
             } else {
-                for (int i = tid; i < NC * T; i += NT) { L.cw[i] += al * L.dw[i]; L.cl[i] += al * L.dl[i]; }
+#pragma unroll
+                for (int j = 0; j < NPR; ++j)
+                    if (p_on[j]) { Pwp[j] += al * Pdwp[j]; Pwm[j] += al * Pdwm[j]; Plp[j] += al * Pdlp[j]; Plm[j] += al * Pdlm[j]; }
                 if (tid < T) {
                     int t = tid; const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
                     L.u[t] += al * v[0]; L.u[T + t] += al * v[1]; L.d[t] += al * v[2];
@@ -1111,12 +1169,19 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 if (tid < 3) L.s[tid * (T + 1) + T] += al * L.pv[tid];
                 __syncthreads();
                 MF(11);
-                if (screened) {        // the screening holds only while every stage stays within DELTA of its reference position
-                    double dv = 0;
-                    if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
-                    dv = block_reduce(dv, L.red, tid, true);
-                    if (dv > DELTA) screened = false;      // from the next iteration on: every term (the streaming loop)
-                }
+                // ONE block reduction for (i) the reach of the hinge screening - it holds only while every stage stays within DELTA of its
+                // reference position - and (ii) the mean complementarity after the step (light convergence pass, recentring)
+                double dv = 0, m_ = 0;
+                if (screened && tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
+#pragma unroll
+                for (int j = 0; j < NPR; ++j) if (p_on[j]) m_ += Plp[j] * Pwp[j] + Plm[j] * Pwm[j];
+                dv = wave_allreduce(dv, true); m_ = wave_allreduce(m_, false);
+                __syncthreads();
+                if (lane == 0) { L.red[wave] = dv; L.red[4 + wave] = m_; }
+                __syncthreads();
+                dv = fmax(fmax(L.red[0], L.red[1]), fmax(L.red[2], L.red[3]));
+                m_ = ((L.red[4] + L.red[5]) + (L.red[6] + L.red[7])) / mcnt;
+                if (screened && dv > DELTA) screened = false;      // from the next iteration on: every term (the streaming loop)
                 MF(13);
                 // Light convergence pass: the residuals of a Newton step of length al shrink by (1 - al) (the dynamics are
                 // eliminated exactly, the constraints are affine) and the new complementarity is known now.  When these predict
@@ -1125,23 +1190,20 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 // A cold attempt that is still running after SU_CENTRE_FROM iterations is cycling: from there on every pair is kept inside a
                 // (very) wide neighbourhood of the central path, lam w >= SU_CENTRE_GAMMA mu after the step, by raising the multiplier
                 // (same rule and reason as the oracle's su_solve_impl: two neighbouring rate rows traded places for ever,
-                // tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz).  The mean complementarity it needs is the one the light
-                // convergence pass computes anyway.
+                // tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz).
                 const bool recentre = attempt >= 0 && it >= SU_CENTRE_FROM;
-                if (c.light_check || recentre) {
-                    double m_ = 0;
-                    for (int i = tid; i < NC * T; i += NT) m_ += L.cl[i] * L.cw[i];
-                    m_ = block_reduce(m_, L.red, tid, false) / mcnt;
-                    if (recentre) {
-                        const double floor_ = SU_CENTRE_GAMMA * m_;
-                        for (int i = tid; i < NC * T; i += NT)
-                            if (con_on(i / NC, i % NC) && L.cl[i] * L.cw[i] < floor_) L.cl[i] = floor_ / L.cw[i];
-                        __syncthreads();
-                    }
-                    const double prd = (1 - al) * rdn, prp = (1 - al) * rpn;
-                    expect_conv = c.light_check && ((prd <= c.tol_rd * sc && prp <= c.tol_rp && m_ <= c.tol_mu * sc) ||
-                                                    (prd <= 100 * c.tol_rd * sc && prp <= c.tol_rp && m_ <= 0.1 * c.tol_mu * sc));
+                if (recentre) {
+                    const double floor_ = SU_CENTRE_GAMMA * m_;
+#pragma unroll
+                    for (int j = 0; j < NPR; ++j)
+                        if (p_on[j]) {
+                            if (Plp[j] * Pwp[j] < floor_) Plp[j] = floor_ / Pwp[j];
+                            if (Plm[j] * Pwm[j] < floor_) Plm[j] = floor_ / Pwm[j];
+                        }
                 }
+                const double prd = (1 - al) * rdn, prp = (1 - al) * rpn;
+                expect_conv = c.light_check && ((prd <= c.tol_rd * sc && prp <= c.tol_rp && m_ <= c.tol_mu * sc) ||
+                                                (prd <= 100 * c.tol_rd * sc && prp <= c.tol_rp && m_ <= 0.1 * c.tol_mu * sc));
             }
             mark(8);
         }
@@ -1153,7 +1215,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     rollout();
     __syncthreads();
     mark(15);
-    if (status == 0 && a.lam_keep) for (int i = tid; i < NC * T; i += NT) a.lam_keep[i] = L.cl[i];
+    if (status == 0 && a.lam_keep) {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j)
+            if (p_ok[j]) { const int o = p_t[j] * NC + 2 * p_k[j]; a.lam_keep[o] = p_on[j] ? Plp[j] : 0.0; a.lam_keep[o + 1] = p_on[j] ? Plm[j] : 0.0; }
+    }
     if (status == 0) {       // otherwise keep the nominal (reference :696-700)
         for (int i = tid; i < 3 * (T + 1); i += NT) a.out_s[i] = L.s[i];
         for (int i = tid; i < 2 * T; i += NT) a.out_u[i] = L.u[i];
