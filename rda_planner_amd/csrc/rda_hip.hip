@@ -74,6 +74,7 @@ struct Dev {
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_opts::su_tol)
     int su_light;                        // su_device Cfg::light_check
+    int su_split;                        // su_device Args::split (time split of the Newton system)
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
@@ -260,7 +261,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (it > 0) { a.pose = d.pose; a.pose_lin = 1; }
     a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
-    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = d.su_prof;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = d.su_prof; a.split = d.su_split;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
@@ -1264,7 +1265,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
-    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0;
+    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1285,6 +1286,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &o->su_warm[0], &o->su_warm[1], &o->su_warm_cap); }
     geti("RDA_ZERO_COPY", &o->zero_copy); geti("RDA_EARLY_FINISH", &o->early_finish); geti("RDA_FUSE_TRACK", &o->fuse_track);
     { const char *e = getenv("RDA_SU_PROF"); if (e && *e) o->su_prof = 1; }
+    { const char *e = getenv("RDA_SU_SPLIT"); if (e && *e) o->su_split = atoi(e) != 0; }
     if (o->su_cold_probe < 1) o->su_cold_probe = 1;
 }
 
@@ -1350,7 +1352,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_easy_max = o.su_easy_max; H->d.su_easy_nopred = o.su_easy_nopred;
     H->d.su_pre = o.su_pre; H->d.lmz_tail = o.lmz_tail;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
-    H->d.su_light = o.su_light;
+    H->d.su_light = o.su_light; H->d.su_split = o.su_split;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = H->ev_used[2] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
@@ -2842,7 +2844,7 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     ar.c.ab0 = cfg->acce_bound[0]; ar.c.ab1 = cfg->acce_bound[1]; ar.c.ws = cfg->ws; ar.c.wu = cfg->wu;
     ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
     rda_opts od; rda_opts_init(&od);                   // the stop tolerances of the defaults (RDA_SU_TOL overrides)
-    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2];
+    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2]; ar.split = od.su_split;
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.cb = dsoa + 2 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;

@@ -105,6 +105,9 @@ struct Args {
     // keep the first near terms of every thread's slice in registers after the first pass that visits them (pays when the solve takes
     // several interior-point iterations; a one-pass solve only sees the longer code: the caller says which it expects)
     int term_cache = 1;
+    // time split of the Newton system (TT = 10, 20, 25, 30): the stages [T/2, T) are factorised by wave 0 and the stages [0, T/2) by wave 1 at
+    // the same time (see solve); 0 = one recursion over the whole horizon on wave 0 (rounds 1-3)
+    int split = 1;
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
@@ -152,6 +155,8 @@ constexpr int HB = 64;   // full 8x8 stage Hessian base; re-used after the matri
 constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
 constexpr int MF = 36;   // forward sweep rows [6][6]
 __device__ __host__ inline int ev(int n) { return (n + 1) & ~1; }
+// time split of the Newton system: the horizons with a compile-time instantiation are cut in two halves (0 = no split)
+__device__ __host__ constexpr int split_point(int T) { return (T == 10 || T == 20 || T == 25 || T == 30) ? T / 2 : 0; }
 struct Lds {
     double *s, *u, *d, *phin, *ref, *Ak, *Bk, *Ck, *csn, *Q1, *Q2;   // csn: cos [T] | sin [T] of the nominal headings
     double *Ft;        // [T][FT]  (constant during the solve)
@@ -169,8 +174,9 @@ struct Lds {
     double *vv;        // [T][8]   forward sweep outputs per stage: dx+ (5) | v_2 ; v = entries 3..5
     double *xd, *lw, *ra;                  // [T][5] per inequality PAIR (see the pair threads in solve): x+ - x-, lam w (+ and -), max |r_p|
     double *dy;                            // [T][8]
-    double *pv, *red;                      // 8, NT
+    double *pv, *red;                      // 8, NT + 32 (reductions, flags, the two waves' 2 x 64-double scratch of the matrix recursion)
     double *p0;                            // [2][T] reference positions of the hinge screening
+    double *uk, *ub, *xs;                  // time split (split_point(T) > 0): unit backward sweeps [5][8 m], their F_v' p [5][m][2], interface block [96]
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
@@ -181,14 +187,16 @@ struct Lds {
         Hb = p; part = p; p += (HB * T > 9 * NT ? HB * T : 9 * NT);    // part (phase 1) is dead before Hb is written (phase 3)
         Wn = p; p += WN * T; kk = p; p += 8 * T; vv = p; p += 8 * T;
         xd = p; p += ev(5 * T); lw = p; p += ev(5 * T); ra = p; p += ev(5 * T);
-        dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT; p0 = p; p += 2 * T;
+        dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT + 32; p0 = p; p += 2 * T;
+        const int m = split_point(T);
+        uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
     }
 };
 inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
-             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 + NT + 2 * T;
+             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0);
     return n * sizeof(double);
 }
 
@@ -566,8 +574,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w): with xd = x+ - x- per pair (L.xd, written by the pair threads for the
     // current right-hand side) the entries 3..7 of a stage are -xd3, -xd4, xd0 + xd3, xd1 + xd4, xd2 - formed where they are used
     // constants of the backward affine map for the current right-hand side: cb = [g_x - W g_v ; -Minv g_v]
-    auto build_cb = [&]() {
-        for (int i = tid; i < 8 * T; i += NT) {
+    auto build_cb = [&](const int first = threadIdx.x, const int stride = NT) {
+        for (int i = first; i < 8 * T; i += stride) {
             int t = i >> 3, r = i & 7;
             const double *gs = &L.gst[8 * t], *xd = &L.xd[5 * t], *wn = &L.Wn[WN * t];
             const double g5 = gs[5] + (xd[0] + xd[3]), g6 = gs[6] + (xd[1] + xd[4]), g7 = gs[7] + xd[2];
@@ -601,8 +609,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // and an FMA.  s_nop 1: a VGPR written by the previous VALU op needs two wait states before a DPP read.
     // One accumulator: a single wave issues an instruction every ~6.4 cycles whether or not it depends on the previous one
     // (tools/latency_micro.cpp), so a second accumulator only adds its initialisation and the final addition to the stage.
-    auto affine = [&](const Row &k, double x) {
-        double e0 = RW(k, 5);
+    auto affine = [&](const Row &k, double x, const bool with_const = true) {
+        double e0 = with_const ? RW(k, 5) : 0.0;
         asm volatile("s_nop 1\n\t"
                      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
                      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -612,61 +620,58 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                      : "+v"(e0) : "v"(x), "v"(RW(k, 0)), "v"(RW(k, 1)), "v"(RW(k, 2)), "v"(RW(k, 3)), "v"(RW(k, 4)));
         return e0;
     };
-    // backward: [p ; kk] <- Mb [p] + cb   (lanes 0..4 carry p, lanes 5..7 deliver kk).  Only lanes 0..7 are active
-    // (v_readlane ignores EXEC), so the per-stage stores need no predicate.
+    // backward over the stages hi-1 .. lo: [p ; kk] <- Mb [p] + cb   (lanes 0..4 of a 16-lane DPP row carry p, lanes 5..7 deliver kk; r8 = the
+    // calling lane's position in its row, < 8).  pl = p_hi in lanes 0..4; returns p_lo.  out: [8 t + r8].  with_const = false: the linear part
+    // only (unit sweeps of the time split).  Only lanes with r8 < 8 may call; row_newbcast reads inside the 16-lane row, so the four rows of a
+    // wave can run four different sweeps with the same instructions.
     // The rows of a stage are requested PD stages ahead (a ring of PD register rows): one stage of the map is ~56 cycles of dependent
     // FMAs (tools/dpp_micro.cpp) while an LDS read needs ~100 - with the rows of the NEXT stage only (round 1-2) every stage waited
     // for its rows: 151 cycles per stage measured in the kernel.
     constexpr int PD = 4;
-    auto bwd_all = [&]() {
-        if (lane < 8) {
-            double pl = 0;
-            Row k[PD];
+    auto bwd_seg = [&](const int lo, const int hi, double pl, double *out, const bool with_const, const int r8) {
+        Row k[PD];
 #pragma unroll
-            for (int j = 0; j < PD; ++j) if (T - 1 - j >= 0) ldrow(L.Hb + HB * (T - 1 - j) + 6 * lane, k[j]);
-            for (int t0 = T - 1; t0 >= 0; t0 -= PD) {
+        for (int j = 0; j < PD; ++j) if (hi - 1 - j >= lo) ldrow(L.Hb + HB * (hi - 1 - j) + 6 * r8, k[j]);
+        for (int t0 = hi - 1; t0 >= lo; t0 -= PD) {
 #pragma unroll
-                for (int j = 0; j < PD; ++j) {
-                    const int t = t0 - j;
-                    if (t >= 0) {
-                        pl = affine(k[j], pl);
-                        L.kk[8 * t + lane] = pl;
-                        if (t - PD >= 0) ldrow(L.Hb + HB * (t - PD) + 6 * lane, k[j]);
-                    }
+            for (int j = 0; j < PD; ++j) {
+                const int t = t0 - j;
+                if (t >= lo) {
+                    pl = affine(k[j], pl, with_const);
+                    out[8 * t + r8] = pl;
+                    if (t - PD >= lo) ldrow(L.Hb + HB * (t - PD) + 6 * r8, k[j]);
                 }
             }
         }
-        wsync();
-        // constants of the forward map: cf = [Fv kk ; kk_2]
-        for (int i = lane; i < 6 * T; i += 64) {
+        return pl;
+    };
+    // constants of the forward map of the stages lo .. hi-1: cf = [Fv kk ; kk_2]   (one wave; wsync before and after by the caller)
+    auto cf_seg = [&](const int lo, const int hi) {
+        for (int i = 6 * lo + lane; i < 6 * hi; i += 64) {
             int t = i / 6, r = i % 6;
             const double *kq = &L.kk[8 * t + 5], *F = &L.Ft[FT * t];
             L.Mf[MF * t + 6 * r + 5] = r < 5 ? Fel(F, r, 5) * kq[0] + Fel(F, r, 6) * kq[1] : kq[2];
         }
-        wsync();
     };
-    // forward: [dx+ ; v_2] <- Mf [dx] + cf   (lanes 0..4 carry dx; v = outputs 3..5)
-    auto fwd_all = [&]() {
-        if (lane < 8) {
-            const int row = lane < 6 ? lane : 5;
-            double xl = 0;
-            Row k[PD];
+    // forward over the stages lo .. hi-1: [dx+ ; v_2] <- Mf [dx] + cf   (lanes 0..4 carry dx; v = outputs 3..5); xl = dx_lo in lanes 0..4; lanes < 8 only
+    auto fwd_seg = [&](const int lo, const int hi, double xl) {
+        const int row = lane < 6 ? lane : 5;
+        Row k[PD];
 #pragma unroll
-            for (int j = 0; j < PD; ++j) if (j < T) ldrow(L.Mf + MF * j + 6 * row, k[j]);
-            for (int t0 = 0; t0 < T; t0 += PD) {
+        for (int j = 0; j < PD; ++j) if (lo + j < hi) ldrow(L.Mf + MF * (lo + j) + 6 * row, k[j]);
+        for (int t0 = lo; t0 < hi; t0 += PD) {
 #pragma unroll
-                for (int j = 0; j < PD; ++j) {
-                    const int t = t0 + j;
-                    if (t < T) {
-                        L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
-                        xl = affine(k[j], xl);
-                        L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
-                        if (t + PD < T) ldrow(L.Mf + MF * (t + PD) + 6 * row, k[j]);
-                    }
+            for (int j = 0; j < PD; ++j) {
+                const int t = t0 + j;
+                if (t < hi) {
+                    L.dy[8 * t + lane] = xl;                    // entries 0..4 = dx_t
+                    xl = affine(k[j], xl);
+                    L.vv[8 * t + lane] = xl;                    // entries 3..5 = v_t
+                    if (t + PD < hi) ldrow(L.Mf + MF * (t + PD) + 6 * row, k[j]);
                 }
             }
-            if (lane < 3) L.pv[lane] = xl;
         }
+        return xl;
     };
     // ---- Riccati matrix recursion (wave 0): lane 8r+q owns entry (r,q) ------------------------------------------
     struct Row5 { d2 a, b; double c; };
@@ -686,11 +691,16 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // executes one wave's instructions in order, so a write followed by reads needs no barrier); the column of X a
     // lane needs sits in its own 8-lane group and is consumed straight from the neighbours' registers by
     // v_fmac_f64 with a DPP row_newbcast operand (bank_mask selects the lower / upper group of the 16-lane row).
-    double *const Px = L.red + 16, *const Ms = L.red + 80;
+    double *const Px = L.red + 16, *const Ms = L.red + 80;             // wave 0 (stages [msp, T)): P_msp stays in Px for the interface of the time split
+    double *const PxA = L.red + 144, *const MsA = L.red + 208;          // wave 1 (stages [0, msp))
+    // time split (see the header of the pass loop): compile-time split point of this instantiation, runtime switch
+    constexpr int MSP = split_point(TT > 0 ? TT : 1);
+    const int msp = (MSP > 0 && a.split) ? MSP : 0;
+    constexpr int MQ = MSP > 0 ? MSP : 1;                               // = msp wherever the split code runs (compile-time: constant addresses, unrolled loops)
     unsigned long long stopf = 0, seq = 0;               // seq = tag of the current interior-point iteration (early-verdict flags)
     unsigned long long *const flag_meas = reinterpret_cast<unsigned long long *>(L.red + 12), *const flag_stop = flag_meas + 1;
     double okmin = 1.0, lastp = 0.0;
-    auto mat_step = [&](int t, const MatK &k) {
+    auto mat_step = [&](int t, const MatK &k, double *const Px, double *const Ms) {
         // X = P F : lane (q,i) needs row i of P
         Row5 pr; ldrow5(Px + 8 * mr_, pr);
         double x = R5(pr, 0) * R5(k.fc, 0) + R5(pr, 1) * R5(k.fc, 1);
@@ -739,6 +749,207 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         okmin = fmin(okmin, fmin(m00, fmin(c22, det)));
         lastp = pn;
         return true;
+    };
+    // the recursion over the stages hi-1 .. lo from P = 0 (one wave, its own scratch); false = the factorisation broke down
+    auto mat_range = [&](const int lo, const int hi, double *const Px_, double *const Ms_) {
+        Px_[lane] = 0.0;
+        MatK ka, kb;
+        okmin = 1.0; lastp = 0.0;
+        if (hi <= lo) return true;
+        ldmat(hi - 1, ka);
+        // The termination measures do not need the factorisation: waves 2 and 3 evaluate the test while this wave
+        // factorises and raise *flag_stop = seq when the iterate has converged; the recursion of that (last, unused)
+        // factorisation is then abandoned.  The test itself is repeated by all threads after the barrier.
+        for (int t = hi - 1; t >= lo; t -= 2) {
+            if (t - 1 >= lo) ldmat(t - 1, kb);
+            mat_step(t, ka, Px_, Ms_);
+            if (stopf == seq) break;
+            if (t - 1 >= lo) {
+                if (t - 2 >= lo) ldmat(t - 2, ka);
+                mat_step(t - 1, kb, Px_, Ms_);
+            }
+        }
+        return (okmin > 0 && lastp == lastp) || stopf == seq;
+    };
+    // ---- time split, interface block xs: X (25) | S^-1 (25) | x0 (5) at 76 | p_m (5) at 82
+    double *const XS_X = L.xs, *const XS_SI = L.xs + 25, *const XS_x0 = L.xs + 76, *const XS_pm = L.xs + 82;
+    // unit backward sweeps of segment A (no constants): p_msp = e_i; waves 2 (i = DPP row 0..3) and 3 (i = 4).  Then b = F_v' p_{t+1} per stage.
+    auto unit_sweeps = [&]() {
+        const int r8 = lane & 15, ui = wave == 2 ? (lane >> 4) : 4;
+        const bool act = r8 < 10 && (wave == 2 || lane < 16);
+        if (act) {
+            // lanes 0..7 of the row: the backward map of the stage (rows of Mb) without its constant - p(i)_t, kk(i)_t; lanes 8, 9: the columns 5, 6 of F as
+            // rows - b(i)_t = F_v' p(i)_{t+1} comes out of the same five v_fmac_f64_dpp (the input of stage t IS p_{t+1})
+            const double *base = r8 < 8 ? L.Hb + 6 * r8 : L.Ft + 6 * (r8 - 3);
+            const int stride = r8 < 8 ? HB : FT;
+            double *const outp = r8 < 8 ? L.uk + 8 * MQ * ui + r8 : L.ub + 2 * MQ * ui + (r8 - 8);
+            const int ostride = r8 < 8 ? 8 : 2;
+            double pl = r8 == ui ? 1.0 : 0.0;
+            Row k[PD];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) if (MQ - 1 - j >= 0) ldrow(base + stride * (MQ - 1 - j), k[j]);
+            for (int t0 = MQ - 1; t0 >= 0; t0 -= PD) {
+#pragma unroll
+                for (int j = 0; j < PD; ++j) {
+                    const int t = t0 - j;
+                    if (t >= 0) {
+                        pl = affine(k[j], pl, false);
+                        outp[ostride * t] = pl;
+                        if (t - PD >= 0) ldrow(base + stride * (t - PD), k[j]);
+                    }
+                }
+            }
+        }
+    };
+    // sum over the 8 lanes of an aligned group (xor 1, xor 2, half mirror)
+    auto sum8 = [&](double v) { v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); return v; };
+    // X[j][i] = sum_t b(j)_t . kk(i)_t : symmetric, 15 entries x 4 lanes (each lane the stages t = q mod 4), wave 2.  Then S = I - X P_msp (rows in
+    // lanes 0..4), S^-1 by Gauss-Jordan and Y = S^-1 X.  The elimination runs WITHOUT row exchanges, the pivot row reaching the other lanes as a DPP
+    // operand of the update itself (one v_fmac_f64_dpp per entry): on the recorded interface matrices (tools/experiments/two_segment.py) the
+    // pivots stay above 0.05 max|S| and the inverse is exact to 1e-15 - S = I + Phi P with Phi, P positive semidefinite has real eigenvalues >= 1,
+    // but its leading minors are not guaranteed, so a pivot below 1e-6 max|S| sends the iteration to the variant with partial pivoting.
+    auto interface_matrix = [&]() {
+        if (lane < 60) {
+            const int e = lane >> 2, q = lane & 3;
+            // (j, i), j <= i, of entry e = 0..14:  rows start at 0, 5, 9, 12, 14
+            const int j = e >= 14 ? 4 : (e >= 12 ? 3 : (e >= 9 ? 2 : (e >= 5 ? 1 : 0)));
+            const int i = e - (j == 0 ? 0 : (j == 1 ? 5 : (j == 2 ? 9 : (j == 3 ? 12 : 14)))) + j;
+            double x = 0;
+            const double *ubj = &L.ub[j * MQ * 2], *uki = &L.uk[8 * MQ * i + 5];
+#pragma unroll
+            for (int tt = 0; tt < (MSP + 3) / 4; ++tt) {
+                const int t = q + 4 * tt;
+                if (t < MQ) x += ubj[2 * t] * uki[8 * t] + ubj[2 * t + 1] * uki[8 * t + 1];
+            }
+            x += dpp_f64<0xB1>(x); x += dpp_f64<0x4E>(x);
+            if (q == 0) { XS_X[5 * j + i] = x; XS_X[5 * i + j] = x; }
+        }
+        wsync();
+        double am[5], ai[5];
+        const int r = lane < 5 ? lane : 0;
+        {
+            double xr[5];
+#pragma unroll
+            for (int k2 = 0; k2 < 5; ++k2) xr[k2] = XS_X[5 * r + k2];
+#pragma unroll
+            for (int c2 = 0; c2 < 5; ++c2) {
+                double v = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < 5; ++k2) v += xr[k2] * Px[8 * k2 + c2];
+                am[c2] = lane < 5 ? (r == c2 ? 1.0 : 0.0) - v : 0.0;     // (the other lanes run along; nothing of theirs is read)
+                ai[c2] = (lane < 5 && r == c2) ? 1.0 : 0.0;
+            }
+        }
+        double smax = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 5; ++c2) smax = fmax(smax, fabs(am[c2]));
+        smax = fmax(fmax(bcast(smax, 0), bcast(smax, 1)), fmax(fmax(bcast(smax, 2), bcast(smax, 3)), bcast(smax, 4)));
+        double s0[5], pmin = smax;
+#pragma unroll
+        for (int c2 = 0; c2 < 5; ++c2) s0[c2] = am[c2];
+        // Gauss-Jordan, pivot (k, k): every lane adds nf x (row k) to its row, nf = -a[.][k] / a[k][k]; the pivot lane itself nf = 1 / a[k][k] - 1
+#define SU_GJ_STEP(K)                                                                                                                   \
+        {                                                                                                                                \
+            const double pk = dpp_f64<0x150 + K>(am[K]);                                                                                  \
+            pmin = fmin(pmin, fabs(pk));                                                                                                  \
+            const double ip = frcp(pk);                                                                                                    \
+            const double nf = lane == K ? ip - 1.0 : -am[K] * ip;                                                                           \
+            asm volatile("s_nop 1\n\t"                                                                                                   \
+                         "v_fmac_f64_dpp %0, %0, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %1, %1, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %2, %2, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %3, %3, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %4, %4, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %5, %5, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %6, %6, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %7, %7, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %8, %8, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                                  \
+                         "v_fmac_f64_dpp %9, %9, %10 row_newbcast:" #K " row_mask:0xf bank_mask:0xf"                                       \
+                         : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]), "+v"(am[4]), "+v"(ai[0]), "+v"(ai[1]), "+v"(ai[2]), "+v"(ai[3]), "+v"(ai[4]) \
+                         : "v"(nf));                                                                                                      \
+        }
+        SU_GJ_STEP(0) SU_GJ_STEP(1) SU_GJ_STEP(2) SU_GJ_STEP(3) SU_GJ_STEP(4)
+#undef SU_GJ_STEP
+        pmin = fmin(fmin(bcast(pmin, 0), bcast(pmin, 1)), fmin(fmin(bcast(pmin, 2), bcast(pmin, 3)), bcast(pmin, 4)));
+        int mycol = lane < 5 ? lane : 0;
+        if (!(pmin > 1e-6 * smax)) {               // (uniform; not seen on any recorded system) the same elimination with partial pivoting
+#pragma unroll
+            for (int c2 = 0; c2 < 5; ++c2) { am[c2] = lane < 5 ? s0[c2] : 0.0; ai[c2] = (lane < 5 && r == c2) ? 1.0 : 0.0; }
+            bool usedrow = lane >= 5;
+#pragma unroll
+            for (int k2 = 0; k2 < 5; ++k2) {
+                const double cand = usedrow ? -1.0 : fabs(am[k2]);
+                int pl_ = 0; double best = bcast(cand, 0);
+                { const double c1 = bcast(cand, 1); if (c1 > best) { best = c1; pl_ = 1; } }
+                { const double c1 = bcast(cand, 2); if (c1 > best) { best = c1; pl_ = 2; } }
+                { const double c1 = bcast(cand, 3); if (c1 > best) { best = c1; pl_ = 3; } }
+                { const double c1 = bcast(cand, 4); if (c1 > best) { best = c1; pl_ = 4; } }
+                const int pv_ = __builtin_amdgcn_readfirstlane(pl_);
+                double pm_[5], pi_[5];
+#pragma unroll
+                for (int c2 = 0; c2 < 5; ++c2) {
+                    pm_[c2] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(am[c2]), pv_), __builtin_amdgcn_readlane(__double2loint(am[c2]), pv_));
+                    pi_[c2] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ai[c2]), pv_), __builtin_amdgcn_readlane(__double2loint(ai[c2]), pv_));
+                }
+                const double ip = frcp(pm_[k2]);
+                if (lane == pv_) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 5; ++c2) { am[c2] = pm_[c2] * ip; ai[c2] = pi_[c2] * ip; }
+                    usedrow = true; mycol = k2;
+                } else {
+                    const double f = am[k2] * ip;
+#pragma unroll
+                    for (int c2 = 0; c2 < 5; ++c2) { am[c2] -= f * pm_[c2]; ai[c2] -= f * pi_[c2]; }
+                }
+            }
+        }
+        if (lane < 5) {
+#pragma unroll
+            for (int c2 = 0; c2 < 5; ++c2) XS_SI[5 * mycol + c2] = ai[c2];
+        }
+    };
+    // x0[j] = sum_t b(j)_t . kk_t of A's own backward sweep (wave 1: 5 x 8 lanes, each the stages t = q mod 8)
+    auto interface_x0 = [&]() {
+        if (lane < 40) {
+            const int j = lane >> 3, q = lane & 7;
+            double x = 0;
+            const double *ubj = &L.ub[j * MQ * 2];
+#pragma unroll
+            for (int tt = 0; tt < (MSP + 7) / 8; ++tt) {
+                const int t = q + 8 * tt;
+                if (t < MQ) x += ubj[2 * t] * L.kk[8 * t + 5] + ubj[2 * t + 1] * L.kk[8 * t + 6];
+            }
+            x = sum8(x);
+            if (q == 0) XS_x0[j] = x;
+        }
+    };
+    // x_m = S^-1 (x0 + X p_m) (lanes 0..4), pi = P_msp x_m + p_m; returns (x_m, pi) of lane j < 5.  Called by waves 0 and 1 alike.
+    auto interface_solve = [&](double &xm, double &pi) {
+        const int j = lane < 5 ? lane : 0;
+        double si[5], xx[5], pmv[5], pj[5];
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) { si[k2] = XS_SI[5 * j + k2]; xx[k2] = XS_X[5 * j + k2]; pmv[k2] = XS_pm[k2]; pj[k2] = Px[8 * j + k2]; }
+        double rr = XS_x0[j], w = XS_pm[j];
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) rr += xx[k2] * pmv[k2];
+        double v = 0.0;
+        // x_m,j = sum_k S^-1[j][k] rr_k and pi_j = p_m,j + sum_k P[j][k] x_m,k : the vectors sit in lanes 0..4
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(v) : "v"(rr), "v"(si[0]), "v"(si[1]), "v"(si[2]), "v"(si[3]), "v"(si[4]));
+        xm = v;
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(w) : "v"(xm), "v"(pj[0]), "v"(pj[1]), "v"(pj[2]), "v"(pj[3]), "v"(pj[4]));
+        pi = w;
     };
 
     // Two attempts (same rule as the oracle): when the first one ends without convergence -- the iteration cap, ~0.1 % of
@@ -982,31 +1193,14 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         }
         __syncthreads();
         mark(2);
-        // ---- (4) wave 0: Riccati matrix recursion; wave 1: adjoint sweep for the reduced gradient;
-        //          wave 2: Newton right-hand side of the predictor --------------------------------------------
+        // ---- (4) waves 0 / 1: Riccati matrix recursion of the stages [msp, T) / [0, msp) (time split; msp = 0: wave 0 takes them all);
+        //          wave 2: adjoint sweep for the reduced gradient + early verdict; wave 3: the other termination measures ------------
         bool fail = false;
         if (wave == 0) {
-          if (!expect_conv) {
-            Px[lane] = 0.0;                               // P_T = 0
-            MatK ka, kb;
-            bool ok = true; okmin = 1.0; lastp = 0.0;
-            ldmat(T - 1, ka);
-            // The termination measures do not need the factorisation: waves 1 and 3 evaluate the test while this wave
-            // factorises and raise *flag_stop = seq when the iterate has converged; the recursion of that (last, unused)
-            // factorisation is then abandoned.  The test itself is repeated by all threads after the barrier.
-            for (int t = T - 1; t >= 0; t -= 2) {
-                if (t >= 1) ldmat(t - 1, kb);
-                ok = mat_step(t, ka) && ok;
-                if (stopf == seq) break;
-                if (t >= 1) {
-                    if (t >= 2) ldmat(t - 2, ka);
-                    ok = mat_step(t - 1, kb) && ok;
-                }
-            }
-            ok = ok && okmin > 0 && lastp == lastp;
-            fail = !ok && stopf != seq;
-          }
+            if (!expect_conv) fail = msp > 0 ? !mat_range(MSP, T, Px, Ms) : !mat_range(0, T, Px, Ms);
         } else if (wave == 1) {
+            if (!expect_conv && msp > 0) fail = !mat_range(0, MSP, PxA, MsA);
+        } else if (wave == 2) {
             // Adjoint sweep p_t = g_x,t + A_t' p_{t+1}, one stage per lane.  A_t = [[1,0,a13],[0,1,a23],[0,0,1]] in all three
             // motion models, so p0 and p1 are suffix sums of g0, g1 and p2 is the suffix sum of g2 + a13 p0' + a23 p1'
             // (' = the value of stage t+1): three wave scans instead of T dependent stages.  Only the termination measure
@@ -1040,8 +1234,6 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 if ((rd <= c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= c.tol_mu * sc_) || (rd <= 100 * c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= 0.1 * c.tol_mu * sc_))
                     if (lane == 0) __atomic_store_n(flag_stop, seq, __ATOMIC_RELAXED);
             }
-        } else if (wave == 2) {
-            // (the Newton right-hand side is formed inside build_cb since round 4: nothing to prepare here)
         } else {
             // termination measures that do not depend on the sweeps
             double g = 0, rp_ = 0, m_ = 0;
@@ -1053,7 +1245,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 __atomic_store_n(flag_meas, seq, __ATOMIC_RELEASE);
             }
         }
-        __syncthreads();
+        const int anyfail = __syncthreads_or(fail ? 1 : 0);
         mark(4);
         // ---- (4b) closed-loop sweep matrices from W, Minv (all threads; Mb overwrites the consumed Hb,
         //           Mf overwrites the consumed hs..cy) --------------------------------------------------------------
@@ -1104,7 +1296,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             expect_conv = false; __syncthreads(); --it; continue;
         }
         mu_prev = mu;              // (after the repeat decision: the repeated pass smooths with the same width as the light one)
-        if (__syncthreads_or(fail ? 1 : 0)) { status = 2; break; }
+        if (anyfail) { status = 2; break; }
         mark(5);
 
         double sigma = 0;
@@ -1113,6 +1305,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
         // two.  Should that iteration not finish the solve, the following ones are ordinary predictor-corrector iterations.
         const bool nopred = attempt < 0 && a.warm_nopred != 0 && it == 0;
         if (nopred) sigma = a.warm_sig;
+        bool unit_done = false;                    // time split: the unit sweeps / interface matrix of this factorisation exist
+        if (msp > 0) __syncthreads();              // (the unit sweeps of waves 2 / 3 read the closed-loop rows all threads have just written)
         for (int pass = nopred ? 1 : 0; pass < 2; ++pass) {
             if (pass == 1) {
                 // corrector right-hand side: targets lam w + dlam dw - sigma mu (no second-order term without a predictor), new x+ - x-
@@ -1127,10 +1321,63 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 __syncthreads();
                 MF(9);
             }
-            build_cb();
-            __syncthreads();
-            mark(6);
-            if (wave == 0) { bwd_all(); fwd_all(); }
+            if (MSP == 0 || msp == 0) {
+                build_cb();
+                __syncthreads();
+                mark(6);
+                if (wave == 0) {
+                    if (lane < 8) bwd_seg(0, T, 0.0, L.kk, true, lane);
+                    wsync(); cf_seg(0, T); wsync();
+                    if (lane < 8) { const double xe = fwd_seg(0, T, 0.0); if (lane < 3) L.pv[lane] = xe; }
+                }
+            } else {
+                // TIME SPLIT.  Segment B = stages [msp, T) was factorised from P_T = 0 (wave 0), segment A = [0, msp) from P = 0 (wave 1): A's gains are
+                // those of a horizon that ends at msp with a LINEAR terminal term pi' x_msp.  With pi = P_msp x_msp + p_msp (the gradient of B's
+                // cost-to-go at the true x_msp) both halves solve the same Newton system as one recursion over [0, T) - the first-order conditions
+                // are identical.  x_msp responds linearly to pi: x_msp = x0 + X pi, where x0 is A's own answer (pi = 0) and X[j][i] = sum_t b(j)_t . kk(i)_t
+                // comes from five UNIT backward sweeps of A (p_msp = e_i, no constants: kk(i)_t; b(j)_t = F_v' p(j)_{t+1}) - so
+                //     (I - X P_msp) x_msp = x0 + X p_msp ,   pi = P_msp x_msp + p_msp ,   kk_t += sum_i pi_i kk(i)_t  (t < msp)
+                // and the two forward sweeps start from 0 and x_msp.  Unit sweeps, X, S^-1 and S^-1 X depend on the factorisation only: once per
+                // interior-point iteration, by waves 2 / 3 beside the sweep constants and the first backward sweeps.
+                // tools/experiments/two_segment.py: the algebra in numpy, on random and on recorded systems.
+                if (!unit_done) {                          // first pass of this factorisation: the sweep constants on waves 0 / 1, the unit sweeps on 2 / 3
+                    if (wave < 2) build_cb(tid, NT / 2); else unit_sweeps();
+                } else build_cb(tid, NT);
+                __syncthreads();
+                mark(6);
+                if (wave == 0) {
+                    double pe = 0;
+                    if (lane < 8) pe = bwd_seg(MSP, T, 0.0, L.kk, true, lane);
+                    if (lane < 5) XS_pm[lane] = pe;
+                } else if (wave == 1) {
+                    if (lane < 8) bwd_seg(0, MSP, 0.0, L.kk, true, lane);
+                    wsync(); interface_x0();
+                } else if (wave == 2 && !unit_done) interface_matrix();
+                unit_done = true;
+                __syncthreads();
+                MF(3);
+                if (wave < 2) {
+                    double xm, pi;
+                    interface_solve(xm, pi);
+                    if (wave == 0) {
+                        cf_seg(MSP, T); wsync();          // (the forward constants of B here rather than behind the backward sweep: this wave has the shorter prelude)
+                        if (lane < 8) { const double xe = fwd_seg(MSP, T, lane < 5 ? xm : 0.0); if (lane < 3) L.pv[lane] = xe; }
+                    } else {
+                        double pv5[5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) pv5[i] = bcast(pi, i);
+                        for (int e = lane; e < 3 * MSP; e += 64) {
+                            const int t = e / 3, k2 = 5 + e % 3;
+                            double v = L.kk[8 * t + k2];
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) v += pv5[i] * L.uk[8 * MSP * i + 8 * t + k2];
+                            L.kk[8 * t + k2] = v;
+                        }
+                        wsync(); cf_seg(0, MSP); wsync();
+                        if (lane < 8) fwd_seg(0, MSP, 0.0);
+                    }
+                }
+            }
             __syncthreads();
             mark(7);
             // ---- slack / multiplier steps (pair threads, registers), step length ---------------------------------------

@@ -51,11 +51,11 @@ def main():
     if args.fine:
         NAMES.update({14: "(2) stage derivatives + inequality rows", 12: "(3a) stage gradients", 2: "(3b) Hessian bases", 9: "(6a) corrector rc + gh", 6: "(6b) sweep constants",
                       15: "(8a) slack / multiplier rows", 0: "(8b) step-length reduction", 11: "(8c) update", 13: "(8d) reach check", 8: "(8e) sigma / light check",
-                      10: "set-up + final roll-out + write-back", 3: "-", })
+                      10: "set-up + final roll-out + write-back", 3: "(7a) backward sweeps + interface (time split)", 7: "(7b) forward sweeps (split: + interface solve)"})
     tot = sum(out)
     print(f"T={args.horizon} N={args.n_obs} moving={args.moving}: {solves} su-solves, {ipm / solves:.2f} interior-point iterations per solve, "
           f"{tot / solves:.0f} ticks per solve")
-    for k in ((1, 14, 12, 2, 4, 5, 9, 6, 7, 15, 0, 11, 13, 8, 10) if args.fine else (0, 11, 13, 9, 3, 14, 12, 1, 2, 4, 5, 6, 7, 8, 15, 10)):
+    for k in ((1, 14, 12, 2, 4, 5, 9, 6, 3, 7, 15, 0, 11, 13, 8, 10) if args.fine else (0, 11, 13, 9, 3, 14, 12, 1, 2, 4, 5, 6, 7, 8, 15, 10)):
         print(f"  [{k:2d}] {NAMES[k]:34s} {out[k] / solves:9.0f} ticks/solve  {100.0 * out[k] / tot:5.1f} %")
 
 
