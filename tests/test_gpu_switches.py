@@ -60,3 +60,36 @@ def test_switch_reproduces_the_default_closed_loop(defaults, monkeypatch, env, c
         assert g[4] == w[4] and g[5] == w[5], (k, g[4:], w[4:])
         assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), (k, float(np.abs(g[0] - w[0]).max()))
         assert g[2] == w[2] and g[3] == w[3], (k, g[2:4], w[2:4])
+
+
+@pytest.mark.parametrize("T,dyn,moving", [(20, "acker", False), (25, "omni", True), (30, "diff", True), (10, "acker", False)])
+def test_time_split_of_the_su_newton_system_changes_nothing_but_rounding(T, dyn, moving):
+    """rda_opts::su_split (round 4): the horizons with a compile-time instantiation factorise and sweep the Newton system of the su
+    interior point in two halves on two waves, joined by a 5 x 5 interface system - the SAME linear system as one recursion over the
+    horizon.  Two handles, su_split = 1 / 0, stepped from the same state (re-synchronised every step): same ADMM and interior-point
+    iteration counts, controls equal to rounding (1e-9: an interior-point iterate is a smooth function of its Newton directions)."""
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd.rda_solver import hip_options
+    car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+    path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    scene = sc.scene_polygons(40, lo=(8, 14), hi=(40, 36), seed=7, keep_clear=clear, clear_radius=3.0, moving=moving)
+    kw = dict(receding=T, iter_num=3, max_edge_num=4, max_obs_num=40, time_print=False)
+    a = MPC(car_t, [p.copy() for p in path], hip_opts=hip_options(su_split=1), **kw)
+    b = MPC(car_t, [p.copy() for p in path], hip_opts=hip_options(su_split=0), **kw)
+    st = path[0].copy().reshape(3, 1)
+    if dyn == "omni":
+        st[2, 0] = 0.0
+    worst = 0.0
+    for k in range(40):
+        cur = [o if not np.any(o.velocity) else o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) for o in scene]
+        ua, ia = a.control(st.copy(), 4.0, list(cur))
+        ub, ib = b.control(st.copy(), 4.0, list(cur))
+        assert ia["iters"] == ib["iters"] and ia["status"] == ib["status"] == 0, (k, ia["iters"], ib["iters"])
+        assert abs(ia["su_ipm_iters"] - ib["su_ipm_iters"]) <= 1, (k, ia["su_ipm_iters"], ib["su_ipm_iters"])
+        worst = max(worst, float(np.abs(ua - ub).max()), float(np.abs(a.cur_vel_array - b.cur_vel_array).max()))
+        b.rda.set_state(a.rda.get_state())
+        b.cur_vel_array = a.cur_vel_array.copy(); b.cur_index = a.cur_index
+        st = sc.kinematic_step(st, ua, car_t, 0.1)
+    print(f"T={T} {dyn}: max |u_split - u_unsplit| over the horizon {worst:.2e}")
+    assert worst <= 1e-9
