@@ -173,6 +173,7 @@ struct Lds {
     double *kk;        // [T][8]   backward sweep outputs per stage: p (5) | feed-forward kk (3)
     double *vv;        // [T][8]   forward sweep outputs per stage: dx+ (5) | v_2 ; v = entries 3..5
     double *xd, *lw, *ra;                  // [T][5] per inequality PAIR (see the pair threads in solve): x+ - x-, lam w (+ and -), max |r_p|
+    double *m7;                            // [T][8] column of d_t in the stage Hessian (entries 0..6) | 1 / its diagonal: d_t is eliminated before the recursion
     double *dy;                            // [T][8]
     double *pv, *red;                      // 8, NT + 32 (reductions, flags, the two waves' 2 x 64-double scratch of the matrix recursion)
     double *p0;                            // [2][T] reference positions of the hinge screening
@@ -186,7 +187,7 @@ struct Lds {
         gst = p; p += 8 * T; gad = p; p += ev(3 * T);
         Hb = p; part = p; p += (HB * T > 9 * NT ? HB * T : 9 * NT);    // part (phase 1) is dead before Hb is written (phase 3)
         Wn = p; p += WN * T; kk = p; p += 8 * T; vv = p; p += 8 * T;
-        xd = p; p += ev(5 * T); lw = p; p += ev(5 * T); ra = p; p += ev(5 * T);
+        xd = p; p += ev(5 * T); lw = p; p += ev(5 * T); ra = p; p += ev(5 * T); m7 = p; p += 8 * T;
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT + 32; p0 = p; p += 2 * T;
         const int m = split_point(T);
         uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
@@ -196,7 +197,7 @@ inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
-             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0);
+             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0);
     return n * sizeof(double);
 }
 
@@ -328,6 +329,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
 
     // ---- load nominal, reference; linearise -------------------------------------------------
     for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; if (!a.ref_flag) L.ref[i] = a.ref[i]; }
+    for (int i = tid; i < WN * T; i += NT) L.Wn[i] = 0.0;       // (W[.][2], Minv[.][2] stay zero: d_t is not part of the recursion)
     if (tid < T) { L.u[tid] = pf_u0; L.u[T + tid] = pf_u1; }
     // reference positions of the hinge screening: where the masks were made (pose table), else the nominal positions of stages 1..T
     for (int i = tid; i < 2 * T; i += NT)
@@ -461,7 +463,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     // ... and of a step: [dx (5) | .] in dy, v = (du0, du1, dd) in vv[3..5]
     auto pair_step = [&](int t, int k) {
         const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
-        if (k == 2) return v[2];
+        if (k == 2) {                                         // dd = -(g7 + m7' [dx; du]) / H77 ; also left where the update reads it
+            const double *m7 = &L.m7[8 * t];
+            const double g7 = L.gst[8 * t + 7] + L.xd[5 * t + 2];
+            const double dd = -(g7 + (m7[0] * y[0] + m7[1] * y[1] + m7[2] * y[2] + m7[3] * y[3] + m7[4] * y[4]) + (m7[5] * v[0] + m7[6] * v[1])) * m7[7];
+            L.vv[8 * t + 5] = dd;
+            return dd;
+        }
         const bool second = k == 1 || k == 4;
         const double dv = second ? v[1] : v[0];
         return k < 3 ? dv : dv - (second ? y[4] : y[3]);
@@ -577,12 +585,14 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
     auto build_cb = [&](const int first = threadIdx.x, const int stride = NT) {
         for (int i = first; i < 8 * T; i += stride) {
             int t = i >> 3, r = i & 7;
-            const double *gs = &L.gst[8 * t], *xd = &L.xd[5 * t], *wn = &L.Wn[WN * t];
-            const double g5 = gs[5] + (xd[0] + xd[3]), g6 = gs[6] + (xd[1] + xd[4]), g7 = gs[7] + xd[2];
+            const double *gs = &L.gst[8 * t], *xd = &L.xd[5 * t], *wn = &L.Wn[WN * t], *m7 = &L.m7[8 * t];
+            // (d_t eliminated: g' = g - m7 g7 / H77 on the entries 0..6; the rows of d in W / Minv are zero)
+            const double g7 = gs[7] + xd[2], c7 = g7 * m7[7];
+            const double g5 = gs[5] + (xd[0] + xd[3]) - m7[5] * c7, g6 = gs[6] + (xd[1] + xd[4]) - m7[6] * c7;
             double v;
             if (r < 5) {
-                const double gr = r < 3 ? gs[r] : (r == 3 ? gs[3] - xd[3] : gs[4] - xd[4]);
-                v = gr - (wn[3 * r] * g5 + wn[3 * r + 1] * g6 + wn[3 * r + 2] * g7);
+                const double gr = (r < 3 ? gs[r] : (r == 3 ? gs[3] - xd[3] : gs[4] - xd[4])) - m7[r] * c7;
+                v = gr - (wn[3 * r] * g5 + wn[3 * r + 1] * g6);
             } else {
                 int k = r - 5;
                 double n0 = k == 0 ? wn[15] : (k == 1 ? wn[16] : wn[17]);
@@ -722,31 +732,28 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                      : "+v"(me), "+v"(mo) : "v"(x), "v"(R5(k.fr, 0)), "v"(R5(k.fr, 1)), "v"(R5(k.fr, 2)), "v"(R5(k.fr, 3)), "v"(R5(k.fr, 4)));
         const double m = k.hb + ((mq_ & 1) ? mo : me);
         Ms[8 * mr_ + mq_] = m;
-        // pivot block Mvv (rows/cols 5..7), M[r][5..7], M[5..7][q]
-        const double m00 = Ms[45], m01 = Ms[46], m02 = Ms[47], m11 = Ms[54], m12 = Ms[55], m22 = Ms[63];
-        const double a0 = Ms[8 * mr_ + 5], a1 = Ms[8 * mr_ + 6], a2 = Ms[8 * mr_ + 7];
-        double b0 = Ms[40 + mq_], b1 = Ms[48 + mq_], b2 = Ms[56 + mq_];
-        stopf = __atomic_load_n(flag_stop, __ATOMIC_RELAXED);   // "this iterate has converged" (wave 1), same LDS round
-        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2));      // keep these loads in the same LDS round as the pivot block
-        // inverse of Mvv by the adjugate, on every lane; reciprocal of the determinant by v_rcp_f64 + two Newton steps
-        double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
-        double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
-        double det = m00 * c00 + m01 * c01 + m02 * c02;
+        // pivot block Mvv (rows/cols 5, 6: d_t was eliminated when the stage Hessians were assembled), M[r][5..6], M[5..6][q]
+        const double m00 = Ms[45], m01 = Ms[46], m11 = Ms[54];
+        const double a0 = Ms[8 * mr_ + 5], a1 = Ms[8 * mr_ + 6];
+        double b0 = Ms[40 + mq_], b1 = Ms[48 + mq_];
+        stopf = __atomic_load_n(flag_stop, __ATOMIC_RELAXED);   // "this iterate has converged" (wave 2), same LDS round
+        asm volatile("" : "+v"(b0), "+v"(b1));               // keep these loads in the same LDS round as the pivot block
+        // inverse of the 2 x 2 block on every lane; reciprocal of the determinant by v_rcp_f64 + two Newton steps
+        const double det = m00 * m11 - m01 * m01;
         double id = __builtin_amdgcn_rcp(det);
         id = __builtin_fma(id, __builtin_fma(-det, id, 1.0), id);
         id = __builtin_fma(id, __builtin_fma(-det, id, 1.0), id);
-        double n00 = c00 * id, n01 = c01 * id, n02 = c02 * id, n11 = c11 * id, n12 = c12 * id, n22 = c22 * id;
-        // W row r = M[r][5..7] Minv ;  P = Mxx - W Mvx
-        double w0 = a0 * n00 + a1 * n01 + a2 * n02;
-        double w1 = a0 * n01 + a1 * n11 + a2 * n12;
-        double w2 = a0 * n02 + a1 * n12 + a2 * n22;
-        double pn = m - (w0 * b0 + w1 * b1 + w2 * b2);
+        const double n00 = m11 * id, n01 = -m01 * id, n11 = m00 * id;
+        // W row r = M[r][5..6] Minv ;  P = Mxx - W Mvx
+        const double w0 = a0 * n00 + a1 * n01;
+        const double w1 = a0 * n01 + a1 * n11;
+        double pn = m - (w0 * b0 + w1 * b1);
         Px[8 * mr_ + mq_] = (mr_ < 5 && mq_ < 5) ? pn : 0.0;
-        double *o = &L.Wn[WN * t];
-        if (mq_ == 0 && mr_ < 5) { o[3 * mr_] = w0; o[3 * mr_ + 1] = w1; o[3 * mr_ + 2] = w2; }      // (the q = 0 lane of a row holds its whole W row: no selects)
-        if (lane == 63) { o[15] = n00; o[16] = n01; o[17] = n02; o[18] = n11; o[19] = n12; o[20] = n22; }
-        // breakdown check: the running minimum of the three leading minors' signs (one v_min each; a NaN shows in the last P instead)
-        okmin = fmin(okmin, fmin(m00, fmin(c22, det)));
+        double *o = &L.Wn[WN * t];                            // (the entries that belong to d - W[.][2], Minv[.][2] - are zero for the whole solve: set-up)
+        if (mq_ == 0 && mr_ < 5) { o[3 * mr_] = w0; o[3 * mr_ + 1] = w1; }      // (the q = 0 lane of a row holds its whole W row: no selects)
+        if (lane == 63) { o[15] = n00; o[16] = n01; o[18] = n11; }
+        // breakdown check: the running minimum of the leading minors' signs (one v_min each; a NaN shows in the last P instead)
+        okmin = fmin(okmin, fmin(m00, det));
         lastp = pn;
         return true;
     };
@@ -1176,19 +1183,26 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
             const double v0 = h00 * a0 + h01 * a1 + hd0 * a3, v1 = h01 * a0 + h11 * a1 + hd1 * a3, v2 = h22 * a2, v3 = hd0 * a0 + hd1 * a1 + hdd * a3;
             const double bu0 = dg[0], bu1 = dg[1], bd = dg[2], br0 = dg[3], br1 = dg[4];
             double *row = &L.Hb[HB * t + 8 * r];
+            // d_t enters only its own stage (F has no column for it), so it is eliminated HERE, before the recursion: column m7 = H[0..6][7],
+            // H' = H - m7 m7' / H77 on the entries 0..6, d decoupled (round 4: the pivot block of the recursion becomes 2 x 2; the step of d is
+            // recovered per stage by its inequality pair: dd = -(g7 + m7'y) / H77)
+            const double i77 = frcp(hdd + bd);
+            const double m7r = r < 7 ? v3 : 0.0;              // (v3 of a row r < 7 = hd0 a0 + hd1 a1)
+            L.m7[8 * t + r] = r < 7 ? m7r : i77;
+            const double f7 = m7r * i77;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                double m = Fel(F, 0, q) * v0 + Fel(F, 1, q) * v1 + Fel(F, 2, q) * v2 + (q == 7 ? v3 : 0.0);
+                double m = Fel(F, 0, q) * v0 + Fel(F, 1, q) * v1 + Fel(F, 2, q) * v2;
                 // barrier weights: u0 box, u1 box, d box, rate u0 (rows u0 - up0), rate u1
                 if (r == q) {
                     if (r == 5) m += 2 * c.wu + c.eps_u + bu0 + br0;
                     else if (r == 6) m += c.eps_u + bu1 + br1;
-                    else if (r == 7) m += bd;
                     else if (r == 3) m += br0;
                     else if (r == 4) m += br1;
                 } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= br0;
                 else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= br1;
-                row[q] = m;
+                if (q < 7) m -= f7 * (hd0 * Fel(F, 0, q) + hd1 * Fel(F, 1, q));
+                row[q] = (r == 7 || q == 7) ? (r == q ? 1.0 : 0.0) : m;
             }
         }
         __syncthreads();

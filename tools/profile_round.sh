@@ -7,14 +7,14 @@
 #   3. SQ issue counters, four passes (ns and c4)                           -> <cfg>_issue_counters.txt
 #   4. plain bench runs (no profiler) of every config + the C5 fleet + the su phase profiles -> bench_<cfg>.json, suprof_<cfg>.txt
 # then `python tools/profile_collect.py <tag>` (CPU) turns that into the committed summaries under profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 OUT="gpurun_out/prof_${TAG}"
 mkdir -p "$OUT" "$OUT/scratch"
 SCR="$OUT/scratch"
 BENCH="python bench.py --no-cpu-baseline --no-sizes --egos 0 --fleet-egos 0 --no-ip-legs"
-declare -A ARGS=( [ns]="--steps 200 --warmup 10" [n20]="--n-obs 20 --steps 100 --warmup 10" [n2000]="--n-obs 2000 --steps 60 --warmup 5" [c4]="--moving --horizon 30 --steps 60 --warmup 5" [ip]="--steps 60 --warmup 5" )
+declare -A ARGS=( [ns]="--steps 100 --warmup 10" [n20]="--n-obs 20 --steps 100 --warmup 10" [n2000]="--n-obs 2000 --steps 60 --warmup 5" [c4]="--moving --horizon 30 --steps 60 --warmup 5" [ip]="--steps 60 --warmup 5" )
 declare -A ENVS=( [ip]="RDA_LMZ_MODE=1 RDA_LMZ_MU=1e-3" )
 
 : > "$OUT/pmc_fetch_write.txt"
@@ -83,15 +83,21 @@ PY
   done
 done
 
-timeout 400 python bench.py --egos 16 --fleet-egos 64 2> /dev/null | grep '^{' > "$OUT/bench_ns.json"
+timeout 400 python bench.py --egos 16 --fleet-egos 64 2> /dev/null | grep '^{' > "$OUT/bench_ns.json"                 # 200-step window, every leg, sizes
+timeout 200 python bench.py --steps 20 --warmup 5 2> /dev/null | grep '^{' > "$OUT/bench_ns_driver_window.json"        # the driver's command
 for CFG in n20 n2000 c4; do timeout 300 $BENCH ${ARGS[$CFG]} 2> /dev/null | grep '^{' > "$OUT/bench_${CFG}.json"; done
-timeout 300 python bench.py --no-cpu-baseline --no-ip-legs --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 2> /dev/null | grep '^{' > "$OUT/bench_c5_fleet.json"
+timeout 300 python bench.py --no-cpu-baseline --no-sizes --no-ip-legs --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 2> /dev/null | grep '^{' > "$OUT/bench_c5_fleet.json"
 D="$SCR/stats_c5"; mkdir -p "$D"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o f -- python bench.py --no-cpu-baseline --no-ip-legs --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 --steps 100 > /dev/null 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o f -- python bench.py --no-cpu-baseline --no-sizes --no-ip-legs --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 --steps 100 > /dev/null 2>&1 || true
 find "$D" -name '*kernel_stats.csv' -exec cp {} "$OUT/c5_fleet_kernel_stats.csv" \;
-python tools/su_phase_profile.py > "$OUT/suprof_ns.txt" 2>&1
-python tools/su_phase_profile.py --n-obs 2000 --steps 60 > "$OUT/suprof_n2000.txt" 2>&1
+python tools/su_phase_profile.py > "$OUT/suprof_ns_fixed_binding.txt" 2>&1
+python tools/su_phase_profile.py --order > "$OUT/suprof_ns.txt" 2>&1
+python tools/su_phase_profile.py --n-obs 2000 --steps 60 --order > "$OUT/suprof_n2000.txt" 2>&1
 python tools/su_phase_profile.py --moving --horizon 30 --steps 60 --order > "$OUT/suprof_c4.txt" 2>&1
+if [ -f tools/_bin/librda_hip_fine.so ]; then      # -DSU_FINE build of the same sources (sub-phases of the iteration)
+  RDA_HIP_SO=$PWD/tools/_bin/librda_hip_fine.so python tools/su_phase_profile.py --order --fine > "$OUT/suprof_ns_fine.txt" 2>&1
+  RDA_HIP_SO=$PWD/tools/_bin/librda_hip_fine.so python tools/su_phase_profile.py --moving --horizon 30 --steps 60 --order --fine > "$OUT/suprof_c4_fine.txt" 2>&1
+fi
 # the scratch tree (raw rocprofv3 output, tens of MB) does not travel back
 find "$SCR" -type f -delete
 ls -la "$OUT"; head -12 "$OUT/ns_kernel_stats.csv"
