@@ -270,7 +270,7 @@ __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return
 // RefWait: called by all threads before the first use of the reference, when a.ref_flag is set - returns when the reference (a.ref) is complete
 // (k_su_tracked: another workgroup samples it meanwhile; the functor bounds the wait and samples it itself on expiry).
 struct NoRefWait { __device__ __forceinline__ void operator()(double *) const {} };
-template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(const Args &a, double *smem, RefWait ref_wait = RefWait())
+template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool solve(const Args &a, double *smem, RefWait ref_wait = RefWait())
 {
     const Cfg &c = a.c;
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,39 +387,29 @@ template <int TT, typename RefWait = NoRefWait> __device__ inline bool solve(con
                 inc[3 * t + 1] = (B[2] * u0 + B[3] * u1) + C[1];
             }
             wsync();
-            // (the increments are fetched into registers first: a load behind a store into the same LDS buffer cannot be hoisted by the
-            // compiler, and one LDS round trip per stage was two thirds of this roll-out)
-            if (lane == 0) {
-                double ph = L.s[2 * (T + 1)];
-                if constexpr (TT > 0) {
-                    double v[TT];
+            // the running sums as wave prefix scans, one stage per lane (T <= 64): six shuffle steps instead of T dependent additions on one lane
+            // holding T registers (round 4: the unrolled register arrays of the serial form were the reason the T = 25 / 30 instantiations
+            // spilled to scratch).  Another summation order than the serial loop: rounding level, like every reduction of this kernel.
+            auto prefix = [&](double v) {
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) v[t] = inc[3 * t + 2];
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) { ph += v[t]; v[t] = ph; }
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) L.s[2 * (TT + 1) + t + 1] = v[t];
-                } else
-                for (int t = 0; t < T; ++t) { ph += inc[3 * t + 2]; L.s[2 * (T + 1) + t + 1] = ph; }
+                for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+                return v;
+            };
+            {
+                const double ph0 = L.s[2 * (T + 1)];
+                const double v = prefix(lane < T ? inc[3 * lane + 2] : 0.0);
+                if (lane < T) L.s[2 * (T + 1) + lane + 1] = ph0 + v;
             }
             wsync();
-            for (int t = lane; t < T; t += 64) {        // x, y increments need the heading of their own stage
-                const double ph = L.s[2 * (T + 1) + t];
-                inc[3 * t] += L.Ak[9 * t + 2] * ph; inc[3 * t + 1] += L.Ak[9 * t + 5] * ph;
-            }
-            wsync();
-            if (lane == 0) {
-                double x = L.s[0], y = L.s[T + 1];
-                if constexpr (TT > 0) {
-                    double vx[TT], vy[TT];
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) { vx[t] = inc[3 * t]; vy[t] = inc[3 * t + 1]; }
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) { x += vx[t]; y += vy[t]; vx[t] = x; vy[t] = y; }
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) { L.s[t + 1] = vx[t]; L.s[(TT + 1) + t + 1] = vy[t]; }
-                } else
-                for (int t = 0; t < T; ++t) { x += inc[3 * t]; y += inc[3 * t + 1]; L.s[t + 1] = x; L.s[(T + 1) + t + 1] = y; }
+            {
+                const double x0 = L.s[0], y0 = L.s[T + 1];
+                double ix = 0, iy = 0;
+                if (lane < T) {                                  // x, y increments need the heading of their own stage
+                    const double ph = L.s[2 * (T + 1) + lane];
+                    ix = inc[3 * lane] + L.Ak[9 * lane + 2] * ph; iy = inc[3 * lane + 1] + L.Ak[9 * lane + 5] * ph;
+                }
+                const double px = prefix(ix), py = prefix(iy);
+                if (lane < T) { L.s[lane + 1] = x0 + px; L.s[(T + 1) + lane + 1] = y0 + py; }
             }
         }
     };
