@@ -868,8 +868,10 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
 __global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_rows_fast(Dev d, int it) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
-// (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower; the work list with two waves per SIMD is 4 % faster for fleets)
-__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_enum(Dev d, int it) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+// (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower.  Round 4, same-box A/B (tools/experiments/ab_so.sh): the common
+// path at TWO waves per SIMD - no scratch spills - is 9 % slower at N = 2000 and 20 % slower for the 64-ego C5 fleet than at three waves with its 53 spilled
+// registers, so it stays at three; the work list at ONE wave per SIMD (no spills; round 2-3: two waves, 91 spilled registers) is +1 % / +-0 %: kept)
+__global__ __launch_bounds__(64 * GS / 4, 1) void k_lammuz_enum(Dev d, int it) { lammuz_body_rows<2>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 
 // Block partials from the STORED terms - the same row_term, the same row order as mode 0 of the packed kernel forms them in flight - and
 // the tail of the step.  Runs behind every LamMuZ form that leaves its rows to more than one workgroup or launch (split launch, one
@@ -2487,7 +2489,7 @@ __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_rows(const Dev 
     lammuz_body_rows<0>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
 }
 __global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_fleet_rows_fast(const Dev *devs, int it) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
-__global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_enum(const Dev *devs, int it) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+__global__ __launch_bounds__(64 * GS / 4, 1) void k_lammuz_fleet_enum(const Dev *devs, int it) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 __global__ __launch_bounds__(256) void k_lmz_finalize_fleet(const Dev *devs, const EgoIO *io, int it, int k)
 {
     finalize_body(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
