@@ -281,6 +281,7 @@ int  rda_get_lmz_history(rda_handle *h, double *points, int32_t *valid);
 int  rda_set_lmz_history(rda_handle *h, const double *points, const int32_t *valid);
 /* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
+int  rda_debug_flush_supports(rda_handle *h);             /* forget every remembered LamMuZ support (a cache: results must not depend on it) */
 int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ work list of the last executed iteration (split launch form) */
 
 /* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns the obstacle slots

@@ -1530,6 +1530,15 @@ extern "C" int rda_debug_su_prof(rda_handle *H, long long *out16)
 }
 
 // debug: rows the common-path LamMuZ kernel of the LAST executed iteration put on the work list (split launch form only)
+// debug / test hook: forget every remembered support (both buffers -> "none").  The supports are a cache - every answer is accepted on its
+// optimality certificate alone - so a loop must return the same bits with or without them (tests/test_gpu_supports.py).
+extern "C" int rda_debug_flush_supports(rda_handle *H)
+{
+    if (!H) return RDA_ERR_ARG;
+    HIPCHK(hipMemsetAsync(H->d.hint, 0xff, 2 * (size_t)H->d.hint_len * sizeof(int), H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    return RDA_OK;
+}
 extern "C" int rda_debug_worklist(rda_handle *H, int *rows)
 {
     if (!H || !rows) return RDA_ERR_ARG;

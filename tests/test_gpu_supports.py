@@ -53,3 +53,35 @@ def test_supports_follow_the_horizon_with_a_fixed_binding():
 def test_supports_with_moving_obstacles_stay_mostly_valid():
     hist, rows = _first_launch_worklist(order=True, moving=True)
     assert np.median(hist[4:]) <= 0.10 * rows, hist
+
+
+@pytest.mark.parametrize("n_obs,order,moving", [(60, True, False), (40, False, True), (600, True, False)])
+def test_flushing_the_supports_cache_mid_loop_changes_no_bit(n_obs, order, moving):
+    """the remembered supports are NOT part of rda_get_state - results may not depend on them.  Two identical loops;
+    one forgets every remembered support (rda_debug_flush_supports) before every third step: controls, states, residuals, iteration
+    counts and the whole dual state must agree bit for bit (every LamMuZ answer is accepted on its optimality certificate alone, and
+    exact ties are broken by candidate id, not by what was tried first).  600 obstacles: the split launch form (common path + work list)."""
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd._lib import hip_api
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 25, 0], [44, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(40, 40), seed=sc.SEED + 3, keep_clear=clear, clear_radius=3.2, moving=moving)
+    kw = dict(sample_time=0.1, time_print=False, receding=20, iter_num=3, max_edge_num=4, max_obs_num=n_obs, ro1=200, obstacle_order=order)
+    a = MPC(car_t, [p.copy() for p in path], **kw)
+    b = MPC(car_t, [p.copy() for p in path], **kw)
+    lib = hip_api().lib
+    lib.rda_debug_flush_supports.argtypes = [C.c_void_p]
+    state = path[0].copy().reshape(3, 1)
+    for k in range(18):
+        cur = obstacles if not moving else [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) for o in obstacles]
+        if k % 3 == 2:
+            assert lib.rda_debug_flush_supports(b.rda._be.handle) == 0
+        ua, ia = a.control(state.copy(), 4.0, list(cur))
+        ub, ib = b.control(state.copy(), 4.0, list(cur))
+        assert ia["iters"] == ib["iters"] and ia["resi_dual"] == ib["resi_dual"] and ia["resi_pri"] == ib["resi_pri"], k
+        assert np.array_equal(ua, ub) and np.array_equal(a.cur_vel_array, b.cur_vel_array), (k, float(np.abs(ua - ub).max()))
+        state = sc.kinematic_step(state, ua, car_t, 0.1)
+    sa, sb = a.rda.get_state(), b.rda.get_state()
+    for key in ("lam", "mu", "z", "xi", "zeta"):
+        assert np.array_equal(sa[key], sb[key]), key
