@@ -575,13 +575,18 @@ template <int GW> __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, co
             const double tol = 1e-10 * (1.0 + fabs(phim * W.q[lane]) + P.ro2 * (fabs(W.M[lane][0] * best.H0) + fabs(W.M[lane][1] * best.H1)));
             // complementarity: a support entry that came out at its bound (0) is just an inactive-side constraint
             const bool pos = (lane == best.i1 && best.l1 > 0) || (lane == best.i2 && best.l2 > 0);
-            pass = pos ? fabs(gi) <= 1e3 * tol : gi >= -tol;
+            // STRICT complementarity for the rows outside the support (null rows of a padded obstacle aside): a row with a zero
+            // multiplier AND a zero gradient means the optimum is described by two supports, whose closed forms agree to rounding
+            // only - such a row goes to the enumeration, which ranks them by (cost, id), so that the answer does not depend on which
+            // support happened to be remembered (tests/test_gpu_supports.py: flushing the cache changes no bit)
+            const bool null_row = W.A[lane][0] == 0 && W.A[lane][1] == 0;
+            pass = pos ? fabs(gi) <= 1e3 * tol : (null_row ? gi >= -tol : gi > tol);
         } else if (lane < E + R) {
             const int j = lane - E;
             const double gj = -phim * Rb.h[j] + P.ro2 * (Rb.G[j][0] * best.H0 + Rb.G[j][1] * best.H1);
             const double tol = 1e-10 * (1.0 + fabs(phim * Rb.h[j]) + P.ro2 * (fabs(Rb.G[j][0] * best.H0) + fabs(Rb.G[j][1] * best.H1)));
             const bool pos = (j == best.j1 && best.g1 > 0) || (j == best.j2 && best.g2 > 0);
-            pass = pos ? fabs(gj) <= 1e3 * tol : gj >= -tol;
+            pass = pos ? fabs(gj) <= 1e3 * tol : gj > tol;
         }
         return Grp<GW>::ballot(!pass, wlane) == 0;
     };
