@@ -425,6 +425,15 @@ def main():
                      "mean_admm_iters": round(float(np.mean(its_f)), 3), "max_du_vs_python_closed_loop": du_f if not args.moving else None,
                      "second_window": cabi_closed_loop.second_window,
                      "what": "obstacle_order=False: slots bound once at staging, rda_step_tracked per step (the headline protocol of rounds 2-3; the reference's default re-sorts every tick)"}
+        follow = None
+        if rank == 0 and world == 1:
+            # NOT the reference's semantics (opt-in, rda_opts::duals_follow): the headline loop - scene re-sorted every tick - with the duals
+            # moving WITH their obstacles through the re-binding instead of staying with the slot (quirk Q5)
+            el_w, times_w, _, its_w = cabi_closed_loop(per_tick_scene=bool(args.moving), ordered=True, compare=False, duals_follow_obstacles=True)
+            follow = {"steps_per_s": round(K / el_w, 2), "median_ms_per_step": round(float(np.median(times_w) * 1e3), 5),
+                      "mean_admm_iters": round(float(np.mean(its_w)), 3), "second_window": cabi_closed_loop.second_window,
+                      "what": "the headline protocol (obstacle_order=True, re-sorted on the device every tick) with duals_follow_obstacles=True: "
+                              "an extension, NOT reference semantics - never `value`"}
         if rank == 0 and world == 1 and not args.size_leg:
             el_y, times_y, du_y, _ = cabi_closed_loop(per_tick_scene=bool(args.moving), driver="python", ordered=True)
             pydrv = {"steps_per_s": round(K / el_y, 2), "median_ms_per_step": round(float(np.median(times_y) * 1e3), 5),
@@ -805,6 +814,7 @@ def main():
         "mean_admm_iters": round(float(np.mean(head["iters"])) if head else mean_iters, 3),
         "second_window": head["second_window"] if head else None,
         "fixed_slot_binding": fixed if head else None,
+        "duals_follow_obstacles": follow if head else None,
         "pcie_inclusive": pcie if head else None,
         "python_caller_closed_loop": pydrv if head else None,
         "device_resident_replay": replay,
@@ -881,6 +891,7 @@ def main():
                 e = {k: j.get(k) for k in keep}
                 e["workload"] = j["config"]["workload"]
                 e["fixed_slot_binding_steps_per_s"] = (j.get("fixed_slot_binding") or {}).get("steps_per_s")
+                e["duals_follow_obstacles_steps_per_s"] = (j.get("duals_follow_obstacles") or {}).get("steps_per_s")
                 e["pcie_inclusive_steps_per_s"] = (j.get("pcie_inclusive") or {}).get("steps_per_s")
                 e["replay_steps_per_s"] = j["device_resident_replay"]["steps_per_s"]
                 if e.get("cpu_baseline"):

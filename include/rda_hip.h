@@ -112,6 +112,15 @@ typedef struct rda_opts {
     int32_t su_split;        /* [1] su Newton system of the horizons 10, 20, 25, 30 cut in two halves that two waves factorise and sweep at
                                 the same time, joined by a 5 x 5 interface system (same linear system, same answers up to rounding; 0: one
                                 recursion over the whole horizon)                                                          RDA_SU_SPLIT */
+    int32_t duals_follow;    /* [0] NOT reference semantics (opt-in).  The reference keeps lam, mu, z, xi, zeta per obstacle SLOT while its
+                                default caller re-sorts the obstacle list on every tick (mpc.py:205-206), so after a re-sort most slots
+                                continue from another obstacle's duals and the ADMM does not reach iter_threshold within iter_num (SURVEY
+                                quirk Q5).  1: when the device pipeline re-binds the slots (rda_upload_scene*, rda_scene_resort) the dual
+                                state moves WITH its obstacle - slot s takes the duals of the slot that held the same entry of the caller's
+                                raw scene at the previous staging, an obstacle that was in no slot starts from the initial duals (zeros).
+                                Obstacle i of the raw scene must denote the same obstacle from call to call.  The first su-problem of a
+                                tick reads the terms of the previous tick's slots (as always).  Needs slots staged by the device pipeline
+                                (rda_upload_obstacles / rda_step: RDA_ERR_UNSUPPORTED) and an unsharded handle.      RDA_DUALS_FOLLOW */
     double  su_warm[2];      /* [1e-3, 1e-3] slack floor / barrier parameter of a warm start ("0,0" = always cold)      RDA_SU_WARM */
     double  su_warm_endgame[2]; /* [0.9999, 1e-5] floors of the fraction to the boundary / centering parameter, warm attempts  RDA_SU_WARM_ENDGAME */
     double  su_warm_clip;    /* [0.01]                                                                                  RDA_SU_WARM_CLIP */
@@ -282,6 +291,7 @@ int  rda_set_lmz_history(rda_handle *h, const double *points, const int32_t *val
 /* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
 int  rda_debug_flush_supports(rda_handle *h);             /* forget every remembered LamMuZ support (a cache: results must not depend on it) */
+int  rda_debug_slot_src(rda_handle *h, int32_t *src /*N*/, int32_t *used); /* slot -> entry of the caller's raw scene (device pipeline; used = 0: host-staged slots) */
 int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ work list of the last executed iteration (split launch form) */
 
 /* Obstacle sharding across the GPUs of one node (one process per GPU).  Rank r owns the obstacle slots

@@ -1191,6 +1191,59 @@ __global__ __launch_bounds__(256) void k_lmz_finalize_all(Dev d)
     finalize_body(q, blockIdx.x, gridDim.x, -1, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0});
 }
 
+// ---- rda_opts::duals_follow: the dual state moves with its obstacle when the device pipeline re-binds the slots ----------------------
+// map[s] = the slot that held, at the previous staging, the raw-scene entry slot s holds now (-1: it was in no slot -> initial duals).
+// Padding slots (s >= used: copies of the last obstacle, quirk Q3) keep their own state for as long as they stay padding slots.
+__global__ __launch_bounds__(256) void k_follow_map(int N, const int *now, int used, const int *prev, int prev_used, int *map)
+{
+    __shared__ int tile[256];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int want = (s < N && s < used) ? now[s] : -1;
+    int m = -1;
+    for (int base = 0; base < prev_used; base += 256) {
+        __syncthreads();
+        if (base + (int)threadIdx.x < prev_used) tile[threadIdx.x] = prev[base + threadIdx.x];
+        __syncthreads();
+        const int cnt = prev_used - base < 256 ? prev_used - base : 256;
+        if (want >= 0) for (int k = 0; k < cnt; ++k) if (tile[k] == want) m = base + k;
+    }
+    if (s < N) map[s] = s < used ? m : (s >= prev_used ? s : -1);
+}
+// rows (stage, slot) of lam | mu | xi (T+1 stages) and z | zeta (T stages), gathered through the map into `tmp` (same layouts, one after
+// the other), then written back: two launches, the state never aliases itself
+__global__ __launch_bounds__(256) void k_follow_gather(Dev d, const int *map, double *tmp)
+{
+    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    const size_t rows = (size_t)(T + 1) * N;
+    double *tl = tmp, *tm = tl + rows * E, *tx = tm + rows * R, *tz = tx + rows * 2, *tzt = tz + (size_t)T * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / N), sl = (int)(i % N), m = map[sl];
+        const size_t o = (size_t)t * N + (m >= 0 ? m : 0);
+        for (int e = 0; e < E; ++e) tl[i * E + e] = m >= 0 ? d.lam[o * E + e] : 0.0;
+        for (int j = 0; j < R; ++j) tm[i * R + j] = m >= 0 ? d.mu[o * R + j] : 0.0;
+        tx[2 * i] = m >= 0 ? d.xi[2 * o] : 0.0; tx[2 * i + 1] = m >= 0 ? d.xi[2 * o + 1] : 0.0;
+        if (t < T) { tz[i] = m >= 0 ? d.z[o] : 0.0; tzt[i] = m >= 0 ? d.zeta[o] : 0.0; }
+    }
+}
+__global__ __launch_bounds__(256) void k_follow_back(Dev d, const int *map, const double *tmp, const int *now, int *prev)
+{
+    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    const size_t rows = (size_t)(T + 1) * N;
+    const double *tl = tmp, *tm = tl + rows * E, *tx = tm + rows * R, *tz = tx + rows * 2, *tzt = tz + (size_t)T * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / N), sl = (int)(i % N);
+        if (map[sl] == sl) continue;                              // the slot kept its obstacle
+        for (int e = 0; e < E; ++e) d.lam[i * E + e] = tl[i * E + e];
+        for (int j = 0; j < R; ++j) d.mu[i * R + j] = tm[i * R + j];
+        d.xi[2 * i] = tx[2 * i]; d.xi[2 * i + 1] = tx[2 * i + 1];
+        if (t < T) {
+            d.z[i] = tz[i]; d.zeta[i] = tzt[i];
+            if (d.ipf) d.ipf[i] = 0;                              // interior-point mode: the kept central point belonged to another obstacle (cold start)
+        }
+    }
+}
+__global__ void k_follow_keep(int n, const int *now, int *prev) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) prev[i] = now[i]; }
+
 // ------------------------------------------------------------------------------------------------
 struct rda_handle {
     Dev d;
@@ -1230,6 +1283,8 @@ struct rda_handle {
     int ip_rows;             // interior-point mode runs the row-parallel kernel (shape allows it and rda_opts::lmz_ip_rows)
     int admm_it;             // host-driven ADMM pieces (rda_admm_*): the iteration rda_admm_su was last called with
     int stepped;             // a step has been queued on this handle (sharded handles: rda_reset / rda_set_state are refused from then on)
+    // rda_opts::duals_follow: slot -> raw-scene entry of the staging the dual state is arranged by (prev_used = -1: none yet)
+    int follow; int *d_prev_sel, *d_follow_map; double *d_follow_tmp; int prev_used;
 };
 
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
@@ -1267,7 +1322,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
-    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1;
+    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1289,6 +1344,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     geti("RDA_ZERO_COPY", &o->zero_copy); geti("RDA_EARLY_FINISH", &o->early_finish); geti("RDA_FUSE_TRACK", &o->fuse_track);
     { const char *e = getenv("RDA_SU_PROF"); if (e && *e) o->su_prof = 1; }
     { const char *e = getenv("RDA_SU_SPLIT"); if (e && *e) o->su_split = atoi(e) != 0; }
+    { const char *e = getenv("RDA_DUALS_FOLLOW"); if (e && *e) o->duals_follow = atoi(e) != 0; }
     if (o->su_cold_probe < 1) o->su_cold_probe = 1;
 }
 
@@ -1355,6 +1411,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_pre = o.su_pre; H->d.lmz_tail = o.lmz_tail;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light; H->d.su_split = o.su_split;
+    H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = H->ev_used[2] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
@@ -1376,6 +1433,10 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     rc |= dalloc(&d.s, 3 * (T + 1)); rc |= dalloc(&d.u, 2 * T); rc |= dalloc(&d.pose, 4 * T);
     rc |= dalloc(&d.ctrl, 1);
     rc |= dalloc(&d.su_lam_keep, 10 * T);
+    if (H->follow) {
+        rc |= dalloc(&H->d_prev_sel, N); rc |= dalloc(&H->d_follow_map, N);
+        rc |= dalloc(&H->d_follow_tmp, N * (T + 1) * (E + R + 2) + 2 * N * T);
+    }
     if (o.su_prof) rc |= dalloc(&d.su_prof, 16);
     const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
     rc |= dalloc(&H->d_step, step_n);
@@ -1425,7 +1486,7 @@ extern "C" void rda_destroy(rda_handle *H)
     void *ptrs[] = { d.wl, d.hint, d.oc_lamc, d.oc_vtx, d.oc_cnt, d.G, d.h, d.A, d.b, d.cone, d.lam, d.mu, d.z, d.xi, d.zeta, d.dis, d.coef, d.coefL,
                      d.s, d.u, d.pose, d.su_prof, d.ipw, d.ipf, d.ctrl, d.su_lam_keep, H->d_step, H->d_out_u,
                      H->d_tr_s, H->d_tr_u, H->d_tr_ref, H->d_tr_speed, H->d_tr_out_u, H->d_tr_out_s, H->d_tr_info,
-                     H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path };
+                     H->d_sc_sel, H->d_sc_blk, H->d_sc_key, H->d_path, H->d_prev_sel, H->d_follow_map, H->d_follow_tmp };
     for (void *p : ptrs) dev_free(p);
     if (H->h_stage_A) (void)hipHostFree(H->h_stage_A);
     if (H->h_stage_b) (void)hipHostFree(H->h_stage_b);
@@ -1539,6 +1600,15 @@ extern "C" int rda_debug_flush_supports(rda_handle *H)
     HIPCHK(hipStreamSynchronize(H->stream));
     return RDA_OK;
 }
+extern "C" int rda_debug_slot_src(rda_handle *H, int32_t *src, int32_t *used)
+{
+    if (!H || !src || !used) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    if (H->scene_on_s2) HIPCHK(hipStreamSynchronize(H->stream2));
+    *used = H->d.slot_src ? H->d.src_used : 0;
+    if (*used > 0) HIPCHK(hipMemcpy(src, H->d.slot_src, (size_t)*used * sizeof(int), hipMemcpyDeviceToHost));
+    return RDA_OK;
+}
 extern "C" int rda_debug_worklist(rda_handle *H, int *rows)
 {
     if (!H || !rows) return RDA_ERR_ARG;
@@ -1555,6 +1625,7 @@ static int obstacles_stage(rda_handle *H, int n_obs, const double *A, const doub
     const size_t T = d.c.T, N = d.c.N, E = d.c.E;
     if (n_obs <= 0) { d.obstacle_num = 0; return RDA_OK; }       // nothing written: stale A, b stay
     if (!A || !b || !cone) return RDA_ERR_ARG;
+    if (H->follow) return RDA_ERR_UNSUPPORTED;                   // duals_follow: host-staged slots carry no obstacle identity
     d.sc_bad = nullptr;
     const size_t nt = per_t ? T + 1 : 1;
     for (size_t n = 0; n < N; ++n) {
@@ -1620,6 +1691,20 @@ static void scene_kernels(rda_handle *H, const scene::Args &a, hipStream_t st)
     hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
     d.nt = a.nt; d.obstacle_num = N;
     d.slot_src = H->d_sc_sel; d.src_used = n < N ? n : N;          // the remembered supports follow the obstacles through the re-binding (Dev::hint)
+    if (H->follow) {
+        // rda_opts::duals_follow: the dual state is re-arranged from the previous binding to this one.  Nothing of a tick's head reads
+        // lam, mu, xi, z, zeta (the su-problem reads the condensed terms, which the first LamMuZ launch of the tick rewrites for every
+        // slot): inside a tick this runs on the second stream beside the first su-problem like the rest of the staging.
+        const int used = d.src_used, nb = (N + 255) / 256;
+        if (H->prev_used >= 0) {
+            const unsigned gb = (unsigned)(((size_t)(d.c.T + 1) * N + 255) / 256);
+            hipLaunchKernelGGL(k_follow_map, dim3(nb), dim3(256), 0, st, N, (const int *)H->d_sc_sel, used, (const int *)H->d_prev_sel, H->prev_used, H->d_follow_map);
+            hipLaunchKernelGGL(k_follow_gather, dim3(gb), dim3(256), 0, st, d, (const int *)H->d_follow_map, H->d_follow_tmp);
+            hipLaunchKernelGGL(k_follow_back, dim3(gb), dim3(256), 0, st, d, (const int *)H->d_follow_map, (const double *)H->d_follow_tmp, (const int *)H->d_sc_sel, H->d_prev_sel);
+        }
+        hipLaunchKernelGGL(k_follow_keep, dim3(nb), dim3(256), 0, st, used, (const int *)H->d_sc_sel, H->d_prev_sel);
+        H->prev_used = used;
+    }
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);
 }
 
@@ -2332,6 +2417,7 @@ extern "C" int rda_shard_config(rda_handle *H, int rank, int world)
 {
     if (!H || world < 1 || rank < 0 || rank >= world) return RDA_ERR_ARG;
     if (H->d.c.N % world != 0 && !H->d.c.accelerated) return RDA_ERR_UNSUPPORTED;    // padded shards rely on the hinge of the accelerated cost
+    if (world > 1 && H->follow) return RDA_ERR_UNSUPPORTED;                          // duals_follow moves rows between slots = between ranks
     HIPCHK(hipStreamSynchronize(H->stream));
     Dev &d = H->d;
     dev_free(d.coef); d.coef = nullptr; dev_free(d.coefL); d.coefL = nullptr;

@@ -142,6 +142,14 @@ class RDA_solver:
             # (a copy: the caller's struct may configure a second solver that is not in interior-point mode)
             opts = Opts.from_buffer_copy(opts) if opts is not None else hip_options()
             opts.lmz_mode, opts.lmz_mu = 1, float(self.lmz_central)
+        # duals_follow_obstacles=True (NOT reference semantics, opt-in; rda_opts::duals_follow): when the device pipeline re-binds the obstacle
+        # slots - a caller that re-sorts its list every tick, obstacle_order=True, the reference's default - the duals move with their
+        # obstacles instead of staying with the slot (quirk Q5: the ADMM then never converges within iter_num).  Entry i of the obstacle
+        # list must denote the same obstacle from tick to tick; needs the device-side obstacle pipeline (MPC: device_obstacles=True).
+        self.duals_follow_obstacles = bool(kwargs.get("duals_follow_obstacles", False))
+        if self.duals_follow_obstacles and make is _hip_backend:
+            opts = Opts.from_buffer_copy(opts) if opts is not None else hip_options()
+            opts.duals_follow = 1
         self._be = make(cfg, G, h, opts) if (make is _hip_backend and opts is not None) else make(cfg, G, h)   # test backends select the mode themselves
         self._R = G.shape[0]
         self.pipeline = True        # MPC overlaps its per-tick obstacle staging with the first su-problem (set False to serialise)

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--order", action="store_true", help="re-sort the obstacles by distance every tick (MPC default; the headline loop of bench.py keeps the slot binding fixed)")
     ap.add_argument("--fine", action="store_true", help="the library was built with -DSU_FINE (make -C rda_planner_amd/csrc CXXFLAGS+=-DSU_FINE): the set-up slots carry sub-phases of the iteration, the whole set-up is booked under slot 10")
     ap.add_argument("--iter-num", type=int, default=0, help="ADMM iterations per step (1: only the FIRST su-solve of every tick - the one inside k_su_tracked - is profiled)")
+    ap.add_argument("--lmz-central", type=float, default=0.0, help="interior-point LamMuZ mode (central duals at this mu)")
+    ap.add_argument("--circle", action="store_true", help="circle robot (norm2 cone: the interior-point LamMuZ kernel)")
+    ap.add_argument("--per-step", action="store_true", help="print (ADMM iterations, su interior-point iterations) of every step")
     args = ap.parse_args()
     import bench
     from rda_planner_amd.mpc import MPC
@@ -34,6 +37,10 @@ def main():
     kw["obstacle_order"] = bool(args.order)
     if args.iter_num:
         kw["iter_num"] = args.iter_num
+    if args.lmz_central > 0:
+        kw["lmz_central"] = args.lmz_central
+    if args.circle:
+        car_t = sc.circle_robot(radius=0.8, dynamics="diff")
     mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, hip_opts=hip_options(su_prof=1), **kw)
     lib = hip_api().lib
     state = path[0].copy().reshape(3, 1)
@@ -47,6 +54,8 @@ def main():
             lib.rda_debug_su_prof(mpc.rda._be.handle, out)
         elif k > 9:
             solves += info["iters"]; ipm += info["su_ipm_iters"]
+        if args.per_step:
+            print(k, info["iters"], info["su_ipm_iters"], info["status"])
     assert lib.rda_debug_su_prof(mpc.rda._be.handle, out) == 0
     if args.fine:
         NAMES.update({14: "(2) stage derivatives + inequality rows", 12: "(3a) stage gradients", 2: "(3b) Hessian bases", 9: "(6a) corrector rc + gh", 6: "(6b) sweep constants",
