@@ -80,6 +80,12 @@ typedef struct rda_opts {
     double  lmz_mu;          /* 1e-6                                                                                      RDA_LMZ_MU */
     double  su_tol[3];       /* interior-point stop of the su-problem: |r_dual|_inf <= [0] (1+|grad|_inf), |r_prim|_inf <= [1], mean
                                 complementarity <= [2] (1+|grad|_inf); 1e-9, 1e-10, 1e-11                                  RDA_SU_TOL */
+    double  su_tol_early[3]; /* [0, 0, 0 = off] opt-in: the su-problems of the ADMM iterations BEFORE the last one of a step (it < iter_num - 1)
+                                stop at these instead of su_tol.  The reference's own solver stops at ECOS defaults (1e-8 class) in EVERY
+                                iteration; su_tol is 1000 x tighter because the parity tolerance is stated against it.  "1e-6,1e-7,1e-8":
+                                two interior-point iterations fewer per su-problem.  A step that stops early returns the control of an
+                                su-problem solved to THIS tolerance (some 1e-3 from the exact one where an inequality is weakly active,
+                                tests/test_oracle_su.py), so the stated tolerance TOL_U does not hold with it.            RDA_SU_TOL_EARLY */
     /* ---- A/B switches (defaults in brackets) ---- */
     int32_t lmz_warm;        /* [1] try the remembered support first, then the supports one row away from it, before a row is
                                 enumerated; every answer is accepted on its optimality certificate alone.  The supports are a cache of

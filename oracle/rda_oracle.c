@@ -46,6 +46,9 @@ static double cur_warm_tau = 0.9999, cur_warm_sig = 1e-5, cur_warm_clip = 0.01; 
 void orc_set_su_easy(double wfl, double mu0, double clip, double tau, double sig, int max) { g_su_easy[0] = wfl; g_su_easy[1] = mu0; g_su_easy[2] = clip; g_su_easy[3] = tau; g_su_easy[4] = sig; g_su_easy_max = max; }
 static double g_su_tol[3] = {1e-9, 1e-10, 1e-11};   /* interior-point stop of the su-problem: rd, rp, mu */
 void orc_set_su_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_tol[0] = rd; g_su_tol[1] = rp; g_su_tol[2] = mu; } }
+/* mirror of rda_opts::su_tol_early: the su-problems of the ADMM iterations BEFORE the last one of a step stop at these (0: same as su_tol) */
+static double g_su_tol_early[3] = {0, 0, 0};
+void orc_set_su_tol_early(double rd, double rp, double mu) { g_su_tol_early[0] = rd; g_su_tol_early[1] = rp; g_su_tol_early[2] = mu; }
 static int g_lmz_mode = 0;   /* 0: support enumeration + tie-breaks T1-T3, 1: interior point (oracle/lmz_ipm.c) */
 void orc_set_lmz_mode(int mode) { g_lmz_mode = mode ? 1 : 0; }
 static int g_centre = 1;     /* tie-break T1: central separating normal in the slack regime (orc_set_centre(0): max clearance) */
@@ -1057,8 +1060,11 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
      * active bounds and takes near-full steps - the same rule as csrc/rda_hip.hip su_body */
     const int easy = warm && g_su_easy_max > 0 && H->su_last <= g_su_easy_max;
     cur_warm_clip = easy ? g_su_easy[2] : g_su_warm_clip; cur_warm_tau = easy ? g_su_easy[3] : g_su_warm_tau; cur_warm_sig = easy ? g_su_easy[4] : g_su_warm_sig;
+    double tol_keep[3] = { g_su_tol[0], g_su_tol[1], g_su_tol[2] };
+    if (it < c->iter_num - 1 && g_su_tol_early[0] > 0 && g_su_tol_early[1] > 0 && g_su_tol_early[2] > 0) memcpy(g_su_tol, g_su_tol_early, sizeof g_su_tol);
     int st = su_solve_impl(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm,
                            H->su_lam_keep, warm, easy ? g_su_easy[0] : g_su_warm_wfl, easy ? g_su_easy[1] : g_su_warm_mu0, g_su_warm_cap, it == 0);
+    memcpy(g_su_tol, tol_keep, sizeof g_su_tol);
     H->su_last = st == 0 ? ipm : 99;
     H->ipm_total += ipm;
     if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }

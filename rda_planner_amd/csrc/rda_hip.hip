@@ -73,6 +73,7 @@ struct Dev {
     int su_warm_first;                 // the first su-problem of a step starts from the previous step's multipliers, shifted by one stage
     int su_warm_cap;                   // iterations granted to the warm start before the cold one takes over
     double su_tol[3];                  // interior-point stop of the su-problem (rda_opts::su_tol)
+    double su_tol_early[3];            // ... of the ADMM iterations before the last one of a step (rda_opts::su_tol_early; 0 = su_tol)
     int su_light;                        // su_device Cfg::light_check
     int su_split;                        // su_device Args::split (time split of the Newton system)
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
@@ -251,6 +252,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     a.c.ab0 = d.c.acce_bound[0]; a.c.ab1 = d.c.acce_bound[1]; a.c.ws = d.c.ws; a.c.wu = d.c.wu;
     a.c.slack_gain = d.c.slack_gain; a.c.max_sd = d.c.max_sd; a.c.min_sd = d.c.min_sd; a.c.ro1 = d.c.ro1; a.c.ro2 = d.c.ro2;
     a.c.eps_u = d.c.eps_u; a.c.tol_rd = d.su_tol[0]; a.c.tol_rp = d.su_tol[1]; a.c.tol_mu = d.su_tol[2]; a.c.light_check = d.su_light;
+    if (it < d.c.iter_num - 1 && d.su_tol_early[0] > 0) { a.c.tol_rd = d.su_tol_early[0]; a.c.tol_rp = d.su_tol_early[1]; a.c.tol_mu = d.su_tol_early[2]; }
     a.in_s = it == 0 ? in_s : d.s; a.in_u = it == 0 ? in_u : d.u;
     a.ref = ref; a.ref_speed = ref_speed; a.ref_flag = ref_flag; a.ref_seq = ref_seq;
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.cb = coef_arr(d, 0, 8); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
@@ -1319,7 +1321,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
-    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11;
+    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0;
@@ -1332,6 +1334,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     auto getd = [](const char *name, double *v) { const char *e = getenv(name); if (e && *e) *v = atof(e); };
     geti("RDA_LMZ_MODE", &o->lmz_mode); geti("RDA_TIE_CENTRE", &o->tie_centre); getd("RDA_LMZ_MU", &o->lmz_mu);
     { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol[0], &o->su_tol[1], &o->su_tol[2]); }
+    { const char *e = getenv("RDA_SU_TOL_EARLY"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol_early[0], &o->su_tol_early[1], &o->su_tol_early[2]); }
     geti("RDA_LMZ_WARM", &o->lmz_warm); geti("RDA_LMZ_ROWS", &o->lmz_rows); geti("RDA_LMZ_DENSE_FROM", &o->lmz_dense_from);
     geti("RDA_LMZ_SPLIT", &o->lmz_split); geti("RDA_LMZ_TAIL", &o->lmz_tail); geti("RDA_LMZ_IP_ROWS", &o->lmz_ip_rows); geti("RDA_LMZ_IP_WARM", &o->lmz_ip_warm);
     geti("RDA_SU_PRE", &o->su_pre); geti("RDA_SU_LIGHT", &o->su_light);
@@ -1413,6 +1416,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_light = o.su_light; H->d.su_split = o.su_split;
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
+    { const bool on = o.su_tol_early[0] > 0 && o.su_tol_early[1] > 0 && o.su_tol_early[2] > 0; for (int i = 0; i < 3; ++i) H->d.su_tol_early[i] = on ? o.su_tol_early[i] : 0.0; }
     H->nccl_lib = nullptr; H->comm = nullptr; H->p_allgather = nullptr; H->p_comm_destroy = nullptr; H->ev_used[0] = H->ev_used[1] = H->ev_used[2] = 0;
     H->d_tr_s = H->d_tr_u = H->d_tr_ref = H->d_tr_speed = H->d_tr_out_u = H->d_tr_out_s = nullptr; H->d_tr_info = nullptr;
     const size_t T = cfg->T, N = cfg->N, E = cfg->E, R = cfg->R;

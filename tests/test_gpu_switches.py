@@ -94,3 +94,52 @@ def test_time_split_of_the_su_newton_system_changes_nothing_but_rounding(T, dyn,
         st = sc.kinematic_step(st, ua, car_t, 0.1)
     print(f"T={T} {dyn}: max |u_split - u_unsplit| over the horizon {worst:.2e}")
     assert worst <= 1e-5
+
+
+def test_su_tol_early_saves_interior_point_iterations_and_stays_near_the_default_and_the_oracle():
+    """rda_opts::su_tol_early (opt-in): the su-problems of the ADMM iterations before the last one of a step stop at ECOS-class tolerances
+    (1e-6, 1e-7, 1e-8) - what the reference's own solver delivers in every iteration.  Re-sorted scene (the reference's default caller: most
+    steps run all iter_num iterations and their LAST su-problem - the one whose control is returned - is solved to su_tol; a step that
+    stops early returns a control of the looser class).  Per step from the same state: fewer interior-point iterations, the control within 5e-3 of the default's (an su-problem stopped at 1e-8 class lies up
+    to 2.6e-3 from its exact solution where an inequality is weakly active: tests/test_oracle_su.py) and of the oracle with the same
+    switch (orc_set_su_tol_early) - NOT within TOL_U: the stated tolerance belongs to the default."""
+    import ctypes as C
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd.rda_solver import hip_options
+    from oracle.oracle_backend import oracle_backend, api as orc_api
+    early = (1e-6, 1e-7, 1e-8)
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 25, 0], [44, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    scene = sc.scene_polygons(60, lo=(8, 12), hi=(44, 38), seed=sc.SEED + 11, keep_clear=clear, clear_radius=3.2)
+    kw = dict(receding=20, iter_num=4, max_edge_num=4, max_obs_num=60, time_print=False, ro1=200, obstacle_order=True)
+    dflt = MPC(car_t, [p.copy() for p in path], **kw)
+    fast = MPC(car_t, [p.copy() for p in path], hip_opts=hip_options(su_tol_early=early), **kw)
+    cpu = MPC(car_t, [p.copy() for p in path], _backend=oracle_backend, **kw)
+    lib = orc_api().lib
+    lib.orc_set_su_tol_early.argtypes = [C.c_double] * 3
+    lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
+    lib.orc_set_su_tol_early(*early); lib.orc_set_su_warm(0.0, 0.0, 0)
+    try:
+        st = path[0].copy().reshape(3, 1)
+        ipm_d = ipm_f = flips = 0
+        w_dflt = w_orc = 0.0
+        for k in range(30):
+            ud, idf = dflt.control(st.copy(), 4.0, list(scene))
+            uf, iff = fast.control(st.copy(), 4.0, list(scene))
+            uc, ic = cpu.control(st.copy(), 4.0, list(scene))
+            assert idf["status"] == iff["status"] == ic["status"] == 0
+            ipm_d += idf["su_ipm_iters"]; ipm_f += iff["su_ipm_iters"]
+            if idf["iters"] == iff["iters"] == ic["iters"]:
+                w_dflt = max(w_dflt, float(np.abs(ud - uf).max())); w_orc = max(w_orc, float(np.abs(uc - uf).max()))
+            else:
+                flips += 1
+            for other in (fast, cpu):
+                other.rda.set_state(dflt.rda.get_state())
+                other.cur_vel_array = dflt.cur_vel_array.copy(); other.cur_index = dflt.cur_index
+            st = sc.kinematic_step(st, ud, car_t, 0.1)
+        print(f"interior-point iterations per step {ipm_d / 30:.1f} -> {ipm_f / 30:.1f}; |u_fast - u_default| {w_dflt:.2e}, |u_fast - u_oracle(same switch)| {w_orc:.2e}")
+        assert ipm_f <= 0.85 * ipm_d and flips <= 2, (ipm_d, ipm_f, flips)
+        assert w_dflt <= 5e-3 and w_orc <= 5e-3, (w_dflt, w_orc)
+    finally:
+        lib.orc_set_su_tol_early(0.0, 0.0, 0.0); lib.orc_set_su_warm(1e-3, 1e-3, 30)
