@@ -126,7 +126,9 @@ typedef struct rda_opts {
                                 raw scene at the previous staging, an obstacle that was in no slot starts from the initial duals (zeros).
                                 Obstacle i of the raw scene must denote the same obstacle from call to call.  The first su-problem of a
                                 tick reads the terms of the previous tick's slots (as always).  Needs slots staged by the device pipeline
-                                (rda_upload_obstacles / rda_step: RDA_ERR_UNSUPPORTED) and an unsharded handle.      RDA_DUALS_FOLLOW */
+                                (rda_upload_obstacles / rda_step: RDA_ERR_UNSUPPORTED) and an unsharded handle.  rda_get_state /
+                                rda_set_state speak the CURRENT slot order (rda_debug_slot_src tells which obstacle a slot holds); the
+                                kept central points of the interior-point LamMuZ mode are dropped for a re-bound slot.  RDA_DUALS_FOLLOW */
     double  su_warm[2];      /* [1e-3, 1e-3] slack floor / barrier parameter of a warm start ("0,0" = always cold)      RDA_SU_WARM */
     double  su_warm_endgame[2]; /* [0.9999, 1e-5] floors of the fraction to the boundary / centering parameter, warm attempts  RDA_SU_WARM_ENDGAME */
     double  su_warm_clip;    /* [0.01]                                                                                  RDA_SU_WARM_CLIP */

@@ -159,3 +159,23 @@ def test_host_staged_slots_and_shards_are_refused():
     rc = hip_api().shard_config(rda._be.handle, 0, 2)
     assert rc != 0 and b"unsupported" in lib.rda_strerror(rc).lower()
     assert hip_api().shard_config(rda._be.handle, 0, 1) == 0
+
+
+def test_follow_in_the_interior_point_lammuz_mode():
+    """lmz_central: the kept central-path points of a re-bound slot are dropped (cold start of that row), the duals follow.  The
+    interior-point LamMuZ answers are tolerance-level objects (tests/test_gpu_central.py: 1e-4), so is this comparison."""
+    from rda_planner_amd.mpc import MPC
+    car_t, path, obstacles = _scene(40)
+    kw = dict(sample_time=0.1, time_print=False, receding=15, iter_num=3, max_edge_num=4, max_obs_num=40, ro1=200, lmz_central=1e-3)
+    fixed = MPC(car_t, [p.copy() for p in path], obstacle_order=False, **kw)
+    follow = MPC(car_t, [p.copy() for p in path], obstacle_order=True, duals_follow_obstacles=True, **kw)
+    state = path[0].copy().reshape(3, 1)
+    worst = 0.0
+    for k in range(25):
+        ua, ia = fixed.control(state.copy(), 4.0, list(obstacles))
+        ub, ib = follow.control(state.copy(), 4.0, list(obstacles))
+        assert ia["status"] == 0 and ib["status"] == 0 and ib["lmz_fail"] == 0
+        if ia["iters"] == ib["iters"]:
+            worst = max(worst, float(np.abs(ua - ub).max()))
+        state = sc.kinematic_step(state, ua, car_t, 0.1)
+    assert worst <= 5e-3, worst

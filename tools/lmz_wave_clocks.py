@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SO = os.path.join(ROOT, "tools", "librda_hip_clk.so")
+SO = os.environ.get("RDA_LMZ_CLK_SO") or os.path.join(ROOT, "tools", "librda_hip_clk.so")      # (RDA_LMZ_CLK_SO: another -DRDA_LMZ_CLK build, A/B)
 NAMES = ["stop flag", "robot data, half-spaces -> LDS, barrier", "pose, duals, pose products, support cache", "warm candidate + certificate",
          "shared enumeration of failing rows (2 barriers)", "central normal (T1)", "dual / residual updates, row record", "block partial"]
 
