@@ -1194,47 +1194,43 @@ __global__ __launch_bounds__(256) void k_lmz_finalize_all(Dev d)
 }
 
 // ---- rda_opts::duals_follow: the dual state moves with its obstacle when the device pipeline re-binds the slots ----------------------
-// map[s] = the slot that held, at the previous staging, the raw-scene entry slot s holds now (-1: it was in no slot -> initial duals).
-// Padding slots (s >= used: copies of the last obstacle, quirk Q3) keep their own state for as long as they stay padding slots.
-__global__ __launch_bounds__(256) void k_follow_map(int N, const int *now, int used, const int *prev, int prev_used, int *map)
+// One workgroup per slot s.  map[s] = the slot that held, at the previous staging, the raw-scene entry slot s holds now (-1: it was in
+// no slot -> initial duals, zeros).  Padding slots (s >= used: copies of the last obstacle, quirk Q3) keep their own state for as long
+// as they stay padding slots.  The rows (stage, slot) of lam | mu | xi (T+1 stages) and z | zeta (T stages) of a slot that changes hands
+// are gathered through the map into `tmp` (same layouts, one after the other) and written back by a second launch: the state never
+// aliases itself.
+__global__ __launch_bounds__(64) void k_follow_gather(Dev d, const int *now, int used, const int *prev, int prev_used, int *map, double *tmp)
 {
-    __shared__ int tile[256];
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    const int want = (s < N && s < used) ? now[s] : -1;
+    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R, sl = blockIdx.x, lane = threadIdx.x;
     int m = -1;
-    for (int base = 0; base < prev_used; base += 256) {
-        __syncthreads();
-        if (base + (int)threadIdx.x < prev_used) tile[threadIdx.x] = prev[base + threadIdx.x];
-        __syncthreads();
-        const int cnt = prev_used - base < 256 ? prev_used - base : 256;
-        if (want >= 0) for (int k = 0; k < cnt; ++k) if (tile[k] == want) m = base + k;
-    }
-    if (s < N) map[s] = s < used ? m : (s >= prev_used ? s : -1);
-}
-// rows (stage, slot) of lam | mu | xi (T+1 stages) and z | zeta (T stages), gathered through the map into `tmp` (same layouts, one after
-// the other), then written back: two launches, the state never aliases itself
-__global__ __launch_bounds__(256) void k_follow_gather(Dev d, const int *map, double *tmp)
-{
-    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    if (sl < used) {
+        const int want = now[sl];
+        for (int j = lane; j < prev_used; j += 64) if (prev[j] == want) m = j;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    } else m = sl >= prev_used ? sl : -1;
+    if (lane == 0) map[sl] = m;
+    if (m == sl) return;                                      // the slot kept its obstacle
     const size_t rows = (size_t)(T + 1) * N;
     double *tl = tmp, *tm = tl + rows * E, *tx = tm + rows * R, *tz = tx + rows * 2, *tzt = tz + (size_t)T * N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i / N), sl = (int)(i % N), m = map[sl];
-        const size_t o = (size_t)t * N + (m >= 0 ? m : 0);
+    for (int t = lane; t <= T; t += 64) {
+        const size_t i = (size_t)t * N + sl, o = (size_t)t * N + (m >= 0 ? m : 0);
         for (int e = 0; e < E; ++e) tl[i * E + e] = m >= 0 ? d.lam[o * E + e] : 0.0;
         for (int j = 0; j < R; ++j) tm[i * R + j] = m >= 0 ? d.mu[o * R + j] : 0.0;
         tx[2 * i] = m >= 0 ? d.xi[2 * o] : 0.0; tx[2 * i + 1] = m >= 0 ? d.xi[2 * o + 1] : 0.0;
         if (t < T) { tz[i] = m >= 0 ? d.z[o] : 0.0; tzt[i] = m >= 0 ? d.zeta[o] : 0.0; }
     }
 }
-__global__ __launch_bounds__(256) void k_follow_back(Dev d, const int *map, const double *tmp, const int *now, int *prev)
+// map == nullptr: the first staging of a handle, only the binding is recorded
+__global__ __launch_bounds__(64) void k_follow_back(Dev d, const int *map, const double *tmp, const int *now, int used, int *prev)
 {
-    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R;
+    const int T = d.c.T, N = d.c.N, E = d.c.E, R = d.c.R, sl = blockIdx.x, lane = threadIdx.x;
+    if (lane == 0 && sl < used) prev[sl] = now[sl];
+    if (!map || map[sl] == sl) return;
     const size_t rows = (size_t)(T + 1) * N;
     const double *tl = tmp, *tm = tl + rows * E, *tx = tm + rows * R, *tz = tx + rows * 2, *tzt = tz + (size_t)T * N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i / N), sl = (int)(i % N);
-        if (map[sl] == sl) continue;                              // the slot kept its obstacle
+    for (int t = lane; t <= T; t += 64) {
+        const size_t i = (size_t)t * N + sl;
         for (int e = 0; e < E; ++e) d.lam[i * E + e] = tl[i * E + e];
         for (int j = 0; j < R; ++j) d.mu[i * R + j] = tm[i * R + j];
         d.xi[2 * i] = tx[2 * i]; d.xi[2 * i + 1] = tx[2 * i + 1];
@@ -1244,7 +1240,6 @@ __global__ __launch_bounds__(256) void k_follow_back(Dev d, const int *map, cons
         }
     }
 }
-__global__ void k_follow_keep(int n, const int *now, int *prev) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) prev[i] = now[i]; }
 
 // ------------------------------------------------------------------------------------------------
 struct rda_handle {
@@ -1699,14 +1694,11 @@ static void scene_kernels(rda_handle *H, const scene::Args &a, hipStream_t st)
         // rda_opts::duals_follow: the dual state is re-arranged from the previous binding to this one.  Nothing of a tick's head reads
         // lam, mu, xi, z, zeta (the su-problem reads the condensed terms, which the first LamMuZ launch of the tick rewrites for every
         // slot): inside a tick this runs on the second stream beside the first su-problem like the rest of the staging.
-        const int used = d.src_used, nb = (N + 255) / 256;
-        if (H->prev_used >= 0) {
-            const unsigned gb = (unsigned)(((size_t)(d.c.T + 1) * N + 255) / 256);
-            hipLaunchKernelGGL(k_follow_map, dim3(nb), dim3(256), 0, st, N, (const int *)H->d_sc_sel, used, (const int *)H->d_prev_sel, H->prev_used, H->d_follow_map);
-            hipLaunchKernelGGL(k_follow_gather, dim3(gb), dim3(256), 0, st, d, (const int *)H->d_follow_map, H->d_follow_tmp);
-            hipLaunchKernelGGL(k_follow_back, dim3(gb), dim3(256), 0, st, d, (const int *)H->d_follow_map, (const double *)H->d_follow_tmp, (const int *)H->d_sc_sel, H->d_prev_sel);
-        }
-        hipLaunchKernelGGL(k_follow_keep, dim3(nb), dim3(256), 0, st, used, (const int *)H->d_sc_sel, H->d_prev_sel);
+        const int used = d.src_used;
+        const bool have = H->prev_used >= 0;
+        if (have) hipLaunchKernelGGL(k_follow_gather, dim3(N), dim3(64), 0, st, d, (const int *)H->d_sc_sel, used, (const int *)H->d_prev_sel, H->prev_used, H->d_follow_map, H->d_follow_tmp);
+        hipLaunchKernelGGL(k_follow_back, dim3(N), dim3(64), 0, st, d, have ? (const int *)H->d_follow_map : (const int *)nullptr, (const double *)H->d_follow_tmp,
+                           (const int *)H->d_sc_sel, used, H->d_prev_sel);
         H->prev_used = used;
     }
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((N * a.nt + 3) / 4)), dim3(256), 0, st, d);
