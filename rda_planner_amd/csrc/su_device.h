@@ -102,9 +102,7 @@ struct Args {
     int warm_nopred = 0;             // the first iteration of the warm attempt is a plain Newton step towards sigma*mu (no predictor)
     double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
     double *lam_keep = nullptr;
-    // keep the first near terms of every thread's slice in registers after the first pass that visits them (pays when the solve takes
-    // several interior-point iterations; a one-pass solve only sees the longer code: the caller says which it expects)
-    int term_cache = 1;
+    int term_cache = 1;              // (unused since the near terms of a screened solve live in LDS: Lds::near)
     // time split of the Newton system (TT = 10, 20, 25, 30): the stages [T/2, T) are factorised by wave 0 and the stages [0, T/2) by wave 1 at
     // the same time (see solve); 0 = one recursion over the whole horizon on wave 0 (rounds 1-3)
     int split = 1;
@@ -150,6 +148,7 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
 }
 
 // LDS carve-up (doubles).  Per-lane rows of the sweep matrices are 16-byte aligned (row stride 6).
+constexpr int NEAR_MAX = 256;  // near terms of a solve kept in LDS, one per thread in the hinge sums (a solve with more visits its masks in global memory instead)
 constexpr int FT = 48;   // F' of the stage, [8 columns q][6]: F[0..4][q] | pad   (x+ = F y, x = [s(3) up(2)])
 constexpr int HB = 64;   // full 8x8 stage Hessian base; re-used after the matrix sweep for Mb [8][6]
 constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
@@ -178,6 +177,7 @@ struct Lds {
     double *pv, *red;                      // 8, NT + 32 (reductions, flags, the two waves' 2 x 64-double scratch of the matrix recursion)
     double *p0;                            // [2][T] reference positions of the hinge screening
     double *uk, *ub, *xs;                  // time split (split_point(T) > 0): unit backward sweeps [5][8 m], their F_v' p [5][m][2], interface block [96]
+    double *near; int *ncnt, *sto;         // near list of the hinge screening: [NEAR_MAX][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
@@ -191,13 +191,15 @@ struct Lds {
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT + 32; p0 = p; p += 2 * T;
         const int m = split_point(T);
         uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
+        near = p; p += 4 * NEAR_MAX; ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
     }
 };
 inline size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
-             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0);
+             + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0)
+             + 4 * NEAR_MAX + NT / 2 + ev(T + 2) / 2 + 1;
     return n * sizeof(double);
 }
 
@@ -500,10 +502,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     constexpr int MW = 4;
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
-    constexpr int KC = 6;                                       // near terms kept in registers (the rest of the mask: rmask, fetched per pass)
-    double cax[KC] = {0, 0, 0, 0, 0, 0}, cay[KC] = {0, 0, 0, 0, 0, 0}, ccb[KC] = {0, 0, 0, 0, 0, 0};
-    unsigned long long rmask[MW] = {0, 0, 0, 0}; int ncache = -1;      // -1: not fetched yet
     bool screened = c.accelerated && a.P * KB * GS <= 64 * MW && (!masks_in || a.pose_ok);
+    bool listed = false;                                       // (uniform) the near terms are in L.near
     {
         double saa = 0, sga = 0, sgx = 0;
         if (ract) {
@@ -556,6 +556,49 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             if (cnt > 0.3 * (double)a.P * a.Nloc * T || dv > 0.5 * DELTA) screened = false;
         }
         MS(14);
+        // ---- near list (round 4).  The terms the masks name are fetched ONCE, here, into a compact stage-major list in LDS: (ax, ay, cb, stage).
+        // The per-iteration hinge sums (phase 1 below) then take one term per thread - no trip to memory, no loop, no register cache - and
+        // one thread per (stage, quantity) adds the stage's contributions up in list order (chunk, then bit: the order of the mask walk).
+        if (screened) {
+            int mine = 0;
+            if (ract) for (int w = 0; w < MW; ++w) mine += __popcll(amask[w]);
+            L.ncnt[tid] = mine;
+            __syncthreads();
+            if (wave == 0) {                                      // first entry of every stage (sto[T]: the total): stage totals, one wave scan (T <= 64)
+                int tot = 0;
+                if (lane < T) for (int k = 0; k < nch; ++k) tot += L.ncnt[lane * nch + k];
+                int inc = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+                if (lane < T) L.sto[lane] = inc - tot;
+                if (lane == T - 1) L.sto[T] = inc;
+            }
+            __syncthreads();
+            listed = L.sto[T] <= NEAR_MAX;
+            if (listed && ract && mine > 0) {
+                int off = L.sto[rt];
+                for (int k = 0; k < rc_; ++k) off += L.ncnt[rt * nch + k];
+                double *q = &L.near[4 * (size_t)off];
+                const int Nl = a.Nloc;
+                for (int w = 0; w < MW; ++w) {
+                    unsigned long long m = amask[w];
+                    while (m) {                                   // four loads in flight
+                        size_t o4[4]; int cnt = 0;
+                        while (m && cnt < 4) {
+                            const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
+                            const int blk = bit / GS, row = bit % GS;
+                            const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
+                            o4[cnt++] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
+                        }
+                        double x[4], y[4], cb[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < cnt) { x[k] = a.ax[o4[k]]; y[k] = a.ay[o4[k]]; cb[k] = a.cb[o4[k]]; }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < cnt) { q[0] = x[k]; q[1] = y[k]; q[2] = cb[k]; q[3] = (double)rt; q += 4; }
+                    }
+                }
+            }
+        }
         L.part[tid * 9] = saa; L.part[tid * 9 + 1] = sga; L.part[tid * 9 + 2] = sgx;
         __syncthreads();
         if (tid < T) {
@@ -980,8 +1023,34 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         const double heps = (attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;
         // (rescue phase: the smoothed hinge is non-zero for EVERY term - the oracle sums them all, so does this pass; such iterations are rare)
         const bool screened_now = screened && !(heps > 0);
-        // ---- (1) hinge sums per stage: (stage, chunk) partials, then one thread per (stage, quantity) --
-        {
+        // ---- (1) hinge sums per stage.  Screened solves with the near terms in LDS (the common case): one thread per (stage, quantity)
+        //          walks the stage's list.  Else: (stage, chunk) partials over the masks / over every term, then one thread per (stage, quantity) --
+        if (screened_now && listed) {
+            const int nn = L.sto[T];
+            if (tid < nn) {                                        // one near term per thread: its nine contributions (zeros while the hinge is inactive)
+                const double *q = &L.near[4 * tid];
+                const double ax = q[0], ay = q[1], cb = q[2]; const int t = (int)q[3];
+                const double Im = ax * L.s[t + 1] + ay * L.s[(T + 1) + t + 1] - cb - L.d[t];
+                const bool on = Im < 0;
+                double *pp = &L.part[tid * 9];
+                pp[0] = on ? ax * ax : 0.0; pp[1] = on ? ax * ay : 0.0; pp[2] = on ? ay * ay : 0.0; pp[3] = on ? ax : 0.0; pp[4] = on ? ay : 0.0;
+                pp[5] = on ? 1.0 : 0.0; pp[6] = on ? Im * ax : 0.0; pp[7] = on ? Im * ay : 0.0; pp[8] = on ? Im : 0.0;
+            }
+            __syncthreads();
+            for (int i = tid; i < 9 * T; i += NT) {
+                const int t = i / 9, k = i - 9 * t;
+                const int j0 = L.sto[t], j1 = L.sto[t + 1];
+                double acc = 0;
+                const double *pj = &L.part[j0 * 9 + k];
+                int j = j0;
+                for (; j + 4 <= j1; j += 4, pj += 36) {            // four loads in flight, added in list order
+                    const double v0 = pj[0], v1 = pj[9], v2 = pj[18], v3 = pj[27];
+                    acc += v0; acc += v1; acc += v2; acc += v3;
+                }
+                for (; j < j1; ++j, pj += 9) acc += pj[0];
+                L.hs[i] = acc;
+            }
+        } else {
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
             if (ract) {
                 const double px = L.s[rt + 1], py = L.s[(T + 1) + rt + 1], dd = L.d[rt];
@@ -1001,53 +1070,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     }
                 };
                 const int Nl = a.Nloc;
-                if (screened_now && !a.term_cache) {
+                if (screened_now) {
                     // visit only the terms that may be active, four loads in flight
                     for (int w = 0; w < MW; ++w) {
                         unsigned long long m = amask[w];
-                        while (m) {
-                            size_t off[4]; int cnt = 0;
-                            while (m && cnt < 4) {
-                                const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
-                                const int blk = bit / GS, row = bit % GS;
-                                const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
-                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
-                            }
-                            double x[4], y[4], cb[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) if (q < cnt) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.cb[off[q]]; }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) if (q < cnt) term(x[q], y[q], cb[q]);
-                        }
-                    }
-                } else if (screened_now) {
-                    // (solves that take several interior-point iterations) the cached terms, then the rest of the mask with four loads in flight
-                    // The first KC near terms of the thread's slice are fetched by the first pass that visits them and stay in registers: every
-                    // later pass used to start with the same trip to the L2.  (Not fetched ahead in the set-up: a barrier waits for outstanding
-                    // loads, the trip would only move.)  Same terms, same order.
-                    if (ncache < 0) {
-                        unsigned long long m0 = amask[0], m1 = amask[1], m2 = amask[2], m3 = amask[3];
-                        ncache = 0;
-#pragma unroll
-                        for (int k = 0; k < KC; ++k) {
-                            int bit = -1;
-                            if (m0) { bit = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
-                            else if (m1) { bit = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
-                            else if (m2) { bit = 128 + __ffsll((long long)m2) - 1; m2 &= m2 - 1; }
-                            else if (m3) { bit = 192 + __ffsll((long long)m3) - 1; m3 &= m3 - 1; }
-                            if (bit >= 0) {
-                                const int blk = bit / GS, row = bit % GS;
-                                const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
-                                const size_t off = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
-                                cax[k] = a.ax[off]; cay[k] = a.ay[off]; ccb[k] = a.cb[off]; ncache = k + 1;
-                            }
-                        }
-                        rmask[0] = m0; rmask[1] = m1; rmask[2] = m2; rmask[3] = m3;
-                    }
-#pragma unroll
-                    for (int k = 0; k < KC; ++k) if (k < ncache) term(cax[k], cay[k], ccb[k]);
-                    for (int w = 0; w < MW; ++w) {
-                        unsigned long long m = rmask[w];
                         while (m) {
                             size_t off[4]; int cnt = 0;
                             while (m && cnt < 4) {
