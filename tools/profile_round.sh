@@ -84,7 +84,9 @@ PY
 done
 
 timeout 400 python bench.py --egos 16 --fleet-egos 64 2> /dev/null | grep '^{' > "$OUT/bench_ns.json"                 # 200-step window, every leg, sizes
+S0=$SECONDS
 timeout 200 python bench.py --steps 20 --warmup 5 2> /dev/null | grep '^{' > "$OUT/bench_ns_driver_window.json"        # the driver's command
+echo "wall clock of the driver's command (python bench.py --steps 20 --warmup 5): $((SECONDS - S0)) s" > "$OUT/driver_window_wall.txt"
 for CFG in n20 n2000 c4; do timeout 300 $BENCH ${ARGS[$CFG]} 2> /dev/null | grep '^{' > "$OUT/bench_${CFG}.json"; done
 timeout 300 python bench.py --no-cpu-baseline --no-sizes --no-ip-legs --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 2> /dev/null | grep '^{' > "$OUT/bench_c5_fleet.json"
 D="$SCR/stats_c5"; mkdir -p "$D"
