@@ -148,7 +148,9 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
 }
 
 // LDS carve-up (doubles).  Per-lane rows of the sweep matrices are 16-byte aligned (row stride 6).
-constexpr int NEAR_MAX = 256;  // near terms of a solve kept in LDS, one per thread in the hinge sums (a solve with more visits its masks in global memory instead)
+// near terms of a solve kept in LDS, one or two per thread in the hinge sums (a solve with more visits its masks in global memory instead);
+// the long horizons have no room for the second half (160 KB of LDS per workgroup)
+__device__ __host__ constexpr int near_max(int T) { return T <= 40 ? 512 : 256; }
 constexpr int FT = 48;   // F' of the stage, [8 columns q][6]: F[0..4][q] | pad   (x+ = F y, x = [s(3) up(2)])
 constexpr int HB = 64;   // full 8x8 stage Hessian base; re-used after the matrix sweep for Mb [8][6]
 constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
@@ -177,7 +179,7 @@ struct Lds {
     double *pv, *red;                      // 8, NT + 32 (reductions, flags, the two waves' 2 x 64-double scratch of the matrix recursion)
     double *p0;                            // [2][T] reference positions of the hinge screening
     double *uk, *ub, *xs;                  // time split (split_point(T) > 0): unit backward sweeps [5][8 m], their F_v' p [5][m][2], interface block [96]
-    double *near; int *ncnt, *sto;         // near list of the hinge screening: [NEAR_MAX][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
+    double *near, *con; int *ncnt, *sto;   // near list of the hinge screening: [near_max][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
@@ -191,7 +193,8 @@ struct Lds {
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT + 32; p0 = p; p += 2 * T;
         const int m = split_point(T);
         uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
-        near = p; p += 4 * NEAR_MAX; ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
+        near = p; p += 4 * near_max(T); ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
+        con = part; if (near_max(T) > NT) { con = p; p += 9 * near_max(T); }      // the terms' contributions [near_max][9] (one per thread: the scratch of the partials)
     }
 };
 inline size_t lds_bytes(int T)
@@ -199,7 +202,7 @@ inline size_t lds_bytes(int T)
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
              + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0)
-             + 4 * NEAR_MAX + NT / 2 + ev(T + 2) / 2 + 1;
+             + 4 * near_max(T) + NT / 2 + ev(T + 2) / 2 + 1 + (near_max(T) > NT ? 9 * near_max(T) : 0);
     return n * sizeof(double);
 }
 
@@ -574,7 +577,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 if (lane == T - 1) L.sto[T] = inc;
             }
             __syncthreads();
-            listed = L.sto[T] <= NEAR_MAX;
+            listed = L.sto[T] <= near_max(T);
             if (listed && ract && mine > 0) {
                 int off = L.sto[rt];
                 for (int k = 0; k < rc_; ++k) off += L.ncnt[rt * nch + k];
@@ -1027,12 +1030,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         //          walks the stage's list.  Else: (stage, chunk) partials over the masks / over every term, then one thread per (stage, quantity) --
         if (screened_now && listed) {
             const int nn = L.sto[T];
-            if (tid < nn) {                                        // one near term per thread: its nine contributions (zeros while the hinge is inactive)
-                const double *q = &L.near[4 * tid];
+            for (int e = tid; e < nn; e += NT) {                    // one near term per thread (two beyond NT): its nine contributions (zeros while the hinge is inactive)
+                const double *q = &L.near[4 * e];
                 const double ax = q[0], ay = q[1], cb = q[2]; const int t = (int)q[3];
                 const double Im = ax * L.s[t + 1] + ay * L.s[(T + 1) + t + 1] - cb - L.d[t];
                 const bool on = Im < 0;
-                double *pp = &L.part[tid * 9];
+                double *pp = &L.con[e * 9];
                 pp[0] = on ? ax * ax : 0.0; pp[1] = on ? ax * ay : 0.0; pp[2] = on ? ay * ay : 0.0; pp[3] = on ? ax : 0.0; pp[4] = on ? ay : 0.0;
                 pp[5] = on ? 1.0 : 0.0; pp[6] = on ? Im * ax : 0.0; pp[7] = on ? Im * ay : 0.0; pp[8] = on ? Im : 0.0;
             }
@@ -1041,7 +1044,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 const int t = i / 9, k = i - 9 * t;
                 const int j0 = L.sto[t], j1 = L.sto[t + 1];
                 double acc = 0;
-                const double *pj = &L.part[j0 * 9 + k];
+                const double *pj = &L.con[j0 * 9 + k];
                 int j = j0;
                 for (; j + 4 <= j1; j += 4, pj += 36) {            // four loads in flight, added in list order
                     const double v0 = pj[0], v1 = pj[9], v2 = pj[18], v3 = pj[27];
