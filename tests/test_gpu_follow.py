@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from helpers import TOL_U
+from follow_lib import PiecewiseOracle, follow
 from rda_planner_amd import scenarios as sc
 
 pytestmark = pytest.mark.gpu
@@ -57,30 +58,6 @@ def test_result_does_not_depend_on_the_slot_order(n_obs, moving):
     assert np.mean(it_slot[5:]) >= np.mean(it_follow[5:]) + 0.5, (np.mean(it_slot[5:]), np.mean(it_follow[5:]))   # what the option is for
 
 
-class _PiecewiseOracle:
-    """the oracle's api with `step` driven through orc_admm_*: `hook()` runs between the first su-problem and the first LamMuZ pass"""
-
-    def __init__(self, base, iter_num):
-        self._b, self.iter_num, self.hook = base, iter_num, None
-
-    def __getattr__(self, k):
-        return getattr(self._b, k)
-
-    def step(self, h, nom_s, nom_u, ref, speed, n_obs, A, b, cone, per_t, out_u, out_s, info):
-        B = self._b
-        assert B.upload_obstacles(h, n_obs, A, b, cone, per_t) == 0
-        assert B.admm_begin(h, nom_s, nom_u, ref, speed) == 0
-        stopped = C.c_int(0)
-        for it in range(self.iter_num):
-            assert B.admm_su(h, it, C.byref(stopped)) == 0
-            if stopped.value:
-                break
-            if it == 0 and self.hook is not None:
-                self.hook()
-            assert B.admm_lammuz(h) == 0
-        return B.admm_finish(h, out_u, out_s, info)
-
-
 def _slot_src(mpc):
     from rda_planner_amd._lib import hip_api
     lib = hip_api().lib
@@ -101,7 +78,7 @@ def test_obstacles_entering_and_leaving_the_slots_match_the_oracle(n_obs, slots,
     car_t, path, obstacles = _scene(n_obs, moving, seed=9)
     kw = dict(sample_time=0.1, time_print=False, receding=15, iter_num=3, max_edge_num=4, max_obs_num=slots, ro1=200, obstacle_order=True)
     gpu = MPC(car_t, [p.copy() for p in path], duals_follow_obstacles=True, **kw)
-    papi = _PiecewiseOracle(orc_api(), kw["iter_num"])
+    papi = PiecewiseOracle(orc_api(), kw["iter_num"])
     cpu = MPC(car_t, [p.copy() for p in path], _backend=lambda cfg, G, h: _Backend(papi, cfg, G, h), **kw)
     orc_api().lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
     orc_api().lib.orc_set_su_warm(0.0, 0.0, 0)                   # the cold oracle: the independent checker
@@ -115,17 +92,8 @@ def test_obstacles_entering_and_leaving_the_slots_match_the_oracle(n_obs, slots,
             assert len(now) == slots
 
             def hook(prev=prev, now=now):
-                if prev is None:
-                    return
-                st = cpu.rda.get_state()
-                where = {int(s): i for i, s in enumerate(prev)}
-                new = {key: np.zeros_like(st[key]) for key in ("lam", "mu", "z", "xi", "zeta")}
-                for i, s in enumerate(now):
-                    j = where.get(int(s), -1)
-                    if j >= 0:
-                        for key in new:
-                            new[key][i] = st[key][j]
-                cpu.rda.set_state(dict(new, dis=None, a_lam=None, b_lam=None))
+                if prev is not None:
+                    cpu.rda.set_state(follow(cpu.rda.get_state(), prev, now))
             papi.hook = hook
             uc, ic = cpu.control(state.copy(), 4.0, list(cur))
             assert ig["status"] == 0 and ic["status"] == 0
