@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1, replica mode: skip the extra obstacle-shard leg (one ego, N_obs = --shard-n-obs)")
     ap.add_argument("--force-shard-leg", action="store_true", help="run the obstacle-shard leg on ONE GPU with a one-rank communicator (plumbing check)")
     ap.add_argument("--shard-n-obs", type=int, default=2000)
-    ap.add_argument("--shard-leg-timeout", type=float, default=240.0)
+    ap.add_argument("--shard-leg-timeout", type=float, default=120.0)
     ap.add_argument("--no-sizes", action="store_true", help="skip the `sizes` legs (N=20, N=2000, C4, C5 shape: one short sub-run of this script each)")
     ap.add_argument("--sizes-budget-s", type=float, default=75.0, help="wall-clock budget of the `sizes` legs; a leg that would start after it is skipped (and says so)")
     ap.add_argument("--size-leg", action="store_true", help="(internal) reduced set of legs: what one entry of `sizes` needs")
