@@ -58,6 +58,8 @@ void orc_set_centre(int on) { g_centre = on; }
 static FILE *g_su_dump = NULL; static int g_su_trace = 0;
 void orc_set_su_dump(const char *path) { if (g_su_dump) fclose(g_su_dump); g_su_dump = (path && path[0]) ? fopen(path, "wb") : NULL; }
 void orc_set_su_trace(int on) { g_su_trace = on; }
+static int g_su_accept = 1;                      /* su_solve_impl: the near-converged iterate kept as a safety net (see there) */
+void orc_set_su_accept(int on) { g_su_accept = on ? 1 : 0; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 
 struct orc_handle {
@@ -716,6 +718,12 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
     double *w = malloc(sizeof(double) * mc), *lm = malloc(sizeof(double) * mc), *rp = malloc(sizeof(double) * mc);
     double *dw = malloc(sizeof(double) * mc), *dl = malloc(sizeof(double) * mc), *rc = malloc(sizeof(double) * mc);
     double *s = malloc(sizeof(double) * 3 * (T + 1));
+    /* Safety net of the CHECKER (not mirrored in the kernel; orc_set_su_accept(0) switches it off): the best iterate that is primal
+     * feasible to tolerance, dual feasible to 10 x and complementary to 1000 x the stop tolerances (the class ECOS stops at) is kept.
+     * A solve whose every attempt then loses its end game in rounding - the dual residual GROWS from 1e-9 to 1e-5 while mu falls from 1e-9 to
+     * 1e-15 and the Cholesky factor breaks down (soak seed 9, scene 13, step 15; tests/golden/su_hard/omni_T25_N20_end_game_noise.npz:
+     * the kernel's arithmetic converges in 16 iterations) - returns that iterate instead of "no update". */
+    double *x_acc = malloc(sizeof(double) * n), *lm_acc = malloc(sizeof(double) * mc), acc_merit = INFINITY; int have_acc = 0;
     /* Two attempts.  The second one only runs when the first ends without convergence (the iteration
      * cap, ~0.1% of closed-loop solves, where the iterates cycle): it restarts from the same nominal
      * with a more central point (slack floor 0.1, mu0 = 10), which is enough to break the cycle. */
@@ -778,6 +786,10 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         /* past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
          * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
         if (rdn <= 100 * g_su_tol[0] * sc && rpn <= g_su_tol[1] && mu <= 0.1 * g_su_tol[2] * sc) { status = 0; break; }
+        if (g_su_accept && rpn <= g_su_tol[1] && rdn <= 10 * g_su_tol[0] * sc && mu <= 1e3 * g_su_tol[2] * sc) {
+            const double merit = fmax(rdn / (g_su_tol[0] * sc), mu / (g_su_tol[2] * sc));
+            if (!have_acc || merit < acc_merit) { memcpy(x_acc, x, sizeof(double) * n); memcpy(lm_acc, lm, sizeof(double) * mc); have_acc = 1; acc_merit = merit; }
+        }
         /* K = H + C' diag(lm/w) C */
         memcpy(K, Hm, sizeof(double) * n * n);
         for (int i = 0; i < mc; ++i) {
@@ -857,13 +869,15 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
     }
     used += it;
     }
+    /* every attempt failed: the safety net (see above) */
+    if (status != 0 && have_acc) { memcpy(x, x_acc, sizeof(double) * n); memcpy(lm, lm_acc, sizeof(double) * mc); status = 0; }
     if (ipm_iters) *ipm_iters = used;
     if (status == 0 && lam_keep) memcpy(lam_keep, lm, sizeof(double) * mc);
     su_rollout(&S, x, s);
     memcpy(s_out, s, sizeof(double) * 3 * (T + 1));
     for (int t = 0; t < T; ++t) { u_out[t] = x[2 * t]; u_out[T + t] = x[2 * t + 1]; d_out[t] = x[2 * T + t]; }
     free(S.Ak); free(S.Bk); free(S.Ck); free(S.Gam); free(S.Q0); free(S.Q1); free(S.Q2);
-    free(con); free(x); free(grad); free(Hm); free(K); free(rhs); free(dx); free(w); free(lm); free(rp); free(dw); free(dl); free(rc); free(s);
+    free(con); free(x); free(grad); free(Hm); free(K); free(rhs); free(dx); free(w); free(lm); free(rp); free(dw); free(dl); free(rc); free(s); free(x_acc); free(lm_acc);
     return status;
 }
 

@@ -455,6 +455,20 @@ def test_su_hard_instances_from_the_soak_run(orc, hip, name):
         assert np.abs(so[k] - sh[k]).max() < 1e-6
 
 
+def test_su_end_game_noise_instance_converges_in_the_kernel(orc, hip):
+    """the one su-problem of 19 200 round-4 soak steps on which a side failed - the ORACLE (its dual residual grows from 8e-10 to 3e-5 as mu
+    falls below 1e-9, Cholesky breakdown; tests/test_oracle_su.py::test_end_game_lost_in_rounding_returns_the_near_converged_iterate).
+    The kernel's cold solve converges (16 iterations); the iterate the checker's safety net returns is of the looser class (mu = 2e-9
+    instead of 1e-11: 1e-4 from the kernel's point, see test_stop_tolerance_vs_weakly_active_rows) - within the stated tolerance TOL_U."""
+    cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", "omni_T25_N20_end_game_noise.npz"))
+    so = hp.su_solve(orc.lib.orc_su_solve, cfg, inp)
+    sh = hp.su_solve(hip.lib.rda_su_solve, cfg, inp)
+    assert so[0] == 0 and sh[0] == 0 and sh[4] <= 20, (so[0], sh[0], sh[4])
+    d = max(float(np.abs(so[k] - sh[k]).max()) for k in (1, 2, 3))
+    print(f"|(s, u, d)_gpu - oracle's accepted iterate| {d:.2e} ({sh[4]} interior-point iterations)")
+    assert d <= hp.TOL_U
+
+
 @pytest.mark.parametrize("name", ["omni_T15_N30_weakly_active_a", "omni_T15_N13_weakly_active_b", "acker_T15_N27_weakly_active_c"])
 def test_su_weakly_active_instances_from_the_round4_soak(orc, hip, name):
     """the su-problems behind the largest GPU-vs-oracle control differences of the round-4 soak (weakly active inequality rows, see

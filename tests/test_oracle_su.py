@@ -327,3 +327,39 @@ def test_su_replay_tool_records_and_replays(tmp_path, monkeypatch):
     finally:                                   # the recording run switched the oracle's su start rules and thread count: back to the defaults
         lib = su_replay._lib()
         lib.orc_set_su_warm(1e-3, 1e-3, 30); lib.orc_set_threads(1); lib.orc_set_su_dump(b""); lib.orc_set_su_trace(0)
+
+
+def test_end_game_lost_in_rounding_returns_the_near_converged_iterate(orc):
+    """recorded instance (soak seed 9, scene 13, step 15: omni, T=25, 20 slots).  At complementarity 2e-9 the dual residual is 8e-10 -
+    one decade of mu short of the stop test - and from there it GROWS (4e-7, 5e-6, ... 3e-5: barrier weights lam/w beyond 1e10) while mu
+    falls to 1e-15, where the Cholesky factor breaks down; the central restart ends the same way.  The checker keeps the best iterate that
+    is primal feasible and within 10 x / 1000 x of the dual / complementarity tolerances (the class ECOS stops at) and returns it instead
+    of `no update` (orc_set_su_accept; not mirrored in the kernel, whose arithmetic converges here: tests/test_gpu_parity.py).  Without the
+    net the solve fails; with it the point is a minimiser to 1e-6."""
+    import ctypes as C
+    import os
+    cfg, si = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", "omni_T25_N20_end_game_noise.npz"))
+    orc.lib.orc_set_su_accept.argtypes = [C.c_int]
+    try:
+        orc.lib.orc_set_su_accept(0)
+        st0 = hp.su_solve(orc.lib.orc_su_solve, cfg, si)[0]
+    finally:
+        orc.lib.orc_set_su_accept(1)
+    st, s, u, d, it = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+    assert st0 != 0 and st == 0 and it <= 40, (st0, st, it)        # (both attempts run: 16 + 16 iterations)
+    si2 = dict(si, nom_u=si["nom_u"].reshape(2, -1))
+    f0 = _objective(cfg, si2, s, u, d)
+    rng = np.random.default_rng(1)
+
+    def roll(U):
+        S = np.zeros((3, cfg.T + 1)); S[:, 0] = si2["nom_s"][:, 0]
+        for t in range(cfg.T):
+            A, B, Cc = _lin(2, si2["nom_s"][:, t], si2["nom_u"][:, t], cfg.dt, cfg.L)
+            S[:, t + 1] = A @ S[:, t] + B @ U[:, t] + Cc
+        return S
+    for k in range(20):
+        U2 = np.clip(u + rng.normal(0, 1e-4, u.shape), -np.array([[10.0], [1.0]]), np.array([[10.0], [1.0]]))
+        for t in range(1, cfg.T):
+            U2[:, t] = np.clip(U2[:, t], U2[:, t - 1] - [1.0, 0.05], U2[:, t - 1] + [1.0, 0.05])
+        D2 = np.clip(d + rng.normal(0, 1e-4, d.shape), cfg.min_sd, cfg.max_sd)
+        assert _objective(cfg, si2, roll(U2), U2, D2) >= f0 - 1e-6 * (1 + abs(f0))

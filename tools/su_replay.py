@@ -95,13 +95,25 @@ def solve(l, pr):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=["record", "count", "trace", "distance"]); ap.add_argument("name"); ap.add_argument("problems", nargs="*", type=int)
+    ap.add_argument("cmd", choices=["record", "count", "trace", "distance", "gpu"]); ap.add_argument("name"); ap.add_argument("problems", nargs="*", type=int)
     ap.add_argument("--n-obs", type=int, default=200); ap.add_argument("--horizon", type=int, default=30); ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--moving", action="store_true")
     a = ap.parse_args()
     if a.cmd == "record":
         return record(a.name, a.n_obs, a.horizon, a.steps, a.moving)
     l, probs = _lib(), load(a.name)
+    if a.cmd == "gpu":            # the same recorded problems through the kernel's cold solve (rda_su_solve) beside the oracle's: status, iterations, |du|
+        from rda_planner_amd._lib import hip_api
+        hl = hip_api().lib
+        for i, pr in enumerate(probs):
+            T = pr["T"]
+            so, uo, do, it = np.zeros(3 * (T + 1)), np.zeros(2 * T), np.zeros(T), C.c_int(0)
+            P = lambda x: x.ctypes.data_as(c_double_p)  # noqa: E731
+            sg = hl.rda_su_solve(C.byref(pr["cfg"]), P(pr["s"]), P(pr["u"]), P(pr["ref"]), pr["ref_speed"], P(pr["a"]), P(pr["cc"]), P(pr["g"]), P(pr["d"]),
+                                 P(so), P(uo), P(do), C.byref(it))
+            sc_, ic, _, uc, _ = solve(l, pr)
+            print(f"problem {i} (ADMM iteration {pr['it']}): gpu status {sg} / {it.value} iterations, oracle status {sc_} / {ic} iterations, max |u_gpu - u_oracle| {np.abs(uo - uc).max():.2e}")
+        return
     if a.cmd == "count":
         its = np.array([solve(l, pr)[1] for pr in probs])
         print(f"{len(its)} su-problems: {its.mean():.2f} interior-point iterations per cold solve (median {np.median(its):.0f}, max {its.max()}); by ADMM iteration " +
