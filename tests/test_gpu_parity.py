@@ -456,7 +456,7 @@ def test_su_hard_instances_from_the_soak_run(orc, hip, name):
 
 
 def test_su_end_game_noise_instance_converges_in_the_kernel(orc, hip):
-    """the one su-problem of 19 200 round-4 soak steps on which a side failed - the ORACLE (its dual residual grows from 8e-10 to 3e-5 as mu
+    """the one su-problem of 32 000 round-4 soak steps on which a side failed - the ORACLE (its dual residual grows from 8e-10 to 3e-5 as mu
     falls below 1e-9, Cholesky breakdown; tests/test_oracle_su.py::test_end_game_lost_in_rounding_returns_the_near_converged_iterate).
     The kernel's cold solve converges (16 iterations); the iterate the checker's safety net returns is of the looser class (mu = 2e-9
     instead of 1e-11: 1e-4 from the kernel's point, see test_stop_tolerance_vs_weakly_active_rows) - within the stated tolerance TOL_U."""
