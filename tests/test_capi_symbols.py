@@ -68,3 +68,12 @@ def test_host_side_helpers_build_and_load():
     import importlib
     mod = importlib.import_module("rda_planner_amd._flatten")
     assert callable(mod.flatten)
+
+
+def test_integration_md_names_every_entry_point_of_the_header():
+    """INTEGRATION.md is the map from the C-ABI to the reference interfaces it replaces: no function of include/rda_hip.h may be missing"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = sorted(set(re.findall(r"\b(rda_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "rda_hip.h")).read())))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert [n for n in names if n not in doc] == []
