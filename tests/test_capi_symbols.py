@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -77,3 +78,37 @@ def test_integration_md_names_every_entry_point_of_the_header():
     names = sorted(set(re.findall(r"\b(rda_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "rda_hip.h")).read())))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     assert [n for n in names if n not in doc] == []
+
+
+def _header_struct_fields(name):
+    """[(field, 'int' | 'double', length)] of `typedef struct <name> { ... } <name>;` in include/rda_hip.h, in declaration order"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "rda_hip.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(int32_t|double)\s+(.*)", decl.strip(), re.S)
+        if not m:
+            continue
+        for item in m.group(2).split(","):
+            mm = re.match(r"\s*(\w+)\s*(?:\[(\d+)\])?\s*$", item)
+            out.append((mm.group(1), "int" if m.group(1) == "int32_t" else "double", int(mm.group(2) or 1)))
+    return out
+
+
+@pytest.mark.parametrize("cname,pyname", [("rda_opts", "Opts"), ("rda_cfg", "Cfg"), ("rda_info", "Info")])
+def test_ctypes_structs_mirror_the_header_field_by_field(cname, pyname):
+    """the ctypes mirrors of the C-ABI structs (rda_planner_amd/_capi.py) against include/rda_hip.h: names, order, types, array lengths -
+    a field added on one side only shifts everything behind it silently"""
+    import ctypes as C
+    from rda_planner_amd import _capi
+    want = _header_struct_fields(cname)
+    got = []
+    for fname, ftype in getattr(_capi, pyname)._fields_:
+        length = getattr(ftype, "_length_", 1)
+        base = getattr(ftype, "_type_", ftype) if length > 1 else ftype
+        got.append((fname, "int" if base is C.c_int else "double", length))
+        assert base in (C.c_int, C.c_double), (fname, base)
+    assert got == want
