@@ -438,6 +438,7 @@ def main():
             except (AssertionError, RuntimeError) as e:          # the headline must not depend on an opt-in leg
                 follow = {"error": str(e)[:200]}
         early = None
+        hardw = None
         if rank == 0 and world == 1 and not args.size_leg:
             # opt-in rda_opts::su_tol_early: the su-problems before the last ADMM iteration of a step at the reference solver's own class of
             # tolerance (ECOS defaults, 1e-8) instead of the 1000 x tighter su_tol the parity tolerance is stated against
@@ -449,6 +450,16 @@ def main():
                          "what": "the headline protocol with su_tol_early = (1e-6, 1e-7, 1e-8): opt-in, the stated parity tolerance does not hold with it - never `value`"}
             except (AssertionError, RuntimeError) as e:
                 early = {"error": str(e)[:200]}
+            # opt-in rda_opts::su_hard_warm (found at the end of round 4, default off until it has been soaked): the warm attempts of a step that
+            # follows an UNCONVERGED step start well inside the boxes (slack floor 1) with the previous multipliers and mu0 = 1e-3
+            try:
+                el_g, times_g, _, its_g = cabi_closed_loop(per_tick_scene=bool(args.moving), ordered=True, compare=False, hip_opts=_ho(su_hard_warm=(1.0, 1e-3)))
+                hardw = {"steps_per_s": round(K / el_g, 2), "median_ms_per_step": round(float(np.median(times_g) * 1e3), 5),
+                         "mean_admm_iters": round(float(np.mean(its_g)), 3),
+                         "what": "the headline protocol with su_hard_warm = (1, 1e-3): same su-problems solved to the same tolerance from another start; "
+                                 "opt-in until validated by the soak - never `value`"}
+            except (AssertionError, RuntimeError) as e:
+                hardw = {"error": str(e)[:200]}
         if rank == 0 and world == 1 and not args.size_leg:
             el_y, times_y, du_y, _ = cabi_closed_loop(per_tick_scene=bool(args.moving), driver="python", ordered=True)
             pydrv = {"steps_per_s": round(K / el_y, 2), "median_ms_per_step": round(float(np.median(times_y) * 1e3), 5),
@@ -831,6 +842,7 @@ def main():
         "fixed_slot_binding": fixed if head else None,
         "duals_follow_obstacles": follow if head else None,
         "su_tol_early": early if head else None,
+        "su_hard_warm": hardw if head else None,
         "pcie_inclusive": pcie if head else None,
         "python_caller_closed_loop": pydrv if head else None,
         "device_resident_replay": replay,

@@ -58,6 +58,8 @@ void orc_set_centre(int on) { g_centre = on; }
 static FILE *g_su_dump = NULL; static int g_su_trace = 0;
 void orc_set_su_dump(const char *path) { if (g_su_dump) fclose(g_su_dump); g_su_dump = (path && path[0]) ? fopen(path, "wb") : NULL; }
 void orc_set_su_trace(int on) { g_su_trace = on; }
+static double g_su_hard_wfl = 0, g_su_hard_mu0 = 0;   /* mirror of rda_opts::su_hard_warm: start of the warm attempts of a step that follows an UNCONVERGED step (0 = off) */
+void orc_set_su_hard_warm(double wfl, double mu0) { g_su_hard_wfl = wfl; g_su_hard_mu0 = mu0; }
 static int g_su_accept = 1;                      /* su_solve_impl: the near-converged iterate kept as a safety net (see there) */
 void orc_set_su_accept(int on) { g_su_accept = on ? 1 : 0; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
@@ -75,6 +77,7 @@ struct orc_handle {
     int stop, iters, su_status, ipm_total, lmz_fail; double resi_dual, resi_pri;
     double *su_lam_keep;          /* inequality multipliers of the last converged su-solve (10T - 4 rows) */
     int su_last;                  /* interior-point iterations of the last su-solve (99: none / not converged): picks the next warm start */
+    int prev_unconv;              /* the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop) */
     int P, rank, Nloc, have_gath; size_t chunk; double *gath;      /* obstacle sharding */
 };
 
@@ -1073,11 +1076,12 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
     /* while the su-solves are easy (the last one took <= max iterations) the warm attempt starts 1e-6 from the previous solution's
      * active bounds and takes near-full steps - the same rule as csrc/rda_hip.hip su_body */
     const int easy = warm && g_su_easy_max > 0 && H->su_last <= g_su_easy_max;
+    const int hard = warm && !easy && g_su_hard_mu0 > 0 && H->prev_unconv;
     cur_warm_clip = easy ? g_su_easy[2] : g_su_warm_clip; cur_warm_tau = easy ? g_su_easy[3] : g_su_warm_tau; cur_warm_sig = easy ? g_su_easy[4] : g_su_warm_sig;
     double tol_keep[3] = { g_su_tol[0], g_su_tol[1], g_su_tol[2] };
     if (it < c->iter_num - 1 && g_su_tol_early[0] > 0 && g_su_tol_early[1] > 0 && g_su_tol_early[2] > 0) memcpy(g_su_tol, g_su_tol_early, sizeof g_su_tol);
     int st = su_solve_impl(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm,
-                           H->su_lam_keep, warm, easy ? g_su_easy[0] : g_su_warm_wfl, easy ? g_su_easy[1] : g_su_warm_mu0, g_su_warm_cap, it == 0);
+                           H->su_lam_keep, warm, easy ? g_su_easy[0] : (hard ? g_su_hard_wfl : g_su_warm_wfl), easy ? g_su_easy[1] : (hard ? g_su_hard_mu0 : g_su_warm_mu0), g_su_warm_cap, it == 0);
     memcpy(g_su_tol, tol_keep, sizeof g_su_tol);
     H->su_last = st == 0 ? ipm : 99;
     H->ipm_total += ipm;
@@ -1169,6 +1173,7 @@ int orc_admm_finish(orc_handle *H, double *out_u, double *out_s, orc_info *info)
 {
     int T = H->c.T;
     if (!H->stop) admm_residuals(H);
+    H->prev_unconv = !(H->resi_dual < H->c.iter_threshold && H->resi_pri < H->c.iter_threshold);
     memcpy(out_u, H->u, sizeof(double) * 2 * T); memcpy(out_s, H->s, sizeof(double) * 3 * (T + 1));
     if (info) { info->resi_dual = H->resi_dual; info->resi_pri = H->resi_pri; info->iters = H->iters; info->su_status = H->su_status; info->su_ipm_iters = H->ipm_total; info->lmz_fail = H->lmz_fail; }
     return 0;

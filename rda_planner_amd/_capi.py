@@ -25,7 +25,7 @@ class Cfg(C.Structure):
 
 class Opts(C.Structure):
     """rda_opts of include/rda_hip.h: per-handle solver options that are not reference arguments (filled by rda_opts_init)"""
-    _fields_ = [("lmz_mode", C.c_int), ("tie_centre", C.c_int), ("lmz_mu", C.c_double), ("su_tol", C.c_double * 3), ("su_tol_early", C.c_double * 3),
+    _fields_ = [("lmz_mode", C.c_int), ("tie_centre", C.c_int), ("lmz_mu", C.c_double), ("su_tol", C.c_double * 3), ("su_tol_early", C.c_double * 3), ("su_hard_warm", C.c_double * 2),
                 ("lmz_warm", C.c_int), ("lmz_rows", C.c_int), ("lmz_dense_from", C.c_int), ("lmz_split", C.c_int),
                 ("lmz_tail", C.c_int), ("lmz_ip_rows", C.c_int), ("lmz_ip_warm", C.c_int), ("su_pre", C.c_int), ("su_light", C.c_int),
                 ("su_warm_first", C.c_int), ("su_warm_cap", C.c_int), ("su_easy_max", C.c_int), ("su_easy_nopred", C.c_int),

@@ -49,6 +49,7 @@ struct Ctrl {
     int verdict_iter;             // ... and for which the early-stop verdict has been TAKEN (by the LamMuZ tail; else the next su launch takes it)
     int pose_ok;                  // Dev::pose and the near masks of Dev::coef describe the same terms (a LamMuZ launch / k_lmz_finalize made them)
     int prev_iters;               // ADMM iterations of the previous step: the LamMuZ tail runs where the step is expected to end (lmz_tail)
+    int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -88,6 +89,7 @@ struct Dev {
     double su_warm_clip;               // start of a warm attempt: relative margin inside the boxes (cold 0.01)
     double su_warm_tau, su_warm_sig;   // end game of the warm attempt (floors; cold solves: 0.995, 1e-3)
     double su_warm_wfl, su_warm_mu0;   // interior-point start of the su-problems of ADMM iterations >= 1 ("0,0" = cold)
+    double su_hard_wfl, su_hard_mu0;   // ... of the steps that follow an UNCONVERGED step (rda_opts::su_hard_warm; mu0 = 0: the rule is off)
     int lmz_mode;            // 0: support enumeration + tie-breaks T1-T3 (default), 1: interior point, central path at lmz_mu (norm2 robots: always)
     double lmz_mu;           // barrier parameter of the returned central-path point (mode 1)
     int centre;              // tie-break T1: central separating normal in the slack regime
@@ -195,6 +197,7 @@ __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
         f.info->iters = d.ctrl->iters; f.info->su_status = d.ctrl->su_status; f.info->su_ipm_iters = d.ctrl->ipm_iters;
         f.info->lmz_fail = d.ctrl->lmz_fail;
         d.ctrl->prev_iters = d.ctrl->iters;
+        d.ctrl->prev_unconv = !(d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold);
     }
     // polygons of the staged scene that failed the reference's convexity test (mpc.py:476-549 prints a warning per polygon)
     if (f.slot && tid == 1) *(long long *)(f.out_u + 2 * T + 3 * (T + 1) + 6) = d.sc_bad ? (long long)*d.sc_bad : 0ll;
@@ -272,14 +275,21 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // 1e-6 from the previous solution's active bounds with its multipliers and takes near-full steps: ONE iteration + the
     // convergence pass.  After a solve that needed more (moving obstacles, a changed active set) the moderate start above is used.
     // (su_last / su_probe / su_lam_keep are solver history of the handle: rda_reset clears them, rda_get/set_su_history carry them.)
+    bool hard = false;
     if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
         a.warm_nopred = d.su_easy_nopred;
+    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && d.ctrl->prev_unconv) {
+        // The ADMM of the previous step did not converge (a caller that re-sorts its obstacles every tick, quirk Q5; many moving obstacles):
+        // consecutive su-problems are far apart.  A warm attempt then does best from a point WELL inside the boxes (slack floor 1) with
+        // the previous multipliers and next to no barrier (mu0 1e-3) - and it beats the cold start, so that rule is skipped: 7.3 -> 4.9
+        // interior-point iterations per su-solve on the re-sorted north star (oracle), headline loop +26 % (env knobs, one box).
+        a.warm_wfl = d.su_hard_wfl; a.warm_mu0 = d.su_hard_mu0; hard = true;
     }
     // Hard regime (many moving obstacles: consecutive su-problems are far apart): a warm attempt then needs MORE iterations than a cold
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
-    if (a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
+    if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
     a.term_cache = a.warm_mu0 == 0 || d.ctrl->su_last > 1;       // cold start or a hard predecessor: several interior-point iterations ahead
     su::solve<TT>(a, smem_su, ref_wait);
     __syncthreads();
@@ -1182,7 +1192,7 @@ __global__ void k_reset(Dev d)
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
         coef_arr(d, r, 8)[k] = coef_arr(d, r, 3)[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; }      // solver history of the handle
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; }      // solver history of the handle
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
     if (d.ipf) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.c.N * T; i += gridDim.x * blockDim.x) d.ipf[i] = 0;
 }
@@ -1316,7 +1326,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
-    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0;
+    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0; o->su_hard_warm[0] = 0; o->su_hard_warm[1] = 0;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0;
@@ -1329,6 +1339,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     auto getd = [](const char *name, double *v) { const char *e = getenv(name); if (e && *e) *v = atof(e); };
     geti("RDA_LMZ_MODE", &o->lmz_mode); geti("RDA_TIE_CENTRE", &o->tie_centre); getd("RDA_LMZ_MU", &o->lmz_mu);
     { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol[0], &o->su_tol[1], &o->su_tol[2]); }
+    { const char *e = getenv("RDA_SU_HARD_WARM"); if (e) sscanf(e, "%lf,%lf", &o->su_hard_warm[0], &o->su_hard_warm[1]); }
     { const char *e = getenv("RDA_SU_TOL_EARLY"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol_early[0], &o->su_tol_early[1], &o->su_tol_early[2]); }
     geti("RDA_LMZ_WARM", &o->lmz_warm); geti("RDA_LMZ_ROWS", &o->lmz_rows); geti("RDA_LMZ_DENSE_FROM", &o->lmz_dense_from);
     geti("RDA_LMZ_SPLIT", &o->lmz_split); geti("RDA_LMZ_TAIL", &o->lmz_tail); geti("RDA_LMZ_IP_ROWS", &o->lmz_ip_rows); geti("RDA_LMZ_IP_WARM", &o->lmz_ip_warm);
@@ -1403,6 +1414,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.centre = o.tie_centre ? 1 : 0;
     H->d.lmz_mode = (o.lmz_mode || cfg->robot_norm2) ? 1 : 0; H->d.lmz_mu = o.lmz_mu > 0 ? o.lmz_mu : 1e-6;      // the enumeration has no norm2-robot candidates
     H->d.su_warm_wfl = o.su_warm[0]; H->d.su_warm_mu0 = o.su_warm[1]; H->d.su_warm_cap = o.su_warm_cap; H->d.su_warm_first = o.su_warm_first;
+    H->d.su_hard_wfl = o.su_hard_warm[0]; H->d.su_hard_mu0 = o.su_hard_warm[0] > 0 ? o.su_hard_warm[1] : 0.0;
     H->d.su_warm_tau = o.su_warm_endgame[0]; H->d.su_warm_sig = o.su_warm_endgame[1]; H->d.su_warm_clip = o.su_warm_clip;
     for (int i = 0; i < 5; ++i) H->d.su_easy[i] = o.su_easy[i];
     H->d.su_easy_max = o.su_easy_max; H->d.su_easy_nopred = o.su_easy_nopred;

@@ -363,3 +363,42 @@ def test_end_game_lost_in_rounding_returns_the_near_converged_iterate(orc):
             U2[:, t] = np.clip(U2[:, t], U2[:, t - 1] - [1.0, 0.05], U2[:, t - 1] + [1.0, 0.05])
         D2 = np.clip(d + rng.normal(0, 1e-4, d.shape), cfg.min_sd, cfg.max_sd)
         assert _objective(cfg, si2, roll(U2), U2, D2) >= f0 - 1e-6 * (1 + abs(f0))
+
+
+def test_warm_start_after_an_unconverged_step_saves_iterations_and_moves_nothing(orc):
+    """mirror of rda_opts::su_hard_warm (opt-in): when the ADMM of the previous step did not converge (here: a caller that re-sorts its
+    obstacle list every tick while the duals stay with their slots, quirk Q5), the warm attempts start from a point well inside the boxes
+    (slack floor 1) with the previous multipliers and mu0 = 1e-3.  Same su-problems, same stop tolerance: fewer interior-point iterations,
+    the controls of the closed loop within 1e-4; a loop whose steps converge never sees the rule (bit-identical)."""
+    import ctypes as C
+    from rda_planner_amd import scenarios as sc
+    from rda_planner_amd.mpc import MPC
+    from oracle.oracle_backend import oracle_backend
+    orc.lib.orc_set_su_hard_warm.argtypes = [C.c_double, C.c_double]
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    obstacles = sc.scene_polygons(80, lo=(8, 12), hi=(40, 38), seed=sc.SEED + 31, keep_clear=clear, clear_radius=3.2)
+
+    def loop(order, hard):
+        orc.lib.orc_set_su_hard_warm(*hard)
+        m = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, receding=15, iter_num=4, max_edge_num=4, max_obs_num=80,
+                ro1=200, obstacle_order=order, _backend=oracle_backend)
+        st, us, ipm, its = path[0].copy().reshape(3, 1), [], 0, 0
+        for k in range(30):
+            u, info = m.control(st, 4.0, list(obstacles))
+            assert info["status"] == 0
+            us.append(u.ravel().copy()); ipm += info["su_ipm_iters"]; its += info["iters"]
+            st = sc.kinematic_step(st, u, car_t, 0.1)
+        return np.array(us), ipm, its
+    try:
+        u0, ipm0, its0 = loop(True, (0.0, 0.0))
+        u1, ipm1, its1 = loop(True, (1.0, 1e-3))
+        f0, fi0, _ = loop(False, (0.0, 0.0))
+        f1, fi1, _ = loop(False, (1.0, 1e-3))
+    finally:
+        orc.lib.orc_set_su_hard_warm(0.0, 0.0)
+    print(f"re-sorted loop: {ipm0} -> {ipm1} interior-point iterations over 30 steps ({its0} / {its1} ADMM iterations), max |du| {np.abs(u0 - u1).max():.1e}")
+    assert its0 == its1 and ipm1 <= 0.85 * ipm0, (ipm0, ipm1)
+    assert np.abs(u0 - u1).max() <= 1e-4
+    assert fi0 == fi1 and np.array_equal(f0, f1)
