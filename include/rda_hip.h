@@ -88,10 +88,11 @@ typedef struct rda_opts {
                                 tests/test_oracle_su.py), so the stated tolerance TOL_U does not hold with it.            RDA_SU_TOL_EARLY */
     double  su_hard_warm[2]; /* [0, 0 = off] slack floor / barrier parameter of the warm attempts of a step that follows an UNCONVERGED step
                                 (its ADMM used all iter_num iterations with a residual above iter_threshold): "1,1e-3" - a point well inside
-                                the boxes with the previous multipliers; the cold-start rule is skipped there.  Same su-problems, same stop
-                                tolerance, another start: headline loop (re-sorted every tick) 1396 -> 1759 steps/s, fixed binding unchanged
-                                (same box).  Off by default until it has been through the soak; the flag it keys on is not yet part of
-                                rda_get_su_history.                                                                    RDA_SU_HARD_WARM */
+                                the boxes with the previous multipliers; the cold-start rule is skipped there.  Applies only while the su-solves
+                                really are hard (the last one took more than 3 iterations).  Same su-problems, same stop tolerance, another
+                                start: headline loop (re-sorted every tick) 1396 -> 1759 steps/s with the first condition alone, fixed
+                                binding unchanged (same box).  Off by default until it has been through the soak; the flag it keys on is
+                                not yet part of rda_get_su_history.                                                    RDA_SU_HARD_WARM */
     /* ---- A/B switches (defaults in brackets) ---- */
     int32_t lmz_warm;        /* [1] try the remembered support first, then the supports one row away from it, before a row is
                                 enumerated; every answer is accepted on its optimality certificate alone.  The supports are a cache of

@@ -1076,7 +1076,10 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
     /* while the su-solves are easy (the last one took <= max iterations) the warm attempt starts 1e-6 from the previous solution's
      * active bounds and takes near-full steps - the same rule as csrc/rda_hip.hip su_body */
     const int easy = warm && g_su_easy_max > 0 && H->su_last <= g_su_easy_max;
-    const int hard = warm && !easy && g_su_hard_mu0 > 0 && H->prev_unconv;
+    /* after an unconverged step, and only while the su-solves really are hard (the last one took more than 3 iterations: a wide floor makes
+     * an EASY problem cost 3 iterations, which would lock the easy start out for good - measured with iter_num = 1 and with
+     * iter_threshold = 0.02 before this second key existed) */
+    const int hard = warm && !easy && g_su_hard_mu0 > 0 && H->prev_unconv && H->su_last > 3 && H->su_last < 99;
     cur_warm_clip = easy ? g_su_easy[2] : g_su_warm_clip; cur_warm_tau = easy ? g_su_easy[3] : g_su_warm_tau; cur_warm_sig = easy ? g_su_easy[4] : g_su_warm_sig;
     double tol_keep[3] = { g_su_tol[0], g_su_tol[1], g_su_tol[2] };
     if (it < c->iter_num - 1 && g_su_tol_early[0] > 0 && g_su_tol_early[1] > 0 && g_su_tol_early[2] > 0) memcpy(g_su_tol, g_su_tol_early, sizeof g_su_tol);

@@ -279,11 +279,13 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
         a.warm_nopred = d.su_easy_nopred;
-    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && d.ctrl->prev_unconv) {
+    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && d.ctrl->prev_unconv && d.ctrl->su_last > 3 && d.ctrl->su_last < 99) {
         // The ADMM of the previous step did not converge (a caller that re-sorts its obstacles every tick, quirk Q5; many moving obstacles):
         // consecutive su-problems are far apart.  A warm attempt then does best from a point WELL inside the boxes (slack floor 1) with
         // the previous multipliers and next to no barrier (mu0 1e-3) - and it beats the cold start, so that rule is skipped: 7.3 -> 4.9
-        // interior-point iterations per su-solve on the re-sorted north star (oracle), headline loop +26 % (env knobs, one box).
+        // interior-point iterations per su-solve on the re-sorted north star (oracle), headline loop +26 % (env knobs, one box).  Only while the
+        // su-solves really are hard (the last one took more than 3 iterations): the wide floor makes an EASY problem cost 3 iterations, which
+        // would lock the easy start out for good (oracle, iter_num = 1 / iter_threshold = 0.02: 1.0 -> 3.0 iterations per solve without this key).
         a.warm_wfl = d.su_hard_wfl; a.warm_mu0 = d.su_hard_mu0; hard = true;
     }
     // Hard regime (many moving obstacles: consecutive su-problems are far apart): a warm attempt then needs MORE iterations than a cold

@@ -368,7 +368,9 @@ def test_end_game_lost_in_rounding_returns_the_near_converged_iterate(orc):
 def test_warm_start_after_an_unconverged_step_saves_iterations_and_moves_nothing(orc):
     """mirror of rda_opts::su_hard_warm (opt-in): when the ADMM of the previous step did not converge (here: a caller that re-sorts its
     obstacle list every tick while the duals stay with their slots, quirk Q5), the warm attempts start from a point well inside the boxes
-    (slack floor 1) with the previous multipliers and mu0 = 1e-3.  Same su-problems, same stop tolerance: fewer interior-point iterations,
+    (slack floor 1) with the previous multipliers and mu0 = 1e-3 - while the su-solves really are hard (the last one took more than 3
+    iterations; without that second key a loop of EASY problems that merely runs out of ADMM iterations is locked out of its easy start).
+    Same su-problems, same stop tolerance: fewer interior-point iterations,
     the controls of the closed loop within 1e-4; a loop whose steps converge never sees the rule (bit-identical)."""
     import ctypes as C
     from rda_planner_amd import scenarios as sc
@@ -378,14 +380,14 @@ def test_warm_start_after_an_unconverged_step_saves_iterations_and_moves_nothing
     car_t = sc.rectangle_robot(dynamics="acker")
     path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
-    obstacles = sc.scene_polygons(80, lo=(8, 12), hi=(40, 38), seed=sc.SEED + 31, keep_clear=clear, clear_radius=3.2)
+    obstacles = sc.scene_polygons(200, lo=(8, 10), hi=(40, 40), seed=sc.SEED, keep_clear=clear, clear_radius=3.2)      # (the north-star scene)
 
-    def loop(order, hard):
+    def loop(order, hard, iter_num=4, steps=40):
         orc.lib.orc_set_su_hard_warm(*hard)
-        m = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, receding=15, iter_num=4, max_edge_num=4, max_obs_num=80,
+        m = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, receding=20, iter_num=iter_num, max_edge_num=4, max_obs_num=200,
                 ro1=200, obstacle_order=order, _backend=oracle_backend)
         st, us, ipm, its = path[0].copy().reshape(3, 1), [], 0, 0
-        for k in range(30):
+        for k in range(steps):
             u, info = m.control(st, 4.0, list(obstacles))
             assert info["status"] == 0
             us.append(u.ravel().copy()); ipm += info["su_ipm_iters"]; its += info["iters"]
@@ -396,9 +398,12 @@ def test_warm_start_after_an_unconverged_step_saves_iterations_and_moves_nothing
         u1, ipm1, its1 = loop(True, (1.0, 1e-3))
         f0, fi0, _ = loop(False, (0.0, 0.0))
         f1, fi1, _ = loop(False, (1.0, 1e-3))
+        g0, gi0, _ = loop(False, (0.0, 0.0), iter_num=1, steps=25)          # every step 'unconverged' (one ADMM iteration), every su-problem easy
+        g1, gi1, _ = loop(False, (1.0, 1e-3), iter_num=1, steps=25)
     finally:
         orc.lib.orc_set_su_hard_warm(0.0, 0.0)
-    print(f"re-sorted loop: {ipm0} -> {ipm1} interior-point iterations over 30 steps ({its0} / {its1} ADMM iterations), max |du| {np.abs(u0 - u1).max():.1e}")
-    assert its0 == its1 and ipm1 <= 0.85 * ipm0, (ipm0, ipm1)
+    print(f"re-sorted loop: {ipm0} -> {ipm1} interior-point iterations over 40 steps ({its0} / {its1} ADMM iterations), max |du| {np.abs(u0 - u1).max():.1e}")
+    assert its0 == its1 and ipm1 <= 0.9 * ipm0, (ipm0, ipm1)
     assert np.abs(u0 - u1).max() <= 1e-4
     assert fi0 == fi1 and np.array_equal(f0, f1)
+    assert gi1 <= 1.1 * gi0 and np.abs(g0 - g1).max() <= 1e-4, (gi0, gi1)        # not locked out (1.0 -> 3.0 iterations per solve without the second key)
