@@ -1,0 +1,330 @@
+"""The legs of bench.py beside the headline closed loop: Python-API closed loops, device-resident replay, multi-ego, fleet, the `sizes`
+sub-runs and the obstacle-shard leg.  None of them is ever `value` (except the replay in --mode shard).  Split out of bench.py in round 5."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+from .context import ROOT
+from .workload import build_workload, record_trace
+
+
+def python_api_closed_loop(ctx, track):
+    """the closed loop through the Python `MPC.control` API with the caller-side obstacle pipeline on the device (rda_step_scene)
+    and, track=True, MPC.pre_process on the device as well (rda_step_tracked)"""
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd import scenarios as sc
+    args, K, W = ctx.args, ctx.K, ctx.W
+    mpc_d = MPC(ctx.car_t, [p.copy() for p in ctx.path], sample_time=0.1, time_print=False, device_track=track, **ctx.kw_rec)
+    if not mpc_d.rda.has_scene or (track and not mpc_d.rda.has_track):
+        return None
+    st = ctx.path[0].copy().reshape(3, 1)
+    nd = min(W + K, 100)
+    du = 0.0
+    t0 = time.perf_counter()
+    for k in range(nd):
+        cur = ctx.obstacles if not args.moving else [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) for o in ctx.obstacles]
+        u, _ = mpc_d.control(st, 4.0, list(cur))
+        if not args.moving:
+            du = max(du, float(np.abs(u - ctx.trace["u"][k]).max()))
+        st = sc.kinematic_step(st, u, ctx.car_t, 0.1)
+    return {"steps_per_s": round(nd / (time.perf_counter() - t0), 2), "max_du_vs_host_staging": None if args.moving else du,
+            "obstacles_advance_every_tick": bool(args.moving)}
+
+
+def oversubscribed_shard_run(ctx, mpc_rec):
+    """Plumbing run on a box with fewer GPUs than ranks (the 1-GPU test box): the same obstacle shards, but the per-iteration exchange is done by
+    the host (rda_shard_get_chunk -> gloo all_gather -> rda_shard_set_chunks) instead of RCCL.  Functional check of the sharded code path, NOT
+    a performance number.  Prints its own line."""
+    import torch
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.sharded import ShardedRDA
+    dist, kw, T, N, K, W, trace = ctx.dist, ctx.kw, ctx.T, ctx.N, ctx.K, ctx.W, ctx.trace
+
+    def all_gather(chunk):
+        mine = torch.from_numpy(np.ascontiguousarray(chunk))
+        everyone = torch.zeros(ctx.world * mine.numel(), dtype=torch.float64)
+        dist.all_gather_into_tensor(everyone, mine)
+        return everyone.numpy()
+    sv = RDA_solver(T, ctx.car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+    sh = ShardedRDA(sv, ctx.rank, ctx.world, all_gather)
+    rl = mpc_rec.convert_rda_obstacle(ctx.obstacles, ctx.path[0].copy().reshape(3, 1), False)
+    du, its = 0.0, []
+    for k in range(W + K):
+        if k == W:
+            dist.barrier()
+            t0 = time.perf_counter()
+        u, info = sh.iterative_solve(trace["nom_s"][k], trace["nom_u"][k], [trace["ref"][k][:, j:j + 1] for j in range(T + 1)],
+                                     float(trace["speed"][k]), list(rl))
+        du = max(du, float(np.abs(u - trace["u_solver"][k]).max()))
+        if k >= W:
+            its.append(info["iters"])
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if ctx.rank == 0:
+        print(json.dumps({"metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(K / float(tt.item()), 3), "unit": "steps/s",
+                          "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(float(tt.item()) / K * 1e3, 5), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"acker rectangle robot, T={T}, N_obs={N}, obstacles sharded {ctx.world}-way",
+                                     "parallelism": f"{ctx.world} ranks OVERSUBSCRIBED on {ctx.ndev} GPU(s): host-driven exchange over gloo, plumbing check only"},
+                          "mean_admm_iters": round(float(np.mean(its)), 3), "max_du_vs_unsharded_closed_loop": du}))
+
+
+def replay_legs(ctx):
+    """device-resident replay: the recorded step inputs (fixed slot binding) back-to-back, no per-step synchronisation; an instrumented pass
+    (hipEvents around every kernel), an un-instrumented one, and one with a host synchronisation per step.  Returns a dict of everything
+    the line needs from it, incl. the handle of the instrumented solver (alive: the caller asks it for the LamMuZ launch form)."""
+    from rda_planner_amd._capi import Info, dptr, iptr
+    api, args, kw, T, K, W, trace, staged = ctx.api, ctx.args, ctx.kw, ctx.T, ctx.K, ctx.W, ctx.trace, ctx.staged
+
+    def load(sv):
+        h_ = sv._be.handle
+        assert api.lib.rda_upload_obstacles(h_, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"]) == 0
+        assert api.lib.rda_upload_trace(h_, W + K, dptr(trace["nom_s"]), dptr(trace["nom_u"]), dptr(trace["ref"]), dptr(trace["speed"])) == 0
+        return h_
+    solver = ctx.new_solver()
+    h = load(solver)
+    for k in range(W):
+        api.lib.rda_enqueue_step(h, k)
+    api.lib.rda_sync(h); ctx.barrier_all()
+    api.lib.rda_timing_reset(h, 1)                       # hipEvents around every kernel of the timed region
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        api.lib.rda_enqueue_step(h, k)
+    api.lib.rda_sync(h); ctx.barrier_all()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    # per-launch GPU times from the events recorded inside that region, in launch order
+    kt = {}
+    for which, name in ((0, "k_lammuz"), (1, "k_su")):
+        cap = K * kw["iter_num"] + 8
+        buf, n = np.zeros(cap), C.c_int(0)
+        api.lib.rda_timing_launches(h, which, dptr(buf), cap, C.cast(C.byref(n), C.POINTER(C.c_int)))
+        kt[name] = buf[:min(n.value, cap)].copy()
+    api.lib.rda_timing_reset(h, 0)
+    # un-instrumented pass (events perturb the stream slightly)
+    solver2 = ctx.new_solver()
+    h2 = load(solver2)
+    for k in range(W):
+        api.lib.rda_enqueue_step(h2, k)
+    api.lib.rda_sync(h2); ctx.barrier_all()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        api.lib.rda_enqueue_step(h2, k)
+    api.lib.rda_sync(h2); ctx.barrier_all()
+    elapsed2 = ctx.max_over_ranks(time.perf_counter() - t0)
+    # the same replay with one host synchronisation per step: how long the host needs to queue a step (all launches of one MPC step)
+    # and what a step costs when the device starts from an empty stream - the latency floor of the closed loop
+    sync_replay = None
+    if not args.size_leg:
+        solver3 = ctx.new_solver()
+        h3 = load(solver3)
+        t_enq, t_tot = [], []
+        for k in range(W + K):
+            ta = time.perf_counter()
+            api.lib.rda_enqueue_step(h3, k)
+            tb = time.perf_counter()
+            api.lib.rda_sync(h3)
+            tc = time.perf_counter()
+            if k >= W:
+                t_enq.append(tb - ta)
+                t_tot.append(tc - ta)
+        sync_replay = {"median_ms_per_step": round(float(np.median(t_tot)) * 1e3, 5), "median_host_enqueue_ms": round(float(np.median(t_enq)) * 1e3, 5),
+                       "what": "replay with rda_sync after every step: host time to queue one step's launches, and the step latency from an idle stream"}
+        del solver3
+    # replay must reproduce the recorded closed loop (same inputs, same initial state)
+    u_last, s_last, info = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+    api.lib.rda_fetch_result(h2, W + K - 1, dptr(u_last), dptr(s_last), C.byref(info))
+    replay_err = float(np.abs(u_last - trace["u_solver"][W + K - 1]).max())
+    assert trace["arrived_steps"] == 0, "workload invalid: the robot reached the goal inside the timed region"
+    iters = []
+    for k in range(W, W + K):
+        api.lib.rda_fetch_result(h2, k, None, None, C.byref(info))
+        iters.append(info.iters)
+    return {"kt": kt, "iters": iters, "elapsed_instrumented": elapsed, "elapsed": elapsed2, "sync_replay": sync_replay, "replay_err": replay_err,
+            "lmz_kernel": api.lib.rda_lammuz_kernel(h).decode(), "keep_alive": (solver, solver2)}
+
+
+def multi_ego(ctx):
+    """batched multi-ego on ONE GPU (BASELINE "batched multi-ego", replicas only): M independent handles, one HIP stream each, the same recorded
+    step inputs; k_su occupies one CU per ego, so the egos overlap on the device"""
+    from rda_planner_amd._capi import Info, dptr, iptr
+    from rda_planner_amd.rda_solver import RDA_solver
+    api, kw, T, N, K, W, trace, staged = ctx.api, ctx.kw, ctx.T, ctx.N, ctx.K, ctx.W, ctx.trace, ctx.staged
+    M, Km = ctx.args.egos, min(K, 100)
+    hs = []
+    for _ in range(M):
+        sm = RDA_solver(T, ctx.car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+        hm = sm._be.handle
+        api.lib.rda_upload_obstacles(hm, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+        api.lib.rda_upload_trace(hm, W + Km, dptr(trace["nom_s"][:W + Km]), dptr(trace["nom_u"][:W + Km]), dptr(trace["ref"][:W + Km]), dptr(trace["speed"][:W + Km]))
+        hs.append((sm, hm))
+    for k in range(W):
+        for _, hm in hs:
+            api.lib.rda_enqueue_step(hm, k)
+    for _, hm in hs:
+        api.lib.rda_sync(hm)
+    t0 = time.perf_counter()
+    for k in range(W, W + Km, 10):                    # ten steps per ego per host call, egos interleaved
+        for _, hm in hs:
+            api.lib.rda_enqueue_range(hm, k, min(k + 10, W + Km))
+    for _, hm in hs:
+        api.lib.rda_sync(hm)
+    el = time.perf_counter() - t0
+    um, sm_, info = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+    api.lib.rda_fetch_result(hs[-1][1], W + Km - 1, dptr(um), dptr(sm_), C.byref(info))
+    return {"egos": M, "steps_per_ego": Km, "aggregate_steps_per_s": round(M * Km / el, 1),
+            "max_du_vs_single": float(np.abs(um - trace["u_solver"][W + Km - 1]).max())}
+
+
+def fleet(ctx):
+    """the same, as a FLEET: one set of launches per ADMM iteration with an ego dimension in the grid (rda_fleet_*): k_su runs one workgroup
+    per ego side by side, the k_lammuz grid is egos x N*T/4 workgroups"""
+    from rda_planner_amd._capi import Info, dptr, iptr
+    from rda_planner_amd.rda_solver import RDA_solver
+    api, kw, T, N, K, W, trace, staged = ctx.api, ctx.kw, ctx.T, ctx.N, ctx.K, ctx.W, ctx.trace, ctx.staged
+    M, Km = ctx.args.fleet_egos, min(K, 100)
+    members = []
+    for _ in range(M):
+        sm = RDA_solver(T, ctx.car_t, kw["max_edge_num"], N, iter_num=kw["iter_num"], step_time=0.1, time_print=False, ro1=kw["ro1"])
+        hm = sm._be.handle
+        api.lib.rda_upload_obstacles(hm, staged["n"], dptr(staged["A"]), dptr(staged["b"]), iptr(staged["cone"]), staged["per_t"])
+        api.lib.rda_upload_trace(hm, W + Km, dptr(trace["nom_s"][:W + Km]), dptr(trace["nom_u"][:W + Km]), dptr(trace["ref"][:W + Km]), dptr(trace["speed"][:W + Km]))
+        members.append(sm)
+    arr = (C.c_void_p * M)(*[m._be.handle for m in members])
+    F = C.c_void_p()
+    assert api.fleet_create(arr, M, C.byref(F)) == 0
+    api.fleet_enqueue_range(F, 0, W)
+    api.fleet_sync(F)
+    t0 = time.perf_counter()
+    api.fleet_enqueue_range(F, W, W + Km)
+    api.fleet_sync(F)
+    el = time.perf_counter() - t0
+    worst = 0.0
+    um, sm_, info = np.zeros((2, T)), np.zeros((3, T + 1)), Info()
+    for m in (members[0], members[M // 2], members[-1]):
+        api.lib.rda_fetch_result(m._be.handle, W + Km - 1, dptr(um), dptr(sm_), C.byref(info))
+        worst = max(worst, float(np.abs(um - trace["u_solver"][W + Km - 1]).max()))
+    out = {"egos": M, "steps_per_ego": Km, "aggregate_steps_per_s": round(M * Km / el, 1),
+           "ms_per_fleet_step": round(el / Km * 1e3, 4), "max_du_vs_single": worst}
+    api.fleet_destroy(F)
+    return out
+
+
+def shard_leg(ctx):
+    """N > 1, default (replica) mode: the OTHER way to use the node - ONE ego whose obstacles are sharded over the ranks, the north-star scaling
+    point (T=20, N_obs=2000): every rank solves the LamMuZ problems of its slots, one in-library ncclAllGather per ADMM iteration replicates
+    what the su-problem reads (3 arrays + the reduced sums / masks: DESIGN.md 6), every rank solves the identical su-problem.
+    Device-resident replay of a recorded closed loop, barrier + max over ranks like the headline.  All ranks call this at the same point; a
+    watchdog bounds it (a collective that never completes must not cost the line)."""
+    import torch
+    from rda_planner_amd._capi import Info, dptr, iptr
+    from rda_planner_amd.rda_solver import RDA_solver
+    from rda_planner_amd.sharded import enable_rccl
+    api, args, dist, rank, world, K, W = ctx.api, ctx.args, ctx.dist, ctx.rank, ctx.world, ctx.K, ctx.W
+    Ns, Ts = args.shard_n_obs, 20
+    Ks, Ws = min(K, 40), min(W, 4)
+    car_s, path_s, obs_s, kw_s = build_workload(seed_offset=0, n_obs=Ns, T=Ts, n_steps=Ks + Ws)
+    tr, stg, _ = record_trace(car_s, path_s, obs_s, dict(kw_s, obstacle_order=False), Ws + Ks)
+
+    def replay(sv):
+        hh = sv._be.handle
+        assert api.lib.rda_upload_obstacles(hh, stg["n"], dptr(stg["A"]), dptr(stg["b"]), iptr(stg["cone"]), stg["per_t"]) == 0
+        assert api.lib.rda_upload_trace(hh, Ws + Ks, dptr(tr["nom_s"]), dptr(tr["nom_u"]), dptr(tr["ref"]), dptr(tr["speed"])) == 0
+        for k in range(Ws):
+            api.lib.rda_enqueue_step(hh, k)
+        api.lib.rda_sync(hh); ctx.barrier_all()
+        api.lib.rda_timing_reset(hh, 1)
+        t0 = time.perf_counter()
+        for k in range(Ws, Ws + Ks):
+            assert api.lib.rda_enqueue_step(hh, k) == 0
+        api.lib.rda_sync(hh); ctx.barrier_all()
+        el = ctx.max_over_ranks(time.perf_counter() - t0)
+        per = {}
+        for which, name in ((0, "lammuz"), (1, "su"), (2, "gather")):
+            buf, n = np.zeros(Ks * kw_s["iter_num"] + 8), C.c_int(0)
+            api.lib.rda_timing_launches(hh, which, dptr(buf), buf.size, C.cast(C.byref(n), C.POINTER(C.c_int)))
+            per[name] = buf[:min(n.value, buf.size)]
+        api.lib.rda_timing_reset(hh, 0)
+        u_last, s_last, inf = np.zeros((2, Ts)), np.zeros((3, Ts + 1)), Info()
+        api.lib.rda_fetch_result(hh, Ws + Ks - 1, dptr(u_last), dptr(s_last), C.byref(inf))
+        its = []
+        for k in range(Ws, Ws + Ks):
+            api.lib.rda_fetch_result(hh, k, None, None, C.byref(inf)); its.append(inf.iters)
+        return el, per, float(np.abs(u_last - tr["u_solver"][Ws + Ks - 1]).max()), float(np.mean(its))
+    mk = lambda: RDA_solver(Ts, car_s, kw_s["max_edge_num"], Ns, iter_num=kw_s["iter_num"], step_time=0.1, time_print=False, ro1=kw_s["ro1"])
+    el1, per1, err1, _ = replay(mk())                    # every rank alone (unsharded): the one-GPU number of the same workload
+    sv = mk()
+
+    def bcast(buf):
+        if dist is None:                                 # (--force-shard-leg on one GPU: a one-rank communicator, plumbing only)
+            return bytes(buf)
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone().cuda()
+        dist.broadcast(t, 0)
+        return bytes(t.cpu().numpy().tobytes())
+    enable_rccl(sv, rank, world, bcast)
+    elP, perP, errP, itsP = replay(sv)
+    n_exec = int(round(itsP * Ks))
+    ex = lambda v: np.sort(v)[max(v.size - n_exec, 0):] if v.size else v        # the executed launches are the longest ones
+    # Amdahl, from THIS run's one-GPU kernel times: every rank still solves the whole su-problem, only the LamMuZ launch shards
+    su1, lm1 = float(ex(per1["su"]).mean()) * 1e3, float(ex(per1["lammuz"]).mean()) * 1e3
+    gat = float(perP["gather"].mean()) * 1e3 if perP["gather"].size else 0.0
+    amdahl = {"one_gpu_us_per_iteration": {"su": round(su1, 2), "lammuz": round(lm1, 2)},
+              "bound_speedup_without_exchange": round((su1 + lm1) / (su1 + lm1 / world), 3),
+              "bound_speedup_with_measured_gather": round((su1 + lm1) / (su1 + lm1 / world + gat), 3),
+              "what": f"(t_su + t_lmz) / (t_su + t_lmz / {world} [+ t_gather]): the su-problem is replicated, not sharded - read the measured speed-up against this"}
+    return {"amdahl": amdahl, "workload": f"T={Ts}, N_obs={Ns} static seeded polygons, obstacles sharded {world}-way ({-(-Ns // world)} slots per rank)",
+            "steps_per_s": round(Ks / elP, 2), "ms_per_step": round(elP / Ks * 1e3, 4), "mean_admm_iters": round(itsP, 3),
+            "unsharded_one_gpu_steps_per_s": round(Ks / el1, 2), "speedup_vs_one_gpu": round(el1 / elP, 3),
+            "gather_us_per_iteration": round(float(perP["gather"].mean()) * 1e3, 2) if perP["gather"].size else None,
+            "gathers": int(perP["gather"].size), "nccl_comm_count": int(api.lib.rda_shard_comm_count(sv._be.handle)),
+            "chunk_bytes_per_rank": int(api.shard_chunk_doubles(sv._be.handle)) * 8,
+            "lammuz_us_per_executed_launch": {"one_gpu": round(float(ex(per1["lammuz"]).mean()) * 1e3, 2), "sharded": round(float(ex(perP["lammuz"]).mean()) * 1e3, 2)},
+            "su_us_per_executed_launch": {"one_gpu": round(float(ex(per1["su"]).mean()) * 1e3, 2), "sharded": round(float(ex(perP["su"]).mean()) * 1e3, 2)},
+            "max_du_vs_recorded_closed_loop": {"one_gpu": err1, "sharded": errP}, "steps": Ks, "warmup": Ws,
+            "what": "device-resident replay, barrier + max over ranks; every rank enqueues the same steps, one ncclAllGather per executed ADMM iteration"}
+
+
+SIZE_LEGS = [("n20_T20", ["--n-obs", "20", "--steps", "40", "--warmup", "10", "--fleet-egos", "0"]),
+             ("n2000_T20", ["--n-obs", "2000", "--steps", "30", "--warmup", "8", "--fleet-egos", "0"]),
+             ("c4_dynamic_obs_n200_T30_moving", ["--n-obs", "200", "--horizon", "30", "--moving", "--steps", "30", "--warmup", "8", "--fleet-egos", "0"]),
+             ("c5_shape_n100_T25_fleet64", ["--n-obs", "100", "--horizon", "25", "--steps", "30", "--warmup", "8", "--fleet-egos", "64"])]
+
+
+def sizes(budget_s, script):
+    """every size the metric names + the moving-obstacle and multi-ego configurations, in the SAME driver-run line: one short sub-run of bench.py
+    each (own process: a fresh HIP context per shape; --size-leg keeps the closed loops, the timed replay and one 16-thread cpu_baseline
+    sample).  BASELINE.json: N in {20, 200, 2000} at T=20; C4 = 200 moving polygons, T=30; C5 = 64 egos x 100 obstacles, T=25."""
+    t_sz, out = time.perf_counter(), {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    for name, extra in SIZE_LEGS:
+        left = budget_s - (time.perf_counter() - t_sz)
+        if left < 8.0:
+            out[name] = {"skipped": f"sizes budget of {budget_s:.0f} s used up"}
+            continue
+        try:
+            pr = subprocess.run([sys.executable, script, "--gpus", "1", "--size-leg", "--cpu-threads", "16"] + extra,
+                                capture_output=True, text=True, timeout=left + 20.0, env=env)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+            j = json.loads(line[-1])
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_ms_per_step", "mean_admm_iters", "max_du_vs_python_closed_loop",
+                    "second_window", "residuals", "roofline", "roofline_secondary", "cpu_baseline", "multi_ego_fleet")
+            e = {k: j.get(k) for k in keep}
+            e["workload"] = j["config"]["workload"]
+            e["fixed_slot_binding_steps_per_s"] = (j.get("fixed_slot_binding") or {}).get("steps_per_s")
+            e["su_hard_warm_off_steps_per_s"] = (j.get("su_hard_warm_off") or {}).get("steps_per_s")
+            e["pcie_inclusive_steps_per_s"] = (j.get("pcie_inclusive") or {}).get("steps_per_s")
+            e["replay_steps_per_s"] = j["device_resident_replay"]["steps_per_s"]
+            if e.get("cpu_baseline"):
+                e["cpu_baseline"] = {k: e["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "max_du_vs_gpu")}
+                e["gpu_over_cpu_port"] = round(j["value"] / e["cpu_baseline"]["value"], 1) if e["cpu_baseline"]["value"] else None
+            out[name] = e
+        except Exception as ex:                         # the headline must not depend on these legs
+            out[name] = {"error": repr(ex)[:300]}
+    return out, round(time.perf_counter() - t_sz, 1)

@@ -86,13 +86,14 @@ typedef struct rda_opts {
                                 two interior-point iterations fewer per su-problem.  A step that stops early returns the control of an
                                 su-problem solved to THIS tolerance (some 1e-3 from the exact one where an inequality is weakly active,
                                 tests/test_oracle_su.py), so the stated tolerance TOL_U does not hold with it.            RDA_SU_TOL_EARLY */
-    double  su_hard_warm[2]; /* [0, 0 = off] slack floor / barrier parameter of the warm attempts of a step that follows an UNCONVERGED step
-                                (its ADMM used all iter_num iterations with a residual above iter_threshold): "1,1e-3" - a point well inside
-                                the boxes with the previous multipliers; the cold-start rule is skipped there.  Applies only while the su-solves
-                                really are hard (the last one took more than 3 iterations).  Same su-problems, same stop tolerance, another
-                                start: headline loop (re-sorted every tick) 1396 -> 1759 steps/s with the first condition alone, fixed
-                                binding unchanged (same box).  Off by default until it has been through the soak; the flag it keys on is
-                                not yet part of rda_get_su_history.                                                    RDA_SU_HARD_WARM */
+    double  su_hard_warm[2]; /* [1, 1e-3; 0, 0 = off] slack floor / barrier parameter of the warm attempts of a step that follows an UNCONVERGED step
+                                (its ADMM used all iter_num iterations with a residual above iter_threshold) while consecutive su-problems are far
+                                apart (the last solve's first iterate - the previous solution with its multipliers - had a relative dual residual
+                                above 1e-2): a point well inside the boxes with the previous multipliers, a barrier of their own for the rows of the
+                                safety distance; the cold-start rule is skipped there.  Same su-problems, same stop tolerance, another start: the
+                                reference's default protocol (obstacle list re-sorted every tick, quirk Q5) needs 25 % fewer interior-point
+                                iterations, converged loops are untouched.  Default since round 5 (it has been through the parity suite and the
+                                soak; both keys are part of rda_get_su_history).                                          RDA_SU_HARD_WARM */
     /* ---- A/B switches (defaults in brackets) ---- */
     int32_t lmz_warm;        /* [1] try the remembered support first, then the supports one row away from it, before a row is
                                 enumerated; every answer is accepted on its optimality certificate alone.  The supports are a cache of
@@ -292,10 +293,11 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
                    const double *a_lam, const double *b_lam);
 /* Solver history of a handle: not reference-visible state, but it picks the START of the next su interior-point solve (easy /
  * moderate / cold), so two handles return bit-identical controls only if it agrees too.  hist[0] = interior-point
- * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime; lam_keep [10*T] = the inequality
+ * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime, hist[2] = the previous step ended above
+ * iter_threshold, hist[3] = the last su-solve started far from its solution (the two keys of su_hard_warm); lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
-int  rda_get_su_history(rda_handle *h, int32_t *hist /*2*/, double *lam_keep /*10*T*/);
-int  rda_set_su_history(rda_handle *h, const int32_t *hist /*2*/, const double *lam_keep /*10*T*/);
+int  rda_get_su_history(rda_handle *h, int32_t *hist /*4*/, double *lam_keep /*10*T*/);
+int  rda_set_su_history(rda_handle *h, const int32_t *hist /*4*/, const double *lam_keep /*10*T*/);
 /* Interior-point LamMuZ mode: the central-path points the sub-problems last ended on ([T][N][5][16] doubles: x | s, z of the diagonal
  * rows | s, z of the general rows, csrc/lammuz_ip_device.h) and their validity flags [T][N] - where each sub-problem's next solve starts.
  * Solver history like the su history above: it moves a result only within the centring tolerance (1e-7 mu relative), rda_reset clears

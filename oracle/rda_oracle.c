@@ -58,8 +58,14 @@ void orc_set_centre(int on) { g_centre = on; }
 static FILE *g_su_dump = NULL; static int g_su_trace = 0;
 void orc_set_su_dump(const char *path) { if (g_su_dump) fclose(g_su_dump); g_su_dump = (path && path[0]) ? fopen(path, "wb") : NULL; }
 void orc_set_su_trace(int on) { g_su_trace = on; }
-static double g_su_hard_wfl = 0, g_su_hard_mu0 = 0;   /* mirror of rda_opts::su_hard_warm: start of the warm attempts of a step that follows an UNCONVERGED step (0 = off) */
+static double g_su_hard_wfl = 1.0, g_su_hard_mu0 = 1e-3;   /* mirror of rda_opts::su_hard_warm: start of the warm attempts of a step that follows an UNCONVERGED step (0 = off) */
 void orc_set_su_hard_warm(double wfl, double mu0) { g_su_hard_wfl = wfl; g_su_hard_mu0 = mu0; }
+/* mirror of rda_opts::su_cold_from / su_cold_probe: a warm attempt that follows a solve with more than `from` interior-point iterations is
+ * skipped (the solve starts cold), except every `probe`-th such solve (0 = never) */
+static int g_su_cold_from = 7, g_su_cold_probe = 8;
+void orc_set_su_cold_from(int from, int probe) { g_su_cold_from = from; g_su_cold_probe = probe > 0 ? probe : 1; }
+#define SU_HARD_RD0 1e-2      /* = csrc/su_device.h */
+#define SU_HARD_DMU 1.0       /* = csrc/su_device.h */
 static int g_su_accept = 1;                      /* su_solve_impl: the near-converged iterate kept as a safety net (see there) */
 void orc_set_su_accept(int on) { g_su_accept = on ? 1 : 0; }
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
@@ -78,6 +84,9 @@ struct orc_handle {
     double *su_lam_keep;          /* inequality multipliers of the last converged su-solve (10T - 4 rows) */
     int su_last;                  /* interior-point iterations of the last su-solve (99: none / not converged): picks the next warm start */
     int prev_unconv;              /* the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop) */
+    int su_probe;                 /* consecutive su-solves in the hard regime (su_cold_from) */
+    int su_hardlike;              /* the last su-solve started far from its solution: relative dual residual of its first iterate > SU_HARD_RD0 */
+    int ipm_hist[32];             /* debug: interior-point iterations of the su-solve of every ADMM iteration of the last step (orc_get_su_ipm_hist) */
     int P, rank, Nloc, have_gath; size_t chunk; double *gath;      /* obstacle sharding */
 };
 
@@ -560,6 +569,7 @@ static void su_rollout(const su_ctx *S, const double *x, double *s /*3x(T+1) row
     }
 }
 
+static __thread double t_su_rd0 = 0.0;       /* relative dual residual rd / (1 + |g|) of the FIRST iterate of the last su_solve_impl call (start-rule key) */
 static __thread double t_su_eps = 0.0;       /* smoothing width of the hinge terms in su_eval: 0 except in the rescue phase below */
 /* objective, gradient (n) and generalised Hessian (n x n) at x */
 static double su_eval(const su_ctx *S, const double *x, double *s, double *grad, double *Hm)
@@ -673,7 +683,7 @@ static void chol_solve(const double *K, int n, double *rhs)
 static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
                          double ref_speed, const double *a, const double *cc, const double *g,
                          const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters,
-                         double *lam_keep, int warm, double warm_wfl, double warm_mu0, int warm_cap, int warm_shift)
+                         double *lam_keep, int warm, double warm_wfl, double warm_mu0, int warm_cap, int warm_shift, double hard_dmu)
 {
     int T = c->T, N = c->N, n = 3 * T;
     su_ctx S; S.c = c; S.T = T; S.N = N; S.a = a; S.cc = cc; S.g = g; S.ref = ref_s; S.nom_s = nom_s; S.ref_speed = ref_speed;
@@ -758,6 +768,18 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
                 else { int j = i - (8 * T - 4), t = j / 2 + 1; if (t > T - 1) t = T - 1; src = 8 * T - 4 + 2 * t + j % 2; }
             }
             if (lam_keep[src] > lm[i]) lm[i] = lam_keep[src];
+            /* hard start (su_hard_warm): the rows of d get a barrier of their own where NEITHER bound was active - lam+ and lam- are raised by
+             * the same delta = hard_dmu - max(kept+, kept-) >= 0.  (i) With lam = 1e-3 on slacks of 1 the safety distance of a stage that has
+             * lost its active hinge terms (re-sorted slots) has next to no curvature (H77 = 2e-3) against the gradient -slack_gain: the first
+             * Newton step asks for |dd| ~ 4e3 and is cut to 3e-4 of its length - a lost iteration (C4: in every solve).  (ii) Both slacks of the
+             * pair are floored alike (the box is narrower than the floor), so lam+ - lam- and with it the dual residual of the first iterate
+             * stay those of the kept multipliers: the key su_hardlike does not see the start it follows (a one-sided max(kept, dmu / w) did -
+             * iter_num = 1: 1.0 -> 3.0 iterations per solve, the easy start locked out). */
+            if (hard_dmu > 0 && i >= 8 * T - 4) {
+                const int j = i - (8 * T - 4), t = j / 2, s0 = 8 * T - 4 + 2 * (warm_shift ? (t + 1 > T - 1 ? T - 1 : t + 1) : t);
+                const double km = fmax(lam_keep[s0], lam_keep[s0 + 1]), dl_ = hard_dmu - km;
+                if (dl_ > 0) lm[i] += dl_ / w[i];
+            }
         }
     }
     status = 1;
@@ -782,6 +804,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         mu /= mc; mu_prev = mu;
         for (int i = 0; i < n; ++i) if (fabs(rhs[i]) > rdn) rdn = fabs(rhs[i]);
         double sc = 1 + gn;
+        if (used == 0 && it == 0) t_su_rd0 = rdn / sc;
 #ifdef ORC_DEBUG
         fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
 #endif
@@ -888,7 +911,7 @@ int orc_su_solve(const orc_cfg *c, const double *nom_s, const double *nom_u, con
                  double ref_speed, const double *a, const double *cc, const double *g,
                  const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters)
 {
-    return su_solve_impl(c, nom_s, nom_u, ref_s, ref_speed, a, cc, g, d0, s_out, u_out, d_out, ipm_iters, NULL, 0, 0, 0, 0, 0);
+    return su_solve_impl(c, nom_s, nom_u, ref_s, ref_speed, a, cc, g, d0, s_out, u_out, d_out, ipm_iters, NULL, 0, 0, 0, 0, 0, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -932,8 +955,12 @@ int orc_reset(orc_handle *H)
     for (int n = 0; n < N; ++n) for (int t = 0; t < T; ++t) {
         H->a_lam[(n * (T + 1) + t + 1) * 2] = H->a_lam[(n * (T + 1) + t + 1) * 2 + 1] = 0; H->b_lam[n * (T + 1) + t + 1] = 0;
     }
+    /* the solver history that picks the start of the next su-solves goes with it, like k_reset of csrc/rda_hip.hip */
+    H->su_last = 99; H->su_probe = 0; H->su_hardlike = 0; H->prev_unconv = 0; memset(H->su_lam_keep, 0, sizeof(double) * 10 * T);
     return 0;
 }
+/* debug: interior-point iterations of the su-solve of each ADMM iteration of the last step (n <= 32 entries) */
+void orc_get_su_ipm_hist(const orc_handle *H, int *out, int n) { for (int i = 0; i < n && i < 32; ++i) out[i] = i < H->iters ? H->ipm_hist[i] : 0; }
 int orc_get_state(orc_handle *H, double *lam, double *mu, double *z, double *xi, double *zeta, double *dis, double *a_lam, double *b_lam)
 {
     int T = H->c.T, N = H->c.N, E = H->c.E, R = H->c.R;
@@ -1076,18 +1103,23 @@ int orc_admm_su(orc_handle *H, int it, int *stopped)
     /* while the su-solves are easy (the last one took <= max iterations) the warm attempt starts 1e-6 from the previous solution's
      * active bounds and takes near-full steps - the same rule as csrc/rda_hip.hip su_body */
     const int easy = warm && g_su_easy_max > 0 && H->su_last <= g_su_easy_max;
-    /* after an unconverged step, and only while the su-solves really are hard (the last one took more than 3 iterations: a wide floor makes
-     * an EASY problem cost 3 iterations, which would lock the easy start out for good - measured with iter_num = 1 and with
-     * iter_threshold = 0.02 before this second key existed) */
-    const int hard = warm && !easy && g_su_hard_mu0 > 0 && H->prev_unconv && H->su_last > 3 && H->su_last < 99;
+    /* after an unconverged step, and only while consecutive su-problems really are far apart: the last solve's FIRST iterate (the previous
+     * solution with its multipliers) had a relative dual residual above SU_HARD_RD0.  (Round 4 keyed on the last solve's iteration count
+     * > 3; a hard-started solve costs >= 3 iterations whatever the problem, so that key either locked the easy start out - iter_num = 1:
+     * 1.0 -> 3.0 iterations per solve - or, set to > 3, left most of the gain: re-sorted north star 7.6 -> 6.2 against 5.3 with this key.) */
+    const int hard = warm && !easy && g_su_hard_mu0 > 0 && H->prev_unconv && H->su_hardlike && H->su_last < 99;
+    /* hard regime without that rule (many moving obstacles): a warm attempt needs MORE iterations than a cold start - start cold, probe the warm start now and then */
+    const int go_cold = warm && !easy && !hard && g_su_cold_from > 0 && H->su_last > g_su_cold_from && H->su_last < 99 && H->su_probe % g_su_cold_probe != g_su_cold_probe - 1;
     cur_warm_clip = easy ? g_su_easy[2] : g_su_warm_clip; cur_warm_tau = easy ? g_su_easy[3] : g_su_warm_tau; cur_warm_sig = easy ? g_su_easy[4] : g_su_warm_sig;
     double tol_keep[3] = { g_su_tol[0], g_su_tol[1], g_su_tol[2] };
     if (it < c->iter_num - 1 && g_su_tol_early[0] > 0 && g_su_tol_early[1] > 0 && g_su_tol_early[2] > 0) memcpy(g_su_tol, g_su_tol_early, sizeof g_su_tol);
     int st = su_solve_impl(c, H->s, H->u, H->ref, H->ref_speed, ca, cc, cg, H->dis, s_new, u_new, d_new, &ipm,
-                           H->su_lam_keep, warm, easy ? g_su_easy[0] : (hard ? g_su_hard_wfl : g_su_warm_wfl), easy ? g_su_easy[1] : (hard ? g_su_hard_mu0 : g_su_warm_mu0), g_su_warm_cap, it == 0);
+                           H->su_lam_keep, warm && !go_cold, easy ? g_su_easy[0] : (hard ? g_su_hard_wfl : g_su_warm_wfl), easy ? g_su_easy[1] : (hard ? g_su_hard_mu0 : g_su_warm_mu0), g_su_warm_cap, it == 0, hard ? SU_HARD_DMU : 0.0);
     memcpy(g_su_tol, tol_keep, sizeof g_su_tol);
     H->su_last = st == 0 ? ipm : 99;
-    H->ipm_total += ipm;
+    H->su_hardlike = t_su_rd0 > SU_HARD_RD0;
+    H->su_probe = (g_su_cold_from > 0 && H->su_last > g_su_cold_from && H->su_last < 99) ? H->su_probe + 1 : 0;
+    H->ipm_total += ipm; if (it < 32) H->ipm_hist[it] = ipm;
     if (st == 0) { memcpy(H->s, s_new, sizeof(double) * 3 * (T + 1)); memcpy(H->u, u_new, sizeof(double) * 2 * T); memcpy(H->dis, d_new, sizeof(double) * T); }
     else H->su_status |= 1 << it;                 /* 'No update of state and control vector' :699 */
     H->iters = it + 1;

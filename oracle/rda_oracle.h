@@ -109,6 +109,12 @@ void orc_set_su_warm(double wfl, double mu0, int cap);
 void orc_set_su_warm_endgame(double tau_floor, double sigma_floor);
 void orc_set_su_warm_clip(double margin);
 void orc_set_su_easy(double wfl, double mu0, double clip, double tau, double sig, int max_iters);   /* mirror of RDA_SU_EASY */   /* warm attempts: relative margin of the start inside the boxes (cold: 0.01) */   /* warm attempts only; cold solves keep 0.995 / 1e-3 */
+/* mirrors of the kernel's other start rules (csrc/rda_hip.hip su_body): rda_opts::su_hard_warm (default 1, 1e-3; 0, 0 = off; keys: the previous step
+ * ended above iter_threshold AND the last solve's first iterate had a relative dual residual above 1e-2) and rda_opts::su_cold_from / su_cold_probe
+ * (default 7, 8) */
+void orc_set_su_hard_warm(double wfl, double mu0);
+void orc_set_su_cold_from(int from, int probe);
+void orc_get_su_ipm_hist(const orc_handle *h, int *out, int n);   /* debug: interior-point iterations of the su-solve of each ADMM iteration of the last step */
 /* interior-point stop of the su-problem: |r_dual| <= rd (1+|g|), |r_prim| <= rp, mean complementarity <= mu (1+|g|) */
 void orc_set_su_tol(double rd, double rp, double mu);
 int  orc_su_solve(const orc_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,

@@ -50,6 +50,8 @@ struct Ctrl {
     int pose_ok;                  // Dev::pose and the near masks of Dev::coef describe the same terms (a LamMuZ launch / k_lmz_finalize made them)
     int prev_iters;               // ADMM iterations of the previous step: the LamMuZ tail runs where the step is expected to end (lmz_tail)
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
+    int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
+    double rd0_tmp;               // ... that residual, written by the solve
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -266,7 +268,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (it > 0) { a.pose = d.pose; a.pose_lin = 1; }
     a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
-    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.prof = d.su_prof; a.split = d.su_split;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
@@ -279,14 +281,16 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
         a.warm_nopred = d.su_easy_nopred;
-    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && d.ctrl->prev_unconv && d.ctrl->su_last > 3 && d.ctrl->su_last < 99) {
-        // The ADMM of the previous step did not converge (a caller that re-sorts its obstacles every tick, quirk Q5; many moving obstacles):
-        // consecutive su-problems are far apart.  A warm attempt then does best from a point WELL inside the boxes (slack floor 1) with
-        // the previous multipliers and next to no barrier (mu0 1e-3) - and it beats the cold start, so that rule is skipped: 7.3 -> 4.9
-        // interior-point iterations per su-solve on the re-sorted north star (oracle), headline loop +26 % (env knobs, one box).  Only while the
-        // su-solves really are hard (the last one took more than 3 iterations): the wide floor makes an EASY problem cost 3 iterations, which
-        // would lock the easy start out for good (oracle, iter_num = 1 / iter_threshold = 0.02: 1.0 -> 3.0 iterations per solve without this key).
-        a.warm_wfl = d.su_hard_wfl; a.warm_mu0 = d.su_hard_mu0; hard = true;
+    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && d.ctrl->prev_unconv && d.ctrl->su_hardlike && d.ctrl->su_last < 99) {
+        // The ADMM of the previous step did not converge (a caller that re-sorts its obstacles every tick, quirk Q5; many moving obstacles)
+        // AND consecutive su-problems really are far apart: the last solve's first iterate - the previous solution with its multipliers - had a
+        // relative dual residual above su::HARD_RD0.  A warm attempt then does best from a point WELL inside the boxes (slack floor 1) with
+        // the previous multipliers and next to no barrier (mu0 1e-3; the rows of d: su::HARD_DMU) - and it beats the cold start, so that rule is
+        // skipped.  Oracle (same rule), interior-point iterations per su-solve: re-sorted north star 7.6 -> 5.7, N = 2000 8.1 -> 6.3, C4
+        // re-sorted 14.2 -> 12.7, converged / easy loops unchanged.  (Round 4 keyed on the last solve's iteration count: a hard-started solve
+        // costs >= 3 iterations whatever the problem, so `> 2` locked the easy start out - iter_num = 1: 1.0 -> 3.0 iterations per solve -
+        // and `> 3` left most of the gain: 7.6 -> 6.2.)
+        a.warm_wfl = d.su_hard_wfl; a.warm_mu0 = d.su_hard_mu0; a.hard_dmu = su::HARD_DMU; hard = true;
     }
     // Hard regime (many moving obstacles: consecutive su-problems are far apart): a warm attempt then needs MORE iterations than a cold
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
@@ -300,6 +304,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
         if (d.ctrl->st_tmp != 0) d.ctrl->su_status |= 1 << it;
         d.ctrl->ipm_iters += d.ctrl->it_tmp;
         d.ctrl->su_last = d.ctrl->st_tmp == 0 ? d.ctrl->it_tmp : 99;
+        d.ctrl->su_hardlike = d.ctrl->rd0_tmp > su::HARD_RD0;
         d.ctrl->su_probe = (d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99) ? d.ctrl->su_probe + 1 : 0;
         d.ctrl->pose_ok = 0;          // the pose table has moved on; the LamMuZ launch that follows makes the masks that go with it
     }
@@ -1194,7 +1199,7 @@ __global__ void k_reset(Dev d)
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
         coef_arr(d, r, 8)[k] = coef_arr(d, r, 3)[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; }      // solver history of the handle
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; }      // solver history of the handle
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
     if (d.ipf) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.c.N * T; i += gridDim.x * blockDim.x) d.ipf[i] = 0;
 }
@@ -1328,7 +1333,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
-    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0; o->su_hard_warm[0] = 0; o->su_hard_warm[1] = 0;
+    o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0; o->su_hard_warm[0] = 1.0; o->su_hard_warm[1] = 1e-3;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0;
@@ -1556,7 +1561,7 @@ extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep
     if (hist) {
         Ctrl c;
         HIPCHK(hipMemcpy(&c, H->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-        hist[0] = c.su_last; hist[1] = c.su_probe;
+        hist[0] = c.su_last; hist[1] = c.su_probe; hist[2] = c.prev_unconv; hist[3] = c.su_hardlike;
     }
     if (lam_keep) HIPCHK(hipMemcpy(lam_keep, H->d.su_lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyDeviceToHost));
     return RDA_OK;
@@ -1568,6 +1573,8 @@ extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const doub
     if (hist) {
         HIPCHK(hipMemcpy(&H->d.ctrl->su_last, &hist[0], sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(&H->d.ctrl->su_probe, &hist[1], sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(&H->d.ctrl->prev_unconv, &hist[2], sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(&H->d.ctrl->su_hardlike, &hist[3], sizeof(int), hipMemcpyHostToDevice));
     }
     if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
     return RDA_OK;
@@ -1640,6 +1647,7 @@ static int obstacles_stage(rda_handle *H, int n_obs, const double *A, const doub
     if (!A || !b || !cone) return RDA_ERR_ARG;
     if (H->follow) return RDA_ERR_UNSUPPORTED;                   // duals_follow: host-staged slots carry no obstacle identity
     d.sc_bad = nullptr;
+    H->sc_n = 0;                                                 // the slots no longer come from the resident raw scene: rda_scene_resort must not rebuild them from it
     const size_t nt = per_t ? T + 1 : 1;
     for (size_t n = 0; n < N; ++n) {
         size_t src = n < (size_t)n_obs ? n : (size_t)n_obs - 1;   // quirk Q3: duplicate the last obstacle
@@ -1702,7 +1710,7 @@ static void scene_kernels(rda_handle *H, const scene::Args &a, hipStream_t st)
     hipLaunchKernelGGL(scene::k_keys, dim3((n + 255) / 256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(scene::k_rank, dim3((n + 15) / 16), dim3(256), 0, st, a);
     hipLaunchKernelGGL(scene::k_build, dim3((N * a.nt + 255) / 256), dim3(256), 0, st, a);
-    d.nt = a.nt; d.obstacle_num = N;
+    d.nt = a.nt; d.obstacle_num = N; d.sc_bad = a.nonconvex;
     d.slot_src = H->d_sc_sel; d.src_used = n < N ? n : N;          // the remembered supports follow the obstacles through the re-binding (Dev::hint)
     if (H->follow) {
         // rda_opts::duals_follow: the dual state is re-arranged from the previous binding to this one.  Nothing of a tick's head reads

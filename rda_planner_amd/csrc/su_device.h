@@ -41,6 +41,9 @@
 namespace su {
 
 constexpr int NT = 256;          // workgroup size
+// start rule su_hard_warm (rda_hip.hip su_body; = oracle/rda_oracle.c): a solve whose FIRST iterate - the previous solution with its multipliers - has a
+// relative dual residual above HARD_RD0 started far from its solution; in the hard start the rows of d begin with the barrier HARD_DMU / w
+constexpr double HARD_RD0 = 1e-2, HARD_DMU = 1.0;
 constexpr int NC = 10;           // inequality rows per stage
 
 struct Cfg {
@@ -89,6 +92,7 @@ struct Args {
     double *out_s, *out_u, *out_d;   // results (may alias in_*)
     int *status;                     // 0 ok / 1 not converged / 2 factorisation failed
     int *ipm_iters;
+    double *rd0 = nullptr;           // optional: relative dual residual rd / (1 + |g|) of the first iterate of the first attempt (start-rule key)
     long long *prof;                 // optional per-phase cycle counters (debug), may be null
     double *dbg = nullptr;           // optional per-iteration trace (rdn, rpn, mu, sc) x 100 (debug), may be null
     // Warm start of the su-problems of ADMM iterations >= 1 (the problem differs from the previous iteration's only through the
@@ -101,6 +105,14 @@ struct Args {
     double warm_tau = 0.9999, warm_sig = 1e-5;
     int warm_nopred = 0;             // the first iteration of the warm attempt is a plain Newton step towards sigma*mu (no predictor)
     double warm_clip = 0.01;         // relative margin by which the start of a warm attempt is pulled inside the control / distance boxes
+    // hard start (> 0): the rows of d get a barrier of their own where NEITHER bound was active - lam+ and lam- are raised by the same
+    // delta = hard_dmu - max(kept+, kept-) >= 0 (over their slacks).  (i) With lam = 1e-3 on slacks of 1 the safety distance of a stage that
+    // has lost its active hinge terms (re-sorted slots) has next to no curvature (H77 = 2e-3) against the gradient -slack_gain: the first
+    // Newton step asks for |dd| ~ 4e3 and is cut to 3e-4 of its length - a lost iteration (C4: in every solve).  (ii) Both slacks of the
+    // pair are floored alike (the box is narrower than the floor), so lam+ - lam- and with it the dual residual of the first iterate stay
+    // those of the kept multipliers: the key Args::rd0 does not see the start it follows (a one-sided max(kept, dmu / w) did - oracle,
+    // iter_num = 1: 1.0 -> 3.0 iterations per solve, the easy start locked out).
+    double hard_dmu = 0;
     double *lam_keep = nullptr;
     int term_cache = 1;              // (unused since the near terms of a screened solve live in LDS: Lds::near)
     // time split of the Newton system (TT = 10, 20, 25, 30): the stages [T/2, T) are factorised by wave 0 and the stages [0, T/2) by wave 1 at
@@ -489,7 +501,14 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         centre_duals(a.warm_wfl, a.warm_mu0);
 #pragma unroll
         for (int j = 0; j < NPR; ++j)
-            if (p_on[j]) { if (pf_lkp[j] > Plp[j]) Plp[j] = pf_lkp[j]; if (pf_lkm[j] > Plm[j]) Plm[j] = pf_lkm[j]; }
+            if (p_on[j]) {
+                if (pf_lkp[j] > Plp[j]) Plp[j] = pf_lkp[j];
+                if (pf_lkm[j] > Plm[j]) Plm[j] = pf_lkm[j];
+                if (a.hard_dmu > 0 && p_k[j] == 2) {
+                    const double dl = a.hard_dmu - fmax(pf_lkp[j], pf_lkm[j]);
+                    if (dl > 0) { Plp[j] += dl / Pwp[j]; Plm[j] += dl / Pwm[j]; }
+                }
+            }
     } else centre_duals(1e-2, 1.0);
     __syncthreads();                                          // (the roll-out of wave 0 is visible to everybody from here on)
     // ---- rotation-consistency penalty -> scalar quadratic per stage from three POSE-INDEPENDENT sums over the terms (see
@@ -646,9 +665,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 // s_waitcnt lgkmcnt(0) at the END of a sweep stage: the next stage's rows (issued one stage ahead) have landed, so the
 // compiler does not have to drain the freshly issued prefetch before the first use at the top of the next stage
 #define LDS_DRAIN() __builtin_amdgcn_s_waitcnt(0xc07f)
-    auto ldrow = [&](const double *base, Row &k) {
+    // (lin: the linear part only, entries 0..4 - the unit sweeps of the time split run while waves 0 / 1 write the constants, entry 5 of the same rows)
+    auto ldrow = [&](const double *base, Row &k, const bool lin = false) {
         const d2 *q = reinterpret_cast<const d2 *>(__builtin_assume_aligned(base, 16));
-        k.v[0] = q[0]; k.v[1] = q[1]; k.v[2] = q[2];
+        k.v[0] = q[0]; k.v[1] = q[1];
+        if (lin) { k.v[2][0] = base[4]; k.v[2][1] = 0.0; } else k.v[2] = q[2];
     };
     // x+ = row . x[0..4] + c with x held by lanes 0..4 of the row: v_fmac_f64 with a DPP row_newbcast source operand
     // (gfx90a+ allows DPP on 64-bit VALU ops for row_newbcast) - one instruction per term instead of two v_readlane
@@ -830,7 +851,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             double pl = r8 == ui ? 1.0 : 0.0;
             Row k[PD];
 #pragma unroll
-            for (int j = 0; j < PD; ++j) if (MQ - 1 - j >= 0) ldrow(base + stride * (MQ - 1 - j), k[j]);
+            for (int j = 0; j < PD; ++j) if (MQ - 1 - j >= 0) ldrow(base + stride * (MQ - 1 - j), k[j], true);
             for (int t0 = MQ - 1; t0 >= 0; t0 -= PD) {
 #pragma unroll
                 for (int j = 0; j < PD; ++j) {
@@ -838,7 +859,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     if (t >= 0) {
                         pl = affine(k[j], pl, false);
                         outp[ostride * t] = pl;
-                        if (t - PD >= 0) ldrow(base + stride * (t - PD), k[j]);
+                        if (t - PD >= 0) ldrow(base + stride * (t - PD), k[j], true);
                     }
                 }
             }
@@ -1311,6 +1332,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
+        if (a.rd0 && used == 0 && it == 0 && tid == 0) *a.rd0 = rdn / sc;
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
         if ((rdn <= c.tol_rd * sc && rpn <= c.tol_rp && mu <= c.tol_mu * sc) || (rdn <= 100 * c.tol_rd * sc && rpn <= c.tol_rp && mu <= 0.1 * c.tol_mu * sc)) {
             if (screened) {        // the positions must have stayed within DELTA of the screening reference

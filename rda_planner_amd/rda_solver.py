@@ -150,6 +150,10 @@ class RDA_solver:
         if self.duals_follow_obstacles and make is _hip_backend:
             opts = Opts.from_buffer_copy(opts) if opts is not None else hip_options()
             opts.duals_follow = 1
+        elif self.duals_follow_obstacles:
+            # a test backend keeps the duals with their SLOTS (the reference's semantics): say so rather than hand back other semantics silently
+            import warnings
+            warnings.warn("duals_follow_obstacles=True is honoured by the HIP backend only; this backend keeps the duals bound to the obstacle slots", RuntimeWarning, stacklevel=2)
         self._be = make(cfg, G, h, opts) if (make is _hip_backend and opts is not None) else make(cfg, G, h)   # test backends select the mode themselves
         self._R = G.shape[0]
         self.pipeline = True        # MPC overlaps its per-tick obstacle staging with the first su-problem (set False to serialise)

@@ -11,7 +11,8 @@ HIP-vs-oracle test (tests/helpers.py, where the reason for its size is written d
     applied control  |u_gpu - u_oracle|  <=  TOL_U = 5e-4   (speed, m/s; steering / yaw rate / heading, rad)
     whole horizon    2 x T controls       <=  TOL_U
     residuals        relative             <=  1e-4
-  (measured on THESE fixed scenes: <= 3e-5; the tests print their values with -s)
+  (measured on THESE fixed scenes: <= 3e-5, and what is ASSERTED on them is TOL_U_FIXED = 1e-4, so that a regression of the su kernel on
+   the BASELINE sizes cannot hide inside the randomised soak's bound; the tests print their values with -s)
     ADMM iteration counts equal on >= 95 % of the steps (the early-stop test `resi < 0.2` may flip when a residual
     sits within 1e-6 of the threshold).  A step on which the counts differ is NOT skipped: its applied control must agree
     to TOL_U_FLIP = 5e-2 (the two sides ended one ADMM iteration apart; below the stop threshold one more iteration moves
@@ -28,7 +29,7 @@ import pytest
 from rda_planner_amd import scenarios as sc
 from rda_planner_amd._capi import Info, dptr
 
-from helpers import TOL_U, TOL_U_FLIP
+from helpers import TOL_U, TOL_U_FIXED, TOL_U_FLIP
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +91,7 @@ def test_north_star_T20_N200_closed_loop_vs_cold_oracle(cold_orc):
     u0, u, res, same, flip = _closed_loop_vs_cold_oracle(car_t, path, obstacles, kw, 60)
     print(f"NS T=20 N=200, 60 steps: max |du0| {u0:.2e}, max |du| horizon {u:.2e}, residual {res:.2e}, same iteration count {same:.0%}, "
           f"max |du0| on the other steps {flip:.2e}")
-    assert u0 <= TOL_U and u <= TOL_U and res <= 1e-4 and same >= 0.95 and flip <= TOL_U_FLIP
+    assert u0 <= TOL_U_FIXED and u <= TOL_U_FIXED and res <= 1e-4 and same >= 0.95 and flip <= TOL_U_FLIP
 
 
 def test_north_star_every_iteration_vs_cold_oracle(cold_orc):
@@ -98,7 +99,7 @@ def test_north_star_every_iteration_vs_cold_oracle(cold_orc):
     car_t, path, obstacles, kw = _workload(200, 20, 40, iter_threshold=0.0)
     u0, u, res, same, flip = _closed_loop_vs_cold_oracle(car_t, path, obstacles, kw, 30)
     print(f"NS T=20 N=200, 30 steps x 4 iterations: max |du0| {u0:.2e}, max |du| horizon {u:.2e}, residual {res:.2e}")
-    assert same == 1.0 and u0 <= TOL_U and u <= TOL_U and res <= 1e-4
+    assert same == 1.0 and u0 <= TOL_U_FIXED and u <= TOL_U_FIXED and res <= 1e-4
 
 
 def test_c4_dynamic_obs_T30_N200_closed_loop_vs_cold_oracle(cold_orc):
@@ -107,7 +108,7 @@ def test_c4_dynamic_obs_T30_N200_closed_loop_vs_cold_oracle(cold_orc):
     u0, u, res, same, flip = _closed_loop_vs_cold_oracle(car_t, path, obstacles, kw, 24, advance=True)
     print(f"C4 T=30 N=200 moving, 24 steps: max |du0| {u0:.2e}, max |du| horizon {u:.2e}, residual {res:.2e}, same iteration count {same:.0%}, "
           f"max |du0| on the other steps {flip:.2e}")
-    assert u0 <= TOL_U and u <= TOL_U and res <= 1e-4 and same >= 0.9 and flip <= TOL_U_FLIP
+    assert u0 <= TOL_U_FIXED and u <= TOL_U_FIXED and res <= 1e-4 and same >= 0.9 and flip <= TOL_U_FLIP
 
 
 def test_c4_dynamic_obs_every_iteration_vs_cold_oracle(cold_orc):
@@ -115,7 +116,7 @@ def test_c4_dynamic_obs_every_iteration_vs_cold_oracle(cold_orc):
     car_t, path, obstacles, kw = _workload(200, 30, 40, moving=True, iter_threshold=0.0)
     u0, u, res, same, flip = _closed_loop_vs_cold_oracle(car_t, path, obstacles, kw, 12, advance=True)
     print(f"C4 T=30 N=200 moving, 12 steps x 4 iterations: max |du0| {u0:.2e}, max |du| horizon {u:.2e}, residual {res:.2e}")
-    assert same == 1.0 and u0 <= TOL_U and u <= TOL_U and res <= 1e-4
+    assert same == 1.0 and u0 <= TOL_U_FIXED and u <= TOL_U_FIXED and res <= 1e-4
 
 
 def test_scaling_point_T20_N2000_vs_cold_oracle(cold_orc):
@@ -123,7 +124,7 @@ def test_scaling_point_T20_N2000_vs_cold_oracle(cold_orc):
     u0, u, res, same, flip = _closed_loop_vs_cold_oracle(car_t, path, obstacles, kw, 20)
     print(f"S8 T=20 N=2000, 20 steps: max |du0| {u0:.2e}, max |du| horizon {u:.2e}, residual {res:.2e}, same iteration count {same:.0%}, "
           f"max |du0| on the other steps {flip:.2e}")
-    assert u0 <= TOL_U and u <= TOL_U and res <= 1e-4 and same >= 0.95 and flip <= TOL_U_FLIP
+    assert u0 <= TOL_U_FIXED and u <= TOL_U_FIXED and res <= 1e-4 and same >= 0.95 and flip <= TOL_U_FLIP
 
 
 def test_c5_fleet_64x100_T25_members_vs_cold_oracle(cold_orc, hip):
@@ -157,7 +158,7 @@ def test_c5_fleet_64x100_T25_members_vs_cold_oracle(cold_orc, hip):
             members[e]._dev_u = None
             states[e] = sc.kinematic_step(states[e], uc, scenes[e][0], 0.1)
     print(f"C5 64x100 T=25, {steps} fleet steps, all {B} members: max |du| {worst:.2e}, same iteration count {same}/{total}, max |du0| on the others {worst_flip:.2e}")
-    assert worst <= TOL_U and same >= 0.97 * total and worst_flip <= TOL_U_FLIP
+    assert worst <= TOL_U_FIXED and same >= 0.97 * total and worst_flip <= TOL_U_FLIP
     fleet.close()
 
 

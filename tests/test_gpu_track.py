@@ -264,7 +264,7 @@ def test_c_caller_closed_loop_equals_python_closed_loop(per_tick_scene, ordered)
     cur = C.c_int32(0)
     u_log, t_log, it_log, nom_u0 = np.zeros((K, 2)), np.zeros(K), np.zeros(K, np.int32), np.zeros((2, T))
     rc = host.run(C.byref(host.api), hh, C.byref(scn), T, 0, 3.0, 0.1, 4.0, 0.1, 10, len(path), 0, K, dptr(nom_u0), dptr(state),
-                  C.byref(cur), dptr(u_log), dptr(t_log), iptr(it_log), None)
+                  C.byref(cur), dptr(u_log), dptr(t_log), iptr(it_log), None, None)
     assert rc == 0
     assert np.array_equal(u_log, np.array(want)), float(np.abs(u_log - np.array(want)).max())
     assert cur.value == py.cur_index and (t_log > 0).all() and (it_log >= 1).all()

@@ -366,10 +366,11 @@ def test_end_game_lost_in_rounding_returns_the_near_converged_iterate(orc):
 
 
 def test_warm_start_after_an_unconverged_step_saves_iterations_and_moves_nothing(orc):
-    """mirror of rda_opts::su_hard_warm (opt-in): when the ADMM of the previous step did not converge (here: a caller that re-sorts its
+    """mirror of rda_opts::su_hard_warm (default since round 5): when the ADMM of the previous step did not converge (here: a caller that re-sorts its
     obstacle list every tick while the duals stay with their slots, quirk Q5), the warm attempts start from a point well inside the boxes
-    (slack floor 1) with the previous multipliers and mu0 = 1e-3 - while the su-solves really are hard (the last one took more than 3
-    iterations; without that second key a loop of EASY problems that merely runs out of ADMM iterations is locked out of its easy start).
+    (slack floor 1) with the previous multipliers and mu0 = 1e-3 - while consecutive su-problems really are far apart (the last solve's first
+    iterate had a relative dual residual above 1e-2; without that second key a loop of EASY problems that merely runs out of ADMM iterations
+    is locked out of its easy start: a hard-started solve costs three iterations whatever the problem).
     Same su-problems, same stop tolerance: fewer interior-point iterations,
     the controls of the closed loop within 1e-4; a loop whose steps converge never sees the rule (bit-identical)."""
     import ctypes as C
@@ -401,9 +402,9 @@ def test_warm_start_after_an_unconverged_step_saves_iterations_and_moves_nothing
         g0, gi0, _ = loop(False, (0.0, 0.0), iter_num=1, steps=25)          # every step 'unconverged' (one ADMM iteration), every su-problem easy
         g1, gi1, _ = loop(False, (1.0, 1e-3), iter_num=1, steps=25)
     finally:
-        orc.lib.orc_set_su_hard_warm(0.0, 0.0)
+        orc.lib.orc_set_su_hard_warm(1.0, 1e-3)
     print(f"re-sorted loop: {ipm0} -> {ipm1} interior-point iterations over 40 steps ({its0} / {its1} ADMM iterations), max |du| {np.abs(u0 - u1).max():.1e}")
-    assert its0 == its1 and ipm1 <= 0.9 * ipm0, (ipm0, ipm1)
+    assert its0 == its1 and ipm1 <= 0.85 * ipm0, (ipm0, ipm1)
     assert np.abs(u0 - u1).max() <= 1e-4
     assert fi0 == fi1 and np.array_equal(f0, f1)
-    assert gi1 <= 1.1 * gi0 and np.abs(g0 - g1).max() <= 1e-4, (gi0, gi1)        # not locked out (1.0 -> 3.0 iterations per solve without the second key)
+    assert gi1 <= 1.1 * gi0 and np.abs(g0 - g1).max() <= 1e-4, (gi0, gi1)        # not locked out (1.0 -> 3.0 iterations per solve with a key on the last solve's iteration count)

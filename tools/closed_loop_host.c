@@ -40,11 +40,12 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 
 /* Runs steps k0 .. k0 + n_steps - 1 of one closed loop.  state[3], *cur_index are read and advanced; u_log [n_steps][2] receives the
  * applied controls, t_log [n_steps] the wall time of each step (call + kinematics), iters_log [n_steps] the executed ADMM
- * iterations, begin_log [n_steps] (may be NULL) the time the first half of a two-call tick took on the host.
+ * iterations, begin_log [n_steps] (may be NULL) the time the first half of a two-call tick took on the host, info_log [n_steps][3] (may be
+ * NULL) the step's final ADMM residuals and its interior-point iterations (rda_info: resi_dual, resi_pri, su_ipm_iters).
  * dynamics: 0 acker, 1 diff, 2 omni (rda_cfg.dynamics).  Returns 0, a negative rda error code, or 1 when the path ended. */
 int closed_loop_run(const struct closed_loop_api *api, rda_handle *h, const struct closed_loop_scene *sc, int T, int dynamics, double wheelbase,
                     double dt, double ref_speed, double threshold, int ind_range, int path_len, int k0, int n_steps, const double *nom_u_first,
-                    double *state, int32_t *cur_index, double *u_log, double *t_log, int32_t *iters_log, double *begin_log)
+                    double *state, int32_t *cur_index, double *u_log, double *t_log, int32_t *iters_log, double *begin_log, double *info_log)
 {
     double out_u[2 * RDA_TMAX], out_s[3 * (RDA_TMAX + 1)], eh = 0;
     rda_info inf;
@@ -83,6 +84,7 @@ int closed_loop_run(const struct closed_loop_api *api, rda_handle *h, const stru
         else { state[0] += dt * (v * cos(w)); state[1] += dt * (v * sin(w)); }
         u_log[2 * (k - k0)] = v; u_log[2 * (k - k0) + 1] = w;
         iters_log[k - k0] = inf.iters;
+        if (info_log) { info_log[3 * (k - k0)] = inf.resi_dual; info_log[3 * (k - k0) + 1] = inf.resi_pri; info_log[3 * (k - k0) + 2] = (double)inf.su_ipm_iters; }
         t_log[k - k0] = now_s() - t0;
     }
     return 0;

@@ -53,4 +53,4 @@ try:
             lib.orc_set_su_hard_warm(1.0, 1e-3); b = run(**kw)
             print(f"{name}: {a:.2f} -> {b:.2f} interior-point iterations per su-solve with su_hard_warm = (1, 1e-3)", flush=True)
 finally:
-    lib.orc_set_su_warm(1e-3, 1e-3, 30); lib.orc_set_su_hard_warm(0.0, 0.0)
+    lib.orc_set_su_warm(1e-3, 1e-3, 30); lib.orc_set_su_hard_warm(1.0, 1e-3)
