@@ -68,9 +68,10 @@ typedef struct rda_handle rda_handle;
 
 enum { RDA_OK = 0, RDA_ERR_ARG = -1, RDA_ERR_UNSUPPORTED = -2, RDA_ERR_HIP = -3, RDA_ERR_NODEVICE = -4 };
 
-/* Solver options that are NOT arguments of the reference's constructor.  rda_opts_init fills the defaults below and then applies
- * the RDA_* environment overrides (DESIGN.md 7 lists them); a caller changes what it wants and hands the struct to rda_create_opts,
- * which copies it.  The first block is what a user may want to choose; the rest are the A/B switches of the kernels' restructurings -
+/* Solver options that are NOT arguments of the reference's constructor.  rda_opts_init fills the defaults below - and nothing else: the
+ * library reads no environment variable (round 5; the RDA_* names in the right-hand column are switches of the Python host package,
+ * rda_planner_amd.rda_solver.hip_options, which applies them to the struct it hands over).  A caller changes what it wants and hands the
+ * struct to rda_create_opts, which copies it.  The first block is what a user may want to choose; the rest are the A/B switches of the kernels' restructurings -
  * every one of them changes where / when work is done, never the result (tests/test_gpu_switches.py). */
 typedef struct rda_opts {
     int32_t lmz_mode;        /* 0 (default) support enumeration with the tie-breaks T1-T3 of DESIGN.md 2; 1 interior point ending on the
@@ -137,6 +138,12 @@ typedef struct rda_opts {
                                 (rda_upload_obstacles / rda_step: RDA_ERR_UNSUPPORTED) and an unsharded handle.  rda_get_state /
                                 rda_set_state speak the CURRENT slot order (rda_debug_slot_src tells which obstacle a slot holds); the
                                 kept central points of the interior-point LamMuZ mode are dropped for a re-bound slot.  RDA_DUALS_FOLLOW */
+    int32_t su_accept;       /* [1] safety net of the su interior point: the best iterate that is primal feasible to su_tol[1], dual feasible to
+                                10 x su_tol[0] and complementary to 1000 x su_tol[2] (the class the reference's solver stops at) is remembered; a
+                                solve whose every attempt then loses its end game in rounding (dual residual growing while the complementarity
+                                falls below 1e-15, factorisation breaking down: one oracle solve in 32 000 soak steps) returns it instead of
+                                'no update' (rda_solver.py:696-700).  Same rule as the oracle's orc_set_su_accept.  0: off; 2: test switch - every solve
+                                hands back its remembered iterate (the path is otherwise never taken)                     RDA_SU_ACCEPT */
     double  su_warm[2];      /* [1e-3, 1e-3] slack floor / barrier parameter of a warm start ("0,0" = always cold)      RDA_SU_WARM */
     double  su_warm_endgame[2]; /* [0.9999, 1e-5] floors of the fraction to the boundary / centering parameter, warm attempts  RDA_SU_WARM_ENDGAME */
     double  su_warm_clip;    /* [0.01]                                                                                  RDA_SU_WARM_CLIP */
@@ -357,6 +364,11 @@ int  rda_lammuz_batch(int B, int E, int R, const double *A, const double *b, con
 int  rda_su_solve(const rda_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
                   double ref_speed, const double *a, const double *cc, const double *g,
                   const double *d0, double *s, double *u, double *d, int32_t *ipm_iters);
+/* ... with the caller's rda_opts (NULL = rda_opts_init): su_tol, su_split, su_accept; su_prof = 1 prints the phase cycles, 2 also one line per
+ * interior-point iteration, on stderr */
+int  rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const double *nom_s, const double *nom_u, const double *ref_s,
+                       double ref_speed, const double *a, const double *cc, const double *g,
+                       const double *d0, double *s, double *u, double *d, int32_t *ipm_iters);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,7 @@ void orc_set_su_cold_from(int from, int probe) { g_su_cold_from = from; g_su_col
 #define SU_HARD_RD0 1e-2      /* = csrc/su_device.h */
 #define SU_HARD_DMU 1.0       /* = csrc/su_device.h */
 static int g_su_accept = 1;                      /* su_solve_impl: the near-converged iterate kept as a safety net (see there) */
-void orc_set_su_accept(int on) { g_su_accept = on ? 1 : 0; }
+void orc_set_su_accept(int on) { g_su_accept = on; }      /* 2: test switch - ALWAYS return the remembered iterate (= csrc/su_device.h Args::accept) */
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 
 struct orc_handle {
@@ -896,7 +896,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
     used += it;
     }
     /* every attempt failed: the safety net (see above) */
-    if (status != 0 && have_acc) { memcpy(x, x_acc, sizeof(double) * n); memcpy(lm, lm_acc, sizeof(double) * mc); status = 0; }
+    if ((status != 0 || g_su_accept == 2) && have_acc) { memcpy(x, x_acc, sizeof(double) * n); memcpy(lm, lm_acc, sizeof(double) * mc); status = 0; }
     if (ipm_iters) *ipm_iters = used;
     if (status == 0 && lam_keep) memcpy(lam_keep, lm, sizeof(double) * mc);
     su_rollout(&S, x, s);

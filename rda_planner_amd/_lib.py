@@ -78,6 +78,8 @@ def hip_api():
                                          c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double,
                                          C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
         lib.rda_su_solve.argtypes = [C.POINTER(Cfg)] + [c_double_p] * 3 + [C.c_double] + [c_double_p] * 7 + [c_int_p]
+        lib.rda_su_solve_opts.argtypes = [C.POINTER(Cfg), C.c_void_p] + [c_double_p] * 3 + [C.c_double] + [c_double_p] * 7 + [c_int_p]
+        lib.rda_su_solve_opts.restype = C.c_int
         for name in ("upload_trace", "enqueue_step", "sync", "fetch_result", "timing_reset",
                      "timing_read", "timing_launches", "lammuz_batch", "su_solve"):
             getattr(lib, "rda_" + name).restype = C.c_int

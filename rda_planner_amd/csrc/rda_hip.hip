@@ -79,6 +79,7 @@ struct Dev {
     double su_tol_early[3];            // ... of the ADMM iterations before the last one of a step (rda_opts::su_tol_early; 0 = su_tol)
     int su_light;                        // su_device Cfg::light_check
     int su_split;                        // su_device Args::split (time split of the Newton system)
+    int su_accept;                       // su_device Args::accept (safety net: the best near-converged iterate)
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
@@ -268,7 +269,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (it > 0) { a.pose = d.pose; a.pose_lin = 1; }
     a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
-    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
@@ -1336,31 +1337,14 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0; o->su_hard_warm[0] = 1.0; o->su_hard_warm[1] = 1e-3;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
-    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0;
+    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
     // conditions already hold there (a converging ADMM in a static scene: 57 % of the north-star solves) - zero Newton steps
     { const double ez[5] = {1e-12, 1e-12, 1e-12, 0.999999, 1e-7}; for (int i = 0; i < 5; ++i) o->su_easy[i] = ez[i]; }
-    auto geti = [](const char *name, int32_t *v) { const char *e = getenv(name); if (e && *e) *v = atoi(e); };
-    auto getd = [](const char *name, double *v) { const char *e = getenv(name); if (e && *e) *v = atof(e); };
-    geti("RDA_LMZ_MODE", &o->lmz_mode); geti("RDA_TIE_CENTRE", &o->tie_centre); getd("RDA_LMZ_MU", &o->lmz_mu);
-    { const char *e = getenv("RDA_SU_TOL"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol[0], &o->su_tol[1], &o->su_tol[2]); }
-    { const char *e = getenv("RDA_SU_HARD_WARM"); if (e) sscanf(e, "%lf,%lf", &o->su_hard_warm[0], &o->su_hard_warm[1]); }
-    { const char *e = getenv("RDA_SU_TOL_EARLY"); if (e) sscanf(e, "%lf,%lf,%lf", &o->su_tol_early[0], &o->su_tol_early[1], &o->su_tol_early[2]); }
-    geti("RDA_LMZ_WARM", &o->lmz_warm); geti("RDA_LMZ_ROWS", &o->lmz_rows); geti("RDA_LMZ_DENSE_FROM", &o->lmz_dense_from);
-    geti("RDA_LMZ_SPLIT", &o->lmz_split); geti("RDA_LMZ_TAIL", &o->lmz_tail); geti("RDA_LMZ_IP_ROWS", &o->lmz_ip_rows); geti("RDA_LMZ_IP_WARM", &o->lmz_ip_warm);
-    geti("RDA_SU_PRE", &o->su_pre); geti("RDA_SU_LIGHT", &o->su_light);
-    geti("RDA_SU_WARM_FIRST", &o->su_warm_first); geti("RDA_SU_EASY_NOPRED", &o->su_easy_nopred);
-    { const char *e = getenv("RDA_SU_COLD_FROM"); if (e) sscanf(e, "%d,%d", &o->su_cold_from, &o->su_cold_probe); }
-    { const char *e = getenv("RDA_SU_EASY"); if (e) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%d", &o->su_easy[0], &o->su_easy[1], &o->su_easy[2], &o->su_easy[3], &o->su_easy[4], &o->su_easy_max); }
-    getd("RDA_SU_WARM_CLIP", &o->su_warm_clip);
-    { const char *e = getenv("RDA_SU_WARM_ENDGAME"); if (e) sscanf(e, "%lf,%lf", &o->su_warm_endgame[0], &o->su_warm_endgame[1]); }
-    { const char *e = getenv("RDA_SU_WARM"); if (e) sscanf(e, "%lf,%lf,%d", &o->su_warm[0], &o->su_warm[1], &o->su_warm_cap); }
-    geti("RDA_ZERO_COPY", &o->zero_copy); geti("RDA_EARLY_FINISH", &o->early_finish); geti("RDA_FUSE_TRACK", &o->fuse_track);
-    { const char *e = getenv("RDA_SU_PROF"); if (e && *e) o->su_prof = 1; }
-    { const char *e = getenv("RDA_SU_SPLIT"); if (e && *e) o->su_split = atoi(e) != 0; }
-    { const char *e = getenv("RDA_DUALS_FOLLOW"); if (e && *e) o->duals_follow = atoi(e) != 0; }
+    // (No environment overrides here since round 5: a library call has no process-global configuration.  The RDA_* switches of the A/B tools and
+    // tests are applied by the Python host package - rda_planner_amd.rda_solver.hip_options - to the struct it hands to rda_create_opts.)
     if (o->su_cold_probe < 1) o->su_cold_probe = 1;
 }
 
@@ -1427,7 +1411,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_easy_max = o.su_easy_max; H->d.su_easy_nopred = o.su_easy_nopred;
     H->d.su_pre = o.su_pre; H->d.lmz_tail = o.lmz_tail;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
-    H->d.su_light = o.su_light; H->d.su_split = o.su_split;
+    H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept;
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     { const bool on = o.su_tol_early[0] > 0 && o.su_tol_early[1] > 0 && o.su_tol_early[2] > 0; for (int i = 0; i < 3; ++i) H->d.su_tol_early[i] = on ? o.su_tol_early[i] : 0.0; }
@@ -2907,10 +2891,12 @@ extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const doub
                  {(void **)&dzeta, zeta, sB * 8}, {(void **)&ddbar, dbar, sB * 8} };
     for (auto &c : ins) { HIPCHK(hipMalloc(c.dst, c.bytes)); HIPCHK(hipMemcpy(*c.dst, c.src, c.bytes, hipMemcpyHostToDevice)); }
     HIPCHK(hipMalloc((void **)&dlam, sB * E * 8)); HIPCHK(hipMalloc((void **)&dmu, sB * R * 8)); HIPCHK(hipMalloc((void **)&dz, sB * 8)); HIPCHK(hipMalloc((void **)&dcmh, sB * 4 * 8));
-    rda_opts od; rda_opts_init(&od);                   // tie-break T1 of the defaults (RDA_TIE_CENTRE overrides)
+    rda_opts od; rda_opts_init(&od);                   // tie-break T1 of the defaults
     RobotCands rcands; rcands.nmv = robot_candidates(R, G, h, rcands.muc, rcands.rv, &rcands.nrv); rcands.centre = od.tie_centre ? 1 : 0;
     long long *dprof = nullptr;
-    if (getenv("RDA_LMZ_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 8 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 8 * sizeof(long long))); }
+#ifdef RDA_LMZ_PROF     // debug build only: phase cycles of sub-problem 0 on stderr
+    HIPCHK(hipMalloc((void **)&dprof, 8 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 8 * sizeof(long long)));
+#endif
     hipLaunchKernelGGL(k_lammuz_batch, dim3((B + 3) / 4), dim3(256), 0, 0, B, E, R, dA, db, dcone, dp, dphi, dG, dh, dxi, dzeta, ddbar,
                        ro2, delta, accelerated, dlam, dmu, dz, dcmh, dprof, rcands);
     HIPCHK(hipGetLastError());
@@ -2929,7 +2915,7 @@ extern "C" int rda_lammuz_batch(int B, int E, int R, const double *A, const doub
     return RDA_OK;
 }
 
-extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
+extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const double *nom_s, const double *nom_u, const double *ref_s,
                             double ref_speed, const double *a, const double *cc, const double *g,
                             const double *d0, double *s, double *u, double *dd, int32_t *ipm_iters)
 {
@@ -2958,17 +2944,18 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     ar.c.dt = cfg->dt; ar.c.L = cfg->L; ar.c.umax0 = cfg->max_speed[0]; ar.c.umax1 = cfg->max_speed[1];
     ar.c.ab0 = cfg->acce_bound[0]; ar.c.ab1 = cfg->acce_bound[1]; ar.c.ws = cfg->ws; ar.c.wu = cfg->wu;
     ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
-    rda_opts od; rda_opts_init(&od);                   // the stop tolerances of the defaults (RDA_SU_TOL overrides)
-    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2]; ar.split = od.su_split;
+    rda_opts od; rda_opts_init(&od);                   // the stop tolerances / switches: the caller's, else the defaults
+    if (opts) od = *opts;
+    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2]; ar.split = od.su_split; ar.accept = od.su_accept;
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.cb = dsoa + 2 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;
     ar.d_in = d0 ? dd0 : nullptr; ar.out_s = dos; ar.out_u = dou; ar.out_d = dod; ar.status = dst; ar.ipm_iters = dst + 1;
     long long *dprof = nullptr;
-    if (getenv("RDA_SU_PROF")) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }
+    if (od.su_prof) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }
     ar.prof = dprof;
     double *ddbg = nullptr;
-    if (getenv("RDA_SU_TRACE")) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }
+    if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }      // (su_prof = 2: one stderr line per interior-point iteration)
     ar.dbg = ddbg;
     const size_t lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_hook<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
@@ -2993,4 +2980,10 @@ extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const doubl
     void *fr[] = { dsoa, dns, dnu, dref, dspeed, dd0, dos, dou, dod, dst };
     for (void *p : fr) dev_free(p);
     return st[0] == 0 ? 0 : 1;
+}
+extern "C" int rda_su_solve(const rda_cfg *cfg, const double *nom_s, const double *nom_u, const double *ref_s,
+                            double ref_speed, const double *a, const double *cc, const double *g,
+                            const double *d0, double *s, double *u, double *dd, int32_t *ipm_iters)
+{
+    return rda_su_solve_opts(cfg, nullptr, nom_s, nom_u, ref_s, ref_speed, a, cc, g, d0, s, u, dd, ipm_iters);
 }

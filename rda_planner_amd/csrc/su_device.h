@@ -118,6 +118,9 @@ struct Args {
     // time split of the Newton system (TT = 10, 20, 25, 30): the stages [T/2, T) are factorised by wave 0 and the stages [0, T/2) by wave 1 at
     // the same time (see solve); 0 = one recursion over the whole horizon on wave 0 (rounds 1-3)
     int split = 1;
+    // safety net (= oracle/rda_oracle.c su_solve_impl, rda_opts::su_accept): the best iterate that is primal feasible to tol_rp, dual feasible to
+    // 10 x tol_rd and complementary to 1000 x tol_mu is remembered (controls, distances, multipliers: Lds::acc) and returned when every attempt fails
+    int accept = 1;                  // (2: test switch, see the end of solve)
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
@@ -163,6 +166,10 @@ __device__ inline void lin_model(const Cfg &c, const double *st, const double *u
 // near terms of a solve kept in LDS, one or two per thread in the hinge sums (a solve with more visits its masks in global memory instead);
 // the long horizons have no room for the second half (160 KB of LDS per workgroup)
 __device__ __host__ constexpr int near_max(int T) { return T <= 40 ? 512 : 256; }
+// ... and what the LIST itself may hold (round 5).  A solve with more near terms than near_max keeps them in LDS all the same and sums them as (stage,
+// chunk) partials - what it did over the masks in global memory before (N = 2000: 13.6 k cycles per hinge pass, 25 % of the solve).  Sized to the LDS
+// the other arrays leave (160 KB per workgroup; 32 B per term)
+__device__ __host__ constexpr int near_cap(int T) { return T <= 20 ? 1792 : (T <= 25 ? 1536 : (T <= 30 ? 1280 : (T <= 50 ? 1024 : 256))); }
 constexpr int FT = 48;   // F' of the stage, [8 columns q][6]: F[0..4][q] | pad   (x+ = F y, x = [s(3) up(2)])
 constexpr int HB = 64;   // full 8x8 stage Hessian base; re-used after the matrix sweep for Mb [8][6]
 constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
@@ -175,7 +182,7 @@ struct Lds {
     double *Ft;        // [T][FT]  (constant during the solve)
     double *part;      // [NT][9] partial sums of the chunked reductions (aliases Hb)
     double *hs;        // [T][9]  hinge sums
-    double *Hw, *gw;   // [T][16], [T][4]
+    double *Hw, *gw;   // [T][9] (7 used; the region keeps its 16 T: Mf overlays it), [T][4]
     double *bw;        // [T][5]  barrier weights lam/w of the inequality pairs, + and - row summed (u0 box, u1 box, d box, rate u0, rate u1)
     double *cy;        // [T][5]  lam+ - lam- of the pairs (C'lam of the stage gradient)
     double *gst;       // [T][8]  stage gradient (objective + C'lam)
@@ -191,7 +198,8 @@ struct Lds {
     double *pv, *red;                      // 8, NT + 32 (reductions, flags, the two waves' 2 x 64-double scratch of the matrix recursion)
     double *p0;                            // [2][T] reference positions of the hinge screening
     double *uk, *ub, *xs;                  // time split (split_point(T) > 0): unit backward sweeps [5][8 m], their F_v' p [5][m][2], interface block [96]
-    double *near, *con; int *ncnt, *sto;   // near list of the hinge screening: [near_max][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
+    double *acc;                           // [13 T] safety net: u (2T) | d (T) | multipliers of the pairs [T][10]
+    double *near, *con; int *ncnt, *sto;   // near list of the hinge screening: [near_cap][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
@@ -205,7 +213,8 @@ struct Lds {
         dy = p; p += 8 * T; pv = p; p += 8; red = p; p += NT + 32; p0 = p; p += 2 * T;
         const int m = split_point(T);
         uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
-        near = p; p += 4 * near_max(T); ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
+        acc = p; p += ev(13 * T);
+        near = p; p += 4 * near_cap(T); ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
         con = part; if (near_max(T) > NT) { con = p; p += 9 * near_max(T); }      // the terms' contributions [near_max][9] (one per thread: the scratch of the partials)
     }
 };
@@ -214,7 +223,7 @@ inline size_t lds_bytes(int T)
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
              + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0)
-             + 4 * near_max(T) + NT / 2 + ev(T + 2) / 2 + 1 + (near_max(T) > NT ? 9 * near_max(T) : 0);
+             + ev(13 * T) + 4 * near_cap(T) + NT / 2 + ev(T + 2) / 2 + 1 + (near_max(T) > NT ? 9 * near_max(T) : 0);
     return n * sizeof(double);
 }
 
@@ -295,6 +304,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     long long tprev = clock64();
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
     const bool prof_on = a.prof != nullptr;
+
     auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
 #ifdef SU_FINE      // one-off build for tools/su_phase_profile.py --fine: the set-up slots are re-used for sub-phases of the iteration
 #define MS(k) mark(10)
@@ -525,7 +535,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
     bool screened = c.accelerated && a.P * KB * GS <= 64 * MW && (!masks_in || a.pose_ok);
-    bool listed = false;                                       // (uniform) the near terms are in L.near
+    bool listed = false, listed_fast = false;                  // (uniform) the near terms are in L.near; ... and few enough for one term per thread (L.con)
     {
         double saa = 0, sga = 0, sgx = 0;
         if (ract) {
@@ -596,7 +606,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 if (lane == T - 1) L.sto[T] = inc;
             }
             __syncthreads();
-            listed = L.sto[T] <= near_max(T);
+            listed = L.sto[T] <= near_cap(T); listed_fast = L.sto[T] <= near_max(T);
             if (listed && ract && mine > 0) {
                 int off = L.sto[rt];
                 for (int k = 0; k < rc_; ++k) off += L.ncnt[rt * nch + k];
@@ -1020,6 +1030,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     // closed-loop solves, where the iterates cycle -- restart from the same nominal with a more central point (slack floor
     // 0.1, mu0 = 10) and every hinge term in play.
     int status = 1, it = 0, used = 0;
+    bool have_acc = false; double acc_merit = 0.0;            // (uniform) safety net
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
     bool ref_pending = a.ref_flag != nullptr;      // the reference of a tracked tick is sampled by a second workgroup: picked up at its first use
     MS(9);
@@ -1049,7 +1060,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         const bool screened_now = screened && !(heps > 0);
         // ---- (1) hinge sums per stage.  Screened solves with the near terms in LDS (the common case): one thread per (stage, quantity)
         //          walks the stage's list.  Else: (stage, chunk) partials over the masks / over every term, then one thread per (stage, quantity) --
-        if (screened_now && listed) {
+        if (screened_now && listed_fast) {
             const int nn = L.sto[T];
             for (int e = tid; e < nn; e += NT) {                    // one near term per thread (two beyond NT): its nine contributions (zeros while the hinge is inactive)
                 const double *q = &L.near[4 * e];
@@ -1094,8 +1105,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     }
                 };
                 const int Nl = a.Nloc;
-                if (screened_now) {
-                    // visit only the terms that may be active, four loads in flight
+                if (screened_now && listed) {
+                    // more near terms than threads x 2: the stage's stretch of the LDS list, dealt to the chunks of the stage (round 5)
+                    const int j1 = L.sto[rt + 1];
+                    for (int j = L.sto[rt] + rc_; j < j1; j += nch) { const double *q = &L.near[4 * j]; term(q[0], q[1], q[2]); }
+                } else if (screened_now) {
+                    // (more near terms than the list holds) visit only the terms that may be active, four loads in flight
                     for (int w = 0; w < MW; ++w) {
                         unsigned long long m = amask[w];
                         while (m) {
@@ -1166,12 +1181,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             gs[2] += 0.5 * c.ro2 * (L.Q1[t] + 2 * L.Q2[t] * dl); Hs22 += c.ro2 * L.Q2[t];
             gs[0] += c.ro1 * h[6]; gs[1] += c.ro1 * h[7];
             Hs00 += c.ro1 * h[0]; Hs01 += c.ro1 * h[1]; Hs11 += c.ro1 * h[2];
-            double *Hw = &L.Hw[16 * t], *gw = &L.gw[4 * t];
+            // the seven distinct entries of the symmetric 4 x 4 block, stage stride 9: the stage threads write [T][16] rows 128 bytes apart onto ONE
+            // LDS bank (16-way conflicts: profiles/r04_ns_issue_counters.txt SQ_LDS_BANK_CONFLICT); an odd stride spreads them
+            double *Hw = &L.Hw[9 * t], *gw = &L.gw[4 * t];
             double hsd0 = -c.ro1 * h[3], hsd1 = -c.ro1 * h[4];
-            Hw[0] = Hs00; Hw[1] = Hs01; Hw[2] = 0; Hw[3] = hsd0;
-            Hw[4] = Hs01; Hw[5] = Hs11; Hw[6] = 0; Hw[7] = hsd1;
-            Hw[8] = 0; Hw[9] = 0; Hw[10] = Hs22; Hw[11] = 0;
-            Hw[12] = hsd0; Hw[13] = hsd1; Hw[14] = 0; Hw[15] = c.ro1 * h[5];
+            Hw[0] = Hs00; Hw[1] = Hs01; Hw[2] = hsd0; Hw[3] = Hs11; Hw[4] = hsd1; Hw[5] = Hs22; Hw[6] = c.ro1 * h[5];
             gw[0] = gs[0]; gw[1] = gs[1]; gw[2] = gs[2]; gw[3] = -c.ro1 * h[8] - c.slack_gain;
         }
         // pair threads: primal residuals, reciprocals, affine (predictor) targets; what the stage phases need goes to the [T][5] arrays
@@ -1216,8 +1230,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (!expect_conv)
         for (int i = tid; i < 8 * T; i += NT) {               // one thread per (stage, row): Hw and the row's J column stay in registers
             int t = i >> 3, r = i & 7;
-            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[16 * t], *dg = &L.bw[5 * t];
-            const double h00 = Hw[0], h01 = Hw[1], hd0 = Hw[3], h11 = Hw[5], hd1 = Hw[7], h22 = Hw[10], hdd = Hw[15];
+            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[9 * t], *dg = &L.bw[5 * t];
+            const double h00 = Hw[0], h01 = Hw[1], hd0 = Hw[2], h11 = Hw[3], hd1 = Hw[4], h22 = Hw[5], hdd = Hw[6];
             const double a0 = Fel(F, 0, r), a1 = Fel(F, 1, r), a2 = Fel(F, 2, r), a3 = r == 7 ? 1.0 : 0.0;
             // v = Hw J[:, r]
             const double v0 = h00 * a0 + h01 * a1 + hd0 * a3, v1 = h01 * a0 + h11 * a1 + hd1 * a3, v2 = h22 * a2, v3 = hd0 * a0 + hd1 * a1 + hdd * a3;
@@ -1334,7 +1348,19 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
         if (a.rd0 && used == 0 && it == 0 && tid == 0) *a.rd0 = rdn / sc;
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
-        if ((rdn <= c.tol_rd * sc && rpn <= c.tol_rp && mu <= c.tol_mu * sc) || (rdn <= 100 * c.tol_rd * sc && rpn <= c.tol_rp && mu <= 0.1 * c.tol_mu * sc)) {
+        const bool conv_now = (rdn <= c.tol_rd * sc && rpn <= c.tol_rp && mu <= c.tol_mu * sc) || (rdn <= 100 * c.tol_rd * sc && rpn <= c.tol_rp && mu <= 0.1 * c.tol_mu * sc);
+        if (a.accept && !conv_now && rpn <= c.tol_rp && rdn <= 10 * c.tol_rd * sc && mu <= 1e3 * c.tol_mu * sc) {     // (uniform) safety net: see Args::accept
+            const double merit = fmax(rdn / (c.tol_rd * sc), mu / (c.tol_mu * sc));
+            if (!have_acc || merit < acc_merit) {
+                have_acc = true; acc_merit = merit;
+                for (int i = tid; i < 2 * T; i += NT) L.acc[i] = L.u[i];
+                for (int i = tid; i < T; i += NT) L.acc[2 * T + i] = L.d[i];
+#pragma unroll
+                for (int j = 0; j < NPR; ++j)
+                    if (p_ok[j]) { const int o = 3 * T + 10 * p_t[j] + 2 * p_k[j]; L.acc[o] = p_on[j] ? Plp[j] : 0.0; L.acc[o + 1] = p_on[j] ? Plm[j] : 0.0; }
+            }
+        }
+        if (conv_now) {
             if (screened) {        // the positions must have stayed within DELTA of the screening reference
                 double dv = 0;
                 if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
@@ -1513,6 +1539,16 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     used += it;
     }
     __syncthreads();
+    if ((status != 0 || a.accept == 2) && have_acc) {          // every attempt failed: the safety net (the remembered iterate is primal feasible: inside the boxes).  accept == 2: test switch -
+                                                                // ALWAYS hand the remembered iterate back (tests/test_gpu_parity.py: this path is otherwise never taken)
+        for (int i = tid; i < 2 * T; i += NT) L.u[i] = L.acc[i];
+        for (int i = tid; i < T; i += NT) L.d[i] = L.acc[2 * T + i];
+#pragma unroll
+        for (int j = 0; j < NPR; ++j)
+            if (p_ok[j]) { const int o = 3 * T + 10 * p_t[j] + 2 * p_k[j]; Plp[j] = L.acc[o]; Plm[j] = L.acc[o + 1]; }
+        status = 0;
+        __syncthreads();
+    }
     // consistent final rollout (removes accumulated rounding in s)
     rollout();
     __syncthreads();

@@ -55,11 +55,48 @@ class _Backend:
             pass
 
 
+# RDA_* environment switches of the A/B tools and tests (tools/experiments/env_ab.sh, tests/test_gpu_switches.py): applied HERE, by the host
+# package, to the rda_opts it hands to rda_create_opts - librda_hip.so itself reads no environment variable (round 5: a library call has no
+# process-global configuration).  name -> (fields filled in order from a comma-separated value)
+_ENV_SWITCHES = {
+    "RDA_LMZ_MODE": ("lmz_mode",), "RDA_TIE_CENTRE": ("tie_centre",), "RDA_LMZ_MU": ("lmz_mu",), "RDA_SU_TOL": ("su_tol",), "RDA_SU_HARD_WARM": ("su_hard_warm",),
+    "RDA_SU_TOL_EARLY": ("su_tol_early",), "RDA_LMZ_WARM": ("lmz_warm",), "RDA_LMZ_ROWS": ("lmz_rows",), "RDA_LMZ_DENSE_FROM": ("lmz_dense_from",),
+    "RDA_LMZ_SPLIT": ("lmz_split",), "RDA_LMZ_TAIL": ("lmz_tail",), "RDA_LMZ_IP_ROWS": ("lmz_ip_rows",), "RDA_LMZ_IP_WARM": ("lmz_ip_warm",), "RDA_SU_PRE": ("su_pre",),
+    "RDA_SU_LIGHT": ("su_light",), "RDA_SU_WARM_FIRST": ("su_warm_first",), "RDA_SU_EASY_NOPRED": ("su_easy_nopred",), "RDA_SU_COLD_FROM": ("su_cold_from", "su_cold_probe"),
+    "RDA_SU_EASY": ("su_easy", "su_easy_max"), "RDA_SU_WARM_CLIP": ("su_warm_clip",), "RDA_SU_WARM_ENDGAME": ("su_warm_endgame",), "RDA_SU_WARM": ("su_warm", "su_warm_cap"),
+    "RDA_ZERO_COPY": ("zero_copy",), "RDA_EARLY_FINISH": ("early_finish",), "RDA_FUSE_TRACK": ("fuse_track",), "RDA_SU_PROF": ("su_prof",), "RDA_SU_SPLIT": ("su_split",),
+    "RDA_DUALS_FOLLOW": ("duals_follow",), "RDA_SU_ACCEPT": ("su_accept",),
+}
+
+
+def _apply_env(o):
+    import os
+    for name, fields in _ENV_SWITCHES.items():
+        raw = os.environ.get(name)
+        if not raw:
+            continue
+        vals = [v for v in raw.split(",")]
+        for f in fields:                                   # an array field takes as many values as it has entries; what is not given stays
+            cur = getattr(o, f)
+            n = len(cur) if hasattr(cur, "__len__") else 1
+            take, vals = vals[:n], vals[n:]
+            for i, v in enumerate(take):
+                if hasattr(cur, "__len__"):
+                    cur[i] = float(v)
+                elif isinstance(cur, int):
+                    setattr(o, f, int(float(v)))
+                else:
+                    setattr(o, f, float(v))
+    if o.su_cold_probe < 1:
+        o.su_cold_probe = 1
+
+
 def hip_options(**changes):
-    """rda_opts with the library defaults (and RDA_* environment overrides), then `changes` applied (field=value)"""
+    """rda_opts with the library defaults, the RDA_* environment switches (`_ENV_SWITCHES`), then `changes` applied (field=value)"""
     from ._lib import hip_api
     o = Opts()
     hip_api().opts_init(C.byref(o))
+    _apply_env(o)
     known = {f[0] for f in Opts._fields_}
     for k, v in changes.items():
         if k not in known:
@@ -80,7 +117,7 @@ def hip_options(**changes):
 
 def _hip_backend(cfg, G, h, opts=None):
     from ._lib import hip_api          # raises loudly when librda_hip.so / the GPU is missing
-    return _Backend(hip_api(), cfg, G, h, opts)
+    return _Backend(hip_api(), cfg, G, h, opts if opts is not None else hip_options())
 
 
 class RDA_solver:
@@ -154,7 +191,7 @@ class RDA_solver:
             # a test backend keeps the duals with their SLOTS (the reference's semantics): say so rather than hand back other semantics silently
             import warnings
             warnings.warn("duals_follow_obstacles=True is honoured by the HIP backend only; this backend keeps the duals bound to the obstacle slots", RuntimeWarning, stacklevel=2)
-        self._be = make(cfg, G, h, opts) if (make is _hip_backend and opts is not None) else make(cfg, G, h)   # test backends select the mode themselves
+        self._be = make(cfg, G, h, opts) if make is _hip_backend else make(cfg, G, h)   # test backends select the mode themselves
         self._R = G.shape[0]
         self.pipeline = True        # MPC overlaps its per-tick obstacle staging with the first su-problem (set False to serialise)
 

@@ -2,7 +2,15 @@
 cvxpy / pathos stand-ins of oracle/refshim - see oracle/ref_harness.py).  /root/reference exists in the build container only;
 the fixtures travel, so the `-m gpu` tests can compare the HIP path with reference output on the GPU box.
 
-    python tests/golden/make_ref_golden.py
+    python tests/golden/make_ref_golden.py [--backend refshim|cvxpy] [--only-na]
+
+--backend refshim (default; the only one possible in the build image): the fixtures named below.
+--backend cvxpy   (the day a CVXPY 1.5.2 + ECOS wheel is installable, /root/reference/setup.py:8): the SAME script on the real solver stack,
+                  writing ref_*_cvxpy.npz BESIDE the shim fixtures (nothing is overwritten).  The plumbing loops then run with the reference's
+                  own prob.solve() - no oracle answers injected - so everything non-unique in them (lam, mu, z individually, and whatever later
+                  iterations make of them) is ECOS's; tests/test_ref_golden.py::test_cvxpy_fixtures_agree_with_the_shim_fixtures_where_the_answer_is_unique
+                  compares the unique quantities across the two sets when both exist.  The requested backend must be the one that imports: asking
+                  for cvxpy while only the stand-in is importable is an error, not a silent fallback.
 
 ref_plumbing.npz  - mode "oracle": closed loops of the reference `mpc.MPC` + `RDA_solver` whose `prob.solve()` calls are answered
                     by the oracle's two argmins (cold).  Per MPC step the solver inputs (nominal, reference, the obstacle list the
@@ -21,6 +29,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+SUFFIX = ""          # "_cvxpy" for fixtures written on the real solver stack
+INJECT_ORACLE = True  # plumbing: answer prob.solve() with the oracle's argmins (shim backend)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
@@ -69,7 +79,8 @@ def plumbing(rs, mp, orc):
         kw, car_t, path = S["kw"], S["car"], S["path"]
         T = kw["receding"]
         rmpc = mp.MPC(car_t, [p.copy() for p in path], process_num=1, time_print=False, **kw)
-        rh.OracleAnswers(rmpc.rda, rs, orc)
+        if INJECT_ORACLE:
+            rh.OracleAnswers(rmpc.rda, rs, orc)
         log = rh.record_iterations(rmpc.rda)
         stager = RDA_solver.__new__(RDA_solver)
         stager.max_obs_num, stager.max_edge_num, stager.T = kw["max_obs_num"], kw["max_edge_num"], T
@@ -105,7 +116,7 @@ def plumbing(rs, mp, orc):
                     out[f"{q}.{key}"] = v if S["full"] else projections(v.shape, 7) @ v.ravel()
             state = sc.kinematic_step(state, u, car_t, 0.1)
         print(f"plumbing {name}: {S['steps']} steps recorded")
-    np.savez_compressed(os.path.join(HERE, "ref_plumbing.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "ref_plumbing" + SUFFIX + ".npz"), **out)
 
 
 def problems(rs, mp):
@@ -195,7 +206,7 @@ def problems(rs, mp):
             k += 1
     out["su.count"] = k
     print("su problems:", k)
-    np.savez_compressed(os.path.join(HERE, "ref_problems.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "ref_problems" + SUFFIX + ".npz"), **out)
 
 
 
@@ -253,20 +264,29 @@ def lammuz_problems_nonaccelerated(rs, mp):
         out[f"lmz.{k}"] = np.array(v)
     out["lmz.G"], out["lmz.h"] = G, h
     print("LamMuZ problems (not accelerated):", len(rows["cost"]), "sub-problems;", int(np.sum(np.array(rows["cost"]) > 1e-6)), "with a positive optimal value")
-    np.savez_compressed(os.path.join(HERE, "ref_problems_na.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "ref_problems_na" + SUFFIX + ".npz"), **out)
 
 
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=["refshim", "cvxpy"], default="refshim")
+    ap.add_argument("--only-na", action="store_true", help="add the non-accelerated LamMuZ fixtures without touching the other files")
+    args = ap.parse_args()
     rs, mp, backend = rh.load()
-    assert backend == "refshim" or True
+    if backend != args.backend:
+        sys.exit(f"make_ref_golden: --backend {args.backend} requested, but the reference imports on {backend!r} here "
+                 + ("(cvxpy / ecos are not installed: oracle/refshim answers)" if backend == "refshim" else "(the real cvxpy is importable: pass --backend cvxpy)"))
+    if backend == "cvxpy":
+        SUFFIX, INJECT_ORACLE = "_cvxpy", False
     orc = orc_api()
     orc.lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
     orc.lib.orc_set_su_warm(0.0, 0.0, 0)
-    if "--only-na" in sys.argv:                     # add the non-accelerated LamMuZ fixtures without touching the other files
+    if args.only_na:
         lammuz_problems_nonaccelerated(rs, mp)
         sys.exit(0)
     plumbing(rs, mp, orc)
     problems(rs, mp)
     lammuz_problems_nonaccelerated(rs, mp)
-    for f in ("ref_plumbing.npz", "ref_problems.npz", "ref_problems_na.npz"):
-        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+    for f in ("ref_plumbing", "ref_problems", "ref_problems_na"):
+        print(f + SUFFIX + ".npz", os.path.getsize(os.path.join(HERE, f + SUFFIX + ".npz")) // 1024, "KiB")

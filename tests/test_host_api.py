@@ -540,3 +540,29 @@ def test_flatten_extension_equals_numpy_flatten():
         _same_scene(sv.flatten_scene(list(lst)), sv._flatten_scene_numpy(list(lst)))
     assert _flat_solver(2).flatten_scene([sc.circle(1, 2, 0.5)]) is None                                               # circles need E >= 3
     _same_scene(sv.flatten_scene([]), sv._flatten_scene_numpy([]))
+
+
+def test_env_switches_are_applied_by_the_host_package_not_by_the_library(monkeypatch):
+    """round 5: librda_hip.so reads no environment variable; the RDA_* switches of the A/B tools and of tests/test_gpu_switches.py
+    are applied by rda_solver.hip_options to the rda_opts it hands to rda_create_opts.  The table must name fields of the struct, fill arrays in
+    order (sscanf semantics of the old C code: what is not given stays) and leave everything else alone."""
+    import re
+    from rda_planner_amd._capi import Opts
+    from rda_planner_amd.rda_solver import _ENV_SWITCHES, _apply_env
+    known = {f[0] for f in Opts._fields_}
+    assert all(f in known for fields in _ENV_SWITCHES.values() for f in fields)
+    o = Opts()
+    o.su_warm[0], o.su_warm[1], o.su_warm_cap, o.su_cold_probe = 1e-3, 1e-3, 30, 8
+    o.su_easy_max = 2
+    monkeypatch.setenv("RDA_SU_WARM", "0,0,0")
+    monkeypatch.setenv("RDA_LMZ_MODE", "1")
+    monkeypatch.setenv("RDA_LMZ_MU", "1e-3")
+    monkeypatch.setenv("RDA_SU_EASY", "1e-6,1e-6,1e-6,0.9,1e-3,3")
+    monkeypatch.setenv("RDA_SU_COLD_FROM", "5")
+    _apply_env(o)
+    assert list(o.su_warm) == [0.0, 0.0] and o.su_warm_cap == 0 and o.lmz_mode == 1 and o.lmz_mu == 1e-3
+    assert list(o.su_easy) == [1e-6, 1e-6, 1e-6, 0.9, 1e-3] and o.su_easy_max == 3
+    assert o.su_cold_from == 5 and o.su_cold_probe == 8           # second value not given: stays
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_src = "".join(open(os.path.join(root, "rda_planner_amd", "csrc", f)).read() for f in os.listdir(os.path.join(root, "rda_planner_amd", "csrc")) if f.endswith((".hip", ".h")))
+    assert not re.search(r"\bgetenv\s*\(", lib_src), "librda_hip.so must not read the environment"
