@@ -212,6 +212,39 @@ def fleet(ctx):
     out = {"egos": M, "steps_per_ego": Km, "aggregate_steps_per_s": round(M * Km / el, 1),
            "ms_per_fleet_step": round(el / Km * 1e3, 4), "max_du_vs_single": worst}
     api.fleet_destroy(F)
+    del members
+    try:
+        out["python_api_closed_loop"] = fleet_python_api(ctx, M)
+    except Exception as e:                                  # the line must not depend on this leg
+        out["python_api_closed_loop"] = {"error": repr(e)[:200]}
+    return out
+
+
+def fleet_python_api(ctx, M, steps=24):
+    """the same fleet driven END TO END from the Python API (SURVEY 8 f3 'batched for multi-ego'): `Fleet.control` over M `MPC` members - every
+    member's pre_process on the device (rda_fleet_step_tracked), all raw scenes flattened in one pass and staged by one call
+    (rda_fleet_upload_scenes), one set of launches per ADMM iteration; closed loops (each member applies its control to its own kinematic model)"""
+    from rda_planner_amd import scenarios as sc
+    from rda_planner_amd.fleet import Fleet
+    from rda_planner_amd.mpc import MPC
+    members = [MPC(ctx.car_t, [p.copy() for p in ctx.path], sample_time=0.1, time_print=False, **ctx.kw) for _ in range(M)]
+    fl = Fleet(members)
+    states = [ctx.path[0].copy().reshape(3, 1) for _ in range(M)]
+    obs = [list(ctx.obstacles) for _ in range(M)]
+    its, t0 = [], 0.0
+    for k in range(4 + steps):
+        if k == 4:
+            t0 = time.perf_counter()
+        res = fl.control([s.copy() for s in states], 4.0, obs)
+        for i in range(M):
+            states[i] = sc.kinematic_step(states[i], res[i][0], ctx.car_t, 0.1)
+        if k >= 4:
+            its.append(res[0][1]["iters"])
+    el = time.perf_counter() - t0
+    out = {"egos": M, "steps_per_ego": steps, "aggregate_steps_per_s": round(M * steps / el, 1), "ms_per_fleet_step": round(el / steps * 1e3, 3),
+           "mean_admm_iters": round(float(np.mean(its)), 3), "one_pass_scene_staging_ticks": int(fl.batched_ticks),
+           "what": "Fleet.control: Python objects in, controls out; obstacle_order=True (every member's scene re-sorted on the device every tick)"}
+    fl.close()
     return out
 
 

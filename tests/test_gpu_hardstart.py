@@ -107,5 +107,5 @@ def test_safety_net_hands_back_the_best_near_converged_iterate(hip, orc, T, N, d
         orc.lib.orc_set_su_accept(1)
     e_conv, e_orc = float(np.abs(u2 - u1).max()), float(np.abs(u2 - uc).max())
     print(f"T={T} N={N}: |u_remembered - u_converged| {e_conv:.2e}, |u_remembered - oracle's remembered| {e_orc:.2e}, {it2} iterations")
-    assert stc == 0 and 0 < e_conv <= 2e-4 and e_orc <= 2e-4              # (an iterate 10 x / 1000 x short of the stop test: the reference solver's class)
+    assert stc == 0 and 0 < e_conv <= 2e-4 and e_orc <= 1e-8              # (an iterate 10 x / 1000 x short of the stop test: the reference solver's class; the two cold solves walk the same path)
     assert np.abs(d2 - d1).max() <= 2e-4 and np.abs(s2 - s1).max() <= 2e-3

@@ -70,7 +70,7 @@ def main():
     from rda_planner_amd.mpc import MPC
     from rda_planner_amd import scenarios as sc
     car_t, path, obstacles, kw = bench.build_workload(n_obs=args.n_obs, T=args.horizon, n_steps=args.steps + 20, moving=False)
-    kw["obstacle_order"] = False
+    kw["obstacle_order"] = not os.environ.get("LMZ_CLK_FIXED")      # the reference default: re-sorted every tick (LMZ_CLK_FIXED=1: fixed binding)
     mpc = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, **kw)
     lib = _lib.hip_api().lib
     import numpy as np

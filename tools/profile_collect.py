@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 for name in os.listdir(src):
@@ -66,13 +66,21 @@ for cfg in ("ns", "n20", "n2000", "c4", "ip"):
     if not os.path.exists(f) or cfg not in workloads:
         continue
     kern = {}
-    for mm in re.finditer(r"^(?:void )?([\w<>]+)\s+(SQ_\w+)\s+dispatches\s+(\d+) per-dispatch\s+([\d.]+)", open(f).read(), re.M):
-        kern.setdefault(mm.group(1), {"dispatches": int(mm.group(3))})[mm.group(2)] = float(mm.group(4))
+    # per EXECUTED dispatch since round 5 (tools/profile_round.sh separates them like the FETCH / WRITE passes do); older files: per dispatch
+    text = open(f).read()
+    executed = " per-executed " in text
+    for mm in re.finditer(r"^(?:void )?([\w<>]+)\s+(SQ_\w+)\s+dispatches\s+(\d+) per-dispatch\s+([\d.]+)(?: executed\s+(\d+) per-executed\s+([\d.]+))?", text, re.M):
+        d = kern.setdefault(mm.group(1), {"dispatches": int(mm.group(3))})
+        d[mm.group(2)] = float(mm.group(6)) if mm.group(6) else float(mm.group(4))
+        if mm.group(5):
+            d["executed"] = int(mm.group(5))
     if kern:
         issue[cfg] = {k: workloads[cfg][k] for k in ("n_obs", "horizon", "moving", "lmz_mode")}
         issue[cfg]["kernels"] = kern
+        issue[cfg]["per"] = "executed" if executed else "dispatch"
 if issue:
-    json.dump({"_comment": "rocprofv3 --pmc SQ_* (four passes per configuration, tools/profile_round.sh), wave-instructions / cycles per dispatch averaged over all "
-                           "dispatches of the kernel in the pass (executed and skipped).  Use ratios within a kernel.",
+    json.dump({"_comment": "rocprofv3 --pmc SQ_* (four passes per configuration, tools/profile_round.sh; every process is bench.py --only-headline: the headline loop of "
+                           "that configuration and nothing else), wave-instructions / cycles per EXECUTED dispatch (`per`: executed - a dispatch that counted more than "
+                           "0.4 of a large one of its kernel; launches queued behind the early-stop flag are left out).",
                "source": f"profiles/{tag}_<cfg>_issue_counters.txt", "workloads": issue}, open(os.path.join(dst, "issue.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "detail"} for k, v in workloads.items()}, indent=1))
