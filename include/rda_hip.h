@@ -123,7 +123,8 @@ typedef struct rda_opts {
     int32_t zero_copy;       /* [1] result slot written into pinned host memory by the kernel, host polls a sequence word  RDA_ZERO_COPY */
     int32_t early_finish;    /* [1] the launch that detects the early stop hands the result over (0: k_finish does)      RDA_EARLY_FINISH */
     int32_t fuse_track;      /* [1] k_su_tracked (tracking beside su-problem 0; 0: k_track then k_su)                   RDA_FUSE_TRACK */
-    int32_t su_prof;         /* [0] phase cycle counters of the su-solves (rda_debug_su_prof)                           RDA_SU_PROF */
+    int32_t su_prof;         /* [0] phase cycle counters of the su-solves (rda_debug_su_prof): PROFILING builds of the library only (-DSU_PROF /
+                                -DSU_FINE, tools/su_phase_profile.py) - the product build refuses 1 with RDA_ERR_UNSUPPORTED   RDA_SU_PROF */
     int32_t su_split;        /* [1] su Newton system of the horizons 10, 20, 25, 30 cut in two halves that two waves factorise and sweep at
                                 the same time, joined by a 5 x 5 interface system (same linear system, same answers up to rounding; 0: one
                                 recursion over the whole horizon)                                                          RDA_SU_SPLIT */

@@ -1439,7 +1439,11 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
         rc |= dalloc(&H->d_prev_sel, N); rc |= dalloc(&H->d_follow_map, N);
         rc |= dalloc(&H->d_follow_tmp, N * (T + 1) * (E + R + 2) + 2 * N * T);
     }
+#if defined(SU_PROF) || defined(SU_FINE)
     if (o.su_prof) rc |= dalloc(&d.su_prof, 16);
+#else
+    if (o.su_prof) { rda_destroy(H); *partial = nullptr; return RDA_ERR_UNSUPPORTED; }     // phase counters: profiling builds only (-DSU_PROF / -DSU_FINE, tools/su_phase_profile.py)
+#endif
     const size_t step_n = 3 * (T + 1) + 2 * T + 3 * (T + 1) + 1;
     rc |= dalloc(&H->d_step, step_n);
     // result block, identical on the device and in pinned memory: u [2T] | s [3(T+1)] | rda_info (4 doubles) | track::Out (4 doubles):

@@ -170,10 +170,22 @@ __device__ __host__ constexpr int near_max(int T) { return T <= 40 ? 512 : 256; 
 // chunk) partials - what it did over the masks in global memory before (N = 2000: 13.6 k cycles per hinge pass, 25 % of the solve).  Sized to the LDS
 // the other arrays leave (160 KB per workgroup; 32 B per term)
 __device__ __host__ constexpr int near_cap(int T) { return T <= 20 ? 1792 : (T <= 25 ? 1536 : (T <= 30 ? 1280 : (T <= 50 ? 1024 : 256))); }
-constexpr int FT = 48;   // F' of the stage, [8 columns q][6]: F[0..4][q] | pad   (x+ = F y, x = [s(3) up(2)])
-constexpr int HB = 64;   // full 8x8 stage Hessian base; re-used after the matrix sweep for Mb [8][6]
-constexpr int WN = 24;   // W (5x3) | Minv sym (6) | pad
-constexpr int MF = 36;   // forward sweep rows [6][6]
+// Stage strides of the big per-stage arrays (doubles).  The natural sizes 48 / 64 are multiples of 32 dwords: the rows of stage t and t + 2 (or t + 1)
+// then start on the same LDS banks and every (stage, row)-thread phase runs 2-way conflicted.  Round 5, k_su<20> in the headline loop,
+// SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS per dispatch (tools/experiments/lds_conflicts.sh): 48/64/24/36 -> 1.04, HB = 66 -> 0.94, + FT = 50 -> 0.84,
+// + WN = 26, MF = 38 -> 0.86; launch time 108.6 -> 107.9 us.  The LDS array is busy ~12 % of a launch (active + conflict cycles over 4 x wave cycles):
+// bank conflicts are not what bounds this kernel, the padding that is free is kept.
+#ifndef SU_FT
+#define SU_FT 50
+#define SU_HB 66
+#define SU_WN 24
+#define SU_MF 36
+#endif
+constexpr int FT = SU_FT;   // F' of the stage, [8 columns q][6]: F[0..4][q] | pad   (x+ = F y, x = [s(3) up(2)])   (48 used)
+constexpr int HB = SU_HB;   // full 8x8 stage Hessian base; re-used after the matrix sweep for Mb [8][6]               (64 used)
+constexpr int WN = SU_WN;   // W (5x3) | Minv sym (6) | pad                                                          (21 used)
+constexpr int MF = SU_MF;   // forward sweep rows [6][6]                                                             (36 used)
+static_assert(FT >= 48 && HB >= 64 && WN >= 21 && MF >= 36 && FT % 2 == 0 && HB % 2 == 0 && MF % 2 == 0, "stage strides: rows are read as 16-byte pairs");
 __device__ __host__ inline int ev(int n) { return (n + 1) & ~1; }
 // time split of the Newton system: the horizons with a compile-time instantiation are cut in two halves (0 = no split)
 __device__ __host__ constexpr int split_point(int T) { return (T == 10 || T == 20 || T == 25 || T == 30) ? T / 2 : 0; }
@@ -254,10 +266,11 @@ __device__ __forceinline__ double bcast(double v, int src)
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
-template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+// (lanes without a source - shifted in from outside the row, or rows outside ROWS - read 0)
+template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ double dpp_f64(double v)
 {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 // all-reduce over the 64 lanes: DPP inside the 16-lane rows (xor 1, xor 2, half mirror, mirror), v_readlane across rows
@@ -303,7 +316,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     Lds L; L.carve(smem, T);
     long long tprev = clock64();
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
+    // The phase counters exist in the PROFILING builds only (-DSU_PROF, -DSU_FINE: tools/su_phase_profile.py).  As a run-time switch of the product build
+    // they cost 32 VGPRs (the 16 counters) and a branch per mark: k_su<20> 108.6 -> 107.1 us in the headline loop without them (round 5, same box).
+#if defined(SU_PROF) || defined(SU_FINE)
     const bool prof_on = a.prof != nullptr;
+#else
+    constexpr bool prof_on = false;
+#endif
 
     auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
 #ifdef SU_FINE      // one-off build for tools/su_phase_profile.py --fine: the set-up slots are re-used for sub-phases of the iteration
@@ -357,6 +376,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     // ---- load nominal, reference; linearise -------------------------------------------------
     for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; if (!a.ref_flag) L.ref[i] = a.ref[i]; }
     for (int i = tid; i < WN * T; i += NT) L.Wn[i] = 0.0;       // (W[.][2], Minv[.][2] stay zero: d_t is not part of the recursion)
+    for (int i = tid; i < FT * T; i += NT) L.Ft[i] = 0.0;       // (the stage threads fill in the non-zeros after the barrier)
     if (tid < T) { L.u[tid] = pf_u0; L.u[T + tid] = pf_u1; }
     // reference positions of the hinge screening: where the masks were made (pose table), else the nominal positions of stages 1..T
     for (int i = tid; i < 2 * T; i += NT)
@@ -369,14 +389,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         double cp, sp;
         if (a.pose_lin) { cp = pf_cp; sp = pf_sp; } else sincos(st[2], &sp, &cp);
         L.csn[t] = cp; L.csn[T + t] = sp;
-        lin_model(c, st, ut, cp, sp, &L.Ak[9 * t], &L.Bk[6 * t], &L.Ck[3 * t]);
+        // (the model in registers, then to LDS: Ak / Bk / Ck for the roll-outs, and the non-zeros of F = [[A 0 B 0],[0 0 I2 0]] (5 x 8, stored
+        // transposed and padded: Ft[q][i]) straight from the registers - the rest of Ft was zeroed by all threads above.  Round 5: the T stage
+        // threads used to write all 48 entries and read A, B back from LDS: 4.8 k cycles per solve)
+        double Am[9], Bm[6], Cm[3];
+        lin_model(c, st, ut, cp, sp, Am, Bm, Cm);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L.Ak[9 * t + i] = Am[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) L.Bk[6 * t + i] = Bm[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) L.Ck[3 * t + i] = Cm[i];
         L.phin[t] = st[2];
-        // F = [[A 0 B 0],[0 0 I2 0]]  (5x8), stored transposed and padded: Ft[q][i]
         double *F = &L.Ft[FT * t];
-        for (int i = 0; i < FT; ++i) F[i] = 0;
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
-            for (int q = 0; q < 3; ++q) F[6 * q + r] = L.Ak[9 * t + 3 * r + q];
-            for (int q = 0; q < 2; ++q) F[6 * (5 + q) + r] = L.Bk[6 * t + 2 * r + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) F[6 * q + r] = Am[3 * r + q];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) F[6 * (5 + q) + r] = Bm[2 * r + q];
         }
         F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
@@ -417,9 +448,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // the running sums as wave prefix scans, one stage per lane (T <= 64): six shuffle steps instead of T dependent additions on one lane
             // holding T registers (round 4: the unrolled register arrays of the serial form were the reason the T = 25 / 30 instantiations
             // spilled to scratch).  Another summation order than the serial loop: rounding level, like every reduction of this kernel.
+            // (round 5: as DPP moves - row_shr 1, 2, 4, 8 inside the 16-lane rows, then the row totals across with row_bcast:15 / :31 - instead of six
+            // __shfl_up = ds_bpermute round trips per scan: two dependent scan rounds per roll-out, two roll-outs per solve)
             auto prefix = [&](double v) {
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+                v += dpp_f64<0x111>(v); v += dpp_f64<0x112>(v); v += dpp_f64<0x114>(v); v += dpp_f64<0x118>(v);
+                v += dpp_f64<0x142, 0xA>(v); v += dpp_f64<0x143, 0xC>(v);
                 return v;
             };
             {

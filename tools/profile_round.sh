@@ -79,10 +79,10 @@ try:
     for k in sorted(vals):
         if "k_su" in k[0] or "k_lammuz" in k[0] or "k_lmz" in k[0]:
             v = vals[k]
-            # an EXECUTED dispatch: more than 0.4 of a large one (98th percentile) of that kernel and counter - launches queued behind the early-stop
-            # flag return at once and count next to nothing (same rule as the FETCH / WRITE passes above)
+            # an EXECUTED dispatch: more than 0.02 of a large one (98th percentile) of that kernel and counter - launches queued behind the early-stop
+            # flag return at once and issue next to nothing (a cheap su-solve still issues a tenth of a hard one)
             top = sorted(v)[max(0, int(0.98 * len(v)) - 1)]
-            ex = [x for x in v if x > 0.4 * top] or v
+            ex = [x for x in v if x > 0.02 * top] or v
             print(f"{k[0]:28s} {k[1]:28s} dispatches {len(v):5d} per-dispatch {sum(v)/len(v):14.1f} executed {len(ex):5d} per-executed {sum(ex)/len(ex):14.1f}")
 except Exception as e:
     print("parse failed", e)
@@ -99,10 +99,11 @@ timeout 300 python bench.py --no-cpu-baseline --no-sizes --no-ip-legs --egos 0 -
 D="$SCR/stats_c5"; mkdir -p "$D"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o f -- python bench.py --no-cpu-baseline --no-sizes --no-ip-legs --egos 0 --fleet-egos 64 --n-obs 100 --horizon 25 --steps 100 > /dev/null 2>&1 || true
 find "$D" -name '*kernel_stats.csv' -exec cp {} "$OUT/c5_fleet_kernel_stats.csv" \;
-python tools/su_phase_profile.py > "$OUT/suprof_ns_fixed_binding.txt" 2>&1
-python tools/su_phase_profile.py --order > "$OUT/suprof_ns.txt" 2>&1
-python tools/su_phase_profile.py --n-obs 2000 --steps 60 --order > "$OUT/suprof_n2000.txt" 2>&1
-python tools/su_phase_profile.py --moving --horizon 30 --steps 60 --order > "$OUT/suprof_c4.txt" 2>&1
+# (the phase counters live in the profiling builds: tools/_bin/librda_hip_prof.so = -DSU_PROF, librda_hip_fine.so = -DSU_FINE, same sources)
+RDA_HIP_SO=$PWD/tools/_bin/librda_hip_prof.so python tools/su_phase_profile.py > "$OUT/suprof_ns_fixed_binding.txt" 2>&1
+RDA_HIP_SO=$PWD/tools/_bin/librda_hip_prof.so python tools/su_phase_profile.py --order > "$OUT/suprof_ns.txt" 2>&1
+RDA_HIP_SO=$PWD/tools/_bin/librda_hip_prof.so python tools/su_phase_profile.py --n-obs 2000 --steps 60 --order > "$OUT/suprof_n2000.txt" 2>&1
+RDA_HIP_SO=$PWD/tools/_bin/librda_hip_prof.so python tools/su_phase_profile.py --moving --horizon 30 --steps 60 --order > "$OUT/suprof_c4.txt" 2>&1
 if [ -f tools/_bin/librda_hip_fine.so ]; then      # -DSU_FINE build of the same sources (sub-phases of the iteration)
   RDA_HIP_SO=$PWD/tools/_bin/librda_hip_fine.so python tools/su_phase_profile.py --order --fine > "$OUT/suprof_ns_fine.txt" 2>&1
   RDA_HIP_SO=$PWD/tools/_bin/librda_hip_fine.so python tools/su_phase_profile.py --moving --horizon 30 --steps 60 --order --fine > "$OUT/suprof_c4_fine.txt" 2>&1

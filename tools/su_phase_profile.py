@@ -1,5 +1,7 @@
 """Phase cycle counters of the su-solves of a closed loop (rda_opts::su_prof + rda_debug_su_prof): where k_su's time goes in steady
-state - not in the cold stand-alone hook.  python tools/su_phase_profile.py [--n-obs N] [--horizon T] [--moving] [--steps K]
+state - not in the cold stand-alone hook.  Needs a PROFILING build of the library (the product build has no counters since round 5):
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSU_PROF -shared -o tools/_bin/librda_hip_prof.so rda_planner_amd/csrc/rda_hip.hip   (-DSU_FINE for --fine)
+  RDA_HIP_SO=tools/_bin/librda_hip_prof.so python tools/su_phase_profile.py [--n-obs N] [--horizon T] [--moving] [--steps K]
 Prints, per su-solve, the clock64 ticks of every phase marker of su::solve (su_device.h `mark(k)`)."""
 import argparse
 import ctypes as C
