@@ -145,6 +145,9 @@ typedef struct rda_opts {
                                 falls below 1e-15, factorisation breaking down: one oracle solve in 32 000 soak steps) returns it instead of
                                 'no update' (rda_solver.py:696-700).  Same rule as the oracle's orc_set_su_accept.  0: off; 2: test switch - every solve
                                 hands back its remembered iterate (the path is otherwise never taken)                     RDA_SU_ACCEPT */
+    int32_t su_first_attempt; /* [0] test switch: 1 = every su-solve starts with its LAST-RESORT attempt (plain long-step path following: no
+                                predictor, fixed centring, lam w >= 1e-2 mu; normally reached only when the warm and the cold attempt have both
+                                failed - csrc/su_device.h SU_SAFE_*).  Same solution, more iterations.                    (no env switch) */
     double  su_warm[2];      /* [1e-3, 1e-3] slack floor / barrier parameter of a warm start ("0,0" = always cold)      RDA_SU_WARM */
     double  su_warm_endgame[2]; /* [0.9999, 1e-5] floors of the fraction to the boundary / centering parameter, warm attempts  RDA_SU_WARM_ENDGAME */
     double  su_warm_clip;    /* [0.01]                                                                                  RDA_SU_WARM_CLIP */

@@ -66,6 +66,8 @@ static int g_su_cold_from = 7, g_su_cold_probe = 8;
 void orc_set_su_cold_from(int from, int probe) { g_su_cold_from = from; g_su_cold_probe = probe > 0 ? probe : 1; }
 #define SU_HARD_RD0 1e-2      /* = csrc/su_device.h */
 #define SU_HARD_DMU 1.0       /* = csrc/su_device.h */
+static int g_su_first_attempt = 0;               /* mirror of rda_opts::su_first_attempt (test switch): 1 = start with the last-resort attempt */
+void orc_set_su_first_attempt(int a) { g_su_first_attempt = a ? 1 : 0; }
 static int g_su_accept = 1;                      /* su_solve_impl: the near-converged iterate kept as a safety net (see there) */
 void orc_set_su_accept(int on) { g_su_accept = on; }      /* 2: test switch - ALWAYS return the remembered iterate (= csrc/su_device.h Args::accept) */
 void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
@@ -674,6 +676,10 @@ static void chol_solve(const double *K, int n, double *rhs)
 #endif
 #define SU_CENTRE_GAMMA 1e-5      /* = su_device.h */
 #define SU_SMOOTH_K 0.1           /* = su_device.h */
+#define SU_SAFE_SIGMA 0.3         /* last-resort attempt: centring parameter ... */
+#define SU_SAFE_SIGMA_END 0.05    /* ... once the last step was >= 0.9 */
+#define SU_SAFE_TAU 0.9           /* ... fraction to the boundary */
+#define SU_SAFE_GAMMA 1e-2        /* ... lam w >= this x mu after every step          (all four = su_device.h) */
 #ifndef SU_CENTRE_FROM
 #define SU_CENTRE_FROM 25         /* = su_device.h */
 #endif
@@ -737,12 +743,12 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
      * 1e-15 and the Cholesky factor breaks down (soak seed 9, scene 13, step 15; tests/golden/su_hard/omni_T25_N20_end_game_noise.npz:
      * the kernel's arithmetic converges in 16 iterations) - returns that iterate instead of "no update". */
     double *x_acc = malloc(sizeof(double) * n), *lm_acc = malloc(sizeof(double) * mc), acc_merit = INFINITY; int have_acc = 0;
-    /* Two attempts.  The second one only runs when the first ends without convergence (the iteration
-     * cap, ~0.1% of closed-loop solves, where the iterates cycle): it restarts from the same nominal
-     * with a more central point (slack floor 0.1, mu0 = 10), which is enough to break the cycle. */
+    /* Attempts: [-1 the warm start,] 0 the cold start, 1 the last resort.  The last one only runs when the others end without convergence
+     * (the iteration cap, ~0.1% of closed-loop solves, where the iterates cycle): it restarts from the same nominal with a more central
+     * point (slack floor 0.1, mu0 = 10) and - since round 5 - as a plain long-step path-following iteration (`safe` below). */
     int status = 1, it = 0, used = 0;
     warm = warm && lam_keep != NULL;
-    for (int attempt = warm ? -1 : 0; attempt < 2 && status != 0; ++attempt) {
+    for (int attempt = g_su_first_attempt ? 1 : (warm ? -1 : 0); attempt < 2 && status != 0; ++attempt) {
     const double wfl = attempt < 0 ? warm_wfl : (attempt ? 1e-1 : 1e-2), mu0 = attempt < 0 ? warm_mu0 : (attempt ? 10.0 : 1.0);
     const int it_cap = attempt < 0 ? warm_cap : 100;
     for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
@@ -783,7 +789,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         }
     }
     status = 1;
-    double mu_prev = 1.0;
+    double mu_prev = 1.0, al_prev = 0.0;
     for (it = 0; it < it_cap; ++it) {
         /* ... and in that rescue phase the hinge terms are smoothed over a width eps = SU_SMOOTH_K sqrt(mu) (mu of the previous iterate;
          * -> 0 with the complementarity: 3e-6 at the stop, 2e-8 in the controls): the other cycle of the semismooth iteration is a hinge
@@ -825,9 +831,16 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         }
         if (chol_factor(K, n)) { status = 2; break; }
         double sigma = 0, mu_aff = 0;
-        for (int pass = 0; pass < 2; ++pass) {
+        /* Last resort (attempt 1, round 5): plain long-step path following - no predictor, a fixed centring parameter (smaller once the steps
+         * are nearly full), a shorter fraction to the boundary, and every pair kept in the wide neighbourhood lam w >= SU_SAFE_GAMMA mu after
+         * each step.  Mehrotra's heuristics can cycle on this problem class (two rows trading places with steps of 0.02 / 0.6 for ever:
+         * tests/golden/su_hard/omni_T15_N51_rate_and_distance_rows_cycle.npz - both former attempts ran into their caps); this iteration has the
+         * textbook guarantee and is only reached when the two others have failed. */
+        const int safe = attempt == 1;
+        if (safe) sigma = al_prev >= 0.9 ? SU_SAFE_SIGMA_END : SU_SAFE_SIGMA;
+        for (int pass = safe ? 1 : 0; pass < 2; ++pass) {
             /* rc = lm*w (+ corrector) - sigma*mu */
-            for (int i = 0; i < mc; ++i) rc[i] = lm[i] * w[i] + (pass ? dl[i] * dw[i] - sigma * mu : 0.0);
+            for (int i = 0; i < mc; ++i) rc[i] = lm[i] * w[i] + (pass ? (safe ? 0.0 : dl[i] * dw[i]) - sigma * mu : 0.0);
             for (int i = 0; i < n; ++i) dx[i] = -rhs[i];
             for (int i = 0; i < mc; ++i) {
                 double v = (lm[i] * rp[i] - rc[i]) / w[i];
@@ -856,6 +869,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         /* fraction to the boundary: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game) */
         const double tau_min = attempt < 0 ? cur_warm_tau : 0.995;
         double al = 1.0, tau = 1.0 - mu; if (tau < tau_min) tau = tau_min;
+        if (safe) tau = SU_SAFE_TAU;
         for (int i = 0; i < mc; ++i) {
             if (dw[i] < 0 && -tau * w[i] / dw[i] < al) al = -tau * w[i] / dw[i];
             if (dl[i] < 0 && -tau * lm[i] / dl[i] < al) al = -tau * lm[i] / dl[i];
@@ -887,11 +901,13 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
          * the controls jump by 1e-2 (soak scene 30, step 39: the cold attempt AND the central restart ran into their caps;
          * tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz: 200 iterations and status 1 -> 32 iterations).  Solves that end
          * earlier - all of a recorded C4 / north-star closed loop (tools/su_replay.py) - are untouched. */
-        if (attempt >= 0 && it >= SU_CENTRE_FROM) {
+        if ((attempt >= 0 && it >= SU_CENTRE_FROM) || safe) {
+            const double gam = safe ? SU_SAFE_GAMMA : SU_CENTRE_GAMMA;
             double mun = 0; for (int i = 0; i < mc; ++i) mun += lm[i] * w[i];
             mun /= mc;
-            for (int i = 0; i < mc; ++i) if (lm[i] * w[i] < SU_CENTRE_GAMMA * mun) lm[i] = SU_CENTRE_GAMMA * mun / w[i];
+            for (int i = 0; i < mc; ++i) if (lm[i] * w[i] < gam * mun) lm[i] = gam * mun / w[i];
         }
+        al_prev = al;
     }
     used += it;
     }

@@ -114,6 +114,7 @@ void orc_set_su_easy(double wfl, double mu0, double clip, double tau, double sig
  * (default 7, 8) */
 void orc_set_su_hard_warm(double wfl, double mu0);
 void orc_set_su_cold_from(int from, int probe);
+void orc_set_su_first_attempt(int first);   /* test switch (= rda_opts::su_first_attempt): 1 = every su-solve starts with the last-resort attempt */
 void orc_get_su_ipm_hist(const orc_handle *h, int *out, int n);   /* debug: interior-point iterations of the su-solve of each ADMM iteration of the last step */
 /* interior-point stop of the su-problem: |r_dual| <= rd (1+|g|), |r_prim| <= rp, mean complementarity <= mu (1+|g|) */
 void orc_set_su_tol(double rd, double rp, double mu);

@@ -30,7 +30,7 @@ class Opts(C.Structure):
                 ("lmz_tail", C.c_int), ("lmz_ip_rows", C.c_int), ("lmz_ip_warm", C.c_int), ("su_pre", C.c_int), ("su_light", C.c_int),
                 ("su_warm_first", C.c_int), ("su_warm_cap", C.c_int), ("su_easy_max", C.c_int), ("su_easy_nopred", C.c_int),
                 ("su_cold_from", C.c_int), ("su_cold_probe", C.c_int), ("zero_copy", C.c_int), ("early_finish", C.c_int),
-                ("fuse_track", C.c_int), ("su_prof", C.c_int), ("su_split", C.c_int), ("duals_follow", C.c_int), ("su_accept", C.c_int),
+                ("fuse_track", C.c_int), ("su_prof", C.c_int), ("su_split", C.c_int), ("duals_follow", C.c_int), ("su_accept", C.c_int), ("su_first_attempt", C.c_int),
                 ("su_warm", C.c_double * 2), ("su_warm_endgame", C.c_double * 2), ("su_warm_clip", C.c_double),
                 ("su_easy", C.c_double * 5)]
 

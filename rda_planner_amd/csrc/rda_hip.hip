@@ -80,6 +80,7 @@ struct Dev {
     int su_light;                        // su_device Cfg::light_check
     int su_split;                        // su_device Args::split (time split of the Newton system)
     int su_accept;                       // su_device Args::accept (safety net: the best near-converged iterate)
+    int su_first_attempt;                // su_device Args::first_attempt (test switch)
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
@@ -269,7 +270,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (it > 0) { a.pose = d.pose; a.pose_lin = 1; }
     a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
-    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept;
+    a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept; a.first_attempt = d.su_first_attempt;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
@@ -1337,7 +1338,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0; o->su_hard_warm[0] = 1.0; o->su_hard_warm[1] = 1e-3;
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
-    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1;
+    o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1; o->su_first_attempt = 0;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1411,7 +1412,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_easy_max = o.su_easy_max; H->d.su_easy_nopred = o.su_easy_nopred;
     H->d.su_pre = o.su_pre; H->d.lmz_tail = o.lmz_tail;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
-    H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept;
+    H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept; H->d.su_first_attempt = o.su_first_attempt;
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     { const bool on = o.su_tol_early[0] > 0 && o.su_tol_early[1] > 0 && o.su_tol_early[2] > 0; for (int i = 0; i < 3; ++i) H->d.su_tol_early[i] = on ? o.su_tol_early[i] : 0.0; }
@@ -2950,7 +2951,7 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
     ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
     rda_opts od; rda_opts_init(&od);                   // the stop tolerances / switches: the caller's, else the defaults
     if (opts) od = *opts;
-    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2]; ar.split = od.su_split; ar.accept = od.su_accept;
+    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2]; ar.split = od.su_split; ar.accept = od.su_accept; ar.first_attempt = od.su_first_attempt;
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.cb = dsoa + 2 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;

@@ -34,6 +34,15 @@
 #define SU_CENTRE_GAMMA 1e-5     // cold attempts still running after SU_CENTRE_FROM iterations: lam w >= SU_CENTRE_GAMMA mu after every step (= oracle/rda_oracle.c)
 #define SU_CENTRE_FROM 25
 #define SU_SMOOTH_K 0.1          // ... and smooths its hinge terms over SU_SMOOTH_K sqrt(mu)
+// Last-resort attempt (attempt 1, round 5; = oracle/rda_oracle.c): plain long-step path following - no predictor, a fixed centring parameter (smaller once
+// the steps are nearly full), a shorter fraction to the boundary, every pair kept in the wide neighbourhood lam w >= SU_SAFE_GAMMA mu after each step.
+// Mehrotra's heuristics can cycle on this problem class (two rows trading places with steps of 0.02 / 0.6 for ever:
+// tests/golden/su_hard/omni_T15_N51_rate_and_distance_rows_cycle.npz - both former attempts of the oracle ran into their caps); this iteration has the
+// textbook guarantee (16 - 22 iterations on every recorded hard instance) and is only reached when the other attempts have failed.
+#define SU_SAFE_SIGMA 0.3
+#define SU_SAFE_SIGMA_END 0.05
+#define SU_SAFE_TAU 0.9
+#define SU_SAFE_GAMMA 1e-2
 // fp contraction per source expression, not per optimiser context: see lammuz_device.h (k_su, k_su_tracked, k_su_fleet and the
 // rda_su_solve hook inline the same solve and must round alike)
 #pragma clang fp contract(on)
@@ -121,6 +130,7 @@ struct Args {
     // safety net (= oracle/rda_oracle.c su_solve_impl, rda_opts::su_accept): the best iterate that is primal feasible to tol_rp, dual feasible to
     // 10 x tol_rd and complementary to 1000 x tol_mu is remembered (controls, distances, multipliers: Lds::acc) and returned when every attempt fails
     int accept = 1;                  // (2: test switch, see the end of solve)
+    int first_attempt = 0;           // test switch (rda_opts::su_first_attempt): 1 = start with the last-resort attempt
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
@@ -1059,9 +1069,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         pi = w;
     };
 
-    // Two attempts (same rule as the oracle): when the first one ends without convergence -- the iteration cap, ~0.1 % of
-    // closed-loop solves, where the iterates cycle -- restart from the same nominal with a more central point (slack floor
-    // 0.1, mu0 = 10) and every hinge term in play.
+    // Attempts (same rule as the oracle): when the cold one ends without convergence -- the iteration cap, ~0.1 % of closed-loop
+    // solves, where the iterates cycle -- restart from the same nominal with a more central point (slack floor 0.1, mu0 = 10),
+    // every hinge term in play and, since round 5, as the plain path-following iteration SU_SAFE_* (`safe`).
     int status = 1, it = 0, used = 0;
     bool have_acc = false; double acc_merit = 0.0;            // (uniform) safety net
     if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
@@ -1071,7 +1081,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     // converges within 3-4; with many moving obstacles it needs as many iterations as the cold start (8-20) but does arrive:
     // cutting it at 5 / 7 / 12 iterations and starting over cost +29 / +35 / +5 % on the dynamic_obs benchmark, 30 costs
     // nothing], 0: the cold start, 1: the central restart described above.
-    for (int attempt = warm ? -1 : 0; attempt < 2 && status != 0; ++attempt) {
+    for (int attempt = a.first_attempt ? 1 : (warm ? -1 : 0); attempt < 2 && status != 0; ++attempt) {
+    const bool safe = attempt == 1;                // (uniform) the last-resort iteration, see SU_SAFE_*
+    double al_prev = 0.0;
     if (attempt == 1 || (attempt == 0 && warm)) {
         __syncthreads();
         clip_controls(0.01);
@@ -1417,8 +1429,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         // The first iteration of an easy-mode warm attempt skips the predictor (a.warm_nopred): next to the solution the affine step
         // is a full step, so sigma ends at its floor anyway and the second-order term dl*dw is O(error^2) - one sweep pair instead of
         // two.  Should that iteration not finish the solve, the following ones are ordinary predictor-corrector iterations.
-        const bool nopred = attempt < 0 && a.warm_nopred != 0 && it == 0;
-        if (nopred) sigma = a.warm_sig;
+        const bool nopred = (attempt < 0 && a.warm_nopred != 0 && it == 0) || safe;
+        if (nopred) sigma = safe ? (al_prev >= 0.9 ? SU_SAFE_SIGMA_END : SU_SAFE_SIGMA) : a.warm_sig;
         bool unit_done = false;                    // time split: the unit sweeps / interface matrix of this factorisation exist
         if (msp > 0) __syncthreads();              // (the unit sweeps of waves 2 / 3 read the closed-loop rows all threads have just written)
         for (int pass = nopred ? 1 : 0; pass < 2; ++pass) {
@@ -1511,7 +1523,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             MF(0);
             // fraction to the boundary: 1 for the predictor; corrector: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
             double fr = 1.0;
-            if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; }
+            if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; if (safe) fr = SU_SAFE_TAU; }
             const double al = ratio > fr ? fr / ratio : 1.0;
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
@@ -1552,9 +1564,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 // (very) wide neighbourhood of the central path, lam w >= SU_CENTRE_GAMMA mu after the step, by raising the multiplier
                 // (same rule and reason as the oracle's su_solve_impl: two neighbouring rate rows traded places for ever,
                 // tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz).
-                const bool recentre = attempt >= 0 && it >= SU_CENTRE_FROM;
+                const bool recentre = (attempt >= 0 && it >= SU_CENTRE_FROM) || safe;
+                al_prev = al;
                 if (recentre) {
-                    const double floor_ = SU_CENTRE_GAMMA * m_;
+                    const double floor_ = (safe ? SU_SAFE_GAMMA : SU_CENTRE_GAMMA) * m_;
 #pragma unroll
                     for (int j = 0; j < NPR; ++j)
                         if (p_on[j]) {

@@ -109,3 +109,50 @@ def test_safety_net_hands_back_the_best_near_converged_iterate(hip, orc, T, N, d
     print(f"T={T} N={N}: |u_remembered - u_converged| {e_conv:.2e}, |u_remembered - oracle's remembered| {e_orc:.2e}, {it2} iterations")
     assert stc == 0 and 0 < e_conv <= 2e-4 and e_orc <= 1e-8              # (an iterate 10 x / 1000 x short of the stop test: the reference solver's class; the two cold solves walk the same path)
     assert np.abs(d2 - d1).max() <= 2e-4 and np.abs(s2 - s1).max() <= 2e-3
+
+
+SU_HARD = ["acker_T15_N27_weakly_active_c", "acker_T15_N45_rate_rows_cycle", "diff_T10_N13", "omni_T10_N33_restart", "omni_T15_N13", "omni_T15_N13_weakly_active_b",
+           "omni_T15_N30_weakly_active_a", "omni_T15_N40_hinge_flips", "omni_T15_N51_rate_and_distance_rows_cycle", "omni_T25_N20_end_game_noise",
+           "omni_T25_N26_stagnating_dual"]
+
+
+@pytest.mark.parametrize("name", SU_HARD)
+def test_last_resort_attempt_converges_on_every_recorded_hard_instance_like_the_oracles(hip, orc, name):
+    """round 5: the last-resort attempt of the su interior point is a plain long-step path-following iteration (csrc/su_device.h SU_SAFE_*,
+    oracle/rda_oracle.c `safe`).  Entered directly (rda_opts::su_first_attempt = 1 / orc_set_su_first_attempt) it converges on all eleven recorded
+    hard instances - 16 to 22 iterations in the oracle - incl. the one both Mehrotra attempts of the oracle cycled on for 100 iterations each
+    (soak seed 32, scene 57, step 58: a rate row and a distance row trading places); kernel and oracle walk the same path."""
+    import os
+    from rda_planner_amd._capi import Opts, dptr
+    import helpers as hp
+    cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", name + ".npz"))
+    T = cfg.T
+    o = Opts(); hip.opts_init(C.byref(o)); o.su_first_attempt = 1
+    s, u, d, it = np.zeros((3, T + 1)), np.zeros((2, T)), np.zeros(T), C.c_int(0)
+    st = hip.lib.rda_su_solve_opts(C.byref(cfg), C.byref(o), dptr(inp["nom_s"]), dptr(inp["nom_u"]), dptr(inp["ref"]), inp["vref"], dptr(inp["a"]),
+                                   dptr(inp["cc"]), dptr(inp["g"]), dptr(inp["d0"]), dptr(s), dptr(u), dptr(d), C.byref(it))
+    orc.lib.orc_set_su_first_attempt.argtypes = [C.c_int]
+    try:
+        orc.lib.orc_set_su_first_attempt(1)
+        so = hp.su_solve(orc.lib.orc_su_solve, cfg, inp)
+    finally:
+        orc.lib.orc_set_su_first_attempt(0)
+    print(f"{name}: last-resort attempt alone: gpu {it.value} / oracle {so[4]} iterations, |du| {np.abs(u - so[2]).max():.1e}")
+    # (the end-game-noise instance is the one where the oracle's dense Cholesky loses digits below mu = 1e-9: two iterations apart, weakly-active-row level)
+    noisy = name == "omni_T25_N20_end_game_noise"
+    assert st == 0 and so[0] == 0 and it.value <= 30 and abs(it.value - so[4]) <= (2 if noisy else 1)
+    tol = 1e-4 if noisy else 1e-6
+    assert np.abs(u - so[2]).max() < tol and np.abs(s - so[1]).max() < 10 * tol and np.abs(d - so[3]).max() < tol
+
+
+def test_the_instance_the_oracle_cycled_on_is_solved_by_both_sides(hip, orc):
+    """tests/golden/su_hard/omni_T15_N51_rate_and_distance_rows_cycle.npz through the default attempts: whatever the cold attempts do, both sides
+    end with status 0 and the same trajectory (to the weakly-active-row level: the paths differ)"""
+    import os
+    import helpers as hp
+    cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", "omni_T15_N51_rate_and_distance_rows_cycle.npz"))
+    so = hp.su_solve(orc.lib.orc_su_solve, cfg, inp)
+    sh = hp.su_solve(hip.lib.rda_su_solve, cfg, inp)
+    print(f"cycling instance: gpu status {sh[0]} / {sh[4]} iterations, oracle status {so[0]} / {so[4]} iterations, |du| {np.abs(sh[2] - so[2]).max():.1e}")
+    assert so[0] == 0 and sh[0] == 0
+    assert max(float(np.abs(so[k] - sh[k]).max()) for k in (1, 2, 3)) <= hp.TOL_U
