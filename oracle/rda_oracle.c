@@ -676,6 +676,7 @@ static void chol_solve(const double *K, int n, double *rhs)
 #endif
 #define SU_CENTRE_GAMMA 1e-5      /* = su_device.h */
 #define SU_SMOOTH_K 0.1           /* = su_device.h */
+#define SU_COLD_CAP 50            /* iterations granted to the cold attempt (= su_device.h) */
 #define SU_SAFE_SIGMA 0.3         /* last-resort attempt: centring parameter ... */
 #define SU_SAFE_SIGMA_END 0.05    /* ... once the last step was >= 0.9 */
 #define SU_SAFE_TAU 0.9           /* ... fraction to the boundary */
@@ -750,7 +751,9 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
     warm = warm && lam_keep != NULL;
     for (int attempt = g_su_first_attempt ? 1 : (warm ? -1 : 0); attempt < 2 && status != 0; ++attempt) {
     const double wfl = attempt < 0 ? warm_wfl : (attempt ? 1e-1 : 1e-2), mu0 = attempt < 0 ? warm_mu0 : (attempt ? 10.0 : 1.0);
-    const int it_cap = attempt < 0 ? warm_cap : 100;
+    /* (the cold attempt: 50 since round 5 - it was 100 while the last resort was a second Mehrotra attempt; every recorded solve that the cold
+     * attempt finishes at all takes <= 37 iterations, a cycling one is better off in the last resort after 50 than after 100) */
+    const int it_cap = attempt < 0 ? warm_cap : (attempt == 0 ? SU_COLD_CAP : 100);
     for (int t = 0; t < T; ++t) for (int i = 0; i < 2; ++i) {
         const double clipm = attempt < 0 ? cur_warm_clip : 0.01;
         double v = nom_u[i * T + t], lim = (1.0 - clipm) * c->max_speed[i];

@@ -39,6 +39,7 @@
 // Mehrotra's heuristics can cycle on this problem class (two rows trading places with steps of 0.02 / 0.6 for ever:
 // tests/golden/su_hard/omni_T15_N51_rate_and_distance_rows_cycle.npz - both former attempts of the oracle ran into their caps); this iteration has the
 // textbook guarantee (16 - 22 iterations on every recorded hard instance) and is only reached when the other attempts have failed.
+#define SU_COLD_CAP 50
 #define SU_SAFE_SIGMA 0.3
 #define SU_SAFE_SIGMA_END 0.05
 #define SU_SAFE_TAU 0.9
@@ -1094,7 +1095,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         __syncthreads();
         status = 1;
     }
-    const int it_cap = attempt < 0 ? a.warm_cap : 100;
+    const int it_cap = attempt < 0 ? a.warm_cap : (attempt == 0 ? SU_COLD_CAP : 100);       // (the cold attempt: 50 since round 5, see the oracle)
     const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
     bool expect_conv = false;
     double mu_prev = 1.0;
