@@ -30,17 +30,19 @@ def body_rates(u, dyn, L):
     return np.array([v * np.cos(w), v * np.sin(w)])
 
 
-def draw_scene(rng, seed, s, steps):
-    """the random draws of scene s (kinematics, horizon, obstacle field, solver arguments) - one rng stream per soak, consumed in scene order"""
+def draw_scene(rng, seed, s, steps, large=False):
+    """the random draws of scene s (kinematics, horizon, obstacle field, solver arguments) - one rng stream per soak, consumed in scene order.
+    `large`: the BASELINE regime instead of the examples' (T in {20, 25, 30}, 100 - 420 obstacles in a field 2.5 times as wide)"""
     dyn = ["acker", "diff", "omni"][int(rng.integers(3))]
-    T = int(rng.choice([10, 15, 20, 25]))
-    N = int(rng.integers(8, 60))
+    T = int(rng.choice([20, 25, 30] if large else [10, 15, 20, 25]))
+    N = int(rng.integers(100, 420)) if large else int(rng.integers(8, 60))
     car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
     y = 25.0
     path = sc.line_path([4, y, 0], [4 + 0.4 * steps + 12, y, 0], 0.1)
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
     moving = bool(rng.integers(2))
-    scene = sc.scene_polygons(N, lo=(6, y - 12), hi=(4 + 0.4 * steps + 14, y + 12), seed=1000 * seed + s, keep_clear=clear,
+    half = 30 if large else 12
+    scene = sc.scene_polygons(N, lo=(6, y - half), hi=(4 + 0.4 * steps + 14, y + half), seed=1000 * seed + s, keep_clear=clear,
                               clear_radius=float(rng.uniform(2.4, 3.4)), moving=moving)
     for _ in range(int(rng.integers(0, 4))):
         scene.append(sc.circle(float(rng.uniform(10, 40)), y + float(rng.choice([-1, 1])) * float(rng.uniform(3.5, 8)),
@@ -52,7 +54,7 @@ def draw_scene(rng, seed, s, steps):
 
 
 def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, only=-1, threads=None, dump_dir="", dump_tol=1e-5,
-             su_dump="", so="", log=print, hip_kw=None):
+             su_dump="", so="", log=print, hip_kw=None, large=False):
     """returns a dict of totals + the per-step outliers; `log` receives one line per remarkable step"""
     lib = orc_api().lib
     if so:
@@ -78,7 +80,7 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
                ipm_gpu=0, ipm_cpu=0)
     try:
         for s in range(scenes):
-            d = draw_scene(rng, seed, s, steps)
+            d = draw_scene(rng, seed, s, steps, large)
             if only >= 0 and s != only:
                 continue
             kw = dict(d["kw"])
