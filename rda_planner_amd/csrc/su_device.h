@@ -180,7 +180,7 @@ __device__ __host__ constexpr int near_max(int T) { return T <= 40 ? 512 : 256; 
 // ... and what the LIST itself may hold (round 5).  A solve with more near terms than near_max keeps them in LDS all the same and sums them as (stage,
 // chunk) partials - what it did over the masks in global memory before (N = 2000: 13.6 k cycles per hinge pass, 25 % of the solve).  Sized to the LDS
 // the other arrays leave (160 KB per workgroup; 32 B per term)
-__device__ __host__ constexpr int near_cap(int T) { return T <= 20 ? 1792 : (T <= 25 ? 1536 : (T <= 30 ? 1280 : (T <= 50 ? 1024 : 256))); }
+__device__ __host__ constexpr int near_cap(int T) { return T <= 20 ? 1792 : (T <= 25 ? 1536 : (T <= 30 ? 1280 : (T <= 35 ? 1024 : (T <= 40 ? 896 : (T <= 50 ? 1024 : 256))))); }
 // Stage strides of the big per-stage arrays (doubles).  The natural sizes 48 / 64 are multiples of 32 dwords: the rows of stage t and t + 2 (or t + 1)
 // then start on the same LDS banks and every (stage, row)-thread phase runs 2-way conflicted.  Round 5, k_su<20> in the headline loop,
 // SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS per dispatch (tools/experiments/lds_conflicts.sh): 48/64/24/36 -> 1.04, HB = 66 -> 0.94, + FT = 50 -> 0.84,
@@ -197,7 +197,7 @@ constexpr int HB = SU_HB;   // full 8x8 stage Hessian base; re-used after the ma
 constexpr int WN = SU_WN;   // W (5x3) | Minv sym (6) | pad                                                          (21 used)
 constexpr int MF = SU_MF;   // forward sweep rows [6][6]                                                             (36 used)
 static_assert(FT >= 48 && HB >= 64 && WN >= 21 && MF >= 36 && FT % 2 == 0 && HB % 2 == 0 && MF % 2 == 0, "stage strides: rows are read as 16-byte pairs");
-__device__ __host__ inline int ev(int n) { return (n + 1) & ~1; }
+__device__ __host__ constexpr int ev(int n) { return (n + 1) & ~1; }
 // time split of the Newton system: the horizons with a compile-time instantiation are cut in two halves (0 = no split)
 __device__ __host__ constexpr int split_point(int T) { return (T == 10 || T == 20 || T == 25 || T == 30) ? T / 2 : 0; }
 struct Lds {
@@ -241,7 +241,7 @@ struct Lds {
         con = part; if (near_max(T) > NT) { con = p; p += 9 * near_max(T); }      // the terms' contributions [near_max][9] (one per thread: the scratch of the partials)
     }
 };
-inline size_t lds_bytes(int T)
+constexpr size_t lds_bytes(int T)
 {
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
@@ -249,6 +249,10 @@ inline size_t lds_bytes(int T)
              + ev(13 * T) + 4 * near_cap(T) + NT / 2 + ev(T + 2) / 2 + 1 + (near_max(T) > NT ? 9 * near_max(T) : 0);
     return n * sizeof(double);
 }
+// every horizon the interface accepts (RDA_TMAX = 64) must fit the 160 KB a workgroup can have (round 5: T = 36 .. 40 did not for a while - the near
+// list was sized per range of T, the safety-net block and the padded strides came on top, and no test created such a handle)
+constexpr bool lds_fits_all() { for (int T = 1; T <= 64; ++T) if (lds_bytes(T) > 160 * 1024) return false; return true; }
+static_assert(lds_fits_all(), "su::Lds: some horizon T <= 64 needs more than 160 KB of LDS - shrink near_cap(T) there");
 
 // constraint row k of stage t: value c'y, rhs e.  y = [s(3) up(2) u(2) d]
 __device__ __forceinline__ double con_val(int k, double u0, double u1, double up0, double up1, double dd)

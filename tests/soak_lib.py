@@ -30,13 +30,32 @@ def body_rates(u, dyn, L):
     return np.array([v * np.cos(w), v * np.sin(w)])
 
 
-def draw_scene(rng, seed, s, steps, large=False):
+def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False):
     """the random draws of scene s (kinematics, horizon, obstacle field, solver arguments) - one rng stream per soak, consumed in scene order.
-    `large`: the BASELINE regime instead of the examples' (T in {20, 25, 30}, 100 - 420 obstacles in a field 2.5 times as wide)"""
+    `large`: the BASELINE regime instead of the examples' (T in {20, 25, 30}, 100 - 420 obstacles in a field 2.5 times as wide).
+    `exotic`: what the examples do not use but the reference interface allows - the reference's default max_edge_num = 5 and more (polygons
+    with 3 .. E vertices), a circle robot (norm2 cone, R = 3; `circle_robot`: the interior-point LamMuZ mode only, like the library), accelerated=False, horizons outside the compiled instantiations (5, 12, 40),
+    obstacle_order=False, other penalty weights"""
     dyn = ["acker", "diff", "omni"][int(rng.integers(3))]
     T = int(rng.choice([20, 25, 30] if large else [10, 15, 20, 25]))
     N = int(rng.integers(100, 420)) if large else int(rng.integers(8, 60))
-    car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+    E, extra, kmax = 4, {}, 4
+    if exotic:
+        T = int(rng.choice([5, 12, 20, 40]))
+        E = int(rng.choice([5, 6, 8])); kmax = E
+        if rng.random() < 0.4 and dyn != "acker" and circle_robot:        # (the draw is made either way: same scenes in both LamMuZ modes)
+            car_t = sc.circle_robot(radius=float(rng.uniform(0.5, 1.0)), dynamics=dyn)
+        else:
+            car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+        if rng.random() < 0.25:
+            extra["accelerated"] = False
+        if rng.random() < 0.3:
+            extra["obstacle_order"] = False
+        if rng.random() < 0.5:
+            extra.update(ro2=float(rng.choice([0.5, 2.0])), slack_gain=float(rng.choice([4, 8, 12])), max_sd=float(rng.choice([0.8, 1.0, 1.5])),
+                         min_sd=float(rng.choice([0.05, 0.1, 0.3])))
+    else:
+        car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
     y = 25.0
     path = sc.line_path([4, y, 0], [4 + 0.4 * steps + 12, y, 0], 0.1)
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
@@ -44,17 +63,23 @@ def draw_scene(rng, seed, s, steps, large=False):
     half = 30 if large else 12
     scene = sc.scene_polygons(N, lo=(6, y - half), hi=(4 + 0.4 * steps + 14, y + half), seed=1000 * seed + s, keep_clear=clear,
                               clear_radius=float(rng.uniform(2.4, 3.4)), moving=moving)
+    if kmax > 4:             # every other polygon redrawn with 3 .. E vertices (same centre region, own stream)
+        r2 = np.random.default_rng(7000 * seed + s)
+        for i in range(0, len(scene), 2):
+            o = scene[i]; c = o.vertex.mean(axis=1)
+            scene[i] = sc.regular_polygon(c[0], c[1], int(r2.integers(3, kmax + 1)), float(r2.uniform(0.5, 1.0)), float(r2.uniform(-np.pi, np.pi)),
+                                          tuple(o.velocity.ravel()))
     for _ in range(int(rng.integers(0, 4))):
         scene.append(sc.circle(float(rng.uniform(10, 40)), y + float(rng.choice([-1, 1])) * float(rng.uniform(3.5, 8)),
                                float(rng.uniform(0.4, 1.2)), (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))))
-    kw = dict(receding=T, iter_num=int(rng.integers(2, 5)), max_edge_num=4, max_obs_num=int(rng.integers(max(4, N // 2), N + 6)),
-              ro1=float(rng.choice([200, 300])), time_print=False)
+    kw = dict(receding=T, iter_num=int(rng.integers(2, 5)), max_edge_num=E, max_obs_num=int(rng.integers(max(4, N // 2), N + 6)),
+              ro1=float(rng.choice([200, 300])), time_print=False, **extra)
     speed = float(rng.uniform(2.5, 4.5))
     return dict(dyn=dyn, T=T, N=N, car=car_t, path=path, scene=scene, kw=kw, speed=speed, moving=moving)
 
 
 def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, only=-1, threads=None, dump_dir="", dump_tol=1e-5,
-             su_dump="", so="", log=print, hip_kw=None, large=False):
+             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False):
     """returns a dict of totals + the per-step outliers; `log` receives one line per remarkable step"""
     lib = orc_api().lib
     if so:
@@ -80,7 +105,7 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
                ipm_gpu=0, ipm_cpu=0)
     try:
         for s in range(scenes):
-            d = draw_scene(rng, seed, s, steps, large)
+            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0)
             if only >= 0 and s != only:
                 continue
             kw = dict(d["kw"])
@@ -93,6 +118,8 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
                 st[2, 0] = 0.0
             L = d["car"].wheelbase or 1.0
             tag = f"scene {s} ({d['dyn']} T={d['T']} N={d['N']}{' moving' if d['moving'] else ''})"
+            if exotic:
+                tag = tag[:-1] + f" E={kw['max_edge_num']} robot={d['car'].cone_type}" + "".join(f" {k}={v}" for k, v in kw.items() if k in ("accelerated", "obstacle_order", "ro2")) + ")"
             for k in range(steps):
                 cur = [o if not np.any(o.velocity) else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
                                                          else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in d["scene"]]
