@@ -30,12 +30,13 @@ def body_rates(u, dyn, L):
     return np.array([v * np.cos(w), v * np.sin(w)])
 
 
-def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False):
+def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False, tight=False):
     """the random draws of scene s (kinematics, horizon, obstacle field, solver arguments) - one rng stream per soak, consumed in scene order.
     `large`: the BASELINE regime instead of the examples' (T in {20, 25, 30}, 100 - 420 obstacles in a field 2.5 times as wide).
     `exotic`: what the examples do not use but the reference interface allows - the reference's default max_edge_num = 5 and more (polygons
     with 3 .. E vertices), a circle robot (norm2 cone, R = 3; `circle_robot`: the interior-point LamMuZ mode only, like the library), accelerated=False, horizons outside the compiled instantiations (5, 12, 40),
-    obstacle_order=False, other penalty weights"""
+    obstacle_order=False, other penalty weights.
+    `tight`: half the clearance between path and obstacles (1.2 - 1.7 m for a 1.6 m wide body: the lane is blocked here and there)"""
     dyn = ["acker", "diff", "omni"][int(rng.integers(3))]
     T = int(rng.choice([20, 25, 30] if large else [10, 15, 20, 25]))
     N = int(rng.integers(100, 420)) if large else int(rng.integers(8, 60))
@@ -62,7 +63,7 @@ def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=Fals
     moving = bool(rng.integers(2))
     half = 30 if large else 12
     scene = sc.scene_polygons(N, lo=(6, y - half), hi=(4 + 0.4 * steps + 14, y + half), seed=1000 * seed + s, keep_clear=clear,
-                              clear_radius=float(rng.uniform(2.4, 3.4)), moving=moving)
+                              clear_radius=float(rng.uniform(2.4, 3.4)) * (0.5 if tight else 1.0), moving=moving)
     if kmax > 4:             # every other polygon redrawn with 3 .. E vertices (same centre region, own stream)
         r2 = np.random.default_rng(7000 * seed + s)
         for i in range(0, len(scene), 2):
@@ -79,7 +80,7 @@ def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=Fals
 
 
 def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, only=-1, threads=None, dump_dir="", dump_tol=1e-5,
-             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False):
+             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False, tight=False):
     """returns a dict of totals + the per-step outliers; `log` receives one line per remarkable step"""
     lib = orc_api().lib
     if so:
@@ -105,7 +106,7 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
                ipm_gpu=0, ipm_cpu=0)
     try:
         for s in range(scenes):
-            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0)
+            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0, tight)
             if only >= 0 and s != only:
                 continue
             kw = dict(d["kw"])
