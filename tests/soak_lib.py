@@ -30,12 +30,13 @@ def body_rates(u, dyn, L):
     return np.array([v * np.cos(w), v * np.sin(w)])
 
 
-def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False, tight=False):
+def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False, tight=False, robots=False):
     """the random draws of scene s (kinematics, horizon, obstacle field, solver arguments) - one rng stream per soak, consumed in scene order.
     `large`: the BASELINE regime instead of the examples' (T in {20, 25, 30}, 100 - 420 obstacles in a field 2.5 times as wide).
     `exotic`: what the examples do not use but the reference interface allows - the reference's default max_edge_num = 5 and more (polygons
     with 3 .. E vertices), a circle robot (norm2 cone, R = 3; `circle_robot`: the interior-point LamMuZ mode only, like the library), accelerated=False, horizons outside the compiled instantiations (5, 12, 40),
     obstacle_order=False, other penalty weights.
+    `robots` (with exotic): convex bodies with 3 / 5 / 6 / 8 edges instead of the rectangle.
     `tight`: half the clearance between path and obstacles (1.2 - 1.7 m for a 1.6 m wide body: the lane is blocked here and there)"""
     dyn = ["acker", "diff", "omni"][int(rng.integers(3))]
     T = int(rng.choice([20, 25, 30] if large else [10, 15, 20, 25]))
@@ -48,6 +49,13 @@ def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=Fals
             car_t = sc.circle_robot(radius=float(rng.uniform(0.5, 1.0)), dynamics=dyn)
         else:
             car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+        if robots and car_t.cone_type == "Rpositive" and rng.random() < 0.6:
+            # a convex k-gon body, k in {3, 5, 6, 8} (R = k half-spaces; E + R + 1 > 16 leaves the packed LamMuZ kernel for the one-row-per-wave form)
+            k = int(rng.choice([3, 5, 6, 8]))
+            ang = 2 * np.pi * (np.arange(k) + 0.5) / k
+            V = np.vstack((1.5 + 2.3 * np.cos(ang) if dyn == "acker" else 2.3 * np.cos(ang), 0.9 * np.sin(ang)))
+            Gk, hk = sc.polygon_halfspaces(V)
+            car_t = car_t._replace(G=Gk, h=hk)
         if rng.random() < 0.25:
             extra["accelerated"] = False
         if rng.random() < 0.3:
@@ -80,7 +88,7 @@ def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=Fals
 
 
 def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, only=-1, threads=None, dump_dir="", dump_tol=1e-5,
-             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False, tight=False):
+             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False, tight=False, robots=False):
     """returns a dict of totals + the per-step outliers; `log` receives one line per remarkable step"""
     lib = orc_api().lib
     if so:
@@ -106,7 +114,7 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
                ipm_gpu=0, ipm_cpu=0)
     try:
         for s in range(scenes):
-            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0, tight)
+            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0, tight, robots)
             if only >= 0 and s != only:
                 continue
             kw = dict(d["kw"])
@@ -120,7 +128,7 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
             L = d["car"].wheelbase or 1.0
             tag = f"scene {s} ({d['dyn']} T={d['T']} N={d['N']}{' moving' if d['moving'] else ''})"
             if exotic:
-                tag = tag[:-1] + f" E={kw['max_edge_num']} robot={d['car'].cone_type}" + "".join(f" {k}={v}" for k, v in kw.items() if k in ("accelerated", "obstacle_order", "ro2")) + ")"
+                tag = tag[:-1] + f" E={kw['max_edge_num']} robot={d['car'].cone_type} R={np.shape(d['car'].G)[0]}" + "".join(f" {k}={v}" for k, v in kw.items() if k in ("accelerated", "obstacle_order", "ro2")) + ")"
             for k in range(steps):
                 cur = [o if not np.any(o.velocity) else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
                                                          else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in d["scene"]]
