@@ -181,3 +181,55 @@ def test_fleet_control_equals_member_control(mixed):
     assert sum(arrived) >= 3
     assert (fleet.batched_ticks == 0) if mixed else (fleet.batched_ticks > 0)
     fleet.close()
+
+
+@pytest.mark.parametrize("T,E,robot_k", [(40, 4, 4), (12, 8, 8), (33, 6, 3), (64, 5, 5)])
+def test_fleet_control_equals_member_control_other_shapes(T, E, robot_k):
+    """the same bit-for-bit statement on shapes the examples do not use: horizons without a compile-time su instantiation (generic T), obstacle
+    polygons with up to E vertices, robot bodies with 3 / 5 / 8 edges (E + R + 1 > 16: the fleet form of the one-row-per-wave LamMuZ kernel)"""
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd.fleet import Fleet
+    B = 5
+    rng = np.random.default_rng(100 * T + E)
+    solo, memb, cars, scenes, states = [], [], [], [], []
+    for i in range(B):
+        dyn = ["acker", "diff", "omni"][i % 3]
+        car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)
+        if robot_k != 4:
+            ang = 2 * np.pi * (np.arange(robot_k) + 0.5) / robot_k
+            Gk, hk = sc.polygon_halfspaces(np.vstack(((1.5 if dyn == "acker" else 0.0) + 2.3 * np.cos(ang), 0.9 * np.sin(ang))))
+            car_t = car_t._replace(G=Gk, h=hk)
+        y = 20.0 + 3 * i
+        path = sc.line_path([4, y, 0], [30, y, 0], 0.1)
+        clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+        scene = []
+        while len(scene) < 14:
+            c = rng.uniform((6, y - 10), (34, y + 10))
+            if np.min(np.linalg.norm(clear - c, axis=1)) < 3.0:
+                continue
+            vel = rng.uniform(-0.4, 0.4, 2) if i % 2 == 0 else (0.0, 0.0)
+            scene.append(sc.regular_polygon(c[0], c[1], int(rng.integers(3, E + 1)), rng.uniform(0.5, 1.0), rng.uniform(-np.pi, np.pi), vel))
+        scene.append(sc.circle(15.0, y + 4.0, 0.8, (0.0, -0.2)))
+        kw = dict(receding=T, iter_num=3, max_edge_num=E, max_obs_num=12)
+        solo.append(MPC(car_t, [p.copy() for p in path], **kw))
+        memb.append(MPC(car_t, [p.copy() for p in path], **kw))
+        cars.append(car_t); scenes.append(scene)
+        st = path[0].copy().reshape(3, 1)
+        if dyn == "omni":
+            st[2, 0] = 0.0
+        states.append(st)
+    fleet = Fleet(memb)
+    for k in range(25):
+        cur = [[o if not o.velocity.any() else (o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive"
+                                                else o._replace(center=o.center + o.velocity * (0.1 * k))) for o in scenes[i]] for i in range(B)]
+        res = fleet.control([s.copy() for s in states], 3.5, [list(c) for c in cur])
+        for i in range(B):
+            u, info = solo[i].control(states[i].copy(), 3.5, list(cur[i]))
+            uf, inf = res[i]
+            assert info["status"] == 0 and inf["status"] == 0, (k, i)
+            assert np.array_equal(u, uf), (k, i, np.abs(u - uf).max())
+            assert info["iters"] == inf["iters"] and info["resi_dual"] == inf["resi_dual"] and info["resi_pri"] == inf["resi_pri"]
+            assert np.array_equal(np.hstack(info["opt_state_list"]), np.hstack(inf["opt_state_list"]))
+            states[i] = sc.kinematic_step(states[i], u, cars[i], 0.1)
+    assert fleet.batched_ticks > 0
+    fleet.close()
