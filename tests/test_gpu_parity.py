@@ -233,7 +233,7 @@ def test_error_codes(hip):
     assert b"unsupported" in hip.lib.rda_strerror(-2)
 
 
-@pytest.mark.parametrize("world,n_obs,su_pre", [(2, 6, 1), (2, 5, 1), (3, 7, 1), (2, 6, 0)])
+@pytest.mark.parametrize("world,n_obs,su_pre", [(2, 6, 1), (2, 5, 1), (3, 7, 1), (2, 6, 0), (8, 200, 1), (4, 2001, 1)])
 def test_obstacle_shards_emulated_ranks_one_gpu(hip, world, n_obs, su_pre):
     """N>1 path of the HIP library on one device: `world` handles act as the ranks of an obstacle shard, the per-iteration
     all-gather is emulated on the host (rda_shard_get_chunk / set_chunks).  All ranks must agree bit for bit with each
@@ -246,7 +246,7 @@ def test_obstacle_shards_emulated_ranks_one_gpu(hip, world, n_obs, su_pre):
     from rda_planner_amd.sharded import ShardedRDA
     from test_sharded_gloo import _problem
     import ctypes
-    car_t, T, N, rl, steps = _problem(n_obs)
+    car_t, T, N, rl, steps = _problem(n_obs, 8 if n_obs <= 50 else 20)       # (the last two: BASELINE sizes, 25 / 501 slots per rank, uneven at 2001)
     single = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
     ranks = [RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False, hip_opts=hip_options(su_pre=su_pre)) for _ in range(world)]
     sh = [ShardedRDA(ranks[r], r, world, lambda c: c) for r in range(world)]

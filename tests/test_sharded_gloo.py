@@ -11,12 +11,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _problem(N=6):
+def _problem(N=6, T=8):
     from rda_planner_amd import scenarios as sc
     from rda_planner_amd.mpc import MPC
     car_t = sc.rectangle_robot(dynamics="acker")
-    T = 8
-    obstacles = sc.scene_polygons(N, lo=(4, -6), hi=(16, 6), seed=11)
+    if N <= 50:
+        obstacles = sc.scene_polygons(N, lo=(4, -6), hi=(16, 6), seed=11)
+    else:                                               # BASELINE sizes: a field that leaves the lane along the x axis open
+        lane = np.array([[x, 0.0] for x in np.arange(0.0, 14.0, 1.0)])
+        obstacles = sc.scene_polygons(N, lo=(2, -40), hi=(50, 40), seed=11, keep_clear=lane, clear_radius=3.0)
     conv = MPC.__new__(MPC)
     conv.receding, conv.dt, conv.state = T, 0.1, np.zeros((3, 1))
     rl = MPC.convert_rda_obstacle(conv, obstacles, np.zeros((3, 1)), False)
