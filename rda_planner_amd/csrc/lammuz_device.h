@@ -513,12 +513,12 @@ template <int GW> struct Grp {
     template <typename Tv> static __device__ __forceinline__ Tv bcast(Tv v, int src) { return __shfl(v, src, GW); }
 };
 
-// Warm start for polygon obstacles: the support (non-zero pattern) of the previous (lam, mu) of this (obstacle, stage)
+// Warm start (polygon obstacles; since round 5 circles too - warm_circle): the support (non-zero pattern) of the previous (lam, mu) of this (obstacle, stage)
 // usually survives from one ADMM iteration / MPC step to the next.  Lanes 0 and 1 solve that one support for the
 // two hinge states, every lane then checks the optimality conditions of the FULL problem for the result
 // (lam_i >= 0 : g_i + nu A_i'a^ >= 0 off the support, mu_j >= 0 : g_j >= 0 off the support, nu >= 0 for |A'lam| <= 1).
 // The problem is convex, so a point that passes is a global minimiser and the enumeration is skipped; any doubt
-// (sign, tolerance, circle obstacle, no hint yet) falls back to solve_wave.  Call after prepare_wave.  `hint` is the
+// (sign, tolerance, no hint yet) falls back to solve_wave.  Call after prepare_wave.  `hint` is the
 // candidate index il*n_mu + im remembered from the last solve of this (n, t) (-1: none); it is only a hint - whatever it
 // is, a result is accepted on the certificate alone.
 // k-th neighbour of a support candidate c in the list cand[0..ncand) of n rows (0 = empty, 1..n = one row, beyond = a pair that meets in
@@ -540,10 +540,102 @@ __device__ __forceinline__ int support_neighbour(int c, int n, const unsigned ch
     return k == 0 ? 1 + a : (k == 1 ? 1 + b : -1);
 }
 
+// ---- remembered support of a CIRCLE obstacle (round 5).  With lam_3 = -|a| (always tight: the cost falls with m) the problem is: min over the disc |a| <= 1 and
+// mu >= 0 of phi(m) + ro2/2 |H|^2,  m = kappa0 + at'ut + l0 |at| - h'mu (l0 = -radius),  H = at + xi + G'mu,  at = R'a - convex, with a kink at a = 0.  The three
+// lam candidates of the enumeration are the three places the minimiser can be: a = 0 (gradient of the smooth part inside the kink's subdifferential),
+// 0 < |a| < 1 (gradient zero), |a| = 1 (gradient = -nu a, nu >= 0).  STRICT margins between them, like the strict complementarity of the polygon rows: a point on the
+// border of two cases is described by two candidates and goes to the enumeration, which ranks them by (cost, id).  Round 1: the remembered (lam case, mu support) in
+// both hinge states; round 2: the other two lam cases and the mu supports one row away.  Before this, every circle row went through the 64-lane enumeration on
+// every ADMM iteration, one row after the other: 200 circles 658 -> 871 steps/s, 40 circles 748 -> 1134 (Python API loop, tools/experiments/circle_obstacles.py).
+// A routine of its own, called by the single-ego launch form only (lammuz_body_rows<0, true>) BEHIND the polygon rows' attempt: sharing solve_wave_warm's candidate
+// evaluations put the circle cases (the interior one is a Newton iteration) into the polygon rows' code - 121 instead of 53 spilled VGPRs in the dense launch form,
+// N = 2000: LamMuZ 75.6 -> 82.6 us, the 64-ego fleet 99 k -> 89 k ego-steps/s (same-box A/B, tools/experiments/ab_so.sh); out of line (noinline) its 248 VGPRs
+// became the register count of every kernel that can reach it (occupancy 3 -> 1).  The dense forms and the fleet keep sending their circle rows to the enumeration.
+template <int GW> __device__ __forceinline__ bool warm_circle(const WaveLDS &W, const RobotLDS &Rb, const Params &P, int wlane, int hint, Sol &best)
+{
+    const int lane = wlane & (GW - 1), R = P.R, E = P.E, nm0 = 1 + R + R * (R - 1) / 2;
+    if (hint < 0) return false;
+    const int il = hint / nm0, im = hint - il * nm0;
+    if (il > 2) return false;
+    // Every tolerance RELATIVE to the size of the gradient's own terms (no "1 +"): in the slack regime (m > 0, H -> 0) they are all of size delta = 1e-6, and
+    // the interior candidate comes from a Newton iteration that accepts its point at an ABSOLUTE 1e-9 - there it can hand back a point that is not stationary
+    // at all (found by tools/soak.py --circles: |a| = 0.51 with one mu row, the minimiser had |a| = 1 and two; the enumeration drops such a candidate by its
+    // cost, a certificate with absolute tolerances let it pass).  Anything that does not pass goes to the enumeration, as ever.
+    auto certify = [&]() -> bool {
+        const double na = best.i1 >= 0 ? hypot(best.l1, best.l2) : 0.0;
+        if (na > 1.0 + 1e-12) return false;
+        const double phim = (best.m < 0 ? best.m : 0.0) - P.delta;
+        const double dvx = P.px - W.b[0], dvy = P.py - W.b[1], l0 = W.b[2];
+        const double ut0 = P.cs * dvx + P.sn * dvy, ut1 = -P.sn * dvx + P.cs * dvy;                    // R'(p - centre)
+        const double at0 = P.cs * best.l1 + P.sn * best.l2, at1 = -P.sn * best.l1 + P.cs * best.l2;    // R'a
+        const double g0 = phim * ut0 + P.ro2 * best.H0, g1 = phim * ut1 + P.ro2 * best.H1, ck = phim * l0;
+        const double gs = fabs(phim) * (hypot(ut0, ut1) + fabs(l0)) + P.ro2 * hypot(best.H0, best.H1);
+        bool pass;
+        if (!(na > 0)) pass = hypot(g0, g1) < ck * (1.0 - 1e-6);
+        else {
+            const double gr0 = g0 + ck * at0 / na, gr1 = g1 + ck * at1 / na;
+            if (na < 1.0 - 1e-6) pass = na > 1e-6 && hypot(gr0, gr1) <= 1e-7 * gs;
+            else { const double nu = -(gr0 * at0 + gr1 * at1), tz = gr1 * at0 - gr0 * at1; pass = na >= 1.0 - 1e-12 && nu > 1e-6 * gs && fabs(tz) <= 1e-7 * gs; }
+        }
+        if (lane >= E && lane < E + R) {          // the robot side, one row per lane: mu_j >= 0 with gradient g_j - zero on the support, positive off it
+            const int j = lane - E;
+            const double gj = -phim * Rb.h[j] + P.ro2 * (Rb.G[j][0] * best.H0 + Rb.G[j][1] * best.H1);
+            const double sj = fabs(phim * Rb.h[j]) + P.ro2 * (fabs(Rb.G[j][0] * best.H0) + fabs(Rb.G[j][1] * best.H1));
+            const bool pos = (j == best.j1 && best.g1 > 0) || (j == best.j2 && best.g2 > 0);
+            pass = pass && (pos ? fabs(gj) <= 1e-7 * sj : gj > 1e-6 * sj);
+        }
+        return Grp<GW>::ballot(!pass, wlane) == 0;
+    };
+    auto take = [&](const Sol &s, int src, int cid) {
+        best.cost = Grp<GW>::bcast(s.cost, src); best.id = cid;
+        best.m = Grp<GW>::bcast(s.m, src); best.H0 = Grp<GW>::bcast(s.H0, src); best.H1 = Grp<GW>::bcast(s.H1, src);
+        best.i1 = Grp<GW>::bcast(s.i1, src); best.i2 = Grp<GW>::bcast(s.i2, src);
+        best.j1 = Grp<GW>::bcast(s.j1, src); best.j2 = Grp<GW>::bcast(s.j2, src);
+        best.l1 = Grp<GW>::bcast(s.l1, src); best.l2 = Grp<GW>::bcast(s.l2, src);
+        best.g1 = Grp<GW>::bcast(s.g1, src); best.g2 = Grp<GW>::bcast(s.g2, src);
+    };
+    Sol s; s.m = 0; s.H0 = s.H1 = 0; s.i1 = s.i2 = s.j1 = s.j2 = -1; s.l1 = s.l2 = s.g1 = s.g2 = 0; s.cost = 0; s.id = 0;
+    {
+        bool ok = false;
+        if (lane < 2) ok = eval_candidate(W, Rb, P, il, im, lane, s);
+        const double m0 = Grp<GW>::bcast(s.m, 0), m1 = Grp<GW>::bcast(s.m, 1);
+        const unsigned long long okb = Grp<GW>::ballot(ok, wlane);
+        int src = -1;
+        if ((okb & 1) && m0 >= 0) src = 0; else if ((okb & 2) && m1 < 0) src = 1;
+        if (src >= 0) {
+            take(s, src, 2 * (il * nm0 + im) + src);
+            if (certify()) return true;
+        }
+    }
+    if (GW >= 16) {
+        const int q = (lane >> 1) & 7, c = lane & 1;
+        int nil = -1, nim = -1;
+        if (lane < 16) {
+            if (q < 4) { nil = q < 2 ? (il + 1 + q) % 3 : -1; nim = im; }          // the other two of a = 0, |a| = 1, 0 < |a| < 1
+            else { nil = il; nim = support_neighbour(im, R, Rb.muc, Rb.nmv, q - 4); }
+        }
+        bool ok = false;
+        if (lane < 16 && nil >= 0 && nim >= 0) ok = eval_candidate(W, Rb, P, nil, nim, c, s);
+        const bool valid = ok && (c == 0 ? s.m >= 0 : s.m < 0);
+        const unsigned long long vb = Grp<GW>::ballot(valid, wlane);
+        const bool use = valid && !(c == 1 && ((vb >> (lane - 1)) & 1ull));
+        const double cost = use ? s.cost : INFINITY;
+        const double cmin = -Grp<GW>::max(-cost);
+        if (cmin < INFINITY) {
+            const unsigned long long wb = Grp<GW>::ballot(use && cost == cmin, wlane);
+            const int src = __ffsll((long long)wb) - 1;
+            const int cid = Grp<GW>::bcast(2 * (nil * nm0 + nim) + c, src);
+            take(s, src, cid);
+            if (certify()) return true;
+        }
+    }
+    return false;
+}
+
 template <int GW> __device__ __forceinline__ bool solve_wave_warm(WaveLDS &W, const RobotLDS &Rb, const Params &P, int wlane, int hint, Sol &best)
 {
     const int lane = wlane & (GW - 1);                          // lane inside the group
-    if (P.norm2 || hint < 0) return false;
+    if (P.norm2 || hint < 0) return false;                      // (circle obstacles: warm_circle, where the launch form calls it)
     const int R = P.R, E = P.E, nm0 = 1 + R + R * (R - 1) / 2;
     const int il = hint / nm0, im = hint - il * nm0;            // support of the last max-clearance optimum of this (n, t)
     if (il >= 1 + E + E * (E - 1) / 2) return false;

@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d, int it) { lammuz_body(d, 
 __device__ unsigned long long *g_lmz_clk = nullptr;
 __device__ int *g_lmz_faillog = nullptr;          // [0] count, then (old hint, new support id, circle?) triples of the rows whose certificate failed
 #endif
-template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
+template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_body_rows(const Dev &d, const int block, const int nblocks, const int it, const Fin &fin)
 {
 #pragma clang fp contract(on)          // see lammuz_device.h
     constexpr int WPB = GS / 4;        // waves per workgroup (4 rows each)
@@ -727,6 +727,8 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
     const int hpar = MODE == 0 ? ey.hpar : (d.ctrl->hint_par & 1);
     const int hint_in = MODE == 0 ? ey.hint : (MODE != 2 ? hint_read(d, hpar, n, t, it == 0) : -1);
     bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, hint_in, best);
+    // CW (the single-ego kernel only, see lmz::warm_circle): the remembered case of a circle obstacle's row, four rows of the wave side by side
+    if (CW && MODE == 0 && d.warm && P.norm2 && live && !bad) ok = lmz::warm_circle<16>(W, rb, P, lane, hint_in, best);
     LMZ_CLK(3);
     if (MODE != 2 && !live && !ok) {                           // a dead row never asks for the enumeration; nothing of `best` is used
         best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
@@ -886,7 +888,7 @@ template <int MODE = 0> __device__ __forceinline__ void lammuz_body_rows(const D
 
 // two builds: all registers and one wave per SIMD (no spills: the shorter critical path a single ego wants), or two
 // waves per SIMD with a few spilled registers (more sub-problems in flight: what a full chip wants)
-__global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
+__global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0, true>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_rows_fast(Dev d, int it) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 // (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower.  Round 4, same-box A/B (tools/experiments/ab_so.sh): the common

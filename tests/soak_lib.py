@@ -30,13 +30,14 @@ def body_rates(u, dyn, L):
     return np.array([v * np.cos(w), v * np.sin(w)])
 
 
-def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False, tight=False, robots=False):
+def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=False, tight=False, robots=False, circles=False):
     """the random draws of scene s (kinematics, horizon, obstacle field, solver arguments) - one rng stream per soak, consumed in scene order.
     `large`: the BASELINE regime instead of the examples' (T in {20, 25, 30}, 100 - 420 obstacles in a field 2.5 times as wide).
     `exotic`: what the examples do not use but the reference interface allows - the reference's default max_edge_num = 5 and more (polygons
     with 3 .. E vertices), a circle robot (norm2 cone, R = 3; `circle_robot`: the interior-point LamMuZ mode only, like the library), accelerated=False, horizons outside the compiled instantiations (5, 12, 40),
     obstacle_order=False, other penalty weights.
     `robots` (with exotic): convex bodies with 3 / 5 / 6 / 8 edges instead of the rectangle.
+    `circles`: two of three polygons become circle obstacles (norm2 cone) of about the same size, moving ones stay moving.
     `tight`: half the clearance between path and obstacles (1.2 - 1.7 m for a 1.6 m wide body: the lane is blocked here and there)"""
     dyn = ["acker", "diff", "omni"][int(rng.integers(3))]
     T = int(rng.choice([20, 25, 30] if large else [10, 15, 20, 25]))
@@ -78,6 +79,9 @@ def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=Fals
             o = scene[i]; c = o.vertex.mean(axis=1)
             scene[i] = sc.regular_polygon(c[0], c[1], int(r2.integers(3, kmax + 1)), float(r2.uniform(0.5, 1.0)), float(r2.uniform(-np.pi, np.pi)),
                                           tuple(o.velocity.ravel()))
+    if circles:
+        scene = [o if i % 3 == 0 else sc.circle(float(o.vertex[0].mean()), float(o.vertex[1].mean()), 0.45 * float(np.ptp(o.vertex[0]) + np.ptp(o.vertex[1])) / 2 + 0.3,
+                                                tuple(o.velocity.ravel())) for i, o in enumerate(scene)]
     for _ in range(int(rng.integers(0, 4))):
         scene.append(sc.circle(float(rng.uniform(10, 40)), y + float(rng.choice([-1, 1])) * float(rng.uniform(3.5, 8)),
                                float(rng.uniform(0.4, 1.2)), (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))))
@@ -88,7 +92,7 @@ def draw_scene(rng, seed, s, steps, large=False, exotic=False, circle_robot=Fals
 
 
 def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, only=-1, threads=None, dump_dir="", dump_tol=1e-5,
-             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False, tight=False, robots=False):
+             su_dump="", so="", log=print, hip_kw=None, large=False, exotic=False, tight=False, robots=False, circles=False):
     """returns a dict of totals + the per-step outliers; `log` receives one line per remarkable step"""
     lib = orc_api().lib
     if so:
@@ -114,7 +118,7 @@ def run_soak(scenes=12, steps=100, seed=0, lmz_central=0.0, cold_oracle=False, o
                ipm_gpu=0, ipm_cpu=0)
     try:
         for s in range(scenes):
-            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0, tight, robots)
+            d = draw_scene(rng, seed, s, steps, large, exotic, lmz_central > 0, tight, robots, circles)
             if only >= 0 and s != only:
                 continue
             kw = dict(d["kw"])

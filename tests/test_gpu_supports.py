@@ -55,8 +55,9 @@ def test_supports_with_moving_obstacles_stay_mostly_valid():
     assert np.median(hist[4:]) <= 0.10 * rows, hist
 
 
-@pytest.mark.parametrize("n_obs,order,moving", [(60, True, False), (40, False, True), (600, True, False), (600, False, True), (200, True, True)])
-def test_flushing_the_supports_cache_mid_loop_changes_no_bit(n_obs, order, moving):
+@pytest.mark.parametrize("n_obs,order,moving,circles", [(60, True, False, False), (40, False, True, False), (600, True, False, False), (600, False, True, False),
+                                                        (200, True, True, False), (60, True, True, True), (200, True, False, True), (600, False, True, True)])
+def test_flushing_the_supports_cache_mid_loop_changes_no_bit(n_obs, order, moving, circles):
     """the remembered supports are NOT part of rda_get_state - results may not depend on them.  Two identical loops;
     one forgets every remembered support (rda_debug_flush_supports) before every third step: controls, states, residuals, iteration
     counts and the whole dual state must agree bit for bit.  A remembered support is accepted on the optimality certificate of the FULL
@@ -70,6 +71,9 @@ def test_flushing_the_supports_cache_mid_loop_changes_no_bit(n_obs, order, movin
     path = sc.line_path([4, 25, 0], [44, 25, 0], 0.1)
     clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
     obstacles = sc.scene_polygons(n_obs, lo=(8, 10), hi=(40, 40), seed=sc.SEED + 3, keep_clear=clear, clear_radius=3.2, moving=moving)
+    if circles:        # two of three obstacles as circles (norm2 cone; remembered supports since round 5: lammuz_device.h certify_circle)
+        obstacles = [o if i % 3 == 0 else sc.circle(float(o.vertex[0].mean()), float(o.vertex[1].mean()), 0.7, tuple(o.velocity.ravel()))
+                     for i, o in enumerate(obstacles)]
     kw = dict(sample_time=0.1, time_print=False, receding=20, iter_num=3, max_edge_num=4, max_obs_num=n_obs, ro1=200, obstacle_order=order)
     a = MPC(car_t, [p.copy() for p in path], **kw)
     b = MPC(car_t, [p.copy() for p in path], **kw)
@@ -77,7 +81,8 @@ def test_flushing_the_supports_cache_mid_loop_changes_no_bit(n_obs, order, movin
     lib.rda_debug_flush_supports.argtypes = [C.c_void_p]
     state = path[0].copy().reshape(3, 1)
     for k in range(18):
-        cur = obstacles if not moving else [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) for o in obstacles]
+        cur = obstacles if not moving else [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive" else o._replace(center=o.center + o.velocity * (0.1 * k))
+                                            for o in obstacles]
         if k % 3 == 2:
             assert lib.rda_debug_flush_supports(b.rda._be.handle) == 0
         ua, ia = a.control(state.copy(), 4.0, list(cur))

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--large", action="store_true", help="scenes of the BASELINE regime: T in {20, 25, 30}, 100 - 420 obstacles (the oracle needs ~0.1 s per step there)")
     ap.add_argument("--exotic", action="store_true", help="what the examples do not use: max_edge_num 5 - 8, circle robot, accelerated=False, T in {5, 12, 40}, obstacle_order=False, other weights")
     ap.add_argument("--robots", action="store_true", help="with --exotic: convex robot bodies with 3 / 5 / 6 / 8 edges (R up to 8; E + R + 1 > 16 runs the one-row-per-wave LamMuZ kernel)")
+    ap.add_argument("--circles", action="store_true", help="two of three obstacles are circles (norm2 cone: the reference's dynamic_obs example)")
     ap.add_argument("--tight", action="store_true", help="half the clearance between path and obstacles: blocked lanes, collisions, su-problems that are hard or fail")
     ap.add_argument("--hard-off", action="store_true", help="GPU side without rda_opts::su_hard_warm (the start rule of round 4)")
     a = ap.parse_args()
@@ -44,7 +45,7 @@ def main():
             ch["su_hard_warm"] = (0.0, 0.0)
         hip_kw = {"hip_opts": hip_options(**ch)}
     out = run_soak(scenes=a.scenes, steps=a.steps, seed=a.seed, lmz_central=a.lmz_central, cold_oracle=a.cold, only=a.only, dump_dir=a.dump_dir,
-                   dump_tol=a.tol, su_dump=a.dump, so=a.so, hip_kw=hip_kw, large=a.large, exotic=a.exotic, tight=a.tight, robots=a.robots)
+                   dump_tol=a.tol, su_dump=a.dump, so=a.so, hip_kw=hip_kw, large=a.large, exotic=a.exotic, tight=a.tight, robots=a.robots, circles=a.circles)
     print(f"soak: {out['steps']} steps over {a.scenes} scenes in {time.time() - t0:.0f} s; max |du| raw {out['worst_raw']:.2e} body {out['worst_body']:.2e} "
           f"(whole horizon, body {out['worst_hor_body']:.2e}); control mismatches > {a.tol:g}: {out['over_raw']}; "
           f"iteration-count mismatches: {out['iter_mismatch']}; steps with a failed su-solve: {out['failed']}; "
