@@ -46,6 +46,14 @@ for scene_i in range(scene, last + 1):
             stop = [C.c_int(0), C.c_int(0)]
             for j, m in enumerate(ms):
                 assert api.admm_su(m.rda._be.handle, it, C.byref(stop[j])) == 0
+            if os.environ.get("SU_HIST"):          # the su-solves' own state after this su launch: history keys + kept multipliers
+                hs = []
+                for m in ms:
+                    hist = (C.c_int32 * 4)(); keep = np.zeros(10 * T)
+                    assert api.lib.rda_get_su_history(m.rda._be.handle, C.cast(hist, C.POINTER(C.c_int)), dptr(keep)) == 0
+                    hs.append((list(hist), keep))
+                if hs[0][0] != hs[1][0] or np.abs(hs[0][1] - hs[1][1]).max() > 0:
+                    print(f"scene {scene_i} step {k}: su history differs after su({it}): {hs[0][0]} vs {hs[1][0]}, kept multipliers max diff {np.abs(hs[0][1] - hs[1][1]).max():.3e}")
             if stop[0].value or stop[1].value:
                 break
             for m in ms:
