@@ -564,6 +564,9 @@ template <int GW> __device__ __forceinline__ bool warm_circle(const WaveLDS &W, 
     auto certify = [&]() -> bool {
         const double na = best.i1 >= 0 ? hypot(best.l1, best.l2) : 0.0;
         if (na > 1.0 + 1e-12) return false;
+        // a mu support row whose multiplier is (numerically) zero describes the same point as the support without it: two candidates, one optimum - the
+        // enumeration ranks them by (cost, id) (found by tools/experiments/circle_warm_debug2.py: mu = (0, 3e-17, 0, 0) remembered, the enumeration's answer 0)
+        if ((best.j1 >= 0 && !(best.g1 > 1e-12)) || (best.j2 >= 0 && !(best.g2 > 1e-12))) return false;
         const double phim = (best.m < 0 ? best.m : 0.0) - P.delta;
         const double dvx = P.px - W.b[0], dvy = P.py - W.b[1], l0 = W.b[2];
         const double ut0 = P.cs * dvx + P.sn * dvy, ut1 = -P.sn * dvx + P.cs * dvy;                    // R'(p - centre)

@@ -329,6 +329,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     const Cfg &c = a.c;
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
+#ifdef SU_POISON_LDS      // debug build (tools/experiments/README.md): every double of the workgroup's LDS starts as a NaN - a read of a word this solve has not written shows
+    for (int i = tid; i < (int)(lds_bytes(T) / sizeof(double)); i += NT) smem[i] = __builtin_nan("");
+    __syncthreads();
+#endif
     long long tprev = clock64();
     long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // phase cycle counters stay in registers (k is a literal)
     // The phase counters exist in the PROFILING builds only (-DSU_PROF, -DSU_FINE: tools/su_phase_profile.py).  As a run-time switch of the product build

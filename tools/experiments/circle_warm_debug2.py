@@ -25,6 +25,9 @@ for scene_i in range(scene, last + 1):
     d = draws[scene_i]
     kw = dict(d["kw"], device_track=False, device_obstacles=False)
     ms = [MPC(d["car"], [p.copy() for p in d["path"]], **kw, hip_opts=hip_options(**o)) for o in (dict(lmz_rows=1), (dict(lmz_rows=1) if os.environ.get("SAME_KERNEL") == "2" else dict(lmz_rows=1, lmz_warm=0)) if os.environ.get("SAME_KERNEL") else dict(lmz_rows=0))]
+    if os.environ.get("CHUNK"):
+        for m in ms:
+            assert api.shard_config(m.rda._be.handle, 0, 1) == 0
     st = d["path"][0].copy().reshape(3, 1)
     T, K = d["kw"]["receding"], d["kw"]["iter_num"]
     np.set_printoptions(linewidth=220, precision=12)
@@ -58,6 +61,24 @@ for scene_i in range(scene, last + 1):
                 break
             for m in ms:
                 assert api.admm_lammuz(m.rda._be.handle) == 0
+            if os.environ.get("CHUNK"):            # what the su-problem READS of this launch: (ax, ay, cb) [T][N], block sums [T][J][5], near masks [T][J]
+                cs = []
+                for m in ms:
+                    n_ch = api.shard_chunk_doubles(m.rda._be.handle)
+                    c = np.zeros(n_ch); assert api.shard_get_chunk(m.rda._be.handle, dptr(c)) == 0
+                    cs.append(c)
+                if not np.array_equal(cs[0].view(np.uint64), cs[1].view(np.uint64)):
+                    idx = np.flatnonzero(cs[0].view(np.uint64) != cs[1].view(np.uint64))
+                    N_ = ms[0].rda.max_obs_num; J_ = -(-N_ // 8)
+                    print(f"scene {scene_i} step {k} iteration {it}: {len(idx)} words of the su-problem's input chunk differ (chunk {len(cs[0])} = 3*{T}*{N_} + 6*{T}*{J_}); first {idx[:8].tolist()}; values {cs[0][idx[:4]]} vs {cs[1][idx[:4]]}")
+                    sa_, sb_ = ms[0].rda.get_state(), ms[1].rda.get_state()
+                    for w in idx[:3]:
+                        if w < 3 * T * N_:
+                            arr, rem = divmod(int(w), T * N_); t_, n_ = divmod(rem, N_)
+                            print(f"   word {w}: array {arr} (0 ax, 1 ay, 2 cb) stage {t_} slot {n_} cone {ins[0][1][n_]}: {cs[0][w]!r} vs {cs[1][w]!r}")
+                            for key in ("lam", "mu", "xi"):
+                                print(f"     {key} col {t_ + 1}: {sa_[key][n_][t_ + 1].tolist()} | {sb_[key][n_][t_ + 1].tolist()}")
+                            print(f"     z {sa_['z'][n_][t_]!r} | {sb_['z'][n_][t_]!r}   zeta {sa_['zeta'][n_][t_]!r} | {sb_['zeta'][n_][t_]!r}   dis {sa_['dis'][t_]!r} | {sb_['dis'][t_]!r}")
             sa, sb = ms[0].rda.get_state(), ms[1].rda.get_state()
             dl = np.abs(sa["lam"] - sb["lam"])
         if os.environ.get("ALL_DUALS"):        # lam [N][T+1][E]: fold the other duals' differences into the same (slot, column) grid
