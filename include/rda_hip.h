@@ -99,7 +99,9 @@ typedef struct rda_opts {
     int32_t lmz_warm;        /* [1] try the remembered support first, then the supports one row away from it, before a row is
                                 enumerated; every answer is accepted on its optimality certificate alone.  The supports are a cache of
                                 the handle (not part of rda_get_state): they follow the source obstacle of a slot through the
-                                re-binding of a re-sorted scene (rda_upload_scene*) and the horizon through the tick   RDA_LMZ_WARM */
+                                re-binding of a re-sorted scene (rda_upload_scene*) and the horizon through the tick.  Circle obstacles
+                                (norm2 cone) have one since round 5 in the single-ego launch form; in the dense forms and in a
+                                fleet their rows are enumerated as before                                                RDA_LMZ_WARM */
     int32_t lmz_rows;        /* [1] four sub-problems per wave when E+R+1 <= 16                                        RDA_LMZ_ROWS */
     int32_t lmz_dense_from;  /* [256] grid size (CUs at one wave per SIMD) above which the split form of the LamMuZ launch is used; x 7/4 for moving scenes  RDA_LMZ_DENSE_FROM */
     int32_t lmz_split;       /* [1] dense grids: common-path kernel + work-list kernel + finalize                      RDA_LMZ_SPLIT */
