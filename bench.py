@@ -48,7 +48,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from benchlib import closed_loop, cpu_baseline, legs, roofline       # noqa: E402
+from benchlib import closed_loop, compact, cpu_baseline, legs, roofline       # noqa: E402
 from benchlib.context import Ctx, stats                              # noqa: E402
 from benchlib.workload import build_workload, record_trace           # noqa: E402,F401  (tools/ import them from here)
 
@@ -73,7 +73,7 @@ def parse_args():
     ap.add_argument("--shard-n-obs", type=int, default=2000)
     ap.add_argument("--shard-leg-timeout", type=float, default=120.0)
     ap.add_argument("--no-sizes", action="store_true", help="skip the `sizes` legs (N=20, N=2000, C4, C5 shape: one short sub-run of this script each)")
-    ap.add_argument("--sizes-budget-s", type=float, default=75.0, help="wall-clock budget of the `sizes` legs; a leg that would start after it is skipped (and says so)")
+    ap.add_argument("--sizes-budget-s", type=float, default=120.0, help="wall-clock budget of the `sizes` legs; a leg that would start after it is skipped (and says so)")
     ap.add_argument("--size-leg", action="store_true", help="(internal) reduced set of legs: what one entry of `sizes` needs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline with this one thread count instead of the sweep")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
@@ -167,7 +167,7 @@ def base_line(ctx, value, ms_step, protocol):
     args, kw, T, N, world = ctx.args, ctx.kw, ctx.T, ctx.N, ctx.world
     kind_word = "moving" if args.moving else "static"
     return {
-        "metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(value, 3), "unit": "steps/s",
+        "metric": f"MPC steps/sec (ADMM early stop or iter_num cap: see residuals), T={T}, N_obs={N}", "value": round(value, 3), "unit": "steps/s",
         "n_gpus": world, "steps": ctx.K, "warmup": ctx.W, "ms_per_step": round(ms_step, 5),
         "higher_is_better": True, "scaling": "strong" if ctx.shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"north-star: acker rectangle robot, T={T}, N_obs={N} {kind_word} seeded polygons, E={kw['max_edge_num']}, iter_num={kw['iter_num']}, iter_threshold=0.2, ro1={kw['ro1']}",
@@ -190,7 +190,7 @@ def headline_only(ctx):
     out["second_window"] = hd.second_window
     out["roofline"], out["roofline_secondary"] = rooflines(ctx, tm.kernel_ms, tm.lmz_kernel, int(np.sum(tm.iters)))
     out["only_headline"] = True
-    print(json.dumps(out))
+    compact.emit(out, "bench_detail_only_headline.json")
 
 
 def main():
@@ -353,6 +353,8 @@ def main():
         "parity": {"stated_tolerance_applied_control": 5e-4, "asserted_on_the_baseline_sizes": 1e-4,
                    "where": "tests/helpers.py TOL_U / TOL_U_FIXED; asserted by tests/test_gpu_soak.py (random scenes) and tests/test_gpu_baseline_sizes.py; DESIGN.md 2"},
     })
+    if head is not None and head.elapsed_per_rank:
+        out["per_rank_steps_per_s"] = [round(K / e, 3) for e in head.elapsed_per_rank]
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline.run(ctx)
     if world == 1 and not args.no_sizes and (N, T, moving) == (200, 20, False):
@@ -360,7 +362,7 @@ def main():
     if want_shard_leg:
         def give_up():
             out["obstacle_shard_leg"] = {"error": f"no result within {args.shard_leg_timeout:.0f} s (collective did not complete)"}
-            print(json.dumps(out), flush=True)
+            compact.emit(out)
             os._exit(0)
         wd = threading.Timer(args.shard_leg_timeout, give_up)
         wd.daemon = True; wd.start()
@@ -369,7 +371,7 @@ def main():
         except Exception as e:                               # the headline line must not depend on this leg
             out["obstacle_shard_leg"] = {"error": repr(e)}
         wd.cancel()
-    print(json.dumps(out))
+    compact.emit(out, None if args.size_leg else "bench_detail.json", detail_to_stdout=args.size_leg)
     if dist is not None:
         dist.destroy_process_group()
 

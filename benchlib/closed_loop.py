@@ -18,6 +18,7 @@ class Loop:
     second_window: Any = None    # more steps of the same loop right behind the timed ones (C driver, one rank)
     kernel_ms: Any = None        # timing pass: hipEvent times per launch, {"k_lammuz": [...], "k_su": [...]}
     lmz_kernel: str = ""
+    elapsed_per_rank: Any = None # this loop's wall time on every rank (N > 1: the per-rank values of the driver line)
 
 
 def residual_summary(info, iter_threshold):
@@ -97,8 +98,11 @@ def run(ctx, per_tick_scene, driver="c", car=None, compare=True, ordered=False, 
         go(W, K)
         api.lib.rda_sync(hh)
         ctx.barrier_all()
-        el = ctx.max_over_ranks(time.perf_counter() - t_start)
+        el_local = time.perf_counter() - t_start
+        el = ctx.max_over_ranks(el_local)
         res = Loop(el, t_log[W:W + K].copy(), 0.0, [int(v) for v in it_log[W:W + K]], info=info_log[W:W + K].copy())
+        if ctx.world > 1:
+            res.elapsed_per_rank = ctx.gather_over_ranks(el_local)
         if timing:
             kt_ = {}
             for which, name in ((0, "k_lammuz"), (1, "k_su")):

@@ -50,6 +50,16 @@ class Ctx:
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def gather_over_ranks(self, x):
+        """one float per rank, on every rank (the per-rank values of the driver line)"""
+        if self.dist is None:
+            return [x]
+        import torch
+        mine = torch.tensor([x], dtype=torch.float64, device=self.tdev)
+        everyone = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(everyone, mine)
+        return [float(t.item()) for t in everyone]
+
     # ---- solvers -----------------------------------------------------------------------------------------------------------
     def new_solver(self, car=None, **extra):
         from rda_planner_amd.rda_solver import RDA_solver

@@ -19,10 +19,11 @@ def run(ctx):
     sweep, err, n_total = {}, 0.0, 0
     k = 0
     counts = sorted({t for t in (1, 8, 16, 32, 64, ncore) if t <= ncore}) if not args.cpu_threads else [min(args.cpu_threads, ncore)]
+    min_steps = 20 if args.cpu_threads else 3            # a `sizes` leg is ONE thread count: at least 20 steps of it (N = 2000: ~16 s)
     for nthr in counts:
         orc_api().lib.orc_set_threads(nthr)
         n_cpu, t_cpu = 0, 0.0
-        while t_cpu < 2.5 or n_cpu < 3:                  # consecutive steps of ONE closed loop (the duals stay warm) ...
+        while t_cpu < 2.5 or n_cpu < min_steps:          # consecutive steps of ONE closed loop (the duals stay warm) ...
             kk = k % (W + K)                             # ... wrapping around the recorded trace when it is used up
             tr_c = trace_o if trace_o is not None else trace     # the headline workload: the scene re-sorted on every tick
             n_c, A_c, b_c, cone_c, pt_c = tr_c["staged"][kk] if tr_c.get("staged") else (staged["n"], staged["A"], staged["b"], staged["cone"], staged["per_t"])
@@ -38,9 +39,9 @@ def run(ctx):
         n_total += n_cpu
     best = max(sweep, key=sweep.get)
     return {"value": sweep[best], "unit": "steps/s", "cores": best, "kind": "port",
-            "single_thread": sweep.get(1), "thread_sweep": sweep, "host_cores": ncore,
+            "single_thread": sweep.get(1), "thread_sweep": sweep, "host_cores": ncore, "steps": n_total,
             "sample": f"{n_total} steps of the headline closed loop (obstacle_order=True: the staged slots of every tick as the GPU run had them; consecutive, "
-                      "wrapping around), ~2.5 s per thread count (oracle/rda_oracle.c: OpenMP over obstacles, OMP_PROC_BIND=close, su-problem serial, the "
+                      f"wrapping around), >= 2.5 s and >= {min_steps} steps per thread count (oracle/rda_oracle.c: OpenMP over obstacles, OMP_PROC_BIND=close, su-problem serial, the "
                       "kernel's start rules mirrored); best thread count reported",
             "note": "a restatement of the ADMM in C, NOT the reference's CVXPY+ECOS+pathos path (not installable here): the "
                     "north-star '>=100x the reference CPU path' cannot be measured against this number",

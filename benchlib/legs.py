@@ -67,7 +67,7 @@ def oversubscribed_shard_run(ctx, mpc_rec):
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if ctx.rank == 0:
-        print(json.dumps({"metric": f"MPC steps/sec (ADMM-converged), T={T}, N_obs={N}", "value": round(K / float(tt.item()), 3), "unit": "steps/s",
+        print(json.dumps({"metric": f"MPC steps/sec (ADMM early stop or iter_num cap), T={T}, N_obs={N}", "value": round(K / float(tt.item()), 3), "unit": "steps/s",
                           "n_gpus": ctx.world, "steps": K, "warmup": W, "ms_per_step": round(float(tt.item()) / K * 1e3, 5), "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                           "config": {"workload": f"acker rectangle robot, T={T}, N_obs={N}, obstacles sharded {ctx.world}-way",
@@ -344,8 +344,8 @@ def sizes(budget_s, script):
         try:
             pr = subprocess.run([sys.executable, script, "--gpus", "1", "--size-leg", "--cpu-threads", "16"] + extra,
                                 capture_output=True, text=True, timeout=left + 20.0, env=env)
-            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
-            j = json.loads(line[-1])
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("DETAIL {")]      # the sub-run's full dictionary (its last line is the compact one)
+            j = json.loads(line[-1][len("DETAIL "):])
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_ms_per_step", "mean_admm_iters", "max_du_vs_python_closed_loop",
                     "second_window", "residuals", "roofline", "roofline_secondary", "cpu_baseline", "multi_ego_fleet")
             e = {k: j.get(k) for k in keep}
@@ -355,7 +355,7 @@ def sizes(budget_s, script):
             e["pcie_inclusive_steps_per_s"] = (j.get("pcie_inclusive") or {}).get("steps_per_s")
             e["replay_steps_per_s"] = j["device_resident_replay"]["steps_per_s"]
             if e.get("cpu_baseline"):
-                e["cpu_baseline"] = {k: e["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "max_du_vs_gpu")}
+                e["cpu_baseline"] = {k: e["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "steps", "sample", "max_du_vs_gpu")}
                 e["gpu_over_cpu_port"] = round(j["value"] / e["cpu_baseline"]["value"], 1) if e["cpu_baseline"]["value"] else None
             out[name] = e
         except Exception as ex:                         # the headline must not depend on these legs

@@ -52,3 +52,62 @@ def test_bench_cli_keeps_the_flags_the_driver_and_the_profile_script_use():
         assert flag in out.stdout, flag
     text = open(os.path.join(ROOT, "tools", "profile_round.sh")).read()
     assert "bench.py --only-headline" in text
+
+
+def _worst_case_full_line():
+    """the round-5 driver-window dictionary (21.5 KB, the one the driver could not parse) with every optional block present and the strings
+    a failing leg would add"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_ns_driver_window.json")))
+    full["n_gpus"] = 8
+    full["per_rank_steps_per_s"] = [1919.845123456] * 8
+    full["duals_follow_obstacles"] = {"error": "x" * 200}
+    full["obstacle_shard_leg"] = {"amdahl": {"bound_speedup_without_exchange": 1.46, "bound_speedup_with_measured_gather": 1.41, "what": "y" * 300},
+                                  "workload": "T=20, N_obs=2000 static seeded polygons, obstacles sharded 8-way (250 slots per rank)", "steps_per_s": 1000.123456,
+                                  "ms_per_step": 1.0, "unsharded_one_gpu_steps_per_s": 800.0, "speedup_vs_one_gpu": 1.25, "gather_us_per_iteration": 21.5,
+                                  "gathers": 160, "chunk_bytes_per_rank": 300000, "what": "z" * 400}
+    for e in full["sizes"].values():
+        e["multi_ego_fleet"] = {"egos": 64, "aggregate_steps_per_s": 71982.7, "c_abi_closed_loop": {"ego_steps_per_s": 41234.5, "what": "w" * 300}}
+    full["sizes"]["extra_leg_that_failed"] = {"error": "TimeoutExpired(" + "q" * 400 + ")"}
+    full["residuals"]["max_resi_dual"] = float("inf")                 # a failed LamMuZ problem makes a residual infinite: must not become `Infinity`
+    full["config"]["env_switches"] = {f"RDA_SWITCH_{i}": "1" * 30 for i in range(12)}
+    return full
+
+
+def test_driver_line_is_compact_and_parseable():
+    """VERDICT r05 #1: BENCH_r05.json had parsed = null because the one line was 21.5 KB; the driver's tail holds 8 018 characters"""
+    from benchlib import compact
+    full = _worst_case_full_line()
+    assert len(json.dumps(full)) > 20000
+    s = compact.line(full)
+    assert len(s) <= 6000 and "\n" not in s and s.startswith("{")
+    assert "Infinity" not in s and "NaN" not in s
+    j = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "roofline_secondary", "cpu_baseline", "residuals", "second_window", "sizes"):
+        assert k in j, k
+    assert "dropped_for_length" not in j
+    assert j["value"] == 1919.85 and j["roofline"]["kernel"] == "k_su<20>" and j["roofline"]["bound"] == "hbm" and j["roofline"]["peak"] == 8000.0
+    assert set(("achieved", "frac", "traffic", "unit")) <= set(j["roofline"]) and set(("value", "unit", "cores", "kind", "sample")) <= set(j["cpu_baseline"])
+    assert len(j["config"]["protocol"]) <= 200 and "workload" in j["config"] and "model" not in j["config"]
+    for name in ("n20_T20", "n2000_T20", "c4_dynamic_obs_n200_T30_moving", "c5_shape_n100_T25_fleet64"):
+        e = j["sizes"][name]
+        assert e["value"] > 0 and e["roofline"]["frac"] > 0 and e["cpu_baseline"]["value"] > 0 and e["fleet"]["closed_loop_ego_steps_per_s"] > 0
+    assert j["obstacle_shard_leg"]["amdahl_bound"] == 1.41 and len(j["per_rank_steps_per_s"]) == 8
+    # a pathological input still ends in a line the driver can parse: optional blocks are shed, the contract keys never
+    full["sizes"] = {f"leg_{i}": dict(full["sizes"]["n20_T20"]) for i in range(40)}
+    s = compact.line(full)
+    j = json.loads(s)
+    assert len(s) <= 6000 and "sizes" in j["dropped_for_length"] and "roofline" in j and "cpu_baseline" in j and "value" in j
+
+
+def test_bench_prints_exactly_one_stdout_line(capsys, tmp_path, monkeypatch):
+    from benchlib import compact
+    monkeypatch.setattr(compact, "ROOT", str(tmp_path))
+    compact.emit(_worst_case_full_line())
+    out = capsys.readouterr().out
+    assert out.count("\n") == 1 and json.loads(out)["value"] == 1919.85
+    detail = json.load(open(tmp_path / "gpurun_out" / "bench_detail.json"))
+    assert "what" in detail["fixed_slot_binding"]
+    compact.emit(_worst_case_full_line(), None, detail_to_stdout=True)            # a `sizes` sub-run: the parent reads the DETAIL line
+    lines = capsys.readouterr().out.splitlines()
+    assert len(lines) == 2 and lines[0].startswith("DETAIL {") and json.loads(lines[0][7:])["value"] == 1919.845 and lines[1].startswith("{")
