@@ -320,6 +320,8 @@ int  rda_get_lmz_history(rda_handle *h, double *points, int32_t *valid);
 int  rda_set_lmz_history(rda_handle *h, const double *points, const int32_t *valid);
 /* debug: accumulated clock64 phase counters of the su-solves of this handle since the last call (rda_opts::su_prof), 16 values */
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
+/* -DSU_TRACE builds only (RDA_ERR_UNSUPPORTED otherwise): per-wave (event id, clock64) pairs of the LAST su launch, out[4][cap][2] (tools/su_trace.py) */
+int  rda_debug_su_trace(rda_handle *h, long long *out, int cap, int *n_out);
 int  rda_debug_flush_supports(rda_handle *h);             /* forget every remembered LamMuZ support (a cache: results must not depend on it) */
 int  rda_debug_slot_src(rda_handle *h, int32_t *src /*N*/, int32_t *used); /* slot -> entry of the caller's raw scene (device pipeline; used = 0: host-staged slots) */
 int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ work list of the last executed iteration (split launch form) */

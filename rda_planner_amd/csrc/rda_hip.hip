@@ -1442,7 +1442,9 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
         rc |= dalloc(&H->d_prev_sel, N); rc |= dalloc(&H->d_follow_map, N);
         rc |= dalloc(&H->d_follow_tmp, N * (T + 1) * (E + R + 2) + 2 * N * T);
     }
-#if defined(SU_PROF) || defined(SU_FINE)
+#if defined(SU_TRACE)
+    if (o.su_prof) rc |= dalloc(&d.su_prof, su::PROF_WORDS);                   // 16 + the per-wave event trace of the LAST su launch (tools/su_trace.py)
+#elif defined(SU_PROF) || defined(SU_FINE)
     if (o.su_prof) rc |= dalloc(&d.su_prof, 16);
 #else
     if (o.su_prof) { rda_destroy(H); *partial = nullptr; return RDA_ERR_UNSUPPORTED; }     // phase counters: profiling builds only (-DSU_PROF / -DSU_FINE, tools/su_phase_profile.py)
@@ -1599,6 +1601,26 @@ extern "C" int rda_debug_su_prof(rda_handle *H, long long *out16)
     HIPCHK(hipMemcpy(out16, H->d.su_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(H->d.su_prof, 0, 16 * sizeof(long long)));
     return RDA_OK;
+}
+
+// debug, -DSU_TRACE builds only: (event id, clock64) pairs of the four waves of the LAST su launch of this handle, [4][cap][2]; *n_out = events per wave
+extern "C" int rda_debug_su_trace(rda_handle *H, long long *out, int cap, int *n_out)
+{
+    if (!H || !out || !n_out || cap < 1) return RDA_ERR_ARG;
+#if defined(SU_TRACE)
+    if (!H->d.su_prof) return RDA_ERR_UNSUPPORTED;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    std::vector<long long> buf(2 * 4 * su::TRACE_CAP);
+    HIPCHK(hipMemcpy(buf.data(), H->d.su_prof + 16, buf.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    const int n = cap < su::TRACE_CAP ? cap : su::TRACE_CAP;
+    for (int w = 0; w < 4; ++w)
+        for (int e = 0; e < n; ++e) { out[(w * cap + e) * 2] = buf[(w * su::TRACE_CAP + e) * 2]; out[(w * cap + e) * 2 + 1] = buf[(w * su::TRACE_CAP + e) * 2 + 1]; }
+    *n_out = n;
+    return RDA_OK;
+#else
+    (void)H;
+    return RDA_ERR_UNSUPPORTED;
+#endif
 }
 
 // debug: rows the common-path LamMuZ kernel of the LAST executed iteration put on the work list (split launch form only)
@@ -2959,7 +2981,7 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;
     ar.d_in = d0 ? dd0 : nullptr; ar.out_s = dos; ar.out_u = dou; ar.out_d = dod; ar.status = dst; ar.ipm_iters = dst + 1;
     long long *dprof = nullptr;
-    if (od.su_prof) { HIPCHK(hipMalloc((void **)&dprof, 16 * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, 16 * sizeof(long long))); }
+    if (od.su_prof) { HIPCHK(hipMalloc((void **)&dprof, su::PROF_WORDS * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, su::PROF_WORDS * sizeof(long long))); }
     ar.prof = dprof;
     double *ddbg = nullptr;
     if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }      // (su_prof = 2: one stderr line per interior-point iteration)

@@ -55,6 +55,14 @@ constexpr int NT = 256;          // workgroup size
 // relative dual residual above HARD_RD0 started far from its solution; in the hard start the rows of d begin with the barrier HARD_DMU / w
 constexpr double HARD_RD0 = 1e-2, HARD_DMU = 1.0;
 constexpr int NC = 10;           // inequality rows per stage
+// -DSU_TRACE (tools/su_trace.py): lane 0 of every wave logs (event id, clock64) at the phase boundaries of the solve - before and behind every barrier - into the
+// profiling buffer behind the 16 phase counters, [4 waves][TRACE_CAP][2]; every launch starts over, so the buffer holds the LAST launch of the handle
+constexpr int TRACE_CAP = 1024;
+#ifdef SU_TRACE
+constexpr int PROF_WORDS = 16 + 2 * 4 * TRACE_CAP;
+#else
+constexpr int PROF_WORDS = 16;
+#endif
 
 struct Cfg {
     int T, N, dynamics, accelerated;
@@ -222,7 +230,7 @@ struct Lds {
     double *p0;                            // [2][T] reference positions of the hinge screening
     double *uk, *ub, *xs;                  // time split (split_point(T) > 0): unit backward sweeps [5][8 m], their F_v' p [5][m][2], interface block [96]
     double *acc;                           // [13 T] safety net: u (2T) | d (T) | multipliers of the pairs [T][10]
-    double *near, *con; int *ncnt, *sto;   // near list of the hinge screening: [near_cap][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
+    double *near; int *ncnt, *sto;   // near list of the hinge screening: [near_cap][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
     __device__ void carve(double *b, int T) {
         double *p = b;
         s = p; p += ev(3 * (T + 1)); u = p; p += 2 * T; d = p; p += ev(T); phin = p; p += ev(T); ref = p; p += ev(3 * (T + 1));
@@ -238,7 +246,6 @@ struct Lds {
         uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
         acc = p; p += ev(13 * T);
         near = p; p += 4 * near_cap(T); ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
-        con = part; if (near_max(T) > NT) { con = p; p += 9 * near_max(T); }      // the terms' contributions [near_max][9] (one per thread: the scratch of the partials)
     }
 };
 constexpr size_t lds_bytes(int T)
@@ -246,7 +253,7 @@ constexpr size_t lds_bytes(int T)
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
              + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0)
-             + ev(13 * T) + 4 * near_cap(T) + NT / 2 + ev(T + 2) / 2 + 1 + (near_max(T) > NT ? 9 * near_max(T) : 0);
+             + ev(13 * T) + 4 * near_cap(T) + NT / 2 + ev(T + 2) / 2 + 1;
     return n * sizeof(double);
 }
 // every horizon the interface accepts (RDA_TMAX = 64) must fit the 160 KB a workgroup can have (round 5: T = 36 .. 40 did not for a while - the near
@@ -309,6 +316,18 @@ __device__ __forceinline__ double block_reduce(double v, double *red, int tid, b
     return r;
 }
 
+// ... with ONE barrier: every call site owns its NT / 64 slots, so the barrier that keeps a later writer from a slow reader of the previous reduction
+// is any barrier between two executions of the same site (round 6: the step-length and the reach / complementarity reductions run twice per iteration)
+__device__ __forceinline__ double block_reduce1(double v, double *slots, int tid, bool is_max)
+{
+    v = wave_allreduce(v, is_max);
+    if ((tid & 63) == 0) slots[tid >> 6] = v;
+    __syncthreads();
+    double r = slots[0];
+    for (int w = 1; w < NT / 64; ++w) r = is_max ? (slots[w] > r ? slots[w] : r) : r + slots[w];
+    return r;
+}
+
 // C' x for one stage: x = per-row values of the 10 inequality rows -> entries 3..7 of y
 __device__ __forceinline__ void con_T(const double *x, int t, double &y3, double &y4, double &y5, double &y6, double &y7)
 {
@@ -344,6 +363,18 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #endif
 
     auto mark = [&](int k) { if (prof_on) { long long now = clock64(); pacc[k] += now - tprev; tprev = now; } };
+#ifdef SU_TRACE
+    int trn = 0;
+    auto tr_ = [&](int id) {
+        if (a.prof && (threadIdx.x & 63) == 0 && trn < TRACE_CAP) {
+            long long *q = a.prof + 16 + ((threadIdx.x >> 6) * TRACE_CAP + trn) * 2;
+            q[0] = id; q[1] = clock64(); ++trn;
+        }
+    };
+#define TR(id) tr_(id)
+#else
+#define TR(id)
+#endif
 #ifdef SU_FINE      // one-off build for tools/su_phase_profile.py --fine: the set-up slots are re-used for sub-phases of the iteration
 #define MS(k) mark(10)
 #define MF(k) mark(k)
@@ -351,6 +382,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #define MS(k) mark(k)
 #define MF(k)
 #endif
+    TR(100);
     const double vref = *a.ref_speed;
     // (stage, chunk) mapping of the obstacle reductions
     const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
@@ -369,12 +401,31 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         pf_u0 = a.in_u[tid]; pf_u1 = a.in_u[T + tid]; if (a.d_in) pf_d = a.d_in[tid];
         if (a.pose_lin) { pf_cp = a.pose[4 * tid + 2]; pf_sp = a.pose[4 * tid + 3]; }
     }
+    // Inequality pair (stage t, linear form k) -> thread.  Horizons with a compile-time instantiation up to 32 stages: the form k is WAVE-UNIFORM per
+    // half wave - wave 0 holds k = 0 (lanes 0..31) and k = 1 (lanes 32..63), wave 1 the rate pairs k = 3 / 4, wave 2 (lanes 0..31) the distance pair
+    // k = 2, lane & 31 = the stage - so the three shapes of a pair's linear form (a control, the distance with its eliminated-variable dot product,
+    // a control difference) are branches whole waves skip instead of three divergent passes in every wave (round 6; rounds 3-5 dealt pair
+    // p = 5 t + k to thread p: 5 T <= 150 threads in waves 0 / 1 / 2, every wave holding every k).  Other horizons: pair p = 5 t + k on thread p (two per thread beyond NT).
+    constexpr bool PAIRS_BY_WAVE = TT > 0 && TT <= 32;
+    auto pair_map = [&](const int j, int &t, int &k) -> bool {
+        if (PAIRS_BY_WAVE) {
+            const int half = lane >> 5, tl = lane & 31;
+            k = wave == 0 ? half : (wave == 1 ? 3 + half : 2);
+            const bool ok = j == 0 && tl < T && (wave < 2 || (wave == 2 && half == 0));
+            t = ok ? tl : 0; if (!ok) k = 0;
+            return ok;
+        }
+        const int pi = tid + j * NT;
+        const bool ok = pi < 5 * T;
+        t = ok ? pi / 5 : 0; k = ok ? pi % 5 : 0;
+        return ok;
+    };
     double pf_lkp[2] = {0, 0}, pf_lkm[2] = {0, 0};           // kept multipliers of this thread's inequality pairs (+ row, - row; see the pair threads below)
     if (warm)
         for (int j = 0; j < 2; ++j) {
-            const int pi = tid + j * NT;
-            if (pi < 5 * T) {
-                const int t = pi / 5, kk = pi % 5, ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
+            int t, kk;
+            if (pair_map(j, t, kk)) {
+                const int ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
                 pf_lkp[j] = a.lam_keep[ts * NC + 2 * kk]; pf_lkm[j] = a.lam_keep[ts * NC + 2 * kk + 1];
             }
         }
@@ -510,8 +561,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     double Pdwp[NPR], Pdwm[NPR], Pdlp[NPR], Pdlm[NPR];        // steps
 #pragma unroll
     for (int j = 0; j < NPR; ++j) {
-        const int pi = tid + j * NT;
-        p_ok[j] = pi < 5 * T; p_t[j] = p_ok[j] ? pi / 5 : 0; p_k[j] = p_ok[j] ? pi % 5 : 0;
+        p_ok[j] = pair_map(j, p_t[j], p_k[j]);
         p_on[j] = p_ok[j] && (p_k[j] < 3 || p_t[j] >= 1);
         p_ep[j] = con_rhs(c, 2 * p_k[j]); p_em[j] = con_rhs(c, 2 * p_k[j] + 1);
         Pwp[j] = Pwm[j] = 1.0; Plp[j] = Plm[j] = 0.0; Prpp[j] = Prpm[j] = Prcp[j] = Prcm[j] = 0.0;
@@ -555,6 +605,32 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             } else { Pwp[j] = Pwm[j] = 1.0; Plp[j] = Plm[j] = 0.0; }
         }
     };
+    // What the stage phases of an interior-point iteration need of the rows, from the current slacks / multipliers and controls / distances: primal
+    // residuals, reciprocals (once per iteration), affine (predictor) targets in registers; barrier weights lam/w, lam+ - lam-, x+ - x-, lam w and
+    // max |r_p| per pair to the [T][5] arrays.  Called where the pairs change: at the start of an attempt and right after the update of every
+    // iteration (between the two barriers of its reach / complementarity reduction - round 6: it used to be a phase of its own at the top of the
+    // next iteration), so the iteration itself starts with the fused stage phase.  A barrier must follow before the stage phase reads the arrays.
+    auto pair_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            if (p_ok[j]) {
+                const int o = 5 * p_t[j] + p_k[j];
+                if (p_on[j]) {
+                    const double cv = pair_val(p_t[j], p_k[j]);
+                    const double wp = Pwp[j], wm = Pwm[j], lp = Plp[j], lm = Plm[j];
+                    Prpp[j] = cv + wp - p_ep[j]; Prpm[j] = wm - cv - p_em[j];
+                    const double iwp = frcp(wp), iwm = frcp(wm);
+                    Piwp[j] = iwp; Piwm[j] = iwm; Pilp[j] = frcp(lp); Pilm[j] = frcp(lm);
+                    Prcp[j] = lp * wp; Prcm[j] = lm * wm;
+                    L.bw[o] = lp * iwp + lm * iwm;
+                    L.cy[o] = lp - lm;
+                    L.xd[o] = (lp * Prpp[j] - Prcp[j]) * iwp - (lm * Prpm[j] - Prcm[j]) * iwm;
+                    L.lw[o] = Prcp[j] + Prcm[j];
+                    L.ra[o] = fmax(fabs(Prpp[j]), fabs(Prpm[j]));
+                } else { L.bw[o] = 0; L.cy[o] = 0; L.xd[o] = 0; L.lw[o] = 0; L.ra[o] = 0; }
+            }
+        }
+    };
     // Start.  Cold: slacks floored at 1e-2, lam = 1/w (mu0 = 1).  Warm (ADMM iterations >= 1): the primal point is the previous
     // solution, so the slacks are the previous ones; they are floored at warm_wfl, the multipliers are the larger of the centred
     // ones (warm_mu0 / w) and those the previous solve ended with.  Starting with a small mu0 WITHOUT the old multipliers costs
@@ -587,7 +663,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     constexpr double DELTA = SCREEN_DELTA;
     unsigned long long amask[MW] = {0, 0, 0, 0};
     bool screened = c.accelerated && a.P * KB * GS <= 64 * MW && (!masks_in || a.pose_ok);
-    bool listed = false, listed_fast = false;                  // (uniform) the near terms are in L.near; ... and few enough for one term per thread (L.con)
+    bool listed = false;                                       // (uniform) the near terms are in L.near
     {
         double saa = 0, sga = 0, sgx = 0;
         if (ract) {
@@ -658,7 +734,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 if (lane == T - 1) L.sto[T] = inc;
             }
             __syncthreads();
-            listed = L.sto[T] <= near_cap(T); listed_fast = L.sto[T] <= near_max(T);
+            listed = L.sto[T] <= near_cap(T);
             if (listed && ract && mine > 0) {
                 int off = L.sto[rt];
                 for (int k = 0; k < rc_; ++k) off += L.ncnt[rt * nch + k];
@@ -699,9 +775,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     // Newton right-hand side gradient gh = gst + C'((lam*rp - rc)/w): with xd = x+ - x- per pair (L.xd, written by the pair threads for the
     // current right-hand side) the entries 3..7 of a stage are -xd3, -xd4, xd0 + xd3, xd1 + xd4, xd2 - formed where they are used
     // constants of the backward affine map for the current right-hand side: cb = [g_x - W g_v ; -Minv g_v]
-    auto build_cb = [&](const int first = threadIdx.x, const int stride = NT) {
-        for (int i = first; i < 8 * T; i += stride) {
-            int t = i >> 3, r = i & 7;
+    auto cb_entry = [&](const int t, const int r) {
             const double *gs = &L.gst[8 * t], *xd = &L.xd[5 * t], *wn = &L.Wn[WN * t], *m7 = &L.m7[8 * t];
             // (d_t eliminated: g' = g - m7 g7 / H77 on the entries 0..6; the rows of d in W / Minv are zero)
             const double g7 = gs[7] + xd[2], c7 = g7 * m7[7];
@@ -717,7 +791,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 double n2 = k == 0 ? wn[17] : (k == 1 ? wn[19] : wn[20]);
                 v = -(n0 * g5 + n1 * g6 + n2 * g7);
             }
-            L.Hb[HB * t + 6 * r + 5] = v;
+            return v;
+    };
+    auto build_cb = [&](const int first = threadIdx.x, const int stride = NT) {
+        for (int i = first; i < 8 * T; i += stride) {
+            const int t = i >> 3, r = i & 7;
+            L.Hb[HB * t + 6 * r + 5] = cb_entry(t, r);
         }
     };
     // ---- vector sweeps (wave 0, lane-parallel): one affine map per stage -----------------------------------
@@ -828,6 +907,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     constexpr int MQ = MSP > 0 ? MSP : 1;                               // = msp wherever the split code runs (compile-time: constant addresses, unrolled loops)
     unsigned long long stopf = 0, seq = 0;               // seq = tag of the current interior-point iteration (early-verdict flags)
     unsigned long long *const flag_meas = reinterpret_cast<unsigned long long *>(L.red + 12), *const flag_stop = flag_meas + 1;
+    // (round 6) flag_fail = seq: a recursion of this iteration broke down (instead of __syncthreads_or: 1.4 k cycles per iteration on the traced timeline);
+    // flag_unit = seq: wave 3's unit sweep of this factorisation is in LDS (wave 2 goes on to the interface matrix without a block barrier)
+    unsigned long long *const flag_fail = flag_meas + 2, *const flag_unit = flag_meas + 3, *const flag_unit2 = reinterpret_cast<unsigned long long *>(L.pv + 4);
     double okmin = 1.0, lastp = 0.0;
     auto mat_step = [&](int t, const MatK &k, double *const Px, double *const Ms) {
         // X = P F : lane (q,i) needs row i of P
@@ -1083,9 +1165,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     // every hinge term in play and, since round 5, as the plain path-following iteration SU_SAFE_* (`safe`).
     int status = 1, it = 0, used = 0;
     bool have_acc = false; double acc_merit = 0.0;            // (uniform) safety net
-    if (tid == 0) { *flag_meas = 0; *flag_stop = 0; }
+    if (tid == 0) { *flag_meas = 0; *flag_stop = 0; *flag_fail = 0; *flag_unit = 0; *flag_unit2 = 0; }
     bool ref_pending = a.ref_flag != nullptr;      // the reference of a tracked tick is sampled by a second workgroup: picked up at its first use
-    MS(9);
+    MS(9); TR(101);
     // Attempts: [-1: the warm start, at most warm_cap = 30 iterations.  Where consecutive su-problems are close (static scenes) it
     // converges within 3-4; with many moving obstacles it needs as many iterations as the cold start (8-20) but does arrive:
     // cutting it at 5 / 7 / 12 iterations and starting over cost +29 / +35 / +5 % on the dynamic_obs benchmark, 30 costs
@@ -1103,43 +1185,29 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         __syncthreads();
         status = 1;
     }
+    pair_rows();
+    __syncthreads();
     const int it_cap = attempt < 0 ? a.warm_cap : (attempt == 0 ? SU_COLD_CAP : 100);       // (the cold attempt: 50 since round 5, see the oracle)
     const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
     bool expect_conv = false;
     double mu_prev = 1.0;
     for (it = 0; it < it_cap; ++it) {
+        TR(1);
         seq += 1;
         const double heps = (attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;
         // (rescue phase: the smoothed hinge is non-zero for EVERY term - the oracle sums them all, so does this pass; such iterations are rare)
         const bool screened_now = screened && !(heps > 0);
-        // ---- (1) hinge sums per stage.  Screened solves with the near terms in LDS (the common case): one thread per (stage, quantity)
-        //          walks the stage's list.  Else: (stage, chunk) partials over the masks / over every term, then one thread per (stage, quantity) --
-        if (screened_now && listed_fast) {
-            const int nn = L.sto[T];
-            for (int e = tid; e < nn; e += NT) {                    // one near term per thread (two beyond NT): its nine contributions (zeros while the hinge is inactive)
-                const double *q = &L.near[4 * e];
-                const double ax = q[0], ay = q[1], cb = q[2]; const int t = (int)q[3];
-                const double Im = ax * L.s[t + 1] + ay * L.s[(T + 1) + t + 1] - cb - L.d[t];
-                const bool on = Im < 0;
-                double *pp = &L.con[e * 9];
-                pp[0] = on ? ax * ax : 0.0; pp[1] = on ? ax * ay : 0.0; pp[2] = on ? ay * ay : 0.0; pp[3] = on ? ax : 0.0; pp[4] = on ? ay : 0.0;
-                pp[5] = on ? 1.0 : 0.0; pp[6] = on ? Im * ax : 0.0; pp[7] = on ? Im * ay : 0.0; pp[8] = on ? Im : 0.0;
-            }
-            __syncthreads();
-            for (int i = tid; i < 9 * T; i += NT) {
-                const int t = i / 9, k = i - 9 * t;
-                const int j0 = L.sto[t], j1 = L.sto[t + 1];
-                double acc = 0;
-                const double *pj = &L.con[j0 * 9 + k];
-                int j = j0;
-                for (; j + 4 <= j1; j += 4, pj += 36) {            // four loads in flight, added in list order
-                    const double v0 = pj[0], v1 = pj[9], v2 = pj[18], v3 = pj[27];
-                    acc += v0; acc += v1; acc += v2; acc += v3;
-                }
-                for (; j < j1; ++j, pj += 9) acc += pj[0];
-                L.hs[i] = acc;
-            }
-        } else {
+        // ---- (1)-(3) ONE phase, no barrier inside (round 6; rounds 1-5: hinge contributions | barrier | stage sums | barrier | stage derivatives and
+        //      pair rows | barrier | gradients and Hessian bases - four phases of 1.5-4 k cycles each, 9.3 k of a 44.7 k-cycle iteration).  Lane i = 8 t + r
+        //      belongs to the aligned 8-lane group of stage t and owns row r of its 8 x 8 Hessian base: the group (a) sums the stage's stretch of the
+        //      near list - lane r the terms j0 + r, j0 + r + 8, ... - and adds the eight partials up with three DPP steps (every lane of the group then
+        //      holds the nine hinge sums), (b) forms the stage derivatives wrt (s_next, d) in registers (each lane for itself: same loads, no trip
+        //      through LDS), (c) writes entry r of the stage gradient and (d) row r of the Hessian base.  The rows' barrier weights / multiplier
+        //      differences (L.bw, L.cy) were left by the pair threads at the END of the previous iteration (pair_rows).
+        //      Solves whose near terms are not in the LDS list (more than near_cap, unscreened, rescue phase): (stage, chunk) partials over the masks / over
+        //      every term -> L.hs first, as before.
+        const bool fused_hinge = screened_now && listed;
+        if (!fused_hinge) {
             double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
             if (ract) {
                 const double px = L.s[rt + 1], py = L.s[(T + 1) + rt + 1], dd = L.d[rt];
@@ -1159,11 +1227,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     }
                 };
                 const int Nl = a.Nloc;
-                if (screened_now && listed) {
-                    // more near terms than threads x 2: the stage's stretch of the LDS list, dealt to the chunks of the stage (round 5)
-                    const int j1 = L.sto[rt + 1];
-                    for (int j = L.sto[rt] + rc_; j < j1; j += nch) { const double *q = &L.near[4 * j]; term(q[0], q[1], q[2]); }
-                } else if (screened_now) {
+                if (screened_now) {
                     // (more near terms than the list holds) visit only the terms that may be active, four loads in flight
                     for (int w = 0; w < MW; ++w) {
                         unsigned long long m = amask[w];
@@ -1211,110 +1275,114 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 for (int ch = 0; ch < nch; ++ch) acc += L.part[(t * nch + ch) * 9 + k];
                 L.hs[i] = acc;
             }
-        }
-        __syncthreads();
-        mark(1);
-        if (ref_pending) {                         // (uniform) first pass of a tracked tick: the hinge sums above did not need the reference,
-            ref_pending = false;                   // the stage gradients below do.  L.part (the functor's scratch) is free from here to the next phase 1
-            ref_wait(L.part);
-            for (int i = tid; i < 3 * (T + 1); i += NT) L.ref[i] = a.ref[i];
             __syncthreads();
-            MS(9);
         }
-        // ---- (2) per-stage derivatives wrt w = (s_next, d)  (threads < T)  ||  inequality rows: barrier weight
-        //          lam/w (kept in dw, which is dead here), primal residual, predictor target  (all threads) ------
-        if (NT - 1 - tid < T) {                    // (the HIGH thread ids: the pair threads are the low ones - 5 T <= 150 of 256 for T <= 30)
-            int t = NT - 1 - tid;
-            const double *h = &L.hs[9 * t];
-            double st[3] = { L.s[t + 1], L.s[(T + 1) + t + 1], L.s[2 * (T + 1) + t + 1] };
-            double w3[3] = { 1, 1, wz };
-            double gs[3], Hs00, Hs01, Hs11, Hs22;
-            for (int r = 0; r < 3; ++r) gs[r] = 2 * c.ws * w3[r] * (st[r] - L.ref[r * (T + 1) + t + 1]);
-            Hs00 = 2 * c.ws; Hs11 = 2 * c.ws; Hs22 = 2 * c.ws * wz; Hs01 = 0;
-            double dl = st[2] - L.phin[t];
-            gs[2] += 0.5 * c.ro2 * (L.Q1[t] + 2 * L.Q2[t] * dl); Hs22 += c.ro2 * L.Q2[t];
-            gs[0] += c.ro1 * h[6]; gs[1] += c.ro1 * h[7];
-            Hs00 += c.ro1 * h[0]; Hs01 += c.ro1 * h[1]; Hs11 += c.ro1 * h[2];
-            // the seven distinct entries of the symmetric 4 x 4 block, stage stride 9: the stage threads write [T][16] rows 128 bytes apart onto ONE
-            // LDS bank (16-way conflicts: profiles/r04_ns_issue_counters.txt SQ_LDS_BANK_CONFLICT); an odd stride spreads them
-            double *Hw = &L.Hw[9 * t], *gw = &L.gw[4 * t];
-            double hsd0 = -c.ro1 * h[3], hsd1 = -c.ro1 * h[4];
-            Hw[0] = Hs00; Hw[1] = Hs01; Hw[2] = hsd0; Hw[3] = Hs11; Hw[4] = hsd1; Hw[5] = Hs22; Hw[6] = c.ro1 * h[5];
-            gw[0] = gs[0]; gw[1] = gs[1]; gw[2] = gs[2]; gw[3] = -c.ro1 * h[8] - c.slack_gain;
-        }
-        // pair threads: primal residuals, reciprocals, affine (predictor) targets; what the stage phases need goes to the [T][5] arrays
+        for (int i0 = 0; i0 < 8 * T; i0 += NT) {                   // (one round for T <= 32)
+            const int i = i0 + tid; const bool act = i < 8 * T;
+            const int t = act ? i >> 3 : 0, r = i & 7;
+            double h[9];
+            if (fused_hinge) {
+                double sxx = 0, sxy = 0, syy = 0, sx = 0, sy = 0, s1 = 0, ix = 0, iy = 0, i1 = 0;
+                const double px = L.s[t + 1], py = L.s[(T + 1) + t + 1], dd = L.d[t];
+                const int j1 = act ? L.sto[t + 1] : 0;
+                int j = L.sto[t] + r;
+                auto term = [&](const d2 q01, const double cb) {
+                    const double ax = q01[0], ay = q01[1];
+                    const double Im = ax * px + ay * py - cb - dd;
+                    if (Im < 0) {
+                        sxx += ax * ax; sxy += ax * ay; syy += ay * ay; sx += ax; sy += ay; s1 += 1.0;
+                        ix += Im * ax; iy += Im * ay; i1 += Im;
+                    }
+                };
+                for (; j + 8 < j1; j += 16) {                      // two terms in flight, added in list order
+                    const d2 qa = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(&L.near[4 * j], 16)); const double ca = L.near[4 * j + 2];
+                    const d2 qb = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(&L.near[4 * (j + 8)], 16)); const double cb = L.near[4 * (j + 8) + 2];
+                    term(qa, ca); term(qb, cb);
+                }
+                if (j < j1) {
+                    const d2 qa = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(&L.near[4 * j], 16)); const double ca = L.near[4 * j + 2];
+                    term(qa, ca);
+                }
+                TR(3);
+                h[0] = sum8(sxx); h[1] = sum8(sxy); h[2] = sum8(syy); h[3] = sum8(sx); h[4] = sum8(sy); h[5] = sum8(s1);
+                h[6] = sum8(ix); h[7] = sum8(iy); h[8] = sum8(i1);
+                TR(4);
+            } else {
 #pragma unroll
-        for (int j = 0; j < NPR; ++j) {
-            if (p_ok[j]) {
-                const int o = 5 * p_t[j] + p_k[j];
-                if (p_on[j]) {
-                    const double cv = pair_val(p_t[j], p_k[j]);
-                    const double wp = Pwp[j], wm = Pwm[j], lp = Plp[j], lm = Plm[j];
-                    Prpp[j] = cv + wp - p_ep[j]; Prpm[j] = wm - cv - p_em[j];
-                    const double iwp = frcp(wp), iwm = frcp(wm);
-                    Piwp[j] = iwp; Piwm[j] = iwm; Pilp[j] = frcp(lp); Pilm[j] = frcp(lm);
-                    Prcp[j] = lp * wp; Prcm[j] = lm * wm;
-                    L.bw[o] = lp * iwp + lm * iwm;
-                    L.cy[o] = lp - lm;
-                    L.xd[o] = (lp * Prpp[j] - Prcp[j]) * iwp - (lm * Prpm[j] - Prcm[j]) * iwm;
-                    L.lw[o] = Prcp[j] + Prcm[j];
-                    L.ra[o] = fmax(fabs(Prpp[j]), fabs(Prpm[j]));
-                } else { L.bw[o] = 0; L.cy[o] = 0; L.xd[o] = 0; L.lw[o] = 0; L.ra[o] = 0; }
+                for (int k = 0; k < 9; ++k) h[k] = L.hs[9 * t + k];
             }
-        }
-        __syncthreads();
-        MF(14);
-        // ---- (3) stage gradients and stage Hessian bases  J' Hw J + direct + barrier  (all threads) -------
-        // J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
-        for (int i = tid; i < 8 * T; i += NT) {
-            int t = i >> 3, j = i & 7;
-            const double *F = &L.Ft[FT * t], *gw = &L.gw[4 * t], *ld = &L.cy[5 * t];        // ld = lam+ - lam- per pair
-            double v = Fel(F, 0, j) * gw[0] + Fel(F, 1, j) * gw[1] + Fel(F, 2, j) * gw[2] + (j == 7 ? gw[3] : 0.0);
-            // + direct control cost + C' lam   (the rate pairs exist for t >= 1; their multipliers are 0 at t = 0)
-            const double r0 = ld[3], r1 = ld[4];
-            if (j == 3) v -= r0;
-            else if (j == 4) v -= r1;
-            else if (j == 5) v += ld[0] + r0 + 2 * c.wu * (L.u[t] - vref) + c.eps_u * L.u[t];
-            else if (j == 6) v += ld[1] + r1 + c.eps_u * L.u[T + t];
-            else if (j == 7) v += ld[2];
-            L.gst[i] = v;
-        }
-        MF(12);
-        // (skipped in a pass that is expected to be the convergence check only, see `expect_conv`)
-        if (!expect_conv)
-        for (int i = tid; i < 8 * T; i += NT) {               // one thread per (stage, row): Hw and the row's J column stay in registers
-            int t = i >> 3, r = i & 7;
-            const double *F = &L.Ft[FT * t], *Hw = &L.Hw[9 * t], *dg = &L.bw[5 * t];
-            const double h00 = Hw[0], h01 = Hw[1], hd0 = Hw[2], h11 = Hw[3], hd1 = Hw[4], h22 = Hw[5], hdd = Hw[6];
+            mark(1);
+            if (ref_pending) {                     // (uniform) first pass of a tracked tick: the hinge sums above did not need the reference,
+                ref_pending = false;               // the stage gradients below do.  L.part (the functor's scratch) is free from here to the next phase 1
+                ref_wait(L.part);
+                for (int q = tid; q < 3 * (T + 1); q += NT) L.ref[q] = a.ref[q];
+                __syncthreads();
+                MS(9);
+            }
+            // ---- (2) derivatives of the stage cost wrt w = (s_next, d): the seven distinct entries of the symmetric 4 x 4 block, the gradient ---------
+            double gw0, gw1, gw2, gw3, h00, h01, hd0, h11, hd1, h22, hdd;
+            {
+                const double st0 = L.s[t + 1], st1 = L.s[(T + 1) + t + 1], st2 = L.s[2 * (T + 1) + t + 1];
+                double gs0 = 2 * c.ws * 1.0 * (st0 - L.ref[t + 1]), gs1 = 2 * c.ws * 1.0 * (st1 - L.ref[(T + 1) + t + 1]);
+                double gs2 = 2 * c.ws * wz * (st2 - L.ref[2 * (T + 1) + t + 1]);
+                double Hs00 = 2 * c.ws, Hs11 = 2 * c.ws, Hs22 = 2 * c.ws * wz, Hs01 = 0;
+                const double dl = st2 - L.phin[t];
+                gs2 += 0.5 * c.ro2 * (L.Q1[t] + 2 * L.Q2[t] * dl); Hs22 += c.ro2 * L.Q2[t];
+                gs0 += c.ro1 * h[6]; gs1 += c.ro1 * h[7];
+                Hs00 += c.ro1 * h[0]; Hs01 += c.ro1 * h[1]; Hs11 += c.ro1 * h[2];
+                h00 = Hs00; h01 = Hs01; hd0 = -c.ro1 * h[3]; h11 = Hs11; hd1 = -c.ro1 * h[4]; h22 = Hs22; hdd = c.ro1 * h[5];
+                gw0 = gs0; gw1 = gs1; gw2 = gs2; gw3 = -c.ro1 * h[8] - c.slack_gain;
+                if (act && r == 0) { double *gw = &L.gw[4 * t]; gw[0] = gw0; gw[1] = gw1; gw[2] = gw2; gw[3] = gw3; }      // (termination measure |g|_inf: wave 3, phase 4)
+            }
+            MF(14); TR(5);
+            // ---- (3) stage gradient entry r and row r of the stage Hessian base  J' Hw J + direct + barrier ;  J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
+            const double *F = &L.Ft[FT * t];
             const double a0 = Fel(F, 0, r), a1 = Fel(F, 1, r), a2 = Fel(F, 2, r), a3 = r == 7 ? 1.0 : 0.0;
-            // v = Hw J[:, r]
-            const double v0 = h00 * a0 + h01 * a1 + hd0 * a3, v1 = h01 * a0 + h11 * a1 + hd1 * a3, v2 = h22 * a2, v3 = hd0 * a0 + hd1 * a1 + hdd * a3;
-            const double bu0 = dg[0], bu1 = dg[1], bd = dg[2], br0 = dg[3], br1 = dg[4];
-            double *row = &L.Hb[HB * t + 8 * r];
-            // d_t enters only its own stage (F has no column for it), so it is eliminated HERE, before the recursion: column m7 = H[0..6][7],
-            // H' = H - m7 m7' / H77 on the entries 0..6, d decoupled (round 4: the pivot block of the recursion becomes 2 x 2; the step of d is
-            // recovered per stage by its inequality pair: dd = -(g7 + m7'y) / H77)
-            const double i77 = frcp(hdd + bd);
-            const double m7r = r < 7 ? v3 : 0.0;              // (v3 of a row r < 7 = hd0 a0 + hd1 a1)
-            L.m7[8 * t + r] = r < 7 ? m7r : i77;
-            const double f7 = m7r * i77;
+            if (act) {
+                const double *ld = &L.cy[5 * t];                  // ld = lam+ - lam- per pair
+                double v = a0 * gw0 + a1 * gw1 + a2 * gw2 + (r == 7 ? gw3 : 0.0);
+                // + direct control cost + C' lam   (the rate pairs exist for t >= 1; their multipliers are 0 at t = 0).  Every operand is fetched by every lane
+                // and the row's term is SELECTED (round 6): as branches on r each of the five cases was a load -> wait -> add round of its own
+                const double l0 = ld[0], l1 = ld[1], l2 = ld[2], r0 = ld[3], r1 = ld[4], u0 = L.u[t], u1 = L.u[T + t];
+                const double e5 = l0 + r0 + 2 * c.wu * (u0 - vref) + c.eps_u * u0, e6 = l1 + r1 + c.eps_u * u1;
+                const double ad = r == 3 ? -r0 : (r == 4 ? -r1 : (r == 5 ? e5 : (r == 6 ? e6 : l2)));
+                if (r >= 3) v += ad;
+                L.gst[i] = v;
+            }
+            MF(12); TR(6);
+            // (skipped in a pass that is expected to be the convergence check only, see `expect_conv`)
+            if (!expect_conv && act) {
+                const double *dg = &L.bw[5 * t];
+                // v = Hw J[:, r]
+                const double v0 = h00 * a0 + h01 * a1 + hd0 * a3, v1 = h01 * a0 + h11 * a1 + hd1 * a3, v2 = h22 * a2, v3 = hd0 * a0 + hd1 * a1 + hdd * a3;
+                const double bu0 = dg[0], bu1 = dg[1], bd = dg[2], br0 = dg[3], br1 = dg[4];
+                double *row = &L.Hb[HB * t + 8 * r];
+                // d_t enters only its own stage (F has no column for it), so it is eliminated HERE, before the recursion: column m7 = H[0..6][7],
+                // H' = H - m7 m7' / H77 on the entries 0..6, d decoupled (round 4: the pivot block of the recursion becomes 2 x 2; the step of d is
+                // recovered per stage by its inequality pair: dd = -(g7 + m7'y) / H77)
+                const double i77 = frcp(hdd + bd);
+                const double m7r = r < 7 ? v3 : 0.0;              // (v3 of a row r < 7 = hd0 a0 + hd1 a1)
+                L.m7[8 * t + r] = r < 7 ? m7r : i77;
+                const double f7 = m7r * i77;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double m = Fel(F, 0, q) * v0 + Fel(F, 1, q) * v1 + Fel(F, 2, q) * v2;
-                // barrier weights: u0 box, u1 box, d box, rate u0 (rows u0 - up0), rate u1
-                if (r == q) {
-                    if (r == 5) m += 2 * c.wu + c.eps_u + bu0 + br0;
-                    else if (r == 6) m += c.eps_u + bu1 + br1;
-                    else if (r == 3) m += br0;
-                    else if (r == 4) m += br1;
-                } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= br0;
-                else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= br1;
-                if (q < 7) m -= f7 * (hd0 * Fel(F, 0, q) + hd1 * Fel(F, 1, q));
-                row[q] = (r == 7 || q == 7) ? (r == q ? 1.0 : 0.0) : m;
+                for (int q = 0; q < 8; ++q) {
+                    double m = Fel(F, 0, q) * v0 + Fel(F, 1, q) * v1 + Fel(F, 2, q) * v2;
+                    // barrier weights: u0 box, u1 box, d box, rate u0 (rows u0 - up0), rate u1
+                    if (r == q) {
+                        if (r == 5) m += 2 * c.wu + c.eps_u + bu0 + br0;
+                        else if (r == 6) m += c.eps_u + bu1 + br1;
+                        else if (r == 3) m += br0;
+                        else if (r == 4) m += br1;
+                    } else if ((r == 3 && q == 5) || (r == 5 && q == 3)) m -= br0;
+                    else if ((r == 4 && q == 6) || (r == 6 && q == 4)) m -= br1;
+                    if (q < 7) m -= f7 * (hd0 * Fel(F, 0, q) + hd1 * Fel(F, 1, q));
+                    row[q] = (r == 7 || q == 7) ? (r == q ? 1.0 : 0.0) : m;
+                }
             }
         }
+        TR(7);
         __syncthreads();
-        mark(2);
+        mark(2); TR(8);
         // ---- (4) waves 0 / 1: Riccati matrix recursion of the stages [msp, T) / [0, msp) (time split; msp = 0: wave 0 takes them all);
         //          wave 2: adjoint sweep for the reduced gradient + early verdict; wave 3: the other termination measures ------------
         bool fail = false;
@@ -1367,8 +1435,15 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 __atomic_store_n(flag_meas, seq, __ATOMIC_RELEASE);
             }
         }
-        const int anyfail = __syncthreads_or(fail ? 1 : 0);
-        mark(4);
+        TR(9);
+        if (fail) __atomic_store_n(flag_fail, seq, __ATOMIC_RELAXED);
+        __syncthreads();
+        const bool anyfail = __atomic_load_n(flag_fail, __ATOMIC_RELAXED) == seq;
+        mark(4); TR(10);
+        // The first iteration of an easy-mode warm attempt skips the predictor (a.warm_nopred): next to the solution the affine step
+        // is a full step, so sigma ends at its floor anyway and the second-order term dl*dw is O(error^2) - one sweep pair instead of
+        // two.  Should that iteration not finish the solve, the following ones are ordinary predictor-corrector iterations.
+        const bool nopred = (attempt < 0 && a.warm_nopred != 0 && it == 0) || safe;
         // ---- (4b) closed-loop sweep matrices from W, Minv (all threads; Mb overwrites the consumed Hb,
         //           Mf overwrites the consumed hs..cy) --------------------------------------------------------------
         if (!expect_conv)
@@ -1396,6 +1471,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     for (int j = 0; j < 5; ++j) mf[j] = -wn[3 * j + 2];
                 }
             }
+            // (round 6) ... and the constant of the PREDICTOR's backward map with its row - build_cb for the first right-hand side used to be a phase of
+            // its own on waves 0 / 1 (2.3 k cycles on the traced timeline, beside the unit sweeps of waves 2 / 3)
+            if (!nopred) mb[5] = cb_entry(t, r);
         }
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
@@ -1422,6 +1500,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 if (dv > DELTA) {           // safety net (the per-iteration check below normally acts first): all terms, and a
                     screened = false;       // fresh, well-centred set of slacks / multipliers at the current primal point
                     centre_duals(1e-2, 1.0);
+                    pair_rows();
+                    __syncthreads();
                     continue;
                 }
             }
@@ -1435,14 +1515,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         mark(5);
 
         double sigma = 0;
-        // The first iteration of an easy-mode warm attempt skips the predictor (a.warm_nopred): next to the solution the affine step
-        // is a full step, so sigma ends at its floor anyway and the second-order term dl*dw is O(error^2) - one sweep pair instead of
-        // two.  Should that iteration not finish the solve, the following ones are ordinary predictor-corrector iterations.
-        const bool nopred = (attempt < 0 && a.warm_nopred != 0 && it == 0) || safe;
         if (nopred) sigma = safe ? (al_prev >= 0.9 ? SU_SAFE_SIGMA_END : SU_SAFE_SIGMA) : a.warm_sig;
         bool unit_done = false;                    // time split: the unit sweeps / interface matrix of this factorisation exist
+        TR(11);
         if (msp > 0) __syncthreads();              // (the unit sweeps of waves 2 / 3 read the closed-loop rows all threads have just written)
         for (int pass = nopred ? 1 : 0; pass < 2; ++pass) {
+            TR(20 + 10 * pass);
             if (pass == 1) {
                 // corrector right-hand side: targets lam w + dlam dw - sigma mu (no second-order term without a predictor), new x+ - x-
                 const double smu = sigma * mu;
@@ -1454,10 +1532,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                         L.xd[5 * p_t[j] + p_k[j]] = (Plp[j] * Prpp[j] - Prcp[j]) * Piwp[j] - (Plm[j] * Prpm[j] - Prcm[j]) * Piwm[j];
                     }
                 __syncthreads();
-                MF(9);
+                MF(9); TR(31);
             }
             if (MSP == 0 || msp == 0) {
-                build_cb();
+                if (pass == 1) build_cb();                  // (the predictor's constants were formed with the closed-loop rows, 4b)
                 __syncthreads();
                 mark(6);
                 if (wave == 0) {
@@ -1475,22 +1553,40 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 // and the two forward sweeps start from 0 and x_msp.  Unit sweeps, X, S^-1 and S^-1 X depend on the factorisation only: once per
                 // interior-point iteration, by waves 2 / 3 beside the sweep constants and the first backward sweeps.
                 // tools/experiments/two_segment.py: the algebra in numpy, on random and on recorded systems.
-                if (!unit_done) {                          // first pass of this factorisation: the sweep constants on waves 0 / 1, the unit sweeps on 2 / 3
-                    if (wave < 2) build_cb(tid, NT / 2); else unit_sweeps();
-                } else build_cb(tid, NT);
-                __syncthreads();
-                mark(6);
+                // Predictor (pass 0): its constants were formed with the closed-loop rows (4b), so the backward sweeps of waves 0 / 1 start at once; waves 2 / 3
+                // run the unit sweeps beside them and wave 2 goes straight on to the interface matrix once wave 3's sweep is in LDS (flag_unit, no block
+                // barrier).  A corrector that is the FIRST pass of its factorisation (no predictor): constants on waves 0 / 1 beside the unit sweeps, barrier,
+                // backward sweeps beside the interface matrix - as in rounds 4-5.
+                if (pass == 1) {
+                    if (!unit_done) { if (wave < 2) build_cb(tid, NT / 2); else unit_sweeps(); }
+                    else build_cb(tid, NT);
+                    TR(22 + 10 * pass);
+                    __syncthreads();
+                    mark(6); TR(23 + 10 * pass);
+                }
                 if (wave == 0) {
                     double pe = 0;
                     if (lane < 8) pe = bwd_seg(MSP, T, 0.0, L.kk, true, lane);
                     if (lane < 5) XS_pm[lane] = pe;
                 } else if (wave == 1) {
                     if (lane < 8) bwd_seg(0, MSP, 0.0, L.kk, true, lane);
+                    if (pass == 0) {                       // (x0 reads the b(j)_t of the unit sweeps: both waves' must be in LDS)
+                        while (__atomic_load_n(flag_unit, __ATOMIC_ACQUIRE) != seq) __builtin_amdgcn_s_sleep(1);
+                        while (__atomic_load_n(flag_unit2, __ATOMIC_ACQUIRE) != seq) __builtin_amdgcn_s_sleep(1);
+                    }
                     wsync(); interface_x0();
+                } else if (pass == 0) {
+                    unit_sweeps();
+                    if (lane == 0) __atomic_store_n(wave == 3 ? flag_unit : flag_unit2, seq, __ATOMIC_RELEASE);
+                    if (wave == 2) {
+                        while (__atomic_load_n(flag_unit, __ATOMIC_ACQUIRE) != seq) __builtin_amdgcn_s_sleep(1);
+                        interface_matrix();
+                    }
                 } else if (wave == 2 && !unit_done) interface_matrix();
                 unit_done = true;
+                TR(24 + 10 * pass);
                 __syncthreads();
-                MF(3);
+                MF(3); TR(25 + 10 * pass);
                 if (wave < 2) {
                     double xm, pi;
                     interface_solve(xm, pi);
@@ -1513,8 +1609,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     }
                 }
             }
+            TR(26 + 10 * pass);
             __syncthreads();
-            mark(7);
+            mark(7); TR(27 + 10 * pass);
             // ---- slack / multiplier steps (pair threads, registers), step length ---------------------------------------
             // step to the boundary: the largest ratio -dx / x over all slacks and multipliers; al = min(1, fr / ratio)
             double ratio = 0.0;
@@ -1527,9 +1624,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     Pdwp[j] = dwp; Pdwm[j] = dwm; Pdlp[j] = dlp; Pdlm[j] = dlm;
                     ratio = fmax(ratio, fmax(fmax(-dwp * Piwp[j], -dwm * Piwm[j]), fmax(-dlp * Pilp[j], -dlm * Pilm[j])));
                 }
-            MF(15);
-            ratio = block_reduce(ratio, L.red, tid, true);
-            MF(0);
+            MF(15); TR(28 + 10 * pass);
+            ratio = block_reduce1(ratio, L.red + 272 + 4 * pass, tid, true);
+            MF(0); TR(29 + 10 * pass);
             // fraction to the boundary: 1 for the predictor; corrector: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
             double fr = 1.0;
             if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; if (safe) fr = SU_SAFE_TAU; }
@@ -1549,20 +1646,24 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     if (t >= 1) for (int r = 0; r < 3; ++r) L.s[r * (T + 1) + t] += al * y[r];
                 }
                 if (tid < 3) L.s[tid * (T + 1) + T] += al * L.pv[tid];
+                TR(40);
                 __syncthreads();
-                MF(11);
+                MF(11); TR(41);
                 // ONE block reduction for (i) the reach of the hinge screening - it holds only while every stage stays within DELTA of its
-                // reference position - and (ii) the mean complementarity after the step (light convergence pass, recentring)
+                // reference position - and (ii) the mean complementarity after the step (light convergence pass, recentring); slots of their own (see
+                // block_reduce1), and between its two barriers the pair threads prepare the rows of the NEXT iteration (pair_rows)
                 double dv = 0, m_ = 0;
                 if (screened && tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
 #pragma unroll
                 for (int j = 0; j < NPR; ++j) if (p_on[j]) m_ += Plp[j] * Pwp[j] + Plm[j] * Pwm[j];
                 dv = wave_allreduce(dv, true); m_ = wave_allreduce(m_, false);
+                if (lane == 0) { L.red[280 + wave] = dv; L.red[284 + wave] = m_; }
+                pair_rows();
+                TR(42);
                 __syncthreads();
-                if (lane == 0) { L.red[wave] = dv; L.red[4 + wave] = m_; }
-                __syncthreads();
-                dv = fmax(fmax(L.red[0], L.red[1]), fmax(L.red[2], L.red[3]));
-                m_ = ((L.red[4] + L.red[5]) + (L.red[6] + L.red[7])) / mcnt;
+                TR(43);
+                dv = fmax(fmax(L.red[280], L.red[281]), fmax(L.red[282], L.red[283]));
+                m_ = ((L.red[284] + L.red[285]) + (L.red[286] + L.red[287])) / mcnt;
                 if (screened && dv > DELTA) screened = false;      // from the next iteration on: every term (the streaming loop)
                 MF(13);
                 // Light convergence pass: the residuals of a Newton step of length al shrink by (1 - al) (the dynamics are
@@ -1583,6 +1684,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                             if (Plp[j] * Pwp[j] < floor_) Plp[j] = floor_ / Pwp[j];
                             if (Plm[j] * Pwm[j] < floor_) Plm[j] = floor_ / Pwm[j];
                         }
+                    pair_rows();                                   // (rare path: the rows of the next iteration once more, with the raised multipliers)
+                    __syncthreads();
                 }
                 const double prd = (1 - al) * rdn, prp = (1 - al) * rpn;
                 expect_conv = c.light_check && ((prd <= c.tol_rd * sc && prp <= c.tol_rp && m_ <= c.tol_mu * sc) ||
@@ -1605,9 +1708,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         __syncthreads();
     }
     // consistent final rollout (removes accumulated rounding in s)
+    TR(102);
     rollout();
     __syncthreads();
-    mark(15);
+    mark(15); TR(103);
     if (status == 0 && a.lam_keep) {
 #pragma unroll
         for (int j = 0; j < NPR; ++j)
@@ -1632,7 +1736,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         a.pose_out[4 * tid] = px; a.pose_out[4 * tid + 1] = py; a.pose_out[4 * tid + 2] = cp; a.pose_out[4 * tid + 3] = sp;
     }
     if (tid == 0) { *a.status = status; *a.ipm_iters = used; }
-    mark(10);
+    mark(10); TR(104);
     if (prof_on && tid == 0) for (int k = 0; k < 16; ++k) a.prof[k] += pacc[k];
     return true;
 }
@@ -1641,6 +1745,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #undef MS
 #undef MF
 #undef LDS_DRAIN
+#undef TR
 
 }  // namespace su
 

@@ -4,7 +4,7 @@ for bit: controls, states, residuals, iteration counts.
 
   RDA_LMZ_DENSE_FROM=0   every LamMuZ launch in the split form (common-path kernel + work-list kernel) instead of the fused kernel
   RDA_LMZ_SPLIT=0        (with DENSE_FROM=0) every launch as the fused two-workgroups-per-CU kernel
-  RDA_SU_PRE=0           the su set-up evaluates all condensed terms itself (no block sums / near masks from the LamMuZ launch)
+  RDA_SU_PRE=0           the su set-up evaluates all condensed terms itself (no block sums / near masks from the LamMuZ launch); rounding level since round 6
   RDA_LMZ_TAIL=1         the early-stop verdict and the hand-over by the last-arriving LamMuZ workgroup, not by the next su launch / k_finish
   RDA_SU_LIGHT=0         convergence pass with the factorisation
   RDA_ZERO_COPY=0        result through a D2H copy + stream synchronise
@@ -56,8 +56,17 @@ def test_switch_reproduces_the_default_closed_loop(defaults, monkeypatch, env, c
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     got, want = _loop(*case), defaults[case]
+    # RDA_SU_PRE=0 changes the REFERENCE of the hinge screening (the nominal positions instead of the pose table of the LamMuZ launch): another - equally
+    # valid - superset of the active terms in the near list.  Since round 6 the eight lanes of a stage group take the list's terms in turn (su_device.h,
+    # fused stage phase), so extra inactive terms re-deal the active ones among the lanes: the same sums in another association.  Rounding level, same
+    # iteration counts; every other switch stays bit for bit.
+    rounding = "RDA_SU_PRE" in env
     for k, (g, w) in enumerate(zip(got, want)):
         assert g[4] == w[4] and g[5] == w[5], (k, g[4:], w[4:])
+        if rounding:
+            assert np.abs(g[0] - w[0]).max() < 1e-10 and np.abs(g[1] - w[1]).max() < 1e-10, (k, float(np.abs(g[0] - w[0]).max()))
+            assert abs(g[2] - w[2]) <= 1e-9 * (1 + abs(w[2])) and abs(g[3] - w[3]) <= 1e-9 * (1 + abs(w[3])), (k, g[2:4], w[2:4])
+            continue
         assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), (k, float(np.abs(g[0] - w[0]).max()))
         assert g[2] == w[2] and g[3] == w[3], (k, g[2:4], w[2:4])
 
