@@ -522,6 +522,63 @@ def test_closed_loop_corridor_example():
     assert info["arrive"] and minc > 0.2, (info["arrive"], minc)
 
 
+def test_closed_loop_dynamic_obs_example(orc):
+    """The reference's own dynamic scene (example/dynamic_obs/dynamic_obs.yaml:24-32 through the headless world: 7 moving CIRCLES - norm2 obstacle cone,
+    per-stage (A, b) lists) with the keywords of dynamic_obs.py:22 (T = 10, iter_num = 2, max_obs_num = 6, min_sd = 0.5, wu = 0.2, max_acce = [10, 1],
+    reference speed 6, re-sorted every tick): the GPU path against the COLD oracle (every su-problem from the cold start, like ECOS in the reference)
+    step by step at TOL_U_FIXED - state re-synchronised every step - and, run on its own, to the goal without touching anything."""
+    from oracle.oracle_backend import oracle_backend
+    from rda_planner_amd.mpc import MPC
+    import rda_planner_amd.world as irsim
+    yaml_path = os.path.join(os.path.dirname(__file__), "golden", "world_dynamic_obs.yaml")
+    kw = dict(receding=10, process_num=5, iter_num=2, max_edge_num=4, max_obs_num=6, min_sd=0.5, wu=0.2, obstacle_order=True, time_print=False)
+    path = sc.path_track_ref()
+
+    def car_of(env):
+        ri = env.get_robot_info()
+        return sc.car(ri.G, ri.h, ri.cone_type, ri.wheelbase, [10, 1], [10, 1.0], "acker")
+    orc.lib.orc_set_su_warm.argtypes = [C.c_double, C.c_double, C.c_int]
+    orc.lib.orc_set_su_warm(0.0, 0.0, 0)
+    try:
+        env = irsim.make(yaml_path)
+        car_t = car_of(env)
+        cpu = MPC(car_t, [p.copy() for p in path], sample_time=0.1, _backend=oracle_backend, **kw)
+        gpu = MPC(car_t, [p.copy() for p in path], sample_time=0.1, **kw)
+        worst, same, steps = 0.0, 0, 150
+        for i in range(steps):
+            obs = env.get_obstacle_info_list()
+            assert sum(o.cone_type == "norm2" for o in obs) == 7
+            uc, ic = cpu.control(env.robot.state.copy(), 6, list(obs))
+            ug, ig = gpu.control(env.robot.state.copy(), 6, list(obs))
+            assert ic["status"] == 0 and ig["status"] == 0, (i, ic["status"], ig["status"])
+            if ic["iters"] == ig["iters"]:
+                same += 1
+                worst = max(worst, float(np.abs(uc - ug).max()), float(np.abs(cpu.cur_vel_array - gpu.cur_vel_array).max()))
+            else:
+                assert np.abs(uc - ug).max() <= hp.TOL_U_FLIP, (i, float(np.abs(uc - ug).max()))
+            gpu.rda.set_state(cpu.rda.get_state())
+            gpu.cur_vel_array = cpu.cur_vel_array.copy()
+            gpu._dev_u = None
+            env.step(uc)
+            if env.done() or ic["arrive"]:
+                break
+        print(f"dynamic_obs example vs cold oracle: {i + 1} steps, max |du| over the horizon {worst:.2e}, same ADMM iteration count on {same}")
+        assert worst <= hp.TOL_U_FIXED and same >= 0.95 * (i + 1), (worst, same, i + 1)
+    finally:
+        orc.lib.orc_set_su_warm(1e-3, 1e-3, 30)
+    env = irsim.make(yaml_path)
+    solo = MPC(car_of(env), [p.copy() for p in path], sample_time=0.1, **kw)
+    minc = np.inf
+    for i in range(500):
+        u, info = solo.control(env.robot.state, 6, env.get_obstacle_info_list())
+        env.step(u)
+        minc = min(minc, env.clearance())
+        if env.done() or info["arrive"]:
+            break
+    print(f"dynamic_obs example, GPU path on its own: {i + 1} steps, arrive={info['arrive']}, collided={env.collided}, min clearance {minc:.2f} m")
+    assert info["arrive"] and not env.collided and minc > 0.1, (info["arrive"], env.collided, minc)
+
+
 def test_closed_loop_lidar_example():
     """BASELINE config C3 (example/lidar_nav/lidar_path_track.py): boxes clustered from each lidar scan, max_obs_num=4 - the set of
     obstacles, their order and their number change from tick to tick.  The GPU path follows the oracle step by step (state

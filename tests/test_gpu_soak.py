@@ -45,3 +45,11 @@ def test_mini_soak_interior_point_lammuz_mode():
     from soak_lib import run_soak
     out = run_soak(scenes=12, steps=50, seed=12, cold_oracle=True, lmz_central=1e-3)
     _check(out, "mini-soak, lmz_central = 1e-3 vs cold oracle")
+
+
+def test_mini_soak_circle_obstacles():
+    """two of three obstacles are CIRCLES (norm2 obstacle cone: what the reference's dynamic_obs example is made of); the remembered supports of circle rows
+    (`lmz::warm_circle`, round 5) and the enumeration behind them against the cold oracle.  VERDICT r05 #6c: the 45 040-step circle soak was a tool run only."""
+    from soak_lib import run_soak
+    out = run_soak(scenes=12, steps=50, seed=101, cold_oracle=True, circles=True)
+    _check(out, "mini-soak, circle obstacles vs cold oracle")

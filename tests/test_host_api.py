@@ -234,6 +234,28 @@ def test_headless_world_runs_the_example_loop():
     assert np.linalg.norm(env.robot.state[0:2] - np.array([[10.0], [42.0]])) > 15.0   # and the robot made progress
 
 
+def test_headless_world_loads_the_dynamic_obs_scene():
+    """the reference's dynamic scene (example/dynamic_obs/dynamic_obs.yaml:24-32) as a fixture of the headless world: 7 moving circles with the radii of the
+    YAML's shape list, and the example's loop (dynamic_obs.py:22 keywords) steps on the oracle backend"""
+    from collections import namedtuple
+    import rda_planner_amd.world as irsim
+    env = irsim.make(os.path.join(os.path.dirname(__file__), "golden", "world_dynamic_obs.yaml"))
+    obs = env.get_obstacle_info_list()
+    assert len(obs) == 7 and all(o.cone_type == "norm2" for o in obs)
+    assert [float(o.radius) for o in obs] == [0.5, 0.6, 0.7, 1.0, 0.5, 0.5, 0.5]
+    assert all(0.3 <= float(np.linalg.norm(o.velocity)) <= 1.0 for o in obs)
+    assert np.allclose(env.robot.state.ravel(), [10, 40, 1.57])
+    car = namedtuple("car", "G h cone_type wheelbase max_speed max_acce dynamics")
+    ri = env.get_robot_info()
+    mpc_opt = MPC(car(ri.G, ri.h, ri.cone_type, ri.wheelbase, [10, 1], [10, 1.0], "acker"), sc.path_track_ref(), receding=10, sample_time=env.step_time,
+                  process_num=5, iter_num=2, max_edge_num=4, max_obs_num=6, min_sd=0.5, wu=0.2, obstacle_order=True, _backend=oracle_backend)
+    for i in range(12):
+        opt_vel, info = mpc_opt.control(env.robot.state, 6, env.get_obstacle_info_list())
+        assert info["status"] == 0 if "status" in info else True
+        env.step(opt_vel)
+    assert not env.collided and np.linalg.norm(env.robot.state[0:2] - np.array([[10.0], [40.0]])) > 2.0
+
+
 def test_corridor_example_is_traversed():
     """BASELINE config C2 (example/corridor/corridor.py:8-30, corridor.yaml:22-33): the straight reference path is blocked by
     four boxes inside a 8 m wide corridor; with the reference's default MPC parameters the robot slaloms to the goal.
