@@ -217,6 +217,83 @@ def fleet(ctx):
         out["python_api_closed_loop"] = fleet_python_api(ctx, M)
     except Exception as e:                                  # the line must not depend on this leg
         out["python_api_closed_loop"] = {"error": repr(e)[:200]}
+    try:
+        out["c_abi_closed_loop"] = fleet_closed_loop(ctx, M)
+        out["c_abi_closed_loop"]["member_by_member_resort_ego_steps_per_s"] = fleet_closed_loop(ctx, M, steps=12, warm=4, check=(), resort=1)["ego_steps_per_s"]
+    except Exception as e:
+        out["c_abi_closed_loop"] = {"error": repr(e)[:200]}
+    return out
+
+
+def fleet_closed_loop(ctx, M, steps=30, warm=6, check=(0, 1), resort=2):
+    """BASELINE config C5 as a CLOSED LOOP through the C-ABI: M egos, each with its OWN seeded scene (seed + ego), its own path index and state;
+    the caller is C (tools/closed_loop_host.c closed_loop_fleet_run): per fleet tick rda_fleet_scene_resort (resort = 2; 1: rda_scene_resort member by member -
+    the reference re-sorts each robot's list on every tick, mpc.py:205-206), ONE rda_fleet_step_tracked (every member's pre_process + ADMM loop, one host synchronisation), kinematics of every member in
+    C.  Members `check` are also run SOLO through closed_loop_run in the same protocol: the fleet is documented to be bit-identical to solo handles."""
+    import ctypes as C
+    from rda_planner_amd._capi import dptr, iptr
+    api, T, N, kw = ctx.api, ctx.T, ctx.N, ctx.kw
+    host = ctx.closed_loop_host()
+    n_all = warm + steps
+    solvers, states, scenes = [], np.zeros((M, 3)), []
+
+    def stage(sv, e):
+        car_t, path, obstacles, _ = build_workload(seed_offset=e, n_obs=N, T=T, n_steps=n_all + 10)
+        hh = sv._be.handle
+        n_sc, kind, nvert, geom, vel = sv.flatten_scene(list(obstacles))
+        kind, nvert = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(nvert, np.int32)
+        geom, vel = np.ascontiguousarray(geom, float), np.ascontiguousarray(vel, float)
+        P = np.ascontiguousarray(np.hstack(path)[0:3, :].T, dtype=float)
+        st = np.ascontiguousarray(path[0], float).ravel()[0:3].copy()
+        assert api.upload_path(hh, int(P.shape[0]), dptr(P)) == 0
+        assert api.upload_scene(hh, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(st), 1, None) == 0
+        return st, int(P.shape[0])
+    plen = np.zeros(M, np.int32)
+    for e in range(M):
+        sv = ctx.new_solver()
+        states[e], plen[e] = stage(sv, e)
+        solvers.append(sv)
+    arr = (C.c_void_p * M)(*[sv._be.handle for sv in solvers])
+    F = C.c_void_p()
+    assert api.fleet_create(arr, M, C.byref(F)) == 0
+    cur = np.zeros(M, np.int32)
+    nom_u0 = np.zeros((M, 2, T))
+    u_log, t_log = np.zeros((n_all, M, 2)), np.zeros(n_all)
+    it_log, ipm_log = np.zeros((n_all, M), np.int32), np.zeros((n_all, M), np.int32)
+    L, dyn = float(ctx.car_t.wheelbase or 0.0), {"acker": 0, "diff": 1, "omni": 2}[ctx.car_t.dynamics]
+
+    def go(k0, n):
+        rc = host.fleet_run(C.byref(host.fleet_api), F, arr, M, T, dyn, L, 0.1, 4.0, 0.1, 10, iptr(plen), resort, k0, n, dptr(nom_u0), dptr(states), iptr(cur),
+                            dptr(u_log[k0:]), dptr(t_log[k0:]), iptr(it_log[k0:]), iptr(ipm_log[k0:]))
+        assert rc == 0, rc
+    go(0, warm)
+    api.fleet_sync(F)
+    t0 = time.perf_counter()
+    go(warm, steps)
+    api.fleet_sync(F)
+    el = time.perf_counter() - t0
+    out = {"egos": M, "steps_per_ego": steps, "warmup": warm, "ego_steps_per_s": round(M * steps / el, 1), "ms_per_fleet_tick": round(el / steps * 1e3, 4),
+           "median_ms_per_fleet_tick": round(float(np.median(t_log[warm:])) * 1e3, 4), "mean_admm_iters": round(float(it_log[warm:].mean()), 3),
+           "su_interior_point_iters_per_ego_step": round(float(ipm_log[warm:].mean()), 2),
+           "resort": "rda_fleet_scene_resort (one launch set)" if resort == 2 else "rda_scene_resort member by member",
+           "what": "closed loop through the C-ABI, caller in C: per fleet tick the members' scenes re-sorted + ONE rda_fleet_step_tracked (one host "
+                   "synchronisation) + every member's kinematics; every member its own seeded scene, re-sorted about its robot on every tick (the headline protocol)"}
+    api.fleet_destroy(F)
+    del solvers
+    # solo runs of the same members in the same protocol (closed_loop_run: rda_tracked_begin + rda_scene_resort + rda_tracked_finish)
+    worst = 0.0
+    for e in check:
+        sv = ctx.new_solver()
+        st, pl = stage(sv, e)
+        scn = host.Scene(0, 0, 1, 0, None, None, None, None, None)
+        cur_c = C.c_int32(0)
+        ul, tl, il = np.zeros((n_all, 2)), np.zeros(n_all), np.zeros(n_all, np.int32)
+        rc = host.run(C.byref(host.api), sv._be.handle, C.byref(scn), T, dyn, L, 0.1, 4.0, 0.1, 10, pl, 0, n_all, dptr(np.zeros((2, T))), dptr(st),
+                      C.byref(cur_c), dptr(ul), dptr(tl), iptr(il), None, None)
+        assert rc == 0, rc
+        worst = max(worst, float(np.abs(ul - u_log[:, e, :]).max()))
+    out["max_du_vs_solo_closed_loop"] = worst
+    out["members_checked_against_solo"] = list(check)
     return out
 
 

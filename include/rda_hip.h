@@ -292,6 +292,11 @@ int  rda_fleet_step_tracked(rda_fleet *f, const double *states /*B*3*/, const do
                             double threshold, int ind_range, const double *nom_u /*B*2*T or NULL*/,
                             double *out_u, double *out_s, rda_info *info, double *ref_out /*B*3*(T+1) or NULL*/,
                             int32_t *min_index /*B*/, double *end_heading /*B*/);
+/* rda_scene_resort for every member in ONE launch set: the members' resident raw scenes (rda_upload_scene*, obstacles that do not move between ticks) re-ranked
+ * about states[i * stride + 0..1] (stride >= 2: the caller's [B][3] state array serves) and their slots rebuilt on the fleet's stream; the next fleet step runs
+ * behind it.  Replaces one MPC.convert_rda_obstacle + distance sort per robot and tick (mpc.py:189-218, obstacle_order=True).  Slots bit-identical to
+ * rda_scene_resort on each member.  Until the next fleet step has returned the members must not be used on their own. */
+int  rda_fleet_scene_resort(rda_fleet *f, const double *states, int stride);
 /* steps k0 .. k1-1 of every member's uploaded trace, asynchronous; read with rda_fetch_result after rda_fleet_sync */
 int  rda_fleet_enqueue_range(rda_fleet *f, int k0, int k1);
 int  rda_fleet_sync(rda_fleet *f);

@@ -151,6 +151,9 @@ class CApi:
             f("fleet_sync").argtypes = [C.c_void_p]
             for name in ("fleet_create", "fleet_size", "fleet_step", "fleet_enqueue_range", "fleet_sync"):
                 f(name).restype = C.c_int
+            if hasattr(lib, f"{prefix}_fleet_scene_resort"):
+                f("fleet_scene_resort").argtypes = [C.c_void_p, c_double_p, C.c_int]
+                f("fleet_scene_resort").restype = C.c_int
             self.has_fleet_scenes = hasattr(lib, f"{prefix}_fleet_upload_scenes")
             if self.has_fleet_scenes:
                 f("fleet_upload_scenes").argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, c_int_p]

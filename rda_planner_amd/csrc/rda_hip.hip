@@ -341,9 +341,8 @@ __global__ void k_begin(Dev d) { begin_body(d); }
 // ------------------------------------------------------------------------------------------------
 // K1: one wavefront per (obstacle n, stage t); 4 wavefronts per workgroup.
 // candidate list + vertices of every staged obstacle slot (one wave per (slot, time slot)); runs once per upload
-__global__ __launch_bounds__(256) void k_prepare(Dev d)
+__device__ __forceinline__ void prepare_body(const Dev &d, lmz::WaveLDS *wl)
 {
-    __shared__ lmz::WaveLDS wl[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, E = d.c.E;
     const int w = blockIdx.x * 4 + wv;
     if (w >= d.c.N * d.nt) return;
@@ -358,6 +357,8 @@ __global__ __launch_bounds__(256) void k_prepare(Dev d)
     if (lane < 56) d.oc_vtx[(size_t)w * 56 + lane] = (&W.vtx[0][0])[lane];
     if (lane == 0) { d.oc_cnt[2 * w] = W.npv; d.oc_cnt[2 * w + 1] = W.nlv; }
 }
+__global__ __launch_bounds__(256) void k_prepare(Dev d) { __shared__ lmz::WaveLDS wl[4]; prepare_body(d, wl); }
+__global__ __launch_bounds__(256) void k_prepare_fleet(const Dev *devs) { __shared__ lmz::WaveLDS wl[4]; prepare_body(devs[blockIdx.y], wl); }
 
 // Unit w of a rank's LamMuZ grid -> (stage t, local slot nl): the SLOT runs fastest and a stage is padded to GS J units, so a
 // workgroup of the packed kernels (GS = 8 rows: 2 waves x 4 rows) owns the slots GS j .. GS j + GS-1 of ONE stage: with the stage-major
@@ -2645,15 +2646,17 @@ struct rda_fleet {
     // tracked stepping (device-side pre_process), allocated on first use
     track::In *h_trk_in, *d_trk_in; track::Out *h_trk_out, *d_trk_out;
     double **h_paths, **d_paths; int *h_lens, *d_lens; EgoIO *h_io_track, *d_io_track;
+    // rda_fleet_scene_resort (allocated on first use): the members' scene arguments, their robots' positions; rob_pending: a copy out of h_rob may be queued
+    scene::Args *h_sc, *d_sc; double *h_rob, *d_rob; int rob_pending;
 };
 
 extern "C" void rda_fleet_destroy(rda_fleet *F)
 {
     if (!F) return;
     (void)hipStreamSynchronize(F->stream);
-    void *dp[] = { F->d_devs, F->d_io_step, F->d_io_trace, F->d_in, F->d_out, F->d_info, F->d_trk_in, F->d_trk_out, F->d_paths, F->d_lens, F->d_io_track };
+    void *dp[] = { F->d_devs, F->d_io_step, F->d_io_trace, F->d_in, F->d_out, F->d_info, F->d_trk_in, F->d_trk_out, F->d_paths, F->d_lens, F->d_io_track, F->d_sc, F->d_rob };
     for (void *q : dp) dev_free(q);
-    void *hp[] = { F->h_devs, F->h_io, F->h_in, F->h_out, F->h_info, F->h_trk_in, F->h_trk_out, F->h_paths, F->h_lens, F->h_io_track };
+    void *hp[] = { F->h_devs, F->h_io, F->h_in, F->h_out, F->h_info, F->h_trk_in, F->h_trk_out, F->h_paths, F->h_lens, F->h_io_track, F->h_sc, F->h_rob };
     for (void *q : hp) if (q) (void)hipHostFree(q);
     (void)hipEventDestroy(F->ev);
     (void)hipStreamDestroy(F->stream);
@@ -2766,6 +2769,7 @@ extern "C" int rda_fleet_step(rda_fleet *F, const double *nom_s, const double *n
     HIPCHK(hipMemcpyAsync(F->h_out, F->d_out, B * nout * sizeof(double), hipMemcpyDeviceToHost, F->stream));
     HIPCHK(hipMemcpyAsync(F->h_info, F->d_info, B * sizeof(rda_info), hipMemcpyDeviceToHost, F->stream));
     HIPCHK(hipStreamSynchronize(F->stream));
+    F->rob_pending = 0;
     for (rda_handle *Hm : F->egos) Hm->pending_scene = 0;      // their staged scenes have been consumed
     for (size_t i = 0; i < B; ++i) {
         memcpy(out_u + i * nu, F->h_out + i * nout, nu * sizeof(double));
@@ -2807,6 +2811,51 @@ extern "C" int rda_fleet_upload_scenes(rda_fleet *F, const int32_t *counts, cons
         if (rc != RDA_OK) return rc;
         off += (size_t)n;
     }
+    return RDA_OK;
+}
+
+// rda_scene_resort for every member in ONE launch set (round 6): the members' resident raw scenes (rda_upload_scene*, static obstacles) re-ranked about
+// states[i * stride + 0..1] and their slots rebuilt on the fleet's stream; the next fleet step runs behind it.  Same device code per member as
+// rda_scene_resort: bit-identical slots.  Members with rda_opts::duals_follow, without a resident scene, or inside a tick: RDA_ERR_UNSUPPORTED / _ARG.
+extern "C" int rda_fleet_scene_resort(rda_fleet *F, const double *states, int stride)
+{
+    if (!F || !states || stride < 2) return RDA_ERR_ARG;
+    const size_t B = F->B;
+    for (rda_handle *H : F->egos) {
+        if (H->sc_n <= 0 || H->d.obstacle_num == 0 || H->pending) return RDA_ERR_ARG;
+        if (H->follow) return RDA_ERR_UNSUPPORTED;
+    }
+    if (!F->d_sc) {
+        int rc = 0;
+        rc |= dalloc(&F->d_sc, B); rc |= dalloc(&F->d_rob, 2 * B);
+        if (rc) return RDA_ERR_HIP;
+        HIPCHK(hipHostMalloc((void **)&F->h_sc, B * sizeof(scene::Args)));
+        HIPCHK(hipHostMalloc((void **)&F->h_rob, 2 * B * sizeof(double)));
+        memset((void *)F->h_sc, 0, B * sizeof(scene::Args));
+    }
+    int rc = fleet_refresh(F);
+    if (rc != RDA_OK) return rc;
+    bool changed = false;
+    int nmax = 0, wmax = 0;
+    for (size_t i = 0; i < B; ++i) {
+        scene::Args a = F->egos[i]->sc_args;
+        a.order = 1; a.robot_val = 0; a.rx = 0; a.ry = 0;
+        if (memcmp(&a, &F->h_sc[i], sizeof(scene::Args)) != 0) changed = true;
+        nmax = a.n > nmax ? a.n : nmax; wmax = a.N * a.nt > wmax ? a.N * a.nt : wmax;
+    }
+    if (changed || F->rob_pending) { HIPCHK(hipStreamSynchronize(F->stream)); F->rob_pending = 0; }
+    if (changed) {
+        for (size_t i = 0; i < B; ++i) { scene::Args a = F->egos[i]->sc_args; a.order = 1; a.robot_val = 0; a.rx = 0; a.ry = 0; memcpy((void *)&F->h_sc[i], &a, sizeof(a)); }
+        HIPCHK(hipMemcpyAsync(F->d_sc, F->h_sc, B * sizeof(scene::Args), hipMemcpyHostToDevice, F->stream));
+    }
+    for (size_t i = 0; i < B; ++i) { F->h_rob[2 * i] = states[i * stride]; F->h_rob[2 * i + 1] = states[i * stride + 1]; }
+    HIPCHK(hipMemcpyAsync(F->d_rob, F->h_rob, 2 * B * sizeof(double), hipMemcpyHostToDevice, F->stream));
+    F->rob_pending = 1;
+    hipLaunchKernelGGL(scene::k_keys_fleet, dim3((nmax + 255) / 256, (unsigned)B), dim3(256), 0, F->stream, (const scene::Args *)F->d_sc, (const double *)F->d_rob);
+    hipLaunchKernelGGL(scene::k_rank_fleet, dim3((nmax + 15) / 16, (unsigned)B), dim3(256), 0, F->stream, (const scene::Args *)F->d_sc, (const double *)F->d_rob);
+    hipLaunchKernelGGL(scene::k_build_fleet, dim3((wmax + 255) / 256, (unsigned)B), dim3(256), 0, F->stream, (const scene::Args *)F->d_sc, (const double *)F->d_rob);
+    hipLaunchKernelGGL(k_prepare_fleet, dim3((unsigned)((wmax + 3) / 4), (unsigned)B), dim3(256), 0, F->stream, (const Dev *)F->d_devs);
+    HIPCHK(hipGetLastError());
     return RDA_OK;
 }
 
@@ -2901,7 +2950,7 @@ extern "C" int rda_fleet_enqueue_range(rda_fleet *F, int k0, int k1)
     return RDA_OK;
 }
 
-extern "C" int rda_fleet_sync(rda_fleet *F) { if (!F) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(F->stream)); return RDA_OK; }
+extern "C" int rda_fleet_sync(rda_fleet *F) { if (!F) return RDA_ERR_ARG; HIPCHK(hipStreamSynchronize(F->stream)); F->rob_pending = 0; return RDA_OK; }
 extern "C" int rda_fleet_size(rda_fleet *F) { return F ? F->B : RDA_ERR_ARG; }
 
 // ---- pure-function hooks ------------------------------------------------------------------------

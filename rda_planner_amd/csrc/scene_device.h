@@ -28,10 +28,9 @@ struct Args {
 };
 
 // distance key of one obstacle: rda_obs_distance, mpc.py:214-218 (circle: centre distance; polygon: nearest vertex)
-__global__ void k_keys(Args a)
+__device__ __forceinline__ void keys_body(const Args &a, const int i)
 {
 #pragma clang fp contract(off)        // numpy does not fuse: keep every product and sum separately rounded
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (!a.order) { a.key[i] = (double)i; return; }
     const double x = a.robot_val ? a.rx : a.robot[0], y = a.robot_val ? a.ry : a.robot[1];
@@ -49,13 +48,14 @@ __global__ void k_keys(Args a)
         a.key[i] = best;
     }
 }
+__global__ void k_keys(Args a) { keys_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // stable rank by key (Python's list.sort is stable); the first min(n, N) survive (rda_solver.py:491-493)
 // O(n^2) compares spread over 16 lanes per key (256-thread blocks = 16 keys; launch with (n + 15) / 16 blocks): a count, so the
 // result does not depend on how the compares are split
-__global__ void k_rank(Args a)
+__device__ __forceinline__ void rank_body(const Args &a, const int blk)
 {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int i = blk * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
     const bool live = i < a.n;
     const double ki = live ? a.key[i] : 0.0;
     int r = 0;
@@ -64,12 +64,12 @@ __global__ void k_rank(Args a)
     for (int off = 8; off >= 1; off >>= 1) r += __shfl_xor(r, off, 16);
     if (live && l == 0 && r < a.N) a.sel[r] = i;
 }
+__global__ void k_rank(Args a) { rank_body(a, blockIdx.x); }
 
 // one thread per (slot, time slot): half-space form of the selected obstacle at time t
-__global__ void k_build(Args a)
+__device__ __forceinline__ void build_body(const Args &a, const int w)
 {
 #pragma clang fp contract(off)
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.N * a.nt) return;
     const int s = w / a.nt, t = w % a.nt;
     const int used = a.n < a.N ? a.n : a.N;
@@ -114,5 +114,24 @@ __global__ void k_build(Args a)
         b[j] = a0 * px[c0] + a1 * py[c0];   // sum(A * cur, axis=1)   :507
     }
 }
+__global__ void k_build(Args a) { build_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
+
+// The same three kernels for a FLEET (rda_fleet_scene_resort, round 6): blockIdx.y = the member, its Args in a device array, its robot position in
+// rob [B][2] - one launch set re-sorts the resident scenes of all members about their robots (64 members x 4 launches on 64 streams cost the host
+// 4 ms per fleet tick; this is 4 launches).  Same device code per member: the slots come out bit-identical to rda_scene_resort on the member.
+__device__ __forceinline__ Args fleet_args(const Args *as, const double *rob)
+{
+    Args a = as[blockIdx.y];
+    a.order = 1; a.robot_val = 1; a.rx = rob[2 * blockIdx.y]; a.ry = rob[2 * blockIdx.y + 1];
+    return a;
+}
+__global__ void k_keys_fleet(const Args *as, const double *rob)
+{
+    const Args a = fleet_args(as, rob);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.nonconvex = 0;        // (k_build, later in the stream, counts into it)
+    keys_body(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void k_rank_fleet(const Args *as, const double *rob) { const Args a = fleet_args(as, rob); rank_body(a, blockIdx.x); }
+__global__ void k_build_fleet(const Args *as, const double *rob) { const Args a = fleet_args(as, rob); build_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
 
 }  // namespace scene

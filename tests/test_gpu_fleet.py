@@ -233,3 +233,66 @@ def test_fleet_control_equals_member_control_other_shapes(T, E, robot_k):
             states[i] = sc.kinematic_step(states[i], u, cars[i], 0.1)
     assert fleet.batched_ticks > 0
     fleet.close()
+
+
+@pytest.mark.parametrize("resort", [2, 1], ids=["fleet-resort", "member-resort"])
+def test_c_fleet_closed_loop_equals_solo_closed_loops(hip, resort):
+    """BASELINE config C5 as a closed loop through the C-ABI with the caller in C (tools/closed_loop_host.c closed_loop_fleet_run, what bench.py's
+    `c_abi_closed_loop` fleet leg times): per fleet tick the members' scenes re-sorted (rda_fleet_scene_resort: one launch set; or rda_scene_resort member by
+    member) + ONE rda_fleet_step_tracked + the members' kinematics.  Every
+    member - own scene (two of them circle-heavy: norm2 rows go through the enumeration in the fleet kernels and through `warm_circle` in the solo
+    kernel), own kinematics-independent path offset - against its SOLO closed loop in the same protocol (closed_loop_run: rda_tracked_begin +
+    rda_scene_resort + rda_tracked_finish): bit for bit, controls and iteration counts."""
+    import os
+    import sys
+    from rda_planner_amd.rda_solver import RDA_solver
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import closed_loop_host as clh
+    host = clh.Host(hip.lib)
+    B, T, N, steps = 5, 10, 16, 40
+    car_t = sc.rectangle_robot(dynamics="acker")
+
+    def make(e):
+        y = 20.0 + 2.5 * e
+        path = sc.line_path([4, y, 0], [44, y, 0], 0.1)
+        clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+        scene = sc.scene_polygons(14 if e % 2 == 0 else 5, lo=(6, y - 6), hi=(44, y + 6), seed=70 + e, keep_clear=clear, clear_radius=2.3)
+        rng = np.random.default_rng(700 + e)
+        while len(scene) < 20:                       # circles (more of them in the odd members)
+            c = rng.uniform((6, y - 6), (44, y + 6))
+            if np.min(np.linalg.norm(clear - c, axis=1)) > 2.6:
+                scene.append(sc.circle(c[0], c[1], rng.uniform(0.4, 1.0)))
+        sv = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+        n_sc, kind, nvert, geom, vel = sv.flatten_scene(list(scene))
+        kind, nvert = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(nvert, np.int32)
+        geom, vel = np.ascontiguousarray(geom, float), np.ascontiguousarray(vel, float)
+        P = np.ascontiguousarray(np.hstack(path)[0:3, :].T, dtype=float)
+        st = np.ascontiguousarray(path[0], float).ravel()[0:3].copy()
+        assert hip.upload_path(sv._be.handle, int(P.shape[0]), dptr(P)) == 0
+        assert hip.upload_scene(sv._be.handle, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(st), 1, None) == 0
+        return sv, st, int(P.shape[0])
+    memb = [make(e) for e in range(B)]
+    states = np.array([m[1] for m in memb])
+    plen = np.array([m[2] for m in memb], np.int32)
+    arr = (C.c_void_p * B)(*[m[0]._be.handle for m in memb])
+    F = C.c_void_p()
+    assert hip.fleet_create(arr, B, C.byref(F)) == 0
+    cur, nom_u0 = np.zeros(B, np.int32), np.zeros((B, 2, T))
+    u_log, t_log = np.zeros((steps, B, 2)), np.zeros(steps)
+    it_log, ipm_log = np.zeros((steps, B), np.int32), np.zeros((steps, B), np.int32)
+    rc = host.fleet_run(C.byref(host.fleet_api), F, arr, B, T, 0, 3.0, 0.1, 4.0, 0.1, 10, iptr(plen), resort, 0, steps, dptr(nom_u0), dptr(states), iptr(cur),
+                        dptr(u_log), dptr(t_log), iptr(it_log), iptr(ipm_log))
+    assert rc == 0, rc
+    hip.fleet_destroy(F)
+    assert np.abs(u_log[:, :, 0]).min() > 0.5 and len({tuple(np.round(u_log[-1, e], 4)) for e in range(B)}) >= 3      # the members do different things
+    for e in range(B):
+        sv, st, pl = make(e)
+        scn = host.Scene(0, 0, 1, 0, None, None, None, None, None)
+        cur_c = C.c_int32(0)
+        ul, tl, il = np.zeros((steps, 2)), np.zeros(steps), np.zeros(steps, np.int32)
+        rc = host.run(C.byref(host.api), sv._be.handle, C.byref(scn), T, 0, 3.0, 0.1, 4.0, 0.1, 10, pl, 0, steps, dptr(np.zeros((2, T))), dptr(st),
+                      C.byref(cur_c), dptr(ul), dptr(tl), iptr(il), None, None)
+        assert rc == 0, rc
+        assert np.array_equal(il, it_log[:, e]), (e, il, it_log[:, e])
+        assert np.array_equal(ul, u_log[:, e, :]), (e, float(np.abs(ul - u_log[:, e, :]).max()))
+        assert np.allclose(st, states[e], rtol=0, atol=0)

@@ -8,6 +8,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include "../include/rda_hip.h"
@@ -88,4 +89,57 @@ int closed_loop_run(const struct closed_loop_api *api, rda_handle *h, const stru
         t_log[k - k0] = now_s() - t0;
     }
     return 0;
+}
+
+/* ---- the same loop for a FLEET (BASELINE config C5, "batched multi-ego"): B egos, one rda_fleet, ONE host synchronisation per fleet tick.  Per tick
+ * rda_fleet_scene_resort (resort = 2; resort = 1: rda_scene_resort member by member) - the reference re-sorts every robot's obstacle list on every tick
+ * (mpc.py:205-206) - then ONE
+ * rda_fleet_step_tracked for all members (every member's MPC.pre_process, ADMM loop and result hand-over; it orders itself behind the members'
+ * re-staging), then the host applies every member's first control to its kinematic model.  states [B][3], cur_index [B] are read and advanced;
+ * u_log [n_steps][B][2], t_log [n_steps] (wall time of a fleet tick), iters_log [n_steps][B], ipm_log [n_steps][B] (may be NULL).  Members whose path
+ * ends stop the run (return 1). */
+typedef int (*fleet_step_tracked_fn)(rda_fleet *, const double *, const double *, const int32_t *, double, int, const double *, double *, double *,
+                                     rda_info *, double *, int32_t *, double *);
+typedef int (*fleet_scene_resort_fn)(rda_fleet *, const double *, int);
+struct closed_loop_fleet_api { fleet_step_tracked_fn fleet_step_tracked; scene_resort_fn scene_resort; fleet_scene_resort_fn fleet_scene_resort; };
+
+int closed_loop_fleet_run(const struct closed_loop_fleet_api *api, rda_fleet *f, rda_handle *const *egos, int B, int T, int dynamics, double wheelbase,
+                          double dt, double ref_speed, double threshold, int ind_range, const int32_t *path_len, int resort, int k0, int n_steps,
+                          const double *nom_u_first, double *states, int32_t *cur_index, double *u_log, double *t_log, int32_t *iters_log,
+                          int32_t *ipm_log)
+{
+    if (T > RDA_TMAX || B < 1) return -1;
+    const size_t nu = 2 * (size_t)T, ns = 3 * ((size_t)T + 1);
+    double *out_u = (double *)malloc(sizeof(double) * B * nu), *out_s = (double *)malloc(sizeof(double) * B * ns);
+    double *speed = (double *)malloc(sizeof(double) * B), *eh = (double *)malloc(sizeof(double) * B);
+    rda_info *inf = (rda_info *)malloc(sizeof(rda_info) * B);
+    int32_t *mi = (int32_t *)malloc(sizeof(int32_t) * B);
+    int rc = 0;
+    if (!out_u || !out_s || !speed || !eh || !inf || !mi) rc = -1;
+    for (int i = 0; i < B && rc == 0; ++i) speed[i] = ref_speed;
+    for (int k = k0; k < k0 + n_steps && rc == 0; ++k) {
+        const double t0 = now_s();
+        if (resort == 2 && api->fleet_scene_resort) rc = api->fleet_scene_resort(f, states, 3);       /* one launch set for all members */
+        else if (resort)
+            for (int i = 0; i < B && rc >= 0; ++i) rc = api->scene_resort(egos[i], states + 3 * i);      /* member by member (64 x 4 launches on 64 streams) */
+        if (rc >= 0)
+            rc = api->fleet_step_tracked(f, states, speed, cur_index, threshold, ind_range, k == 0 ? nom_u_first : 0, out_u, out_s, inf, 0, mi, eh);
+        if (rc < 0) break;
+        rc = 0;
+        for (int i = 0; i < B; ++i) {
+            double *st = states + 3 * i;
+            const double v = out_u[i * nu], w = out_u[i * nu + T], phi = st[2];
+            cur_index[i] = mi[i];
+            if (mi[i] >= path_len[i] - 1) rc = 1;
+            if (dynamics == 0) { st[0] += dt * (v * cos(phi)); st[1] += dt * (v * sin(phi)); st[2] += dt * (v * tan(w) / wheelbase); }
+            else if (dynamics == 1) { st[0] += dt * (v * cos(phi)); st[1] += dt * (v * sin(phi)); st[2] += dt * w; }
+            else { st[0] += dt * (v * cos(w)); st[1] += dt * (v * sin(w)); }
+            u_log[((size_t)(k - k0) * B + i) * 2] = v; u_log[((size_t)(k - k0) * B + i) * 2 + 1] = w;
+            iters_log[(size_t)(k - k0) * B + i] = inf[i].iters;
+            if (ipm_log) ipm_log[(size_t)(k - k0) * B + i] = inf[i].su_ipm_iters;
+        }
+        t_log[k - k0] = now_s() - t0;
+    }
+    free(out_u); free(out_s); free(speed); free(eh); free(inf); free(mi);
+    return rc;
 }

@@ -22,6 +22,10 @@ class Scene(C.Structure):      # struct closed_loop_scene
                 ("nvert", C.POINTER(C.c_int32)), ("geom", C.POINTER(C.c_double)), ("geom0", C.POINTER(C.c_double)), ("vel", C.POINTER(C.c_double))]
 
 
+class FleetApi(C.Structure):   # struct closed_loop_fleet_api
+    _fields_ = [(n_, C.c_void_p) for n_ in ("fleet_step_tracked", "scene_resort", "fleet_scene_resort")]
+
+
 class Host:
     """`run` = closed_loop_run; `api` = the four entry points of librda_hip.so it calls, as function pointers"""
 
@@ -36,3 +40,11 @@ class Host:
                                         C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         self.run = lib.closed_loop_run
+        self.fleet_api = FleetApi(*[C.cast(getattr(rda_lib, "rda_" + n_), C.c_void_p).value if hasattr(rda_lib, "rda_" + n_) else None
+                                    for n_, _ in FleetApi._fields_])
+        lib.closed_loop_fleet_run.restype = C.c_int
+        lib.closed_loop_fleet_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                              C.c_double, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        self.fleet_run = lib.closed_loop_fleet_run
