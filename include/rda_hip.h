@@ -9,8 +9,8 @@
  * (rda_strerror).  One HIP stream per handle; a handle is not thread-safe, distinct handles
  * are independent; no global state: everything that configures a solver travels in rda_cfg (the
  * reference's constructor arguments) and rda_opts (solver options that are not reference arguments),
- * both copied into the handle at creation.  RDA_* environment variables are read by rda_opts_init
- * only, as overrides of its defaults (experiments, A/B runs).
+ * both copied into the handle at creation.  The library reads NO environment variable (since round 5): the RDA_* switches of the
+ * A/B tools are applied by the Python host package (rda_planner_amd.rda_solver.hip_options) to the rda_opts it hands over.
  *
  * reference interface replaced                       | entry point
  * ---------------------------------------------------+-------------------------------------
@@ -105,11 +105,6 @@ typedef struct rda_opts {
     int32_t lmz_rows;        /* [1] four sub-problems per wave when E+R+1 <= 16                                        RDA_LMZ_ROWS */
     int32_t lmz_dense_from;  /* [256] grid size (CUs at one wave per SIMD) above which the split form of the LamMuZ launch is used; x 7/4 for moving scenes  RDA_LMZ_DENSE_FROM */
     int32_t lmz_split;       /* [1] dense grids: common-path kernel + work-list kernel + finalize                      RDA_LMZ_SPLIT */
-    int32_t lmz_tail;        /* [0] 1: the last-arriving LamMuZ workgroup of the iteration a step is expected to end in reduces the residuals,
-                                takes the early-stop verdict and hands the result over, instead of the next su launch / k_finish.  Built
-                                for VERDICT r02 #6 and measured SLOWER (-2 .. -4 % closed loop at the north-star size: draining the
-                                write-through stores + ticket + acquire cost more than the kernel boundary they replace);
-                                same values either way                                                                   RDA_LMZ_TAIL */
     int32_t lmz_ip_rows;     /* [1] interior-point mode: the row-parallel kernel (16 lanes per sub-problem) when the shape allows
                                 (0: one sub-problem per thread)                                                         RDA_LMZ_IP_ROWS */
     int32_t lmz_ip_warm;     /* [1] interior-point mode, row-parallel kernel: every sub-problem starts from the central-path point its last
@@ -314,8 +309,13 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime, hist[2] = the previous step ended above
  * iter_threshold, hist[3] = the last su-solve started far from its solution (the two keys of su_hard_warm); lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
-int  rda_get_su_history(rda_handle *h, int32_t *hist /*4*/, double *lam_keep /*10*T*/);
-int  rda_set_su_history(rda_handle *h, const int32_t *hist /*4*/, const double *lam_keep /*10*T*/);
+#define RDA_SU_HISTORY_INTS 4   /* entries of `hist` in THIS header (round 4: 2 - the array grew in round 5, an ABI break for callers of the count-less forms) */
+int  rda_get_su_history(rda_handle *h, int32_t *hist /*RDA_SU_HISTORY_INTS*/, double *lam_keep /*10*T*/);
+int  rda_set_su_history(rda_handle *h, const int32_t *hist /*RDA_SU_HISTORY_INTS*/, const double *lam_keep /*10*T*/);
+/* ... with the caller's own count: get writes n_hist entries (those this library does not have read 0), set reads
+ * min(n_hist, RDA_SU_HISTORY_INTS) and leaves the others as they are - a caller compiled against an older or newer header stays correct */
+int  rda_get_su_history_n(rda_handle *h, int32_t *hist, int n_hist, double *lam_keep /*10*T*/);
+int  rda_set_su_history_n(rda_handle *h, const int32_t *hist, int n_hist, const double *lam_keep /*10*T*/);
 /* Interior-point LamMuZ mode: the central-path points the sub-problems last ended on ([T][N][5][16] doubles: x | s, z of the diagonal
  * rows | s, z of the general rows, csrc/lammuz_ip_device.h) and their validity flags [T][N] - where each sub-problem's next solve starts.
  * Solver history like the su history above: it moves a result only within the centring tolerance (1e-7 mu relative), rda_reset clears

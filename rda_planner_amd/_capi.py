@@ -27,7 +27,7 @@ class Opts(C.Structure):
     """rda_opts of include/rda_hip.h: per-handle solver options that are not reference arguments (filled by rda_opts_init)"""
     _fields_ = [("lmz_mode", C.c_int), ("tie_centre", C.c_int), ("lmz_mu", C.c_double), ("su_tol", C.c_double * 3), ("su_tol_early", C.c_double * 3), ("su_hard_warm", C.c_double * 2),
                 ("lmz_warm", C.c_int), ("lmz_rows", C.c_int), ("lmz_dense_from", C.c_int), ("lmz_split", C.c_int),
-                ("lmz_tail", C.c_int), ("lmz_ip_rows", C.c_int), ("lmz_ip_warm", C.c_int), ("su_pre", C.c_int), ("su_light", C.c_int),
+                ("lmz_ip_rows", C.c_int), ("lmz_ip_warm", C.c_int), ("su_pre", C.c_int), ("su_light", C.c_int),
                 ("su_warm_first", C.c_int), ("su_warm_cap", C.c_int), ("su_easy_max", C.c_int), ("su_easy_nopred", C.c_int),
                 ("su_cold_from", C.c_int), ("su_cold_probe", C.c_int), ("zero_copy", C.c_int), ("early_finish", C.c_int),
                 ("fuse_track", C.c_int), ("su_prof", C.c_int), ("su_split", C.c_int), ("duals_follow", C.c_int), ("su_accept", C.c_int), ("su_first_attempt", C.c_int),
@@ -75,6 +75,10 @@ class CApi:
             f("get_su_history").argtypes = [C.c_void_p, c_int_p, c_double_p]
             f("set_su_history").argtypes = [C.c_void_p, c_int_p, c_double_p]
             f("get_su_history").restype = f("set_su_history").restype = C.c_int
+            if hasattr(lib, f"{prefix}_get_su_history_n"):
+                f("get_su_history_n").argtypes = [C.c_void_p, c_int_p, C.c_int, c_double_p]
+                f("set_su_history_n").argtypes = [C.c_void_p, c_int_p, C.c_int, c_double_p]
+                f("get_su_history_n").restype = f("set_su_history_n").restype = C.c_int
         f("destroy").argtypes = [C.c_void_p]
         f("destroy").restype = None
         f("set_adjust").argtypes = [C.c_void_p] + [C.c_double] * 5

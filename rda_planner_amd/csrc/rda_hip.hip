@@ -44,11 +44,8 @@ struct Ctrl {
     int su_probe;                 // consecutive su-solves in the hard regime (see su_body)
     int hint_par;                 // which of the two Dev::hint buffers the LamMuZ launch of this iteration WRITES (flipped by every executed su launch)
     int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
-    unsigned ticket;              // workgroups of the LamMuZ launch of this iteration that have published their partials (reset by k_su)
-    int resi_iter;                // ADMM iterations of this step whose residuals are in resi_dual / resi_pri (LamMuZ tail, else k_su / k_finish)
-    int verdict_iter;             // ... and for which the early-stop verdict has been TAKEN (by the LamMuZ tail; else the next su launch takes it)
+    int resi_iter;                // ADMM iterations of this step whose residuals are in resi_dual / resi_pri (k_su / k_finish)
     int pose_ok;                  // Dev::pose and the near masks of Dev::coef describe the same terms (a LamMuZ launch / k_lmz_finalize made them)
-    int prev_iters;               // ADMM iterations of the previous step: the LamMuZ tail runs where the step is expected to end (lmz_tail)
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
     double rd0_tmp;               // ... that residual, written by the solve
@@ -85,7 +82,6 @@ struct Dev {
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
     int su_pre;                        // the su set-up reads the block sums / near masks of the LamMuZ launch (0: it evaluates every term itself)
-    int lmz_tail;                      // the last-arriving LamMuZ workgroup reduces the residuals, decides the early stop and hands the result over (P == 1)
     int su_cold_probe;
     int su_cold_from;                  // a solve that follows one with more interior-point iterations than this starts cold (0 = never)
     double su_easy[5]; int su_easy_max;  // wfl, mu0, clip, tau, sigma of the start used while the su-solves are EASY (the last one took <= su_easy_max
@@ -200,7 +196,6 @@ __device__ __forceinline__ void publish_result(const Dev &d, const Fin &f)
         f.info->resi_dual = d.ctrl->resi_dual; f.info->resi_pri = d.ctrl->resi_pri;
         f.info->iters = d.ctrl->iters; f.info->su_status = d.ctrl->su_status; f.info->su_ipm_iters = d.ctrl->ipm_iters;
         f.info->lmz_fail = d.ctrl->lmz_fail;
-        d.ctrl->prev_iters = d.ctrl->iters;
         d.ctrl->prev_unconv = !(d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold);
     }
     // polygons of the staged scene that failed the reference's convexity test (mpc.py:476-549 prints a warning per polygon)
@@ -224,17 +219,16 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
         if (tid == 0) {
             d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0; d.ctrl->verdict_iter = 0;
+            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0;
         }
         __syncthreads();
     } else if (d.ctrl->stop) {
         if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    // The early stop of rda_solver.py:594 after iteration it-1.  Normally the LamMuZ launch of that iteration has taken the verdict in
-    // its tail (lmz_tail: residuals reduced, stop flag set, result handed over) and nothing is left to do here; with obstacle shards
-    // (the residual partials of the other ranks arrive with the all-gather) or with the tail switched off it is taken here.
-    if (it > 0 && d.ctrl->verdict_iter != it) {
+    // The early stop of rda_solver.py:594 after iteration it-1: the residual partials of the LamMuZ launch are reduced and the verdict taken here
+    // (a tail of the LamMuZ launch that did it instead - rda_opts::lmz_tail, rounds 2-5 - measured 2-4 % slower: tools/experiments/lmz_tail.patch).
+    if (it > 0) {
         if (d.ctrl->resi_iter != it) reduce_residuals(d, tid);          // (k_finish of a host-driven caller may have reduced them already)
         const bool stop_now = d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;   // rda_solver.py:594
         if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + (stop_now ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -250,9 +244,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
             return;
         }
     }
-    else if (it > 0 && fin && fin->verdict && tid == 0)        // (the LamMuZ tail has taken the verdict: not stopped)
-        __hip_atomic_store(fin->verdict, 2 * fin->vseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->ticket = 0; d.ctrl->hint_par ^= 1; }     // the LamMuZ launches of this iteration start with an empty work list / ticket and write the other support buffer
+    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->hint_par ^= 1; }     // the LamMuZ launches of this iteration start with an empty work list and write the other support buffer
     su::Args a;
     a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
@@ -298,7 +290,6 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
     if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
-    a.term_cache = a.warm_mu0 == 0 || d.ctrl->su_last > 1;       // cold start or a hard predecessor: several interior-point iterations ahead
     su::solve<TT>(a, smem_su, ref_wait);
     __syncthreads();
     if (tid == 0) {
@@ -332,7 +323,7 @@ __device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
         d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0; d.ctrl->resi_iter = 0; d.ctrl->verdict_iter = 0; d.ctrl->ticket = 0;
+        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0; d.ctrl->resi_iter = 0;
     }
 }
 
@@ -399,7 +390,7 @@ __device__ __forceinline__ RowOut failed_row(const Dev &d, int k)
 
 // GS row records [GS][6] = (|a|^2, g.a, g x a, dual residual, |Hm|^2, near) in LDS -> the block partial of (stage t, block j): threads
 // q = 0..4 sum one quantity over the rows IN ROW ORDER (dead rows hold zeros), thread 5 packs the near mask.  Stored write-through
-// (sc1: 8-byte agent-scope stores), so the last-arriving workgroup of the launch may read them without a release fence (lmz_tail).
+// (sc1: 8-byte agent-scope stores), as round 2's tail of the launch read them without a release fence (tools/experiments/lmz_tail.patch); kept: the next su launch reads them from L2 either way.
 __device__ __forceinline__ void block_partial(const Dev &d, int t, int j, const double (*rowv)[6], int q)
 {
     const size_t bi = (size_t)t * d.J + j;
@@ -417,43 +408,6 @@ __device__ __forceinline__ void row_record(double *rv, const Dev &d, const RowOu
 {
     const su::RowTerm q = su::row_term(o.ax, o.ay, o.c4, o.c5, o.bl + o.c3, px, py, d.c.max_sd, true);
     rv[0] = q.aa; rv[1] = q.ga; rv[2] = q.gxa; rv[3] = o.res; rv[4] = o.hh; rv[5] = (!d.c.accelerated || q.near) ? 1.0 : 0.0;
-}
-
-// Tail of the LamMuZ step of ADMM iteration `it` on a single rank.  Every workgroup has published its block partials write-through;
-// it drains them and takes a ticket.  The LAST one to arrive acquires, reduces the residual partials of all blocks in a fixed order
-// (the values do not depend on which workgroup that is), takes the early-stop verdict of rda_solver.py:594 and - when the step ends
-// here (stop, or the last iteration) - hands the result over.  The su launch that used to detect the stop (and k_finish) leave the
-// critical path: a two-iteration step is su, lmz, su, lmz.  All threads of the workgroup call; `flag` one LDS word.
-// The tail is an OPTIMISATION, never needed for correctness (a su launch that finds the residuals of the previous iteration not yet
-// reduced takes the verdict itself), and it costs ~4 us on the launch it runs in (drain the write-through stores, ticket, acquire,
-// reduce: measured at the north-star size) against ~8 us for the su launch it replaces - so it only runs where the step is EXPECTED to
-// end: from the iteration count of the previous step on (steps mostly repeat it), and in the last iteration.  Same reduction, same
-// values either way.
-__device__ __forceinline__ bool tail_here(const Dev &d, int it)
-{
-    return d.lmz_tail && d.P == 1 && (it + 1 >= d.c.iter_num || it + 1 >= d.ctrl->prev_iters);
-}
-__device__ __forceinline__ void lmz_tail(const Dev &d, int it, const Fin &fin, unsigned *flag, unsigned nblocks)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its sc1 stores ...
-    __syncthreads();
-    if (threadIdx.x == 0) {                                     // ... before the workgroup's ticket
-        const unsigned old = __hip_atomic_fetch_add(&d.ctrl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = old == nblocks - 1 ? 1u : 0u;
-        if (old == nblocks - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!*flag) return;
-    if (threadIdx.x == 0) d.ctrl->pose_ok = 1;                  // masks and pose table describe the same terms from here on
-    reduce_residuals(d, threadIdx.x);
-    const bool last = it + 1 >= d.c.iter_num;
-    const bool stop = !last && d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;      // rda_solver.py:594
-    __syncthreads();
-    if (threadIdx.x == 0) { d.ctrl->verdict_iter = it + 1; if (stop) d.ctrl->stop = 1; }
-    if ((stop || last) && fin.out_u) {
-        publish_result(d, fin);
-        if (threadIdx.x == 0) d.ctrl->finished = 1;
-    }
 }
 
 // K1, one (slot, stage) sub-problem per wavefront; 4 wavefronts per workgroup (shapes with E+R+1 > 16, RDA_LMZ_ROWS=0, and the
@@ -599,8 +553,8 @@ __global__ __launch_bounds__(256) void k_lammuz(Dev d, int it) { lammuz_body(d, 
 // (DESIGN.md section 5): the rows run it side by side.  Only a row whose certificate fails needs the 64-lane enumeration;
 // those rows are served one after the other by the whole wave.  Same device functions, same arithmetic, same results as
 // lammuz_body.  Requires E + R + 1 <= 16 (else the one-per-wave body is launched).
-// MODE 0: everything in one kernel (single ego, latency), INCLUDING the block partial of the workgroup's GS slots and the tail of
-//         the step (lmz_tail).  Dense grids are served by three launches instead:
+// MODE 0: everything in one kernel (single ego, latency), INCLUDING the block partial of the workgroup's GS slots.  Dense grids are served by
+//         three launches instead:
 // MODE 1: the common path only - three waves per SIMD, no spills; a row whose warm candidate fails its certificate goes on the
 //         handle's work list (Dev::wl) and writes nothing;
 // MODE 2: the rows on the work list, ONE per wave (row 0 of the wave; rows 1-3 idle) and pass, straight to the enumeration, then
@@ -617,7 +571,6 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     __shared__ lmz::WaveLDS wl[GS];
     __shared__ lmz::RobotLDS rb;
     __shared__ double rowv[MODE == 0 ? GS : 1][6];
-    __shared__ unsigned tail_flag;
     const int T = d.c.T, E = d.c.E, R = d.c.R;
 #ifdef RDA_LMZ_CLK
     // debug build only (tools/lmz_wave_clocks.py): clock64 ticks per section of a wave, in the wave's own 16-word slot of g_lmz_clk
@@ -871,8 +824,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     if (MODE == 0) {
         __syncthreads();
         block_partial(d, tb, jb, rowv, threadIdx.x);
-        if (tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
-        else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
+        if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
     }
     LMZ_CLK(7);
 #ifdef RDA_LMZ_CLK
@@ -907,7 +859,6 @@ __device__ __forceinline__ void finalize_body(const Dev &d, const int block, con
 {
 #pragma clang fp contract(on)
     __shared__ double rowv[FPB][GS][6];
-    __shared__ unsigned tail_flag;
     if (it >= 0 && d.ctrl->stop) return;
     const int T = d.c.T, g = threadIdx.x / GS, row = threadIdx.x % GS;
     const int B = block * FPB + g, t = B / d.J, j = B - t * d.J, nl = GS * j + row;
@@ -921,8 +872,7 @@ __device__ __forceinline__ void finalize_body(const Dev &d, const int block, con
     } else { rv[0] = rv[1] = rv[2] = rv[3] = rv[4] = rv[5] = 0.0; }
     __syncthreads();
     if (B < T * d.J) block_partial(d, t, j, rowv[g], row);
-    if (it >= 0 && tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)nblocks);
-    else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
+    if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
 }
 __global__ __launch_bounds__(256) void k_lmz_finalize(Dev d, int it, Fin fin) { finalize_body(d, blockIdx.x, gridDim.x, it, fin); }
 
@@ -1008,9 +958,8 @@ __device__ __forceinline__ void lammuz_ip_body(const Dev &d, const int block, co
     __shared__ lmz::WaveLDS wl[GS];
     __shared__ lmz::RobotLDS rb;
     __shared__ double rowv[GS][6];
-    __shared__ unsigned tail_flag;
     typedef rip::DevLanes L;
-    const int T = d.c.T, E = d.c.E, R = d.c.R;
+    const int E = d.c.E, R = d.c.R;
     if (d.ctrl->stop) return;
     int t, jb; block_of(d, block, t, jb);
     if (t < 0) return;
@@ -1107,8 +1056,7 @@ __device__ __forceinline__ void lammuz_ip_body(const Dev &d, const int block, co
     }
     __syncthreads();
     block_partial(d, t, jb, rowv, threadIdx.x);
-    if (tail_here(d, it)) lmz_tail(d, it, fin, &tail_flag, (unsigned)(T * d.J));
-    else if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
+    if (block == 0 && threadIdx.x == 0) d.ctrl->pose_ok = 1;
 }
 __global__ __launch_bounds__(64 * GS / 4) void k_lammuz_ip(Dev d, int it, Fin fin) { lammuz_ip_body(d, blockIdx.x, it, fin); }
 
@@ -1339,7 +1287,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     memset(o, 0, sizeof(*o));
     o->lmz_mode = 0; o->tie_centre = 1; o->lmz_mu = 1e-6;
     o->su_tol[0] = 1e-9; o->su_tol[1] = 1e-10; o->su_tol[2] = 1e-11; o->su_tol_early[0] = o->su_tol_early[1] = o->su_tol_early[2] = 0; o->su_hard_warm[0] = 1.0; o->su_hard_warm[1] = 1e-3;
-    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_tail = 0; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
+    o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1; o->su_first_attempt = 0;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
@@ -1413,7 +1361,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_warm_tau = o.su_warm_endgame[0]; H->d.su_warm_sig = o.su_warm_endgame[1]; H->d.su_warm_clip = o.su_warm_clip;
     for (int i = 0; i < 5; ++i) H->d.su_easy[i] = o.su_easy[i];
     H->d.su_easy_max = o.su_easy_max; H->d.su_easy_nopred = o.su_easy_nopred;
-    H->d.su_pre = o.su_pre; H->d.lmz_tail = o.lmz_tail;
+    H->d.su_pre = o.su_pre;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept; H->d.su_first_attempt = o.su_first_attempt;
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
@@ -1548,31 +1496,33 @@ extern "C" int rda_reset(rda_handle *H)
     return RDA_OK;
 }
 
-extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep)
+extern "C" int rda_get_su_history_n(rda_handle *H, int32_t *hist, int n_hist, double *lam_keep)
 {
-    if (!H) return RDA_ERR_ARG;
+    if (!H || n_hist < 0) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
-    if (hist) {
+    if (hist && n_hist > 0) {
         Ctrl c;
         HIPCHK(hipMemcpy(&c, H->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-        hist[0] = c.su_last; hist[1] = c.su_probe; hist[2] = c.prev_unconv; hist[3] = c.su_hardlike;
+        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike };
+        for (int i = 0; i < n_hist; ++i) hist[i] = i < RDA_SU_HISTORY_INTS ? all[i] : 0;      // (entries a later version may add read as 0 here)
     }
     if (lam_keep) HIPCHK(hipMemcpy(lam_keep, H->d.su_lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyDeviceToHost));
     return RDA_OK;
 }
-extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const double *lam_keep)
+extern "C" int rda_set_su_history_n(rda_handle *H, const int32_t *hist, int n_hist, const double *lam_keep)
 {
-    if (!H) return RDA_ERR_ARG;
+    if (!H || n_hist < 0) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     if (hist) {
-        HIPCHK(hipMemcpy(&H->d.ctrl->su_last, &hist[0], sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(&H->d.ctrl->su_probe, &hist[1], sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(&H->d.ctrl->prev_unconv, &hist[2], sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(&H->d.ctrl->su_hardlike, &hist[3], sizeof(int), hipMemcpyHostToDevice));
+        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike };
+        for (int i = 0; i < n_hist && i < RDA_SU_HISTORY_INTS; ++i) HIPCHK(hipMemcpy(dst[i], &hist[i], sizeof(int), hipMemcpyHostToDevice));   // entries the caller does not have keep their value
     }
     if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
     return RDA_OK;
 }
+// the forms without a count: RDA_SU_HISTORY_INTS (= 4 since round 5; round 4: 2) entries - a caller built against an older header must use the _n forms
+extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep) { return rda_get_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
+extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const double *lam_keep) { return rda_set_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_lmz_history_doubles(rda_handle *H) { return !H ? RDA_ERR_ARG : (H->d.ipw ? 80 * H->d.c.N * H->d.c.T : 0); }
 extern "C" int rda_get_lmz_history(rda_handle *H, double *points, int32_t *valid)
 {
@@ -1822,8 +1772,7 @@ static hipEvent_t next_event(rda_handle *H, int which)
 }
 
 // K1 launch of ADMM iteration `it`.  Packed rows when the shape allows: a small grid is ONE launch that also forms the block
-// partials and runs the tail of the step (residuals, early-stop verdict, hand-over of the result: lmz_tail); a dense grid is the
-// common-path kernel + the work-list kernel, with k_lmz_finalize (partials + tail) behind them.  One sub-problem per wave (big
+// partials; a dense grid is the common-path kernel + the work-list kernel, with k_lmz_finalize (partials) behind them.  One sub-problem per wave (big
 // shapes, the no-obstacle case of quirk Q9) and the per-thread interior-point kernel likewise end with k_lmz_finalize.
 static void launch_finalize(rda_handle *H, const Dev &d, int it, const Fin &fin)
 {
@@ -3024,7 +2973,8 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
     ar.c.slack_gain = cfg->slack_gain; ar.c.max_sd = cfg->max_sd; ar.c.min_sd = cfg->min_sd; ar.c.ro1 = cfg->ro1; ar.c.ro2 = cfg->ro2;
     rda_opts od; rda_opts_init(&od);                   // the stop tolerances / switches: the caller's, else the defaults
     if (opts) od = *opts;
-    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0]; ar.c.tol_rp = od.su_tol[1]; ar.c.tol_mu = od.su_tol[2]; ar.split = od.su_split; ar.accept = od.su_accept; ar.first_attempt = od.su_first_attempt;
+    ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0] > 0 ? od.su_tol[0] : 1e-9; ar.c.tol_rp = od.su_tol[1] > 0 ? od.su_tol[1] : 1e-10; ar.c.tol_mu = od.su_tol[2] > 0 ? od.su_tol[2] : 1e-11;    // (same fallback as rda_create_opts)
+    ar.split = od.su_split; ar.accept = od.su_accept; ar.first_attempt = od.su_first_attempt;
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.cb = dsoa + 2 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;

@@ -132,7 +132,6 @@ struct Args {
     // iter_num = 1: 1.0 -> 3.0 iterations per solve, the easy start locked out).
     double hard_dmu = 0;
     double *lam_keep = nullptr;
-    int term_cache = 1;              // (unused since the near terms of a screened solve live in LDS: Lds::near)
     // time split of the Newton system (TT = 10, 20, 25, 30): the stages [T/2, T) are factorised by wave 0 and the stages [0, T/2) by wave 1 at
     // the same time (see solve); 0 = one recursion over the whole horizon on wave 0 (rounds 1-3)
     int split = 1;
@@ -1481,6 +1480,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (a.rd0 && used == 0 && it == 0 && tid == 0) *a.rd0 = rdn / sc;
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
         const bool conv_now = (rdn <= c.tol_rd * sc && rpn <= c.tol_rp && mu <= c.tol_mu * sc) || (rdn <= 100 * c.tol_rd * sc && rpn <= c.tol_rp && mu <= 0.1 * c.tol_mu * sc);
+        // (may a remembered iterate have ignored hinge terms outside the near list?  No: the measures tested here were formed by THIS pass's stage
+        // phase, which sums the near list only while `screened` holds - and `screened` is dropped by the reach check right behind every update (and by the
+        // set-up for the nominal) as soon as a stage has left the DELTA ball; from then on every pass sums every term.  So an iterate that passes this test
+        // was measured on a term set that contains every term that can be active at it - the same argument as for the converged iterate.)
         if (a.accept && !conv_now && rpn <= c.tol_rp && rdn <= 10 * c.tol_rd * sc && mu <= 1e3 * c.tol_mu * sc) {     // (uniform) safety net: see Args::accept
             const double merit = fmax(rdn / (c.tol_rd * sc), mu / (c.tol_mu * sc));
             if (!have_acc || merit < acc_merit) {

@@ -61,7 +61,7 @@ class _Backend:
 _ENV_SWITCHES = {
     "RDA_LMZ_MODE": ("lmz_mode",), "RDA_TIE_CENTRE": ("tie_centre",), "RDA_LMZ_MU": ("lmz_mu",), "RDA_SU_TOL": ("su_tol",), "RDA_SU_HARD_WARM": ("su_hard_warm",),
     "RDA_SU_TOL_EARLY": ("su_tol_early",), "RDA_LMZ_WARM": ("lmz_warm",), "RDA_LMZ_ROWS": ("lmz_rows",), "RDA_LMZ_DENSE_FROM": ("lmz_dense_from",),
-    "RDA_LMZ_SPLIT": ("lmz_split",), "RDA_LMZ_TAIL": ("lmz_tail",), "RDA_LMZ_IP_ROWS": ("lmz_ip_rows",), "RDA_LMZ_IP_WARM": ("lmz_ip_warm",), "RDA_SU_PRE": ("su_pre",),
+    "RDA_LMZ_SPLIT": ("lmz_split",), "RDA_LMZ_IP_ROWS": ("lmz_ip_rows",), "RDA_LMZ_IP_WARM": ("lmz_ip_warm",), "RDA_SU_PRE": ("su_pre",),
     "RDA_SU_LIGHT": ("su_light",), "RDA_SU_WARM_FIRST": ("su_warm_first",), "RDA_SU_EASY_NOPRED": ("su_easy_nopred",), "RDA_SU_COLD_FROM": ("su_cold_from", "su_cold_probe"),
     "RDA_SU_EASY": ("su_easy", "su_easy_max"), "RDA_SU_WARM_CLIP": ("su_warm_clip",), "RDA_SU_WARM_ENDGAME": ("su_warm_endgame",), "RDA_SU_WARM": ("su_warm", "su_warm_cap"),
     "RDA_ZERO_COPY": ("zero_copy",), "RDA_EARLY_FINISH": ("early_finish",), "RDA_FUSE_TRACK": ("fuse_track",), "RDA_SU_PROF": ("su_prof",), "RDA_SU_SPLIT": ("su_split",),
@@ -70,23 +70,32 @@ _ENV_SWITCHES = {
 
 
 def _apply_env(o):
+    """the RDA_* switches of the A/B tools, applied to an rda_opts.  Only `hip_options()` calls this: a handle created through the C API (rda_create) or from
+    a raw `Opts()` + rda_opts_init ignores the environment (the library itself reads none).  A value that is not a number is an error that NAMES the variable
+    (the C parser of round 4 ignored such values silently, int(float(v)) alone raised a bare ValueError at every RDA_solver construction)."""
     import os
     for name, fields in _ENV_SWITCHES.items():
         raw = os.environ.get(name)
         if not raw:
             continue
-        vals = [v for v in raw.split(",")]
+        vals = [v.strip() for v in raw.split(",")]
         for f in fields:                                   # an array field takes as many values as it has entries; what is not given stays
             cur = getattr(o, f)
             n = len(cur) if hasattr(cur, "__len__") else 1
             take, vals = vals[:n], vals[n:]
             for i, v in enumerate(take):
+                if v == "":                                # an empty list element: that entry keeps its default
+                    continue
+                try:
+                    x = float(v)
+                except ValueError:
+                    raise ValueError(f"environment switch {name}={raw!r}: {v!r} is not a number (rda_opts::{f}, include/rda_hip.h)") from None
                 if hasattr(cur, "__len__"):
-                    cur[i] = float(v)
+                    cur[i] = x
                 elif isinstance(cur, int):
-                    setattr(o, f, int(float(v)))
+                    setattr(o, f, int(x))
                 else:
-                    setattr(o, f, float(v))
+                    setattr(o, f, x)
     if o.su_cold_probe < 1:
         o.su_cold_probe = 1
 

@@ -43,6 +43,28 @@ def _history(api, s):
     return hist, keep
 
 
+def test_counted_history_accessors_serve_callers_of_other_header_versions(hip):
+    """`hist` grew from 2 to 4 ints in round 5 with no count in the signature.  The `_n` forms take the caller's own count: a round-4 caller
+    (2 ints) reads / writes its two entries and nothing past its buffer; a caller with MORE entries than this library has reads zeros for them."""
+    T, N = 12, 24
+    _, a = _solver(N, T)
+    rl = _obstacles(N)
+    for k in range(4):
+        a.iterative_solve(*_inputs(T, k), 4.0, list(rl))
+    full, _ = _history(hip, a)
+    two = np.full(4, -7, np.int32)
+    assert hip.get_su_history_n(a._be.handle, iptr(two), 2, None) == 0
+    assert np.array_equal(two[:2], full[:2]) and (two[2:] == -7).all()          # nothing written behind the caller's two ints
+    six = np.full(6, -7, np.int32)
+    assert hip.get_su_history_n(a._be.handle, iptr(six), 6, None) == 0
+    assert np.array_equal(six[:4], full) and (six[4:] == 0).all()
+    mod = np.array([3, 1], np.int32)
+    assert hip.set_su_history_n(a._be.handle, iptr(mod), 2, None) == 0            # the other two keys keep their values
+    after, _ = _history(hip, a)
+    assert np.array_equal(after[:2], mod) and np.array_equal(after[2:], full[2:])
+    assert hip.get_su_history_n(a._be.handle, iptr(two), -1, None) != 0
+
+
 def test_two_handles_with_the_same_state_and_history_return_the_same_controls(hip):
     T, N = 12, 24
     car_t, a = _solver(N, T)

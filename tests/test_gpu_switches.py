@@ -5,7 +5,6 @@ for bit: controls, states, residuals, iteration counts.
   RDA_LMZ_DENSE_FROM=0   every LamMuZ launch in the split form (common-path kernel + work-list kernel) instead of the fused kernel
   RDA_LMZ_SPLIT=0        (with DENSE_FROM=0) every launch as the fused two-workgroups-per-CU kernel
   RDA_SU_PRE=0           the su set-up evaluates all condensed terms itself (no block sums / near masks from the LamMuZ launch); rounding level since round 6
-  RDA_LMZ_TAIL=1         the early-stop verdict and the hand-over by the last-arriving LamMuZ workgroup, not by the next su launch / k_finish
   RDA_SU_LIGHT=0         convergence pass with the factorisation
   RDA_ZERO_COPY=0        result through a D2H copy + stream synchronise
   RDA_EARLY_FINISH=0     k_finish hands the result over, not the su launch that detects the early stop
@@ -18,8 +17,7 @@ from rda_planner_amd import scenarios as sc
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = [{"RDA_LMZ_DENSE_FROM": "0"}, {"RDA_LMZ_DENSE_FROM": "0", "RDA_LMZ_SPLIT": "0"}, {"RDA_SU_PRE": "0"}, {"RDA_SU_LIGHT": "0"}, {"RDA_LMZ_TAIL": "1"},
-            {"RDA_LMZ_TAIL": "1", "RDA_LMZ_DENSE_FROM": "0"},
+SWITCHES = [{"RDA_LMZ_DENSE_FROM": "0"}, {"RDA_LMZ_DENSE_FROM": "0", "RDA_LMZ_SPLIT": "0"}, {"RDA_SU_PRE": "0"}, {"RDA_SU_LIGHT": "0"},
             {"RDA_ZERO_COPY": "0"}, {"RDA_EARLY_FINISH": "0"}, {"RDA_FUSE_TRACK": "0"},
             {"RDA_ZERO_COPY": "0", "RDA_EARLY_FINISH": "0", "RDA_FUSE_TRACK": "0", "RDA_SU_PRE": "0", "RDA_LMZ_DENSE_FROM": "0"}]
 

@@ -585,6 +585,14 @@ def test_env_switches_are_applied_by_the_host_package_not_by_the_library(monkeyp
     assert list(o.su_warm) == [0.0, 0.0] and o.su_warm_cap == 0 and o.lmz_mode == 1 and o.lmz_mu == 1e-3
     assert list(o.su_easy) == [1e-6, 1e-6, 1e-6, 0.9, 1e-3] and o.su_easy_max == 3
     assert o.su_cold_from == 5 and o.su_cold_probe == 8           # second value not given: stays
+    #  an empty list element keeps the entry; a value that is not a number is an error that names the variable
+    monkeypatch.setenv("RDA_SU_EASY", "1e-5,,1e-4")
+    _apply_env(o)
+    assert list(o.su_easy)[:3] == [1e-5, 1e-6, 1e-4]
+    monkeypatch.setenv("RDA_LMZ_MODE", "yes")
+    with pytest.raises(ValueError, match="RDA_LMZ_MODE"):
+        _apply_env(o)
+    monkeypatch.delenv("RDA_LMZ_MODE")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib_src = "".join(open(os.path.join(root, "rda_planner_amd", "csrc", f)).read() for f in os.listdir(os.path.join(root, "rda_planner_amd", "csrc")) if f.endswith((".hip", ".h")))
     assert not re.search(r"\bgetenv\s*\(", lib_src), "librda_hip.so must not read the environment"
