@@ -687,6 +687,82 @@ static void chol_solve(const double *K, int n, double *rhs)
 /* Warm start of the su-problems of ADMM iterations >= 1 (same rule as csrc/su_device.h): lam_keep[mc] = the inequality multipliers
  * the last converged solve ended with (this function's own row order); warm != 0: the slacks of the start are floored at warm_wfl
  * and the multipliers are the larger of warm_mu0 / w and lam_keep; the warm attempt gets warm_cap iterations, then the cold rule. */
+/* ---- landing of a converged interior-point iterate on the vertex it approaches (round 6) ------------------------------------------
+ * The interior point stops ON the central path: a row that is only just active (multiplier lam* ~ 1e-7) still has the slack mu / lam*, so two
+ * iterations that stop at different mu hand back controls up to ~1e-4 apart (tests/test_oracle_su.py::test_stop_tolerance_vs_weakly_active_rows) - the
+ * reason for TOL_U.  The landing: freeze the active set A = {lam_i > w_i}, solve the equality-constrained quadratic model at x (the hinge terms'
+ * generalised Hessian at x) for x+, the multipliers nu of A come out of it; accept when x+ is feasible for the other rows, nu >= 0 and the TRUE
+ * gradient at x+ (hinge terms re-evaluated) is stationary; otherwise move rows in / out of A by their signs (primal-dual active set) and try again, a few
+ * rounds; no acceptance: the interior-point iterate is returned as before.  The model is solved by the method of multipliers on
+ * K = H + rho C_A' C_A (one Cholesky factor, a few solves: converges like (|H| / rho)^k), so no row of C_A has to be independent of the others. */
+static int g_su_land = 0; static double g_su_land_tol[3] = {1e-6, 1e-7, 1e-8};   /* = rda_opts::su_land, su_land_tol */
+static __thread int t_su_landed = 0, t_su_land_rounds = 0;
+static long g_pol_stat[8];       /* calls, accepted, rounds summed, last verdict: chol failed, set still moving, not stationary; rows moved */
+void orc_get_su_land_stats(long *out8) { for (int i = 0; i < 8; ++i) { out8[i] = g_pol_stat[i]; g_pol_stat[i] = 0; } }
+void orc_set_su_land(int on) { g_su_land = on; }
+void orc_set_su_land_tol(double rd, double rp, double mu) { if (rd > 0 && rp > 0 && mu > 0) { g_su_land_tol[0] = rd; g_su_land_tol[1] = rp; g_su_land_tol[2] = mu; } }
+int orc_get_su_landed(void) { return t_su_landed; }
+static int su_land(const su_ctx *S, const lincon *con, int mc, int n, double *x, double *lm, double *w, double *s, double *grad, double *Hm, double *K, double tol_rd)
+{
+    double *dx = malloc(sizeof(double) * n), *rhs = malloc(sizeof(double) * n), *nu = malloc(sizeof(double) * mc), *xn = malloc(sizeof(double) * n), *g2 = malloc(sizeof(double) * n);
+    char *act = malloc(mc);
+    int ok = 0, last = 0;
+    __sync_fetch_and_add(&g_pol_stat[0], 1);
+    for (int i = 0; i < mc; ++i) { act[i] = lm[i] > w[i]; nu[i] = act[i] ? lm[i] : 0.0; }
+    for (int round = 0; round < 4 && !ok; ++round) {
+        t_su_land_rounds = round + 1;
+        su_eval(S, x, s, grad, Hm);
+        double hmax = 0, gn = 0;
+        for (int i = 0; i < n; ++i) { if (Hm[i * n + i] > hmax) hmax = Hm[i * n + i]; if (fabs(grad[i]) > gn) gn = fabs(grad[i]); }
+        const double rho = 1e4 * (hmax > 1 ? hmax : 1.0), sc = 1 + gn;
+        memcpy(K, Hm, sizeof(double) * n * n);
+        for (int i = 0; i < mc; ++i) if (act[i]) {
+            int i1 = con[i].i1, i2 = con[i].i2;
+            K[i1 * n + i1] += rho * con[i].c1 * con[i].c1;
+            if (i2 >= 0) { K[i2 * n + i2] += rho * con[i].c2 * con[i].c2; K[i1 * n + i2] += rho * con[i].c1 * con[i].c2; K[i2 * n + i1] += rho * con[i].c1 * con[i].c2; }
+        }
+        if (chol_factor(K, n)) { last = 3; break; }
+        for (int k = 0; k < 6; ++k) {                       /* method of multipliers on the quadratic model: dx always measured from x */
+            for (int i = 0; i < n; ++i) rhs[i] = -grad[i];
+            for (int i = 0; i < mc; ++i) if (act[i]) {
+                double r = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0) - con[i].e, v = nu[i] + rho * r;
+                rhs[con[i].i1] -= con[i].c1 * v; if (con[i].i2 >= 0) rhs[con[i].i2] -= con[i].c2 * v;
+            }
+            memcpy(dx, rhs, sizeof(double) * n);
+            chol_solve(K, n, dx);
+            for (int i = 0; i < mc; ++i) if (act[i]) {
+                double r = con[i].c1 * (x[con[i].i1] + dx[con[i].i1]) + (con[i].i2 >= 0 ? con[i].c2 * (x[con[i].i2] + dx[con[i].i2]) : 0) - con[i].e;
+                nu[i] += rho * r;
+            }
+        }
+        for (int i = 0; i < n; ++i) xn[i] = x[i] + dx[i];
+        /* verdict on x+: feasibility of the rows outside A, signs of nu, stationarity of the TRUE objective */
+        int bad = 0;
+        su_eval(S, xn, s, g2, NULL);
+        for (int i = 0; i < mc; ++i) if (act[i]) { g2[con[i].i1] += con[i].c1 * nu[i]; if (con[i].i2 >= 0) g2[con[i].i2] += con[i].c2 * nu[i]; }
+        double rdn = 0; for (int i = 0; i < n; ++i) if (fabs(g2[i]) > rdn) rdn = fabs(g2[i]);
+        for (int i = 0; i < mc; ++i) {
+            double cx = con[i].c1 * xn[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * xn[con[i].i2] : 0);
+            if (act[i]) { if (nu[i] < -1e-9 * sc) { act[i] = 0; nu[i] = 0; bad = 1; __sync_fetch_and_add(&g_pol_stat[6], 1); } }
+            else if (cx > con[i].e + 1e-11 * (1 + fabs(con[i].e))) { act[i] = 1; nu[i] = 0; bad = 1; __sync_fetch_and_add(&g_pol_stat[6], 1); }
+        }
+        last = bad ? 4 : 5;
+        if (getenv("ORC_LAND_DEBUG")) fprintf(stderr, "landing round %d: bad %d rdn %.2e (tol %.2e) |dx| %.2e\n", round, bad, rdn, tol_rd * sc, fabs(dx[0]));
+        if (!bad && rdn <= 100 * tol_rd * sc) {
+            memcpy(x, xn, sizeof(double) * n);
+            for (int i = 0; i < mc; ++i) {
+                double cx = con[i].c1 * x[con[i].i1] + (con[i].i2 >= 0 ? con[i].c2 * x[con[i].i2] : 0);
+                if (act[i]) { lm[i] = nu[i] > 0 ? nu[i] : 0.0; w[i] = 0.0; } else { lm[i] = 0.0; w[i] = con[i].e - cx; }
+            }
+            ok = 1;
+        } else if (!bad) memcpy(x, xn, sizeof(double) * n), ok = 0, bad = 2;      /* same set, a hinge term switched: linearise again at x+ */
+        if (bad == 2) { /* x moved: the interior-point multipliers no longer belong to it, keep nu */ }
+    }
+    free(dx); free(rhs); free(nu); free(xn); free(g2); free(act);
+    __sync_fetch_and_add(&g_pol_stat[ok ? 1 : last], 1); __sync_fetch_and_add(&g_pol_stat[2], t_su_land_rounds);
+    return ok;
+}
+
 static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *nom_u, const double *ref_s,
                          double ref_speed, const double *a, const double *cc, const double *g,
                          const double *d0, double *s_out, double *u_out, double *d_out, int *ipm_iters,
@@ -744,6 +820,8 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
      * 1e-15 and the Cholesky factor breaks down (soak seed 9, scene 13, step 15; tests/golden/su_hard/omni_T25_N20_end_game_noise.npz:
      * the kernel's arithmetic converges in 16 iterations) - returns that iterate instead of "no update". */
     double *x_acc = malloc(sizeof(double) * n), *lm_acc = malloc(sizeof(double) * mc), acc_merit = INFINITY; int have_acc = 0;
+    double *x_sav = malloc(sizeof(double) * n), *lm_sav = malloc(sizeof(double) * mc), *w_sav = malloc(sizeof(double) * mc); int land_failed = 0;
+    t_su_landed = 0;
     /* Attempts: [-1 the warm start,] 0 the cold start, 1 the last resort.  The last one only runs when the others end without convergence
      * (the iteration cap, ~0.1% of closed-loop solves, where the iterates cycle): it restarts from the same nominal with a more central
      * point (slack floor 0.1, mu0 = 10) and - since round 5 - as a plain long-step path-following iteration (`safe` below). */
@@ -817,10 +895,21 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
 #ifdef ORC_DEBUG
         fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", it, rdn, rpn, mu, sc);
 #endif
-        if (rdn <= g_su_tol[0] * sc && rpn <= g_su_tol[1] && mu <= g_su_tol[2] * sc) { status = 0; break; }
-        /* past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
+        /* (second clause) past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
          * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
-        if (rdn <= 100 * g_su_tol[0] * sc && rpn <= g_su_tol[1] && mu <= 0.1 * g_su_tol[2] * sc) { status = 0; break; }
+#define SU_CONV(tol) ((rdn <= (tol)[0] * sc && rpn <= (tol)[1] && mu <= (tol)[2] * sc) || (rdn <= 100 * (tol)[0] * sc && rpn <= (tol)[1] && mu <= 0.1 * (tol)[2] * sc))
+        if (g_su_land && !land_failed) {
+            /* Landing (round 6, see su_land): the interior point only has to get close enough for the active set to be read off - su_land_tol, the class
+             * ECOS stops at - and the vertex is then computed exactly.  Refused (never seen on the recorded loops): the iteration goes on to su_tol. */
+            if (SU_CONV(g_su_land_tol)) {
+                memcpy(x_sav, x, sizeof(double) * n); memcpy(lm_sav, lm, sizeof(double) * mc); memcpy(w_sav, w, sizeof(double) * mc);
+                if (su_land(&S, con, mc, n, x, lm, w, s, grad, Hm, K, g_su_tol[0])) { t_su_landed = 1; status = 0; break; }
+                memcpy(x, x_sav, sizeof(double) * n); memcpy(lm, lm_sav, sizeof(double) * mc); memcpy(w, w_sav, sizeof(double) * mc);
+                land_failed = 1;
+                su_eval(&S, x, s, grad, Hm);
+            }
+        }
+        if ((!g_su_land || land_failed) && SU_CONV(g_su_tol)) { status = 0; break; }
         if (g_su_accept && rpn <= g_su_tol[1] && rdn <= 10 * g_su_tol[0] * sc && mu <= 1e3 * g_su_tol[2] * sc) {
             const double merit = fmax(rdn / (g_su_tol[0] * sc), mu / (g_su_tol[2] * sc));
             if (!have_acc || merit < acc_merit) { memcpy(x_acc, x, sizeof(double) * n); memcpy(lm_acc, lm, sizeof(double) * mc); have_acc = 1; acc_merit = merit; }
@@ -922,7 +1011,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
     memcpy(s_out, s, sizeof(double) * 3 * (T + 1));
     for (int t = 0; t < T; ++t) { u_out[t] = x[2 * t]; u_out[T + t] = x[2 * t + 1]; d_out[t] = x[2 * T + t]; }
     free(S.Ak); free(S.Bk); free(S.Ck); free(S.Gam); free(S.Q0); free(S.Q1); free(S.Q2);
-    free(con); free(x); free(grad); free(Hm); free(K); free(rhs); free(dx); free(w); free(lm); free(rp); free(dw); free(dl); free(rc); free(s); free(x_acc); free(lm_acc);
+    free(con); free(x); free(grad); free(Hm); free(K); free(rhs); free(dx); free(w); free(lm); free(rp); free(dw); free(dl); free(rc); free(s); free(x_acc); free(lm_acc); free(x_sav); free(lm_sav); free(w_sav);
     return status;
 }
 
