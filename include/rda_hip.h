@@ -151,6 +151,17 @@ typedef struct rda_opts {
     double  su_easy[5];      /* [1e-12, 1e-12, 1e-12, 0.999999, 1e-7] wfl, mu0, clip, tau, sigma of the easy start: the first three lie
                                 BELOW the stop tolerances, i.e. the easy start is the previous solution itself and the stop test may
                                 accept it without a Newton step when the new problem's optimality conditions hold there  RDA_SU_EASY */
+    int32_t su_land;         /* [0] LANDING of the su interior point (round 6; oracle mirror orc_set_su_land): 1 = the interior point runs to
+                                su_land_tol only - close enough for the active set to be read off (lam > w) - and the vertex it approaches is
+                                computed exactly: active rows as equalities, the others dropped, the equality-constrained quadratic model solved
+                                with the same factorisation and sweeps (two steps of the method of multipliers = the two passes of an iteration),
+                                verified on the true objective, rows moved in / out by their signs for at most 4 rounds; refused -> the iterate
+                                is restored and the iteration goes on to su_tol as without the switch.  The answer no longer depends on WHERE on
+                                the central path the iteration stopped (the reason for the stated tolerance of 5e-4: a row that is only just
+                                active keeps the slack mu / lam*): kernel and cold oracle agree to 1e-9 with it (tests/test_gpu_land.py).
+                                Costs one factorisation + a verification pass per solve, saves the last interior-point iteration.  RDA_SU_LAND */
+    double  su_land_tol[3];  /* [1e-6, 1e-7, 1e-8] stop of the interior point when it is landed (the class ECOS stops at)  RDA_SU_LAND_TOL */
+    double  su_land_rho;     /* [1e6] penalty of the landing's active rows, relative to the largest entry of the stage Hessians  RDA_SU_LAND_RHO */
 } rda_opts;
 void rda_opts_init(rda_opts *o);
 
@@ -327,6 +338,7 @@ int  rda_set_lmz_history(rda_handle *h, const double *points, const int32_t *val
 int  rda_debug_su_prof(rda_handle *h, long long *out16);
 /* -DSU_TRACE builds only (RDA_ERR_UNSUPPORTED otherwise): per-wave (event id, clock64) pairs of the LAST su launch, out[4][cap][2] (tools/su_trace.py) */
 int  rda_debug_su_trace(rda_handle *h, long long *out, int cap, int *n_out);
+int  rda_debug_su_land(rda_handle *h, int32_t *out4);      /* su_land: landings accepted, refused, rounds, passes spent on landings since the last call */
 int  rda_debug_flush_supports(rda_handle *h);             /* forget every remembered LamMuZ support (a cache: results must not depend on it) */
 int  rda_debug_slot_src(rda_handle *h, int32_t *src /*N*/, int32_t *used); /* slot -> entry of the caller's raw scene (device pipeline; used = 0: host-staged slots) */
 int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ work list of the last executed iteration (split launch form) */

@@ -49,6 +49,7 @@ struct Ctrl {
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
     double rd0_tmp;               // ... that residual, written by the solve
+    int land_stat[4];             // su_land: landings accepted, refused, rounds, passes spent on landings (rda_debug_su_land)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -78,6 +79,7 @@ struct Dev {
     int su_split;                        // su_device Args::split (time split of the Newton system)
     int su_accept;                       // su_device Args::accept (safety net: the best near-converged iterate)
     int su_first_attempt;                // su_device Args::first_attempt (test switch)
+    int su_land; double su_land_tol[3], su_land_rho;  // su_device Args::land (rda_opts::su_land)
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
@@ -263,6 +265,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept; a.first_attempt = d.su_first_attempt;
+    a.land = d.su_land; a.land_tol[0] = d.su_land_tol[0]; a.land_tol[1] = d.su_land_tol[1]; a.land_tol[2] = d.su_land_tol[2]; a.land_stat = d.ctrl->land_stat; a.land_rho = d.su_land_rho;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
     if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
     if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
@@ -1290,6 +1293,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1; o->su_first_attempt = 0;
+    o->su_land = 0; o->su_land_tol[0] = 1e-6; o->su_land_tol[1] = 1e-7; o->su_land_tol[2] = 1e-8; o->su_land_rho = 1e6;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1364,6 +1368,8 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_pre = o.su_pre;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept; H->d.su_first_attempt = o.su_first_attempt;
+    H->d.su_land = o.su_land ? 1 : 0; H->d.su_land_rho = o.su_land_rho > 0 ? o.su_land_rho : 1e6;
+    { const bool ok = o.su_land_tol[0] > 0 && o.su_land_tol[1] > 0 && o.su_land_tol[2] > 0; const double dflt[3] = {1e-6, 1e-7, 1e-8}; for (int i = 0; i < 3; ++i) H->d.su_land_tol[i] = ok ? o.su_land_tol[i] : dflt[i]; }
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     { const bool on = o.su_tol_early[0] > 0 && o.su_tol_early[1] > 0 && o.su_tol_early[2] > 0; for (int i = 0; i < 3; ++i) H->d.su_tol_early[i] = on ? o.su_tol_early[i] : 0.0; }
@@ -1551,6 +1557,15 @@ extern "C" int rda_debug_su_prof(rda_handle *H, long long *out16)
     HIPCHK(hipStreamSynchronize(H->stream));
     HIPCHK(hipMemcpy(out16, H->d.su_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(H->d.su_prof, 0, 16 * sizeof(long long)));
+    return RDA_OK;
+}
+
+extern "C" int rda_debug_su_land(rda_handle *H, int32_t *out4)
+{
+    if (!H || !out4) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(out4, H->d.ctrl->land_stat, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(H->d.ctrl->land_stat, 0, 4 * sizeof(int)));
     return RDA_OK;
 }
 
@@ -2975,6 +2990,8 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
     if (opts) od = *opts;
     ar.c.eps_u = cfg->eps_u; ar.c.tol_rd = od.su_tol[0] > 0 ? od.su_tol[0] : 1e-9; ar.c.tol_rp = od.su_tol[1] > 0 ? od.su_tol[1] : 1e-10; ar.c.tol_mu = od.su_tol[2] > 0 ? od.su_tol[2] : 1e-11;    // (same fallback as rda_create_opts)
     ar.split = od.su_split; ar.accept = od.su_accept; ar.first_attempt = od.su_first_attempt;
+    ar.land = od.su_land ? 1 : 0; if (od.su_land_rho > 0) ar.land_rho = od.su_land_rho;
+    if (od.su_land_tol[0] > 0 && od.su_land_tol[1] > 0 && od.su_land_tol[2] > 0) { ar.land_tol[0] = od.su_land_tol[0]; ar.land_tol[1] = od.su_land_tol[1]; ar.land_tol[2] = od.su_land_tol[2]; }
     ar.in_s = dns; ar.in_u = dnu; ar.ref = dref; ar.ref_speed = dspeed;
     ar.ax = dsoa; ar.ay = dsoa + T * N; ar.cb = dsoa + 2 * T * N; ar.gx = dsoa + 4 * T * N; ar.gy = dsoa + 5 * T * N;
     ar.P = 1; ar.Nloc = (int)N; ar.chunk = 0;
@@ -2983,7 +3000,11 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
     if (od.su_prof) { HIPCHK(hipMalloc((void **)&dprof, su::PROF_WORDS * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, su::PROF_WORDS * sizeof(long long))); }
     ar.prof = dprof;
     double *ddbg = nullptr;
-    if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }      // (su_prof = 2: one stderr line per interior-point iteration)
+#ifdef SU_LAND_DEBUG
+    if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 6000 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 6000 * sizeof(double))); }
+#else
+    if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }
+#endif      // (su_prof = 2: one stderr line per interior-point iteration)
     ar.dbg = ddbg;
     const size_t lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_hook<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
@@ -2996,6 +3017,32 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
         double hd[400]; HIPCHK(hipMemcpy(hd, ddbg, sizeof(hd), hipMemcpyDeviceToHost));
         for (int i = 0; i < 100 && (i == 0 || hd[4 * i + 3] != 0); ++i)
             fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", i, hd[4 * i], hd[4 * i + 1], hd[4 * i + 2], hd[4 * i + 3]);
+#ifdef SU_LAND_DEBUG
+        {
+            static double hl[2400]; HIPCHK(hipMemcpy(hl, ddbg + 400, sizeof(hl), hipMemcpyDeviceToHost));
+            for (int r = 0; r < 2; ++r) for (int o = 0; o < 5 * (int)T && o < 190; ++o) {
+                const double *q = hl + r * 1200 + 6 * o;
+                if (q[4] != 0 || q[5] != 0 || q[0] < 0 || q[1] < 0 || (r == 0 && (o % 5 == 4 || o % 5 == 3)))
+                    fprintf(stderr, "  round %d pair t=%d k=%d: w+ %.3e w- %.3e nu+ %.3e nu- %.3e act %d %d\n", r, o / 5, o % 5, q[0], q[1], q[2], q[3], (int)q[4], (int)q[5]);       /* round 1 = the interior-point iterate the landing starts from, round 2 = after its first round */
+            }
+        }
+#endif
+#ifdef SU_LAND_DEBUG
+        {
+            static double hl[2400]; HIPCHK(hipMemcpy(hl, ddbg + 400, sizeof(hl), hipMemcpyDeviceToHost));
+            fprintf(stderr, "  rho %.3e\n", hl[600 + 300]);
+            if (T <= 16 && getenv("SU_LAND_DUMP")) {
+                static double big[6000]; HIPCHK(hipMemcpy(big, ddbg, sizeof(big), hipMemcpyDeviceToHost));
+                static int ncase = 0; char nm[256]; snprintf(nm, sizeof nm, "%s_%d.bin", getenv("SU_LAND_DUMP"), ncase++);
+                FILE *f = fopen(nm, "wb"); if (f) { double hd = (double)T; fwrite(&hd, 8, 1, f); fwrite(big, 8, 6000, f); fclose(f); }
+            }
+            for (int o = 0; o < 5 * (int)T && o < 100; ++o) if (hl[600 + o] != 0 || hl[700 + o] != 0) fprintf(stderr, "  start pair t=%d k=%d: bw %.3e xd %.3e cy %.3e\n", o / 5, o % 5, hl[600 + o], hl[700 + o], hl[800 + o]);
+            for (int ps = 0; ps < 2; ++ps) for (int t = 0; t < (int)T && 8 * t + 7 < 150; ++t) {
+                const double *y = hl + 1800 + 300 * ps + 8 * t, *v = hl + 1800 + 300 * ps + 150 + 8 * t;
+                fprintf(stderr, "  pass %d stage %d: dx %.2e %.2e %.2e %.2e %.2e  du %.2e %.2e dd %.2e\n", ps, t, y[0], y[1], y[2], y[3], y[4], v[3], v[4], v[5]);
+            }
+        }
+#endif
         dev_free(ddbg);
     }
     if (dprof) {

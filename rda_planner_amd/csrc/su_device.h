@@ -139,6 +139,16 @@ struct Args {
     // 10 x tol_rd and complementary to 1000 x tol_mu is remembered (controls, distances, multipliers: Lds::acc) and returned when every attempt fails
     int accept = 1;                  // (2: test switch, see the end of solve)
     int first_attempt = 0;           // test switch (rda_opts::su_first_attempt): 1 = start with the last-resort attempt
+    // LANDING (round 6, rda_opts::su_land; = oracle/rda_oracle.c su_land): the interior point runs to land_tol only - close enough for the active set to be
+    // read off its multipliers and slacks - and the vertex it approaches is then computed exactly: active rows (lam > w) become equalities, the others are
+    // dropped, the equality-constrained quadratic model at the iterate is solved with the SAME factorisation and sweeps (weights rho on the active rows, the
+    // two passes of an iteration = two steps of the method of multipliers), the result is verified on the true objective (a light pass: stationarity with
+    // the hinge terms re-evaluated, feasibility of the dropped rows, signs of the multipliers); rows move in / out by those signs and the round is repeated
+    // (at most 4); refused: the interior-point iterate is restored and the iteration goes on to tol_rd / tol_rp / tol_mu as without the switch.
+    // Why: the interior point stops ON the central path, a row that is only just active keeps the slack mu / lam*, and two iterations that stop at different
+    // mu differ by up to 1e-4 in the controls (TOL_U); the vertex does not depend on the path (tools/experiments/su_land_oracle.py: 1e-5 -> 1e-13).
+    int land = 0; double land_tol[3] = {1e-6, 1e-7, 1e-8}; double land_rho = 1e6;      // (land_rho: penalty of the active rows relative to the largest stage-Hessian entry)
+    int *land_stat = nullptr;        // optional [4]: landings accepted, refused, rounds, interior-point iterations that were landing / verification passes
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
@@ -229,6 +239,7 @@ struct Lds {
     double *p0;                            // [2][T] reference positions of the hinge screening
     double *uk, *ub, *xs;                  // time split (split_point(T) > 0): unit backward sweeps [5][8 m], their F_v' p [5][m][2], interface block [96]
     double *acc;                           // [13 T] safety net: u (2T) | d (T) | multipliers of the pairs [T][10]
+    double *hmx, *sav, *base;              // [T] largest diagonal entry of the stage's derivative block (scale of the landing's penalty); [3 T] u | d of the iterate a landing started from; [3 T] ... of the point its current round linearises at
     double *near; int *ncnt, *sto;   // near list of the hinge screening: [near_cap][4] = (ax, ay, cb, stage) of the terms that may be active, stage-major and compact; [NT] per-thread counts; [T+1] first entry of a stage
     __device__ void carve(double *b, int T) {
         double *p = b;
@@ -244,6 +255,7 @@ struct Lds {
         const int m = split_point(T);
         uk = p; p += 40 * m; ub = p; p += 10 * m; xs = p; p += m ? 96 : 0;
         acc = p; p += ev(13 * T);
+        hmx = p; p += ev(T); sav = p; p += ev(3 * T); base = p; p += ev(3 * T);
         near = p; p += 4 * near_cap(T); ncnt = (int *)p; p += NT / 2; sto = (int *)p; p += ev(T + 2) / 2 + 1;
     }
 };
@@ -252,7 +264,7 @@ constexpr size_t lds_bytes(int T)
     size_t n = (size_t)2 * ev(3 * (T + 1)) + 2 * T + 2 * ev(T) + ev(9 * T) + 6 * T + ev(3 * T) + 2 * T + 2 * ev(T)
              + FT * T + ev(9 * T) + 16 * T + 4 * T + 2 * ev(5 * T) + 8 * T + ev(3 * T) + (HB * T > 9 * NT ? HB * T : 9 * NT)
              + WN * T + 16 * T + 3 * ev(5 * T) + 8 * T + 8 * T + 8 + NT + 32 + 2 * T + 50 * split_point(T) + (split_point(T) ? 96 : 0)
-             + ev(13 * T) + 4 * near_cap(T) + NT / 2 + ev(T + 2) / 2 + 1;
+             + ev(13 * T) + ev(T) + 2 * ev(3 * T) + 4 * near_cap(T) + NT / 2 + ev(T + 2) / 2 + 1;
     return n * sizeof(double);
 }
 // every horizon the interface accepts (RDA_TMAX = 64) must fit the 160 KB a workgroup can have (round 5: T = 36 .. 40 did not for a while - the near
@@ -627,6 +639,53 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     L.lw[o] = Prcp[j] + Prcm[j];
                     L.ra[o] = fmax(fabs(Prpp[j]), fabs(Prpm[j]));
                 } else { L.bw[o] = 0; L.cy[o] = 0; L.xd[o] = 0; L.lw[o] = 0; L.ra[o] = 0; }
+            }
+        }
+    };
+    // ---- landing (Args::land): state of the pairs - which of the two rows is active, the iterate the landing started from (slacks / multipliers in
+    //      registers, controls / distances in L.sav) - and what the stage phases read of them while a landing round runs
+    bool Lap[NPR], Lam[NPR];
+    double Swp[NPR], Swm[NPR], Slp[NPR], Slm[NPR];
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) { Lap[j] = Lam[j] = false; Swp[j] = Swm[j] = 1.0; Slp[j] = Slm[j] = 0.0; }
+    // rows of a landing round at the current point x: r+ = c'x - e+, r- = -c'x - e- (kept in Prpp / Prpm), multiplier estimates nu in Plp / Plm;
+    // barrier weight -> penalty rho on the active rows, lam+ - lam- -> nu+ - nu-, x+ - x- -> rho (r+ - r-) over the active rows
+    auto land_rows = [&](const double rho) {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            if (p_ok[j]) {
+                const int o = 5 * p_t[j] + p_k[j];
+                if (p_on[j]) {
+                    const double cv = pair_val(p_t[j], p_k[j]);
+                    Prpp[j] = cv - p_ep[j]; Prpm[j] = -cv - p_em[j];
+                    if (!Lap[j]) Plp[j] = 0.0;
+                    if (!Lam[j]) Plm[j] = 0.0;
+                    L.bw[o] = rho * ((Lap[j] ? 1.0 : 0.0) + (Lam[j] ? 1.0 : 0.0));
+                    L.cy[o] = Plp[j] - Plm[j];
+                    L.xd[o] = rho * ((Lap[j] ? Prpp[j] : 0.0) - (Lam[j] ? Prpm[j] : 0.0));
+                } else { L.bw[o] = 0; L.cy[o] = 0; L.xd[o] = 0; }
+                L.lw[o] = 0; L.ra[o] = 0;
+            }
+        }
+    };
+    // ... and of the verification pass behind it, at x+ (slacks w = e - c'x+ in Pwp / Pwm, multipliers nu in Plp / Plm): lam+ - lam- for the stage
+    // gradients; "primal residual" -> the largest violation (a dropped row that is violated, an active row off its bound), relative to 1 + |e|;
+    // "complementarity" -> the negative parts of the multipliers
+    auto verify_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            if (p_ok[j]) {
+                const int o = 5 * p_t[j] + p_k[j];
+                if (p_on[j]) {
+                    // (an active row sits on its bound to (nu* - nu_2) / rho after the two steps of the method of multipliers: held to 1e-9, a hundred times
+                    // the threshold of a dropped row's violation, by the factor)
+                    const double vp = (Lap[j] ? 1e-2 * fabs(Pwp[j]) : fmax(-Pwp[j], 0.0)) / (1.0 + fabs(p_ep[j]));
+                    const double vm = (Lam[j] ? 1e-2 * fabs(Pwm[j]) : fmax(-Pwm[j], 0.0)) / (1.0 + fabs(p_em[j]));
+                    L.cy[o] = Plp[j] - Plm[j];
+                    L.ra[o] = fmax(vp, vm);
+                    L.lw[o] = fmax(-Plp[j], 0.0) + fmax(-Plm[j], 0.0);
+                } else { L.cy[o] = 0; L.ra[o] = 0; L.lw[o] = 0; }
+                L.bw[o] = 0; L.xd[o] = 0;
             }
         }
     };
@@ -1174,6 +1233,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     for (int attempt = a.first_attempt ? 1 : (warm ? -1 : 0); attempt < 2 && status != 0; ++attempt) {
     const bool safe = attempt == 1;                // (uniform) the last-resort iteration, see SU_SAFE_*
     double al_prev = 0.0;
+    int land = 0, land_rounds = 0, land_its = 0;   // (uniform) 0: interior point; 1: this pass is a landing round; 2: this pass verifies one; passes spent on landings
+    bool land_failed = false;
+    double land_rho = 0.0;
+    bool expect_conv = false;
+    // a landing is refused: back to the interior-point iterate it started from, and on to the tight tolerances (all threads; ends with a barrier)
+    auto land_refuse = [&]() {
+        __syncthreads();
+        for (int i = tid; i < 2 * T; i += NT) L.u[i] = L.sav[i];
+        for (int i = tid; i < T; i += NT) L.d[i] = L.sav[2 * T + i];
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) { Pwp[j] = Swp[j]; Pwm[j] = Swm[j]; Plp[j] = Slp[j]; Plm[j] = Slm[j]; }
+        __syncthreads();
+        rollout();
+        __syncthreads();
+        if (a.land_stat && tid == 0) a.land_stat[1] += 1;
+        land = 0; land_failed = true; expect_conv = false;
+        pair_rows();
+        __syncthreads();
+    };
     if (attempt == 1 || (attempt == 0 && warm)) {
         __syncthreads();
         clip_controls(0.01);
@@ -1188,12 +1266,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     __syncthreads();
     const int it_cap = attempt < 0 ? a.warm_cap : (attempt == 0 ? SU_COLD_CAP : 100);       // (the cold attempt: 50 since round 5, see the oracle)
     const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
-    bool expect_conv = false;
     double mu_prev = 1.0;
-    for (it = 0; it < it_cap; ++it) {
+    for (it = 0; it < it_cap || land != 0; ++it) {
         TR(1);
         seq += 1;
-        const double heps = (attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;
+        if (land != 0) land_its += 1;
+        const double heps = (land == 0 && attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;      // (a landing works on the true hinge terms)
         // (rescue phase: the smoothed hinge is non-zero for EVERY term - the oracle sums them all, so does this pass; such iterations are rare)
         const bool screened_now = screened && !(heps > 0);
         // ---- (1)-(3) ONE phase, no barrier inside (round 6; rounds 1-5: hinge contributions | barrier | stage sums | barrier | stage derivatives and
@@ -1331,7 +1409,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 Hs00 += c.ro1 * h[0]; Hs01 += c.ro1 * h[1]; Hs11 += c.ro1 * h[2];
                 h00 = Hs00; h01 = Hs01; hd0 = -c.ro1 * h[3]; h11 = Hs11; hd1 = -c.ro1 * h[4]; h22 = Hs22; hdd = c.ro1 * h[5];
                 gw0 = gs0; gw1 = gs1; gw2 = gs2; gw3 = -c.ro1 * h[8] - c.slack_gain;
-                if (act && r == 0) { double *gw = &L.gw[4 * t]; gw[0] = gw0; gw[1] = gw1; gw[2] = gw2; gw[3] = gw3; }      // (termination measure |g|_inf: wave 3, phase 4)
+                if (act && r == 0) {       // (termination measure |g|_inf, scale of the landing's penalty: wave 3, phase 4)
+                    double *gw = &L.gw[4 * t]; gw[0] = gw0; gw[1] = gw1; gw[2] = gw2; gw[3] = gw3;
+                    L.hmx[t] = fmax(fmax(h00, h11), fmax(h22, hdd));
+                }
             }
             MF(14); TR(5);
             // ---- (3) stage gradient entry r and row r of the stage Hessian base  J' Hw J + direct + barrier ;  J = d(s_next, d)/dy: rows 0..2 = rows 0..2 of F, row 3 = e_7
@@ -1382,6 +1463,15 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         TR(7);
         __syncthreads();
         mark(2); TR(8);
+#ifdef SU_LAND_DEBUG
+        if (a.dbg && land == 1 && land_rounds == 1 && T <= 16) {      // the whole Newton system of the round: Hb | Ft | gst | xd | m7 per stage
+            double *q = a.dbg + 2800;
+            for (int i = tid; i < 64 * T; i += NT) q[i] = L.Hb[HB * (i / 64) + (i & 63)];
+            for (int i = tid; i < 48 * T; i += NT) q[64 * T + i] = L.Ft[FT * (i / 48) + (i % 48)];
+            for (int i = tid; i < 8 * T; i += NT) { q[112 * T + i] = L.gst[i]; q[120 * T + i] = L.m7[i]; }
+            for (int i = tid; i < 5 * T; i += NT) q[128 * T + i] = L.xd[i];
+        }
+#endif
         // ---- (4) waves 0 / 1: Riccati matrix recursion of the stages [msp, T) / [0, msp) (time split; msp = 0: wave 0 takes them all);
         //          wave 2: adjoint sweep for the reduced gradient + early verdict; wave 3: the other termination measures ------------
         bool fail = false;
@@ -1420,17 +1510,22 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             {
                 const double gn_ = *(volatile double *)&L.red[9], rpn_ = *(volatile double *)&L.red[10];
                 const double mu_ = *(volatile double *)&L.red[11] / mcnt, sc_ = 1 + gn_;
-                if ((rd <= c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= c.tol_mu * sc_) || (rd <= 100 * c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= 0.1 * c.tol_mu * sc_))
+                // (not in a landing round: its rows carry no residual / complementarity, the "measures" of that pass would always pass - and the round NEEDS its
+                // factorisation: an abandoned recursion left the stale factors of the last interior-point iteration in place, found with a dense solve of the
+                // dumped Newton system, scratch of round 6)
+                if (land != 1 && ((rd <= c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= c.tol_mu * sc_) || (rd <= 100 * c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= 0.1 * c.tol_mu * sc_)))
                     if (lane == 0) __atomic_store_n(flag_stop, seq, __ATOMIC_RELAXED);
             }
         } else {
             // termination measures that do not depend on the sweeps
-            double g = 0, rp_ = 0, m_ = 0;
+            double g = 0, rp_ = 0, m_ = 0, hm_ = 0;
+            for (int i = lane; i < T; i += 64) hm_ = fmax(hm_, L.hmx[i]);
+            hm_ = wave_allreduce(hm_, true);
             for (int i = lane; i < 4 * T; i += 64) { double v = fabs(L.gw[i]); if (v > g) g = v; }
             for (int i = lane; i < 5 * T; i += 64) { double v = L.ra[i]; if (v > rp_) rp_ = v; m_ += L.lw[i]; }
             g = wave_allreduce(g, true); rp_ = wave_allreduce(rp_, true); m_ = wave_allreduce(m_, false);
             if (lane == 0) {
-                L.red[9] = g; L.red[10] = rp_; L.red[11] = m_;
+                L.red[9] = g; L.red[10] = rp_; L.red[11] = m_; L.pv[5] = hm_;
                 __atomic_store_n(flag_meas, seq, __ATOMIC_RELEASE);
             }
         }
@@ -1442,7 +1537,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         // The first iteration of an easy-mode warm attempt skips the predictor (a.warm_nopred): next to the solution the affine step
         // is a full step, so sigma ends at its floor anyway and the second-order term dl*dw is O(error^2) - one sweep pair instead of
         // two.  Should that iteration not finish the solve, the following ones are ordinary predictor-corrector iterations.
-        const bool nopred = (attempt < 0 && a.warm_nopred != 0 && it == 0) || safe;
+        const bool nopred = land != 1 && ((attempt < 0 && a.warm_nopred != 0 && it == 0) || safe);      // (a landing round always runs both passes)
         // ---- (4b) closed-loop sweep matrices from W, Minv (all threads; Mb overwrites the consumed Hb,
         //           Mf overwrites the consumed hs..cy) --------------------------------------------------------------
         if (!expect_conv)
@@ -1479,12 +1574,58 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
         if (a.rd0 && used == 0 && it == 0 && tid == 0) *a.rd0 = rdn / sc;
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
-        const bool conv_now = (rdn <= c.tol_rd * sc && rpn <= c.tol_rp && mu <= c.tol_mu * sc) || (rdn <= 100 * c.tol_rd * sc && rpn <= c.tol_rp && mu <= 0.1 * c.tol_mu * sc);
+        const bool landing = a.land != 0 && !land_failed;          // (uniform) the interior point stops at land_tol and is landed
+        const double t_rd = landing ? a.land_tol[0] : c.tol_rd, t_rp = landing ? a.land_tol[1] : c.tol_rp, t_mu = landing ? a.land_tol[2] : c.tol_mu;
+        const bool conv_now = land == 0 && ((rdn <= t_rd * sc && rpn <= t_rp && mu <= t_mu * sc) || (rdn <= 100 * t_rd * sc && rpn <= t_rp && mu <= 0.1 * t_mu * sc));
+        if (land == 2) {
+            // ---- verdict on a landing round (this pass measured x+ with the hinge terms re-evaluated: rdn = stationarity, rpn = largest violation relative to
+            //      1 + |e|, mu mcnt = sum of the negative parts of the multipliers; same thresholds as the oracle's su_land)
+            if (a.land_stat && tid == 0) a.land_stat[2] += 1;
+            const bool moved = rpn > 1e-11 || mu * mcnt > 1e-9 * sc;
+#ifdef SU_LAND_DEBUG
+            if (a.dbg && land_rounds <= 1) {
+                double *q = a.dbg + 400 + 1200;
+#pragma unroll
+                for (int j = 0; j < NPR; ++j) if (p_ok[j]) { const int o = 5 * p_t[j] + p_k[j]; if (o < 190) { q[6 * o] = Pwp[j]; q[6 * o + 1] = Pwm[j]; q[6 * o + 2] = Plp[j]; q[6 * o + 3] = Plm[j]; q[6 * o + 4] = Lap[j]; q[6 * o + 5] = Lam[j]; } }
+            }
+#endif
+            if (!moved && rdn <= 100 * c.tol_rd * sc) {                      // landed
+#pragma unroll
+                for (int j = 0; j < NPR; ++j) if (p_on[j]) { Plp[j] = fmax(Plp[j], 0.0); Plm[j] = fmax(Plm[j], 0.0); }
+                if (a.land_stat && tid == 0) a.land_stat[0] += 1;
+                status = 0; break;
+            }
+            if (land_rounds >= 4 || !(rdn == rdn)) { land_refuse(); continue; }      // refused
+            // next round: rows move in / out of the active set by their signs (primal-dual active set) and the model is solved again from the SAME point -
+            // a full step along a weakly curved direction may have left the boxes by far, x+ is then no place to linearise the hinge terms at; a round whose
+            // set did not move was not stationary because a hinge term switched: that one is linearised again at x+ (= the oracle's su_land)
+#pragma unroll
+            for (int j = 0; j < NPR; ++j)
+                if (p_on[j]) {
+                    if (Lap[j] && Plp[j] < -1e-9 * sc) { Lap[j] = false; Plp[j] = 0.0; } else if (!Lap[j] && Pwp[j] < -1e-11 * (1.0 + fabs(p_ep[j]))) { Lap[j] = true; Plp[j] = 0.0; }
+                    if (Lam[j] && Plm[j] < -1e-9 * sc) { Lam[j] = false; Plm[j] = 0.0; } else if (!Lam[j] && Pwm[j] < -1e-11 * (1.0 + fabs(p_em[j]))) { Lam[j] = true; Plm[j] = 0.0; }
+                }
+            land = 1; land_rounds += 1; expect_conv = false;
+            __syncthreads();
+            if (moved) {
+                for (int i = tid; i < 2 * T; i += NT) L.u[i] = L.base[i];
+                for (int i = tid; i < T; i += NT) L.d[i] = L.base[2 * T + i];
+                __syncthreads();
+                rollout();
+                __syncthreads();
+            } else {
+                for (int i = tid; i < 2 * T; i += NT) L.base[i] = L.u[i];
+                for (int i = tid; i < T; i += NT) L.base[2 * T + i] = L.d[i];
+            }
+            land_rows(land_rho);
+            __syncthreads();
+            continue;
+        }
         // (may a remembered iterate have ignored hinge terms outside the near list?  No: the measures tested here were formed by THIS pass's stage
         // phase, which sums the near list only while `screened` holds - and `screened` is dropped by the reach check right behind every update (and by the
         // set-up for the nominal) as soon as a stage has left the DELTA ball; from then on every pass sums every term.  So an iterate that passes this test
         // was measured on a term set that contains every term that can be active at it - the same argument as for the converged iterate.)
-        if (a.accept && !conv_now && rpn <= c.tol_rp && rdn <= 10 * c.tol_rd * sc && mu <= 1e3 * c.tol_mu * sc) {     // (uniform) safety net: see Args::accept
+        if (a.accept && land == 0 && !conv_now && rpn <= c.tol_rp && rdn <= 10 * c.tol_rd * sc && mu <= 1e3 * c.tol_mu * sc) {     // (uniform) safety net: see Args::accept
             const double merit = fmax(rdn / (c.tol_rd * sc), mu / (c.tol_mu * sc));
             if (!have_acc || merit < acc_merit) {
                 have_acc = true; acc_merit = merit;
@@ -1508,12 +1649,39 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     continue;
                 }
             }
+            if (landing) {
+                // ---- start of the landing: remember the iterate, read the active set off it (lam > w), first round
+                for (int i = tid; i < 2 * T; i += NT) { L.sav[i] = L.u[i]; L.base[i] = L.u[i]; }
+                for (int i = tid; i < T; i += NT) { L.sav[2 * T + i] = L.d[i]; L.base[2 * T + i] = L.d[i]; }
+#pragma unroll
+                for (int j = 0; j < NPR; ++j) {
+                    Swp[j] = Pwp[j]; Swm[j] = Pwm[j]; Slp[j] = Plp[j]; Slm[j] = Plm[j];
+                    Lap[j] = p_on[j] && Plp[j] > Pwp[j]; Lam[j] = p_on[j] && Plm[j] > Pwm[j];
+                }
+                land_rho = a.land_rho * fmax(1.0, fmax(L.pv[5], 2 * c.wu + c.eps_u));
+#ifdef SU_LAND_DEBUG
+                if (a.dbg) {
+                    double *q = a.dbg + 400;
+#pragma unroll
+                    for (int j = 0; j < NPR; ++j) if (p_ok[j]) { const int o = 5 * p_t[j] + p_k[j]; if (o < 190) { q[6 * o] = Pwp[j]; q[6 * o + 1] = Pwm[j]; q[6 * o + 2] = Plp[j]; q[6 * o + 3] = Plm[j]; q[6 * o + 4] = Lap[j]; q[6 * o + 5] = Lam[j]; } }
+                }
+#endif      // (two steps of the method of multipliers contract like (|H| / rho)^2)
+                land = 1; land_rounds = 1; expect_conv = false;
+                __syncthreads();
+                land_rows(land_rho);
+                __syncthreads();
+#ifdef SU_LAND_DEBUG
+                if (a.dbg) { double *q = a.dbg + 400 + 600; for (int i = tid; i < 5 * T && i < 100; i += NT) { q[i] = L.bw[i]; q[100 + i] = L.xd[i]; q[200 + i] = L.cy[i]; } if (tid == 0) q[300] = land_rho; }
+#endif
+                continue;
+            }
             status = 0; break;
         }
         if (expect_conv) {         // the prediction was wrong: repeat this pass with the factorisation (same iteration number)
             expect_conv = false; __syncthreads(); --it; continue;
         }
         mu_prev = mu;              // (after the repeat decision: the repeated pass smooths with the same width as the light one)
+        if (anyfail && land == 1) { land_refuse(); continue; }       // (a landing whose frozen set made the factorisation break down)
         if (anyfail) { status = 2; break; }
         mark(5);
 
@@ -1527,6 +1695,14 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             if (pass == 1) {
                 // corrector right-hand side: targets lam w + dlam dw - sigma mu (no second-order term without a predictor), new x+ - x-
                 const double smu = sigma * mu;
+                if (land == 1) {
+                    // second step of the method of multipliers: nu_1 = nu_0 + rho r(x + dx_0) (active rows; r(x + dx_0) is in Pdwp / Pdwm), the gradient was
+                    // formed with nu_0, so the right-hand side gets rho (r(x) + r(x + dx_0)) through x+ - x-
+#pragma unroll
+                    for (int j = 0; j < NPR; ++j)
+                        if (p_on[j])
+                            L.xd[5 * p_t[j] + p_k[j]] = land_rho * ((Lap[j] ? Prpp[j] + Pdwp[j] : 0.0) - (Lam[j] ? Prpm[j] + Pdwm[j] : 0.0));
+                } else
 #pragma unroll
                 for (int j = 0; j < NPR; ++j)
                     if (p_on[j]) {
@@ -1618,6 +1794,22 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // ---- slack / multiplier steps (pair threads, registers), step length ---------------------------------------
             // step to the boundary: the largest ratio -dx / x over all slacks and multipliers; al = min(1, fr / ratio)
             double ratio = 0.0;
+            if (land == 1) {
+                // landing: the rows at x + dx of this pass, r+ + c'dx and r- - c'dx; pass 0 keeps them for the second right-hand side (Pdwp / Pdwm),
+                // pass 1 ends the round: nu_2 = nu_0 + rho (r(x + dx_0) + r(x + dx_1)) on the active rows, slacks e - c'x+ of all rows
+#pragma unroll
+                for (int j = 0; j < NPR; ++j)
+                    if (p_on[j]) {
+                        const double cdx = pair_step(p_t[j], p_k[j]);
+                        const double rp_ = Prpp[j] + cdx, rm_ = Prpm[j] - cdx;
+                        if (pass == 0) { Pdwp[j] = rp_; Pdwm[j] = rm_; }
+                        else {
+                            if (Lap[j]) Plp[j] += land_rho * (Pdwp[j] + rp_);
+                            if (Lam[j]) Plm[j] += land_rho * (Pdwm[j] + rm_);
+                            Pwp[j] = -rp_; Pwm[j] = -rm_;
+                        }
+                    }
+            } else
 #pragma unroll
             for (int j = 0; j < NPR; ++j)
                 if (p_on[j]) {
@@ -1633,7 +1825,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // fraction to the boundary: 1 for the predictor; corrector: 0.995 far from the solution, -> 1 with the complementarity (superlinear end game)
             double fr = 1.0;
             if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; if (safe) fr = SU_SAFE_TAU; }
-            const double al = ratio > fr ? fr / ratio : 1.0;
+            const double al = land == 1 ? 1.0 : (ratio > fr ? fr / ratio : 1.0);      // (a landing takes the full step of its model)
+#ifdef SU_LAND_DEBUG
+            if (a.dbg && land == 1 && land_rounds == 1) {
+                double *q = a.dbg + 400 + 1200 + 600 + 300 * pass;
+                for (int i = tid; i < 8 * T && i < 150; i += NT) { q[i] = L.dy[i]; q[150 + i] = L.vv[i]; }
+            }
+#endif
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
                 double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? a.warm_sig : SIGMA_FLOOR) : 0.03;
@@ -1642,7 +1840,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             } else {
 #pragma unroll
                 for (int j = 0; j < NPR; ++j)
-                    if (p_on[j]) { Pwp[j] += al * Pdwp[j]; Pwm[j] += al * Pdwm[j]; Plp[j] += al * Pdlp[j]; Plm[j] += al * Pdlm[j]; }
+                    if (p_on[j] && land != 1) { Pwp[j] += al * Pdwp[j]; Pwm[j] += al * Pdwm[j]; Plp[j] += al * Pdlp[j]; Plm[j] += al * Pdlm[j]; }
                 if (tid < T) {
                     int t = tid; const double *y = &L.dy[8 * t], *v = &L.vv[8 * t + 3];
                     L.u[t] += al * v[0]; L.u[T + t] += al * v[1]; L.d[t] += al * v[2];
@@ -1661,7 +1859,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 for (int j = 0; j < NPR; ++j) if (p_on[j]) m_ += Plp[j] * Pwp[j] + Plm[j] * Pwm[j];
                 dv = wave_allreduce(dv, true); m_ = wave_allreduce(m_, false);
                 if (lane == 0) { L.red[280 + wave] = dv; L.red[284 + wave] = m_; }
-                pair_rows();
+                if (land == 1) verify_rows(); else pair_rows();
                 TR(42);
                 __syncthreads();
                 TR(43);
@@ -1677,7 +1875,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 // (very) wide neighbourhood of the central path, lam w >= SU_CENTRE_GAMMA mu after the step, by raising the multiplier
                 // (same rule and reason as the oracle's su_solve_impl: two neighbouring rate rows traded places for ever,
                 // tests/golden/su_hard/acker_T15_N45_rate_rows_cycle.npz).
-                const bool recentre = (attempt >= 0 && it >= SU_CENTRE_FROM) || safe;
+                const bool recentre = land == 0 && ((attempt >= 0 && it >= SU_CENTRE_FROM) || safe);
                 al_prev = al;
                 if (recentre) {
                     const double floor_ = (safe ? SU_SAFE_GAMMA : SU_CENTRE_GAMMA) * m_;
@@ -1691,13 +1889,15 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     __syncthreads();
                 }
                 const double prd = (1 - al) * rdn, prp = (1 - al) * rpn;
-                expect_conv = c.light_check && ((prd <= c.tol_rd * sc && prp <= c.tol_rp && m_ <= c.tol_mu * sc) ||
-                                                (prd <= 100 * c.tol_rd * sc && prp <= c.tol_rp && m_ <= 0.1 * c.tol_mu * sc));
+                expect_conv = c.light_check && ((prd <= t_rd * sc && prp <= t_rp && m_ <= t_mu * sc) ||
+                                                (prd <= 100 * t_rd * sc && prp <= t_rp && m_ <= 0.1 * t_mu * sc));
+                if (land == 1) { land = 2; expect_conv = true; }      // (the next pass verifies the landing: true measures only)
             }
             mark(8);
         }
     }
-    used += it;
+    used += it - land_its;
+    if (a.land_stat && tid == 0) a.land_stat[3] += land_its;
     }
     __syncthreads();
     if ((status != 0 || a.accept == 2) && have_acc) {          // every attempt failed: the safety net (the remembered iterate is primal feasible: inside the boxes).  accept == 2: test switch -
