@@ -151,7 +151,7 @@ typedef struct rda_opts {
     double  su_easy[5];      /* [1e-12, 1e-12, 1e-12, 0.999999, 1e-7] wfl, mu0, clip, tau, sigma of the easy start: the first three lie
                                 BELOW the stop tolerances, i.e. the easy start is the previous solution itself and the stop test may
                                 accept it without a Newton step when the new problem's optimality conditions hold there  RDA_SU_EASY */
-    int32_t su_land;         /* [0] LANDING of the su interior point (round 6; oracle mirror orc_set_su_land): 1 = the interior point runs to
+    int32_t su_land;         /* [1] LANDING of the su interior point (round 6; oracle mirror orc_set_su_land): 1 = the interior point runs to
                                 su_land_tol only - close enough for the active set to be read off (lam > w) - and the vertex it approaches is
                                 computed exactly: active rows as equalities, the others dropped, the equality-constrained quadratic model solved
                                 with the same factorisation and sweeps (two steps of the method of multipliers = the two passes of an iteration),
@@ -160,8 +160,9 @@ typedef struct rda_opts {
                                 the central path the iteration stopped (the reason for the stated tolerance of 5e-4: a row that is only just
                                 active keeps the slack mu / lam*): kernel and cold oracle agree to 1e-9 with it (tests/test_gpu_land.py).
                                 Costs one factorisation + a verification pass per solve, saves the last interior-point iteration.  RDA_SU_LAND */
-    double  su_land_tol[3];  /* [1e-6, 1e-7, 1e-8] stop of the interior point when it is landed (the class ECOS stops at)  RDA_SU_LAND_TOL */
-    double  su_land_rho;     /* [1e6] penalty of the landing's active rows, relative to the largest entry of the stage Hessians  RDA_SU_LAND_RHO */
+    double  su_land_tol[3];  /* [1e-3, 1e-4, 1e-5] first stop of the interior point when it is landed; a refused landing is tried once more at 1e-2 x
+                                these values, then the iteration runs to su_tol                                                  RDA_SU_LAND_TOL */
+    double  su_land_rho;     /* [1e4] penalty of the landing's active rows, relative to the largest entry of the stage Hessians  RDA_SU_LAND_RHO */
 } rda_opts;
 void rda_opts_init(rda_opts *o);
 

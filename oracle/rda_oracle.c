@@ -695,7 +695,7 @@ static void chol_solve(const double *K, int n, double *rhs)
  * gradient at x+ (hinge terms re-evaluated) is stationary; otherwise move rows in / out of A by their signs (primal-dual active set) and try again, a few
  * rounds; no acceptance: the interior-point iterate is returned as before.  The model is solved by the method of multipliers on
  * K = H + rho C_A' C_A (one Cholesky factor, a few solves: converges like (|H| / rho)^k), so no row of C_A has to be independent of the others. */
-static int g_su_land = 0; static double g_su_land_tol[3] = {1e-6, 1e-7, 1e-8};   /* = rda_opts::su_land, su_land_tol */
+static int g_su_land = 1; static double g_su_land_tol[3] = {1e-3, 1e-4, 1e-5};   /* = rda_opts::su_land, su_land_tol (first stop; a refused landing is tried again at 1e-2 x, then never) */
 static __thread int t_su_landed = 0, t_su_land_rounds = 0;
 static long g_pol_stat[8];       /* calls, accepted, rounds summed, last verdict: chol failed, set still moving, not stationary; rows moved */
 void orc_get_su_land_stats(long *out8) { for (int i = 0; i < 8; ++i) { out8[i] = g_pol_stat[i]; g_pol_stat[i] = 0; } }
@@ -869,7 +869,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
             }
         }
     }
-    status = 1;
+    status = 1; land_failed = 0;
     double mu_prev = 1.0, al_prev = 0.0;
     for (it = 0; it < it_cap; ++it) {
         /* ... and in that rescue phase the hinge terms are smoothed over a width eps = SU_SMOOTH_K sqrt(mu) (mu of the previous iterate;
@@ -898,18 +898,22 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         /* (second clause) past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
          * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
 #define SU_CONV(tol) ((rdn <= (tol)[0] * sc && rpn <= (tol)[1] && mu <= (tol)[2] * sc) || (rdn <= 100 * (tol)[0] * sc && rpn <= (tol)[1] && mu <= 0.1 * (tol)[2] * sc))
-        if (g_su_land && !land_failed) {
-            /* Landing (round 6, see su_land): the interior point only has to get close enough for the active set to be read off - su_land_tol, the class
-             * ECOS stops at - and the vertex is then computed exactly.  Refused (never seen on the recorded loops): the iteration goes on to su_tol. */
-            if (SU_CONV(g_su_land_tol)) {
+        if (g_su_land && land_failed < 99) {
+            /* Landing (round 6, see su_land): the interior point only has to get close enough for the active set to be read off - su_land_tol - and the
+             * vertex is then computed exactly.  Refused (the active-set rounds can cycle while borderline rows are undecided): tried again at 1e-2 x
+             * su_land_tol, 1e-4 x ... down to su_tol itself, then the iterate at su_tol is returned as without the landing. */
+            double lt[3], lsc = 1.0; int last = 1;
+            for (int k = 0; k < land_failed && k < 8; ++k) lsc *= 1e-2;
+            for (int k = 0; k < 3; ++k) { lt[k] = lsc * g_su_land_tol[k]; if (lt[k] <= g_su_tol[k]) lt[k] = g_su_tol[k]; else last = 0; }
+            if (SU_CONV(lt)) {
                 memcpy(x_sav, x, sizeof(double) * n); memcpy(lm_sav, lm, sizeof(double) * mc); memcpy(w_sav, w, sizeof(double) * mc);
                 if (su_land(&S, con, mc, n, x, lm, w, s, grad, Hm, K, g_su_tol[0])) { t_su_landed = 1; status = 0; break; }
                 memcpy(x, x_sav, sizeof(double) * n); memcpy(lm, lm_sav, sizeof(double) * mc); memcpy(w, w_sav, sizeof(double) * mc);
-                land_failed = 1;
+                land_failed = last ? 99 : land_failed + 1;
                 su_eval(&S, x, s, grad, Hm);
             }
         }
-        if ((!g_su_land || land_failed) && SU_CONV(g_su_tol)) { status = 0; break; }
+        if ((!g_su_land || land_failed >= 99) && SU_CONV(g_su_tol)) { status = 0; break; }
         if (g_su_accept && rpn <= g_su_tol[1] && rdn <= 10 * g_su_tol[0] * sc && mu <= 1e3 * g_su_tol[2] * sc) {
             const double merit = fmax(rdn / (g_su_tol[0] * sc), mu / (g_su_tol[2] * sc));
             if (!have_acc || merit < acc_merit) { memcpy(x_acc, x, sizeof(double) * n); memcpy(lm_acc, lm, sizeof(double) * mc); have_acc = 1; acc_merit = merit; }

@@ -1293,7 +1293,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1; o->su_first_attempt = 0;
-    o->su_land = 0; o->su_land_tol[0] = 1e-6; o->su_land_tol[1] = 1e-7; o->su_land_tol[2] = 1e-8; o->su_land_rho = 1e6;
+    o->su_land = 1; o->su_land_tol[0] = 1e-3; o->su_land_tol[1] = 1e-4; o->su_land_tol[2] = 1e-5; o->su_land_rho = 1e4;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1368,8 +1368,8 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_pre = o.su_pre;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept; H->d.su_first_attempt = o.su_first_attempt;
-    H->d.su_land = o.su_land ? 1 : 0; H->d.su_land_rho = o.su_land_rho > 0 ? o.su_land_rho : 1e6;
-    { const bool ok = o.su_land_tol[0] > 0 && o.su_land_tol[1] > 0 && o.su_land_tol[2] > 0; const double dflt[3] = {1e-6, 1e-7, 1e-8}; for (int i = 0; i < 3; ++i) H->d.su_land_tol[i] = ok ? o.su_land_tol[i] : dflt[i]; }
+    H->d.su_land = o.su_land ? 1 : 0; H->d.su_land_rho = o.su_land_rho > 0 ? o.su_land_rho : 1e4;
+    { const bool ok = o.su_land_tol[0] > 0 && o.su_land_tol[1] > 0 && o.su_land_tol[2] > 0; const double dflt[3] = {1e-3, 1e-4, 1e-5}; for (int i = 0; i < 3; ++i) H->d.su_land_tol[i] = ok ? o.su_land_tol[i] : dflt[i]; }
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
     for (int i = 0; i < 3; ++i) H->d.su_tol[i] = o.su_tol[i] > 0 ? o.su_tol[i] : (i == 0 ? 1e-9 : (i == 1 ? 1e-10 : 1e-11));
     { const bool on = o.su_tol_early[0] > 0 && o.su_tol_early[1] > 0 && o.su_tol_early[2] > 0; for (int i = 0; i < 3; ++i) H->d.su_tol_early[i] = on ? o.su_tol_early[i] : 0.0; }
@@ -3000,11 +3000,7 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
     if (od.su_prof) { HIPCHK(hipMalloc((void **)&dprof, su::PROF_WORDS * sizeof(long long))); HIPCHK(hipMemset(dprof, 0, su::PROF_WORDS * sizeof(long long))); }
     ar.prof = dprof;
     double *ddbg = nullptr;
-#ifdef SU_LAND_DEBUG
-    if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 6000 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 6000 * sizeof(double))); }
-#else
     if (od.su_prof > 1) { HIPCHK(hipMalloc((void **)&ddbg, 400 * sizeof(double))); HIPCHK(hipMemset(ddbg, 0, 400 * sizeof(double))); }
-#endif      // (su_prof = 2: one stderr line per interior-point iteration)
     ar.dbg = ddbg;
     const size_t lds = su::lds_bytes((int)T);
     RDA_SU_DISPATCH((int)T, HIPCHK(hipFuncSetAttribute((const void *)k_su_hook<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
@@ -3017,32 +3013,6 @@ extern "C" int rda_su_solve_opts(const rda_cfg *cfg, const rda_opts *opts, const
         double hd[400]; HIPCHK(hipMemcpy(hd, ddbg, sizeof(hd), hipMemcpyDeviceToHost));
         for (int i = 0; i < 100 && (i == 0 || hd[4 * i + 3] != 0); ++i)
             fprintf(stderr, "it %d rdn %.3e rpn %.3e mu %.3e sc %.3e\n", i, hd[4 * i], hd[4 * i + 1], hd[4 * i + 2], hd[4 * i + 3]);
-#ifdef SU_LAND_DEBUG
-        {
-            static double hl[2400]; HIPCHK(hipMemcpy(hl, ddbg + 400, sizeof(hl), hipMemcpyDeviceToHost));
-            for (int r = 0; r < 2; ++r) for (int o = 0; o < 5 * (int)T && o < 190; ++o) {
-                const double *q = hl + r * 1200 + 6 * o;
-                if (q[4] != 0 || q[5] != 0 || q[0] < 0 || q[1] < 0 || (r == 0 && (o % 5 == 4 || o % 5 == 3)))
-                    fprintf(stderr, "  round %d pair t=%d k=%d: w+ %.3e w- %.3e nu+ %.3e nu- %.3e act %d %d\n", r, o / 5, o % 5, q[0], q[1], q[2], q[3], (int)q[4], (int)q[5]);       /* round 1 = the interior-point iterate the landing starts from, round 2 = after its first round */
-            }
-        }
-#endif
-#ifdef SU_LAND_DEBUG
-        {
-            static double hl[2400]; HIPCHK(hipMemcpy(hl, ddbg + 400, sizeof(hl), hipMemcpyDeviceToHost));
-            fprintf(stderr, "  rho %.3e\n", hl[600 + 300]);
-            if (T <= 16 && getenv("SU_LAND_DUMP")) {
-                static double big[6000]; HIPCHK(hipMemcpy(big, ddbg, sizeof(big), hipMemcpyDeviceToHost));
-                static int ncase = 0; char nm[256]; snprintf(nm, sizeof nm, "%s_%d.bin", getenv("SU_LAND_DUMP"), ncase++);
-                FILE *f = fopen(nm, "wb"); if (f) { double hd = (double)T; fwrite(&hd, 8, 1, f); fwrite(big, 8, 6000, f); fclose(f); }
-            }
-            for (int o = 0; o < 5 * (int)T && o < 100; ++o) if (hl[600 + o] != 0 || hl[700 + o] != 0) fprintf(stderr, "  start pair t=%d k=%d: bw %.3e xd %.3e cy %.3e\n", o / 5, o % 5, hl[600 + o], hl[700 + o], hl[800 + o]);
-            for (int ps = 0; ps < 2; ++ps) for (int t = 0; t < (int)T && 8 * t + 7 < 150; ++t) {
-                const double *y = hl + 1800 + 300 * ps + 8 * t, *v = hl + 1800 + 300 * ps + 150 + 8 * t;
-                fprintf(stderr, "  pass %d stage %d: dx %.2e %.2e %.2e %.2e %.2e  du %.2e %.2e dd %.2e\n", ps, t, y[0], y[1], y[2], y[3], y[4], v[3], v[4], v[5]);
-            }
-        }
-#endif
         dev_free(ddbg);
     }
     if (dprof) {

@@ -147,7 +147,10 @@ struct Args {
     // (at most 4); refused: the interior-point iterate is restored and the iteration goes on to tol_rd / tol_rp / tol_mu as without the switch.
     // Why: the interior point stops ON the central path, a row that is only just active keeps the slack mu / lam*, and two iterations that stop at different
     // mu differ by up to 1e-4 in the controls (TOL_U); the vertex does not depend on the path (tools/experiments/su_land_oracle.py: 1e-5 -> 1e-13).
-    int land = 0; double land_tol[3] = {1e-6, 1e-7, 1e-8}; double land_rho = 1e6;      // (land_rho: penalty of the active rows relative to the largest stage-Hessian entry)
+    // Stops: the landing is first tried where the interior point reaches land_tol (1e-3 class: the active set is usually readable there - re-sorted north
+    // star: 10 instead of 21 interior-point iterations per step, every landing accepted); a refused landing (the primal-dual active-set rounds can cycle
+    // while borderline rows are still undecided) is tried again at 1e-2 x land_tol, 1e-4 x ... down to the tight tolerances themselves, then never.
+    int land = 0; double land_tol[3] = {1e-3, 1e-4, 1e-5}; double land_rho = 1e4;      // (land_rho: penalty of the active rows relative to the largest stage-Hessian entry)
     int *land_stat = nullptr;        // optional [4]: landings accepted, refused, rounds, interior-point iterations that were landing / verification passes
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
@@ -1234,11 +1237,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     const bool safe = attempt == 1;                // (uniform) the last-resort iteration, see SU_SAFE_*
     double al_prev = 0.0;
     int land = 0, land_rounds = 0, land_its = 0;   // (uniform) 0: interior point; 1: this pass is a landing round; 2: this pass verifies one; passes spent on landings
-    bool land_failed = false;
+    int land_level = 0;                            // (uniform) landings refused so far in this attempt: k -> stop at 1e-2^k x land_tol (not below the tight tolerances); 99 -> no landing
     double land_rho = 0.0;
     bool expect_conv = false;
     // a landing is refused: back to the interior-point iterate it started from, and on to the tight tolerances (all threads; ends with a barrier)
-    auto land_refuse = [&]() {
+    auto land_refuse = [&](const bool last) {
         __syncthreads();
         for (int i = tid; i < 2 * T; i += NT) L.u[i] = L.sav[i];
         for (int i = tid; i < T; i += NT) L.d[i] = L.sav[2 * T + i];
@@ -1248,7 +1251,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         rollout();
         __syncthreads();
         if (a.land_stat && tid == 0) a.land_stat[1] += 1;
-        land = 0; land_failed = true; expect_conv = false;
+        land = 0; land_level = last ? 99 : land_level + 1; expect_conv = false;
         pair_rows();
         __syncthreads();
     };
@@ -1463,15 +1466,6 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         TR(7);
         __syncthreads();
         mark(2); TR(8);
-#ifdef SU_LAND_DEBUG
-        if (a.dbg && land == 1 && land_rounds == 1 && T <= 16) {      // the whole Newton system of the round: Hb | Ft | gst | xd | m7 per stage
-            double *q = a.dbg + 2800;
-            for (int i = tid; i < 64 * T; i += NT) q[i] = L.Hb[HB * (i / 64) + (i & 63)];
-            for (int i = tid; i < 48 * T; i += NT) q[64 * T + i] = L.Ft[FT * (i / 48) + (i % 48)];
-            for (int i = tid; i < 8 * T; i += NT) { q[112 * T + i] = L.gst[i]; q[120 * T + i] = L.m7[i]; }
-            for (int i = tid; i < 5 * T; i += NT) q[128 * T + i] = L.xd[i];
-        }
-#endif
         // ---- (4) waves 0 / 1: Riccati matrix recursion of the stages [msp, T) / [0, msp) (time split; msp = 0: wave 0 takes them all);
         //          wave 2: adjoint sweep for the reduced gradient + early verdict; wave 3: the other termination measures ------------
         bool fail = false;
@@ -1574,28 +1568,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
         if (a.rd0 && used == 0 && it == 0 && tid == 0) *a.rd0 = rdn / sc;
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
-        const bool landing = a.land != 0 && !land_failed;          // (uniform) the interior point stops at land_tol and is landed
-        const double t_rd = landing ? a.land_tol[0] : c.tol_rd, t_rp = landing ? a.land_tol[1] : c.tol_rp, t_mu = landing ? a.land_tol[2] : c.tol_mu;
+        const bool landing = a.land != 0 && land_level < 99;       // (uniform) the interior point stops at 1e-2^level x land_tol and is landed
+        double lsc = 1.0;
+        for (int k = 0; k < land_level && k < 8; ++k) lsc *= 1e-2;
+        const double t_rd = landing ? fmax(lsc * a.land_tol[0], c.tol_rd) : c.tol_rd, t_rp = landing ? fmax(lsc * a.land_tol[1], c.tol_rp) : c.tol_rp,
+                     t_mu = landing ? fmax(lsc * a.land_tol[2], c.tol_mu) : c.tol_mu;
+        const bool land_last = t_rd <= c.tol_rd && t_rp <= c.tol_rp && t_mu <= c.tol_mu;      // a landing refused at the tight tolerances is the last one
         const bool conv_now = land == 0 && ((rdn <= t_rd * sc && rpn <= t_rp && mu <= t_mu * sc) || (rdn <= 100 * t_rd * sc && rpn <= t_rp && mu <= 0.1 * t_mu * sc));
         if (land == 2) {
             // ---- verdict on a landing round (this pass measured x+ with the hinge terms re-evaluated: rdn = stationarity, rpn = largest violation relative to
             //      1 + |e|, mu mcnt = sum of the negative parts of the multipliers; same thresholds as the oracle's su_land)
             if (a.land_stat && tid == 0) a.land_stat[2] += 1;
             const bool moved = rpn > 1e-11 || mu * mcnt > 1e-9 * sc;
-#ifdef SU_LAND_DEBUG
-            if (a.dbg && land_rounds <= 1) {
-                double *q = a.dbg + 400 + 1200;
-#pragma unroll
-                for (int j = 0; j < NPR; ++j) if (p_ok[j]) { const int o = 5 * p_t[j] + p_k[j]; if (o < 190) { q[6 * o] = Pwp[j]; q[6 * o + 1] = Pwm[j]; q[6 * o + 2] = Plp[j]; q[6 * o + 3] = Plm[j]; q[6 * o + 4] = Lap[j]; q[6 * o + 5] = Lam[j]; } }
-            }
-#endif
             if (!moved && rdn <= 100 * c.tol_rd * sc) {                      // landed
 #pragma unroll
                 for (int j = 0; j < NPR; ++j) if (p_on[j]) { Plp[j] = fmax(Plp[j], 0.0); Plm[j] = fmax(Plm[j], 0.0); }
                 if (a.land_stat && tid == 0) a.land_stat[0] += 1;
                 status = 0; break;
             }
-            if (land_rounds >= 4 || !(rdn == rdn)) { land_refuse(); continue; }      // refused
+            if (land_rounds >= 4 || !(rdn == rdn)) { land_refuse(land_last); continue; }      // refused
             // next round: rows move in / out of the active set by their signs (primal-dual active set) and the model is solved again from the SAME point -
             // a full step along a weakly curved direction may have left the boxes by far, x+ is then no place to linearise the hinge terms at; a round whose
             // set did not move was not stationary because a hinge term switched: that one is linearised again at x+ (= the oracle's su_land)
@@ -1659,20 +1650,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     Lap[j] = p_on[j] && Plp[j] > Pwp[j]; Lam[j] = p_on[j] && Plm[j] > Pwm[j];
                 }
                 land_rho = a.land_rho * fmax(1.0, fmax(L.pv[5], 2 * c.wu + c.eps_u));
-#ifdef SU_LAND_DEBUG
-                if (a.dbg) {
-                    double *q = a.dbg + 400;
-#pragma unroll
-                    for (int j = 0; j < NPR; ++j) if (p_ok[j]) { const int o = 5 * p_t[j] + p_k[j]; if (o < 190) { q[6 * o] = Pwp[j]; q[6 * o + 1] = Pwm[j]; q[6 * o + 2] = Plp[j]; q[6 * o + 3] = Plm[j]; q[6 * o + 4] = Lap[j]; q[6 * o + 5] = Lam[j]; } }
-                }
-#endif      // (two steps of the method of multipliers contract like (|H| / rho)^2)
                 land = 1; land_rounds = 1; expect_conv = false;
                 __syncthreads();
                 land_rows(land_rho);
                 __syncthreads();
-#ifdef SU_LAND_DEBUG
-                if (a.dbg) { double *q = a.dbg + 400 + 600; for (int i = tid; i < 5 * T && i < 100; i += NT) { q[i] = L.bw[i]; q[100 + i] = L.xd[i]; q[200 + i] = L.cy[i]; } if (tid == 0) q[300] = land_rho; }
-#endif
                 continue;
             }
             status = 0; break;
@@ -1681,7 +1662,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             expect_conv = false; __syncthreads(); --it; continue;
         }
         mu_prev = mu;              // (after the repeat decision: the repeated pass smooths with the same width as the light one)
-        if (anyfail && land == 1) { land_refuse(); continue; }       // (a landing whose frozen set made the factorisation break down)
+        if (anyfail && land == 1) { land_refuse(land_last); continue; }       // (a landing whose frozen set made the factorisation break down)
         if (anyfail) { status = 2; break; }
         mark(5);
 
@@ -1826,12 +1807,6 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             double fr = 1.0;
             if (pass) { fr = 1.0 - mu; if (fr < tau_min) fr = tau_min; if (safe) fr = SU_SAFE_TAU; }
             const double al = land == 1 ? 1.0 : (ratio > fr ? fr / ratio : 1.0);      // (a landing takes the full step of its model)
-#ifdef SU_LAND_DEBUG
-            if (a.dbg && land == 1 && land_rounds == 1) {
-                double *q = a.dbg + 400 + 1200 + 600 + 300 * pass;
-                for (int i = tid; i < 8 * T && i < 150; i += NT) { q[i] = L.dy[i]; q[150 + i] = L.vv[i]; }
-            }
-#endif
             if (pass == 0) {
                 // centering parameter from the predictor step length, floored (see the oracle for why)
                 double q = 1 - al, fl = al >= 0.95 ? (attempt < 0 ? a.warm_sig : SIGMA_FLOOR) : 0.03;

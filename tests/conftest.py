@@ -36,3 +36,24 @@ def hip():
     """HIP library C-ABI; fails (not skips) when the extension or the GPU is missing"""
     from rda_planner_amd._lib import hip_api
     return hip_api()
+
+
+@pytest.fixture()
+def no_landing(monkeypatch):
+    """Round 6: the su interior point is LANDED on its vertex by default (rda_opts::su_land, oracle orc_set_su_land).  Tests whose subject is the
+    interior-point iteration itself - start rules, iteration counts, stop tolerances, the safety net - switch the landing off on both sides: the handles
+    built through rda_solver.hip_options (RDA_SU_LAND=0 in the environment), the oracle (global switch), and `hip_su_solve`, the su hook with su_land = 0."""
+    import ctypes as C
+    from oracle.oracle_backend import api as orc_api
+    monkeypatch.setenv("RDA_SU_LAND", "0")
+    lib = orc_api().lib
+    lib.orc_set_su_land(0)
+
+    def hip_su_solve(*a):
+        from rda_planner_amd._capi import Opts
+        from rda_planner_amd._lib import hip_api
+        hip = hip_api()
+        o = Opts(); hip.opts_init(C.byref(o)); o.su_land = 0
+        return hip.lib.rda_su_solve_opts(a[0], C.byref(o), *a[1:])
+    yield hip_su_solve
+    lib.orc_set_su_land(1)

@@ -19,6 +19,12 @@ from tests.helpers import TOL_U
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _interior_point_only(no_landing):
+    """this module is about the interior-point iteration (start rules, safety net, last resort): landing off on both sides"""
+    yield
+
+
 def _scene(n=60):
     car_t = sc.rectangle_robot(dynamics="acker")
     path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
@@ -90,7 +96,7 @@ def test_safety_net_hands_back_the_best_near_converged_iterate(hip, orc, T, N, d
     inp = hp.su_inputs(rng, cfg)
 
     def solve(accept):
-        o = Opts(); hip.opts_init(C.byref(o)); o.su_accept = accept
+        o = Opts(); hip.opts_init(C.byref(o)); o.su_accept = accept; o.su_land = 0
         s, u, d, it = np.zeros((3, T + 1)), np.zeros((2, T)), np.zeros(T), C.c_int(0)
         st = hip.lib.rda_su_solve_opts(C.byref(cfg), C.byref(o), dptr(inp["nom_s"]), dptr(inp["nom_u"]), dptr(inp["ref"]), inp["vref"], dptr(inp["a"]),
                                        dptr(inp["cc"]), dptr(inp["g"]), dptr(inp["d0"]), dptr(s), dptr(u), dptr(d), C.byref(it))
@@ -127,7 +133,7 @@ def test_last_resort_attempt_converges_on_every_recorded_hard_instance_like_the_
     import helpers as hp
     cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", name + ".npz"))
     T = cfg.T
-    o = Opts(); hip.opts_init(C.byref(o)); o.su_first_attempt = 1
+    o = Opts(); hip.opts_init(C.byref(o)); o.su_first_attempt = 1; o.su_land = 0
     s, u, d, it = np.zeros((3, T + 1)), np.zeros((2, T)), np.zeros(T), C.c_int(0)
     st = hip.lib.rda_su_solve_opts(C.byref(cfg), C.byref(o), dptr(inp["nom_s"]), dptr(inp["nom_u"]), dptr(inp["ref"]), inp["vref"], dptr(inp["a"]),
                                    dptr(inp["cc"]), dptr(inp["g"]), dptr(inp["d0"]), dptr(s), dptr(u), dptr(d), C.byref(it))

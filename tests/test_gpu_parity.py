@@ -438,7 +438,7 @@ def test_warm_started_lammuz_equals_enumeration(monkeypatch):
 
 @pytest.mark.parametrize("name", ["omni_T15_N13", "diff_T10_N13", "omni_T10_N33_restart", "omni_T25_N26_stagnating_dual", "acker_T15_N45_rate_rows_cycle",
                                   "omni_T15_N40_hinge_flips"])
-def test_su_hard_instances_from_the_soak_run(orc, hip, name):
+def test_su_hard_instances_from_the_soak_run(orc, hip, name, no_landing):
     """two su-problems on which an earlier kernel left the oracle's iteration path (the hinge screening was only verified
     at convergence and the late fallback restarted from a badly centred point): 44 and 10 interior-point iterations in
     the oracle, the kernel must follow.  The third one used to cycle (100 iterations, then the restart from a more central
@@ -448,21 +448,21 @@ def test_su_hard_instances_from_the_soak_run(orc, hip, name):
     on and off for ever until such attempts smooth the hinge terms over 0.1 sqrt(mu) (round 3)"""
     cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", name + ".npz"))
     so = hp.su_solve(orc.lib.orc_su_solve, cfg, inp)
-    sh = hp.su_solve(hip.lib.rda_su_solve, cfg, inp)
+    sh = hp.su_solve(no_landing, cfg, inp)                 # (the interior-point paths are compared: landing off on both sides)
     assert so[0] == 0 and sh[0] == 0
     assert abs(so[4] - sh[4]) <= 1, (so[4], sh[4])
     for k in (1, 2, 3):
         assert np.abs(so[k] - sh[k]).max() < 1e-6
 
 
-def test_su_end_game_noise_instance_converges_in_the_kernel(orc, hip):
+def test_su_end_game_noise_instance_converges_in_the_kernel(orc, hip, no_landing):
     """the one su-problem of 32 000 round-4 soak steps on which a side failed - the ORACLE (its dual residual grows from 8e-10 to 3e-5 as mu
     falls below 1e-9, Cholesky breakdown; tests/test_oracle_su.py::test_end_game_lost_in_rounding_returns_the_near_converged_iterate).
     The kernel's cold solve converges (16 iterations); the iterate the checker's safety net returns is of the looser class (mu = 2e-9
     instead of 1e-11: 1e-4 from the kernel's point, see test_stop_tolerance_vs_weakly_active_rows) - within the stated tolerance TOL_U."""
     cfg, inp = hp.load_su_case(os.path.join(os.path.dirname(__file__), "golden", "su_hard", "omni_T25_N20_end_game_noise.npz"))
     so = hp.su_solve(orc.lib.orc_su_solve, cfg, inp)
-    sh = hp.su_solve(hip.lib.rda_su_solve, cfg, inp)
+    sh = hp.su_solve(no_landing, cfg, inp)
     assert so[0] == 0 and sh[0] == 0 and sh[4] <= 20, (so[0], sh[0], sh[4])
     d = max(float(np.abs(so[k] - sh[k]).max()) for k in (1, 2, 3))
     print(f"|(s, u, d)_gpu - oracle's accepted iterate| {d:.2e} ({sh[4]} interior-point iterations)")

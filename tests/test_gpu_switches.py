@@ -103,7 +103,7 @@ def test_time_split_of_the_su_newton_system_changes_nothing_but_rounding(T, dyn,
     assert worst <= 1e-5
 
 
-def test_su_tol_early_saves_interior_point_iterations_and_stays_near_the_default_and_the_oracle():
+def test_su_tol_early_saves_interior_point_iterations_and_stays_near_the_default_and_the_oracle(no_landing):
     """rda_opts::su_tol_early (opt-in): the su-problems of the ADMM iterations before the last one of a step stop at ECOS-class tolerances
     (1e-6, 1e-7, 1e-8) - what the reference's own solver delivers in every iteration.  Re-sorted scene (the reference's default caller: most
     steps run all iter_num iterations and their LAST su-problem - the one whose control is returned - is solved to su_tol; a step that
