@@ -163,6 +163,12 @@ typedef struct rda_opts {
     double  su_land_tol[3];  /* [1e-3, 1e-4, 1e-5] first stop of the interior point when it is landed; a refused landing is tried once more at 1e-2 x
                                 these values, then the iteration runs to su_tol                                                  RDA_SU_LAND_TOL */
     double  su_land_rho;     /* [1e4] penalty of the landing's active rows, relative to the largest entry of the stage Hessians  RDA_SU_LAND_RHO */
+    int32_t su_land_first;   /* [2] landing FIRST, for the su-problems of ADMM iterations >= 1 (they start from the previous solution of the step and its multipliers).
+                                1: the first pass of the warm attempt is a light one (measures only - the start usually meets the landing's stop as it stands and the
+                                factorisation of that pass was thrown away by the landing round anyway); results are bit-identical to 0.  2: ... and when the start
+                                does not meet the stop the landing is tried all the same, from the start, active set = the rows whose kept multiplier exceeds the
+                                slack, at most two rounds (a warm-started active-set method; accepted only on the verified optimality conditions of the true
+                                problem, so the answer is the same vertex: differences at rounding level); refused: the interior point takes over.  RDA_SU_LAND_FIRST */
 } rda_opts;
 void rda_opts_init(rda_opts *o);
 
@@ -321,7 +327,8 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime, hist[2] = the previous step ended above
  * iter_threshold, hist[3] = the last su-solve started far from its solution (the two keys of su_hard_warm); lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
-#define RDA_SU_HISTORY_INTS 4   /* entries of `hist` in THIS header (round 4: 2 - the array grew in round 5, an ABI break for callers of the count-less forms) */
+#define RDA_SU_HISTORY_INTS 5   /* entries of `hist` in THIS header (round 4: 2, round 5: 4 - the array grows with the start rules, an ABI break for callers of the count-less
+                                   forms: use the _n forms below).  hist[4] (round 6) = the credit of the speculative landings, rda_opts::su_land_first = 2 */
 int  rda_get_su_history(rda_handle *h, int32_t *hist /*RDA_SU_HISTORY_INTS*/, double *lam_keep /*10*T*/);
 int  rda_set_su_history(rda_handle *h, const int32_t *hist /*RDA_SU_HISTORY_INTS*/, const double *lam_keep /*10*T*/);
 /* ... with the caller's own count: get writes n_hist entries (those this library does not have read 0), set reads
@@ -340,6 +347,7 @@ int  rda_debug_su_prof(rda_handle *h, long long *out16);
 /* -DSU_TRACE builds only (RDA_ERR_UNSUPPORTED otherwise): per-wave (event id, clock64) pairs of the LAST su launch, out[4][cap][2] (tools/su_trace.py) */
 int  rda_debug_su_trace(rda_handle *h, long long *out, int cap, int *n_out);
 int  rda_debug_su_land(rda_handle *h, int32_t *out4);      /* su_land: landings accepted, refused, rounds, passes spent on landings since the last call */
+int  rda_debug_su_land_n(rda_handle *h, int32_t *out, int n);   /* ... the first n <= 20 counters: [4] speculative landings (su_land_first = 2) tried, [5] accepted, [6 + k] / [12 + k] tried / accepted by the decade k = 0 .. 5 of the start's relative dual residual (< 1e-4, < 1e-3, < 1e-2, < 1e-1, < 1, >= 1) */
 int  rda_debug_flush_supports(rda_handle *h);             /* forget every remembered LamMuZ support (a cache: results must not depend on it) */
 int  rda_debug_slot_src(rda_handle *h, int32_t *src /*N*/, int32_t *used); /* slot -> entry of the caller's raw scene (device pipeline; used = 0: host-staged slots) */
 int  rda_debug_worklist(rda_handle *h, int *rows);        /* rows on the LamMuZ work list of the last executed iteration (split launch form) */

@@ -49,7 +49,8 @@ struct Ctrl {
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
     double rd0_tmp;               // ... that residual, written by the solve
-    int land_stat[4];             // su_land: landings accepted, refused, rounds, passes spent on landings (rda_debug_su_land)
+    int spec_credit;              // su_land_first = 2: speculative landings are tried while this is >= 0 (+3 per accepted one, capped at 6; -2 per refused one; +1 per eligible solve that had to skip): solver history
+    int land_stat[su::LAND_STATS];  // su_land: landings accepted, refused, rounds, passes spent on landings, speculative landings (rda_debug_su_land, rda_debug_su_land_n)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
 #ifdef RDA_LMZ_STATS
     unsigned lmz_stat[8];    // debug build only: [0] executed launches, [1] rows that needed the enumeration, [2+k] waves with k such rows
@@ -80,6 +81,7 @@ struct Dev {
     int su_accept;                       // su_device Args::accept (safety net: the best near-converged iterate)
     int su_first_attempt;                // su_device Args::first_attempt (test switch)
     int su_land; double su_land_tol[3], su_land_rho;  // su_device Args::land (rda_opts::su_land)
+    int su_land_first;                   // su_device Args::land_first (rda_opts::su_land_first)
     int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
@@ -152,7 +154,18 @@ __host__ __device__ inline size_t drow(const Dev &d, int n, int tt) { return (si
 // partials of every shard.  ONE wave (the first 64 threads of the calling workgroup), lane l sums the partials l, l+64, ... in that
 // order, then a wave reduction: the values do not depend on the kernel (or workgroup size) that takes the verdict, and they are
 // identical on every rank.  All threads of the workgroup call.
-__device__ void reduce_residuals(const Dev &d, int tid)
+struct ResPre { double a[16], b[16]; };       // first batch of shard 0's residual partials, requested ahead (su_body: with everything else the launch reads)
+__device__ __forceinline__ void residual_prefetch(const Dev &d, int tid, ResPre &p)
+{
+    const double *bs = bsum_arr(d, 0);
+    const int nb = d.J * d.c.T;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int i = tid + 64 * k; const int ii = (tid < 64 && i < nb) ? i : 0; p.a[k] = bs[(size_t)ii * NBS + 3]; p.b[k] = bs[(size_t)ii * NBS + 4]; }      // (unconditional loads: see reduce_residuals)
+}
+// `iters`: the value of Ctrl::iters (the caller has it).  `bc` (LDS, 2 doubles, optional): the verdict reaches the other threads through it - (rd, rp) are
+// returned to every thread - instead of a store to the control block and a trip back.
+// (pre by reference + a flag, never a selected pointer: its members stay registers)
+__device__ __forceinline__ void reduce_residuals(const Dev &d, int tid, int iters, const ResPre &pre, const bool have_pre, double *bc, double &out_rd, double &out_rp)
 {
     const int T = d.c.T, N = d.c.N;
     if (tid < 64) {
@@ -163,20 +176,42 @@ __device__ void reduce_residuals(const Dev &d, int tid)
                 const int nb = d.J * T;
                 for (int base = 0; base < nb; base += 64 * 16) {        // sixteen independent loads in flight per lane and quantity,
                     double a[16], b[16];                                 // accumulated in the order of the plain loop
+                    if (have_pre && r == 0 && base == 0) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) { const int i = base + tid + 64 * k; const bool in = i < nb; a[k] = in ? bs[(size_t)i * NBS + 3] : 0.0; b[k] = in ? bs[(size_t)i * NBS + 4] : 0.0; }
+                        for (int k = 0; k < 16; ++k) { a[k] = pre.a[k]; b[k] = pre.b[k]; }
+                    } else {
+                        // (entries beyond nb are read from entry 0 and not added below.  `in ? load : 0` became sixteen conditional loads with a wait each - found in the ISA, round 6)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { const int i = base + tid + 64 * k; const int ii = i < nb ? i : 0; a[k] = bs[(size_t)ii * NBS + 3]; b[k] = bs[(size_t)ii * NBS + 4]; }
+                    }
 #pragma unroll
                     for (int k = 0; k < 16; ++k) if (base + tid + 64 * k < nb) { rd += a[k]; rp += b[k]; }
                 }
             }
         rd = su::wave_allreduce(rd, false);
         rp = su::wave_allreduce(rp, false);
-        if (tid == 0) { d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); d.ctrl->resi_iter = d.ctrl->iters; }
+        if (tid == 0) {
+            d.ctrl->resi_dual = rd / N; d.ctrl->resi_pri = sqrt(rp); d.ctrl->resi_iter = iters;
+            if (bc) { bc[0] = rd / N; bc[1] = sqrt(rp); }
+        }
     }
     __syncthreads();
+    if (bc) { out_rd = bc[0]; out_rp = bc[1]; }
 }
 
 extern __shared__ __attribute__((aligned(16))) double smem_su[];
+
+// The kernel arguments of the one-workgroup launches (Dev by value: 1.3 KB = 21 lines of the scalar cache) are read by s_load where the code needs them - a
+// dependent chain of scalar-cache misses through the launch's prologue (~25 s_load / s_waitcnt pairs in k_su<20>, round 6).  One load per line up front, all
+// in flight together: the later ones hit.
+template <int BYTES> __device__ __forceinline__ void warm_kernargs()
+{
+    const int __attribute__((address_space(4))) *kp = (const int __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    int acc = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) acc |= kp[o / 4];
+    asm volatile("" :: "s"(acc));
+}
 
 // Where a step's result goes: the device slot [u | s | info | track out] (one contiguous block starting at out_u), and optionally
 // `mirror` (pinned host memory): the same block written straight into the caller-visible host buffer and published with a
@@ -217,36 +252,15 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
                                         const unsigned long long *ref_flag = nullptr, unsigned long long ref_seq = 0,
                                         const Fin *fin = nullptr, RefWait ref_wait = RefWait())
 {
+#ifdef SU_TRACE
+    const long long t_entry_ = clock64();
+#endif
     const int tid = threadIdx.x;
-    if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
-        if (tid == 0) {
-            d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0;
-        }
-        __syncthreads();
-    } else if (d.ctrl->stop) {
-        if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    // The early stop of rda_solver.py:594 after iteration it-1: the residual partials of the LamMuZ launch are reduced and the verdict taken here
-    // (a tail of the LamMuZ launch that did it instead - rda_opts::lmz_tail, rounds 2-5 - measured 2-4 % slower: tools/experiments/lmz_tail.patch).
-    if (it > 0) {
-        if (d.ctrl->resi_iter != it) reduce_residuals(d, tid);          // (k_finish of a host-driven caller may have reduced them already)
-        const bool stop_now = d.ctrl->resi_dual < d.c.iter_threshold && d.ctrl->resi_pri < d.c.iter_threshold;   // rda_solver.py:594
-        if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + (stop_now ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (stop_now) {
-            __syncthreads();
-            if (tid == 0) d.ctrl->stop = 1;
-            // The step ends here (rda_solver.py:594-596): hand the result over now - the launches still queued behind this one return
-            // at once and k_finish finds the slot written.
-            if (fin && fin->out_u) {
-                publish_result(d, *fin);
-                if (tid == 0) d.ctrl->finished = 1;
-            }
-            return;
-        }
-    }
-    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->hint_par ^= 1; }     // the LamMuZ launches of this iteration start with an empty work list and write the other support buffer
+    // ---- (round 6) ONE trip to memory for everything this launch reads before its first Newton step.  The prologue used to be a chain of dependent
+    //      trips (~1.5 us each: what the previous launch wrote sits in HBM / another XCD's L2): control block (stop?) -> residual partials -> their verdict
+    //      back through the control block -> solver history for the start rule -> the solve's own inputs.  Now: the part of su::Args that follows from the
+    //      kernel arguments alone is filled first, the solve's inputs (su::prefetch), a copy of the control block and the first batch of the residual
+    //      partials are requested together, and the bookkeeping below works on the copy (thread 0 stores what changes; nothing is read back).
     su::Args a;
     a.c.T = d.c.T; a.c.N = d.c.N; a.c.dynamics = d.c.dynamics; a.c.accelerated = d.c.accelerated;
     a.c.dt = d.c.dt; a.c.L = d.c.L; a.c.umax0 = d.c.max_speed[0]; a.c.umax1 = d.c.max_speed[1];
@@ -259,26 +273,67 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     a.ax = coef_arr(d, 0, 0); a.ay = coef_arr(d, 0, 1); a.cb = coef_arr(d, 0, 8); a.gx = coef_arr(d, 0, 4); a.gy = coef_arr(d, 0, 5);
     a.P = d.P; a.Nloc = d.Nloc; a.chunk = d.chunk;
     // the reduced form of the terms (block sums, near masks at the pose table's positions): no pass over the N terms in the set-up
-    if (d.su_pre) { a.bsum = bsum_arr(d, 0); a.bmask = bmask_arr(d, 0); a.J = d.J; a.pose = d.pose; a.pose_ok = d.ctrl->pose_ok; }
+    if (d.su_pre) { a.bsum = bsum_arr(d, 0); a.bmask = bmask_arr(d, 0); a.J = d.J; a.pose = d.pose; }
     // iterations >= 1 are linearised about the previous solution, whose pose table the previous su launch wrote
     if (it > 0) { a.pose = d.pose; a.pose_lin = 1; }
     a.pose_out = d.pose;
     a.d_in = d.dis; a.out_s = d.s; a.out_u = d.u; a.out_d = d.dis;
+    a.lam_keep = d.su_lam_keep;
+    if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) a.warm_shift = 1;
+    su::Pre pre;
+    su::prefetch<TT>(a, pre);
+    Ctrl cl = *d.ctrl;
+    ResPre rpre;
+    const bool res_pre = it > 0 && d.obstacle_num != 0;
+    if (res_pre) residual_prefetch(d, tid, rpre);
+    if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
+        if (tid == 0) {
+            d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
+            d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->resi_iter = 0;
+        }
+        cl.stop = 0; cl.iters = 0; cl.su_status = 0; cl.ipm_iters = 0; cl.lmz_fail = 0; cl.resi_dual = 0; cl.resi_pri = 0; cl.finished = 0; cl.resi_iter = 0;
+    } else if (cl.stop) {
+        if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // The early stop of rda_solver.py:594 after iteration it-1: the residual partials of the LamMuZ launch are reduced and the verdict taken here
+    // (a tail of the LamMuZ launch that did it instead - rda_opts::lmz_tail, rounds 2-5 - measured 2-4 % slower: tools/experiments/lmz_tail.patch).
+    if (it > 0) {
+        double rd = cl.resi_dual, rp = cl.resi_pri;
+        if (cl.resi_iter != it) reduce_residuals(d, tid, cl.iters, rpre, res_pre, smem_su, rd, rp);          // (k_finish of a host-driven caller may have reduced them already)
+        const bool stop_now = rd < d.c.iter_threshold && rp < d.c.iter_threshold;   // rda_solver.py:594
+        if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + (stop_now ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (stop_now) {
+            __syncthreads();
+            if (tid == 0) d.ctrl->stop = 1;
+            // The step ends here (rda_solver.py:594-596): hand the result over now - the launches still queued behind this one return
+            // at once and k_finish finds the slot written.
+            if (fin && fin->out_u) {
+                publish_result(d, *fin);
+                if (tid == 0) d.ctrl->finished = 1;
+            }
+            return;
+        }
+        __syncthreads();                // (the broadcast slot of the verdict is LDS of the solve)
+    }
+    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->hint_par = cl.hint_par ^ 1; }     // the LamMuZ launches of this iteration start with an empty work list and write the other support buffer
+    if (d.su_pre) a.pose_ok = cl.pose_ok;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept; a.first_attempt = d.su_first_attempt;
+    su::Result res; res.rd0 = cl.rd0_tmp;
     a.land = d.su_land; a.land_tol[0] = d.su_land_tol[0]; a.land_tol[1] = d.su_land_tol[1]; a.land_tol[2] = d.su_land_tol[2]; a.land_stat = d.ctrl->land_stat; a.land_rho = d.su_land_rho;
     // warm start of iterations >= 1 from the multipliers of the previous su-solve of THIS step (only if that one converged)
-    if (it > 0 && d.su_warm_mu0 > 0 && !((d.ctrl->su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
-    if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; a.warm_shift = 1; }
-    a.lam_keep = d.su_lam_keep; a.warm_tau = d.su_warm_tau; a.warm_sig = d.su_warm_sig; a.warm_clip = d.su_warm_clip;
+    if (it > 0 && d.su_warm_mu0 > 0 && !((cl.su_status >> (it - 1)) & 1)) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
+    if (it == 0 && d.su_warm_mu0 > 0 && d.su_warm_first) { a.warm_wfl = d.su_warm_wfl; a.warm_mu0 = d.su_warm_mu0; a.warm_cap = d.su_warm_cap; }
+    a.warm_tau = d.su_warm_tau; a.warm_sig = d.su_warm_sig; a.warm_clip = d.su_warm_clip;
     // While consecutive su-problems are close (static scenes: the previous solve needed one or two iterations) the warm attempt starts
     // 1e-6 from the previous solution's active bounds with its multipliers and takes near-full steps: ONE iteration + the
     // convergence pass.  After a solve that needed more (moving obstacles, a changed active set) the moderate start above is used.
     // (su_last / su_probe / su_lam_keep are solver history of the handle: rda_reset clears them, rda_get/set_su_history carry them.)
     bool hard = false;
-    if (a.warm_mu0 > 0 && d.su_easy_max > 0 && d.ctrl->su_last <= d.su_easy_max) {
+    if (a.warm_mu0 > 0 && d.su_easy_max > 0 && cl.su_last <= d.su_easy_max) {
         a.warm_wfl = d.su_easy[0]; a.warm_mu0 = d.su_easy[1]; a.warm_clip = d.su_easy[2]; a.warm_tau = d.su_easy[3]; a.warm_sig = d.su_easy[4];
         a.warm_nopred = d.su_easy_nopred;
-    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && d.ctrl->prev_unconv && d.ctrl->su_hardlike && d.ctrl->su_last < 99) {
+    } else if (a.warm_mu0 > 0 && d.su_hard_mu0 > 0 && cl.prev_unconv && cl.su_hardlike && cl.su_last < 99) {
         // The ADMM of the previous step did not converge (a caller that re-sorts its obstacles every tick, quirk Q5; many moving obstacles)
         // AND consecutive su-problems really are far apart: the last solve's first iterate - the previous solution with its multipliers - had a
         // relative dual residual above su::HARD_RD0.  A warm attempt then does best from a point WELL inside the boxes (slack floor 1) with
@@ -292,22 +347,36 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // Hard regime (many moving obstacles: consecutive su-problems are far apart): a warm attempt then needs MORE iterations than a cold
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
-    if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99 && d.ctrl->su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
-    su::solve<TT>(a, smem_su, ref_wait);
-    __syncthreads();
-    if (tid == 0) {
+    // landing first: the su-problems of ADMM iterations >= 1 (warm: the previous solution of this step with its multipliers)
+    const bool lf_eligible = it > 0 && a.warm_mu0 > 0 && a.land;
+    if (lf_eligible) a.land_first = d.su_land_first == 2 ? (cl.spec_credit >= 0 ? 2 : 1) : d.su_land_first;
+    if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && cl.su_last > d.su_cold_from && cl.su_last < 99 && cl.su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
+#ifdef SU_TRACE
+    a.t_entry = t_entry_;
+#endif
+    su::solve<TT>(a, smem_su, pre, true, res, ref_wait);
+    if (tid == 0) {                     // (from the verdict the solve left in registers and the copy of the control block: stores only)
+        const int su_last = res.status == 0 ? res.iters : 99;
         d.ctrl->iters = it + 1;
-        if (d.ctrl->st_tmp != 0) d.ctrl->su_status |= 1 << it;
-        d.ctrl->ipm_iters += d.ctrl->it_tmp;
-        d.ctrl->su_last = d.ctrl->st_tmp == 0 ? d.ctrl->it_tmp : 99;
-        d.ctrl->su_hardlike = d.ctrl->rd0_tmp > su::HARD_RD0;
-        d.ctrl->su_probe = (d.su_cold_from > 0 && d.ctrl->su_last > d.su_cold_from && d.ctrl->su_last < 99) ? d.ctrl->su_probe + 1 : 0;
+        if (res.status != 0) d.ctrl->su_status = cl.su_status | (1 << it);
+        d.ctrl->ipm_iters = cl.ipm_iters + res.iters;
+        d.ctrl->su_last = su_last;
+        d.ctrl->su_hardlike = res.rd0 > su::HARD_RD0;
+        d.ctrl->su_probe = (d.su_cold_from > 0 && su_last > d.su_cold_from && su_last < 99) ? cl.su_probe + 1 : 0;
         d.ctrl->pose_ok = 0;          // the pose table has moved on; the LamMuZ launch that follows makes the masks that go with it
+        if (lf_eligible && d.su_land_first == 2) {
+            // speculative landings pay where consecutive su-problems keep their active set (static scenes: 50 - 65 % accepted) and cost two landing rounds where
+            // they do not (C4, moving obstacles: none accepted): a handle that keeps failing tries every third eligible solve only; at one success in two the credit grows
+            int cr = cl.spec_credit;
+            if (res.spec == 1) cr = cr + 3 > 6 ? 6 : cr + 3; else if (res.spec == 2) cr -= 2; else if (cr < 0) cr += 1;
+            d.ctrl->spec_credit = cr;
+        }
     }
 }
 
 template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, const double *in_s, const double *in_u, Fin fin)
 {
+    warm_kernargs<sizeof(Dev) + 2 * sizeof(void *) + sizeof(int) + sizeof(Fin)>();
     su_body<TT>(d, it, in_s, in_u, d.ref, d.ref_speed, nullptr, 0, &fin);
 }
 
@@ -315,7 +384,7 @@ template <int TT> __global__ __launch_bounds__(su::NT) void k_su(Dev d, int it, 
 __device__ __forceinline__ void finish_body(const Dev &d, const Fin &f)
 {
     if (d.ctrl->finished) return;                   // (uniform) the launch that ended the step already handed the result over
-    if (!d.ctrl->stop && d.ctrl->resi_iter != d.ctrl->iters) reduce_residuals(d, threadIdx.x);
+    if (!d.ctrl->stop && d.ctrl->resi_iter != d.ctrl->iters) { ResPre none; double rd, rp; reduce_residuals(d, threadIdx.x, d.ctrl->iters, none, false, nullptr, rd, rp); }
     __syncthreads();
     publish_result(d, f);
 }
@@ -1108,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_lammuz_batch(int B, int E, int R, const
 }
 
 // standalone su-solve hook
-template <int TT> __global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a) { su::solve<TT>(a, smem_su); }
+template <int TT> __global__ __launch_bounds__(su::NT) void k_su_hook(su::Args a) { su::Pre pre; su::Result res; su::solve<TT>(a, smem_su, pre, false, res); }
 
 // horizons with a compile-time specialisation of the su kernel (BASELINE configs C1, north star, C5, C4); any other T runs the generic one
 #define RDA_SU_DISPATCH(T, CALL) do { switch (T) { case 10: { constexpr int TT = 10; CALL; } break; case 20: { constexpr int TT = 20; CALL; } break; \
@@ -1155,7 +1224,7 @@ __global__ void k_reset(Dev d)
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
         coef_arr(d, r, 8)[k] = coef_arr(d, r, 3)[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; }      // solver history of the handle
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; d.ctrl->spec_credit = 0; }      // solver history of the handle
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
     if (d.ipf) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.c.N * T; i += gridDim.x * blockDim.x) d.ipf[i] = 0;
 }
@@ -1293,7 +1362,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1; o->su_first_attempt = 0;
-    o->su_land = 1; o->su_land_tol[0] = 1e-3; o->su_land_tol[1] = 1e-4; o->su_land_tol[2] = 1e-5; o->su_land_rho = 1e4;
+    o->su_land_first = 2; o->su_land = 1; o->su_land_tol[0] = 1e-3; o->su_land_tol[1] = 1e-4; o->su_land_tol[2] = 1e-5; o->su_land_rho = 1e4;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1368,6 +1437,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_pre = o.su_pre;
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept; H->d.su_first_attempt = o.su_first_attempt;
+    H->d.su_land_first = o.su_land_first < 0 ? 0 : (o.su_land_first > 2 ? 2 : o.su_land_first);
     H->d.su_land = o.su_land ? 1 : 0; H->d.su_land_rho = o.su_land_rho > 0 ? o.su_land_rho : 1e4;
     { const bool ok = o.su_land_tol[0] > 0 && o.su_land_tol[1] > 0 && o.su_land_tol[2] > 0; const double dflt[3] = {1e-3, 1e-4, 1e-5}; for (int i = 0; i < 3; ++i) H->d.su_land_tol[i] = ok ? o.su_land_tol[i] : dflt[i]; }
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
@@ -1509,7 +1579,7 @@ extern "C" int rda_get_su_history_n(rda_handle *H, int32_t *hist, int n_hist, do
     if (hist && n_hist > 0) {
         Ctrl c;
         HIPCHK(hipMemcpy(&c, H->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike };
+        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike, c.spec_credit };
         for (int i = 0; i < n_hist; ++i) hist[i] = i < RDA_SU_HISTORY_INTS ? all[i] : 0;      // (entries a later version may add read as 0 here)
     }
     if (lam_keep) HIPCHK(hipMemcpy(lam_keep, H->d.su_lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyDeviceToHost));
@@ -1520,13 +1590,13 @@ extern "C" int rda_set_su_history_n(rda_handle *H, const int32_t *hist, int n_hi
     if (!H || n_hist < 0) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     if (hist) {
-        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike };
+        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike, &H->d.ctrl->spec_credit };
         for (int i = 0; i < n_hist && i < RDA_SU_HISTORY_INTS; ++i) HIPCHK(hipMemcpy(dst[i], &hist[i], sizeof(int), hipMemcpyHostToDevice));   // entries the caller does not have keep their value
     }
     if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
     return RDA_OK;
 }
-// the forms without a count: RDA_SU_HISTORY_INTS (= 4 since round 5; round 4: 2) entries - a caller built against an older header must use the _n forms
+// the forms without a count: RDA_SU_HISTORY_INTS (= 5 since round 6; round 5: 4, round 4: 2) entries - a caller built against an older header must use the _n forms
 extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep) { return rda_get_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const double *lam_keep) { return rda_set_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_lmz_history_doubles(rda_handle *H) { return !H ? RDA_ERR_ARG : (H->d.ipw ? 80 * H->d.c.N * H->d.c.T : 0); }
@@ -1565,7 +1635,16 @@ extern "C" int rda_debug_su_land(rda_handle *H, int32_t *out4)
     if (!H || !out4) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     HIPCHK(hipMemcpy(out4, H->d.ctrl->land_stat, 4 * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(H->d.ctrl->land_stat, 0, 4 * sizeof(int)));
+    HIPCHK(hipMemset(H->d.ctrl->land_stat, 0, su::LAND_STATS * sizeof(int)));
+    return RDA_OK;
+}
+
+extern "C" int rda_debug_su_land_n(rda_handle *H, int32_t *out, int n)
+{
+    if (!H || !out || n < 1 || n > su::LAND_STATS) return RDA_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    HIPCHK(hipMemcpy(out, H->d.ctrl->land_stat, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(H->d.ctrl->land_stat, 0, su::LAND_STATS * sizeof(int)));
     return RDA_OK;
 }
 
@@ -2055,6 +2134,7 @@ struct TrackedRefWait {
 template <int TT> __global__ __launch_bounds__(su::NT) void k_su_tracked(Dev d, track::In in, double *path, int L, const double *nom_u, double *step,
                                                                           track::Out *out, unsigned long long seq)
 {
+    warm_kernargs<sizeof(Dev) + sizeof(track::In) + 5 * sizeof(void *)>();
     const int T = d.c.T, ns = 3 * (T + 1), nu = 2 * T;
     track::Ego e;
     e.path = path; e.L = L; e.nom_u = nom_u; e.nom_s = step; e.ref = step + ns + nu; e.speed = step + 2 * ns + nu;

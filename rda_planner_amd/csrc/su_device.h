@@ -55,6 +55,7 @@ constexpr int NT = 256;          // workgroup size
 // relative dual residual above HARD_RD0 started far from its solution; in the hard start the rows of d begin with the barrier HARD_DMU / w
 constexpr double HARD_RD0 = 1e-2, HARD_DMU = 1.0;
 constexpr int NC = 10;           // inequality rows per stage
+constexpr int LAND_STATS = 20;   // counters of Args::land_stat
 // -DSU_TRACE (tools/su_trace.py): lane 0 of every wave logs (event id, clock64) at the phase boundaries of the solve - before and behind every barrier - into the
 // profiling buffer behind the 16 phase counters, [4 waves][TRACE_CAP][2]; every launch starts over, so the buffer holds the LAST launch of the handle
 constexpr int TRACE_CAP = 1024;
@@ -151,10 +152,23 @@ struct Args {
     // star: 10 instead of 21 interior-point iterations per step, every landing accepted); a refused landing (the primal-dual active-set rounds can cycle
     // while borderline rows are still undecided) is tried again at 1e-2 x land_tol, 1e-4 x ... down to the tight tolerances themselves, then never.
     int land = 0; double land_tol[3] = {1e-3, 1e-4, 1e-5}; double land_rho = 1e4;      // (land_rho: penalty of the active rows relative to the largest stage-Hessian entry)
-    int *land_stat = nullptr;        // optional [4]: landings accepted, refused, rounds, interior-point iterations that were landing / verification passes
+    // LANDING FIRST (rda_opts::su_land_first; warm attempts only - the launch sets it for the su-problems of ADMM iterations >= 1, which start from the previous
+    // solution and its multipliers).  1: the first pass of the attempt is a LIGHT one (true measures only - no Hessian bases, no Riccati recursion, no sweep
+    // matrices): the start usually meets the landing's stop as it stands, and the factorisation of that pass was thrown away by the landing round anyway.
+    // 2: ... and when the start does NOT meet the stop the landing is tried all the same - from the start itself, active set = the rows whose KEPT
+    // multiplier exceeds the slack - with at most two rounds: the warm-started active-set method.  What it returns has passed the verification on the
+    // true objective (stationarity with the hinge terms re-evaluated, feasibility, signs), i.e. it IS the vertex - the answer does not depend on how the
+    // active set was guessed; refused: back to the start, the interior point takes over as without the switch (the landing level is not raised).
+    int land_first = 0;
+    double land_first_rd0 = 1.0;     // ... only from a start whose relative dual residual lies below this (40-step loops, accepted / tried: north star 20 / 31 below 1, 3 / 14 above; N = 2000 31 / 63, 1 / 49; C4 0 / 32, 0 / 86)
+    int *land_stat = nullptr;        // optional [LAND_STATS]: landings accepted, refused, rounds, interior-point iterations that were landing / verification passes;
+                                     // [4] speculative landings (land_first = 2) tried, [5] accepted, [6 + k] / [12 + k] tried / accepted by the decade k of the start's relative dual residual (< 1e-4, .. < 1, >= 1)
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
     // fetched at its first use (the stage gradients of the first interior-point pass), once *ref_flag == ref_seq (agent scope)
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
+#ifdef SU_TRACE
+    long long t_entry = 0;           // clock64() at kernel entry (event 99 of the trace: what the launch spends before the solve starts)
+#endif
 };
 
 __device__ __forceinline__ void wsync()
@@ -352,13 +366,91 @@ __device__ __forceinline__ void con_T(const double *x, int t, double &y3, double
 // entry F[i][q] of the stage transition x+ = F y from the packed transpose
 __device__ __forceinline__ double Fel(const double *Ft_t, int i, int q) { return Ft_t[6 * q + i]; }
 
+// Inequality pair (stage t, linear form k) -> thread.  Horizons with a compile-time instantiation up to 32 stages: the form k is WAVE-UNIFORM per
+// half wave - wave 0 holds k = 0 (lanes 0..31) and k = 1 (lanes 32..63), wave 1 the rate pairs k = 3 / 4, wave 2 (lanes 0..31) the distance pair
+// k = 2, lane & 31 = the stage - so the three shapes of a pair's linear form (a control, the distance with its eliminated-variable dot product,
+// a control difference) are branches whole waves skip instead of three divergent passes in every wave (round 6; rounds 3-5 dealt pair
+// p = 5 t + k to thread p: 5 T <= 150 threads in waves 0 / 1 / 2, every wave holding every k).  Other horizons: pair p = 5 t + k on thread p (two per thread beyond NT).
+template <int TT> __device__ __forceinline__ bool pair_map(const int T, const int j, int &t, int &k)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (TT > 0 && TT <= 32) {
+        const int half = lane >> 5, tl = lane & 31;
+        k = wave == 0 ? half : (wave == 1 ? 3 + half : 2);
+        const bool ok = j == 0 && tl < T && (wave < 2 || (wave == 2 && half == 0));
+        t = ok ? tl : 0; if (!ok) k = 0;
+        return ok;
+    }
+    const int pi = tid + j * NT;
+    const bool ok = pi < 5 * T;
+    t = ok ? pi / 5 : 0; k = ok ? pi % 5 : 0;
+    return ok;
+}
+
+// EVERY global input of the set-up, requested in one go into registers (round 6).  The set-up's phases (nominal, linearisation, start of the duals, term
+// sums) each began with a dependent trip to memory - what the LamMuZ launch wrote sits in HBM / other XCDs' L2s: ~1.5 us a trip - and so did the launch's
+// own prologue before the solve (control block, residual partials: rda_hip.hip su_body).  The caller issues prefetch() FIRST, next to its own loads, so that
+// all of them overlap into one trip; a caller that passes no Pre (the rda_su_solve hook) has the solve issue it at its entry.
+// the verdict of a solve once more, in registers of every thread (uniform): the launch's bookkeeping behind the solve then needs no trip to memory
+struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused)
+struct Pre {
+    double vref = 0;
+    double u0 = 0, u1 = 0, d = 0, cp = 0, sp = 0;      // thread t < T: nominal controls / distance, cos / sin of the pose table (pose_lin)
+    double lkp[2] = {0, 0}, lkm[2] = {0, 0};           // kept multipliers of this thread's inequality pairs (+ row, - row)
+    double q0[8], q1[8], q2[8]; unsigned long long mk[8];   // block partials / near masks of the thread's (stage, chunk) slice, first eight blocks
+    double sv = 0, rv = 0;                             // element tid of the nominal states / the reference (3 (T+1) <= 195 < NT)
+    double p0a = 0, p0b = 0;                           // element tid < 2 T of the screening reference: from the pose table / from the nominal states
+};
+template <int TT> __device__ __forceinline__ void prefetch(const Args &a, Pre &p)
+{
+    const Cfg &c = a.c;
+    const int T = TT > 0 ? TT : c.T, tid = threadIdx.x;
+    p.vref = *a.ref_speed;
+    p.d = c.max_sd;
+    if (tid < T) {
+        p.u0 = a.in_u[tid]; p.u1 = a.in_u[T + tid]; if (a.d_in) p.d = a.d_in[tid];
+        if (a.pose_lin) { p.cp = a.pose[4 * tid + 2]; p.sp = a.pose[4 * tid + 3]; }
+    }
+    if (a.lam_keep)
+        for (int j = 0; j < 2; ++j) {
+            int t, kk;
+            if (pair_map<TT>(T, j, t, kk)) {
+                const int ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
+                p.lkp[j] = a.lam_keep[ts * NC + 2 * kk]; p.lkm[j] = a.lam_keep[ts * NC + 2 * kk + 1];
+            }
+        }
+    const int nch = NT / T, rt = tid / nch, rc_ = tid % nch;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p.q0[k] = 0; p.q1[k] = 0; p.q2[k] = 0; p.mk[k] = 0; }
+    if (a.bsum != nullptr && rt < T) {
+        const int J = a.J, KB = (J + nch - 1) / nch;
+        const double *bs = a.bsum + (size_t)rt * J * NBS;
+        const unsigned long long *bm = a.bmask + (size_t)rt * J;
+        // (blocks beyond the slice are read from block 0 and never used: the consumer tests the same bounds.  Zeroing them here made every load of
+        // the batch CONDITIONAL code with a wait of its own - eight dependent trips instead of one, found in the ISA, round 6)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = rc_ + k * nch; const bool in = k < KB && j < J; const int jj = in ? j : 0;
+            p.q0[k] = bs[(size_t)jj * NBS]; p.q1[k] = bs[(size_t)jj * NBS + 1]; p.q2[k] = bs[(size_t)jj * NBS + 2]; p.mk[k] = bm[jj];
+        }
+    }
+    if (tid < 3 * (T + 1)) { p.sv = a.in_s[tid]; if (!a.ref_flag) p.rv = a.ref[tid]; }
+    if (tid < 2 * T) {
+        if (a.bsum != nullptr && a.pose != nullptr) p.p0a = a.pose[4 * (tid % T) + tid / T];
+        p.p0b = a.in_s[(tid / T) * (T + 1) + (tid % T) + 1];
+    }
+}
+
 // The whole solve.  Must be called by all NT threads of the block with `smem` >= lds_bytes(T).  TT > 0 fixes the horizon
 // at compile time (every LDS offset becomes an immediate, the stage loops get constant bounds); TT == 0 reads it from c.T.
 // RefWait: called by all threads before the first use of the reference, when a.ref_flag is set - returns when the reference (a.ref) is complete
 // (k_su_tracked: another workgroup samples it meanwhile; the functor bounds the wait and samples it itself on expiry).
 struct NoRefWait { __device__ __forceinline__ void operator()(double *) const {} };
-template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool solve(const Args &a, double *smem, RefWait ref_wait = RefWait())
+// (pre / have_pre: see Pre.  The struct is handed over by reference and never through a selected pointer, so that its members stay registers)
+template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool solve(const Args &a, double *smem, Pre &pre, const bool have_pre, Result &res, RefWait ref_wait = RefWait())
 {
+    static_assert(3 * (64 + 1) <= NT && 2 * 64 <= NT, "Pre: one element of the nominal states / screening reference per thread");
+    if (!have_pre) prefetch<TT>(a, pre);
     const Cfg &c = a.c;
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lds L; L.carve(smem, T);
@@ -396,8 +488,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #define MS(k) mark(k)
 #define MF(k)
 #endif
+#ifdef SU_TRACE
+    if (a.prof && (threadIdx.x & 63) == 0) { long long *q = a.prof + 16 + ((threadIdx.x >> 6) * TRACE_CAP + trn) * 2; q[0] = 99; q[1] = a.t_entry; ++trn; }
+#endif
     TR(100);
-    const double vref = *a.ref_speed;
+    const double vref = pre.vref;
     // (stage, chunk) mapping of the obstacle reductions
     const int nch = NT / T;                       // chunks per stage (T <= 64 -> nch >= 4)
     const int rt = tid / nch, rc_ = tid % nch;    // this thread's stage and chunk
@@ -407,66 +502,30 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     const int J = masks_in ? a.J : (a.Nloc + GS - 1) / GS;     // GS-slot blocks per shard
     const int KB = (J + nch - 1) / nch;                         // blocks per shard in one thread's slice: j = rc_ + kb nch
 
-    // ---- EVERY global input of the set-up is requested now, into registers: the set-up's phases (nominal, linearisation, start of the
-    //      duals, term sums) each began with a dependent trip to memory (what the LamMuZ launch wrote sits in HBM / other XCDs' L2s:
-    //      ~1.5 us a trip); this way they overlap into one
-    double pf_u0 = 0, pf_u1 = 0, pf_d = c.max_sd, pf_cp = 0, pf_sp = 0;
-    if (tid < T) {
-        pf_u0 = a.in_u[tid]; pf_u1 = a.in_u[T + tid]; if (a.d_in) pf_d = a.d_in[tid];
-        if (a.pose_lin) { pf_cp = a.pose[4 * tid + 2]; pf_sp = a.pose[4 * tid + 3]; }
-    }
-    // Inequality pair (stage t, linear form k) -> thread.  Horizons with a compile-time instantiation up to 32 stages: the form k is WAVE-UNIFORM per
-    // half wave - wave 0 holds k = 0 (lanes 0..31) and k = 1 (lanes 32..63), wave 1 the rate pairs k = 3 / 4, wave 2 (lanes 0..31) the distance pair
-    // k = 2, lane & 31 = the stage - so the three shapes of a pair's linear form (a control, the distance with its eliminated-variable dot product,
-    // a control difference) are branches whole waves skip instead of three divergent passes in every wave (round 6; rounds 3-5 dealt pair
-    // p = 5 t + k to thread p: 5 T <= 150 threads in waves 0 / 1 / 2, every wave holding every k).  Other horizons: pair p = 5 t + k on thread p (two per thread beyond NT).
-    constexpr bool PAIRS_BY_WAVE = TT > 0 && TT <= 32;
-    auto pair_map = [&](const int j, int &t, int &k) -> bool {
-        if (PAIRS_BY_WAVE) {
-            const int half = lane >> 5, tl = lane & 31;
-            k = wave == 0 ? half : (wave == 1 ? 3 + half : 2);
-            const bool ok = j == 0 && tl < T && (wave < 2 || (wave == 2 && half == 0));
-            t = ok ? tl : 0; if (!ok) k = 0;
-            return ok;
-        }
-        const int pi = tid + j * NT;
-        const bool ok = pi < 5 * T;
-        t = ok ? pi / 5 : 0; k = ok ? pi % 5 : 0;
-        return ok;
-    };
-    double pf_lkp[2] = {0, 0}, pf_lkm[2] = {0, 0};           // kept multipliers of this thread's inequality pairs (+ row, - row; see the pair threads below)
-    if (warm)
-        for (int j = 0; j < 2; ++j) {
-            int t, kk;
-            if (pair_map(j, t, kk)) {
-                const int ts = a.warm_shift ? (t + 1 < T ? t + 1 : T - 1) : t;
-                pf_lkp[j] = a.lam_keep[ts * NC + 2 * kk]; pf_lkm[j] = a.lam_keep[ts * NC + 2 * kk + 1];
-            }
-        }
+    // ---- every global input of the set-up was requested by prefetch() (see Pre): the registers it filled
+    const double pf_u0 = pre.u0, pf_u1 = pre.u1, pf_d = pre.d, pf_cp = pre.cp, pf_sp = pre.sp;
+    auto pair_map = [&](const int j, int &t, int &k) -> bool { return su::pair_map<TT>(T, j, t, k); };
+    const double pf_lkp[2] = {warm ? pre.lkp[0] : 0.0, warm ? pre.lkp[1] : 0.0}, pf_lkm[2] = {warm ? pre.lkm[0] : 0.0, warm ? pre.lkm[1] : 0.0};   // kept multipliers of this thread's inequality pairs
     // block partials / near masks of the thread's slice: eight blocks at a time, all their loads in flight together
-    double pq0[8], pq1[8], pq2[8]; unsigned long long pmk[8];
     auto load_batch = [&](int r, int kb0, double *q0, double *q1, double *q2, unsigned long long *mk) {
         const double *bs = a.bsum + r * a.chunk + (size_t)rt * J * NBS;
         const unsigned long long *bm = a.bmask + r * a.chunk + (size_t)rt * J;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int j = rc_ + (kb0 + k) * nch; const bool in = kb0 + k < KB && j < J; const int jj = in ? j : 0;
-            q0[k] = bs[(size_t)jj * NBS]; q1[k] = bs[(size_t)jj * NBS + 1]; q2[k] = bs[(size_t)jj * NBS + 2]; mk[k] = bm[jj];
-            if (!in) { q0[k] = 0; q1[k] = 0; q2[k] = 0; mk[k] = 0; }
+            q0[k] = bs[(size_t)jj * NBS]; q1[k] = bs[(size_t)jj * NBS + 1]; q2[k] = bs[(size_t)jj * NBS + 2]; mk[k] = bm[jj];      // (no zeroing: see prefetch)
         }
     };
-    if (masks_in && ract) load_batch(0, 0, pq0, pq1, pq2, pmk);
 
     // ---- load nominal, reference; linearise -------------------------------------------------
-    for (int i = tid; i < 3 * (T + 1); i += NT) { L.s[i] = a.in_s[i]; if (!a.ref_flag) L.ref[i] = a.ref[i]; }
+    if (tid < 3 * (T + 1)) { L.s[tid] = pre.sv; if (!a.ref_flag) L.ref[tid] = pre.rv; }
     for (int i = tid; i < WN * T; i += NT) L.Wn[i] = 0.0;       // (W[.][2], Minv[.][2] stay zero: d_t is not part of the recursion)
     for (int i = tid; i < FT * T; i += NT) L.Ft[i] = 0.0;       // (the stage threads fill in the non-zeros after the barrier)
     if (tid < T) { L.u[tid] = pf_u0; L.u[T + tid] = pf_u1; }
     // reference positions of the hinge screening: where the masks were made (pose table), else the nominal positions of stages 1..T
-    for (int i = tid; i < 2 * T; i += NT)
-        L.p0[i] = (masks_in && a.pose_ok) ? a.pose[4 * (i % T) + i / T] : a.in_s[(i / T) * (T + 1) + (i % T) + 1];
+    if (tid < 2 * T) L.p0[tid] = (masks_in && a.pose_ok) ? pre.p0a : pre.p0b;
     __syncthreads();
-    MS(0);
+    MS(0); TR(120);
     if (tid < T) {
         int t = tid;
         double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
@@ -496,7 +555,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
     __syncthreads();
-    MS(11);
+    MS(11); TR(131);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
     auto clip_controls = [&](const double clipm) {          // (the nominal controls / distances: the registers prefetched above)
         if (tid < T) {
@@ -558,7 +617,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         }
     };
     rollout();
-    MS(13);
+    MS(13); TR(133);
     // ---- the inequality rows live in REGISTERS.  The 10 rows of a stage are 5 pairs (+val <= e+, -val <= e-) of one linear form each
     // (k = 0 u0, 1 u1, 2 d, 3 u0 - up0, 4 u1 - up1; the rate pairs exist for t >= 1): pair p = 5 t + k is owned by thread p (5 T <= 256
     // for T <= 51; the generic instantiation takes two per thread), which keeps the pair's slacks and multipliers (w+, w-, lam+, lam-),
@@ -710,6 +769,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             }
     } else centre_duals(1e-2, 1.0);
     __syncthreads();                                          // (the roll-out of wave 0 is visible to everybody from here on)
+    TR(140);
     // ---- rotation-consistency penalty -> scalar quadratic per stage from three POSE-INDEPENDENT sums over the terms (see
     // row_term), and the HINGE SCREENING: Im_su = a'p - cb - d >= a'p0 - cb - max_sd - |a| |p - p0|, so a term whose margin at the
     // reference position p0 exceeds DELTA |a| cannot be active while the stage position stays within DELTA of p0.  Both arrive in
@@ -741,7 +801,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                         double q0[8], q1[8], q2[8]; unsigned long long mk[8];
                         if (r == 0 && kb0 == 0) {                 // (prefetched at kernel entry)
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) { q0[k] = pq0[k]; q1[k] = pq1[k]; q2[k] = pq2[k]; mk[k] = pmk[k]; }
+                            for (int k = 0; k < 8; ++k) { q0[k] = pre.q0[k]; q1[k] = pre.q1[k]; q2[k] = pre.q2[k]; mk[k] = pre.mk[k]; }
                         } else load_batch(r, kb0, q0, q1, q2, mk);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) if (kb0 + k < KB && rc_ + (kb0 + k) * nch < J) {
@@ -766,7 +826,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 }
             }
         }
-        MS(3);
+        MS(3); TR(123);
         if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %;
             double cnt = 0;        // and the nominal itself must lie within DELTA of the screening reference
             for (int w = 0; w < MW; ++w) cnt += (double)__popcll(amask[w]);
@@ -776,7 +836,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             if (masks_in) dv = block_reduce(dv, L.red, tid, true);
             if (cnt > 0.3 * (double)a.P * a.Nloc * T || dv > 0.5 * DELTA) screened = false;
         }
-        MS(14);
+        MS(14); TR(134);
         // ---- near list (round 4).  The terms the masks name are fetched ONCE, here, into a compact stage-major list in LDS: (ax, ay, cb, stage).
         // The per-iteration hinge sums (phase 1 below) then take one term per thread - no trip to memory, no loop, no register cache - and
         // one thread per (stage, quantity) adds the stage's contributions up in list order (chunk, then bit: the order of the mask walk).
@@ -803,23 +863,25 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 const int Nl = a.Nloc;
                 for (int w = 0; w < MW; ++w) {
                     unsigned long long m = amask[w];
-                    while (m) {                                   // four loads in flight
-                        size_t o4[4]; int cnt = 0;
-                        while (m && cnt < 4) {
-                            const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
+                    while (m) {                                   // four loads in flight: UNCONDITIONAL ones (a slot without a term repeats the last one's
+                        size_t o4[4]; int cnt = 0, bit = 0;       // address) - a load under `k < cnt` is conditional code with a wait of its own
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (m) { bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1; ++cnt; }
                             const int blk = bit / GS, row = bit % GS;
                             const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
-                            o4[cnt++] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
+                            o4[k] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
                         }
                         double x[4], y[4], cb[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (k < cnt) { x[k] = a.ax[o4[k]]; y[k] = a.ay[o4[k]]; cb[k] = a.cb[o4[k]]; }
+                        for (int k = 0; k < 4; ++k) { x[k] = a.ax[o4[k]]; y[k] = a.ay[o4[k]]; cb[k] = a.cb[o4[k]]; }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) if (k < cnt) { q[0] = x[k]; q[1] = y[k]; q[2] = cb[k]; q[3] = (double)rt; q += 4; }
                     }
                 }
             }
         }
+        TR(141);
         L.part[tid * 9] = saa; L.part[tid * 9 + 1] = sga; L.part[tid * 9 + 2] = sgx;
         __syncthreads();
         if (tid < T) {
@@ -829,7 +891,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             L.Q2[tid] = s0; L.Q1[tid] = 2 * (L.csn[tid] * s2 - L.csn[T + tid] * s1);
         }
     }
-    MS(12);
+    MS(12); TR(132);
     const double mcnt = (double)(6 * T + 4 * (T - 1));
     const double wz = c.dynamics == 2 ? 0.0 : 1.0;
 
@@ -1239,7 +1301,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     int land = 0, land_rounds = 0, land_its = 0;   // (uniform) 0: interior point; 1: this pass is a landing round; 2: this pass verifies one; passes spent on landings
     int land_level = 0;                            // (uniform) landings refused so far in this attempt: k -> stop at 1e-2^k x land_tol (not below the tight tolerances); 99 -> no landing
     double land_rho = 0.0;
-    bool expect_conv = false;
+    bool expect_conv = attempt < 0 && a.land != 0 && a.land_first != 0;      // (landing first: the first pass of a warm attempt is a light one)
+    int spec_dec = 0;                              // decade of the start's relative dual residual (statistics of the speculative landings)
+    bool spec = false, spec_tried = false;         // (uniform) the running landing is a speculative one (land_first = 2); one has been refused in this attempt
     // a landing is refused: back to the interior-point iterate it started from, and on to the tight tolerances (all threads; ends with a barrier)
     auto land_refuse = [&](const bool last) {
         __syncthreads();
@@ -1251,7 +1315,8 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         rollout();
         __syncthreads();
         if (a.land_stat && tid == 0) a.land_stat[1] += 1;
-        land = 0; land_level = last ? 99 : land_level + 1; expect_conv = false;
+        land = 0; expect_conv = false;
+        if (spec) { spec = false; spec_tried = true; res.spec = 2; } else land_level = last ? 99 : land_level + 1;      // (a refused speculation does not use up a landing level)
         pair_rows();
         __syncthreads();
     };
@@ -1265,7 +1330,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         __syncthreads();
         status = 1;
     }
+    TR(150);
     pair_rows();
+    TR(151);
     __syncthreads();
     const int it_cap = attempt < 0 ? a.warm_cap : (attempt == 0 ? SU_COLD_CAP : 100);       // (the cold attempt: 50 since round 5, see the oracle)
     const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
@@ -1275,6 +1342,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         seq += 1;
         if (land != 0) land_its += 1;
         const double heps = (land == 0 && attempt >= 0 && it >= SU_CENTRE_FROM) ? SU_SMOOTH_K * sqrt(mu_prev) : 0.0;      // (a landing works on the true hinge terms)
+        // stop of this pass (also the early verdict of wave 2, phase 4): the tight tolerances, or - while the solve is to be landed - 1e-2^level x land_tol
+        const bool landing = a.land != 0 && land_level < 99;       // (uniform) the interior point stops at 1e-2^level x land_tol and is landed
+        double lsc = 1.0;
+        for (int k = 0; k < land_level && k < 8; ++k) lsc *= 1e-2;
+        const double t_rd = landing ? fmax(lsc * a.land_tol[0], c.tol_rd) : c.tol_rd, t_rp = landing ? fmax(lsc * a.land_tol[1], c.tol_rp) : c.tol_rp,
+                     t_mu = landing ? fmax(lsc * a.land_tol[2], c.tol_mu) : c.tol_mu;
+        const bool land_last = t_rd <= c.tol_rd && t_rp <= c.tol_rp && t_mu <= c.tol_mu;      // a landing refused at the tight tolerances is the last one
         // (rescue phase: the smoothed hinge is non-zero for EVERY term - the oracle sums them all, so does this pass; such iterations are rare)
         const bool screened_now = screened && !(heps > 0);
         // ---- (1)-(3) ONE phase, no barrier inside (round 6; rounds 1-5: hinge contributions | barrier | stage sums | barrier | stage derivatives and
@@ -1312,16 +1386,17 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     for (int w = 0; w < MW; ++w) {
                         unsigned long long m = amask[w];
                         while (m) {
-                            size_t off[4]; int cnt = 0;
-                            while (m && cnt < 4) {
-                                const int bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1;
+                            size_t off[4]; int cnt = 0, bit = 0;           // (unconditional loads, as in the near-list fill of the set-up)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (m) { bit = 64 * w + __ffsll((long long)m) - 1; m &= m - 1; ++cnt; }
                                 const int blk = bit / GS, row = bit % GS;
                                 const int r = a.P == 1 ? 0 : blk / KB, kb = blk - r * KB;
-                                off[cnt++] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
+                                off[q] = r * a.chunk + (size_t)rt * Nl + GS * (rc_ + kb * nch) + row;
                             }
                             double x[4], y[4], cb[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) if (q < cnt) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.cb[off[q]]; }
+                            for (int q = 0; q < 4; ++q) { x[q] = a.ax[off[q]]; y[q] = a.ay[off[q]]; cb[q] = a.cb[off[q]]; }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) if (q < cnt) term(x[q], y[q], cb[q]);
                         }
@@ -1507,7 +1582,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 // (not in a landing round: its rows carry no residual / complementarity, the "measures" of that pass would always pass - and the round NEEDS its
                 // factorisation: an abandoned recursion left the stale factors of the last interior-point iteration in place, found with a dense solve of the
                 // dumped Newton system, scratch of round 6)
-                if (land != 1 && ((rd <= c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= c.tol_mu * sc_) || (rd <= 100 * c.tol_rd * sc_ && rpn_ <= c.tol_rp && mu_ <= 0.1 * c.tol_mu * sc_)))
+                if (land == 0 && ((rd <= t_rd * sc_ && rpn_ <= t_rp && mu_ <= t_mu * sc_) || (rd <= 100 * t_rd * sc_ && rpn_ <= t_rp && mu_ <= 0.1 * t_mu * sc_)))
                     if (lane == 0) __atomic_store_n(flag_stop, seq, __ATOMIC_RELAXED);
             }
         } else {
@@ -1563,17 +1638,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // its own on waves 0 / 1 (2.3 k cycles on the traced timeline, beside the unit sweeps of waves 2 / 3)
             if (!nopred) mb[5] = cb_entry(t, r);
         }
+        TR(12);
         const double rdn = L.red[8], gn = L.red[9], rpn = L.red[10], mu = L.red[11] / mcnt;
         double sc = 1 + gn;
         if (a.dbg && tid == 0) { a.dbg[4 * it] = rdn; a.dbg[4 * it + 1] = rpn; a.dbg[4 * it + 2] = mu; a.dbg[4 * it + 3] = sc; }
         if (a.rd0 && used == 0 && it == 0 && tid == 0) *a.rd0 = rdn / sc;
+        if (used == 0 && it == 0) res.rd0 = rdn / sc;
         // second clause: see the oracle (rounding noise of the dual residual once lam/w reaches 1e10)
-        const bool landing = a.land != 0 && land_level < 99;       // (uniform) the interior point stops at 1e-2^level x land_tol and is landed
-        double lsc = 1.0;
-        for (int k = 0; k < land_level && k < 8; ++k) lsc *= 1e-2;
-        const double t_rd = landing ? fmax(lsc * a.land_tol[0], c.tol_rd) : c.tol_rd, t_rp = landing ? fmax(lsc * a.land_tol[1], c.tol_rp) : c.tol_rp,
-                     t_mu = landing ? fmax(lsc * a.land_tol[2], c.tol_mu) : c.tol_mu;
-        const bool land_last = t_rd <= c.tol_rd && t_rp <= c.tol_rp && t_mu <= c.tol_mu;      // a landing refused at the tight tolerances is the last one
         const bool conv_now = land == 0 && ((rdn <= t_rd * sc && rpn <= t_rp && mu <= t_mu * sc) || (rdn <= 100 * t_rd * sc && rpn <= t_rp && mu <= 0.1 * t_mu * sc));
         if (land == 2) {
             // ---- verdict on a landing round (this pass measured x+ with the hinge terms re-evaluated: rdn = stationarity, rpn = largest violation relative to
@@ -1583,10 +1654,11 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             if (!moved && rdn <= 100 * c.tol_rd * sc) {                      // landed
 #pragma unroll
                 for (int j = 0; j < NPR; ++j) if (p_on[j]) { Plp[j] = fmax(Plp[j], 0.0); Plm[j] = fmax(Plm[j], 0.0); }
-                if (a.land_stat && tid == 0) a.land_stat[0] += 1;
+                if (a.land_stat && tid == 0) { a.land_stat[0] += 1; if (spec) { a.land_stat[5] += 1; a.land_stat[12 + spec_dec] += 1; } }
+                if (spec) res.spec = 1;
                 status = 0; break;
             }
-            if (land_rounds >= 4 || !(rdn == rdn)) { land_refuse(land_last); continue; }      // refused
+            if (land_rounds >= (spec ? 2 : 4) || !(rdn == rdn)) { land_refuse(land_last); continue; }      // refused
             // next round: rows move in / out of the active set by their signs (primal-dual active set) and the model is solved again from the SAME point -
             // a full step along a weakly curved direction may have left the boxes by far, x+ is then no place to linearise the hinge terms at; a round whose
             // set did not move was not stationary because a hinge term switched: that one is linearised again at x+ (= the oracle's su_land)
@@ -1627,7 +1699,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                     if (p_ok[j]) { const int o = 3 * T + 10 * p_t[j] + 2 * p_k[j]; L.acc[o] = p_on[j] ? Plp[j] : 0.0; L.acc[o + 1] = p_on[j] ? Plm[j] : 0.0; }
             }
         }
-        if (conv_now) {
+        // landing first, mode 2: the light first pass of a warm attempt did not meet the stop - land from the start all the same (see Args::land_first)
+        const bool spec_now = !conv_now && expect_conv && land == 0 && landing && a.land_first == 2 && attempt < 0 && it == 0 && !spec_tried && rdn < a.land_first_rd0 * sc && rpn == rpn;
+        if (conv_now || spec_now) {
             if (screened) {        // the positions must have stayed within DELTA of the screening reference
                 double dv = 0;
                 if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
@@ -1647,12 +1721,20 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #pragma unroll
                 for (int j = 0; j < NPR; ++j) {
                     Swp[j] = Pwp[j]; Swm[j] = Pwm[j]; Slp[j] = Plp[j]; Slm[j] = Plm[j];
-                    Lap[j] = p_on[j] && Plp[j] > Pwp[j]; Lam[j] = p_on[j] && Plm[j] > Pwm[j];
+                    // (a speculative landing reads the set off the KEPT multipliers: the floors of the warm start make every row within sqrt(mu0) of its bound look active)
+                    Lap[j] = p_on[j] && (spec_now ? pf_lkp[j] : Plp[j]) > Pwp[j]; Lam[j] = p_on[j] && (spec_now ? pf_lkm[j] : Plm[j]) > Pwm[j];
                 }
                 land_rho = a.land_rho * fmax(1.0, fmax(L.pv[5], 2 * c.wu + c.eps_u));
-                land = 1; land_rounds = 1; expect_conv = false;
+                land = 1; land_rounds = 1; expect_conv = false; spec = spec_now;
+                if (spec_now) {
+                    const double q = rdn / sc;
+                    spec_dec = q < 1e-4 ? 0 : (q < 1e-3 ? 1 : (q < 1e-2 ? 2 : (q < 1e-1 ? 3 : (q < 1.0 ? 4 : 5))));
+                    if (a.land_stat && tid == 0) { a.land_stat[4] += 1; a.land_stat[6 + spec_dec] += 1; }
+                }
+                TR(13);
                 __syncthreads();
                 land_rows(land_rho);
+                TR(14);
                 __syncthreads();
                 continue;
             }
@@ -1914,6 +1996,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         a.pose_out[4 * tid] = px; a.pose_out[4 * tid + 1] = py; a.pose_out[4 * tid + 2] = cp; a.pose_out[4 * tid + 3] = sp;
     }
     if (tid == 0) { *a.status = status; *a.ipm_iters = used; }
+    res.status = status; res.iters = used;
     mark(10); TR(104);
     if (prof_on && tid == 0) for (int k = 0; k < 16; ++k) a.prof[k] += pacc[k];
     return true;

@@ -34,11 +34,12 @@ def run(name, n_obs, T, moving, steps, ordered, **opts):
         u, info = gpu.control(state.copy(), 4.0, list(cur))
         ipm += info["su_ipm_iters"]; solves += info["iters"]
         state = sc.kinematic_step(state, u, car_t, 0.1)
-    st = (C.c_int32 * 4)()
-    gpu.rda._be.api.lib.rda_debug_su_land(gpu.rda._be.handle, st)
+    st = (C.c_int32 * 20)()
+    gpu.rda._be.api.lib.rda_debug_su_land_n(gpu.rda._be.handle, st, 20)
     st = list(st)
-    print(f"{name:10s} ordered={int(ordered)} {str(opts):60s}: {solves / steps:4.2f} su-solves/step, interior-point its/solve {ipm / solves:5.2f}, "
-          f"landings accepted {st[0]} refused {st[1]} rounds/solve {st[2] / solves:4.2f} landing passes/solve {st[3] / solves:4.2f}", flush=True)
+    print(f"{name:10s} ordered={int(ordered)} {str(opts):40s}: {solves / steps:4.2f} su-solves/step, interior-point its/solve {ipm / solves:5.2f}, "
+          f"landings accepted {st[0]} refused {st[1]} rounds/solve {st[2] / solves:4.2f} landing passes/solve {st[3] / solves:4.2f}; speculative tried {st[4]} accepted {st[5]}, "
+          f"by decade of the start's rd0 (<1e-4 .. >=1): tried {st[6:12]} accepted {st[12:18]}", flush=True)
 
 
 if __name__ == "__main__":
@@ -48,4 +49,5 @@ if __name__ == "__main__":
     for name, n_obs, T, moving in (("NS", 200, 20, False), ("N=20", 20, 20, False), ("N=2000", 2000, 20, False), ("C4", 200, 30, True), ("C5shape", 100, 25, False)):
         for ordered in (True, False):
             run(name, n_obs, T, moving, a.steps, ordered, su_land=0)
-            run(name, n_obs, T, moving, a.steps, ordered, su_land=1)
+            run(name, n_obs, T, moving, a.steps, ordered, su_land_first=1)
+            run(name, n_obs, T, moving, a.steps, ordered, su_land_first=2)
