@@ -659,7 +659,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     // stop flag, half-spaces, pose / duals, support cache, slot -> obstacle, remembered support): everything a row reads is requested
     // here, in two batches, before the first of them is waited for.  The throughput forms (modes 1, 2) keep their loads where the
     // values are used: there the registers are worth more than the latency (three waves per SIMD hide it).
-    struct Early { double px, py, cs, sn, xi0, xi1, zeta, dbar, prev, vtx[4]; int cone, src, hpar, hint, npv, nlv; unsigned char lamc[3]; } ey;
+    struct Early { double px, py, cs, sn, xi0, xi1, zeta, dbar, prev, vtx[4], A, b, G, h; int cone, src, hpar, hint, npv, nlv; unsigned char lamc[3]; } ey;
     if (MODE == 0) {
         const int nl0 = jb * GS + wv * 4 + row, nl = nl0 < d.Nlive ? nl0 : 0, n = d.rank * d.Nloc + nl;
         ey.src = (d.slot_src && n < d.src_used) ? d.slot_src[n] : -1;
@@ -674,7 +674,16 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
         const size_t o = drow(d, n, t + 1), zi = drow(d, n, t), oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
         ey.px = ps[0]; ey.py = ps[1]; ey.cs = ps[2]; ey.sn = ps[3];
         ey.xi0 = d.xi[2 * o]; ey.xi1 = d.xi[2 * o + 1]; ey.zeta = d.zeta[zi]; ey.dbar = d.dis[t]; ey.cone = d.cone[n];
-        ey.prev = gl < E ? d.lam[o * E + gl] : (gl < E + R ? d.mu[o * R + gl - E] : 0.0);
+        // (ONE unconditional load through a selected address: as `gl < E ? lam : (gl < E + R ? mu : 0)` the two loads shared their destination register and the
+        // second one waited - vmcnt(0), in the middle of the batch - for the first; lanes beyond E + R read lam[0] and are zeroed where `prev` is used.  Round 6)
+        ey.prev = *(gl < E ? &d.lam[o * E + gl] : (gl < E + R ? &d.mu[o * R + gl - E] : &d.lam[o * E]));
+        // half-spaces of the row and the robot's (G, h): they used to be fetched one after the other behind this batch - load, vmcnt(0), LDS store, four times
+        // (G, h, A, b): four dependent trips to the L2 in a launch that IS one wave's dependent chain
+        {
+            const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
+            ey.A = d.A[ao * 2 + (gl < 2 * E ? gl : 0)]; ey.b = d.b[ao + (gl < E ? gl : 0)];
+            ey.G = d.G[(int)threadIdx.x < 2 * R ? threadIdx.x : 0]; ey.h = d.h[(int)threadIdx.x < R ? threadIdx.x : 0];
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) ey.lamc[k] = gl + 16 * k < 40 ? d.oc_lamc[oc * 40 + gl + 16 * k] : (unsigned char)0;
 #pragma unroll
@@ -685,8 +694,13 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
             ey.hint = d.hint[(size_t)(ey.hpar ^ 1) * d.hint_len + (size_t)tr * d.hint_stride + key];
         }
     }
-    for (int i = threadIdx.x; i < 2 * R; i += 64 * WPB) rb.G[i >> 1][i & 1] = d.G[i];
-    for (int i = threadIdx.x; i < R; i += 64 * WPB) rb.h[i] = d.h[i];
+    if (MODE == 0) {                                          // (2 R <= 16 < the workgroup: one element per thread, from the batch above)
+        if ((int)threadIdx.x < 2 * R) rb.G[threadIdx.x >> 1][threadIdx.x & 1] = ey.G;
+        if ((int)threadIdx.x < R) rb.h[threadIdx.x] = ey.h;
+    } else {
+        for (int i = threadIdx.x; i < 2 * R; i += 64 * WPB) rb.G[i >> 1][i & 1] = d.G[i];
+        for (int i = threadIdx.x; i < R; i += 64 * WPB) rb.h[i] = d.h[i];
+    }
     for (int i = threadIdx.x; i < 40; i += 64 * WPB) rb.muc[i] = d.muc[i];
     for (int i = threadIdx.x; i < 56; i += 64 * WPB) (&rb.rv[0][0])[i] = (&d.rv[0][0])[i];
     if (threadIdx.x == 0) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
@@ -703,8 +717,13 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
     const size_t ao = ((size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0)) * E;
-    if (gl < 2 * E) W.A[gl >> 1][gl & 1] = d.A[ao * 2 + gl];
-    if (gl < E) W.b[gl] = d.b[ao + gl];
+    if (MODE == 0) {
+        if (gl < 2 * E) W.A[gl >> 1][gl & 1] = ey.A;
+        if (gl < E) W.b[gl] = ey.b;
+    } else {
+        if (gl < 2 * E) W.A[gl >> 1][gl & 1] = d.A[ao * 2 + gl];
+        if (gl < E) W.b[gl] = d.b[ao + gl];
+    }
     __syncthreads();
     LMZ_CLK(1);
     lmz::Params P;
@@ -718,7 +737,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     P.kappa0 = zeta - dbar; P.ro2 = d.c.ro2; P.delta = d.c.delta;
     lmz::Sol best;
     double prev = 0.0;
-    if (MODE == 0) prev = ey.prev;
+    if (MODE == 0) prev = gl < E + R ? ey.prev : 0.0;
     else if (gl < E) prev = d.lam[o * E + gl];
     else if (gl < E + R) prev = d.mu[o * R + gl - E];
     // non-finite data: see lammuz_body (the row solves harmless stand-in data, keeps its previous duals, residual inf)
