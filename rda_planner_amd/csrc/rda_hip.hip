@@ -286,6 +286,10 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     ResPre rpre;
     const bool res_pre = it > 0 && d.obstacle_num != 0;
     if (res_pre) residual_prefetch(d, tid, rpre);
+#ifdef SU_TRACE
+    long long t_mark_[4] = {0, 0, 0, 0};
+    t_mark_[0] = clock64();                  // every load of the prologue has been requested
+#endif
     if (it == 0) {                      // first su-problem of a step: the step's bookkeeping starts here (no separate launch)
         if (tid == 0) {
             d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
@@ -296,6 +300,9 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
         if (fin && fin->verdict && tid == 0) __hip_atomic_store(fin->verdict, 2 * fin->vseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
+#ifdef SU_TRACE
+    t_mark_[1] = clock64();                  // the copy of the control block has arrived (stop flag tested)
+#endif
     // The early stop of rda_solver.py:594 after iteration it-1: the residual partials of the LamMuZ launch are reduced and the verdict taken here
     // (a tail of the LamMuZ launch that did it instead - rda_opts::lmz_tail, rounds 2-5 - measured 2-4 % slower: tools/experiments/lmz_tail.patch).
     if (it > 0) {
@@ -316,6 +323,9 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
         }
         __syncthreads();                // (the broadcast slot of the verdict is LDS of the solve)
     }
+#ifdef SU_TRACE
+    t_mark_[2] = clock64();                  // residuals reduced, verdict taken
+#endif
     if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->hint_par = cl.hint_par ^ 1; }     // the LamMuZ launches of this iteration start with an empty work list and write the other support buffer
     if (d.su_pre) a.pose_ok = cl.pose_ok;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept; a.first_attempt = d.su_first_attempt;
@@ -352,7 +362,8 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     if (lf_eligible) a.land_first = d.su_land_first == 2 ? (cl.spec_credit >= 0 ? 2 : 1) : d.su_land_first;
     if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && cl.su_last > d.su_cold_from && cl.su_last < 99 && cl.su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
 #ifdef SU_TRACE
-    a.t_entry = t_entry_;
+    a.t_entry = t_entry_; t_mark_[3] = clock64();
+    for (int k = 0; k < 4; ++k) a.t_mark[k] = t_mark_[k];
 #endif
     su::solve<TT>(a, smem_su, pre, true, res, ref_wait);
     if (tid == 0) {                     // (from the verdict the solve left in registers and the copy of the control block: stores only)

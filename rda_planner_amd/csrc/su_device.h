@@ -168,6 +168,7 @@ struct Args {
     const unsigned long long *ref_flag = nullptr; unsigned long long ref_seq = 0;
 #ifdef SU_TRACE
     long long t_entry = 0;           // clock64() at kernel entry (event 99 of the trace: what the launch spends before the solve starts)
+    long long t_mark[4] = {0, 0, 0, 0};   // ... and at four points of the launch's prologue (events 95 .. 98)
 #endif
 };
 
@@ -489,7 +490,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #define MF(k)
 #endif
 #ifdef SU_TRACE
-    if (a.prof && (threadIdx.x & 63) == 0) { long long *q = a.prof + 16 + ((threadIdx.x >> 6) * TRACE_CAP + trn) * 2; q[0] = 99; q[1] = a.t_entry; ++trn; }
+    if (a.prof && (threadIdx.x & 63) == 0) { long long *q = a.prof + 16 + ((threadIdx.x >> 6) * TRACE_CAP + trn) * 2; q[0] = 99; q[1] = a.t_entry; ++trn; for (int k = 0; k < 4; ++k) { q += 2; q[0] = 95 + k; q[1] = a.t_mark[k]; ++trn; } }
 #endif
     TR(100);
     const double vref = pre.vref;

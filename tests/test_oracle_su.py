@@ -264,13 +264,23 @@ def test_stop_tolerance_vs_weakly_active_rows(orc, name):
         st_d, _, u_d, _, it_d = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
         orc.lib.orc_set_su_tol(1e-8, 1e-8, 1e-8)
         st_e, _, u_e, _, it_e = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+        # round 6: the LANDED solve (the default; this module switches it off) - the interior point stops at the 1e-3 class, the vertex is computed exactly
+        orc.lib.orc_set_su_tol(1e-9, 1e-10, 1e-11)
+        orc.lib.orc_set_su_land(1)
+        st_l, _, u_l, _, it_l = hp.su_solve(orc.lib.orc_su_solve, cfg, si)
+        landed = orc.lib.orc_get_su_landed()
     finally:
         orc.lib.orc_set_su_tol(1e-9, 1e-10, 1e-11)
+        orc.lib.orc_set_su_land(0)
     assert st_t == 0 and st_d == 0 and st_e == 0 and it_e <= it_d <= it_t
     d_def, d_ecos = float(np.abs(u_d - u_t).max()), float(np.abs(u_e - u_t).max())
-    print(f"{name}: default stop {it_d} iterations, |u - u_tight| {d_def:.2e}; ECOS-class stop {it_e} iterations, {d_ecos:.2e}; tight {it_t}")
-    assert d_def <= 5e-5 < hp.TOL_U
+    d_land = float(np.abs(u_l - u_t).max())
+    print(f"{name}: default stop {it_d} iterations, |u - u_tight| {d_def:.2e}; ECOS-class stop {it_e} iterations, {d_ecos:.2e}; tight {it_t}; "
+          f"landed ({landed}) after {it_l} interior-point iterations: {d_land:.2e}")
+    assert d_def <= 5e-5 < hp.TOL_U_IP
     assert d_ecos >= 2e-4
+    # the landed answer lies where the tight interior point converges to (which is itself 1e-15 / lam* ~ 1e-11 short of the vertex), with FEWER iterations than the default stop
+    assert st_l == 0 and landed == 1 and d_land <= 5e-8 < hp.TOL_U and it_l < it_d
 
 
 def test_warm_started_su_reaches_the_cold_solution():
