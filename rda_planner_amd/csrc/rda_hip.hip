@@ -49,6 +49,7 @@ struct Ctrl {
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
     double rd0_tmp;               // ... that residual, written by the solve
+    int land_hard;                // the last su-solve's landing took three or more rounds (many rows / hinge terms still undecided at the 1e-3-class stop: moving obstacles): the next solve's interior point runs to 1e-2 x su_land_tol before it is landed (C4: 2.7 -> rounds per solve, +4 % steps/s; north star: 1.1 - 1.3 rounds, unaffected): solver history
     int spec_credit;              // su_land_first = 2: speculative landings are tried while this is >= 0 (+3 per accepted one, capped at 6; -2 per refused one; +1 per eligible solve that had to skip): solver history
     int land_stat[su::LAND_STATS];  // su_land: landings accepted, refused, rounds, passes spent on landings, speculative landings (rda_debug_su_land, rda_debug_su_land_n)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
@@ -358,6 +359,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
     // landing first: the su-problems of ADMM iterations >= 1 (warm: the previous solution of this step with its multipliers)
+    a.land_level0 = (a.land && cl.land_hard) ? 1 : 0;
     const bool lf_eligible = it > 0 && a.warm_mu0 > 0 && a.land;
     if (lf_eligible) a.land_first = d.su_land_first == 2 ? (cl.spec_credit >= 0 ? 2 : 1) : d.su_land_first;
     if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && cl.su_last > d.su_cold_from && cl.su_last < 99 && cl.su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
@@ -375,6 +377,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
         d.ctrl->su_hardlike = res.rd0 > su::HARD_RD0;
         d.ctrl->su_probe = (d.su_cold_from > 0 && su_last > d.su_cold_from && su_last < 99) ? cl.su_probe + 1 : 0;
         d.ctrl->pose_ok = 0;          // the pose table has moved on; the LamMuZ launch that follows makes the masks that go with it
+        if (a.land && res.status == 0) d.ctrl->land_hard = res.land_rounds >= 3;
         if (lf_eligible && d.su_land_first == 2) {
             // speculative landings pay where consecutive su-problems keep their active set (static scenes: 50 - 65 % accepted) and cost two landing rounds where
             // they do not (C4, moving obstacles: none accepted): a handle that keeps failing tries every third eligible solve only; at one success in two the credit grows
@@ -1254,7 +1257,7 @@ __global__ void k_reset(Dev d)
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
         coef_arr(d, r, 8)[k] = coef_arr(d, r, 3)[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; d.ctrl->spec_credit = 0; }      // solver history of the handle
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; d.ctrl->spec_credit = 0; d.ctrl->land_hard = 0; }      // solver history of the handle
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
     if (d.ipf) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.c.N * T; i += gridDim.x * blockDim.x) d.ipf[i] = 0;
 }
@@ -1609,7 +1612,7 @@ extern "C" int rda_get_su_history_n(rda_handle *H, int32_t *hist, int n_hist, do
     if (hist && n_hist > 0) {
         Ctrl c;
         HIPCHK(hipMemcpy(&c, H->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike, c.spec_credit };
+        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike, c.spec_credit, c.land_hard };
         for (int i = 0; i < n_hist; ++i) hist[i] = i < RDA_SU_HISTORY_INTS ? all[i] : 0;      // (entries a later version may add read as 0 here)
     }
     if (lam_keep) HIPCHK(hipMemcpy(lam_keep, H->d.su_lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyDeviceToHost));
@@ -1620,13 +1623,13 @@ extern "C" int rda_set_su_history_n(rda_handle *H, const int32_t *hist, int n_hi
     if (!H || n_hist < 0) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     if (hist) {
-        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike, &H->d.ctrl->spec_credit };
+        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike, &H->d.ctrl->spec_credit, &H->d.ctrl->land_hard };
         for (int i = 0; i < n_hist && i < RDA_SU_HISTORY_INTS; ++i) HIPCHK(hipMemcpy(dst[i], &hist[i], sizeof(int), hipMemcpyHostToDevice));   // entries the caller does not have keep their value
     }
     if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
     return RDA_OK;
 }
-// the forms without a count: RDA_SU_HISTORY_INTS (= 5 since round 6; round 5: 4, round 4: 2) entries - a caller built against an older header must use the _n forms
+// the forms without a count: RDA_SU_HISTORY_INTS (= 6 since round 6; round 5: 4, round 4: 2) entries - a caller built against an older header must use the _n forms
 extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep) { return rda_get_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const double *lam_keep) { return rda_set_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_lmz_history_doubles(rda_handle *H) { return !H ? RDA_ERR_ARG : (H->d.ipw ? 80 * H->d.c.N * H->d.c.T : 0); }

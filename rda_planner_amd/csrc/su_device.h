@@ -160,6 +160,7 @@ struct Args {
     // true objective (stationarity with the hinge terms re-evaluated, feasibility, signs), i.e. it IS the vertex - the answer does not depend on how the
     // active set was guessed; refused: back to the start, the interior point takes over as without the switch (the landing level is not raised).
     int land_first = 0;
+    int land_level0 = 0;             // first landing level of the attempts (0: the interior point stops at land_tol; 1: at 1e-2 x land_tol): the launch raises it after a solve whose landing took three or more rounds
     double land_first_rd0 = 1.0;     // ... only from a start whose relative dual residual lies below this (40-step loops, accepted / tried: north star 20 / 31 below 1, 3 / 14 above; N = 2000 31 / 63, 1 / 49; C4 0 / 32, 0 / 86)
     int *land_stat = nullptr;        // optional [LAND_STATS]: landings accepted, refused, rounds, interior-point iterations that were landing / verification passes;
                                      // [4] speculative landings (land_first = 2) tried, [5] accepted, [6 + k] / [12 + k] tried / accepted by the decade k of the start's relative dual residual (< 1e-4, .. < 1, >= 1)
@@ -393,7 +394,7 @@ template <int TT> __device__ __forceinline__ bool pair_map(const int T, const in
 // own prologue before the solve (control block, residual partials: rda_hip.hip su_body).  The caller issues prefetch() FIRST, next to its own loads, so that
 // all of them overlap into one trip; a caller that passes no Pre (the rda_su_solve hook) has the solve issue it at its entry.
 // the verdict of a solve once more, in registers of every thread (uniform): the launch's bookkeeping behind the solve then needs no trip to memory
-struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused)
+struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; int land_rounds = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused; land_rounds: rounds of the non-speculative landings of the solve)
 struct Pre {
     double vref = 0;
     double u0 = 0, u1 = 0, d = 0, cp = 0, sp = 0;      // thread t < T: nominal controls / distance, cos / sin of the pose table (pose_lin)
@@ -1300,7 +1301,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     const bool safe = attempt == 1;                // (uniform) the last-resort iteration, see SU_SAFE_*
     double al_prev = 0.0;
     int land = 0, land_rounds = 0, land_its = 0;   // (uniform) 0: interior point; 1: this pass is a landing round; 2: this pass verifies one; passes spent on landings
-    int land_level = 0;                            // (uniform) landings refused so far in this attempt: k -> stop at 1e-2^k x land_tol (not below the tight tolerances); 99 -> no landing
+    int land_level = a.land_level0;                // (uniform) landings refused so far in this attempt (+ the level the launch starts at): k -> stop at 1e-2^k x land_tol (not below the tight tolerances); 99 -> no landing
     double land_rho = 0.0;
     bool expect_conv = attempt < 0 && a.land != 0 && a.land_first != 0;      // (landing first: the first pass of a warm attempt is a light one)
     int spec_dec = 0;                              // decade of the start's relative dual residual (statistics of the speculative landings)
@@ -1556,12 +1557,16 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // |reduced gradient|_inf is taken from it.
             const bool on = lane < T;
             const double *A = &L.Ak[9 * (on ? lane : 0)], *B = &L.Bk[6 * (on ? lane : 0)], *g = &L.gst[8 * (on ? lane : 0)];
+            // (round 6) the suffix sums as total - inclusive prefix + own value, the prefix by DPP moves (row_shr 1, 2, 4, 8, then the row totals across with
+            // row_bcast:15 / :31 - the roll-out's scan) and the neighbour's value by wave_shl:1 - rounds 1-5: six __shfl_down = ds_bpermute round trips per scan,
+            // three dependent scans per pass, on the critical path of every light pass.  Another summation order: rounding level of a termination measure.
             auto suffix = [&](double v) {
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { double o = __shfl_down(v, off, 64); if (lane + off < 64) v += o; }
-                return v;
+                double q = v;
+                q += dpp_f64<0x111>(q); q += dpp_f64<0x112>(q); q += dpp_f64<0x114>(q); q += dpp_f64<0x118>(q);
+                q += dpp_f64<0x142, 0xA>(q); q += dpp_f64<0x143, 0xC>(q);
+                return v + (bcast(q, 63) - q);
             };
-            auto next = [&](double v) { double o = __shfl_down(v, 1, 64); return lane < 63 ? o : 0.0; };
+            auto next = [&](double v) { return dpp_f64<0x130>(v); };      // wave_shl:1: lane i takes lane i + 1's value, lane 63 reads 0
             const double s0 = suffix(on ? g[0] : 0.0), s1 = suffix(on ? g[1] : 0.0);
             const double p0 = next(s0), p1 = next(s1);
             const double s2 = suffix(on ? g[2] + A[2] * p0 + A[5] * p1 : 0.0);
@@ -1651,6 +1656,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // ---- verdict on a landing round (this pass measured x+ with the hinge terms re-evaluated: rdn = stationarity, rpn = largest violation relative to
             //      1 + |e|, mu mcnt = sum of the negative parts of the multipliers; same thresholds as the oracle's su_land)
             if (a.land_stat && tid == 0) a.land_stat[2] += 1;
+            if (!spec) res.land_rounds += 1;
             const bool moved = rpn > 1e-11 || mu * mcnt > 1e-9 * sc;
             if (!moved && rdn <= 100 * c.tol_rd * sc) {                      // landed
 #pragma unroll
