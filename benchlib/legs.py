@@ -10,6 +10,21 @@ import time
 import numpy as np
 
 from .context import ROOT
+
+# CPU affinity of this process when the module is imported - before libgomp is loaded.  With OMP_PROC_BIND=close (bench.py sets it for the cpu_baseline
+# leg) libgomp binds the MAIN thread of this process to its first place once the oracle's first parallel region has run; a sub-process started afterwards
+# inherits that one-core mask, and its own 16 OpenMP threads then share a core: the cpu_baseline of the `sizes` legs read 5 - 7 x too low in rounds 4 - 5
+# (C4: 8.1 steps/s in the size leg, 56 in a stand-alone run of the same command).  The size legs are started with the original mask.
+_AFFINITY0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+
+def _restore_affinity():
+    if _AFFINITY0:
+        try:
+            os.sched_setaffinity(0, _AFFINITY0)
+        except OSError:
+            pass
+
 from .workload import build_workload, record_trace
 
 
@@ -420,7 +435,7 @@ def sizes(budget_s, script):
             continue
         try:
             pr = subprocess.run([sys.executable, script, "--gpus", "1", "--size-leg", "--cpu-threads", "16"] + extra,
-                                capture_output=True, text=True, timeout=left + 20.0, env=env)
+                                capture_output=True, text=True, timeout=left + 20.0, env=env, preexec_fn=_restore_affinity)
             line = [ln for ln in pr.stdout.splitlines() if ln.startswith("DETAIL {")]      # the sub-run's full dictionary (its last line is the compact one)
             j = json.loads(line[-1][len("DETAIL "):])
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_ms_per_step", "mean_admm_iters", "max_du_vs_python_closed_loop",
