@@ -102,7 +102,9 @@ struct Dev {
     double *G, *h;
     double *A, *b; int *cone;                 // [N][nt][E][2], [N][nt][E], [N]
     // per (slot, time slot) candidate list and vertices of the staged obstacle (pose independent): k_prepare, at upload
-    unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][40], [N*nt][28][2], [N*nt][2] = (npv, nlv)
+    unsigned char *oc_lamc; double *oc_vtx; int *oc_cnt;      // [N*nt][oc_ls], [N*nt][oc_vs], [N*nt][2] = (npv, nlv)
+    int oc_ls, oc_vs;        // strides of the two tables: 1 + E + E (E-1)/2 candidates (rounded up to 4), E (E-1) vertex coordinates - NOT the 40 / 56 of E = 8 (round 6: with moving
+                             // obstacles the tables are per (slot, STAGE): 496 B a row against 96 B of half-spaces; E = 4: 128 B)
     // Remembered supports (candidate index of the last max-clearance optimum, -1 = none) - a pure cache: whatever it holds is only the
     // first candidate of a row, which is accepted on its certificate alone.  Two buffers of hint_len ints, [T][hint_stride] each: a
     // LamMuZ launch reads the one the previous executed launch wrote and writes the other (Ctrl::hint_par, flipped by the su launch of
@@ -430,8 +432,8 @@ __device__ __forceinline__ void prepare_body(const Dev &d, lmz::WaveLDS *wl)
     lmz::wave_sync();
     lmz::build_lists(W, E, d.cone[n], lane);
     lmz::wave_sync();
-    if (lane < 40) d.oc_lamc[(size_t)w * 40 + lane] = W.lamc[lane];
-    if (lane < 56) d.oc_vtx[(size_t)w * 56 + lane] = (&W.vtx[0][0])[lane];
+    if (lane < d.oc_ls) d.oc_lamc[(size_t)w * d.oc_ls + lane] = W.lamc[lane];
+    if (lane < d.oc_vs) d.oc_vtx[(size_t)w * d.oc_vs + lane] = (&W.vtx[0][0])[lane];
     if (lane == 0) { d.oc_cnt[2 * w] = W.npv; d.oc_cnt[2 * w + 1] = W.nlv; }
 }
 __global__ __launch_bounds__(256) void k_prepare(Dev d) { __shared__ lmz::WaveLDS wl[4]; prepare_body(d, wl); }
@@ -574,8 +576,8 @@ __device__ __forceinline__ void lammuz_body(const Dev &d, const int block, const
     lmz::pose_products(W, P, lane);
     {   // candidate list and vertices of this slot from the upload-time cache
         const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
-        if (lane < 40) W.lamc[lane] = d.oc_lamc[oc * 40 + lane];
-        if (lane < 56) (&W.vtx[0][0])[lane] = d.oc_vtx[oc * 56 + lane];
+        if (lane < d.oc_ls) W.lamc[lane] = d.oc_lamc[oc * d.oc_ls + lane];
+        if (lane < d.oc_vs) (&W.vtx[0][0])[lane] = d.oc_vtx[oc * d.oc_vs + lane];
         if (lane == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
     }
     lmz::wave_sync();
@@ -699,9 +701,9 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
             ey.G = d.G[(int)threadIdx.x < 2 * R ? threadIdx.x : 0]; ey.h = d.h[(int)threadIdx.x < R ? threadIdx.x : 0];
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ey.lamc[k] = gl + 16 * k < 40 ? d.oc_lamc[oc * 40 + gl + 16 * k] : (unsigned char)0;
+        for (int k = 0; k < 3; ++k) ey.lamc[k] = gl + 16 * k < d.oc_ls ? d.oc_lamc[oc * d.oc_ls + gl + 16 * k] : (unsigned char)0;      // (wave-uniform bounds for k >= 1 at E <= 5: whole loads drop out)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ey.vtx[k] = gl + 16 * k < 56 ? d.oc_vtx[oc * 56 + gl + 16 * k] : 0.0;
+        for (int k = 0; k < 4; ++k) ey.vtx[k] = gl + 16 * k < d.oc_vs ? d.oc_vtx[oc * d.oc_vs + gl + 16 * k] : 0.0;
         ey.npv = d.oc_cnt[2 * oc]; ey.nlv = d.oc_cnt[2 * oc + 1];
         {   // the remembered support (hint_read with the slot's source already at hand)
             const int key = (ey.src >= 0 && ey.src < d.src_cap) ? d.c.N + ey.src : n, tr = (it == 0 && t + 1 < T) ? t + 1 : t;
@@ -771,13 +773,13 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
         const size_t oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
         if (MODE == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) if (gl + 16 * k < 40) W.lamc[gl + 16 * k] = ey.lamc[k];
+            for (int k = 0; k < 3; ++k) if (gl + 16 * k < d.oc_ls) W.lamc[gl + 16 * k] = ey.lamc[k];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (gl + 16 * k < 56) (&W.vtx[0][0])[gl + 16 * k] = ey.vtx[k];
+            for (int k = 0; k < 4; ++k) if (gl + 16 * k < d.oc_vs) (&W.vtx[0][0])[gl + 16 * k] = ey.vtx[k];
             if (gl == 0) { W.npv = ey.npv; W.nlv = ey.nlv; }
         } else {
-            for (int i = gl; i < 40; i += 16) W.lamc[i] = d.oc_lamc[oc * 40 + i];
-            for (int i = gl; i < 56; i += 16) (&W.vtx[0][0])[i] = d.oc_vtx[oc * 56 + i];
+            for (int i = gl; i < d.oc_ls; i += 16) W.lamc[i] = d.oc_lamc[oc * d.oc_ls + i];
+            for (int i = gl; i < d.oc_vs; i += 16) (&W.vtx[0][0])[i] = d.oc_vtx[oc * d.oc_vs + i];
             if (gl == 0) { W.npv = d.oc_cnt[2 * oc]; W.nlv = d.oc_cnt[2 * oc + 1]; }
         }
     }
@@ -1488,7 +1490,8 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
     rc |= dalloc(&d.wl, (N + GS) * T); d.src_cap = (int)(4 * N + 256); d.hint_stride = (int)N + d.src_cap; d.hint_len = d.hint_stride * (int)T; d.slot_src = nullptr; d.src_used = 0;
-    rc |= dalloc(&d.hint, 2 * (size_t)d.hint_len); rc |= dalloc(&d.oc_lamc, N * (T + 1) * 40); rc |= dalloc(&d.oc_vtx, N * (T + 1) * 56); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
+    rc |= dalloc(&d.hint, 2 * (size_t)d.hint_len); d.oc_ls = (1 + (int)E + (int)E * ((int)E - 1) / 2 + 3) & ~3; d.oc_vs = (int)E * ((int)E - 1) > 2 ? (int)E * ((int)E - 1) : 2;
+    rc |= dalloc(&d.oc_lamc, N * (T + 1) * d.oc_ls); rc |= dalloc(&d.oc_vtx, N * (T + 1) * d.oc_vs); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
     rc |= dalloc(&d.xi, N * (T + 1) * 2); rc |= dalloc(&d.zeta, N * T); rc |= dalloc(&d.dis, T);
     d.P = 1; d.rank = 0; d.Nloc = (int)N; d.Nlive = (int)N; d.J = (int)((N + GS - 1) / GS); d.chunk = chunk_doubles((int)T, (int)N); d.lchunk = lchunk_doubles((int)T, (int)N);
