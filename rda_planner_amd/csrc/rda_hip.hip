@@ -786,10 +786,16 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     lmz::wave_sync();
     LMZ_CLK(2);
     const int hpar = MODE == 0 ? ey.hpar : (d.ctrl->hint_par & 1);
-    const int hint_in = MODE == 0 ? ey.hint : (MODE != 2 ? hint_read(d, hpar, n, t, it == 0) : -1);
+    // (work-list form: only a CIRCLE row reads its remembered support - round 6, see below)
+    const int hint_in = MODE == 0 ? ey.hint : (MODE != 2 ? hint_read(d, hpar, n, t, it == 0) : ((P.norm2 && live) ? hint_read(d, hpar, n, t, it == 0) : -1));
     bool ok = MODE != 2 && d.warm && lmz::solve_wave_warm<16>(W, rb, P, lane, hint_in, best);
     // CW (the single-ego kernel only, see lmz::warm_circle): the remembered case of a circle obstacle's row, four rows of the wave side by side
     if (CW && MODE == 0 && d.warm && P.norm2 && live && !bad) ok = lmz::warm_circle<16>(W, rb, P, lane, hint_in, best);
+    // ... and in the WORK-LIST form (round 6): the common-path kernel of the dense launch forms and the fleet cannot afford the circle cases inline (registers:
+    // lmz::warm_circle's header), so it defers every circle row - and the work-list kernel used to enumerate each of them, on every ADMM iteration (64 lanes, the
+    // interior candidate a Newton iteration: ~31 k cycles a row).  This kernel has the registers (one wave per SIMD): the remembered case first, the enumeration
+    // only when its certificate fails - the same routine as the single-ego form, so a circle row's answer no longer depends on the launch form.
+    if (MODE == 2 && d.warm && P.norm2 && live && !bad) ok = lmz::warm_circle<16>(W, rb, P, lane, hint_in, best);
     LMZ_CLK(3);
     if (MODE != 2 && !live && !ok) {                           // a dead row never asks for the enumeration; nothing of `best` is used
         best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
@@ -798,7 +804,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     }
     unsigned long long need = __ballot(!ok);                   // rows that need the enumeration (wave-uniform from here)
     if (MODE == 2) {
-        need = entry ? 0xffffull : 0ull;                        // row 0 only
+        need = (entry && (need & 1ull)) ? 0xffffull : 0ull;      // row 0 only (and not a circle row whose remembered case was accepted)
         if (!live) {                                            // idle rows: nothing of `best` is used below
             best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
             best.l1 = best.l2 = best.g1 = best.g2 = 0;

@@ -69,6 +69,43 @@ def test_switch_reproduces_the_default_closed_loop(defaults, monkeypatch, env, c
         assert g[2] == w[2] and g[3] == w[3], (k, g[2:4], w[2:4])
 
 
+def _circle_heavy_loop(steps=30):
+    """two of three obstacles are moving CIRCLES (the reference's dynamic_obs kind of scene), 36 slots"""
+    from rda_planner_amd.mpc import MPC
+    car_t = sc.rectangle_robot(dynamics="acker")
+    path = sc.line_path([4, 25, 0], [40, 25, 0], 0.1)
+    clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+    polys = sc.scene_polygons(36, lo=(8, 14), hi=(40, 36), seed=9, keep_clear=clear, clear_radius=3.0, moving=True)
+    scene = [o if k % 3 == 0 else sc.circle(float(o.vertex[0].mean()), float(o.vertex[1].mean()), 0.6, tuple(o.velocity.ravel())) for k, o in enumerate(polys)]
+    mpc = MPC(car_t, [p.copy() for p in path], receding=12, iter_num=4, max_edge_num=4, max_obs_num=36, time_print=False)
+    st = path[0].copy().reshape(3, 1)
+    out = []
+    for k in range(steps):
+        cur = [o._replace(vertex=o.vertex + o.velocity * (0.1 * k)) if o.cone_type == "Rpositive" else o._replace(center=o.center + o.velocity * (0.1 * k)) for o in scene]
+        u, info = mpc.control(st.copy(), 4.0, cur)
+        assert info["status"] == 0
+        out.append((u.copy(), np.hstack(info["opt_state_list"]).copy(), info["resi_dual"], info["resi_pri"], info["iters"]))
+        st = sc.kinematic_step(st, u, car_t, 0.1)
+    return out
+
+
+@pytest.mark.parametrize("env", [{"RDA_LMZ_DENSE_FROM": "0"}, {"RDA_LMZ_DENSE_FROM": "0", "RDA_LMZ_SPLIT": "0"}, {"RDA_LMZ_ROWS": "0"}],
+                         ids=["split-form", "dense-fused-form", "one-row-per-wave"])
+def test_circle_rows_do_not_depend_on_the_launch_form(monkeypatch, env):
+    """ADVICE r05 / VERDICT r05 #6a.  A circle row's remembered case (`lmz::warm_circle`) used to be tried by the single-ego launch form only; the dense forms and
+    the fleet enumerated every circle row on every ADMM iteration - another code path for the same row, equal on the certificate's word alone.  Round 6: the
+    work-list kernel of the split form tries the remembered case first (same routine).  A circle-heavy closed loop must not depend on the launch form:
+    bit for bit against the default (single-ego) form."""
+    want = _circle_heavy_loop()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = _circle_heavy_loop()
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g[4] == w[4], (k, g[4], w[4])
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), (k, float(np.abs(g[0] - w[0]).max()), float(np.abs(g[1] - w[1]).max()))
+        assert g[2] == w[2] and g[3] == w[3], (k, g[2:4], w[2:4])
+
+
 @pytest.mark.parametrize("T,dyn,moving", [(20, "acker", False), (25, "omni", True), (30, "diff", True), (10, "acker", False)])
 def test_time_split_of_the_su_newton_system_changes_nothing_but_rounding(T, dyn, moving):
     """rda_opts::su_split (round 4): the horizons with a compile-time instantiation factorise and sweep the Newton system of the su
