@@ -44,6 +44,7 @@ struct Ctrl {
     int su_probe;                 // consecutive su-solves in the hard regime (see su_body)
     int hint_par;                 // which of the two Dev::hint buffers the LamMuZ launch of this iteration WRITES (flipped by every executed su launch)
     int wl_count;                 // entries of Dev::wl written by the common-path LamMuZ kernel of this iteration (reset by k_su)
+    int wlc_count;                // ... and its CIRCLE rows, which fill Dev::wl from the back (round 6: the work-list kernel serves them four per wave, remembered case first)
     int resi_iter;                // ADMM iterations of this step whose residuals are in resi_dual / resi_pri (k_su / k_finish)
     int pose_ok;                  // Dev::pose and the near masks of Dev::coef describe the same terms (a LamMuZ launch / k_lmz_finalize made them)
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
@@ -83,7 +84,7 @@ struct Dev {
     int su_first_attempt;                // su_device Args::first_attempt (test switch)
     int su_land; double su_land_tol[3], su_land_rho;  // su_device Args::land (rda_opts::su_land)
     int su_land_first;                   // su_device Args::land_first (rda_opts::su_land_first)
-    int *wl;                             // [N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch)
+    int *wl; int wl_cap;                 // [wl_cap >= N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch): polygon rows from the front, circle rows from the back
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
     int su_pre;                        // the su set-up reads the block sums / near masks of the LamMuZ launch (0: it evaluates every term itself)
@@ -329,7 +330,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
 #ifdef SU_TRACE
     t_mark_[2] = clock64();                  // residuals reduced, verdict taken
 #endif
-    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->hint_par = cl.hint_par ^ 1; }     // the LamMuZ launches of this iteration start with an empty work list and write the other support buffer
+    if (tid == 0) { d.ctrl->wl_count = 0; d.ctrl->wlc_count = 0; d.ctrl->hint_par = cl.hint_par ^ 1; }     // the LamMuZ launches of this iteration start with an empty work list and write the other support buffer
     if (d.su_pre) a.pose_ok = cl.pose_ok;
     a.status = &d.ctrl->st_tmp; a.ipm_iters = &d.ctrl->it_tmp; a.rd0 = &d.ctrl->rd0_tmp; a.prof = d.su_prof; a.split = d.su_split; a.accept = d.su_accept; a.first_attempt = d.su_first_attempt;
     su::Result res; res.rd0 = cl.rd0_tmp;
@@ -411,7 +412,7 @@ __device__ __forceinline__ void begin_body(const Dev &d)
 {
     if (threadIdx.x == 0) {
         d.ctrl->stop = 0; d.ctrl->iters = 0; d.ctrl->su_status = 0; d.ctrl->ipm_iters = 0; d.ctrl->lmz_fail = 0;
-        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0; d.ctrl->resi_iter = 0;
+        d.ctrl->resi_dual = 0; d.ctrl->resi_pri = 0; d.ctrl->finished = 0; d.ctrl->wl_count = 0; d.ctrl->wlc_count = 0; d.ctrl->resi_iter = 0;
     }
 }
 
@@ -682,7 +683,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
         ey.hpar = d.ctrl->hint_par & 1;
     }
     if (d.ctrl->stop) return;                                 // (not merged into the batch below: launches behind the stop flag are on the next tick's way and must stay short - measured)
-    if (MODE == 2 && block * WPB >= d.ctrl->wl_count) return;  // work-list form: nothing for this workgroup (the list is short or empty since round 3: no trip for the robot data)
+    if (MODE == 2 && block * WPB >= d.ctrl->wl_count + (d.ctrl->wlc_count + 3) / 4) return;  // work-list form: nothing for this workgroup (the list is short or empty since round 3: no trip for the robot data)
     LMZ_CLK(0);
     if (MODE == 0) {
         const int t = tb, nl0 = jb * GS + wv * 4 + row, nl = nl0 < d.Nlive ? nl0 : 0, n = d.rank * d.Nloc + nl;
@@ -720,15 +721,25 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     for (int i = threadIdx.x; i < 40; i += 64 * WPB) rb.muc[i] = d.muc[i];
     for (int i = threadIdx.x; i < 56; i += 64 * WPB) (&rb.rv[0][0])[i] = (&d.rv[0][0])[i];
     if (threadIdx.x == 0) { rb.nmv = d.nmv; rb.nrv = d.nrv; }
-    const int cnt = MODE == 2 ? d.ctrl->wl_count : 1;
+    // Work-list form: the list has two ends.  Polygon rows (from the front, Ctrl::wl_count) take a wave each: they go straight to the 64-lane enumeration.
+    // Circle rows (from the back, Ctrl::wlc_count) take a 16-lane row each, FOUR per wave: their remembered case runs side by side like in the single-ego
+    // form, and only a row whose certificate fails is enumerated by its wave (round 6).  A wave slot = one polygon row or one group of four circle rows.
+    const int cntP = MODE == 2 ? d.ctrl->wl_count : 1, cntC = MODE == 2 ? d.ctrl->wlc_count : 0;
+    const int cnt = cntP + (cntC + 3) / 4;
     for (int base = MODE == 2 ? block * WPB : 0; base < cnt; base += MODE == 2 ? nblocks * WPB : 1) {       // modes 0, 1: one pass
     if (MODE == 2) __syncthreads();                            // the slabs of the previous pass are free again
-    const bool entry = MODE == 2 && base + wv < cnt;            // (wave-uniform) this wave has a work-list entry in this pass
-    // a row past the end (a dead slot of the padded stage, an idle row of mode 2) shadows unit (0, 0) and writes nothing
+    const bool entry = MODE == 2 && base + wv < cnt;            // (wave-uniform) this wave has a work-list slot in this pass
+    // a row past the end (a dead slot of the padded stage, an idle row of mode 2) shadows an existing unit and writes nothing
     int t, nl;
-    if (MODE == 2) unit_of(d, d.wl[entry ? base + wv : base], t, nl);
-    else { t = tb; nl = jb * GS + wv * 4 + row; }
-    const bool live = MODE == 2 ? (entry && row == 0) : nl < d.Nlive;
+    bool live2 = false;
+    if (MODE == 2) {
+        const int sl = entry ? base + wv : base;               // (a wave without a slot shadows the first slot of the pass)
+        int widx;
+        if (sl < cntP) { widx = sl; live2 = entry && row == 0; }
+        else { const int c0 = 4 * (sl - cntP), ci = c0 + row; live2 = entry && ci < cntC; widx = d.wl_cap - 1 - (live2 ? ci : c0); }
+        unit_of(d, d.wl[widx], t, nl);
+    } else { t = tb; nl = jb * GS + wv * 4 + row; }
+    const bool live = MODE == 2 ? live2 : nl < d.Nlive;
     if (!live) nl = 0;
     const int n = d.rank * d.Nloc + nl;
     lmz::WaveLDS &W = wl[wv * 4 + row];
@@ -804,7 +815,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     }
     unsigned long long need = __ballot(!ok);                   // rows that need the enumeration (wave-uniform from here)
     if (MODE == 2) {
-        need = (entry && (need & 1ull)) ? 0xffffull : 0ull;      // row 0 only (and not a circle row whose remembered case was accepted)
+        need = __ballot(live && !ok);                            // the polygon row of the slot, or the circle rows whose remembered case was not accepted
         if (!live) {                                            // idle rows: nothing of `best` is used below
             best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
             best.l1 = best.l2 = best.g1 = best.g2 = 0;
@@ -824,7 +835,10 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
             best.cost = 0; best.id = 0; best.m = -1; best.H0 = best.H1 = 0; best.i1 = best.i2 = best.j1 = best.j2 = -1;
             best.l1 = best.l2 = best.g1 = best.g2 = 0;
         }
-        if (defer && gl == 0 && live) d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = t * GS * d.J + nl;
+        if (defer && gl == 0 && live) {
+            if (P.norm2) d.wl[d.wl_cap - 1 - atomicAdd(&d.ctrl->wlc_count, 1)] = t * GS * d.J + nl;      // circle rows: from the back (see the work-list form)
+            else d.wl[atomicAdd(&d.ctrl->wl_count, 1)] = t * GS * d.J + nl;
+        }
         need = 0;
     }
     if (MODE == 0) {
@@ -1495,7 +1509,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     int rc = 0;
     rc |= dalloc(&d.G, 2 * R); rc |= dalloc(&d.h, R);
     rc |= dalloc(&d.A, N * (T + 1) * E * 2); rc |= dalloc(&d.b, N * (T + 1) * E); rc |= dalloc(&d.cone, N);
-    rc |= dalloc(&d.wl, (N + GS) * T); d.src_cap = (int)(4 * N + 256); d.hint_stride = (int)N + d.src_cap; d.hint_len = d.hint_stride * (int)T; d.slot_src = nullptr; d.src_used = 0;
+    rc |= dalloc(&d.wl, (N + GS) * T); d.wl_cap = (int)((N + GS) * T); d.src_cap = (int)(4 * N + 256); d.hint_stride = (int)N + d.src_cap; d.hint_len = d.hint_stride * (int)T; d.slot_src = nullptr; d.src_used = 0;
     rc |= dalloc(&d.hint, 2 * (size_t)d.hint_len); d.oc_ls = (1 + (int)E + (int)E * ((int)E - 1) / 2 + 3) & ~3; d.oc_vs = (int)E * ((int)E - 1) > 2 ? (int)E * ((int)E - 1) : 2;
     rc |= dalloc(&d.oc_lamc, N * (T + 1) * d.oc_ls); rc |= dalloc(&d.oc_vtx, N * (T + 1) * d.oc_vs); rc |= dalloc(&d.oc_cnt, N * (T + 1) * 2);
     rc |= dalloc(&d.lam, N * (T + 1) * E); rc |= dalloc(&d.mu, N * (T + 1) * R); rc |= dalloc(&d.z, N * T);
