@@ -2812,6 +2812,13 @@ static int fleet_refresh(rda_fleet *F)
     bool changed = false;
     for (int i = 0; i < F->B; ++i) {
         if (memcmp(&F->h_devs[i], &F->egos[i]->d, sizeof(Dev)) != 0) changed = true;
+        // the fleet's stream must run behind whatever a member still has queued on its OWN stream (an upload, a solo step).  An idle member stream needs no
+        // edge: the event record + wait pair per member cost ~8 us of host time each, twice per fleet tick (re-sort + step) = 1 ms of a 4.2 ms tick of the
+        // 64-ego closed loop with the GPU idle meanwhile (rocprofv3 kernel trace cut into ticks, tools/experiments/fleet_tick_trace.sh, round 6)
+        const hipError_t q = hipStreamQuery(F->egos[i]->stream);
+        if (q == hipSuccess) continue;
+        if (q != hipErrorNotReady) { fprintf(stderr, "librda_hip: hipStreamQuery failed: %s (%s:%d)\n", hipGetErrorString(q), __FILE__, __LINE__); return RDA_ERR_HIP; }
+        (void)hipGetLastError();                            // ("not ready" is an answer, not an error to be found by a later hipGetLastError)
         HIPCHK(hipEventRecord(F->ev, F->egos[i]->stream));
         HIPCHK(hipStreamWaitEvent(F->stream, F->ev, 0));
     }
