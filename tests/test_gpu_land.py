@@ -113,3 +113,41 @@ def test_landed_closed_loop_vs_landed_cold_oracle(landed_cold_orc, name, n_obs, 
     # every solve landed (some at a later stop of the interior point: a refusal is a retry; a refused SPECULATIVE landing - from the start of a warm attempt,
     # before any interior-point iteration - hands over to the interior point, whose iterate is landed later)
     assert st[0] > 0 and st[1] - (st[4] - st[5]) <= 0.1 * st[0], st
+
+
+def _gpu_loop(car_t, path, obstacles, kw, steps, advance, **opts):
+    from rda_planner_amd.mpc import MPC
+    from rda_planner_amd.rda_solver import hip_options
+    gpu = MPC(car_t, [p.copy() for p in path], sample_time=0.1, time_print=False, hip_opts=hip_options(**opts), **kw)
+    state = path[0].copy().reshape(3, 1)
+    us, its, ipm = [], [], 0
+    for i in range(steps):
+        cur = obstacles if not advance else [o._replace(vertex=o.vertex + o.velocity * (0.1 * i)) for o in obstacles]
+        u, info = gpu.control(state.copy(), 4.0, list(cur))
+        assert info["status"] == 0
+        us.append(gpu.cur_vel_array.copy()); its.append(info["iters"]); ipm += info["su_ipm_iters"]
+        state = sc.kinematic_step(state, u, car_t, 0.1)
+    st = (C.c_int32 * 6)()
+    assert gpu.rda._be.api.lib.rda_debug_su_land_n(gpu.rda._be.handle, st, 6) == 0
+    return np.array(us), its, ipm, list(st)
+
+
+@pytest.mark.parametrize("name,n_obs,T,moving,steps", [("north star", 200, 20, False, 40), ("C4", 200, 30, True, 16), ("C5 shape", 100, 25, False, 30)])
+def test_landing_first_reaches_the_same_vertex_with_fewer_interior_point_iterations(name, n_obs, T, moving, steps):
+    """rda_opts::su_land_first (round 6).  Mode 1 (the first pass of a warm attempt is a light one) is bit-identical to mode 0.  Mode 2 (the default: where the start
+    of a warm attempt does not meet the landing's stop, the landing is tried from the start with the active set of the kept multipliers - the warm-started
+    active-set method) takes another path to the SAME vertex: accepted only on the verified optimality conditions of the true problem, so whole closed loops -
+    free-running, never re-synchronised - agree to 1e-9 with the same ADMM iteration counts, and the static sizes spend fewer interior-point iterations."""
+    from test_gpu_baseline_sizes import _workload
+    car_t, path, obstacles, kw = _workload(n_obs, T, steps + 10, moving=moving)
+    u0, it0, ipm0, st0 = _gpu_loop(car_t, path, obstacles, kw, steps, moving, su_land_first=0)
+    u1, it1, ipm1, st1 = _gpu_loop(car_t, path, obstacles, kw, steps, moving, su_land_first=1)
+    u2, it2, ipm2, st2 = _gpu_loop(car_t, path, obstacles, kw, steps, moving, su_land_first=2)
+    d2 = float(np.abs(u2 - u0).max())
+    print(f"{name}: interior-point iterations per step {ipm0 / steps:.2f} (mode 0) / {ipm1 / steps:.2f} (1) / {ipm2 / steps:.2f} (2); speculative landings tried {st2[4]}, "
+          f"accepted {st2[5]}; max |du| over the horizon, mode 2 vs mode 0: {d2:.2e}")
+    assert np.array_equal(u1, u0) and it1 == it0 and ipm1 == ipm0                  # the light first pass changes nothing
+    assert st0[4] == 0 and st1[4] == 0
+    assert it2 == it0 and d2 <= 1e-9, (d2, it2, it0)
+    if not moving:
+        assert st2[5] > 0 and ipm2 < ipm0, (st2, ipm2, ipm0)                        # static sizes: some speculative landings are accepted and save iterations
