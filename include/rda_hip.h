@@ -163,7 +163,8 @@ typedef struct rda_opts {
     double  su_land_tol[3];  /* [1e-3, 1e-4, 1e-5] first stop of the interior point when it is landed; a refused landing is tried once more at 1e-2 x
                                 these values, then the iteration runs to su_tol                                                  RDA_SU_LAND_TOL */
     double  su_land_rho;     /* [1e4] penalty of the landing's active rows, relative to the largest entry of the stage Hessians  RDA_SU_LAND_RHO */
-    int32_t su_land_first;   /* [2] landing FIRST, for the su-problems of ADMM iterations >= 1 (they start from the previous solution of the step and its multipliers).
+    int32_t su_land_first;   /* [2] landing FIRST, for the warm-started su-problems (ADMM iterations >= 1: from the previous solution of the step and its multipliers; the first
+                                one of a tick: from the previous tick's solution, shifted by one stage).
                                 1: the first pass of the warm attempt is a light one (measures only - the start usually meets the landing's stop as it stands and the
                                 factorisation of that pass was thrown away by the landing round anyway); results are bit-identical to 0.  2: ... and when the start
                                 does not meet the stop the landing is tried all the same, from the start, active set = the rows whose kept multiplier exceeds the

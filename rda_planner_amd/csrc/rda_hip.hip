@@ -361,9 +361,9 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // Hard regime (many moving obstacles: consecutive su-problems are far apart): a warm attempt then needs MORE iterations than a cold
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
-    // landing first: the su-problems of ADMM iterations >= 1 (warm: the previous solution of this step with its multipliers)
+    // landing first: the warm-started su-problems
     a.land_level0 = (a.land && cl.land_hard) ? 1 : 0;
-    const bool lf_eligible = it > 0 && a.warm_mu0 > 0 && a.land;
+    const bool lf_eligible = a.warm_mu0 > 0 && a.land;       // (every warm attempt: ADMM iterations >= 1, and the first su-problem of a tick - the previous tick's solution shifted by one stage)
     if (lf_eligible) a.land_first = d.su_land_first == 2 ? (cl.spec_credit >= 0 ? 2 : 1) : d.su_land_first;
     if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && cl.su_last > d.su_cold_from && cl.su_last < 99 && cl.su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
 #ifdef SU_TRACE

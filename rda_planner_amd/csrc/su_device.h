@@ -152,8 +152,8 @@ struct Args {
     // star: 10 instead of 21 interior-point iterations per step, every landing accepted); a refused landing (the primal-dual active-set rounds can cycle
     // while borderline rows are still undecided) is tried again at 1e-2 x land_tol, 1e-4 x ... down to the tight tolerances themselves, then never.
     int land = 0; double land_tol[3] = {1e-3, 1e-4, 1e-5}; double land_rho = 1e4;      // (land_rho: penalty of the active rows relative to the largest stage-Hessian entry)
-    // LANDING FIRST (rda_opts::su_land_first; warm attempts only - the launch sets it for the su-problems of ADMM iterations >= 1, which start from the previous
-    // solution and its multipliers).  1: the first pass of the attempt is a LIGHT one (true measures only - no Hessian bases, no Riccati recursion, no sweep
+    // LANDING FIRST (rda_opts::su_land_first; warm attempts only: the su-problems of ADMM iterations >= 1 start from the previous solution of the step and its
+    // multipliers, the first one of a tick from the previous tick's solution shifted by one stage).  1: the first pass of the attempt is a LIGHT one (true measures only - no Hessian bases, no Riccati recursion, no sweep
     // matrices): the start usually meets the landing's stop as it stands, and the factorisation of that pass was thrown away by the landing round anyway.
     // 2: ... and when the start does NOT meet the stop the landing is tried all the same - from the start itself, active set = the rows whose KEPT
     // multiplier exceeds the slack - with at most two rounds: the warm-started active-set method.  What it returns has passed the verification on the
