@@ -161,7 +161,8 @@ struct Args {
     // active set was guessed; refused: back to the start, the interior point takes over as without the switch (the landing level is not raised).
     int land_first = 0;
     int land_level0 = 0;             // first landing level of the attempts (0: the interior point stops at land_tol; 1: at 1e-2 x land_tol): the launch raises it after a solve whose landing took three or more rounds
-    double land_first_rd0 = 1.0;     // ... only from a start whose relative dual residual lies below this (40-step loops, accepted / tried: north star 20 / 31 below 1, 3 / 14 above; N = 2000 31 / 63, 1 / 49; C4 0 / 32, 0 / 86)
+    double land_first_rd0 = 0.5;     // ... only from a start whose relative dual residual lies below this (60-step loops, accepted / tried below 0.5 | 0.5 .. 1 | above 1: north star 47 / 53 | 7 / 23 | 3 / 14;
+                                     // N = 2000 77 / 79 | 2 / 62 | 1 / 49; C5 shape 47 / 54 | 7 / 17 | 0 / 16; C4 0 / 3 | 2 / 43 | 0 / 86)
     int *land_stat = nullptr;        // optional [LAND_STATS]: landings accepted, refused, rounds, interior-point iterations that were landing / verification passes;
                                      // [4] speculative landings (land_first = 2) tried, [5] accepted, [6 + k] / [12 + k] tried / accepted by the decade k of the start's relative dual residual (< 1e-4, .. < 1, >= 1)
     // the reference may still be in the making when the solve starts (another workgroup samples it, k_su_tracked): it is then
