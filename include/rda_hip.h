@@ -329,8 +329,8 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * iter_threshold, hist[3] = the last su-solve started far from its solution (the two keys of su_hard_warm); lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
 #define RDA_SU_HISTORY_INTS 6   /* entries of `hist` in THIS header (round 4: 2, round 5: 4 - the array grows with the start rules, an ABI break for callers of the count-less
-                                   forms: use the _n forms below).  hist[4] (round 6) = the credit of the speculative landings, rda_opts::su_land_first = 2; hist[5] = the last landing took three or more rounds
-                                   (the next solve's interior point runs to 1e-2 x su_land_tol before it is landed) */
+                                   forms: use the _n forms below).  hist[4] (round 6) = the credit of the speculative landings, rda_opts::su_land_first = 2; hist[5] > 0: one of the last four landings took three or more
+                                   rounds (the next solve's interior point runs to 1e-2 x su_land_tol before it is landed) */
 int  rda_get_su_history(rda_handle *h, int32_t *hist /*RDA_SU_HISTORY_INTS*/, double *lam_keep /*10*T*/);
 int  rda_set_su_history(rda_handle *h, const int32_t *hist /*RDA_SU_HISTORY_INTS*/, const double *lam_keep /*10*T*/);
 /* ... with the caller's own count: get writes n_hist entries (those this library does not have read 0), set reads

@@ -50,7 +50,7 @@ struct Ctrl {
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
     double rd0_tmp;               // ... that residual, written by the solve
-    int land_hard;                // the last su-solve's landing took three or more rounds (many rows / hinge terms still undecided at the 1e-3-class stop: moving obstacles): the next solve's interior point runs to 1e-2 x su_land_tol before it is landed (C4: 2.7 -> rounds per solve, +4 % steps/s; north star: 1.1 - 1.3 rounds, unaffected): solver history
+    int land_hard;                // > 0: one of the last four su-solves' landings took three or more rounds (many rows / hinge terms still undecided at the 1e-3-class stop: moving obstacles): the next solve's interior point runs to 1e-2 x su_land_tol before it is landed (C4: 2.7 -> rounds per solve, +4 % steps/s; north star: 1.1 - 1.3 rounds, unaffected): solver history
     int spec_credit;              // su_land_first = 2: speculative landings are tried while this is >= 0 (+3 per accepted one, capped at 6; -2 per refused one; +1 per eligible solve that had to skip): solver history
     int land_stat[su::LAND_STATS];  // su_land: landings accepted, refused, rounds, passes spent on landings, speculative landings (rda_debug_su_land, rda_debug_su_land_n)
     unsigned long long ref_seq;   // tick number whose reference is complete (k_su_tracked: written by the sampling workgroup)
@@ -362,7 +362,7 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // start.  While the last solve needed more than su_cold_from iterations the solve starts cold; every su_cold_probe-th such solve tries the
     // warm start again, so that the handle finds its way back when the scene calms down.
     // landing first: the warm-started su-problems
-    a.land_level0 = (a.land && cl.land_hard) ? 1 : 0;
+    a.land_level0 = (a.land && cl.land_hard > 0) ? 1 : 0;
     const bool lf_eligible = a.warm_mu0 > 0 && a.land;       // (every warm attempt: ADMM iterations >= 1, and the first su-problem of a tick - the previous tick's solution shifted by one stage)
     if (lf_eligible) a.land_first = d.su_land_first == 2 ? (cl.spec_credit >= 0 ? 2 : 1) : d.su_land_first;
     if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && cl.su_last > d.su_cold_from && cl.su_last < 99 && cl.su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
@@ -380,7 +380,13 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
         d.ctrl->su_hardlike = res.rd0 > su::HARD_RD0;
         d.ctrl->su_probe = (d.su_cold_from > 0 && su_last > d.su_cold_from && su_last < 99) ? cl.su_probe + 1 : 0;
         d.ctrl->pose_ok = 0;          // the pose table has moved on; the LamMuZ launch that follows makes the masks that go with it
-        if (a.land && res.status == 0) d.ctrl->land_hard = res.land_rounds >= 3;
+        if (a.land && res.status == 0) {
+            // sticky: a landing of three or more rounds sends the next FOUR solves to the later stop (a good landing at the later stop says nothing about the
+            // earlier one: with a one-solve memory C4 alternated between the two levels)
+            int lh = cl.land_hard;
+            if (res.land_rounds >= 3) lh = 4; else if (lh > 0) lh -= 1;
+            d.ctrl->land_hard = lh;
+        }
         if (lf_eligible && d.su_land_first == 2) {
             // speculative landings pay where consecutive su-problems keep their active set (static scenes: 50 - 65 % accepted) and cost two landing rounds where
             // they do not (C4, moving obstacles: none accepted): a handle that keeps failing tries every third eligible solve only; at one success in two the credit grows
