@@ -170,6 +170,9 @@ typedef struct rda_opts {
                                 does not meet the stop the landing is tried all the same, from the start, active set = the rows whose kept multiplier exceeds the
                                 slack, at most two rounds (a warm-started active-set method; accepted only on the verified optimality conditions of the true
                                 problem, so the answer is the same vertex: differences at rounding level); refused: the interior point takes over.  RDA_SU_LAND_FIRST */
+    int32_t su_land_blind_from; /* [1] with su_land_first = 2: after this many su-solves in a row that needed no interior-point iteration and one landing round, the next warm
+                                su-problem of the same step starts WITH its landing round - no measuring pass in front of it (one round; refused: the interior
+                                point takes over).  0 = never.                                                                  RDA_SU_LAND_BLIND_FROM */
 } rda_opts;
 void rda_opts_init(rda_opts *o);
 
@@ -328,9 +331,10 @@ int  rda_set_state(rda_handle *h, const double *lam, const double *mu, const dou
  * iterations of the last su-solve (99 = none), hist[1] = consecutive solves in the hard regime, hist[2] = the previous step ended above
  * iter_threshold, hist[3] = the last su-solve started far from its solution (the two keys of su_hard_warm); lam_keep [10*T] = the inequality
  * multipliers of the last converged su-solve.  rda_create and rda_reset set (99, 0, zeros).  NULL pointers are skipped. */
-#define RDA_SU_HISTORY_INTS 6   /* entries of `hist` in THIS header (round 4: 2, round 5: 4 - the array grows with the start rules, an ABI break for callers of the count-less
+#define RDA_SU_HISTORY_INTS 8   /* entries of `hist` in THIS header (round 4: 2, round 5: 4 - the array grows with the start rules, an ABI break for callers of the count-less
                                    forms: use the _n forms below).  hist[4] (round 6) = the credit of the speculative landings, rda_opts::su_land_first = 2; hist[5] > 0: one of the last four landings took three or more
-                                   rounds (the next solve's interior point runs to 1e-2 x su_land_tol before it is landed) */
+                                   rounds (the next solve's interior point runs to 1e-2 x su_land_tol before it is landed); hist[6] = su-solves in a row without an interior-point iteration and with
+                                   one landing round, hist[7] = the gate of the blind landings (rda_opts::su_land_blind_from) */
 int  rda_get_su_history(rda_handle *h, int32_t *hist /*RDA_SU_HISTORY_INTS*/, double *lam_keep /*10*T*/);
 int  rda_set_su_history(rda_handle *h, const int32_t *hist /*RDA_SU_HISTORY_INTS*/, const double *lam_keep /*10*T*/);
 /* ... with the caller's own count: get writes n_hist entries (those this library does not have read 0), set reads

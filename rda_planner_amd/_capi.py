@@ -32,7 +32,7 @@ class Opts(C.Structure):
                 ("su_cold_from", C.c_int), ("su_cold_probe", C.c_int), ("zero_copy", C.c_int), ("early_finish", C.c_int),
                 ("fuse_track", C.c_int), ("su_prof", C.c_int), ("su_split", C.c_int), ("duals_follow", C.c_int), ("su_accept", C.c_int), ("su_first_attempt", C.c_int),
                 ("su_warm", C.c_double * 2), ("su_warm_endgame", C.c_double * 2), ("su_warm_clip", C.c_double),
-                ("su_easy", C.c_double * 5), ("su_land", C.c_int), ("su_land_tol", C.c_double * 3), ("su_land_rho", C.c_double), ("su_land_first", C.c_int)]
+                ("su_easy", C.c_double * 5), ("su_land", C.c_int), ("su_land_tol", C.c_double * 3), ("su_land_rho", C.c_double), ("su_land_first", C.c_int), ("su_land_blind_from", C.c_int)]
 
 
 class Info(C.Structure):

@@ -50,6 +50,9 @@ struct Ctrl {
     int prev_unconv;              // the previous step ended with a residual above iter_threshold (all iter_num iterations, no early stop): picks the warm start (su_hard_warm)
     int su_hardlike;              // the last su-solve started far from its solution (relative dual residual of its first iterate > su::HARD_RD0): the other key of su_hard_warm
     double rd0_tmp;               // ... that residual, written by the solve
+    int land_easy;                // consecutive su-solves of this handle that needed no interior-point iteration and ONE landing round: the next warm su-problem of the same step starts with a blind landing (su_body): solver history
+    double land_rho_prev;         // penalty scale of the last landing (what a blind landing uses)
+    int blind_ok;                 // blind landings are tried while this is >= 0: +1 per accepted one (capped at 4), -6 after a refused one, +1 per opportunity skipped (N = 2000: 7 of 37 accepted, north star 54 of 62): solver history
     int land_hard;                // > 0: one of the last four su-solves' landings took three or more rounds (many rows / hinge terms still undecided at the 1e-3-class stop: moving obstacles): the next solve's interior point runs to 1e-2 x su_land_tol before it is landed (C4: 2.7 -> rounds per solve, +4 % steps/s; north star: 1.1 - 1.3 rounds, unaffected): solver history
     int spec_credit;              // su_land_first = 2: speculative landings are tried while this is >= 0 (+3 per accepted one, capped at 6; -2 per refused one; +1 per eligible solve that had to skip): solver history
     int land_stat[su::LAND_STATS];  // su_land: landings accepted, refused, rounds, passes spent on landings, speculative landings (rda_debug_su_land, rda_debug_su_land_n)
@@ -84,6 +87,7 @@ struct Dev {
     int su_first_attempt;                // su_device Args::first_attempt (test switch)
     int su_land; double su_land_tol[3], su_land_rho;  // su_device Args::land (rda_opts::su_land)
     int su_land_first;                   // su_device Args::land_first (rda_opts::su_land_first)
+    int su_land_blind_from;              // blind landings after this many easy solves in a row (0: never)
     int *wl; int wl_cap;                 // [wl_cap >= N*T] work list: sub-problems whose warm candidate failed its certificate (split LamMuZ launch): polygon rows from the front, circle rows from the back
     int *sc_bad;                         // non-convex counter of the staged raw scene (null: obstacles were staged as (A, b) slots)
     int su_easy_nopred;
@@ -363,8 +367,11 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
     // warm start again, so that the handle finds its way back when the scene calms down.
     // landing first: the warm-started su-problems
     a.land_level0 = (a.land && cl.land_hard > 0) ? 1 : 0;
+    a.land_rho_prev = cl.land_rho_prev;
     const bool lf_eligible = a.warm_mu0 > 0 && a.land;       // (every warm attempt: ADMM iterations >= 1, and the first su-problem of a tick - the previous tick's solution shifted by one stage)
     if (lf_eligible) a.land_first = d.su_land_first == 2 ? (cl.spec_credit >= 0 ? 2 : 1) : d.su_land_first;
+    const bool blind_opportunity = lf_eligible && d.su_land_first == 2 && it > 0 && cl.land_easy >= d.su_land_blind_from && d.su_land_blind_from > 0 && cl.land_rho_prev > 0;
+    if (blind_opportunity && cl.blind_ok >= 0) a.land_blind = 1;
     if (!hard && a.warm_mu0 > 0 && d.su_cold_from > 0 && cl.su_last > d.su_cold_from && cl.su_last < 99 && cl.su_probe % d.su_cold_probe != d.su_cold_probe - 1) a.warm_mu0 = 0;
 #ifdef SU_TRACE
     a.t_entry = t_entry_; t_mark_[3] = clock64();
@@ -380,6 +387,12 @@ __device__ __forceinline__ void su_body(const Dev &d, int it, const double *in_s
         d.ctrl->su_hardlike = res.rd0 > su::HARD_RD0;
         d.ctrl->su_probe = (d.su_cold_from > 0 && su_last > d.su_cold_from && su_last < 99) ? cl.su_probe + 1 : 0;
         d.ctrl->pose_ok = 0;          // the pose table has moved on; the LamMuZ launch that follows makes the masks that go with it
+        if (a.land) {
+            const bool easy1 = res.status == 0 && res.iters == 0 && res.rounds_all == 1;
+            d.ctrl->land_easy = easy1 ? (cl.land_easy < 8 ? cl.land_easy + 1 : 8) : 0;
+            if (res.land_rho > 0) d.ctrl->land_rho_prev = res.land_rho;
+            if (blind_opportunity) d.ctrl->blind_ok = res.blind == 1 ? (cl.blind_ok < 4 ? cl.blind_ok + 1 : 4) : (res.blind == 2 ? -6 : (cl.blind_ok < 0 ? cl.blind_ok + 1 : cl.blind_ok));
+        }
         if (a.land && res.status == 0) {
             // sticky: a landing of three or more rounds sends the next FOUR solves to the later stop (a good landing at the later stop says nothing about the
             // earlier one: with a one-solve memory C4 alternated between the two levels)
@@ -1285,7 +1298,7 @@ __global__ void k_reset(Dev d)
         coef_arr(d, r, 0)[k] = 0; coef_arr(d, r, 1)[k] = 0; coef_arr(d, r, 2)[k] = 0;
         coef_arr(d, r, 8)[k] = coef_arr(d, r, 3)[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; d.ctrl->spec_credit = 0; d.ctrl->land_hard = 0; }      // solver history of the handle
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctrl->su_last = 99; d.ctrl->su_probe = 0; d.ctrl->prev_unconv = 0; d.ctrl->su_hardlike = 0; d.ctrl->spec_credit = 0; d.ctrl->land_hard = 0; d.ctrl->land_easy = 0; d.ctrl->land_rho_prev = 0; d.ctrl->blind_ok = 0; }      // solver history of the handle
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < su::NC * T; i += blockDim.x) d.su_lam_keep[i] = 0;
     if (d.ipf) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.c.N * T; i += gridDim.x * blockDim.x) d.ipf[i] = 0;
 }
@@ -1423,7 +1436,7 @@ extern "C" void rda_opts_init(rda_opts *o)
     o->lmz_warm = 1; o->lmz_rows = 1; o->lmz_dense_from = 256; o->lmz_split = 1; o->lmz_ip_rows = 1; o->lmz_ip_warm = 1;
     o->su_pre = 1; o->su_light = 1; o->su_warm_first = 1; o->su_warm_cap = 30; o->su_easy_max = 2; o->su_easy_nopred = 1;
     o->su_cold_from = 7; o->su_cold_probe = 8; o->zero_copy = 1; o->early_finish = 1; o->fuse_track = 1; o->su_prof = 0; o->su_split = 1; o->duals_follow = 0; o->su_accept = 1; o->su_first_attempt = 0;
-    o->su_land_first = 2; o->su_land = 1; o->su_land_tol[0] = 1e-3; o->su_land_tol[1] = 1e-4; o->su_land_tol[2] = 1e-5; o->su_land_rho = 1e4;
+    o->su_land_blind_from = 1; o->su_land_first = 2; o->su_land = 1; o->su_land_tol[0] = 1e-3; o->su_land_tol[1] = 1e-4; o->su_land_tol[2] = 1e-5; o->su_land_rho = 1e4;
     o->su_warm[0] = 1e-3; o->su_warm[1] = 1e-3; o->su_warm_endgame[0] = 0.9999; o->su_warm_endgame[1] = 1e-5; o->su_warm_clip = 0.01;
     // easy start = the previous solution ITSELF: slack floor, barrier parameter and clip margin below the stop tolerances (1e-12 against
     // mu <= 1e-11 (1 + |grad|), |r_p| <= 1e-10), so that the stop test can accept the start when the new su-problem's optimality
@@ -1499,6 +1512,7 @@ static int create_impl(const rda_cfg *cfg, const rda_opts *opts, const double *G
     H->d.su_cold_from = o.su_cold_from; H->d.su_cold_probe = o.su_cold_probe < 1 ? 1 : o.su_cold_probe;
     H->d.su_light = o.su_light; H->d.su_split = o.su_split; H->d.su_accept = o.su_accept; H->d.su_first_attempt = o.su_first_attempt;
     H->d.su_land_first = o.su_land_first < 0 ? 0 : (o.su_land_first > 2 ? 2 : o.su_land_first);
+    H->d.su_land_blind_from = o.su_land_blind_from;
     H->d.su_land = o.su_land ? 1 : 0; H->d.su_land_rho = o.su_land_rho > 0 ? o.su_land_rho : 1e4;
     { const bool ok = o.su_land_tol[0] > 0 && o.su_land_tol[1] > 0 && o.su_land_tol[2] > 0; const double dflt[3] = {1e-3, 1e-4, 1e-5}; for (int i = 0; i < 3; ++i) H->d.su_land_tol[i] = ok ? o.su_land_tol[i] : dflt[i]; }
     H->follow = o.duals_follow != 0; H->prev_used = -1; H->d_prev_sel = nullptr; H->d_follow_map = nullptr; H->d_follow_tmp = nullptr;
@@ -1641,7 +1655,7 @@ extern "C" int rda_get_su_history_n(rda_handle *H, int32_t *hist, int n_hist, do
     if (hist && n_hist > 0) {
         Ctrl c;
         HIPCHK(hipMemcpy(&c, H->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike, c.spec_credit, c.land_hard };
+        const int32_t all[RDA_SU_HISTORY_INTS] = { c.su_last, c.su_probe, c.prev_unconv, c.su_hardlike, c.spec_credit, c.land_hard, c.land_easy, c.blind_ok };
         for (int i = 0; i < n_hist; ++i) hist[i] = i < RDA_SU_HISTORY_INTS ? all[i] : 0;      // (entries a later version may add read as 0 here)
     }
     if (lam_keep) HIPCHK(hipMemcpy(lam_keep, H->d.su_lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyDeviceToHost));
@@ -1652,13 +1666,13 @@ extern "C" int rda_set_su_history_n(rda_handle *H, const int32_t *hist, int n_hi
     if (!H || n_hist < 0) return RDA_ERR_ARG;
     HIPCHK(hipStreamSynchronize(H->stream));
     if (hist) {
-        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike, &H->d.ctrl->spec_credit, &H->d.ctrl->land_hard };
+        int *dst[RDA_SU_HISTORY_INTS] = { &H->d.ctrl->su_last, &H->d.ctrl->su_probe, &H->d.ctrl->prev_unconv, &H->d.ctrl->su_hardlike, &H->d.ctrl->spec_credit, &H->d.ctrl->land_hard, &H->d.ctrl->land_easy, &H->d.ctrl->blind_ok };
         for (int i = 0; i < n_hist && i < RDA_SU_HISTORY_INTS; ++i) HIPCHK(hipMemcpy(dst[i], &hist[i], sizeof(int), hipMemcpyHostToDevice));   // entries the caller does not have keep their value
     }
     if (lam_keep) HIPCHK(hipMemcpy(H->d.su_lam_keep, lam_keep, (size_t)su::NC * H->d.c.T * sizeof(double), hipMemcpyHostToDevice));
     return RDA_OK;
 }
-// the forms without a count: RDA_SU_HISTORY_INTS (= 6 since round 6; round 5: 4, round 4: 2) entries - a caller built against an older header must use the _n forms
+// the forms without a count: RDA_SU_HISTORY_INTS (= 8 since round 6; round 5: 4, round 4: 2) entries - a caller built against an older header must use the _n forms
 extern "C" int rda_get_su_history(rda_handle *H, int32_t *hist, double *lam_keep) { return rda_get_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_set_su_history(rda_handle *H, const int32_t *hist, const double *lam_keep) { return rda_set_su_history_n(H, hist, RDA_SU_HISTORY_INTS, lam_keep); }
 extern "C" int rda_lmz_history_doubles(rda_handle *H) { return !H ? RDA_ERR_ARG : (H->d.ipw ? 80 * H->d.c.N * H->d.c.T : 0); }

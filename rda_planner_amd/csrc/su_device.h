@@ -160,6 +160,9 @@ struct Args {
     // true objective (stationarity with the hinge terms re-evaluated, feasibility, signs), i.e. it IS the vertex - the answer does not depend on how the
     // active set was guessed; refused: back to the start, the interior point takes over as without the switch (the landing level is not raised).
     int land_first = 0;
+    // BLIND landing (the launch sets it after easy solves - zero interior-point iterations, one landing round - of the same step): the warm attempt starts WITH a
+    // landing round, no measuring pass in front of it (penalty scale: land_rho_prev, what the last landing used); one round only, then as a refused speculation
+    int land_blind = 0; double land_rho_prev = 0;
     int land_level0 = 0;             // first landing level of the attempts (0: the interior point stops at land_tol; 1: at 1e-2 x land_tol): the launch raises it after a solve whose landing took three or more rounds
     double land_first_rd0 = 0.5;     // ... only from a start whose relative dual residual lies below this (60-step loops, accepted / tried below 0.5 | 0.5 .. 1 | above 1: north star 47 / 53 | 7 / 23 | 3 / 14;
                                      // N = 2000 77 / 79 | 2 / 62 | 1 / 49; C5 shape 47 / 54 | 7 / 17 | 0 / 16; C4 0 / 3 | 2 / 43 | 0 / 86)
@@ -395,7 +398,7 @@ template <int TT> __device__ __forceinline__ bool pair_map(const int T, const in
 // own prologue before the solve (control block, residual partials: rda_hip.hip su_body).  The caller issues prefetch() FIRST, next to its own loads, so that
 // all of them overlap into one trip; a caller that passes no Pre (the rda_su_solve hook) has the solve issue it at its entry.
 // the verdict of a solve once more, in registers of every thread (uniform): the launch's bookkeeping behind the solve then needs no trip to memory
-struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; int land_rounds = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused; land_rounds: rounds of the non-speculative landings of the solve)
+struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; int land_rounds = 0; int rounds_all = 0; int blind = 0; double land_rho = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused; land_rounds: rounds of the non-speculative landings of the solve, rounds_all: of all of them; blind: a blind landing was 1 accepted, 2 refused; land_rho: penalty of the last landing)
 struct Pre {
     double vref = 0;
     double u0 = 0, u1 = 0, d = 0, cp = 0, sp = 0;      // thread t < T: nominal controls / distance, cos / sin of the pose table (pose_lin)
@@ -1306,6 +1309,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     double land_rho = 0.0;
     bool expect_conv = attempt < 0 && a.land != 0 && a.land_first != 0;      // (landing first: the first pass of a warm attempt is a light one)
     int spec_dec = 0;                              // decade of the start's relative dual residual (statistics of the speculative landings)
+    bool blind = false;                            // (uniform) the running landing started blind
     bool spec = false, spec_tried = false;         // (uniform) the running landing is a speculative one (land_first = 2); one has been refused in this attempt
     // a landing is refused: back to the interior-point iterate it started from, and on to the tight tolerances (all threads; ends with a barrier)
     auto land_refuse = [&](const bool last) {
@@ -1319,6 +1323,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         __syncthreads();
         if (a.land_stat && tid == 0) a.land_stat[1] += 1;
         land = 0; expect_conv = false;
+        if (blind) { blind = false; res.blind = 2; }
         if (spec) { spec = false; spec_tried = true; res.spec = 2; } else land_level = last ? 99 : land_level + 1;      // (a refused speculation does not use up a landing level)
         pair_rows();
         __syncthreads();
@@ -1337,6 +1342,22 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     pair_rows();
     TR(151);
     __syncthreads();
+    if (attempt < 0 && a.land != 0 && a.land_blind != 0 && a.land_rho_prev > 0) {
+        // ---- blind landing (Args::land_blind): the state a speculative landing starts in, without the measuring pass in front of it
+        for (int i = tid; i < 2 * T; i += NT) { L.sav[i] = L.u[i]; L.base[i] = L.u[i]; }
+        for (int i = tid; i < T; i += NT) { L.sav[2 * T + i] = L.d[i]; L.base[2 * T + i] = L.d[i]; }
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            Swp[j] = Pwp[j]; Swm[j] = Pwm[j]; Slp[j] = Plp[j]; Slm[j] = Plm[j];
+            Lap[j] = p_on[j] && pf_lkp[j] > Pwp[j]; Lam[j] = p_on[j] && pf_lkm[j] > Pwm[j];
+        }
+        land_rho = a.land_rho_prev;
+        land = 1; land_rounds = 1; expect_conv = false; spec = true; blind = true;
+        if (a.land_stat && tid == 0) { a.land_stat[4] += 1; a.land_stat[18] += 1; }
+        __syncthreads();
+        land_rows(land_rho);
+        __syncthreads();
+    }
     const int it_cap = attempt < 0 ? a.warm_cap : (attempt == 0 ? SU_COLD_CAP : 100);       // (the cold attempt: 50 since round 5, see the oracle)
     const double tau_min = attempt < 0 ? a.warm_tau : 0.995;
     double mu_prev = 1.0;
@@ -1658,15 +1679,18 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             //      1 + |e|, mu mcnt = sum of the negative parts of the multipliers; same thresholds as the oracle's su_land)
             if (a.land_stat && tid == 0) a.land_stat[2] += 1;
             if (!spec) res.land_rounds += 1;
+            res.rounds_all += 1;
             const bool moved = rpn > 1e-11 || mu * mcnt > 1e-9 * sc;
             if (!moved && rdn <= 100 * c.tol_rd * sc) {                      // landed
 #pragma unroll
                 for (int j = 0; j < NPR; ++j) if (p_on[j]) { Plp[j] = fmax(Plp[j], 0.0); Plm[j] = fmax(Plm[j], 0.0); }
-                if (a.land_stat && tid == 0) { a.land_stat[0] += 1; if (spec) { a.land_stat[5] += 1; a.land_stat[12 + spec_dec] += 1; } }
+                if (a.land_stat && tid == 0) { a.land_stat[0] += 1; if (spec) { a.land_stat[5] += 1; if (!blind) a.land_stat[12 + spec_dec] += 1; } }
                 if (spec) res.spec = 1;
+                if (blind) { res.blind = 1; if (a.land_stat && tid == 0) a.land_stat[19] += 1; }
+                res.land_rho = land_rho;
                 status = 0; break;
             }
-            if (land_rounds >= (spec ? 2 : 4) || !(rdn == rdn)) { land_refuse(land_last); continue; }      // refused
+            if (land_rounds >= (blind ? 1 : (spec ? 2 : 4)) || !(rdn == rdn)) { land_refuse(land_last); continue; }      // refused
             // next round: rows move in / out of the active set by their signs (primal-dual active set) and the model is solved again from the SAME point -
             // a full step along a weakly curved direction may have left the boxes by far, x+ is then no place to linearise the hinge terms at; a round whose
             // set did not move was not stationary because a hinge term switched: that one is linearised again at x+ (= the oracle's su_land)
@@ -1961,7 +1985,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             mark(8);
         }
     }
-    used += it - land_its;
+    used += it - land_its > 0 ? it - land_its : 0;      // (an accepted BLIND landing has no measuring pass in front of it: two landing passes, the second one breaks at it = 1)
     if (a.land_stat && tid == 0) a.land_stat[3] += land_its;
     }
     __syncthreads();

@@ -65,7 +65,7 @@ _ENV_SWITCHES = {
     "RDA_SU_LIGHT": ("su_light",), "RDA_SU_WARM_FIRST": ("su_warm_first",), "RDA_SU_EASY_NOPRED": ("su_easy_nopred",), "RDA_SU_COLD_FROM": ("su_cold_from", "su_cold_probe"),
     "RDA_SU_EASY": ("su_easy", "su_easy_max"), "RDA_SU_WARM_CLIP": ("su_warm_clip",), "RDA_SU_WARM_ENDGAME": ("su_warm_endgame",), "RDA_SU_WARM": ("su_warm", "su_warm_cap"),
     "RDA_ZERO_COPY": ("zero_copy",), "RDA_EARLY_FINISH": ("early_finish",), "RDA_FUSE_TRACK": ("fuse_track",), "RDA_SU_PROF": ("su_prof",), "RDA_SU_SPLIT": ("su_split",),
-    "RDA_DUALS_FOLLOW": ("duals_follow",), "RDA_SU_ACCEPT": ("su_accept",), "RDA_SU_LAND": ("su_land",), "RDA_SU_LAND_TOL": ("su_land_tol",), "RDA_SU_LAND_RHO": ("su_land_rho",), "RDA_SU_LAND_FIRST": ("su_land_first",),
+    "RDA_DUALS_FOLLOW": ("duals_follow",), "RDA_SU_ACCEPT": ("su_accept",), "RDA_SU_LAND": ("su_land",), "RDA_SU_LAND_TOL": ("su_land_tol",), "RDA_SU_LAND_RHO": ("su_land_rho",), "RDA_SU_LAND_FIRST": ("su_land_first",), "RDA_SU_LAND_BLIND_FROM": ("su_land_blind_from",),
 }
 
 

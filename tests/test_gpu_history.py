@@ -38,7 +38,7 @@ def _obstacles(N):
 
 
 def _history(api, s):
-    hist, keep = np.zeros(6, np.int32), np.zeros(10 * s.T)          # RDA_SU_HISTORY_INTS = 6 since round 6 (+ the credit of the speculative landings, + the landing level key)
+    hist, keep = np.zeros(8, np.int32), np.zeros(10 * s.T)          # RDA_SU_HISTORY_INTS = 8 since round 6 (+ the credit of the speculative landings, the landing level key, the easy-landing count, the gate of the blind landings)
     assert api.get_su_history(s._be.handle, iptr(hist), dptr(keep)) == 0
     return hist, keep
 
@@ -55,9 +55,9 @@ def test_counted_history_accessors_serve_callers_of_other_header_versions(hip):
     two = np.full(4, -7, np.int32)
     assert hip.get_su_history_n(a._be.handle, iptr(two), 2, None) == 0
     assert np.array_equal(two[:2], full[:2]) and (two[2:] == -7).all()          # nothing written behind the caller's two ints
-    eight = np.full(8, -7, np.int32)
-    assert hip.get_su_history_n(a._be.handle, iptr(eight), 8, None) == 0
-    assert np.array_equal(eight[:6], full) and (eight[6:] == 0).all()
+    ten = np.full(10, -7, np.int32)
+    assert hip.get_su_history_n(a._be.handle, iptr(ten), 10, None) == 0
+    assert np.array_equal(ten[:8], full) and (ten[8:] == 0).all()
     mod = np.array([3, 1], np.int32)
     assert hip.set_su_history_n(a._be.handle, iptr(mod), 2, None) == 0            # the other two keys keep their values
     after, _ = _history(hip, a)

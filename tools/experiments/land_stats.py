@@ -39,7 +39,7 @@ def run(name, n_obs, T, moving, steps, ordered, **opts):
     st = list(st)
     print(f"{name:10s} ordered={int(ordered)} {str(opts):40s}: {solves / steps:4.2f} su-solves/step, interior-point its/solve {ipm / solves:5.2f}, "
           f"landings accepted {st[0]} refused {st[1]} rounds/solve {st[2] / solves:4.2f} landing passes/solve {st[3] / solves:4.2f}; speculative tried {st[4]} accepted {st[5]}, "
-          f"by decade of the start's rd0 (<1e-4 .. >=1): tried {st[6:12]} accepted {st[12:18]}", flush=True)
+          f"by decade of the start's rd0 (<1e-4 .. >=1): tried {st[6:12]} accepted {st[12:18]}; blind tried {st[18]} accepted {st[19]}", flush=True)
 
 
 if __name__ == "__main__":
