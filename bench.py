@@ -352,7 +352,7 @@ def main():
                                                for k, v in replay_roofs.items()},
         "parity": {"stated_tolerance_applied_control": 1e-6, "asserted_on_the_baseline_sizes": 1e-7,
                    "where": "tests/helpers.py TOL_U / TOL_U_FIXED (round 6: the su solve is landed on its vertex on both sides; largest difference in 35 360 soak steps "
-                            "against the cold oracle 3.1e-8); asserted by tests/test_gpu_soak.py (random scenes) and tests/test_gpu_baseline_sizes.py; DESIGN.md 2"},
+                            "against the cold oracle 1.3e-8); asserted by tests/test_gpu_soak.py (random scenes) and tests/test_gpu_baseline_sizes.py; DESIGN.md 2"},
     })
     if head is not None and head.elapsed_per_rank:
         out["per_rank_steps_per_s"] = [round(K / e, 3) for e in head.elapsed_per_rank]

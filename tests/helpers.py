@@ -13,8 +13,8 @@ from rda_planner_amd._capi import Cfg, dptr, iptr
 # enough for the active set to be read off, the vertex is then computed exactly and verified on the true objective - the answer no longer depends
 # on the interior-point path (cold / warm / easy / hard starts, speculative landings: tests/test_gpu_land.py 7e-15 .. 9e-11 per su-problem).
 # Largest value seen against the COLD oracle in 35 360 soak steps at the final kernels of round 6 (tools/soak.py --cold: default seeds 0 / 77, --large, --circles,
-# --exotic --robots, --tight, --lmz-central 1e-3; profiles/r06_soak_final_*.txt; 73 k over the round): 3.1e-8 (an --exotic scene; default mode 6.8e-9); the fixed
-# scenes of the BASELINE sizes <= 3e-11.  Asserted with a factor 30 of margin:
+# --exotic --robots, --tight, --lmz-central 1e-3; profiles/r06_soak_final_*.txt): 1.3e-8 (interior-point LamMuZ mode; default mode 6.8e-9); 100 k steps over the round's
+# builds: 3.1e-8; the fixed scenes of the BASELINE sizes <= 3e-11.  Asserted with a factor 30 of margin:
 TOL_U = 1e-6
 # ... and the bound asserted on the FIXED scenes of tests/test_gpu_baseline_sizes.py (BASELINE sizes) and the reference's dynamic_obs scene
 TOL_U_FIXED = 1e-7
