@@ -1336,6 +1336,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (attempt == 1) { screened = false; centre_duals(1e-1, 10.0); }
         else centre_duals(1e-2, 1.0);
         __syncthreads();
+        if (screened) {            // (the restart re-clips the nominal with another margin: its positions get the reach check of their own - rare path)
+            double dv = 0;
+            if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
+            dv = block_reduce(dv, L.red, tid, true);
+            if (dv > DELTA) screened = false;
+        }
         status = 1;
     }
     TR(150);
@@ -1734,18 +1740,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         // landing first, mode 2: the light first pass of a warm attempt did not meet the stop - land from the start all the same (see Args::land_first)
         const bool spec_now = !conv_now && expect_conv && land == 0 && landing && a.land_first == 2 && attempt < 0 && it == 0 && !spec_tried && rdn < a.land_first_rd0 * sc && rpn == rpn;
         if (conv_now || spec_now) {
-            if (screened) {        // the positions must have stayed within DELTA of the screening reference
-                double dv = 0;
-                if (tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
-                dv = block_reduce(dv, L.red, tid, true);
-                if (dv > DELTA) {           // safety net (the per-iteration check below normally acts first): all terms, and a
-                    screened = false;       // fresh, well-centred set of slacks / multipliers at the current primal point
-                    centre_duals(1e-2, 1.0);
-                    pair_rows();
-                    __syncthreads();
-                    continue;
-                }
-            }
+            // (rounds 1-5 re-checked here, with a block reduction of its own, that the positions lie within DELTA of the screening reference: the check behind every
+            // update - and the set-up's, at half the radius - has already taken that verdict for exactly these positions: they do not move between an update
+            // and the stop test of the next pass, and a refused landing goes back to a checked iterate.  2 k cycles per solve, never taken.  Round 6.)
             if (landing) {
                 // ---- start of the landing: remember the iterate, read the active set off it (lam > w), first round
                 for (int i = tid; i < 2 * T; i += NT) { L.sav[i] = L.u[i]; L.base[i] = L.u[i]; }
