@@ -497,6 +497,9 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
 #ifdef SU_TRACE
     if (a.prof && (threadIdx.x & 63) == 0) { long long *q = a.prof + 16 + ((threadIdx.x >> 6) * TRACE_CAP + trn) * 2; q[0] = 99; q[1] = a.t_entry; ++trn; for (int k = 0; k < 4; ++k) { q += 2; q[0] = 95 + k; q[1] = a.t_mark[k]; ++trn; } }
 #endif
+    // the landing counters: fire-and-forget atomic adds of thread 0.  As `a.land_stat[k] += 1` each was a global load - wait - store on the solve's critical path
+    // (the whole workgroup meets the waiting wave at the next barrier): ~1.5 k cycles per counter, three to five per solve
+#define LSTAT(k, v) do { if (a.land_stat && tid == 0) __hip_atomic_fetch_add(&a.land_stat[k], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
     TR(100);
     const double vref = pre.vref;
     // (stage, chunk) mapping of the obstacle reductions
@@ -1321,7 +1324,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         __syncthreads();
         rollout();
         __syncthreads();
-        if (a.land_stat && tid == 0) a.land_stat[1] += 1;
+        LSTAT(1, 1);
         land = 0; expect_conv = false;
         if (blind) { blind = false; res.blind = 2; }
         if (spec) { spec = false; spec_tried = true; res.spec = 2; } else land_level = last ? 99 : land_level + 1;      // (a refused speculation does not use up a landing level)
@@ -1359,7 +1362,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         }
         land_rho = a.land_rho_prev;
         land = 1; land_rounds = 1; expect_conv = false; spec = true; blind = true;
-        if (a.land_stat && tid == 0) { a.land_stat[4] += 1; a.land_stat[18] += 1; }
+        LSTAT(4, 1); LSTAT(18, 1);
         __syncthreads();
         land_rows(land_rho);
         __syncthreads();
@@ -1683,16 +1686,16 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         if (land == 2) {
             // ---- verdict on a landing round (this pass measured x+ with the hinge terms re-evaluated: rdn = stationarity, rpn = largest violation relative to
             //      1 + |e|, mu mcnt = sum of the negative parts of the multipliers; same thresholds as the oracle's su_land)
-            if (a.land_stat && tid == 0) a.land_stat[2] += 1;
+            LSTAT(2, 1);
             if (!spec) res.land_rounds += 1;
             res.rounds_all += 1;
             const bool moved = rpn > 1e-11 || mu * mcnt > 1e-9 * sc;
             if (!moved && rdn <= 100 * c.tol_rd * sc) {                      // landed
 #pragma unroll
                 for (int j = 0; j < NPR; ++j) if (p_on[j]) { Plp[j] = fmax(Plp[j], 0.0); Plm[j] = fmax(Plm[j], 0.0); }
-                if (a.land_stat && tid == 0) { a.land_stat[0] += 1; if (spec) { a.land_stat[5] += 1; if (!blind) a.land_stat[12 + spec_dec] += 1; } }
+                LSTAT(0, 1); if (spec) { LSTAT(5, 1); if (!blind) LSTAT(12 + spec_dec, 1); }
                 if (spec) res.spec = 1;
-                if (blind) { res.blind = 1; if (a.land_stat && tid == 0) a.land_stat[19] += 1; }
+                if (blind) { res.blind = 1; LSTAT(19, 1); }
                 res.land_rho = land_rho;
                 status = 0; break;
             }
@@ -1758,7 +1761,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 if (spec_now) {
                     const double q = rdn / sc;
                     spec_dec = q < 1e-4 ? 0 : (q < 1e-3 ? 1 : (q < 1e-2 ? 2 : (q < 1e-1 ? 3 : (q < 1.0 ? 4 : 5))));
-                    if (a.land_stat && tid == 0) { a.land_stat[4] += 1; a.land_stat[6 + spec_dec] += 1; }
+                    LSTAT(4, 1); LSTAT(6 + spec_dec, 1);
                 }
                 TR(13);
                 __syncthreads();
@@ -1983,7 +1986,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         }
     }
     used += it - land_its > 0 ? it - land_its : 0;      // (an accepted BLIND landing has no measuring pass in front of it: two landing passes, the second one breaks at it = 1)
-    if (a.land_stat && tid == 0) a.land_stat[3] += land_its;
+    LSTAT(3, land_its);
     }
     __syncthreads();
     if ((status != 0 || a.accept == 2) && have_acc) {          // every attempt failed: the safety net (the remembered iterate is primal feasible: inside the boxes).  accept == 2: test switch -
@@ -2031,6 +2034,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     return true;
 }
 #undef RW
+#undef LSTAT
 #undef R5
 #undef MS
 #undef MF
