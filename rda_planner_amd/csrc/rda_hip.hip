@@ -695,7 +695,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
     // stop flag, half-spaces, pose / duals, support cache, slot -> obstacle, remembered support): everything a row reads is requested
     // here, in two batches, before the first of them is waited for.  The throughput forms (modes 1, 2) keep their loads where the
     // values are used: there the registers are worth more than the latency (three waves per SIMD hide it).
-    struct Early { double px, py, cs, sn, xi0, xi1, zeta, dbar, prev, vtx[4], A, b, G, h; int cone, src, hpar, hint, npv, nlv; unsigned char lamc[3]; } ey;
+    struct Early { double px, py, cs, sn, xi0, xi1, zeta, dbar, prev, vtx[4], A, b, G, h, zold; int cone, src, hpar, hint, npv, nlv; unsigned char lamc[3]; } ey;
     if (MODE == 0) {
         const int nl0 = jb * GS + wv * 4 + row, nl = nl0 < d.Nlive ? nl0 : 0, n = d.rank * d.Nloc + nl;
         ey.src = (d.slot_src && n < d.src_used) ? d.slot_src[n] : -1;
@@ -710,6 +710,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
         const size_t o = drow(d, n, t + 1), zi = drow(d, n, t), oc = (size_t)n * d.nt + (d.nt > 1 ? t + 1 : 0);
         ey.px = ps[0]; ey.py = ps[1]; ey.cs = ps[2]; ey.sn = ps[3];
         ey.xi0 = d.xi[2 * o]; ey.xi1 = d.xi[2 * o + 1]; ey.zeta = d.zeta[zi]; ey.dbar = d.dis[t]; ey.cone = d.cone[n];
+        ey.zold = d.z[zi];                // (the previous z of the row's residual: it was fetched where it is used, a trip to memory inside the update phase)
         // (ONE unconditional load through a selected address: as `gl < E ? lam : (gl < E + R ? mu : 0)` the two loads shared their destination register and the
         // second one waited - vmcnt(0), in the middle of the batch - for the first; lanes beyond E + R read lam[0] and are zeroed where `prev` is used.  Round 6)
         ey.prev = *(gl < E ? &d.lam[o * E + gl] : (gl < E + R ? &d.mu[o * R + gl - E] : &d.lam[o * E]));
@@ -926,7 +927,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
         double v = lmz::mu_of(best, j);
         res = (v - prev) * (v - prev); if (wr) d.mu[o * R + j] = v;
     } else if (gl == E + R) {
-        double old = d.z[zi];
+        const double old = MODE == 0 ? ey.zold : d.z[zi];
         res = (znew - old) * (znew - old); if (wr) d.z[zi] = znew;
     }
 #pragma unroll
