@@ -988,7 +988,7 @@ template <int MODE = 0, bool CW = false> __device__ __forceinline__ void lammuz_
 
 // two builds: all registers and one wave per SIMD (no spills: the shorter critical path a single ego wants), or two
 // waves per SIMD with a few spilled registers (more sub-problems in flight: what a full chip wants)
-__global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { lammuz_body_rows<0, true>(d, blockIdx.x, gridDim.x, it, fin); }
+__global__ __launch_bounds__(64 * GS / 4) void k_lammuz_rows(Dev d, int it, Fin fin) { warm_kernargs<sizeof(Dev) + sizeof(int) + sizeof(Fin)>(); lammuz_body_rows<0, true>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_rows_dense(Dev d, int it, Fin fin) { lammuz_body_rows<0>(d, blockIdx.x, gridDim.x, it, fin); }
 __global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_rows_fast(Dev d, int it) { lammuz_body_rows<1>(d, blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 // (measured: the common path with four waves per SIMD and 31 spilled registers is 9 % slower.  Round 4, same-box A/B (tools/experiments/ab_so.sh): the common
