@@ -1614,8 +1614,10 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             // early verdict for wave 0 (see there): wave 3's measures are published under *flag_meas = seq
             while (__atomic_load_n(flag_meas, __ATOMIC_ACQUIRE) != seq) __builtin_amdgcn_s_sleep(1);
             {
-                const double gn_ = *(volatile double *)&L.red[9], rpn_ = *(volatile double *)&L.red[10];
-                const double mu_ = *(volatile double *)&L.red[11] / mcnt, sc_ = 1 + gn_;
+                // (plain LDS reads behind the acquire above.  As `*(volatile double *)&L.red[k]` they were FLAT loads with sc0 sc1 - the cast loses the LDS address
+                // space - each followed by s_waitcnt vmcnt(0): three trips through the flat path on the critical path of every light pass, found in the ISA, round 6)
+                const double gn_ = L.red[9], rpn_ = L.red[10];
+                const double mu_ = L.red[11] / mcnt, sc_ = 1 + gn_;
                 // (not in a landing round: its rows carry no residual / complementarity, the "measures" of that pass would always pass - and the round NEEDS its
                 // factorisation: an abandoned recursion left the stale factors of the last interior-point iteration in place, found with a dense solve of the
                 // dumped Newton system, scratch of round 6)
