@@ -413,9 +413,10 @@ template <int TT> __device__ __forceinline__ void prefetch(const Args &a, Pre &p
     const int T = TT > 0 ? TT : c.T, tid = threadIdx.x;
     p.vref = *a.ref_speed;
     p.d = c.max_sd;
-    if (tid < T) {
-        p.u0 = a.in_u[tid]; p.u1 = a.in_u[T + tid]; if (a.d_in) p.d = a.d_in[tid];
-        if (a.pose_lin) { p.cp = a.pose[4 * tid + 2]; p.sp = a.pose[4 * tid + 3]; }
+    if (tid < 128 && (tid & 63) < T) {          // (lane t of wave 0 - the linearisation - and of wave 1 - the clip of the start, beside it)
+        const int t = tid & 63;
+        p.u0 = a.in_u[t]; p.u1 = a.in_u[T + t]; if (a.d_in) p.d = a.d_in[t];
+        if (a.pose_lin) { p.cp = a.pose[4 * t + 2]; p.sp = a.pose[4 * t + 3]; }
     }
     if (a.lam_keep)
         for (int j = 0; j < 2; ++j) {
@@ -537,7 +538,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
     MS(0); TR(120);
     if (tid < T) {
         int t = tid;
-        double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { L.u[t], L.u[T + t] };
+        double st[3] = { L.s[t], L.s[(T + 1) + t], L.s[2 * (T + 1) + t] }, ut[2] = { pf_u0, pf_u1 };      // (the nominal controls from the registers: wave 1 is clipping L.u meanwhile)
         double cp, sp;
         if (a.pose_lin) { cp = pf_cp; sp = pf_sp; } else sincos(st[2], &sp, &cp);
         L.csn[t] = cp; L.csn[T + t] = sp;
@@ -563,6 +564,20 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         }
         F[6 * 5 + 3] = 1.0; F[6 * 6 + 4] = 1.0;
     }
+    // ... and BESIDE the linearisation (wave 0) wave 1 pulls the start inside the boxes (round 6: it was a phase of its own, the T threads of wave 0 and a barrier).
+    // A warm attempt starts next to the previous solution: pulled inside by warm_clip only (a cold start by 1 %), so that the kept multipliers of the active rows
+    // meet slacks of that size and the start is already nearly complementary
+    if (wave == 1 && lane < T) {
+        const int t = lane;
+        const double clipm = warm ? a.warm_clip : 0.01;
+        const double lim0 = (1.0 - clipm) * c.umax0, lim1 = (1.0 - clipm) * c.umax1;
+        const double v0 = pf_u0, v1 = pf_u1;
+        L.u[t] = v0 > lim0 ? lim0 : (v0 < -lim0 ? -lim0 : v0);
+        L.u[T + t] = v1 > lim1 ? lim1 : (v1 < -lim1 ? -lim1 : v1);
+        const double lo = c.min_sd + clipm * (c.max_sd - c.min_sd), hi = c.max_sd - clipm * (c.max_sd - c.min_sd);
+        const double dv = pf_d;
+        L.d[t] = dv > hi ? hi : (dv < lo ? lo : dv);
+    }
     __syncthreads();
     MS(11); TR(131);
     // ---- initial point (same rule as the oracle) ------------------------------------------------
@@ -579,15 +594,13 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         }
         __syncthreads();
     };
-    // a warm attempt starts next to the previous solution: pulled inside the boxes by warm_clip only (a cold start by 1 %), so that the
-    // kept multipliers of the active rows meet slacks of that size and the start is already nearly complementary
-    clip_controls(warm ? a.warm_clip : 0.01);
+    // (the set-up's own clip: done by wave 1 beside the linearisation, above)
     // state rollout with the current controls.  In all three motion models A = [[1,0,a13],[0,1,a23],[0,0,1]]
     // (rda_solver.py:955,971,987), so the heading is a running sum of per-stage increments and, once it is known, so
     // are x and y: the increments are formed by one lane per stage, the two running sums are 3T dependent additions
     // on values that were fetched in one go (wave 0 only).
-    auto rollout = [&]() {
-        if (wave == 0) {
+    auto rollout = [&](const int wv = 0) {       // (one whole wave; the set-up's runs on wave 3, beside the start of the duals on the pair threads of waves 0 - 2)
+        if (wave == wv) {
             double *inc = L.dy;                         // scratch: dy is dead outside the sweeps
             for (int t = lane; t < T; t += 64) {
                 const double *B = &L.Bk[6 * t], *C = &L.Ck[3 * t];
@@ -625,7 +638,7 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             }
         }
     };
-    rollout();
+    rollout(3);
     MS(13); TR(133);
     // ---- the inequality rows live in REGISTERS.  The 10 rows of a stage are 5 pairs (+val <= e+, -val <= e-) of one linear form each
     // (k = 0 u0, 1 u1, 2 d, 3 u0 - up0, 4 u1 - up1; the rate pairs exist for t >= 1): pair p = 5 t + k is owned by thread p (5 T <= 256
