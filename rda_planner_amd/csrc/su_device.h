@@ -849,23 +849,19 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
             }
         }
         MS(3); TR(123);
-        if (screened) {            // a dense active set is served better by the streaming loop: keep the sparse path for < 30 %;
-            double cnt = 0;        // and the nominal itself must lie within DELTA of the screening reference
-            for (int w = 0; w < MW; ++w) cnt += (double)__popcll(amask[w]);
-            cnt = block_reduce(cnt, L.red, tid, false);
-            double dv = 0;
-            if (masks_in && tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
-            if (masks_in) dv = block_reduce(dv, L.red, tid, true);
-            if (cnt > 0.3 * (double)a.P * a.Nloc * T || dv > 0.5 * DELTA) screened = false;
-        }
-        MS(14); TR(134);
         // ---- near list (round 4).  The terms the masks name are fetched ONCE, here, into a compact stage-major list in LDS: (ax, ay, cb, stage).
         // The per-iteration hinge sums (phase 1 below) then take one term per thread - no trip to memory, no loop, no register cache - and
         // one thread per (stage, quantity) adds the stage's contributions up in list order (chunk, then bit: the order of the mask walk).
+        // A dense active set is served better by the streaming loop (the sparse path is kept for < 30 %), and the nominal itself must lie within DELTA / 2 of
+        // the screening reference.  (Round 6: the count of near terms IS the total of the list's scan and the reach of the nominal travels through the same
+        // barrier pair - rounds 4-5 ran two block reductions, four barriers, in front of the scan for the same two numbers.)
+        int mine = 0;
         if (screened) {
-            int mine = 0;
             if (ract) for (int w = 0; w < MW; ++w) mine += __popcll(amask[w]);
             L.ncnt[tid] = mine;
+            double dv = 0;
+            if (masks_in && tid < T) { double ex = L.s[tid + 1] - L.p0[tid], ey = L.s[(T + 1) + tid + 1] - L.p0[T + tid]; dv = sqrt(ex * ex + ey * ey); }
+            if (masks_in) { dv = wave_allreduce(dv, true); if (lane == 0) L.red[280 + wave] = dv; }
             __syncthreads();
             if (wave == 0) {                                      // first entry of every stage (sto[T]: the total): stage totals, one wave scan (T <= 64)
                 int tot = 0;
@@ -877,6 +873,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
                 if (lane == T - 1) L.sto[T] = inc;
             }
             __syncthreads();
+            const double cnt = (double)L.sto[T];
+            const double dvm = masks_in ? fmax(fmax(L.red[280], L.red[281]), fmax(L.red[282], L.red[283])) : 0.0;
+            if (cnt > 0.3 * (double)a.P * a.Nloc * T || dvm > 0.5 * DELTA) screened = false;
+        }
+        MS(14); TR(134);
+        if (screened) {
             listed = L.sto[T] <= near_cap(T);
             if (listed && ract && mine > 0) {
                 int off = L.sto[rt];
