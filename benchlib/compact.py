@@ -79,6 +79,8 @@ def _size(e):
         cl = fl.get("c_abi_closed_loop")
         if isinstance(cl, dict):
             out["fleet"]["closed_loop_ego_steps_per_s"] = _num(cl.get("ego_steps_per_s"))
+            if isinstance(cl.get("fleets_4_host_threads"), dict):
+                out["fleet"]["closed_loop_4_fleets_ego_steps_per_s"] = _num(cl["fleets_4_host_threads"].get("ego_steps_per_s"))
     return out
 
 
@@ -120,6 +122,8 @@ def compact(full):
             legs["multi_ego_fleet"]["python_fleet_control"] = _sps(fl["python_api_closed_loop"])
         if isinstance(fl.get("c_abi_closed_loop"), dict):
             legs["multi_ego_fleet"]["c_abi_closed_loop_ego_steps_per_s"] = _num(fl["c_abi_closed_loop"].get("ego_steps_per_s"))
+            if isinstance(fl["c_abi_closed_loop"].get("fleets_4_host_threads"), dict):
+                legs["multi_ego_fleet"]["c_abi_closed_loop_4_fleets_ego_steps_per_s"] = _num(fl["c_abi_closed_loop"]["fleets_4_host_threads"].get("ego_steps_per_s"))
     ip = full.get("lammuz_interior_point_closed_loops")
     if isinstance(ip, dict):
         e = {}

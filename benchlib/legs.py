@@ -235,12 +235,18 @@ def fleet(ctx):
     try:
         out["c_abi_closed_loop"] = fleet_closed_loop(ctx, M)
         out["c_abi_closed_loop"]["member_by_member_resort_ego_steps_per_s"] = fleet_closed_loop(ctx, M, steps=12, warm=4, check=(), resort=1)["ego_steps_per_s"]
+        if M % 4 == 0 and M >= 16:
+            # the same M egos as FOUR fleets of M / 4, each ticked by its own host thread: one fleet's su launch (one workgroup per member, the launch waits for
+            # its slowest member) runs beside the other fleets' LamMuZ grids.  2 and 8 fleets are slower (tools/experiments/fleet_groups.py)
+            g4 = fleet_closed_loop(ctx, M, check=(0,), groups=4)
+            out["c_abi_closed_loop"]["fleets_4_host_threads"] = {k: g4[k] for k in ("ego_steps_per_s", "ms_per_fleet_tick", "mean_admm_iters", "host_threads",
+                                                                                     "max_du_vs_solo_closed_loop")}
     except Exception as e:
         out["c_abi_closed_loop"] = {"error": repr(e)[:200]}
     return out
 
 
-def fleet_closed_loop(ctx, M, steps=30, warm=6, check=(0, 1), resort=2):
+def fleet_closed_loop(ctx, M, steps=30, warm=6, check=(0, 1), resort=2, groups=1):
     """BASELINE config C5 as a CLOSED LOOP through the C-ABI: M egos, each with its OWN seeded scene (seed + ego), its own path index and state;
     the caller is C (tools/closed_loop_host.c closed_loop_fleet_run): per fleet tick rda_fleet_scene_resort (resort = 2; 1: rda_scene_resort member by member -
     the reference re-sorts each robot's list on every tick, mpc.py:205-206), ONE rda_fleet_step_tracked (every member's pre_process + ADMM loop, one host synchronisation), kinematics of every member in
@@ -268,32 +274,53 @@ def fleet_closed_loop(ctx, M, steps=30, warm=6, check=(0, 1), resort=2):
         sv = ctx.new_solver()
         states[e], plen[e] = stage(sv, e)
         solvers.append(sv)
-    arr = (C.c_void_p * M)(*[sv._be.handle for sv in solvers])
-    F = C.c_void_p()
-    assert api.fleet_create(arr, M, C.byref(F)) == 0
-    cur = np.zeros(M, np.int32)
-    nom_u0 = np.zeros((M, 2, T))
-    u_log, t_log = np.zeros((n_all, M, 2)), np.zeros(n_all)
-    it_log, ipm_log = np.zeros((n_all, M), np.int32), np.zeros((n_all, M), np.int32)
+    # `groups` fleets of M / groups members each, every fleet ticked by its own host thread (the members are independent robots: nothing couples two fleets; the
+    # C loop runs without the interpreter lock): one fleet's su launch - the wait for its slowest member - overlaps the other fleets' LamMuZ grids
+    assert M % groups == 0
+    Mg = M // groups
     L, dyn = float(ctx.car_t.wheelbase or 0.0), {"acker": 0, "diff": 1, "omni": 2}[ctx.car_t.dynamics]
+    G = []
+    for g in range(groups):
+        arr = (C.c_void_p * Mg)(*[sv._be.handle for sv in solvers[g * Mg:(g + 1) * Mg]])
+        F = C.c_void_p()
+        assert api.fleet_create(arr, Mg, C.byref(F)) == 0
+        G.append(dict(arr=arr, F=F, cur=np.zeros(Mg, np.int32), nom_u0=np.zeros((Mg, 2, T)), states=np.ascontiguousarray(states[g * Mg:(g + 1) * Mg]),
+                      plen=np.ascontiguousarray(plen[g * Mg:(g + 1) * Mg]), u_log=np.zeros((n_all, Mg, 2)), t_log=np.zeros(n_all),
+                      it_log=np.zeros((n_all, Mg), np.int32), ipm_log=np.zeros((n_all, Mg), np.int32), rc=0))
+
+    def go_one(q, k0, n):
+        q["rc"] = host.fleet_run(C.byref(host.fleet_api), q["F"], q["arr"], Mg, T, dyn, L, 0.1, 4.0, 0.1, 10, iptr(q["plen"]), resort, k0, n, dptr(q["nom_u0"]),
+                                 dptr(q["states"]), iptr(q["cur"]), dptr(q["u_log"][k0:]), dptr(q["t_log"][k0:]), iptr(q["it_log"][k0:]), iptr(q["ipm_log"][k0:]))
 
     def go(k0, n):
-        rc = host.fleet_run(C.byref(host.fleet_api), F, arr, M, T, dyn, L, 0.1, 4.0, 0.1, 10, iptr(plen), resort, k0, n, dptr(nom_u0), dptr(states), iptr(cur),
-                            dptr(u_log[k0:]), dptr(t_log[k0:]), iptr(it_log[k0:]), iptr(ipm_log[k0:]))
-        assert rc == 0, rc
+        if groups == 1:
+            go_one(G[0], k0, n)
+        else:
+            import threading
+            th = [threading.Thread(target=go_one, args=(q, k0, n)) for q in G]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+        for q in G:
+            assert q["rc"] == 0, q["rc"]
+            api.fleet_sync(q["F"])
     go(0, warm)
-    api.fleet_sync(F)
     t0 = time.perf_counter()
     go(warm, steps)
-    api.fleet_sync(F)
     el = time.perf_counter() - t0
+    u_log = np.concatenate([q["u_log"] for q in G], axis=1)
+    t_log = np.max([q["t_log"] for q in G], axis=0)
+    it_log, ipm_log = np.concatenate([q["it_log"] for q in G], axis=1), np.concatenate([q["ipm_log"] for q in G], axis=1)
     out = {"egos": M, "steps_per_ego": steps, "warmup": warm, "ego_steps_per_s": round(M * steps / el, 1), "ms_per_fleet_tick": round(el / steps * 1e3, 4),
            "median_ms_per_fleet_tick": round(float(np.median(t_log[warm:])) * 1e3, 4), "mean_admm_iters": round(float(it_log[warm:].mean()), 3),
            "su_interior_point_iters_per_ego_step": round(float(ipm_log[warm:].mean()), 2),
            "resort": "rda_fleet_scene_resort (one launch set)" if resort == 2 else "rda_scene_resort member by member",
            "what": "closed loop through the C-ABI, caller in C: per fleet tick the members' scenes re-sorted + ONE rda_fleet_step_tracked (one host "
                    "synchronisation) + every member's kinematics; every member its own seeded scene, re-sorted about its robot on every tick (the headline protocol)"}
-    api.fleet_destroy(F)
+    out["host_threads"] = groups
+    for q in G:
+        api.fleet_destroy(q["F"])
     del solvers
     # solo runs of the same members in the same protocol (closed_loop_run: rda_tracked_begin + rda_scene_resort + rda_tracked_finish)
     worst = 0.0

@@ -2736,7 +2736,10 @@ __global__ __launch_bounds__(64 * GS / 4, 2) void k_lammuz_fleet_rows(const Dev 
 {
     lammuz_body_rows<0>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, fleet_fin(devs[blockIdx.y], io[blockIdx.y], k));
 }
-__global__ __launch_bounds__(64 * GS / 4, 3) void k_lammuz_fleet_rows_fast(const Dev *devs, int it) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
+#ifndef LMZ_FLEET_FAST_OCC
+#define LMZ_FLEET_FAST_OCC 3
+#endif
+__global__ __launch_bounds__(64 * GS / 4, LMZ_FLEET_FAST_OCC) void k_lammuz_fleet_rows_fast(const Dev *devs, int it) { lammuz_body_rows<1>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 __global__ __launch_bounds__(64 * GS / 4, 1) void k_lammuz_fleet_enum(const Dev *devs, int it) { lammuz_body_rows<2>(devs[blockIdx.y], blockIdx.x, gridDim.x, it, Fin{nullptr, nullptr, nullptr, nullptr, 0, 0}); }
 __global__ __launch_bounds__(256) void k_lmz_finalize_fleet(const Dev *devs, const EgoIO *io, int it, int k)
 {
@@ -3005,6 +3008,13 @@ extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const 
         HIPCHK(hipHostMalloc((void **)&F->h_io_track, B * sizeof(EgoIO)));
         memset(F->h_paths, 0, B * sizeof(double *)); memset(F->h_lens, 0, B * sizeof(int)); memset(F->h_io_track, 0, B * sizeof(EgoIO));
     }
+    // the result of the tick is written where the host reads it (round 6): k_finish_fleet and k_track_fleet store straight into the pinned blocks (write-only,
+    // fire-and-forget stores over the link, complete at the end of their kernels) instead of three device-to-host copies queued behind the last launch
+    // (~10 us each on the tick's critical path).  rda_opts::zero_copy = 0 on any member keeps the copies.
+    bool zc = true;
+    for (size_t i = 0; i < B; ++i) if (!F->egos[i]->zero_copy) zc = false;
+    double *const out_base = zc ? F->h_out : F->d_out;
+    rda_info *const info_base = zc ? F->h_info : F->d_info;
     bool tables = false;
     for (size_t i = 0; i < B; ++i) {
         rda_handle *H = F->egos[i];
@@ -3014,7 +3024,7 @@ extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const 
         in.cur_index = cur_index[i]; in.ind_range = ind_range;
         EgoIO e;
         e.s = F->d_in + i * nin; e.u = nom_u ? e.s + ns : H->d.u; e.ref = e.s + ns + nu; e.speed = e.ref + ns;
-        e.out_u = F->d_out + i * nout; e.out_s = e.out_u + nu; e.info = F->d_info + i;
+        e.out_u = out_base + i * nout; e.out_s = e.out_u + nu; e.info = info_base + i;
         if (memcmp(&e, &F->h_io_track[i], sizeof(EgoIO)) != 0 || F->h_paths[i] != H->d_path || F->h_lens[i] != H->path_len) tables = true;
     }
     int rc = fleet_refresh(F);
@@ -3025,7 +3035,7 @@ extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const 
             rda_handle *H = F->egos[i];
             EgoIO &e = F->h_io_track[i];
             e.s = F->d_in + i * nin; e.u = nom_u ? e.s + ns : H->d.u; e.ref = e.s + ns + nu; e.speed = e.ref + ns;
-            e.out_u = F->d_out + i * nout; e.out_s = e.out_u + nu; e.info = F->d_info + i;
+            e.out_u = out_base + i * nout; e.out_s = e.out_u + nu; e.info = info_base + i;
             F->h_paths[i] = H->d_path; F->h_lens[i] = H->path_len;
         }
         HIPCHK(hipMemcpyAsync(F->d_io_track, F->h_io_track, B * sizeof(EgoIO), hipMemcpyHostToDevice, F->stream));
@@ -3039,12 +3049,14 @@ extern "C" int rda_fleet_step_tracked(rda_fleet *F, const double *states, const 
     }
     HIPCHK(hipMemcpyAsync(F->d_trk_in, F->h_trk_in, B * sizeof(track::In), hipMemcpyHostToDevice, F->stream));
     hipLaunchKernelGGL(k_track_fleet, dim3((unsigned)B), dim3(64), 0, F->stream, F->d_devs, F->d_io_track, F->d_trk_in,
-                       F->d_paths, F->d_lens, F->d_trk_out, (int)B);
+                       F->d_paths, F->d_lens, zc ? F->h_trk_out : F->d_trk_out, (int)B);
     rc = fleet_enqueue(F, F->d_io_track, 0);
     if (rc != RDA_OK) return rc;
-    HIPCHK(hipMemcpyAsync(F->h_out, F->d_out, B * nout * sizeof(double), hipMemcpyDeviceToHost, F->stream));
-    HIPCHK(hipMemcpyAsync(F->h_info, F->d_info, B * sizeof(rda_info), hipMemcpyDeviceToHost, F->stream));
-    HIPCHK(hipMemcpyAsync(F->h_trk_out, F->d_trk_out, B * sizeof(track::Out), hipMemcpyDeviceToHost, F->stream));
+    if (!zc) {
+        HIPCHK(hipMemcpyAsync(F->h_out, F->d_out, B * nout * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+        HIPCHK(hipMemcpyAsync(F->h_info, F->d_info, B * sizeof(rda_info), hipMemcpyDeviceToHost, F->stream));
+        HIPCHK(hipMemcpyAsync(F->h_trk_out, F->d_trk_out, B * sizeof(track::Out), hipMemcpyDeviceToHost, F->stream));
+    }
     if (ref_out) HIPCHK(hipMemcpyAsync(F->h_in, F->d_in, B * nin * sizeof(double), hipMemcpyDeviceToHost, F->stream));
     HIPCHK(hipStreamSynchronize(F->stream));
     for (rda_handle *Hm : F->egos) Hm->pending_scene = 0;      // their staged scenes have been consumed

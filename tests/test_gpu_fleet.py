@@ -296,3 +296,64 @@ def test_c_fleet_closed_loop_equals_solo_closed_loops(hip, resort):
         assert np.array_equal(il, it_log[:, e]), (e, il, it_log[:, e])
         assert np.array_equal(ul, u_log[:, e, :]), (e, float(np.abs(ul - u_log[:, e, :]).max()))
         assert np.allclose(st, states[e], rtol=0, atol=0)
+
+
+def test_fleets_ticked_by_their_own_host_threads_equal_one_fleet(hip):
+    """What bench.py's `c_abi_closed_loop.fleets_4_host_threads` times: the members split over SEVERAL fleets, each fleet's closed loop run by its own host thread
+    (closed_loop_fleet_run, no interpreter lock inside) - nothing couples two fleets, the library keeps no state outside its handles, so the concurrent loops give
+    the controls of ONE fleet of all members (which the test above pins to the solo loops), bit for bit."""
+    import os
+    import sys
+    import threading
+    from rda_planner_amd.rda_solver import RDA_solver
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import closed_loop_host as clh
+    host = clh.Host(hip.lib)
+    B, T, N, steps = 6, 10, 16, 30
+    car_t = sc.rectangle_robot(dynamics="acker")
+
+    def make(e):
+        y = 20.0 + 2.5 * e
+        path = sc.line_path([4, y, 0], [44, y, 0], 0.1)
+        clear = np.array([[p[0, 0], p[1, 0]] for p in path[::10]])
+        scene = sc.scene_polygons(12, lo=(6, y - 6), hi=(44, y + 6), seed=170 + e, keep_clear=clear, clear_radius=2.3)
+        sv = RDA_solver(T, car_t, 4, N, iter_num=3, time_print=False)
+        n_sc, kind, nvert, geom, vel = sv.flatten_scene(list(scene))
+        kind, nvert = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(nvert, np.int32)
+        geom, vel = np.ascontiguousarray(geom, float), np.ascontiguousarray(vel, float)
+        P = np.ascontiguousarray(np.hstack(path)[0:3, :].T, dtype=float)
+        st = np.ascontiguousarray(path[0], float).ravel()[0:3].copy()
+        assert hip.upload_path(sv._be.handle, int(P.shape[0]), dptr(P)) == 0
+        assert hip.upload_scene(sv._be.handle, int(n_sc), iptr(kind), iptr(nvert), dptr(geom), dptr(vel), dptr(st), 1, None) == 0
+        return sv, st, int(P.shape[0])
+
+    def loops(split):
+        memb = [make(e) for e in range(B)]
+        groups = []
+        for lo, hi in split:
+            n = hi - lo
+            arr = (C.c_void_p * n)(*[m[0]._be.handle for m in memb[lo:hi]])
+            F = C.c_void_p()
+            assert hip.fleet_create(arr, n, C.byref(F)) == 0
+            groups.append(dict(n=n, arr=arr, F=F, states=np.array([m[1] for m in memb[lo:hi]]), plen=np.array([m[2] for m in memb[lo:hi]], np.int32),
+                               cur=np.zeros(n, np.int32), nom=np.zeros((n, 2, T)), u=np.zeros((steps, n, 2)), t=np.zeros(steps),
+                               it=np.zeros((steps, n), np.int32), ipm=np.zeros((steps, n), np.int32), rc=-99))
+
+        def run(q):
+            q["rc"] = host.fleet_run(C.byref(host.fleet_api), q["F"], q["arr"], q["n"], T, 0, 3.0, 0.1, 4.0, 0.1, 10, iptr(q["plen"]), 2, 0, steps, dptr(q["nom"]),
+                                     dptr(q["states"]), iptr(q["cur"]), dptr(q["u"]), dptr(q["t"]), iptr(q["it"]), iptr(q["ipm"]))
+        th = [threading.Thread(target=run, args=(q,)) for q in groups]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for q in groups:
+            assert q["rc"] == 0, q["rc"]
+            hip.fleet_destroy(q["F"])
+        return np.concatenate([q["u"] for q in groups], axis=1), np.concatenate([q["it"] for q in groups], axis=1), np.concatenate([q["states"] for q in groups])
+    u1, it1, s1 = loops([(0, B)])
+    u3, it3, s3 = loops([(0, 2), (2, 4), (4, 6)])
+    assert np.abs(u1[:, :, 0]).min() > 0.5
+    assert np.array_equal(it1, it3)
+    assert np.array_equal(u1, u3), float(np.abs(u1 - u3).max())
+    assert np.array_equal(s1, s3)

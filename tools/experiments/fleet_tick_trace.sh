@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 D=gpurun_out/fleet_trace; rm -rf $D; mkdir -p $D
-rocprofv3 --kernel-trace --output-format csv -d $D -o f -- python bench.py --size-leg --cpu-threads 16 --n-obs 100 --horizon 25 --steps 30 --warmup 8 --fleet-egos 64 --no-cpu-baseline > $D/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $D -o f -- python bench.py --size-leg --cpu-threads 16 --n-obs 100 --horizon 25 --steps 30 --warmup 8 --fleet-egos ${EGOS:-64} --no-cpu-baseline > $D/run.log 2>&1
 F=$(find $D -name '*kernel_trace.csv' | head -1)
 python - "$F" <<'PY'
 import csv, sys, collections
