@@ -185,7 +185,10 @@ int  rda_set_adjust(rda_handle *h, double slack_gain, double max_sd, double min_
 int  rda_reset(rda_handle *h);
 const char *rda_strerror(int code);
 int  rda_device_count(void);
-int  rda_set_device(int dev);     /* device used by handles created afterwards (one process per GPU) */
+int  rda_set_device(int dev);     /* device used by handles created afterwards (one process per GPU).  HIP's current device belongs to the calling HOST THREAD
+                                   * (default 0): a thread that drives handles or fleets created on device `dev` calls this once first.  The library keeps
+                                   * no state outside its handles and fleets: distinct handles / fleets may be driven by distinct threads concurrently
+                                   * (one thread at a time per handle or fleet) */
 
 /* One MPC step, host buffers: nom_s 3x(T+1), nom_u 2xT, ref_s 3x(T+1) row-major;
  * obstacles A [n_obs][per_t? T+1 : 1][E][2], b [n_obs][per_t? T+1 : 1][E], cone [n_obs] (0 Rpositive, 1 norm2);
