@@ -273,6 +273,15 @@ def main():
     if head is not None and one:
         head_t = closed_loop.run(ctx, per_tick_scene=moving, ordered=True, timing=True, compare=False)
 
+    # ---- the other sizes the metric names (sub-processes), BEFORE this process runs its fleet legs: a sub-process started after the 64-ego fleet legs
+    #      prints 8 - 15 % less on every size (n20 4.08 k against 4.68 k, C4 684 against 769, the C5 fleet 31.8 k against 34.7 k ego-steps/s; the multi-ego
+    #      and interior-point legs have no such effect, a garbage collection changes nothing, an idle process holding handles neither:
+    #      tools/experiments/sizes_parent_probe.sh, idle_context_probe.sh, round 6) - seconds of all 256 CUs busy leave the device in a slower state for a
+    #      while.  Every size leg is a measurement of its own configuration: it runs on the device as the headline found it.
+    sizes_res = None
+    if one and not shard and not args.no_sizes and (N, T, moving) == (200, 20, False):
+        sizes_res = legs.sizes(args.sizes_budget_s, os.path.abspath(__file__))
+
     # ---- interior-point LamMuZ mode (row-parallel kernel k_lammuz_ip): the robust setting lmz_central = 1e-3 on the headline scene, and a
     #      CIRCLE robot (norm2 robot cone, rda_solver.py:1034-1039: always this mode) - in the headline protocol (re-sorted every tick:
     #      VERDICT r04 #5) and with a fixed binding.  The reference solves EVERY LamMuZ problem with an interior point (rda_solver.py:768,800).
@@ -358,8 +367,8 @@ def main():
         out["per_rank_steps_per_s"] = [round(K / e, 3) for e in head.elapsed_per_rank]
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline.run(ctx)
-    if world == 1 and not args.no_sizes and (N, T, moving) == (200, 20, False):
-        out["sizes"], out["sizes_wall_s"] = legs.sizes(args.sizes_budget_s, os.path.abspath(__file__))
+    if sizes_res is not None:
+        out["sizes"], out["sizes_wall_s"] = sizes_res
     if want_shard_leg:
         def give_up():
             out["obstacle_shard_leg"] = {"error": f"no result within {args.shard_leg_timeout:.0f} s (collective did not complete)"}
