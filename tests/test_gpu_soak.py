@@ -5,13 +5,14 @@ of the scenes moving) + circles, iter_num 2-4, padded / truncated slot counts - 
 the checker is the COLD oracle (every su-problem from a cold interior-point start, like ECOS in the reference: no start heuristic is
 shared with the kernel); the oracle is re-synchronised to the GPU's state after every step, so each step is an independent sample.
 
-ONE stated tolerance (tests/helpers.py TOL_U = 5e-4) - asserted here, in tests/test_gpu_baseline_sizes.py and quoted by bench.py:
+ONE stated tolerance (tests/helpers.py TOL_U = 1e-6 since round 6 - both sides land their su solve on its vertex; rounds 3-5: 5e-4) - asserted
+here, in tests/test_gpu_baseline_sizes.py and quoted by bench.py:
     |u_gpu - u_oracle| <= TOL_U on the applied control in the solver's own coordinates, on every step whose ADMM iteration counts agree;
     zero failed su-solves; at most MAX_FLIPS_PER_1000 steps per 1000 on which the two sides stop one ADMM iteration apart (a residual
     within the solver tolerance of `iter_threshold`), each bounded by TOL_U_FLIP.
-The same difference expressed as body rates (soak_lib.body_rates) is printed, not asserted: for an omni robot it is |v| times the heading
-difference, i.e. LARGER than the raw one at cruise speed - the weakly determined coordinate is not a v ~ 0 artefact (helpers.py explains
-what it is: weakly active inequality rows).
+The same difference expressed as body rates (soak_lib.body_rates) is printed, not asserted.  What the long soaks of round 6 found beyond these seeds
+(tools/soak.py, 235 k steps): largest raw difference 3.3e-7 - and ONE step at 7.9e-5: the steering angle of an Ackermann robot at
+v = -0.004 m/s on a solve whose landings were all refused (the fallback is the interior point; the su-problem is nearly singular in that direction).
 """
 import os
 
