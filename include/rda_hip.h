@@ -157,7 +157,7 @@ typedef struct rda_opts {
                                 with the same factorisation and sweeps (two steps of the method of multipliers = the two passes of an iteration),
                                 verified on the true objective, rows moved in / out by their signs for at most 4 rounds; refused -> the iterate
                                 is restored and the iteration goes on to su_tol as without the switch.  The answer no longer depends on WHERE on
-                                the central path the iteration stopped (the reason for the stated tolerance of 5e-4: a row that is only just
+                                the central path the iteration stopped (the reason for the stated tolerance of rounds 3-5, 5e-4: a row that is only just
                                 active keeps the slack mu / lam*): kernel and cold oracle agree to 1e-9 with it (tests/test_gpu_land.py).
                                 Costs one factorisation + a verification pass per solve, saves the last interior-point iteration.  RDA_SU_LAND */
     double  su_land_tol[3];  /* [1e-3, 1e-4, 1e-5] first stop of the interior point when it is landed; a refused landing is tried once more at 1e-2 x

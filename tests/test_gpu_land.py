@@ -2,7 +2,7 @@
 
 The interior point stops ON the central path: a row that is only just active (multiplier lam* ~ 1e-7) keeps the slack mu / lam*, so two iterations that stop
 at different mu - the kernel's warm Riccati iteration and the oracle's cold dense one - hand back controls up to 1e-4 apart; that, not rounding, is why the
-stated tolerance of the default mode is TOL_U = 5e-4 (tests/helpers.py).  With the landing both sides run the interior point only until the active set
+stated tolerance of rounds 3-5 was TOL_U = 5e-4 (tests/helpers.py: TOL_U_IP today).  With the landing (the default since round 6) both sides run the interior point only until the active set
 can be read off and then compute the vertex itself (active rows as equalities, verified on the true objective), and the answer no longer depends on the
 path: TOL_U_LANDED below, five orders of magnitude tighter, on the su-problems themselves and on closed loops at the BASELINE sizes against the COLD oracle.
 """

@@ -112,7 +112,7 @@ def test_time_split_of_the_su_newton_system_changes_nothing_but_rounding(T, dyn,
     interior point in two halves on two waves, joined by a 5 x 5 interface system - the SAME linear system as one recursion over the
     horizon.  Two handles, su_split = 1 / 0, stepped from the same state (re-synchronised every step): same ADMM and interior-point
     iteration counts (+-1 per step where a stop test sits on its threshold), controls equal to the level at which two runs of the same
-    interior-point iteration with differently rounded Newton directions stop (1e-5; the stated tolerance of the parity tests is 5e-4)."""
+    interior-point iteration with differently rounded Newton directions stop (1e-5; the tolerance of the interior-point-only mode is TOL_U_IP = 5e-4)."""
     from rda_planner_amd.mpc import MPC
     from rda_planner_amd.rda_solver import hip_options
     car_t = sc.rectangle_robot(dynamics=dyn, wheelbase=3.0 if dyn == "acker" else 0)

@@ -252,7 +252,8 @@ def test_stop_tolerance_vs_weakly_active_rows(orc, name):
     the solution (multipliers ~1e-4), so the central-path point at complementarity mu lies ~mu / lam* from the solution and the answer
     moves with the STOP tolerance: against a solve at 1e-12 / 1e-12 / 1e-15 the default stop (1e-9 / 1e-10 / 1e-11) lands within 5e-5
     (this is what two different interior-point paths - kernel and oracle - can differ by per su-problem), while a solve at the ECOS-class
-    tolerances of the reference's solver (1e-8 throughout) lands 2e-4 ... 3e-3 away.  TOL_U = 5e-4 sits between the two."""
+    tolerances of the reference's solver (1e-8 throughout) lands 2e-4 ... 3e-3 away.  The TOL_U = 5e-4 of rounds 3-5 (TOL_U_IP today: the interior-point-only
+    mode) sits between the two; the landed solve of round 6 is checked against the same three problems below."""
     import os
     import ctypes as C
     orc.lib.orc_set_su_tol.argtypes = [C.c_double] * 3
