@@ -11,8 +11,8 @@ here, in tests/test_gpu_baseline_sizes.py and quoted by bench.py:
     zero failed su-solves; at most MAX_FLIPS_PER_1000 steps per 1000 on which the two sides stop one ADMM iteration apart (a residual
     within the solver tolerance of `iter_threshold`), each bounded by TOL_U_FLIP.
 The same difference expressed as body rates (soak_lib.body_rates) is printed, not asserted.  What the long soaks of round 6 found beyond these seeds
-(tools/soak.py, 235 k steps): largest raw difference 3.3e-7 - and ONE step at 7.9e-5: the steering angle of an Ackermann robot at
-v = -0.004 m/s on a solve whose landings were all refused (the fallback is the interior point; the su-problem is nearly singular in that direction).
+(tools/soak.py, 290 k steps): largest raw difference 3.3e-7 - and FOUR steps (of 64 k in the --exotic flavour) at 4.8e-6 .. 1.2e-4: the steering angle
+of an Ackermann robot at |v| <= 0.13 m/s on a solve whose landings were all refused (the fallback is the interior point; the su-problem is nearly singular in that direction).
 """
 import os
 
