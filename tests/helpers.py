@@ -14,7 +14,10 @@ from rda_planner_amd._capi import Cfg, dptr, iptr
 # on the interior-point path (cold / warm / easy / hard starts, speculative landings: tests/test_gpu_land.py 7e-15 .. 9e-11 per su-problem).
 # Largest value seen against the COLD oracle in 35 360 soak steps at the final kernels of round 6 (tools/soak.py --cold: default seeds 0 / 77, --large, --circles,
 # --exotic --robots, --tight, --lmz-central 1e-3; profiles/r06_soak_final_*.txt): 1.3e-8 (interior-point LamMuZ mode; default mode 6.8e-9); 100 k steps over the round's
-# builds: 3.1e-8; the fixed scenes of the BASELINE sizes <= 3e-11.  Asserted with a factor 30 of margin:
+# builds: 3.1e-8; the fixed scenes of the BASELINE sizes <= 3e-11.  Asserted with a factor 30 of margin on the seeds of the tests.
+# THE EXCEPTION (found by the long soaks of the round's last hours, 213 k more steps: DESIGN.md 2): a solve whose landings are ALL refused returns its fallback, the
+# interior point at su_tol - TOL_U_IP below is what holds for it.  Seen on 4 of 64 000 `--exotic` soak steps (0 of 230 000 others): 4.8e-6 .. 1.2e-4 in the steering angle
+# of an Ackermann robot at |v| <= 0.13 m/s, a direction the su-problem is nearly singular in; <= 3.9e-7 in what the robot does with the control (yaw rate).
 TOL_U = 1e-6
 # ... and the bound asserted on the FIXED scenes of tests/test_gpu_baseline_sizes.py (BASELINE sizes) and the reference's dynamic_obs scene
 TOL_U_FIXED = 1e-7
