@@ -897,6 +897,9 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
 #endif
         /* (second clause) past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
          * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
+#ifndef SU_LAND_FALLBACK
+#define SU_LAND_FALLBACK 1e-2
+#endif
 #define SU_CONV(tol) ((rdn <= (tol)[0] * sc && rpn <= (tol)[1] && mu <= (tol)[2] * sc) || (rdn <= 100 * (tol)[0] * sc && rpn <= (tol)[1] && mu <= 0.1 * (tol)[2] * sc))
         if (g_su_land && land_failed < 99) {
             /* Landing (round 6, see su_land): the interior point only has to get close enough for the active set to be read off - su_land_tol - and the
@@ -913,7 +916,13 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
                 su_eval(&S, x, s, grad, Hm);
             }
         }
-        if ((!g_su_land || land_failed >= 99) && SU_CONV(g_su_tol)) { status = 0; break; }
+        /* every landing refused: the fallback is the interior point itself, and it is run SU_LAND_FALLBACK x tighter than su_tol - where the su-problem is nearly
+         * singular (the steering of an Ackermann robot at v ~ 0) the point at su_tol is 1e-5 .. 1e-4 from the vertex, one or two iterations later 1e-7 .. 1e-8
+         * (mirrors csrc/su_device.h).  Not reached within the cap: the safety net below has the iterate that met su_tol. */
+        {
+            const double ft[3] = { SU_LAND_FALLBACK * g_su_tol[0], SU_LAND_FALLBACK * g_su_tol[1], SU_LAND_FALLBACK * g_su_tol[2] };
+            if ((!g_su_land && SU_CONV(g_su_tol)) || (g_su_land && land_failed >= 99 && SU_CONV(ft))) { status = 0; break; }
+        }
         if (g_su_accept && rpn <= g_su_tol[1] && rdn <= 10 * g_su_tol[0] * sc && mu <= 1e3 * g_su_tol[2] * sc) {
             const double merit = fmax(rdn / (g_su_tol[0] * sc), mu / (g_su_tol[2] * sc));
             if (!have_acc || merit < acc_merit) { memcpy(x_acc, x, sizeof(double) * n); memcpy(lm_acc, lm, sizeof(double) * mc); have_acc = 1; acc_merit = merit; }

@@ -398,6 +398,9 @@ template <int TT> __device__ __forceinline__ bool pair_map(const int T, const in
 // own prologue before the solve (control block, residual partials: rda_hip.hip su_body).  The caller issues prefetch() FIRST, next to its own loads, so that
 // all of them overlap into one trip; a caller that passes no Pre (the rda_su_solve hook) has the solve issue it at its entry.
 // the verdict of a solve once more, in registers of every thread (uniform): the launch's bookkeeping behind the solve then needs no trip to memory
+#ifndef SU_LAND_FALLBACK
+#define SU_LAND_FALLBACK 1e-2
+#endif
 struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; int land_rounds = 0; int rounds_all = 0; int blind = 0; double land_rho = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused; land_rounds: rounds of the non-speculative landings of the solve, rounds_all: of all of them; blind: a blind landing was 1 accepted, 2 refused; land_rho: penalty of the last landing)
 struct Pre {
     double vref = 0;
@@ -1394,8 +1397,12 @@ template <int TT, typename RefWait = NoRefWait> __device__ __forceinline__ bool 
         const bool landing = a.land != 0 && land_level < 99;       // (uniform) the interior point stops at 1e-2^level x land_tol and is landed
         double lsc = 1.0;
         for (int k = 0; k < land_level && k < 8; ++k) lsc *= 1e-2;
-        const double t_rd = landing ? fmax(lsc * a.land_tol[0], c.tol_rd) : c.tol_rd, t_rp = landing ? fmax(lsc * a.land_tol[1], c.tol_rp) : c.tol_rp,
-                     t_mu = landing ? fmax(lsc * a.land_tol[2], c.tol_mu) : c.tol_mu;
+        // every landing refused (level 99 with the switch on): the fallback is the interior point itself, run SU_LAND_FALLBACK x tighter than su_tol - in a direction the
+        // su-problem is nearly singular in, the point at su_tol is 1e-5 .. 1e-4 from the vertex (mirrors oracle/rda_oracle.c).  Not reached within the
+        // cap: the safety net (Args::accept) has the iterate that met su_tol.
+        const double fb = (a.land != 0 && !landing) ? SU_LAND_FALLBACK : 1.0;
+        const double t_rd = landing ? fmax(lsc * a.land_tol[0], c.tol_rd) : fb * c.tol_rd, t_rp = landing ? fmax(lsc * a.land_tol[1], c.tol_rp) : fb * c.tol_rp,
+                     t_mu = landing ? fmax(lsc * a.land_tol[2], c.tol_mu) : fb * c.tol_mu;
         const bool land_last = t_rd <= c.tol_rd && t_rp <= c.tol_rp && t_mu <= c.tol_mu;      // a landing refused at the tight tolerances is the last one
         // (rescue phase: the smoothed hinge is non-zero for EVERY term - the oracle sums them all, so does this pass; such iterations are rare)
         const bool screened_now = screened && !(heps > 0);
