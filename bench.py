@@ -361,7 +361,7 @@ def main():
                                                for k, v in replay_roofs.items()},
         "parity": {"stated_tolerance_applied_control": 1e-6, "asserted_on_the_baseline_sizes": 1e-7,
                    "where": "tests/helpers.py TOL_U / TOL_U_FIXED (round 6: the su solve is landed on its vertex on both sides; soaks against the cold oracle at the last "
-                            "commit: 213 k steps, largest difference 3.3e-7 - and FOUR steps (of 64 k in the exotic flavour; ONE, at 1.23e-6, with the tighter fallback stop of the last commit) at 4.8e-6 .. 1.2e-4 in the steering angle of an Ackermann robot "
+                            "commit: 213 k steps, largest difference 3.3e-7 - and FOUR steps (of 64 k in the exotic flavour; NONE - max 4.6e-7 - with the tighter fallback stop of the last commit) at 4.8e-6 .. 1.2e-4 in the steering angle of an Ackermann robot "
                             "at |v| <= 0.13 m/s, <= 3.9e-7 in its yaw rate: a refused landing, whose fallback is the interior point, in a nearly singular direction); asserted by tests/test_gpu_soak.py (random scenes) and "
                             "tests/test_gpu_baseline_sizes.py; DESIGN.md 2"},
     })

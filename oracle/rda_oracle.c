@@ -898,7 +898,7 @@ static int su_solve_impl(const orc_cfg *c, const double *nom_s, const double *no
         /* (second clause) past that complementarity the barrier weights lam/w (1e10 and more) put rounding noise into the dual residual: a
          * point that is primal feasible and complementary to 1e-12 is accepted with the residual the arithmetic can deliver */
 #ifndef SU_LAND_FALLBACK
-#define SU_LAND_FALLBACK 1e-2
+#define SU_LAND_FALLBACK 1e-3
 #endif
 #define SU_CONV(tol) ((rdn <= (tol)[0] * sc && rpn <= (tol)[1] && mu <= (tol)[2] * sc) || (rdn <= 100 * (tol)[0] * sc && rpn <= (tol)[1] && mu <= 0.1 * (tol)[2] * sc))
         if (g_su_land && land_failed < 99) {

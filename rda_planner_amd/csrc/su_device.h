@@ -399,7 +399,7 @@ template <int TT> __device__ __forceinline__ bool pair_map(const int T, const in
 // all of them overlap into one trip; a caller that passes no Pre (the rda_su_solve hook) has the solve issue it at its entry.
 // the verdict of a solve once more, in registers of every thread (uniform): the launch's bookkeeping behind the solve then needs no trip to memory
 #ifndef SU_LAND_FALLBACK
-#define SU_LAND_FALLBACK 1e-2
+#define SU_LAND_FALLBACK 1e-3
 #endif
 struct Result { int status = 1, iters = 0; double rd0 = 0; int spec = 0; int land_rounds = 0; int rounds_all = 0; int blind = 0; double land_rho = 0; };      // (rd0: Args::rd0; left alone by a solve that does not measure it.  spec: a speculative landing (Args::land_first = 2) was 1 accepted, 2 refused; land_rounds: rounds of the non-speculative landings of the solve, rounds_all: of all of them; blind: a blind landing was 1 accepted, 2 refused; land_rho: penalty of the last landing)
 struct Pre {

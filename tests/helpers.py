@@ -18,7 +18,7 @@ from rda_planner_amd._capi import Cfg, dptr, iptr
 # THE EXCEPTION (found by the long soaks of the round's last hours, 213 k more steps: DESIGN.md 2): a solve whose landings are ALL refused returns its fallback, the
 # interior point at su_tol - TOL_U_IP below is what holds for it.  Seen on 4 of 64 000 `--exotic` soak steps (0 of 230 000 others): 4.8e-6 .. 1.2e-4 in the steering angle
 # of an Ackermann robot at |v| <= 0.13 m/s, a direction the su-problem is nearly singular in; <= 3.9e-7 in what the robot does with the control (yaw rate).
-# Since the last commit of the round that fallback runs 1e-2 x tighter than su_tol (SU_LAND_FALLBACK, both sides): the same 64 000 steps again: ONE step at 1.23e-6, the rest <= 8.8e-7.
+# Since the last commit of the round that fallback runs 1e-3 x tighter than su_tol (SU_LAND_FALLBACK, both sides): the same 64 000 steps again: max 4.6e-7, no step outside TOL_U.
 TOL_U = 1e-6
 # ... and the bound asserted on the FIXED scenes of tests/test_gpu_baseline_sizes.py (BASELINE sizes) and the reference's dynamic_obs scene
 TOL_U_FIXED = 1e-7
