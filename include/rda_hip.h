@@ -156,7 +156,7 @@ typedef struct rda_opts {
                                 computed exactly: active rows as equalities, the others dropped, the equality-constrained quadratic model solved
                                 with the same factorisation and sweeps (two steps of the method of multipliers = the two passes of an iteration),
                                 verified on the true objective, rows moved in / out by their signs for at most 4 rounds; refused -> the iterate
-                                is restored and the iteration goes on to su_tol as without the switch.  The answer no longer depends on WHERE on
+                                is restored and the iteration goes on; once every landing of an attempt has been refused it stops at 1e-3 x su_tol (SU_LAND_FALLBACK).  The answer no longer depends on WHERE on
                                 the central path the iteration stopped (the reason for the stated tolerance of rounds 3-5, 5e-4: a row that is only just
                                 active keeps the slack mu / lam*): kernel and cold oracle agree to 1e-9 with it (tests/test_gpu_land.py).
                                 Costs one factorisation + a verification pass per solve, saves the last interior-point iteration.  RDA_SU_LAND */

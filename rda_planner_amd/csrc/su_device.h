@@ -145,7 +145,7 @@ struct Args {
     // dropped, the equality-constrained quadratic model at the iterate is solved with the SAME factorisation and sweeps (weights rho on the active rows, the
     // two passes of an iteration = two steps of the method of multipliers), the result is verified on the true objective (a light pass: stationarity with
     // the hinge terms re-evaluated, feasibility of the dropped rows, signs of the multipliers); rows move in / out by those signs and the round is repeated
-    // (at most 4); refused: the interior-point iterate is restored and the iteration goes on to tol_rd / tol_rp / tol_mu as without the switch.
+    // (at most 4); refused: the interior-point iterate is restored and the iteration goes on (all landings refused: to SU_LAND_FALLBACK x tol_rd / tol_rp / tol_mu).
     // Why: the interior point stops ON the central path, a row that is only just active keeps the slack mu / lam*, and two iterations that stop at different
     // mu differ by up to 1e-4 in the controls (TOL_U); the vertex does not depend on the path (tools/experiments/su_land_oracle.py: 1e-5 -> 1e-13).
     // Stops: the landing is first tried where the interior point reaches land_tol (1e-3 class: the active set is usually readable there - re-sorted north
